@@ -1,0 +1,279 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Golden-vector generator.
+
+Runs ONLY in the build container (it needs /root/reference).  It imports the
+real reference `src/model.py` on CPU -- with empty stand-ins for the
+non-arithmetic modules that are absent from this image (torchvision.models,
+scipy.misc, skimage, nibabel, h5py, nonechucks) -- calls
+its classes / methods in the order of `src/main_missing.py:175-284`, and
+writes small fixtures (inputs are re-generated from seeds, only outputs are
+stored) to tests/golden/.  No reference source text is written anywhere.
+
+    python oracle/gen_golden.py            # all fixtures (~1-2 min CPU)
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, 'tests', 'golden')
+REF_SRC = '/root/reference/src'
+
+
+def import_reference():
+    import scipy
+    sys.dont_write_bytecode = True
+
+    def stub(n, **a):
+        m = types.ModuleType(n); m.__dict__.update(a); sys.modules[n] = m; return m
+    tv = stub('torchvision'); tv.models = stub('torchvision.models')
+    scipy.misc = stub('scipy.misc')
+    sk = stub('skimage')
+    for s in ('io', 'transform', 'color', 'metrics'):
+        setattr(sk, s, stub('skimage.' + s))
+    sk.measure = stub('skimage.measure', compare_nrmse=None, compare_psnr=None, compare_ssim=None)
+    for n in ('nibabel', 'h5py', 'nonechucks'):
+        stub(n)
+    sys.path.insert(0, REF_SRC)
+    import model as ref     # noqa
+    return ref
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def seeded(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def pool8(x):
+    return F.avg_pool2d(x, 8).numpy()
+
+
+# ---------------------------------------------------------------- unit blocks
+def gen_units(ref):
+    out = {}
+    # --- CondConv2d, per-sample (non-uniform) types: 3 kernel geometries
+    for name, (ci, co, k, s, p, hw) in dict(
+            c3s1=(5, 6, 3, 1, 1, (9, 11)), c4s2=(7, 8, 4, 2, 1, (12, 10)),
+            c3s2=(4, 6, 3, 2, 1, (11, 13)), c1s1=(6, 3, 1, 1, 0, (7, 5))).items():
+        torch.manual_seed(100)
+        m = ref.CondConv2d(ci, co, k, s, padding=p)
+        with torch.no_grad():
+            m.bias.copy_(seeded((co,), 7, 0.1))
+        x = seeded((3, ci) + hw, 1).requires_grad_(True)
+        t = torch.tensor([[1.], [2.], [4.]])
+        y = m(x, t)
+        gy = seeded(tuple(y.shape), 2)
+        y.backward(gy)
+        out[f'cond_{name}_y'] = y.detach().numpy()
+        out[f'cond_{name}_dx'] = x.grad.numpy()
+        out[f'cond_{name}_dw'] = m.weight.grad.numpy()
+        out[f'cond_{name}_db'] = m.bias.grad.numpy()
+        out[f'cond_{name}_dfcw'] = m._routing_fn.fc.weight.grad.numpy()
+        out[f'cond_{name}_dfcb'] = m._routing_fn.fc.bias.grad.numpy()
+
+    # --- Conv_BN_Act_New (identity act quirk) and Act_Deconv_BN_Concat_New
+    torch.manual_seed(101)
+    m = quiet(ref.Conv_BN_Act_New, 6, 8, is_cond=True)
+    m.train()
+    x = seeded((3, 6, 12, 16), 3).requires_grad_(True)
+    t = 2 * torch.ones(3, 1)
+    y = m(x, t); y.backward(seeded(tuple(y.shape), 4))
+    out['cba_y'] = y.detach().numpy(); out['cba_dx'] = x.grad.numpy()
+    out['cba_dw'] = m.conv.weight.grad.numpy()
+    out['cba_dbn_w'] = m.bn.weight.grad.numpy(); out['cba_dbn_b'] = m.bn.bias.grad.numpy()
+    out['cba_run_mean'] = m.bn.running_mean.numpy().copy()
+    out['cba_run_var'] = m.bn.running_var.numpy().copy()
+
+    torch.manual_seed(102)
+    m = quiet(ref.Act_Deconv_BN_Concat_New, 6, 5, is_cond=True)
+    m.train()
+    xu = seeded((2, 6, 5, 6), 5).requires_grad_(True)
+    xd = seeded((2, 4, 10, 12), 6)
+    t = 3 * torch.ones(2, 1)
+    y = m(xd, xu, t); y.backward(seeded(tuple(y.shape), 7))
+    out['adb_y'] = y.detach().numpy(); out['adb_dx'] = xu.grad.numpy()
+    out['adb_dw'] = m.conv.weight.grad.numpy()
+
+    # --- SPADEBlockNew
+    torch.manual_seed(103)
+    m = quiet(ref.SPADEBlockNew, (10, 12), in_num_ch=8, out_num_ch=6, s_num_ch=4, is_cond=True)
+    s = torch.softmax(seeded((2, 4, 40, 48), 8), 1).requires_grad_(True)
+    z = seeded((2, 8, 10, 12), 9).requires_grad_(True)
+    t = 1 * torch.ones(2, 1)
+    y = m(s, z, t); y.backward(seeded(tuple(y.shape), 10))
+    out['spade_y'] = y.detach().numpy(); out['spade_ds'] = s.grad.numpy()
+    out['spade_dz'] = z.grad.numpy(); out['spade_dw_gamma'] = m.gamma.weight.grad.numpy()
+
+    # --- ModalityEncoderNew (fixed 160x192 by construction, model.py:2396)
+    torch.manual_seed(104)
+    m = quiet(ref.ModalityEncoderNew, img_num_ch=7, s_num_ch=0, first_num_ch=16, z_size=16, is_cond=True)
+    x = seeded((2, 7, 160, 192), 11)
+    mu, lv = m(x, None, 2 * torch.ones(2, 1))
+    (mu.sum() + 2 * lv.sum()).backward()
+    out['modenc_mu'] = mu.detach().numpy(); out['modenc_lv'] = lv.detach().numpy()
+    out['modenc_dw1'] = m.conv1.weight.grad.numpy()
+
+    # --- Discriminator (dense head and PatchGAN head)
+    for pg in (False, True):
+        torch.manual_seed(105)
+        m = ref.Discriminator(in_num_ch=4, inter_num_ch=16, is_patch_gan=pg)
+        m.train()
+        x = torch.softmax(seeded((2, 4, 160, 192), 12), 1)
+        y = m(x)
+        out[f'disc_{"patch" if pg else "dense"}_y'] = y.detach().numpy()
+
+    # --- bilinear flavours used on the path (model.py:2175, 2432, 2501)
+    x = seeded((2, 3, 5, 6), 13)
+    out['bil_ac_true_x2'] = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True).numpy()
+    out['bil_ac_false_x2'] = F.interpolate(x, scale_factor=(2, 2), mode='bilinear').numpy()
+    xs = seeded((2, 4, 32, 64), 14)
+    out['bil_down_to_5x6'] = F.interpolate(xs, size=(5, 6), mode='bilinear').numpy()
+    np.savez_compressed(os.path.join(OUT, 'units.npz'), **out)
+    print('units.npz', len(out), 'arrays')
+
+
+# ------------------------------------------------------------ full train step
+def make_inputs(B, M, H, W, seed, drop=False):
+    """Synthetic BraTS-shaped batch: N(0,1) inside a centred
+    ellipse, -10 outside; mask_img = (inputs[:,0]==0) as util.py builds it."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 7 * M, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    inside = (((yy - H / 2 + 0.5) / (0.40 * H)) ** 2 + ((xx - W / 2 + 0.5) / (0.42 * W)) ** 2) <= 1
+    x = torch.where(inside[None, None], x, torch.full_like(x, -10.0))
+    mask = torch.ones(B, M)
+    if drop:
+        for b in range(B):
+            d = int(torch.randint(0, M, (1,), generator=g))
+            mask[b, d] = 0
+            x[b, 7 * d:7 * (d + 1)] = 0
+    mask_img = (x[:, 0] == 0).float()
+    return x, mask, mask_img
+
+
+def build_ref_model(ref, M, adv=False):
+    return quiet(
+        ref.MultimodalModel, input_size=(160, 192), modality_num=M, in_num_ch=7, out_num_ch=1,
+        s_num_ch=4, z_size=16, is_cond=True, is_discrim_s=adv, is_distri_z=False,
+        s_compact_method='max', s_sim_method='cosine', z_sim_method='cosine', shared_ana_enc=True,
+        shared_mod_enc=True, shared_inp_dec=False, device=torch.device('cpu'),
+        input_output_act='no', target_output_act='no', target_model_name='U+SA', fuse_method='mean',
+        others={'mod_enc_s': False, 'ana_dec_act': 'softmax', 'old': False, 'softmax_remove_mask': True})
+
+
+HOT_PREFIXES = ('anatomy_encoder_enc_list.', 'anatomy_encoder_dec.', 'modality_encoder_list.',
+                'input_decoder_list.', 'discrim_s.')
+
+
+def reinit_discriminator(module, seed=777):
+    """Seed-independent deterministic weights for discrim_s so that reference
+    and restatement agree without shipping a weight fixture."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in sorted(module.named_parameters()):
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif n.endswith('bias'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.01)
+
+
+def gen_step(ref, tag, B, M, drop=False, adv=False):
+    lam = dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, sim_z=2.0,
+               adv_s=(1.0 if adv else 0.0))
+    torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21
+    model = build_ref_model(ref, M, adv)
+    if adv:
+        reinit_discriminator(model.discrim_s)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    opt_d = torch.optim.Adam(model.parameters(), lr=2e-4, amsgrad=True) if adv else None
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10, drop=drop)
+    # the reference's output_decoder / discriminator constructors consumed global RNG draws the
+    # restatement does not replay; re-seed so the eps draws of `sample` (model.py:3160) and the
+    # sim_s pair choice (model.py:3485) are reproducible on both sides.
+    torch.manual_seed(11); np.random.seed(11)
+    w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items()
+          if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point}
+
+    x_list = [inputs[:, i * 7:(i + 1) * 7] for i in range(M)]
+    # ---- main_missing.py:175-251 call order
+    s_list = model.compute_anatomy_encoding(x_list, mask_img)
+    z_list, mu_list, lv_list = model.compute_modality_encoding(x_list, s_list, phase='train')
+    xf = model.reconstruct_input_si_zi(s_list, z_list)
+    xmix = model.reconstruct_input_si_zj(s_list, z_list)
+    parts = {}
+    parts['recon_x'] = model.compute_recon_loss_x_list(x_list, xf, mask, p=1)
+    parts['recon_x_mix'] = model.compute_recon_loss_x_mix_list(x_list, xmix, mask, p=1)
+    loss = lam['recon_x'] * parts['recon_x'] + lam['recon_x_mix'] * parts['recon_x_mix']
+    s_new = model.compute_anatomy_encoding(xf, mask_img)
+    _, mu_new, _ = model.compute_modality_encoding(xf, s_new, phase='train')
+    parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask)
+    loss = loss + lam['latent_z'] * parts['latent_z']
+    parts['sim_s'] = model.compute_similarity_s_loss(s_list, mask)
+    loss = loss + lam['sim_s'] * parts['sim_s']
+    parts['sim_z'] = model.compute_similarity_z_loss(z_list, mask)
+    loss = loss + lam['sim_z'] * parts['sim_z']
+    if adv:
+        parts['adv_s_d'], parts['adv_s'] = model.compute_adversarial_loss(s_list, mask)
+        loss = loss + lam['adv_s'] * parts['adv_s']
+    loss.backward(retain_graph=adv)
+    grad_norms = {n: float(p.grad.double().norm()) for n, p in model.named_parameters()
+                  if p.grad is not None}
+    gnorm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
+    opt.step(); opt.zero_grad()
+    w1 = {k: float(v.double().sum()) for k, v in model.state_dict().items()
+          if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point}
+    d_step_error = None
+    if adv:
+        # main_missing.py:286-289 as written.  Under torch >= 1.5 the in-place
+        # optimizer.step() above invalidates the retained graph and this raises;
+        # the fixture records that fact (DESIGN.md "adversarial d-step").
+        try:
+            opt_d.zero_grad(); parts['adv_s_d'].backward(); opt_d.step()
+        except RuntimeError as e:
+            d_step_error = str(e).split('\n')[0][:160]
+
+    meta = dict(B=B, M=M, H=160, W=192, drop=drop, adv=adv, lambdas=lam,
+                loss=float(loss), parts={k: float(v) for k, v in parts.items()},
+                grad_norm=gnorm, grad_norms=grad_norms, wsum_before=w0, wsum_after=w1,
+                n_params_with_grad=len(grad_norms), torch=torch.__version__,
+                d_step_reference_error=d_step_error)
+    with open(os.path.join(OUT, f'step_{tag}.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    arrs = dict(mu=torch.stack(mu_list).detach().numpy(), z=torch.stack(z_list).detach().numpy(),
+                lv=torch.stack(lv_list).detach().numpy(),
+                s0_pool8=pool8(s_list[0].detach()), xf0_pool8=pool8(xf[0].detach()),
+                xmix0_pool8=pool8(xmix[0].detach()), mask=mask.numpy())
+    np.savez_compressed(os.path.join(OUT, f'step_{tag}.npz'), **arrs)
+    print(f'step_{tag}: loss={float(loss):.7f} gnorm={gnorm:.4f}',
+          {k: round(float(v), 7) for k, v in parts.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    only = sys.argv[1:]
+    if not only or 'units' in only:
+        gen_units(ref)
+    if not only or 'steps' in only:
+        gen_step(ref, 'b2m4', 2, 4)
+        gen_step(ref, 'b4m2', 4, 2)
+        gen_step(ref, 'b2m4_drop', 2, 4, drop=True)
+    if not only or 'adv' in only:
+        gen_step(ref, 'b2m2_adv', 2, 2, adv=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,142 @@
+"""Pins the oracle (oracle/ref_model.py) against vectors produced by the real
+reference (oracle/gen_golden.py, run in the build container)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_model as R
+from oracle.gen_golden import make_inputs, reinit_discriminator, seeded
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+@pytest.fixture(scope='module')
+def units(golden_dir):
+    return np.load(os.path.join(golden_dir, 'units.npz'))
+
+
+@pytest.mark.parametrize('name,ci,co,k,s,p,hw', [
+    ('c3s1', 5, 6, 3, 1, 1, (9, 11)), ('c4s2', 7, 8, 4, 2, 1, (12, 10)),
+    ('c3s2', 4, 6, 3, 2, 1, (11, 13)), ('c1s1', 6, 3, 1, 1, 0, (7, 5))])
+def test_condconv_per_sample(units, name, ci, co, k, s, p, hw):
+    torch.manual_seed(100)
+    m = R.RefCondConv2d(ci, co, k, s, p)
+    with torch.no_grad():
+        m.bias.copy_(seeded((co,), 7, 0.1))
+    x = seeded((3, ci) + hw, 1).requires_grad_(True)
+    t = torch.tensor([[1.], [2.], [4.]])
+    y = m(x, t)
+    y.backward(seeded(tuple(y.shape), 2))
+    np.testing.assert_allclose(y.detach().numpy(), units[f'cond_{name}_y'], **TOL)
+    np.testing.assert_allclose(x.grad.numpy(), units[f'cond_{name}_dx'], **TOL)
+    np.testing.assert_allclose(m.weight.grad.numpy(), units[f'cond_{name}_dw'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(m.bias.grad.numpy(), units[f'cond_{name}_db'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(m._routing_fn.fc.weight.grad.numpy(), units[f'cond_{name}_dfcw'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m._routing_fn.fc.bias.grad.numpy(), units[f'cond_{name}_dfcb'], rtol=1e-4, atol=1e-5)
+
+
+def test_conv_bn_act(units):
+    torch.manual_seed(101)
+    m = R.RefConvBNAct(6, 8).train()
+    x = seeded((3, 6, 12, 16), 3).requires_grad_(True)
+    y = m(x, 2 * torch.ones(3, 1)); y.backward(seeded(tuple(y.shape), 4))
+    np.testing.assert_allclose(y.detach().numpy(), units['cba_y'], **TOL)
+    np.testing.assert_allclose(x.grad.numpy(), units['cba_dx'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.conv.weight.grad.numpy(), units['cba_dw'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.bn.weight.grad.numpy(), units['cba_dbn_w'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.bn.running_mean.numpy(), units['cba_run_mean'], **TOL)
+    np.testing.assert_allclose(m.bn.running_var.numpy(), units['cba_run_var'], **TOL)
+
+
+def test_up_conv_bn_cat(units):
+    torch.manual_seed(102)
+    m = R.RefUpConvBNCat(6, 5).train()
+    xu = seeded((2, 6, 5, 6), 5).requires_grad_(True)
+    xd = seeded((2, 4, 10, 12), 6)
+    y = m(xd, xu, 3 * torch.ones(2, 1)); y.backward(seeded(tuple(y.shape), 7))
+    np.testing.assert_allclose(y.detach().numpy(), units['adb_y'], **TOL)
+    np.testing.assert_allclose(xu.grad.numpy(), units['adb_dx'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.conv.weight.grad.numpy(), units['adb_dw'], rtol=1e-4, atol=1e-5)
+
+
+def test_spade_block(units):
+    torch.manual_seed(103)
+    m = R.RefSPADEBlock((10, 12), 8, 6, 4)
+    s = torch.softmax(seeded((2, 4, 40, 48), 8), 1).requires_grad_(True)
+    z = seeded((2, 8, 10, 12), 9).requires_grad_(True)
+    y = m(s, z, torch.ones(2, 1)); y.backward(seeded(tuple(y.shape), 10))
+    np.testing.assert_allclose(y.detach().numpy(), units['spade_y'], **TOL)
+    np.testing.assert_allclose(s.grad.numpy(), units['spade_ds'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(z.grad.numpy(), units['spade_dz'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(m.gamma.weight.grad.numpy(), units['spade_dw_gamma'], rtol=1e-4, atol=1e-5)
+
+
+def test_modality_encoder(units):
+    torch.manual_seed(104)
+    m = R.RefModalityEnc(7, 16, 16, 30)
+    x = seeded((2, 7, 160, 192), 11)
+    mu, lv = m(x, 2 * torch.ones(2, 1))
+    (mu.sum() + 2 * lv.sum()).backward()
+    np.testing.assert_allclose(mu.detach().numpy(), units['modenc_mu'], **TOL)
+    np.testing.assert_allclose(lv.detach().numpy(), units['modenc_lv'], **TOL)
+    np.testing.assert_allclose(m.conv1.weight.grad.numpy(), units['modenc_dw1'], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('pg', [False, True])
+def test_discriminator(units, pg):
+    torch.manual_seed(105)
+    m = R.RefDiscriminator(4, 16, (160, 192), pg).train()
+    x = torch.softmax(seeded((2, 4, 160, 192), 12), 1)
+    np.testing.assert_allclose(m(x).detach().numpy(), units[f'disc_{"patch" if pg else "dense"}_y'], **TOL)
+
+
+def _run_step(golden_dir, tag):
+    meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
+    arrs = np.load(os.path.join(golden_dir, f'step_{tag}.npz'))
+    B, M, adv = meta['B'], meta['M'], meta['adv']
+    torch.manual_seed(10); np.random.seed(10)
+    model = R.RefMultimodalModel((160, 192), M, is_discrim_s=adv).train()
+    if adv:
+        reinit_discriminator(model.discrim_s)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10, drop=meta['drop'])
+    torch.manual_seed(11); np.random.seed(11)
+    w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    for k, v in meta['wsum_before'].items():       # identical init under the seed
+        assert abs(w0[k] - v) <= 1e-9 * max(1, abs(v)), k
+    loss, parts, aux = R.ref_forward_losses(model, inputs, mask, mask_img, meta['lambdas'])
+    loss.backward(retain_graph=adv)
+    gn = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None}
+    gnorm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
+    opt.step()
+    return meta, arrs, model, loss, parts, aux, gn, gnorm
+
+
+@pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
+def test_full_step(golden_dir, tag):
+    meta, arrs, model, loss, parts, aux, gn, gnorm = _run_step(golden_dir, tag)
+    assert abs(float(loss) - meta['loss']) <= 2e-5 * abs(meta['loss'])
+    for k, v in meta['parts'].items():
+        assert abs(float(parts[k]) - v) <= 2e-5 * abs(v) + 1e-7, k
+    np.testing.assert_allclose(torch.stack(aux['mu_list']).detach().numpy(), arrs['mu'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(torch.stack(aux['z_list']).detach().numpy(), arrs['z'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(F.avg_pool2d(aux['s_list'][0].detach(), 8).numpy(), arrs['s0_pool8'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(F.avg_pool2d(aux['xf'][0].detach(), 8).numpy(), arrs['xf0_pool8'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(F.avg_pool2d(aux['xmix'][0].detach(), 8).numpy(), arrs['xmix0_pool8'], rtol=1e-4, atol=1e-5)
+    assert abs(gnorm - meta['grad_norm']) <= 1e-3 * meta['grad_norm']
+    # same set of parameters receives a gradient, same per-tensor norms
+    hot = {k: v for k, v in meta['grad_norms'].items() if not k.startswith('output_decoder')}
+    assert set(hot) == set(gn)
+    for k, v in hot.items():
+        assert abs(gn[k] - v) <= 2e-3 * v + 1e-6 * meta['grad_norm'], (k, gn[k], v)
+    w1 = {k: float(v.double().sum()) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    for k, v in meta['wsum_after'].items():
+        # conv biases that feed a BatchNorm / InstanceNorm have an analytically zero gradient:
+        # what arrives is rounding noise, whose sign Adam's first step turns into +-lr.
+        if meta['grad_norms'].get(k, 1.0) < 1e-5 * meta['grad_norm']:
+            continue
+        assert abs(w1[k] - v) <= 5e-5 * max(1.0, abs(v)), (k, w1[k], v)
