@@ -1,0 +1,170 @@
+/* mrdis.h -- C ABI of libmrdis_hip.so: the MI355X (gfx950) hot path of the
+ * multi-modal MR representation-disentanglement training step.
+ *
+ * The reference (ouyangjiahong/representation-disentanglement) is pure
+ * Python/PyTorch and has no FFI; its operator seam is the class factory
+ * `Conv2d(is_cond)` / `CondConv2d.forward` (src/model.py:2075-2120) and the
+ * ATen ops its blocks dispatch.  Each entry point below
+ * names the reference call site it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; nothing is
+ *    allocated or freed inside the library, nothing synchronises the host.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it.
+ *  - activations are NHWC fp32 "views": element (n,h,w,c) of a tensor lives at
+ *    p[((n*H + h)*W + w)*ld + c]; `ld` (>= C, in floats) lets a view address a
+ *    channel slice of a wider buffer (concat elision).
+ *  - return value: 0 = ok, negative = MRDIS_E* (see mrdis_strerror).  No
+ *    entry point throws or aborts.
+ *  - thread-safety: re-entrant for distinct streams / distinct buffers.
+ */
+#ifndef MRDIS_H
+#define MRDIS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRDIS_OK            0
+#define MRDIS_EINVAL       -1   /* bad shape / argument                       */
+#define MRDIS_EUNSUPPORTED -2   /* geometry outside what the kernels cover    */
+#define MRDIS_EWORKSPACE   -3   /* workspace too small                        */
+#define MRDIS_ELAUNCH      -4   /* hipLaunch reported an error                */
+#define MRDIS_EALIGN       -5   /* pointer / ld alignment requirement broken  */
+
+#define MRDIS_MAX_TAPS 16
+
+/* epilogue flags of mrdis_conv2d_fwd */
+#define MRDIS_EPI_NONE   0
+#define MRDIS_EPI_LRELU  1      /* y = leaky_relu(conv + bias, 0.2): model.py:2227, 2375-2394, 2774 */
+
+const char* mrdis_strerror(int code);
+int mrdis_version(void);
+
+/* ---- expert mixing: model.py:2111-2113 --------------------------------------
+ * W   : (E, Co, Ci, kh, kw) checkpoint layout (OIHW with leading expert dim)
+ * r   : (E) routing weights sigmoid(fc(type)) -- one row; the reference's
+ *       inputs_type is constant over the batch at every call site
+ *       (model.py:3138, 3169, 3190, 3211), so one mixed kernel serves a call.
+ * w_tck : out, [T][Ci][Co]   (T = kh*kw)  forward / wgrad layout
+ * w_tkc : out, [T][Co][Ci]                data-gradient layout
+ * E = 1 with r = {1} turns a plain nn.Conv2d weight into the two layouts.    */
+int mrdis_mix_experts_fwd(const float* W, const float* r, float* w_tck, float* w_tkc,
+                          int E, int Co, int Ci, int T, void* stream);
+
+/* backward of the above.  dw_tck: [T][Ci][Co] gradient of the mixed kernel.
+ * dW (E,Co,Ci,T) = r[e] * dWm ;  dr[e] += <dWm, W[e]>  (two-level ordered
+ * reduction through `workspace`, bit-reproducible; caller zeroes dr).        */
+size_t mrdis_mix_experts_bwd_workspace(int E, int Co, int Ci, int T);
+int mrdis_mix_experts_bwd(const float* dw_tck, const float* W, const float* r,
+                          float* dW, float* dr, void* workspace, size_t workspace_bytes,
+                          int E, int Co, int Ci, int T, void* stream);
+
+/* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and
+ * nn.Conv2d of the discriminator model.py:2773-2789 ---------------------------
+ * x : NHWC view (N,H,W,Ci) ld=ldx ; y : NHWC view (N,Ho,Wo,Co) ld=ldy
+ * w_tck from mrdis_mix_experts_fwd ; bias (Co) or NULL.
+ * kernel (kh,kw) in {1x1,3x3,4x4}; stride in {1,2}; zero padding `pad`.      */
+int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
+                     float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                     int kh, int kw, int stride, int pad, int epilogue, void* stream);
+
+/* data gradient (autograd convolution_backward, input part).
+ * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
+int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc,
+                          float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+                          int kh, int kw, int stride, int pad, void* stream);
+
+/* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
+ * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.
+ * dw_tck: [T][Ci][Co] ; dbias (Co) or NULL.                                   */
+size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
+                                         int kh, int kw, int stride, int pad);
+int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
+                            float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                            int N, int H, int W, int Ci, int Co,
+                            int kh, int kw, int stride, int pad, void* stream);
+
+/* ---- LeakyReLU backward (model.py:2227/2240, 2375-2394): dx = dy * (y>0 ? 1 : slope),
+ * y being the activation OUTPUT (sign-preserving for slope > 0).              */
+int mrdis_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
+                    long long P, int C, float slope, void* stream);
+
+/* ---- BatchNorm2d, training mode: model.py:2132/2151, 2179/2191, 2776-2785 --
+ * x view (P = N*H*W rows, C) ; writes y view, save_mean/save_rstd (C) and
+ * updates running_mean/var (momentum 0.1, unbiased var) when non-NULL.
+ * workspace: mrdis_norm_workspace(1, P, C) bytes.                             */
+size_t mrdis_norm_workspace(int groups, long long P, int C);
+int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var,
+                       float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                       long long P, int C, float eps, float momentum, void* stream);
+int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                       const float* save_mean, const float* save_rstd, float* dx, int lddx,
+                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       long long P, int C, void* stream);
+
+/* ---- InstanceNorm2d(affine=False) fused with the SPADE modulation:
+ * model.py:2431/2440 + 2446:  out = IN(z) * (1 + gamma) + beta ---------------
+ * z, gamma, beta, out : (N, HW, C) views ; save_mean/save_rstd : (N*C).       */
+int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* gamma, int ldg,
+                             const float* beta, int ldb, float* out, int ldo,
+                             float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                             int N, long long HW, int C, float eps, void* stream);
+size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C);
+int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float* z, int ldz,
+                             const float* gamma, int ldg, const float* save_mean, const float* save_rstd,
+                             float* dz, int lddz, float* dgamma, int lddg, float* dbeta, int lddb,
+                             void* workspace, size_t workspace_bytes,
+                             int N, long long HW, int C, void* stream);
+
+/* ---- bilinear resize: nn.Upsample at model.py:2175 (align_corners=True),
+ * 2432 / 2501-2509 (align_corners=False, arbitrary output size) --------------*/
+int mrdis_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi,
+                       int Ho, int Wo, int C, int align_corners, void* stream);
+int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
+                       int Ho, int Wo, int C, int align_corners, void* stream);
+
+/* ---- softmax over [100*mask_img, s] with channel 0 dropped: model.py:3150-3153
+ * s view (P, C) ; mask_img (P) ; out view (P, C).                             */
+int mrdis_softmax_mask_drop_fwd(const float* s, int lds, const float* mask_img, float* out, int ldo,
+                                long long P, int C, float mask_scale, void* stream);
+int mrdis_softmax_mask_drop_bwd(const float* dout, int lddo, const float* out, int ldo,
+                                float* ds, int ldds, long long P, int C, void* stream);
+
+/* ---- per-sample mean |gt - x| (p=1) or (gt-x)^2 (p=2) over (C,H,W):
+ * model.py:3260-3266.  out (N).  bwd: dx = w[n] * d|.|/dx / (C*HW).           */
+size_t mrdis_recon_err_workspace(int N, long long HW, int C);
+int mrdis_recon_err_fwd(const float* gt, int ldgt, const float* x, int ldx, float* out,
+                        void* workspace, size_t workspace_bytes,
+                        int N, long long HW, int C, int p, void* stream);
+int mrdis_recon_err_bwd(const float* gt, int ldgt, const float* x, int ldx, const float* w,
+                        float* dx, int lddx, int N, long long HW, int C, int p, void* stream);
+
+/* ---- max_pool2d(kernel k x k, stride k): model.py:3448-3451 ---------------- */
+int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* argmax, int N, int H, int W, int C,
+                      int k, void* stream);
+int mrdis_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int lddx, int N, int H, int W,
+                      int C, int k, void* stream);
+
+/* ---- optimizer side: main_missing.py:272-278 (clip + finite check) and :118/:283
+ * (Adam, amsgrad, L2 weight decay) over one flat fp32 parameter arena --------
+ * sumsq_finite: out[0] += sum(g^2), out[1] += count(non-finite)  (zero `out` first). */
+size_t mrdis_sumsq_workspace(void);
+int mrdis_sumsq_finite(const float* g, long long n, float* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* One fused step.  clip_coef_src points at the device scalar pair written by
+ * mrdis_sumsq_finite: coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); the step is
+ * skipped on device when the non-finite count is > 0.  step_count: 1-based.   */
+int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
+                            long long n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int step_count, const float* norm_finite,
+                            float max_norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRDIS_H */

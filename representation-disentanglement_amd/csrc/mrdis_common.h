@@ -1,0 +1,35 @@
+// Shared helpers for libmrdis_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mrdis.h"
+
+#define MRDIS_CHECK_LAUNCH()                                     \
+    do {                                                         \
+        hipError_t e_ = hipGetLastError();                       \
+        if (e_ != hipSuccess) return MRDIS_ELAUNCH;              \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int mrdis_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD, so
+// give each XCD a contiguous run of logical tile ids -> neighbouring tiles hit the same L2.
+__device__ __forceinline__ int mrdis_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float mrdis_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double mrdis_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

@@ -1,0 +1,788 @@
+// mrdis_conv.hip -- NHWC im2col-free direct convolution for gfx950 (MI355X), fp32.
+//
+// One "tap-table" formulation covers everything the path needs
+// (reference: F.conv2d at src/model.py:2104 and its autograd backward):
+//
+//   out[n, a*os+oh0, b*os+ow0, co] = bias[co] +
+//        sum_t sum_ci in[n, a*is + dh[t], b*is + dw[t], ci] * w[widx[t]][ci][co]
+//
+//   forward conv          : is = stride, os = 1, dh = r - pad
+//   data gradient, s = 1  : is = 1, os = 1, dh = pad - r, w = [T][Co][Ci]
+//   data gradient, s = 2  : four output-parity classes, os = 2, oh0 = parity,
+//                           each class keeps only the taps that hit it
+//
+// Kernel shape: a workgroup (256 threads = 4 waves) owns BM = 128 output
+// positions (NB images x TH x TW) x BN output channels.  Per KC-channel chunk
+// it stages the halo'd input tile ONCE in LDS ([pixel][KC+1], odd stride ->
+// conflict-free ds_read_b32 for the MFMA A operand) together with the
+// [tap][KC][BN] filter slab, then runs every tap out of LDS:
+// v_mfma_f32_32x32x2_f32, A = 32 positions x 2 channels, B = 2 channels x 32
+// couts, exact-fp32 accumulate (a k-ordered fmaf chain, so results match an
+// fp32 reference to rounding).  blockIdx is remapped so that the tiles an XCD
+// works on are contiguous (shared halos / filter slabs hit that XCD's L2).
+//
+// The weight gradient uses the transposed product: M = (tap, ci) flattened
+// into 32-row sub-tiles, N = 32 couts, K = output positions, split over
+// workgroups and waves; partial 32x32 slabs are written once and summed in a
+// fixed order by a second kernel (bit-reproducible, no float atomics).
+#include "mrdis_common.h"
+
+#define TC_BM 128
+#define TC_TAB_INTS 320   // tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad
+
+struct TapConvParams {
+    const float* in; const float* w; const float* bias; float* out;
+    int N, Hin, Win, Cin, ldin;
+    int Hout, Wout, Cout, ldout;
+    int A, B, os, oh0, ow0, is;
+    int ntaps;
+    int dh[MRDIS_MAX_TAPS], dw[MRDIS_MAX_TAPS], widx[MRDIS_MAX_TAPS];
+    int dh_min, dw_min;
+    int NB, TH, TW, TinH, TinW;
+    int tilesA, tilesB, tilesN, coTiles;
+    int epilogue;
+    int vec_in, vec_w;
+};
+
+template <int KC, int BN>
+__global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
+    constexpr int S = KC + 1;
+    constexpr int WAVES_N = (BN == 32) ? 1 : 2;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int MSUB = (TC_BM / 32) / WAVES_M;
+    constexpr int NSUB = (BN / 32) / WAVES_N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tab_in = reinterpret_cast<int*>(smem);
+    int* tab_out = tab_in + 128;
+    int* tap_xoff = tab_in + 256;
+    int* tap_widx = tab_in + 272;
+    float* ws = smem + TC_TAB_INTS;
+    float* xs = ws + p.ntaps * KC * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    int bid = mrdis_xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = bid % p.coTiles;
+    int tile = bid / p.coTiles;
+    const int tb = tile % p.tilesB; tile /= p.tilesB;
+    const int ta = tile % p.tilesA;
+    const int tn = tile / p.tilesA;
+    const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB, co0 = cot * BN;
+
+    if (tid < 128) {
+        const int m = tid, npos = p.NB * p.TH * p.TW;
+        int tin = 0, tout = -1;
+        if (m < npos) {
+            const int nb = m / (p.TH * p.TW);
+            const int rem = m - nb * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S;
+            const int n = n0 + nb, a = a0 + ty, b = b0 + tx;
+            if (n < p.N && a < p.A && b < p.B)
+                tout = (n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0;
+        }
+        tab_in[m] = tin;
+        tab_out[m] = tout;
+    } else if (tid < 128 + MRDIS_MAX_TAPS) {
+        const int t = tid - 128;
+        if (t < p.ntaps) {
+            tap_xoff[t] = ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * S;
+            tap_widx[t] = p.widx[t];
+        }
+    }
+    __syncthreads();
+
+    int abase[MSUB];
+#pragma unroll
+    for (int i = 0; i < MSUB; ++i) abase[i] = tab_in[(wave_m * MSUB + i) * 32 + (lane & 31)] + (lane >> 5);
+    const int bbase = (lane >> 5) * BN + wave_n * NSUB * 32 + (lane & 31);
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tinHW = p.TinH * p.TinW;
+    const int npix_in = p.NB * tinHW;
+    const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        if (c0) __syncthreads();
+        // ---- stage the halo'd input tile: xs[pixel][KC+1]
+        if (p.vec_in) {
+            constexpr int Q = KC / 4;
+            for (int idx = tid; idx < npix_in * Q; idx += 256) {
+                const int pi = idx / Q, q = idx - pi * Q;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Cin)
+                    v = *reinterpret_cast<const float4*>(p.in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c);
+                float* d = xs + pi * S + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < npix_in * KC; idx += 256) {
+                const int pi = idx / KC, k = idx - pi * KC;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c0 + k;
+                float v = 0.f;
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Cin)
+                    v = p.in[((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c];
+                xs[pi * S + k] = v;
+            }
+        }
+        // ---- stage the filter slab: ws[tap][KC][BN]
+        if (p.vec_w) {
+            constexpr int Q = BN / 4;
+            const int total = p.ntaps * KC * Q;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int row = idx / Q, q = idx - row * Q;
+                const int t = row / KC, k = row - t * KC;
+                const int c = c0 + k, co = co0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < p.Cin && co < p.Cout)
+                    v = *reinterpret_cast<const float4*>(p.w + ((long long)tap_widx[t] * p.Cin + c) * p.Cout + co);
+                *reinterpret_cast<float4*>(ws + row * BN + 4 * q) = v;
+            }
+        } else {
+            const int total = p.ntaps * KC * BN;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int row = idx / BN, j = idx - row * BN;
+                const int t = row / KC, k = row - t * KC;
+                const int c = c0 + k, co = co0 + j;
+                float v = 0.f;
+                if (c < p.Cin && co < p.Cout) v = p.w[((long long)tap_widx[t] * p.Cin + c) * p.Cout + co];
+                ws[idx] = v;
+            }
+        }
+        __syncthreads();
+        // ---- every tap out of LDS
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = tap_xoff[t];
+            const float* wt = ws + t * (KC * BN) + bbase;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                float av[MSUB], bv[NSUB];
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i) av[i] = xs[abase[i] + toff + 2 * kk];
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) bv[j] = wt[2 * kk * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NSUB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (position)
+    const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        const int co = co0 + (wave_n * NSUB + j) * 32 + (lane & 31);
+        const bool cok = co < p.Cout;
+        const float bvv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MSUB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int po = tab_out[(wave_m * MSUB + i) * 32 + row];
+                if (po >= 0 && cok) {
+                    float v = acc[i][j][r] + bvv;
+                    if (lrelu) v = v > 0.f ? v : 0.2f * v;
+                    p.out[(long long)po * p.ldout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct TileChoice { int NB, TH, TW; };
+
+static TileChoice choose_tile(int N, int A, int B) {
+    TileChoice best{1, 1, 1};
+    double best_u = -1.0;
+    for (int tw = 1; tw <= 32 && tw <= B; ++tw) {
+        int th = TC_BM / tw; if (th > A) th = A;
+        int nb = TC_BM / (tw * th); if (nb > N) nb = N; if (nb < 1) nb = 1;
+        const double u = ((double)B / ((double)mrdis_cdiv(B, tw) * tw)) * ((double)A / ((double)mrdis_cdiv(A, th) * th)) *
+                         ((double)N / ((double)mrdis_cdiv(N, nb) * nb)) * ((double)(tw * th * nb) / TC_BM);
+        // prefer wide rows (coalesced staging, conflict-free LDS reads) on ties
+        if (u > best_u + 1e-9 || (u > best_u - 1e-9 && tw > best.TW)) { best_u = u; best = {nb, th, tw}; }
+    }
+    return best;
+}
+
+template <int KC, int BN>
+static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, hipStream_t s) {
+    hipLaunchKernelGGL((tapconv_kernel<KC, BN>), dim3(nblk), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+static size_t tapconv_lds(const TapConvParams& p, int KC, int BN) {
+    return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * KC * BN + (size_t)p.NB * p.TinH * p.TinW * (KC + 1));
+}
+
+// fills tiling fields and launches.  `p` must have geometry + taps set.
+static int run_tapconv(TapConvParams p, hipStream_t s) {
+    if (p.ntaps < 1 || p.ntaps > MRDIS_MAX_TAPS) return MRDIS_EUNSUPPORTED;
+    if (p.A <= 0 || p.B <= 0 || p.N <= 0) return MRDIS_OK;   // empty launch
+    int dh_max = p.dh[0], dw_max = p.dw[0];
+    p.dh_min = p.dh[0]; p.dw_min = p.dw[0];
+    for (int t = 1; t < p.ntaps; ++t) {
+        if (p.dh[t] < p.dh_min) p.dh_min = p.dh[t];
+        if (p.dh[t] > dh_max) dh_max = p.dh[t];
+        if (p.dw[t] < p.dw_min) p.dw_min = p.dw[t];
+        if (p.dw[t] > dw_max) dw_max = p.dw[t];
+    }
+    const TileChoice tc = choose_tile(p.N, p.A, p.B);
+    p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
+    p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
+    p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+    p.tilesA = mrdis_cdiv(p.A, p.TH); p.tilesB = mrdis_cdiv(p.B, p.TW); p.tilesN = mrdis_cdiv(p.N, p.NB);
+    const long long ptiles = (long long)p.tilesA * p.tilesB * p.tilesN;
+    int BN = p.Cout <= 32 ? 32 : (p.Cout <= 64 ? 64 : 128);
+    if (BN == 128 && ptiles * mrdis_cdiv(p.Cout, 128) < 512) BN = 64;   // keep the chip full on small grids
+    if (BN == 64 && p.Cout > 32 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
+    int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
+    const size_t LDS_MAX = 64 * 1024;
+    while (tapconv_lds(p, KC, BN) > LDS_MAX && KC > 4) KC >>= 1;
+    while (tapconv_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
+    if (tapconv_lds(p, KC, BN) > LDS_MAX) return MRDIS_EUNSUPPORTED;
+    p.coTiles = mrdis_cdiv(p.Cout, BN);
+    const long long nblk = ptiles * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
+    p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
+    const size_t lds = tapconv_lds(p, KC, BN);
+#define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, s)
+    TC_CASE(4, 32); TC_CASE(4, 64); TC_CASE(4, 128);
+    TC_CASE(8, 32); TC_CASE(8, 64); TC_CASE(8, 128);
+    TC_CASE(16, 32); TC_CASE(16, 64); TC_CASE(16, 128);
+#undef TC_CASE
+    return MRDIS_EUNSUPPORTED;
+}
+
+static int check_conv_geom(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                           int* Ho, int* Wo) {
+    if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return MRDIS_EINVAL;
+    if (kh < 1 || kw < 1 || kh * kw > MRDIS_MAX_TAPS) return MRDIS_EUNSUPPORTED;
+    if (stride != 1 && stride != 2) return MRDIS_EUNSUPPORTED;
+    if (pad < 0 || pad >= kh || pad >= kw) return MRDIS_EUNSUPPORTED;
+    *Ho = (H + 2 * pad - kh) / stride + 1;
+    *Wo = (W + 2 * pad - kw) / stride + 1;
+    if (*Ho <= 0 || *Wo <= 0) return MRDIS_EINVAL;
+    return MRDIS_OK;
+}
+
+extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
+                                float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                                int kh, int kw, int stride, int pad, int epilogue, void* stream) {
+    int Ho, Wo;
+    int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
+    TapConvParams p{};
+    p.in = x; p.w = w_tck; p.bias = bias; p.out = y;
+    p.N = N; p.Hin = H; p.Win = W; p.Cin = Ci; p.ldin = ldx;
+    p.Hout = Ho; p.Wout = Wo; p.Cout = Co; p.ldout = ldy;
+    p.A = Ho; p.B = Wo; p.os = 1; p.oh0 = 0; p.ow0 = 0; p.is = stride;
+    p.ntaps = kh * kw;
+    for (int r = 0; r < kh; ++r)
+        for (int s_ = 0; s_ < kw; ++s_) {
+            const int t = r * kw + s_;
+            p.dh[t] = r - pad; p.dw[t] = s_ - pad; p.widx[t] = t;
+        }
+    p.epilogue = epilogue;
+    return run_tapconv(p, (hipStream_t)stream);
+}
+
+extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc,
+                                     float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+                                     int kh, int kw, int stride, int pad, void* stream) {
+    int Ho, Wo;
+    int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
+    if (rc) return rc;
+    if (!dy || !w_tkc || !dx || lddy < Co || lddx < Ci) return MRDIS_EINVAL;
+    TapConvParams base{};
+    base.in = dy; base.w = w_tkc; base.bias = nullptr; base.out = dx;
+    base.N = N; base.Hin = Ho; base.Win = Wo; base.Cin = Co; base.ldin = lddy;
+    base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
+    base.is = 1; base.epilogue = 0;
+    if (stride == 1) {
+        TapConvParams p = base;
+        p.A = H; p.B = W; p.os = 1; p.oh0 = 0; p.ow0 = 0;
+        p.ntaps = kh * kw;
+        for (int r = 0; r < kh; ++r)
+            for (int s_ = 0; s_ < kw; ++s_) {
+                const int t = r * kw + s_;
+                p.dh[t] = pad - r; p.dw[t] = pad - s_; p.widx[t] = t;
+            }
+        return run_tapconv(p, (hipStream_t)stream);
+    }
+    // stride 2: dx[hi] gathers dy[(hi + pad - r)/2] for the taps r with (hi + pad - r) even.
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            TapConvParams p = base;
+            p.A = (H - ph + 1) / 2; p.B = (W - pw + 1) / 2;
+            p.os = 2; p.oh0 = ph; p.ow0 = pw;
+            p.ntaps = 0;
+            for (int r = 0; r < kh; ++r) {
+                if (((ph + pad - r) & 1) != 0) continue;
+                for (int s_ = 0; s_ < kw; ++s_) {
+                    if (((pw + pad - s_) & 1) != 0) continue;
+                    const int t = p.ntaps++;
+                    // exact: numerator is even; arithmetic shift keeps floor semantics for negatives
+                    p.dh[t] = (ph + pad - r) >> 1; p.dw[t] = (pw + pad - s_) >> 1; p.widx[t] = r * kw + s_;
+                }
+            }
+            if (p.ntaps == 0) return MRDIS_EUNSUPPORTED;   // would need a zero fill; not on the path
+            rc = run_tapconv(p, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return MRDIS_OK;
+}
+
+// =========================================================================== weight gradient
+struct WgradParams {
+    const float* x; const float* dy; float* slab;
+    int N, Hin, Win, Ci, ldx;
+    int A, B, Co, lddy;           // dy extents (Ho, Wo)
+    int is, ntaps;
+    int dh[MRDIS_MAX_TAPS], dw[MRDIS_MAX_TAPS];
+    int dh_min, dw_min;
+    int NB, TH, TW, TinH, TinW, tilesA, tilesB, tilesN, numTiles;
+    int CW, TPS;                  // channels per M sub-tile row group (<=32), taps per sub-tile
+    int nCi, nCo, nG, base;       // ci chunks (32), co chunks (32), tap groups, base = nCi*nCo*nG
+    int splits;
+    int vec_x, vec_dy;
+};
+
+#define WG_TAB_INTS 192   // tab_in[128] tap_xoff[16] + pad
+
+template <int J>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tab_in = reinterpret_cast<int*>(smem);
+    int* tab_pos = tab_in + 128;          // packed (n,a,b) validity -> dy pixel index or -1 (per tile, rebuilt)
+    float* dys = smem + 256;              // [128][32]
+    float* xs = dys + 128 * 32;           // [npix_in][S]
+    const int S = p.CW + 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
+    const int bid = blockIdx.x;
+    const int split = bid / p.base;
+    int b = bid - split * p.base;
+    const int coc = b % p.nCo; b /= p.nCo;
+    const int cic = b % p.nCi;
+    const int g = b / p.nCi;
+    const int c_lo = cic * 32, co_lo = coc * 32;
+
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
+    if (tid < 128) {
+        const int m = tid;
+        int tin = 0;
+        if (m < npos) {
+            const int nb = m / (p.TH * p.TW);
+            const int rem = m - nb * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S;
+        }
+        tab_in[m] = tin;
+    }
+    // per-lane sub-tile row -> (tap, ci) -> offset inside the staged input tile
+    int loff[J];
+    unsigned lvalid = 0;
+    {
+        const int tl = e / p.CW, cl = e - tl * p.CW;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int tap = (g * J + j) * p.TPS + tl;
+            const bool ok = tap < p.ntaps && (c_lo + cl) < p.Ci;
+            loff[j] = ok ? ((p.dh[tap] - p.dh_min) * p.TinW + (p.dw[tap] - p.dw_min)) * S + cl : 0;
+            lvalid |= (ok ? 1u : 0u) << j;
+        }
+    }
+    __syncthreads();
+    // positions handled by this wave: pairs q = wave + 4*pp, position m = 2q + half
+    int aoff[16];
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp) aoff[pp] = tab_in[2 * (wave + 4 * pp) + half];
+
+    f32x16 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int tile = split; tile < p.numTiles; tile += p.splits) {
+        int tt = tile;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int tn = tt / p.tilesA;
+        const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
+        const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+        __syncthreads();
+        if (tid < 128) {
+            const int m = tid;
+            int pos = -1;
+            if (m < npos) {
+                const int nb = m / (p.TH * p.TW);
+                const int rem = m - nb * p.TH * p.TW;
+                const int ty = rem / p.TW, tx = rem - ty * p.TW;
+                const int n = n0 + nb, a = a0 + ty, bb = b0 + tx;
+                if (n < p.N && a < p.A && bb < p.B) pos = (n * p.A + a) * p.B + bb;
+            }
+            tab_pos[m] = pos;
+        }
+        // stage x tile (channels c_lo .. c_lo+CW)
+        if (p.vec_x) {
+            const int Q = p.CW >> 2;
+            for (int idx = tid; idx < npix_in * Q; idx += 256) {
+                const int pi = idx / Q, q = idx - pi * Q;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Ci)
+                    v = *reinterpret_cast<const float4*>(p.x + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c);
+                float* d = xs + pi * S + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < npix_in * p.CW; idx += 256) {
+                const int pi = idx / p.CW, k = idx - pi * p.CW;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + k;
+                float v = 0.f;
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Ci)
+                    v = p.x[((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c];
+                xs[pi * S + k] = v;
+            }
+        }
+        __syncthreads();   // tab_pos visible
+        // stage dy tile [128][32]; invalid positions / couts are zero rows, which also
+        // silences whatever the x tile holds there
+        if (p.vec_dy) {
+            for (int idx = tid; idx < 128 * 8; idx += 256) {
+                const int m = idx >> 3, q = idx & 7;
+                const int pos = tab_pos[m], co = co_lo + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pos >= 0 && co < p.Co)
+                    v = *reinterpret_cast<const float4*>(p.dy + (long long)pos * p.lddy + co);
+                *reinterpret_cast<float4*>(dys + m * 32 + 4 * q) = v;
+            }
+        } else {
+            for (int idx = tid; idx < 128 * 32; idx += 256) {
+                const int m = idx >> 5, q = idx & 31;
+                const int pos = tab_pos[m], co = co_lo + q;
+                float v = 0.f;
+                if (pos >= 0 && co < p.Co) v = p.dy[(long long)pos * p.lddy + co];
+                dys[idx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const int m = 2 * (wave + 4 * pp) + half;
+            const float bv = dys[m * 32 + e];
+            const float* xr = xs + aoff[pp];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                float av = xr[loff[j]];
+                av = ((lvalid >> j) & 1u) ? av : 0.f;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // slab[(split*4 + wave)][b][j][32][32]
+    float* out = p.slab + ((((long long)split * 4 + wave) * p.base + (bid - split * p.base)) * J) * 1024;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            out[j * 1024 + row * 32 + e] = acc[j][r];
+        }
+}
+
+// dw_tck[t][ci][co] = sum over slabs, fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ntaps, int Ci, int Co,
+                                    int CW, int TPS, int J, int nCi, int nCo, int base, int nslab) {
+    const long long total = (long long)ntaps * Ci * Co;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co);
+        const long long r = i / Co;
+        const int ci = (int)(r % Ci), t = (int)(r / Ci);
+        const int coc = co >> 5, n = co & 31;
+        const int cic = (Ci >= 32) ? (ci >> 5) : 0;
+        const int cl = ci - cic * 32;
+        const int jj = t / TPS, m = (t - jj * TPS) * CW + cl;
+        const int g = jj / J, j = jj - g * J;
+        const int b = (g * nCi + cic) * nCo + coc;
+        const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n;
+        const long long stride = (long long)base * J * 1024;
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += src[k * stride];
+        dw[i] = s;
+    }
+}
+
+// column sums of a (P, C) view -> out[C]  (bias gradient).  Two-level, fixed order.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long long P, int C, float* __restrict__ part, int rows_per_blk) {
+    // blockDim = (64, 4): x threads cover channels, y threads rows
+    __shared__ float red[4][64];
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    long long r1 = r0 + rows_per_blk; if (r1 > P) r1 = P;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + threadIdx.x;
+        float s = 0.f;
+        if (c < C)
+            for (long long r = r0 + threadIdx.y; r < r1; r += 4) s += x[r * ld + c];
+        red[threadIdx.y][threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.y == 0 && c < C)
+            part[(long long)blockIdx.x * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
+    out[c] = (float)s;
+}
+
+struct WgradPlan {
+    WgradParams p;
+    int J;
+    size_t lds;
+    long long slab_floats;
+    int colsum_blocks, colsum_rows;
+    long long colsum_floats;
+};
+
+static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    int Ho, Wo;
+    int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
+    if (rc) return rc;
+    WgradParams& p = pl.p;
+    p = WgradParams{};
+    p.N = N; p.Hin = H; p.Win = W; p.Ci = Ci; p.A = Ho; p.B = Wo; p.Co = Co; p.is = stride;
+    p.ntaps = kh * kw;
+    int dh_max = -pad, dw_max = -pad;
+    p.dh_min = -pad; p.dw_min = -pad;
+    for (int r = 0; r < kh; ++r)
+        for (int s_ = 0; s_ < kw; ++s_) {
+            const int t = r * kw + s_;
+            p.dh[t] = r - pad; p.dw[t] = s_ - pad;
+            if (p.dh[t] > dh_max) dh_max = p.dh[t];
+            if (p.dw[t] > dw_max) dw_max = p.dw[t];
+        }
+    // M sub-tiles
+    int CW = 32;
+    if (Ci < 32) { CW = 4; while (CW < Ci) CW <<= 1; }
+    p.CW = CW; p.TPS = 32 / CW;
+    const int subtiles = mrdis_cdiv(p.ntaps, p.TPS);
+    int J = subtiles, nG = 1;
+    if (subtiles > 9) { nG = mrdis_cdiv(subtiles, 8); J = mrdis_cdiv(subtiles, nG); }
+    // round J up to an instantiated size
+    static const int JS[] = {1, 2, 3, 4, 5, 8, 9};
+    int Jr = 9;
+    for (int k = 0; k < 7; ++k) if (JS[k] >= J) { Jr = JS[k]; break; }
+    J = Jr;
+    pl.J = J;
+    p.nG = mrdis_cdiv(subtiles, J);
+    p.nCi = (Ci >= 32) ? mrdis_cdiv(Ci, 32) : 1;
+    p.nCo = mrdis_cdiv(Co, 32);
+    p.base = p.nCi * p.nCo * p.nG;
+    // position tile: shrink until LDS fits (<= 64 KiB -> two workgroups per CU)
+    TileChoice tc = choose_tile(N, Ho, Wo);
+    for (;;) {
+        p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
+        p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
+        p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+        pl.lds = sizeof(float) * (256 + 128 * 32 + (size_t)p.NB * p.TinH * p.TinW * (CW + 1));
+        if (pl.lds <= 64 * 1024) break;
+        if (tc.TH > 1) tc.TH = (tc.TH + 1) / 2; else if (tc.NB > 1) tc.NB = (tc.NB + 1) / 2; else if (tc.TW > 1) tc.TW = (tc.TW + 1) / 2; else return MRDIS_EUNSUPPORTED;
+    }
+    p.tilesA = mrdis_cdiv(Ho, p.TH); p.tilesB = mrdis_cdiv(Wo, p.TW); p.tilesN = mrdis_cdiv(N, p.NB);
+    const long long nt = (long long)p.tilesA * p.tilesB * p.tilesN;
+    if (nt > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.numTiles = (int)nt;
+    long long splits = mrdis_cdiv(1024, p.base);
+    if (splits > nt) splits = nt;
+    if (splits < 1) splits = 1;
+    p.splits = (int)splits;
+    pl.slab_floats = (long long)p.splits * 4 * p.base * J * 1024;
+    const long long P = (long long)N * Ho * Wo;
+    pl.colsum_rows = 256;
+    long long cb = (P + 255) / 256;
+    if (cb > 2048) { pl.colsum_rows = (int)((P + 2047) / 2048); cb = (P + pl.colsum_rows - 1) / pl.colsum_rows; }
+    pl.colsum_blocks = (int)cb;
+    pl.colsum_floats = cb * Co;
+    return MRDIS_OK;
+}
+
+extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
+                                                    int kh, int kw, int stride, int pad) {
+    WgradPlan pl;
+    if (plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
+    return sizeof(float) * (size_t)(pl.slab_floats + pl.colsum_floats) + 256;
+}
+
+template <int J>
+static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
+    hipLaunchKernelGGL((wgrad_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
+                                       float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                                       int N, int H, int W, int Ci, int Co,
+                                       int kh, int kw, int stride, int pad, void* stream) {
+    WgradPlan pl;
+    int rc = plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
+    if (rc) return rc;
+    if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
+    const size_t need = sizeof(float) * (size_t)(pl.slab_floats + pl.colsum_floats) + 256;
+    if (workspace_bytes < need) return MRDIS_EWORKSPACE;
+    if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    WgradParams& p = pl.p;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.vec_x = (Ci % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0) && (p.CW % 4 == 0);
+    p.vec_dy = (Co % 4 == 0) && (lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    switch (pl.J) {
+        case 1: rc = launch_wgrad_t<1>(pl, s); break;
+        case 2: rc = launch_wgrad_t<2>(pl, s); break;
+        case 3: rc = launch_wgrad_t<3>(pl, s); break;
+        case 4: rc = launch_wgrad_t<4>(pl, s); break;
+        case 5: rc = launch_wgrad_t<5>(pl, s); break;
+        case 8: rc = launch_wgrad_t<8>(pl, s); break;
+        case 9: rc = launch_wgrad_t<9>(pl, s); break;
+        default: return MRDIS_EUNSUPPORTED;
+    }
+    if (rc) return rc;
+    const long long total = (long long)p.ntaps * Ci * Co;
+    int rblk = mrdis_cdiv(total, 256); if (rblk > 2048) rblk = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblk), dim3(256), 0, s, p.slab, dw_tck, p.ntaps, Ci, Co,
+                       p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits * 4);
+    MRDIS_CHECK_LAUNCH();
+    if (dbias) {
+        float* part = p.slab + pl.slab_floats;
+        const long long P = (long long)N * p.A * p.B;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(pl.colsum_blocks), dim3(64, 4), 0, s, dy, lddy, P, Co, part, pl.colsum_rows);
+        MRDIS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(mrdis_cdiv(Co, 64)), dim3(64), 0, s, part, pl.colsum_blocks, Co, dbias);
+        MRDIS_CHECK_LAUNCH();
+    }
+    return MRDIS_OK;
+}
+
+// =========================================================================== expert mixing
+__global__ void mix_fwd_kernel(const float* __restrict__ W, const float* __restrict__ r, float* __restrict__ w_tck,
+                               float* __restrict__ w_tkc, int E, int Co, int Ci, int T) {
+    const long long total = (long long)Co * Ci * T;
+    float rr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rr[e] = e < E ? r[e] : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const long long q = i / T;
+        const int ci = (int)(q % Ci), co = (int)(q / Ci);
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s += rr[e] * W[(long long)e * total + i];   // sum over experts in order e = 0..E-1
+        if (w_tck) w_tck[((long long)t * Ci + ci) * Co + co] = s;
+        if (w_tkc) w_tkc[((long long)t * Co + co) * Ci + ci] = s;
+    }
+}
+
+__global__ void mix_bwd_kernel(const float* __restrict__ dw_tck, const float* __restrict__ W, const float* __restrict__ r,
+                               float* __restrict__ dW, float* __restrict__ part, int E, int Co, int Ci, int T) {
+    __shared__ double red[8][4];
+    const long long total = (long long)Co * Ci * T;
+    float rr[8];
+    double dr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { rr[e] = e < E ? r[e] : 0.f; dr[e] = 0.0; }
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const long long q = i / T;
+        const int ci = (int)(q % Ci), co = (int)(q / Ci);
+        const float g = dw_tck[((long long)t * Ci + ci) * Co + co];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < E) {
+                dW[(long long)e * total + i] = rr[e] * g;
+                dr[e] += (double)g * (double)W[(long long)e * total + i];
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double v = mrdis_wave_sum_d(dr[e]);
+        if (lane == 0) red[e][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && (int)threadIdx.x < E)
+        part[(long long)blockIdx.x * 8 + threadIdx.x] = (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+}
+__global__ void mix_bwd_final_kernel(const float* __restrict__ part, int nblk, int E, float* __restrict__ dr) {
+    const int e = threadIdx.x;
+    if (e >= E) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * 8 + e];
+    dr[e] += (float)s;
+}
+
+static int mix_blocks(long long total) { int b = mrdis_cdiv(total, 256); return b > 512 ? 512 : (b < 1 ? 1 : b); }
+
+extern "C" int mrdis_mix_experts_fwd(const float* W, const float* r, float* w_tck, float* w_tkc,
+                                     int E, int Co, int Ci, int T, void* stream) {
+    if (!W || !r || E < 1 || E > 8 || Co < 1 || Ci < 1 || T < 1) return MRDIS_EINVAL;
+    const long long total = (long long)Co * Ci * T;
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, r, w_tck, w_tkc, E, Co, Ci, T);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" size_t mrdis_mix_experts_bwd_workspace(int E, int Co, int Ci, int T) {
+    (void)E;
+    return sizeof(float) * 8 * (size_t)mix_blocks((long long)Co * Ci * T);
+}
+
+extern "C" int mrdis_mix_experts_bwd(const float* dw_tck, const float* W, const float* r,
+                                     float* dW, float* dr, void* workspace, size_t workspace_bytes,
+                                     int E, int Co, int Ci, int T, void* stream) {
+    if (!dw_tck || !W || !r || !dW || !dr || !workspace || E < 1 || E > 8) return MRDIS_EINVAL;
+    const long long total = (long long)Co * Ci * T;
+    const int nb = mix_blocks(total);
+    if (workspace_bytes < sizeof(float) * 8 * (size_t)nb) return MRDIS_EWORKSPACE;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
+                       reinterpret_cast<float*>(workspace), E, Co, Ci, T);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(workspace), nb, E, dr);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

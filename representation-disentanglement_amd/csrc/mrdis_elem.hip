@@ -1,0 +1,676 @@
+// mrdis_elem.hip -- bandwidth-bound neighbours of the convolutions (gfx950, fp32):
+// BatchNorm(train), InstanceNorm+SPADE modulation, bilinear resize, masked
+// softmax, LeakyReLU backward, reconstruction error, max-pool, optimizer step.
+// All tensors are NHWC "views" (rows = pixels, ld = row stride in floats).
+// Reductions are two-level with a fixed summation order (partials in fp32 over
+// short runs, combination in fp64) so every result is bit-reproducible.
+#include "mrdis_common.h"
+
+// ------------------------------------------------------------------ small vector helper
+template <int V> struct Vec;
+template <> struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+};
+template <> struct Vec<4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+static inline bool vec4_ok(const void* p, int ld, int C) { return (C % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)p & 15) == 0); }
+static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+#define EW_LOOP(total) for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (total); idx += (long long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ grouped column statistics
+// rows of group g: [g*P, (g+1)*P).  part[((g*chunks + chunk)*2 + k)*C + c]
+struct StatPlan { int chunks, rpb; };
+static StatPlan stat_plan(int groups, long long P) {
+    long long maxc = 4096 / (groups > 0 ? groups : 1); if (maxc < 1) maxc = 1;
+    long long chunks = (P + 255) / 256; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
+    StatPlan s; s.chunks = (int)chunks; s.rpb = (int)((P + chunks - 1) / chunks);
+    return s;
+}
+extern "C" size_t mrdis_norm_workspace(int groups, long long P, int C) {
+    const StatPlan s = stat_plan(groups, P);
+    return sizeof(float) * 2 * (size_t)groups * s.chunks * C + 64;
+}
+
+// MODE 0: (sum x, sum x^2)            a = x
+// MODE 1: (sum dy, sum dy*xhat)       a = dy, b = x, stats (mean,rstd) per (group? no: per channel) -> BN bwd
+// MODE 2: (sum dzh, sum dzh*zhat)     a = dout, b = z, c = gamma ; dzh = dout*(1+gamma)  -> SPADE/IN bwd
+template <int MODE>
+__global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                    const float* __restrict__ g, int ldg, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, int stat_per_group,
+                                    long long P, int C, int rpb, float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int grp = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const long long r0 = (long long)chunk * rpb;
+    long long r1 = r0 + rpb; if (r1 > P) r1 = P;
+    const long long gbase = (long long)grp * P;
+    // lanes: C >= 64 -> 64 channels per pass; C < 64 and 64 % C == 0 -> 64/C rows per pass
+    const int rpx = (C < 64 && (64 % C) == 0) ? 64 / C : 1;
+    const int cw = (C < 64) ? C : 64;
+    const int sub = threadIdx.x / cw, cl = threadIdx.x - sub * cw;
+    const bool lane_ok = sub < rpx;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + cl;
+        float s0 = 0.f, s1 = 0.f;
+        if (lane_ok && c < C) {
+            float mu = 0.f, rs = 1.f;
+            if (MODE != 0) { const int si = stat_per_group ? grp * C + c : c; mu = mean[si]; rs = rstd[si]; }
+            for (long long r = r0 + threadIdx.y * rpx + sub; r < r1; r += 4 * rpx) {
+                const long long row = gbase + r;
+                if (MODE == 0) { const float x = a[row * lda + c]; s0 += x; s1 += x * x; }
+                else if (MODE == 1) { const float d = a[row * lda + c]; const float xh = (b[row * ldb + c] - mu) * rs; s0 += d; s1 += d * xh; }
+                else { const float d = a[row * lda + c] * (1.f + g[row * ldg + c]); const float zh = (b[row * ldb + c] - mu) * rs; s0 += d; s1 += d * zh; }
+            }
+        }
+        red[0][threadIdx.y][threadIdx.x] = s0; red[1][threadIdx.y][threadIdx.x] = s1;
+        __syncthreads();
+        if (threadIdx.y == 0 && sub == 0 && c < C) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int y = 0; y < 4; ++y)
+                for (int u = 0; u < rpx; ++u) { t0 += red[0][y][u * cw + cl]; t1 += red[1][y][u * cw + cl]; }
+            float* dst = part + ((long long)(grp * chunks + chunk) * 2) * C;
+            dst[c] = t0; dst[C + c] = t1;
+        }
+        __syncthreads();
+    }
+}
+
+// FIN 0: mean / rstd (+ optional running stats, BatchNorm semantics)   FIN 1: raw sums -> out0/out1
+template <int FIN>
+__global__ void stat_final_kernel(const float* __restrict__ part, int chunks, int C, int groups, long long P, float eps,
+                                  float momentum, float* __restrict__ out0, float* __restrict__ out1,
+                                  float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const int grp = i / C, c = i - grp * C;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float* src = part + ((long long)(grp * chunks + k) * 2) * C;
+        s0 += (double)src[c]; s1 += (double)src[C + c];
+    }
+    if (FIN == 0) {
+        const double m = s0 / (double)P;
+        double var = s1 / (double)P - m * m; if (var < 0.0) var = 0.0;
+        out0[i] = (float)m;
+        out1[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {   // nn.BatchNorm2d: running_var uses the unbiased estimate
+            const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+            run_mean[i] = (float)((1.0 - momentum) * (double)run_mean[i] + momentum * m);
+            run_var[i] = (float)((1.0 - momentum) * (double)run_var[i] + momentum * unb);
+        }
+    } else { out0[i] = (float)s0; out1[i] = (float)s1; }
+}
+
+template <int MODE>
+static int launch_stats(const float* a, int lda, const float* b, int ldb, const float* g, int ldg, const float* mean,
+                        const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s) {
+    const StatPlan sp = stat_plan(groups, P);
+    hipLaunchKernelGGL((stat_partial_kernel<MODE>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+                       stat_per_group, P, C, sp.rpb, part);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm (training)
+template <int V>
+__global__ void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                long long P, int C) {
+    const int Q = C / V;
+    EW_LOOP(P * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        Vec<V> a, o; a.load(x + r * ldx + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float sc = rstd[c + k] * (gamma ? gamma[c + k] : 1.f);
+            o.v[k] = (a.v[k] - mean[c + k]) * sc + (beta ? beta[c + k] : 0.f);
+        }
+        o.store(y + r * ldy + c);
+    }
+}
+
+extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var,
+                                  float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                  long long P, int C, float eps, float momentum, void* stream) {
+    if (!x || !y || !save_mean || !save_rstd || !workspace || P < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    int rc = launch_stats<0>(x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(1, P);
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
+                       save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
+    MRDIS_CHECK_LAUNCH();
+    if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
+        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+template <int V>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ sdy, const float* __restrict__ sdyxh, float* __restrict__ dx, int lddx,
+                                    long long P, int C) {
+    const int Q = C / V;
+    const float invP = 1.f / (float)P;
+    EW_LOOP(P * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        Vec<V> d, a, o; d.load(dy + r * lddy + c); a.load(x + r * ldx + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float rs = rstd[c + k];
+            const float xh = (a.v[k] - mean[c + k]) * rs;
+            o.v[k] = (gamma ? gamma[c + k] : 1.f) * rs * (d.v[k] - sdy[c + k] * invP - xh * sdyxh[c + k] * invP);
+        }
+        o.store(dx + r * lddx + c);
+    }
+}
+
+extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
+                                  const float* save_mean, const float* save_rstd, float* dx, int lddx,
+                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                  long long P, int C, void* stream) {
+    if (!dy || !x || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || P < 1 || C < 1) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    int rc = launch_stats<1>(dy, lddy, x, ldx, nullptr, 0, save_mean, save_rstd, 0, 1, P, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(1, P);
+    // dbeta = sum dy ; dgamma = sum dy * xhat
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
+                       dbeta, dgamma, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ InstanceNorm + SPADE modulation
+template <int V>
+__global__ void spade_fwd_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg, const float* __restrict__ b, int ldb,
+                                 float* __restrict__ out, int ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 long long HW, long long rows, int C) {
+    const int Q = C / V;
+    EW_LOOP(rows * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        const int n = (int)(r / HW);
+        Vec<V> a, gg, bb, o; a.load(z + r * ldz + c); gg.load(g + r * ldg + c); bb.load(b + r * ldb + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float zh = (a.v[k] - mean[n * C + c + k]) * rstd[n * C + c + k];
+            o.v[k] = zh * (1.f + gg.v[k]) + bb.v[k];
+        }
+        o.store(out + r * ldo + c);
+    }
+}
+
+extern "C" int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* gamma, int ldg,
+                                        const float* beta, int ldb, float* out, int ldo,
+                                        float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                        int N, long long HW, int C, float eps, void* stream) {
+    if (!z || !gamma || !beta || !out || !save_mean || !save_rstd || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_norm_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    int rc = launch_stats<0>(z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(N, HW);
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+                       save_mean, save_rstd, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    const long long rows = (long long)N * HW;
+    if (vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(beta, ldb, C) && vec4_ok(out, ldo, C))
+        hipLaunchKernelGGL((spade_fwd_kernel<4>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+    else
+        hipLaunchKernelGGL((spade_fwd_kernel<1>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+template <int V>
+__global__ void spade_bwd_kernel(const float* __restrict__ dout, int lddo, const float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
+                                 const float* __restrict__ s1, float* __restrict__ dz, int lddz, float* __restrict__ dgm, int lddg,
+                                 float* __restrict__ dbt, int lddb, long long HW, long long rows, int C) {
+    const int Q = C / V;
+    const float inv = 1.f / (float)HW;
+    EW_LOOP(rows * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        const int n = (int)(r / HW);
+        Vec<V> d, a, gg, oz, og; d.load(dout + r * lddo + c); a.load(z + r * ldz + c); gg.load(g + r * ldg + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int si = n * C + c + k;
+            const float rs = rstd[si];
+            const float zh = (a.v[k] - mean[si]) * rs;
+            const float dzh = d.v[k] * (1.f + gg.v[k]);
+            og.v[k] = d.v[k] * zh;                                            // d gamma
+            oz.v[k] = rs * (dzh - s0[si] * inv - zh * s1[si] * inv);          // instance-norm backward
+        }
+        oz.store(dz + r * lddz + c); og.store(dgm + r * lddg + c);
+        if (dbt) d.store(dbt + r * lddb + c);                                 // d beta = dout
+    }
+}
+
+extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float* z, int ldz,
+                                        const float* gamma, int ldg, const float* save_mean, const float* save_rstd,
+                                        float* dz, int lddz, float* dgamma, int lddg, float* dbeta, int lddb,
+                                        void* workspace, size_t workspace_bytes,
+                                        int N, long long HW, int C, void* stream) {
+    if (!dout || !z || !gamma || !save_mean || !save_rstd || !dz || !dgamma || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
+    // layout of workspace: partials, then the two (N*C) reduced sums
+    const size_t pbytes = mrdis_norm_workspace(N, HW, C);
+    const size_t need = pbytes + sizeof(float) * 2 * (size_t)N * C;
+    if (workspace_bytes < need) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    float* s0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
+    float* s1 = s0 + (size_t)N * C;
+    int rc = launch_stats<2>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(N, HW);
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    const long long rows = (long long)N * HW;
+    const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dz, lddz, C) &&
+                   vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
+    if (v)
+        hipLaunchKernelGGL((spade_bwd_kernel<4>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+    else
+        hipLaunchKernelGGL((spade_bwd_kernel<1>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C) {
+    return mrdis_norm_workspace(N, HW, C) + sizeof(float) * 2 * (size_t)N * C;
+}
+
+// ------------------------------------------------------------------ LeakyReLU backward
+template <int V>
+__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dx, int lddx,
+                                 long long P, int C, float slope) {
+    const int Q = C / V;
+    EW_LOOP(P * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        Vec<V> d, a, o; d.load(dy + r * lddy + c); a.load(y + r * ldy + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = a.v[k] > 0.f ? d.v[k] : slope * d.v[k];
+        o.store(dx + r * lddx + c);
+    }
+}
+extern "C" int mrdis_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
+                               long long P, int C, float slope, void* stream) {
+    if (!dy || !y || !dx || P < 1 || C < 1) return MRDIS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (vec4_ok(dy, lddy, C) && vec4_ok(y, ldy, C) && vec4_ok(dx, lddx, C))
+        hipLaunchKernelGGL((lrelu_bwd_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+    else
+        hipLaunchKernelGGL((lrelu_bwd_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ bilinear resize
+// Source-index rule of ATen's upsample_bilinear2d (area_pixel_compute_source_index), fp32.
+struct BilAxis { int i0, i1; float l0, l1; };
+__device__ __forceinline__ BilAxis bil_axis(int o, float scale, int align, int isz) {
+    float src;
+    if (align) src = scale * (float)o;
+    else { src = scale * ((float)o + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
+    BilAxis a;
+    a.i0 = (int)src; if (a.i0 > isz - 1) a.i0 = isz - 1;
+    a.i1 = a.i0 + ((a.i0 < isz - 1) ? 1 : 0);
+    a.l1 = src - (float)a.i0; a.l0 = 1.f - a.l1;
+    return a;
+}
+static inline float bil_scale(int isz, int osz, int align) {
+    if (align) return osz > 1 ? (float)(isz - 1) / (float)(osz - 1) : 0.f;
+    return (float)isz / (float)osz;
+}
+
+template <int V>
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N, int Hi, int Wi, int Ho, int Wo,
+                                    int C, int align, float sh, float sw) {
+    const int Q = C / V;
+    EW_LOOP((long long)N * Ho * Wo * Q) {
+        const int q = (int)(idx % Q); long long r = idx / Q;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+        const BilAxis ah = bil_axis(ho, sh, align, Hi), aw = bil_axis(wo, sw, align, Wi);
+        const float* base = x + (long long)n * Hi * Wi * ldx + q * V;
+        Vec<V> p00, p01, p10, p11, o;
+        p00.load(base + ((long long)ah.i0 * Wi + aw.i0) * ldx); p01.load(base + ((long long)ah.i0 * Wi + aw.i1) * ldx);
+        p10.load(base + ((long long)ah.i1 * Wi + aw.i0) * ldx); p11.load(base + ((long long)ah.i1 * Wi + aw.i1) * ldx);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            o.v[k] = ah.l0 * (aw.l0 * p00.v[k] + aw.l1 * p01.v[k]) + ah.l1 * (aw.l0 * p10.v[k] + aw.l1 * p11.v[k]);
+        o.store(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + q * V);
+    }
+}
+
+// gather form of the adjoint: input pixel i collects every output o whose stencil touches it.
+__device__ __forceinline__ void bil_range(int i, float scale, int align, int osz, int* lo, int* hi) {
+    if (scale <= 0.f) { *lo = 0; *hi = osz - 1; return; }
+    float a, b;
+    if (align) { a = ((float)i - 1.f) / scale; b = ((float)i + 1.f) / scale; }
+    else { a = ((float)i - 0.5f) / scale - 0.5f; b = ((float)i + 1.5f) / scale - 0.5f; }
+    int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+    if (l < 0) l = 0; if (h > osz - 1) h = osz - 1;
+    *lo = l; *hi = h;
+}
+template <int V>
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo,
+                                    int C, int align, float sh, float sw) {
+    const int Q = C / V;
+    EW_LOOP((long long)N * Hi * Wi * Q) {
+        const int q = (int)(idx % Q); long long r = idx / Q;
+        const int wi = (int)(r % Wi); r /= Wi;
+        const int hi = (int)(r % Hi); const int n = (int)(r / Hi);
+        int hlo, hhi, wlo, whi;
+        bil_range(hi, sh, align, Ho, &hlo, &hhi); bil_range(wi, sw, align, Wo, &wlo, &whi);
+        Vec<V> acc;
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc.v[k] = 0.f;
+        const float* base = dy + (long long)n * Ho * Wo * lddy + q * V;
+        for (int ho = hlo; ho <= hhi; ++ho) {
+            const BilAxis ah = bil_axis(ho, sh, align, Hi);
+            const float wh = (ah.i0 == hi ? ah.l0 : 0.f) + (ah.i1 == hi ? ah.l1 : 0.f);
+            if (wh == 0.f) continue;
+            for (int wo = wlo; wo <= whi; ++wo) {
+                const BilAxis aw = bil_axis(wo, sw, align, Wi);
+                const float ww = (aw.i0 == wi ? aw.l0 : 0.f) + (aw.i1 == wi ? aw.l1 : 0.f);
+                if (ww == 0.f) continue;
+                Vec<V> d; d.load(base + ((long long)ho * Wo + wo) * lddy);
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc.v[k] += wh * ww * d.v[k];
+            }
+        }
+        acc.store(dx + (((long long)n * Hi + hi) * Wi + wi) * lddx + q * V);
+    }
+}
+
+extern "C" int mrdis_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi,
+                                  int Ho, int Wo, int C, int align_corners, void* stream) {
+    if (!x || !y || N < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
+    const float sh = bil_scale(Hi, Ho, align_corners), sw = bil_scale(Wi, Wo, align_corners);
+    hipStream_t s = (hipStream_t)stream;
+    const long long tot = (long long)N * Ho * Wo * C;
+    if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
+        hipLaunchKernelGGL((bilinear_fwd_kernel<4>), dim3(ew_blocks(tot / 4)), dim3(256), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+    else
+        hipLaunchKernelGGL((bilinear_fwd_kernel<1>), dim3(ew_blocks(tot)), dim3(256), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+extern "C" int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
+                                  int Ho, int Wo, int C, int align_corners, void* stream) {
+    if (!dy || !dx || N < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || C < 1 || lddy < C || lddx < C) return MRDIS_EINVAL;
+    const float sh = bil_scale(Hi, Ho, align_corners), sw = bil_scale(Wi, Wo, align_corners);
+    hipStream_t s = (hipStream_t)stream;
+    const long long tot = (long long)N * Hi * Wi * C;
+    if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C))
+        hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(ew_blocks(tot / 4)), dim3(256), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+    else
+        hipLaunchKernelGGL((bilinear_bwd_kernel<1>), dim3(ew_blocks(tot)), dim3(256), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ softmax([scale*mask, s])[1:]
+#define SM_MAXC 8
+__global__ void softmax_md_fwd_kernel(const float* __restrict__ s, int lds_, const float* __restrict__ mask, float* __restrict__ out, int ldo,
+                                      long long P, int C, float scale) {
+    EW_LOOP(P) {
+        float l[SM_MAXC];
+        const float l0 = mask ? scale * mask[idx] : -INFINITY;
+        float mx = l0;
+        for (int c = 0; c < C; ++c) { l[c] = s[idx * lds_ + c]; mx = fmaxf(mx, l[c]); }
+        float den = mask ? expf(l0 - mx) : 0.f;
+        for (int c = 0; c < C; ++c) { l[c] = expf(l[c] - mx); den += l[c]; }
+        const float inv = 1.f / den;
+        for (int c = 0; c < C; ++c) out[idx * ldo + c] = l[c] * inv;
+    }
+}
+__global__ void softmax_md_bwd_kernel(const float* __restrict__ dout, int lddo, const float* __restrict__ out, int ldo, float* __restrict__ ds, int ldds,
+                                      long long P, int C) {
+    EW_LOOP(P) {
+        float o[SM_MAXC], d[SM_MAXC];
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) { o[c] = out[idx * ldo + c]; d[c] = dout[idx * lddo + c]; dot += o[c] * d[c]; }
+        for (int c = 0; c < C; ++c) ds[idx * ldds + c] = o[c] * (d[c] - dot);
+    }
+}
+extern "C" int mrdis_softmax_mask_drop_fwd(const float* s, int lds_, const float* mask_img, float* out, int ldo,
+                                           long long P, int C, float mask_scale, void* stream) {
+    if (!s || !out || P < 1 || C < 1 || C > SM_MAXC) return C > SM_MAXC ? MRDIS_EUNSUPPORTED : MRDIS_EINVAL;
+    hipLaunchKernelGGL(softmax_md_fwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, s, lds_, mask_img, out, ldo, P, C, mask_scale);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+extern "C" int mrdis_softmax_mask_drop_bwd(const float* dout, int lddo, const float* out, int ldo,
+                                           float* ds, int ldds, long long P, int C, void* stream) {
+    if (!dout || !out || !ds || P < 1 || C < 1 || C > SM_MAXC) return C > SM_MAXC ? MRDIS_EUNSUPPORTED : MRDIS_EINVAL;
+    hipLaunchKernelGGL(softmax_md_bwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out, ldo, ds, ldds, P, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ reconstruction error (per-sample mean)
+__global__ void recon_partial_kernel(const float* __restrict__ gt, int ldgt, const float* __restrict__ x, int ldx, long long HW, int C, int p,
+                                     int epb, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const long long tot = HW * C;
+    const long long e0 = (long long)chunk * epb;
+    long long e1 = e0 + epb; if (e1 > tot) e1 = tot;
+    float s = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const long long r = e / C; const int c = (int)(e - r * C);
+        const long long row = (long long)n * HW + r;
+        const float d = gt[row * ldgt + c] - x[row * ldx + c];
+        s += (p == 1) ? fabsf(d) : d * d;
+    }
+    s = mrdis_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long long)n * gridDim.x + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void recon_final_kernel(const float* __restrict__ part, int chunks, int N, double inv, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += (double)part[(long long)n * chunks + k];
+    out[n] = (float)(s * inv);
+}
+static int recon_chunks(int N, long long tot, int* epb) {
+    long long maxc = 4096 / (N > 0 ? N : 1); if (maxc < 1) maxc = 1;
+    long long chunks = (tot + 4095) / 4096; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
+    *epb = (int)((tot + chunks - 1) / chunks);
+    return (int)chunks;
+}
+extern "C" size_t mrdis_recon_err_workspace(int N, long long HW, int C) {
+    int epb; const int ch = recon_chunks(N, HW * C, &epb);
+    return sizeof(float) * (size_t)N * ch + 64;
+}
+extern "C" int mrdis_recon_err_fwd(const float* gt, int ldgt, const float* x, int ldx, float* out,
+                                   void* workspace, size_t workspace_bytes,
+                                   int N, long long HW, int C, int p, void* stream) {
+    if (!gt || !x || !out || !workspace || N < 1 || HW < 1 || C < 1 || (p != 1 && p != 2)) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_recon_err_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
+    int epb; const int ch = recon_chunks(N, HW * C, &epb);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(recon_partial_kernel, dim3(ch, N), dim3(256), 0, s, gt, ldgt, x, ldx, HW, C, p, epb, part);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(recon_final_kernel, dim3(mrdis_cdiv(N, 64)), dim3(64), 0, s, part, ch, N, 1.0 / ((double)HW * C), out);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+__global__ void recon_bwd_kernel(const float* __restrict__ gt, int ldgt, const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                 float* __restrict__ dx, int lddx, int N, long long HW, int C, int p, float inv) {
+    EW_LOOP((long long)N * HW * C) {
+        const long long r = idx / C; const int c = (int)(idx - r * C);
+        const int n = (int)(r / HW);
+        const float d = x[r * ldx + c] - gt[r * ldgt + c];
+        const float g = (p == 1) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+        dx[r * lddx + c] = w[n] * inv * g;
+    }
+}
+extern "C" int mrdis_recon_err_bwd(const float* gt, int ldgt, const float* x, int ldx, const float* w,
+                                   float* dx, int lddx, int N, long long HW, int C, int p, void* stream) {
+    if (!gt || !x || !w || !dx || N < 1 || HW < 1 || C < 1 || (p != 1 && p != 2)) return MRDIS_EINVAL;
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, gt, ldgt, x, ldx, w, dx, lddx,
+                       N, HW, C, p, (float)(1.0 / ((double)HW * C)));
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ max-pool k x k, stride k (floor)
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int32_t* __restrict__ arg, int N, int H, int W, int C,
+                                   int k, int Ho, int Wo) {
+    EW_LOOP((long long)N * Ho * Wo * C) {
+        const int c = (int)(idx % C); long long r = idx / C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho); const int n = (int)(r / Ho);
+        float best = -INFINITY; int bi = (ho * k) * W + wo * k;
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                const int pix = (ho * k + i) * W + (wo * k + j);
+                const float v = x[((long long)n * H * W + pix) * ldx + c];
+                if (v > best || v != v) { best = v; bi = pix; }       // first maximum wins (ATen scan order)
+            }
+        y[idx] = best; arg[idx] = bi;
+    }
+}
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx, int lddx, int N, int H, int W,
+                                   int C, int Ho, int Wo) {
+    EW_LOOP((long long)N * Ho * Wo * C) {
+        const int c = (int)(idx % C); const long long r = idx / C;
+        const int n = (int)(r / ((long long)Ho * Wo));
+        dx[((long long)n * H * W + arg[idx]) * lddx + c] = dy[idx];    // windows are disjoint: no atomics
+    }
+}
+extern "C" int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* argmax, int N, int H, int W, int C,
+                                 int k, void* stream) {
+    if (!x || !y || !argmax || N < 1 || C < 1 || k < 1 || H < k || W < k) return MRDIS_EINVAL;
+    const int Ho = H / k, Wo = W / k;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, argmax, N, H, W, C, k, Ho, Wo);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+extern "C" int mrdis_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int lddx, int N, int H, int W,
+                                 int C, int k, void* stream) {
+    if (!dy || !argmax || !dx || N < 1 || C < 1 || k < 1 || H < k || W < k) return MRDIS_EINVAL;
+    const int Ho = H / k, Wo = W / k;
+    hipStream_t s = (hipStream_t)stream;
+    // dx is a dense (N,H,W,C) view: zero it first (async, capture-safe)
+    if (lddx == C) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, s) != hipSuccess) return MRDIS_ELAUNCH; }
+    else return MRDIS_EUNSUPPORTED;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, s, dy, argmax, dx, lddx, N, H, W, C, Ho, Wo);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ optimizer arena
+__global__ void sumsq_finite_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+    __shared__ double red[4]; __shared__ float bad[4];
+    double s = 0.0; float nb = 0.f;
+    EW_LOOP(n) { const float v = g[idx]; if (!(fabsf(v) <= 3.402823466e38f)) nb += 1.f; else s += (double)v * (double)v; }
+    s = mrdis_wave_sum_d(s); nb = mrdis_wave_sum(nb);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; bad[threadIdx.x >> 6] = nb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        part[2 * blockIdx.x + 1] = (bad[0] + bad[1]) + (bad[2] + bad[3]);
+    }
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) { s += (double)part[2 * k]; b += (double)part[2 * k + 1]; }
+    out[0] += (float)s; out[1] += (float)b;
+}
+#define SUMSQ_BLOCKS 1024
+extern "C" size_t mrdis_sumsq_workspace(void) { return sizeof(float) * 2 * SUMSQ_BLOCKS; }
+extern "C" int mrdis_sumsq_finite(const float* g, long long n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !out || !workspace || n < 1) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_sumsq_workspace()) return MRDIS_EWORKSPACE;
+    int nb = ew_blocks(n); if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_finite_kernel, dim3(nb), dim3(256), 0, s, g, n, reinterpret_cast<float*>(workspace));
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float*>(workspace), nb, out);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// torch.optim.Adam(amsgrad=True, weight_decay=wd) single-tensor rule, fp32:
+//   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; vmax = max(vmax, v)
+//   p -= (lr / (1-b1^t)) * m / (sqrt(vmax)/sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
+                            long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sbc2,
+                            const float* __restrict__ norm_finite, float max_norm, float gscale) {
+    float coef = gscale;
+    if (norm_finite) {
+        if (norm_finite[1] > 0.f) return;                       // non-finite gradient: skip the step (main_missing.py:273-278)
+        if (max_norm > 0.f) {
+            const float tn = sqrtf(norm_finite[0]) * gscale;
+            const float cc = max_norm / (tn + 1e-6f);            // clip_grad_norm_ (main_missing.py:272)
+            coef = gscale * (cc < 1.f ? cc : 1.f);
+        }
+    }
+    const float step = lr / bc1;
+    EW_LOOP(n) {
+        const float pv = p[idx];
+        const float gv = g[idx] * coef + wd * pv;
+        const float mv = b1 * m[idx] + (1.f - b1) * gv;
+        const float vv = b2 * v[idx] + (1.f - b2) * gv * gv;
+        const float vm = fmaxf(vmax[idx], vv);
+        m[idx] = mv; v[idx] = vv; vmax[idx] = vm;
+        p[idx] = pv - step * mv / (sqrtf(vm) / sbc2 + eps);
+    }
+}
+extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
+                                       long long n, float lr, float beta1, float beta2, float eps,
+                                       float weight_decay, int step_count, const float* norm_finite,
+                                       float max_norm, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !vmax || n < 1 || step_count < 1) return MRDIS_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step_count);
+    const float sbc2 = sqrtf(1.f - powf(beta2, (float)step_count));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, sbc2, norm_finite, max_norm, grad_scale);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" const char* mrdis_strerror(int code) {
+    switch (code) {
+        case MRDIS_OK: return "ok";
+        case MRDIS_EINVAL: return "invalid argument";
+        case MRDIS_EUNSUPPORTED: return "unsupported geometry";
+        case MRDIS_EWORKSPACE: return "workspace too small";
+        case MRDIS_ELAUNCH: return "kernel launch failed";
+        case MRDIS_EALIGN: return "misaligned pointer or leading dimension";
+        default: return "unknown error";
+    }
+}
+extern "C" int mrdis_version(void) { return 100; }

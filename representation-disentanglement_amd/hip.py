@@ -1,0 +1,362 @@
+"""ctypes binding of libmrdis_hip.so (include/mrdis.h) for torch tensors.
+
+Plumbing only: torch owns device memory and the HIP stream; every function
+here turns tensors into (device pointer, leading dimension) views and
+enqueues the hand-written gfx950 kernels on torch's current stream.  There is
+NO fallback: if the shared library is missing, importing the product path on
+a GPU box fails loudly (`MrdisLibraryError`).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmrdis_hip.so')
+
+
+class MrdisLibraryError(RuntimeError):
+    pass
+
+
+class MrdisError(RuntimeError):
+    pass
+
+
+_lib = None
+_c = ctypes
+_P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float, _c.c_size_t
+
+_SIGS = {
+    'mrdis_strerror': (_c.c_char_p, [_I]),
+    'mrdis_version': (_I, []),
+    'mrdis_mix_experts_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_bwd_workspace': (_Z, [_I, _I, _I, _I]),
+    'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
+    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
+    'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
+    'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 9 + [_P]),
+    'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P]),
+    'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
+    'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _P]),
+    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _L, _I, _P]),
+    'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _P]),
+    'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
+    'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _P]),
+    'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 7 + [_P]),
+    'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 7 + [_P]),
+    'mrdis_softmax_mask_drop_fwd': (_I, [_P, _I, _P, _P, _I, _L, _I, _F, _P]),
+    'mrdis_softmax_mask_drop_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
+    'mrdis_recon_err_workspace': (_Z, [_I, _L, _I]),
+    'mrdis_recon_err_fwd': (_I, [_P, _I, _P, _I, _P, _P, _Z, _I, _L, _I, _I, _P]),
+    'mrdis_recon_err_bwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
+    'mrdis_maxpool_fwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mrdis_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mrdis_sumsq_workspace': (_Z, []),
+    'mrdis_sumsq_finite': (_I, [_P, _L, _P, _P, _Z, _P]),
+    'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def load(path=None):
+    """Load (once) and type the C-ABI library.  Raises MrdisLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MrdisLibraryError(
+            f'{path} not found: build it with `python __graft_entry__.py` / `make -C '
+            f'{os.path.dirname(path)}`.  There is no CPU or eager fallback for the hot path.')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted from include/mrdis.h
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise MrdisError(f'{what}: {load().mrdis_strerror(rc).decode()} ({rc})')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------- NHWC views
+def nhwc(t):
+    """(tensor, ld) for a logical (N,C,H,W) fp32 tensor whose memory is NHWC with pixel
+    stride ld (channels_last tensors and channel slices of them qualify as they are)."""
+    assert t.dim() == 4 and t.dtype == torch.float32, (t.shape, t.dtype)
+    N, C, H, W = t.shape
+    s = t.stride()
+    ld = s[3] if W > 1 else (s[2] if H > 1 else (s[0] if N > 1 else C))
+    ok = (ld >= C and (C == 1 or s[1] == 1) and (W == 1 or s[3] == ld) and
+          (H == 1 or s[2] == W * ld) and (N == 1 or s[0] == H * W * ld))
+    if not ok:
+        t = t.contiguous(memory_format=torch.channels_last)
+        if t.stride()[1] != 1 and C > 1:      # degenerate shapes: force a real NHWC copy
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        ld = C
+    return t, ld
+
+
+def empty_nhwc(N, C, H, W, device):
+    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+# ---------------------------------------------------------------- expert mixing
+def mix_experts_fwd(W, r):
+    """W (E,Co,Ci,kh,kw), r (E) -> (w_tck [T,Ci,Co], w_tkc [T,Co,Ci])."""
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); r = r.contiguous()
+    w_tck = torch.empty((T, Ci, Co), dtype=torch.float32, device=W.device)
+    w_tkc = torch.empty((T, Co, Ci), dtype=torch.float32, device=W.device)
+    _chk(lib.mrdis_mix_experts_fwd(_ptr(W), _ptr(r), _ptr(w_tck), _ptr(w_tkc), E, Co, Ci, T, _stream()), 'mix_experts_fwd')
+    return w_tck, w_tkc
+
+
+def mix_experts_bwd(dw_tck, W, r):
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); r = r.contiguous(); dw_tck = dw_tck.contiguous()
+    dW = torch.empty_like(W)
+    dr = torch.zeros(E, dtype=torch.float32, device=W.device)
+    nb = lib.mrdis_mix_experts_bwd_workspace(E, Co, Ci, T)
+    ws = _ws(nb, W.device)
+    _chk(lib.mrdis_mix_experts_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(dW), _ptr(dr), _ptr(ws), nb, E, Co, Ci, T, _stream()),
+         'mix_experts_bwd')
+    return dW, dr
+
+
+# ---------------------------------------------------------------- convolution
+def conv_out_hw(H, W, kh, kw, stride, pad):
+    return (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+
+
+def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None):
+    lib = load()
+    x, ldx = nhwc(x)
+    N, Ci, H, W = x.shape
+    T, Ci2, Co = w_tck.shape
+    assert T == kh * kw and Ci2 == Ci, (w_tck.shape, x.shape, kh, kw)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, stride, pad)
+    if out is None:
+        out = empty_nhwc(N, Co, Ho, Wo, x.device)
+    y, ldy = nhwc(out)
+    assert y.data_ptr() == out.data_ptr(), 'conv2d_fwd: `out` must already be an NHWC view'
+    _chk(lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
+                              1 if lrelu else 0, _stream()), 'conv2d_fwd')
+    return out
+
+
+def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad):
+    lib = load()
+    dy, lddy = nhwc(dy)
+    N, Co, Ho, Wo = dy.shape
+    T, Co2, Ci = w_tkc.shape
+    H, W = in_hw
+    assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
+    dx = empty_nhwc(N, Ci, H, W, dy.device)
+    _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad, _stream()),
+         'conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True):
+    lib = load()
+    x, ldx = nhwc(x)
+    dy, lddy = nhwc(dy)
+    N, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    dw = torch.empty((kh * kw, Ci, Co), dtype=torch.float32, device=x.device)
+    db = torch.empty(Co, dtype=torch.float32, device=x.device) if need_bias else None
+    nb = lib.mrdis_conv2d_bwd_weight_workspace(N, H, W, Ci, Co, kh, kw, stride, pad)
+    if nb == 0:
+        raise MrdisError('conv2d_bwd_weight: unsupported geometry')
+    ws = _ws(nb, x.device)
+    _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(db), _ptr(ws), nb, N, H, W, Ci, Co,
+                                     kh, kw, stride, pad, _stream()), 'conv2d_bwd_weight')
+    return dw, db
+
+
+def lrelu_bwd(dy, y, slope=0.2):
+    lib = load()
+    dy, lddy = nhwc(dy); y, ldy = nhwc(y)
+    N, C, H, W = y.shape
+    dx = empty_nhwc(N, C, H, W, y.device)
+    _chk(lib.mrdis_lrelu_bwd(_ptr(dy), lddy, _ptr(y), ldy, _ptr(dx), C, N * H * W, C, slope, _stream()), 'lrelu_bwd')
+    return dx
+
+
+# ---------------------------------------------------------------- norms
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=None):
+    lib = load()
+    x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    P = N * H * W
+    if out is None:
+        out = empty_nhwc(N, C, H, W, x.device)
+    y, ldy = nhwc(out)
+    assert y.data_ptr() == out.data_ptr()
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.mrdis_norm_workspace(1, P, C)
+    ws = _ws(nb, x.device)
+    _chk(lib.mrdis_bn_train_fwd(_ptr(x), ldx, _ptr(y), ldy, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _stream()), 'bn_train_fwd')
+    return out, mean, rstd
+
+
+def bn_train_bwd(dy, x, gamma, mean, rstd):
+    lib = load()
+    dy, lddy = nhwc(dy); x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    P = N * H * W
+    dx = empty_nhwc(N, C, H, W, x.device)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.mrdis_norm_workspace(1, P, C)
+    ws = _ws(nb, x.device)
+    _chk(lib.mrdis_bn_train_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), C, _ptr(dg), _ptr(db),
+                                _ptr(ws), nb, P, C, _stream()), 'bn_train_bwd')
+    return dx, dg, db
+
+
+def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
+    lib = load()
+    z, ldz = nhwc(z); gamma, ldg = nhwc(gamma); beta, ldb = nhwc(beta)
+    N, C, H, W = z.shape
+    out = empty_nhwc(N, C, H, W, z.device)
+    mean = torch.empty(N * C, dtype=torch.float32, device=z.device)
+    rstd = torch.empty(N * C, dtype=torch.float32, device=z.device)
+    nb = lib.mrdis_norm_workspace(N, H * W, C)
+    ws = _ws(nb, z.device)
+    _chk(lib.mrdis_instnorm_spade_fwd(_ptr(z), ldz, _ptr(gamma), ldg, _ptr(beta), ldb, _ptr(out), C, _ptr(mean), _ptr(rstd),
+                                      _ptr(ws), nb, N, H * W, C, eps, _stream()), 'instnorm_spade_fwd')
+    return out, mean, rstd
+
+
+def instnorm_spade_bwd(dout, z, gamma, mean, rstd):
+    """returns (dz, dgamma); dbeta == dout and is not materialised."""
+    lib = load()
+    dout, lddo = nhwc(dout); z, ldz = nhwc(z); gamma, ldg = nhwc(gamma)
+    N, C, H, W = z.shape
+    dz = empty_nhwc(N, C, H, W, z.device)
+    dg = empty_nhwc(N, C, H, W, z.device)
+    nb = lib.mrdis_instnorm_spade_bwd_workspace(N, H * W, C)
+    ws = _ws(nb, z.device)
+    _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
+                                      _ptr(dg), C, None, 0, _ptr(ws), nb, N, H * W, C, _stream()), 'instnorm_spade_bwd')
+    return dz, dg
+
+
+# ---------------------------------------------------------------- resize / softmax / losses
+def bilinear_fwd(x, out_hw, align_corners):
+    lib = load()
+    x, ldx = nhwc(x)
+    N, C, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    y = empty_nhwc(N, C, Ho, Wo, x.device)
+    _chk(lib.mrdis_bilinear_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _stream()), 'bilinear_fwd')
+    return y
+
+
+def bilinear_bwd(dy, in_hw, align_corners):
+    lib = load()
+    dy, lddy = nhwc(dy)
+    N, C, Ho, Wo = dy.shape
+    Hi, Wi = in_hw
+    dx = empty_nhwc(N, C, Hi, Wi, dy.device)
+    _chk(lib.mrdis_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _stream()), 'bilinear_bwd')
+    return dx
+
+
+def softmax_mask_drop_fwd(s, mask_img, scale=100.0):
+    lib = load()
+    s, lds = nhwc(s)
+    N, C, H, W = s.shape
+    out = empty_nhwc(N, C, H, W, s.device)
+    m = None if mask_img is None else mask_img.contiguous()
+    _chk(lib.mrdis_softmax_mask_drop_fwd(_ptr(s), lds, _ptr(m), _ptr(out), C, N * H * W, C, scale, _stream()), 'softmax_mask_drop_fwd')
+    return out
+
+
+def softmax_mask_drop_bwd(dout, out):
+    lib = load()
+    dout, lddo = nhwc(dout); out, ldo = nhwc(out)
+    N, C, H, W = out.shape
+    ds = empty_nhwc(N, C, H, W, out.device)
+    _chk(lib.mrdis_softmax_mask_drop_bwd(_ptr(dout), lddo, _ptr(out), ldo, _ptr(ds), C, N * H * W, C, _stream()), 'softmax_mask_drop_bwd')
+    return ds
+
+
+def recon_err_fwd(gt, x, p):
+    lib = load()
+    gt, ldgt = nhwc(gt); x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    nb = lib.mrdis_recon_err_workspace(N, H * W, C)
+    ws = _ws(nb, x.device)
+    _chk(lib.mrdis_recon_err_fwd(_ptr(gt), ldgt, _ptr(x), ldx, _ptr(out), _ptr(ws), nb, N, H * W, C, p, _stream()), 'recon_err_fwd')
+    return out
+
+
+def recon_err_bwd(gt, x, w, p):
+    lib = load()
+    gt, ldgt = nhwc(gt); x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    dx = empty_nhwc(N, C, H, W, x.device)
+    w = w.contiguous()
+    _chk(lib.mrdis_recon_err_bwd(_ptr(gt), ldgt, _ptr(x), ldx, _ptr(w), _ptr(dx), C, N, H * W, C, p, _stream()), 'recon_err_bwd')
+    return dx
+
+
+def maxpool_fwd(x, k):
+    lib = load()
+    x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, H // k, W // k, x.device)
+    arg = torch.empty((N, H // k, W // k, C), dtype=torch.int32, device=x.device)
+    _chk(lib.mrdis_maxpool_fwd(_ptr(x), ldx, _ptr(y), _ptr(arg), N, H, W, C, k, _stream()), 'maxpool_fwd')
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape, k):
+    lib = load()
+    N, C, H, W = in_shape
+    dy, lddy = nhwc(dy)
+    if lddy != C:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    dx = empty_nhwc(N, C, H, W, dy.device)
+    _chk(lib.mrdis_maxpool_bwd(_ptr(dy), _ptr(arg), _ptr(dx), C, N, H, W, C, k, _stream()), 'maxpool_bwd')
+    return dx
+
+
+# ---------------------------------------------------------------- optimizer arena
+def sumsq_finite(g, out):
+    lib = load()
+    nb = lib.mrdis_sumsq_workspace()
+    ws = _ws(nb, g.device)
+    _chk(lib.mrdis_sumsq_finite(_ptr(g), g.numel(), _ptr(out), _ptr(ws), nb, _stream()), 'sumsq_finite')
+
+
+def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, norm_finite, max_norm, grad_scale=1.0):
+    lib = load()
+    _chk(lib.mrdis_adam_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                     step, _ptr(norm_finite), max_norm, grad_scale, _stream()), 'adam_amsgrad_step')

@@ -1,0 +1,609 @@
+"""Host-side mirror of the reference's operator / module interface for the hot
+path (reference: src/model.py, cited per class).  Same class names, constructor
+arguments, `forward` signatures and state_dict keys/shapes as the reference, so
+`config.yaml`, a `main_missing.py`-style entry and checkpoints carry over; every
+convolution / norm / resize / softmax / loss reduction below executes in the
+hand-written gfx950 kernels of libmrdis_hip.so (see ops.py / hip.py).
+
+Reference quirks that parity depends on are reproduced and marked `QUIRK`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# =============================================================================
+# operator seam: model.py:2065-2120
+# =============================================================================
+class _routing(nn.Module):
+    """model.py:2065-2073."""
+
+    def __init__(self, in_channels, num_experts):
+        super().__init__()
+        self.fc = nn.Linear(in_channels, num_experts)
+
+    def forward(self, inputs_type):
+        return torch.sigmoid(self.fc(inputs_type))
+
+
+class CondConv2d(nn.Module):
+    """Drop-in for the reference CondConv2d (model.py:2075-2117).
+
+    forward(inputs (B,Cin,H,W), inputs_type (B,embeddings)) -> (B,Cout,H',W').
+    Parameters: weight (E,Cout,Cin,kh,kw), bias (Cout), _routing_fn.fc.{weight,bias}.
+
+    When `inputs_type` is provably constant over the batch (a stride-0 expand of
+    one row -- what every call site of the reference amounts to, model.py:3138,
+    3169, 3190, 3211) the experts are mixed ONCE and one batched conv runs;
+    otherwise the per-sample path of the reference is taken (one mix + one
+    batch-1 conv per sample).  Both are the same arithmetic.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 embeddings=1, bias=True, padding_mode='zeros', num_experts=3, dropout_rate=0):
+        super().__init__()
+        if _pair(dilation) != (1, 1) or groups != 1 or padding_mode != 'zeros':
+            raise NotImplementedError('mrdis CondConv2d covers dilation=1, groups=1, zero padding (all the path uses)')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        if self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError('square stride / padding only')
+        self.num_experts = num_experts
+        # identical RNG consumption to the reference constructor (model.py:2083-2097)
+        burn = nn.Conv2d(in_channels, out_channels, self.kernel_size, stride, padding)
+        self._routing_fn = _routing(embeddings, num_experts)
+        self.weight = nn.Parameter(torch.empty(num_experts, out_channels, in_channels, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        del burn
+        nn.init.xavier_normal_(self.weight)
+        if bias:
+            nn.init.constant_(self.bias, 0)
+
+    def _mixed(self, t_row):
+        """t_row: (1, embeddings) -> (w_tck, w_tkc) for that type."""
+        r = torch.sigmoid(F.linear(t_row, self._routing_fn.fc.weight, self._routing_fn.fc.bias))[0]
+        return ops.mix_experts(self.weight, r)
+
+    def forward(self, inputs, inputs_type, lrelu=False):
+        kh, kw = self.kernel_size
+        B = inputs.shape[0]
+        if B == 1 or inputs_type.stride(0) == 0:
+            key = (id(self), inputs_type.data_ptr(), inputs_type._version)
+            w_tck, w_tkc = ops.cached_mix(key, lambda: self._mixed(inputs_type[:1]))
+            return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
+        outs = []                                    # per-sample path, model.py:2114-2117
+        for i in range(B):
+            w_tck, w_tkc = self._mixed(inputs_type[i:i + 1])
+            outs.append(ops.conv2d(inputs[i:i + 1], w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu))
+        return torch.cat(outs, 0)
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d whose forward/backward run in the HIP kernels (discriminator,
+    model.py:2773-2789).  Keeps nn.Conv2d's parameters, init and state_dict."""
+
+    def forward(self, x, lrelu=False):
+        if self.dilation != (1, 1) or self.groups != 1 or self.padding_mode != 'zeros':
+            raise NotImplementedError
+        kh, kw = self.kernel_size
+        one = torch.ones(1, dtype=torch.float32, device=x.device)
+        w_tck, w_tkc = ops.cached_mix((id(self), 0, 0), lambda: ops.mix_experts(self.weight.unsqueeze(0), one))
+        return ops.conv2d(x, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
+
+
+def Conv2d(is_cond):
+    """model.py:2119-2120 -- the plug point every block goes through."""
+    return CondConv2d if is_cond else HipConv2d
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d; training-mode forward/backward in HIP."""
+
+    def forward(self, x):
+        if self.training:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                        self.eps, self.momentum)
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
+
+
+def expand_type(value, batch, device):
+    """(B,1) modality label, constant over the batch, as a stride-0 expand so CondConv2d can
+    prove it (the reference builds (1+i)*ones(B,1), model.py:3138)."""
+    return torch.full((1, 1), float(value), dtype=torch.float32, device=device).expand(batch, 1)
+
+
+# =============================================================================
+# anatomy U-Net: model.py:2122-2195, 2218-2245, 2271-2296
+# =============================================================================
+class Conv_BN_Act_New(nn.Module):
+    """model.py:2122-2153.  QUIRK: the if/if/if-else chain (:2134-2141) makes `act`
+    the identity for 'lrelu'/'relu' (only 'elu' survives)."""
+
+    def __init__(self, in_num_ch, out_num_ch, filter_size=4, stride=2, padding=1, activation='lrelu', is_bn=True, is_cond=False):
+        super().__init__()
+        self.is_bn, self.is_cond = is_bn, is_cond
+        self.conv = Conv2d(is_cond)(in_num_ch, out_num_ch, filter_size, stride, padding=padding)
+        if is_bn:
+            self.bn = BatchNorm2d(out_num_ch)
+        self.act = nn.ELU(inplace=True) if activation == 'elu' else nn.Sequential()
+
+    def forward(self, x, inputs_type=None):
+        x = self.conv(x, inputs_type) if self.is_cond else self.conv(x)
+        if self.is_bn:
+            x = self.bn(x)
+        return self.act(x)
+
+
+class Act_Deconv_BN_Concat_New(nn.Module):
+    """model.py:2155-2195.  identity act (same QUIRK) -> bilinear x2 align_corners=True ->
+    conv3x3 -> [BN -> cat(skip)]; `bn` is created even when is_last (:2179)."""
+
+    def __init__(self, in_num_ch, out_num_ch, filter_size=3, stride=1, padding=1, activation='relu', upsample=True,
+                 is_last=False, is_bn=True, is_cond=False):
+        super().__init__()
+        if not upsample:
+            raise NotImplementedError('ConvTranspose2d variant is not on the path (model.py:2178)')
+        self.is_bn, self.is_cond, self.is_last = is_bn, is_cond, is_last
+        self.act = nn.ELU(inplace=True) if activation == 'elu' else nn.Sequential()
+        self.conv = Conv2d(is_cond)(in_num_ch, out_num_ch, filter_size, stride, padding=padding)
+        self.bn = BatchNorm2d(out_num_ch)
+
+    def forward(self, x_down, x_up, inputs_type=None):
+        x_up = self.act(x_up)
+        x_up = ops.bilinear(x_up, (2 * x_up.shape[2], 2 * x_up.shape[3]), True)
+        x_up = self.conv(x_up, inputs_type) if self.is_cond else self.conv(x_up)
+        if self.is_last:
+            return x_up
+        if self.is_bn:
+            x_up = self.bn(x_up)
+        return torch.cat([x_down, x_up], 1)
+
+
+class AnatomyEncoderEncNew(nn.Module):
+    """model.py:2218-2245."""
+
+    def __init__(self, in_num_ch=7, first_num_ch=32, is_cond=False):
+        super().__init__()
+        self.is_cond = is_cond
+        c = first_num_ch
+        self.down_1 = Conv2d(is_cond)(in_num_ch, c, 4, 2, padding=1)
+        self.act_1 = nn.LeakyReLU(0.2, inplace=True)          # fused into down_1's epilogue
+        self.down_2 = Conv_BN_Act_New(c, 2 * c, is_cond=is_cond)
+        self.down_3 = Conv_BN_Act_New(2 * c, 4 * c, is_cond=is_cond)
+        self.down_4 = Conv_BN_Act_New(4 * c, 8 * c, is_cond=is_cond)
+        self.down_5 = Conv_BN_Act_New(8 * c, 8 * c, activation='no', is_cond=is_cond)
+
+    def forward(self, x, inputs_type=None):
+        d1 = self.down_1(x, inputs_type, lrelu=True) if self.is_cond else self.down_1(x, lrelu=True)
+        d2 = self.down_2(d1, inputs_type)
+        d3 = self.down_3(d2, inputs_type)
+        d4 = self.down_4(d3, inputs_type)
+        d5 = self.down_5(d4, inputs_type)
+        return [d1, d2, d3, d4, d5]
+
+
+class AnatomyEncoderDecNew(nn.Module):
+    """model.py:2271-2296."""
+
+    def __init__(self, first_num_ch=32, out_num_ch=8, output_act='softmax', is_cond=False):
+        super().__init__()
+        c = first_num_ch
+        self.up_4 = Act_Deconv_BN_Concat_New(8 * c, 8 * c, is_cond=is_cond)
+        self.up_3 = Act_Deconv_BN_Concat_New(16 * c, 4 * c, is_cond=is_cond)
+        self.up_2 = Act_Deconv_BN_Concat_New(8 * c, 2 * c, is_cond=is_cond)
+        self.up_1 = Act_Deconv_BN_Concat_New(4 * c, c, is_cond=is_cond)
+        self.output = Act_Deconv_BN_Concat_New(2 * c, out_num_ch, is_last=True, is_cond=is_cond)
+
+    def forward(self, down_list, inputs_type=None):
+        if inputs_type is None:
+            inputs_type = expand_type(1.0, down_list[0].shape[0], down_list[0].device)   # :2286-2287
+        u4 = self.up_4(down_list[3], down_list[4], inputs_type)
+        u3 = self.up_3(down_list[2], u4, inputs_type)
+        u2 = self.up_2(down_list[1], u3, inputs_type)
+        u1 = self.up_1(down_list[0], u2, inputs_type)
+        out = self.output(None, u1, inputs_type)
+        return out, out
+
+
+# =============================================================================
+# modality encoder: model.py:2332-2400
+# =============================================================================
+class ModalityEncoderNew(nn.Module):
+    """model.py:2332-2400.  `convs` is dead code that still owns parameters and
+    state_dict keys (:2346-2357).  `feat_hw` generalises the hard-coded 5*6
+    (:2360, :2396) to (H/32)*(W/32); 30 reproduces the reference."""
+
+    def __init__(self, img_num_ch=7, s_num_ch=8, first_num_ch=16, z_size=16, is_cond=False, feat_hw=30):
+        super().__init__()
+        self.s_num_ch, self.is_cond = s_num_ch, is_cond
+        c = first_num_ch
+        ch = [img_num_ch + s_num_ch, c, 2 * c, 4 * c, 8 * c, 8 * c]
+        conv2d = Conv2d(is_cond)
+        for i in range(5):
+            setattr(self, f'conv{i + 1}', conv2d(ch[i], ch[i + 1], 3, 2, padding=1))
+        dead = []
+        for i in range(5):
+            dead += [nn.Conv2d(ch[i], ch[i + 1], 3, 2, padding=1), nn.LeakyReLU(0.2, inplace=True)]
+        self.convs = nn.Sequential(*dead)
+        self.fcs = nn.Sequential(nn.Linear(feat_hw * 8 * c, 2 * z_size), nn.LeakyReLU(0.2, inplace=True))
+        self.mean = nn.Linear(2 * c, z_size)
+        self.log_var = nn.Linear(2 * c, z_size)
+
+    def forward(self, xi, si, inputs_type=None):
+        x = xi if self.s_num_ch == 0 else torch.cat([xi, si], 1)
+        for i in range(5):
+            conv = getattr(self, f'conv{i + 1}')
+            x = conv(x, inputs_type, lrelu=True) if self.is_cond else conv(x, lrelu=True)   # :2374-2383
+        # `view(-1, 5*6*128)` flattens NCHW order (:2396): make that order physical (tiny tensor)
+        x = x.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1)
+        x = self.fcs(x)
+        return self.mean(x), self.log_var(x)
+
+
+# =============================================================================
+# SPADE decoder: model.py:2424-2454, 2540-2632
+# =============================================================================
+class SPADEBlockNew(nn.Module):
+    """model.py:2424-2454."""
+
+    def __init__(self, input_size, in_num_ch=128, out_num_ch=128, s_num_ch=8, is_cond=False):
+        super().__init__()
+        self.is_cond, self.input_size = is_cond, tuple(input_size)
+        conv2d = Conv2d(is_cond)
+        self.zi_layers = nn.InstanceNorm2d(in_num_ch)     # parameter-free; fused with the modulation
+        self.si_layers = conv2d(s_num_ch, in_num_ch, 3, 1, padding=1)
+        self.gamma = conv2d(in_num_ch, in_num_ch, 3, 1, padding=1)
+        self.beta = conv2d(in_num_ch, in_num_ch, 3, 1, padding=1)
+        self.out = conv2d(in_num_ch, out_num_ch, 3, 1, padding=1)
+
+    def forward(self, si, zi, inputs_type=None):
+        si = ops.bilinear(si, self.input_size, False)                     # :2432/:2441
+        t = (inputs_type,) if self.is_cond else ()
+        si_out = self.si_layers(si, *t)
+        gamma = self.gamma(si_out, *t)
+        beta = self.beta(si_out, *t)
+        mix = ops.instnorm_spade(zi, gamma, beta, self.zi_layers.eps)     # :2440 + :2446
+        return self.out(mix, *t)
+
+
+def _up2(x):
+    """nn.Upsample(scale_factor=(2,2), mode='bilinear')  (model.py:2551)."""
+    return ops.bilinear(x, (2 * x.shape[2], 2 * x.shape[3]), False)
+
+
+class SPADENewShared(nn.Module):
+    """model.py:2540-2582.  QUIRK: `up2` is reused for the third upsample (:2573) -- no effect."""
+
+    def __init__(self, image_size=(192, 160), in_num_ch=7, z_size=16, z_num_ch=128, s_num_ch=8, is_cond=False):
+        super().__init__()
+        self.z_num_ch, self.image_size, self.is_cond = z_num_ch, tuple(image_size), is_cond
+        H, W = image_size
+        self.zi_scaler = nn.Linear(z_size, H * W * z_num_ch // 1024)
+        self.sp1 = SPADEBlockNew((H // 32, W // 32), z_num_ch, z_num_ch, s_num_ch, is_cond)
+        self.sp2 = SPADEBlockNew((H // 16, W // 16), z_num_ch, z_num_ch, s_num_ch, is_cond)
+        self.sp3 = SPADEBlockNew((H // 8, W // 8), z_num_ch, z_num_ch, s_num_ch, is_cond)
+
+    def forward(self, si, zi, inputs_type=None):
+        H, W = self.image_size
+        x = self.zi_scaler(zi).reshape(-1, self.z_num_ch, H // 32, W // 32)
+        x = self.sp1(si, x, inputs_type)
+        x = self.sp2(si, _up2(x), inputs_type)
+        x = self.sp3(si, _up2(x), inputs_type)
+        return _up2(x)
+
+
+class SPADENewNotShared(nn.Module):
+    """model.py:2584-2632."""
+
+    def __init__(self, image_size=(192, 160), in_num_ch=7, z_size=16, z_num_ch=128, s_num_ch=8, is_cond=False,
+                 output_activation='softplus'):
+        super().__init__()
+        self.is_cond = is_cond
+        H, W = image_size
+        self.sp4 = SPADEBlockNew((H // 4, W // 4), z_num_ch, z_num_ch // 2, s_num_ch, is_cond)
+        self.sp5 = SPADEBlockNew((H // 2, W // 2), z_num_ch // 2, z_num_ch // 4, s_num_ch, is_cond)
+        self.sp6 = SPADEBlockNew((H, W), z_num_ch // 4, z_num_ch // 8, s_num_ch, is_cond)
+        self.out = Conv2d(is_cond)(z_num_ch // 8, in_num_ch, 1, 1)
+        if output_activation == 'softplus':
+            self.out_act = nn.Softplus()
+        elif output_activation == 'no':
+            self.out_act = nn.Sequential()
+        else:
+            raise ValueError('No activation in SPADENotShared')
+
+    def forward(self, si, zi_sp4_input, inputs_type=None):
+        x = self.sp4(si, zi_sp4_input, inputs_type)
+        x = self.sp5(si, _up2(x), inputs_type)
+        x = self.sp6(si, _up2(x), inputs_type)
+        x = self.out(x, inputs_type) if self.is_cond else self.out(x)
+        return self.out_act(x)
+
+
+# =============================================================================
+# discriminator: model.py:2769-2800
+# =============================================================================
+class Discriminator(nn.Module):
+    """model.py:2769-2800: 5x (conv4x4 s2 [+BN] + LeakyReLU 0.2) + dense or PatchGAN head.
+    state_dict keys match the reference's nn.Sequential indices."""
+
+    def __init__(self, in_num_ch=8, inter_num_ch=16, input_shape=(160, 192), is_patch_gan=False):
+        super().__init__()
+        c = inter_num_ch
+        L = [HipConv2d(in_num_ch, c, 4, 2, padding=1), nn.LeakyReLU(0.2)]
+        for a, b in ((c, 2 * c), (2 * c, 4 * c), (4 * c, 8 * c), (8 * c, 4 * c)):
+            L += [HipConv2d(a, b, 4, 2, padding=1), BatchNorm2d(b), nn.LeakyReLU(0.2)]
+        self.discrim = nn.Sequential(*L)
+        self.is_patch_gan = is_patch_gan
+        if is_patch_gan:
+            self.fc = HipConv2d(4 * c, 1, 3, 1, padding=1)
+        else:
+            self.fc = nn.Sequential(
+                nn.Flatten(),
+                nn.Linear(int(input_shape[0] * input_shape[1] * 4 * c / (32 * 32)), c * 16),
+                nn.LeakyReLU(0.2),
+                nn.Linear(c * 16, 1))
+
+    def forward(self, x):
+        mods = list(self.discrim)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, HipConv2d) and isinstance(mods[i + 1], nn.LeakyReLU):
+                x = m(x, lrelu=True); i += 2                      # conv + fused LeakyReLU
+            else:
+                x = m(x); i += 1
+        if self.is_patch_gan:
+            return self.fc(x)
+        # nn.Flatten flattens NCHW order: make it physical before the Linear (tiny tensor)
+        return self.fc(x.contiguous(memory_format=torch.contiguous_format))
+
+
+# =============================================================================
+# orchestration + losses: model.py:2916-2970, 3086-3224, 3260-3587
+# =============================================================================
+class MultimodalModel(nn.Module):
+    """model.py:2916-3587 for the configuration the reference ships
+    (config.yaml: is_cond, shared_ana_enc, shared_mod_enc, shared_inp_dec=False,
+    mod_enc_s=False, softmax_remove_mask, 'max' compaction, cosine similarities).
+    Method names and argument order follow the reference."""
+
+    def __init__(self, input_size=(160, 192), modality_num=4, in_num_ch=7, out_num_ch=1, s_num_ch=8, z_size=16,
+                 is_discrim_s=False, is_distri_z=False, shared_ana_enc=False, shared_mod_enc=True, shared_inp_dec=True,
+                 s_compact_method='max', s_sim_method='cosine', z_sim_method='cosine', is_cond=True,
+                 input_output_act='softplus', target_output_act='softplus', target_model_name='U', fuse_method='mean',
+                 device=torch.device('cuda:0'), others=None, is_patch_gan=False):
+        super().__init__()
+        others = dict(others or {'mod_enc_s': True, 'ana_dec_act': 'softmax'})
+        others.setdefault('old', False)
+        if others['old'] or is_distri_z or shared_inp_dec or s_compact_method != 'max' or \
+                s_sim_method != 'cosine' or z_sim_method != 'cosine' or others.get('mod_enc_s', True) or \
+                others.get('ana_dec_act', 'softmax') != 'softmax' or not others.get('softmax_remove_mask', False):
+            raise NotImplementedError('only the shipped config.yaml graph is built (SURVEY.md section 8a); '
+                                      'got a variant that the hot path does not cover')
+        H, W = input_size
+        if H % 32 or W % 32:
+            raise ValueError(f'input_size {input_size} must be a multiple of 32 (five stride-2 stages, model.py:2192)')
+        self.input_size, self.modality_num, self.in_num_ch = tuple(input_size), modality_num, in_num_ch
+        self.device, self.others, self.is_cond = device, others, is_cond
+        self.shared_ana_enc, self.shared_mod_enc = shared_ana_enc, shared_mod_enc
+        n_ana = 1 if shared_ana_enc else modality_num
+        self.anatomy_encoder_enc_list = nn.ModuleList(
+            [AnatomyEncoderEncNew(in_num_ch, 32, is_cond) for _ in range(n_ana)])                 # :3086-3100
+        self.anatomy_encoder_dec = AnatomyEncoderDecNew(32, s_num_ch, is_cond=is_cond)
+        n_mod = 1 if shared_mod_enc else modality_num
+        self.modality_encoder_list = nn.ModuleList(
+            [ModalityEncoderNew(in_num_ch, 0, 16, z_size, is_cond, (H // 32) * (W // 32)) for _ in range(n_mod)])  # :3102-3112
+        dec = [SPADENewNotShared((H, W), in_num_ch, z_size, 128, s_num_ch, is_cond, input_output_act)
+               for _ in range(modality_num)]
+        dec.append(SPADENewShared((H, W), in_num_ch, z_size, 128, s_num_ch, is_cond))            # :3129-3131
+        self.input_decoder_list = nn.ModuleList(dec)
+        # output_decoder (lambda_recon_y = 0, config.yaml:27-28) is outside the hot path: not built.
+        if is_discrim_s:
+            self.discrim_s = Discriminator(s_num_ch, 16, (H, W), is_patch_gan)                    # :2966-2967
+        self.to(device)
+        self._types = {}
+
+    # ---- helpers
+    def _type(self, i, B):
+        key = (i, B)
+        t = self._types.get(key)
+        if t is None:
+            t = self._types[key] = expand_type(1 + i, B, self.device)
+        return t
+
+    # ---- model.py:3135-3157
+    def compute_anatomy_encoding(self, inputs_list, mask_img):
+        si_list = []
+        B = inputs_list[0].shape[0]
+        for i in range(self.modality_num):
+            t = self._type(i, B)
+            enc = self.anatomy_encoder_enc_list[0 if self.shared_ana_enc else i]
+            feats = enc(inputs_list[i], t)
+            si, _ = self.anatomy_encoder_dec(feats, t)
+            si_list.append(ops.softmax_mask_drop(si, mask_img, 100.0))                           # :3150-3153
+        return si_list
+
+    # ---- model.py:3159-3162: eps is drawn from the CPU generator, then moved
+    def sample(self, z_mean, z_log_var):
+        eps = torch.normal(0, 1, size=(z_mean.shape[0], z_mean.shape[1])).to(self.device, non_blocking=True)
+        return z_mean + eps * torch.exp(0.5 * z_log_var)
+
+    # ---- model.py:3164-3185
+    def compute_modality_encoding(self, inputs_list, si_list, phase='train'):
+        zi_list, mu_list, lv_list = [], [], []
+        B = inputs_list[0].shape[0]
+        for i in range(self.modality_num):
+            t = self._type(i, B)
+            enc = self.modality_encoder_list[0 if self.shared_mod_enc else i]
+            mu, lv = enc(inputs_list[i], si_list[i] if si_list is not None else None, t)
+            zi_list.append(self.sample(mu, lv) if phase == 'train' else mu)
+            mu_list.append(mu); lv_list.append(lv)
+        return zi_list, mu_list, lv_list
+
+    # ---- model.py:3187-3203
+    def reconstruct_input_si_zi(self, si_list, zi_list):
+        out = []
+        B = si_list[0].shape[0]
+        for i in range(self.modality_num):
+            t = self._type(i, B)
+            mid = self.input_decoder_list[-1](si_list[i], zi_list[i], t)
+            out.append(self.input_decoder_list[i](si_list[i], mid, t))
+        return out
+
+    # ---- model.py:3205-3224: decoder index i, type j, z_j
+    def reconstruct_input_si_zj(self, si_list, zi_list):
+        out = []
+        B = si_list[0].shape[0]
+        for i in range(self.modality_num):
+            for j in range(self.modality_num):
+                if i == j:
+                    continue
+                t = self._type(j, B)
+                mid = self.input_decoder_list[-1](si_list[i], zi_list[j], t)
+                out.append(self.input_decoder_list[i](si_list[i], mid, t))
+        return out
+
+    # ---------------------------------------------------------------- losses
+    # The reference branches on `mask[:, i].sum() == 0` on the device (a host sync per branch,
+    # SURVEY 0-8).  `mask` arrives from the loader on the host anyway, so callers pass the host
+    # copy (`mask_host`, a CPU tensor or ndarray) next to the device copy and the branches are
+    # decided without touching the GPU.
+    def compute_recon_loss(self, gt, output, p=2):                                               # :3260-3266
+        return ops.recon_err(gt, output, p)
+
+    def compute_recon_loss_x_list(self, gt_list, x_list, mask, p=2, mask_host=None):             # :3315-3325
+        mh = _host_mask(mask, mask_host)
+        loss, idx = torch.zeros((), device=self.device), 0
+        for i in range(len(x_list)):
+            if mh[:, i].sum() == 0:
+                continue
+            idx += 1
+            loss = loss + (mask[:, i] * self.compute_recon_loss(gt_list[i], x_list[i], p)).sum() / float(mh[:, i].sum())
+        return loss if idx == 0 else loss / idx
+
+    def compute_recon_loss_x_mix_list(self, gt_list, x_list, mask, p=2, mask_host=None):         # :3327-3341
+        mh = _host_mask(mask, mask_host)
+        loss, idx = torch.zeros((), device=self.device), 0
+        M = mh.shape[1]
+        for i in range(M):
+            for j in range(M):
+                if i == j:
+                    continue
+                mm_h = mh[:, i] * mh[:, j]
+                if mm_h.sum() == 0:
+                    continue
+                mm = mask[:, i] * mask[:, j]
+                # QUIRK (:3337-3338): x_list is indexed by a counter that only advances on non-empty pairs
+                loss = loss + (mm * self.compute_recon_loss(gt_list[j], x_list[idx], p)).sum() / float(mm_h.sum())
+                idx += 1
+        return loss if idx == 0 else loss / idx
+
+    def compute_latent_z_loss(self, zi_mean_list, zi_mean_list_new, mask, mask_host=None):       # :3384-3394
+        mh = _host_mask(mask, mask_host)
+        loss, idx = torch.zeros((), device=self.device), 0
+        for i in range(len(zi_mean_list)):
+            if mh[:, i].sum() == 0:
+                continue
+            idx += 1
+            loss = loss + (mask[:, i].unsqueeze(1) * torch.abs(zi_mean_list[i] - zi_mean_list_new[i])).sum() / float(mh[:, i].sum())
+        return loss if idx == 0 else loss / idx
+
+    def compute_cosine(self, x, y):                                                              # :3407-3415
+        xn = torch.sqrt(torch.sum(x * x, 1) + 1e-8).clamp_min(1e-8)
+        yn = torch.sqrt(torch.sum(y * y, 1) + 1e-8).clamp_min(1e-8)
+        return torch.sum(x * y, 1) / (xn * yn)
+
+    def compute_compact_s(self, x):                                                              # :3448-3451
+        # view(B,-1) of the NCHW-logical pooled map: (C, H/16, W/16) order
+        p = ops.max_pool(x, 16)
+        return p.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1)
+
+    def compute_similarity_s_loss(self, si_list, mask, margin=0.1, mask_host=None):              # :3478-3513
+        mh = _host_mask(mask, mask_host)
+        loss = torch.zeros((), device=self.device)
+        if len(si_list) == 1:
+            return loss
+        if len(si_list) == 2:
+            i, j = 0, 1
+        else:
+            sel = np.random.choice(len(si_list), 2, replace=False)                               # host RNG, :3485
+            i, j = int(sel[0]), int(sel[1])
+        mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
+        mm_h = mh[:, i] * mh[:, j] * mperm_h
+        if mm_h.sum() > 0:
+            mm = mask[:, i] * mask[:, j] * torch.cat([mask[1:, i], mask[0:1, i]], 0)
+            si_c = self.compute_compact_s(si_list[i])
+            sj_c = self.compute_compact_s(si_list[j])
+            # compact(roll(s_i)) == roll(compact(s_i)): pooling is per-sample
+            si_perm_c = torch.cat([si_c[1:], si_c[0:1]], 0)
+            sim = self.compute_cosine(si_c, sj_c)
+            sim_mix = self.compute_cosine(si_perm_c, si_c)
+            return (mm * torch.clamp_min(margin - sim + sim_mix, 0)).sum() / float(mm_h.sum())
+        return loss                                                                              # reference returns int 0 (:3512)
+
+    def compute_similarity_z_loss(self, zi_list, mask, margin=0.1, mask_host=None):              # :3537-3557
+        mh = _host_mask(mask, mask_host)
+        loss, idx = torch.zeros((), device=self.device), 0
+        if len(zi_list) == 1:
+            return loss
+        for i in range(len(zi_list) - 1):
+            zi = zi_list[i]
+            zp = torch.cat([zi[1:], zi[0:1]], 0)
+            mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
+            for j in range(i + 1, len(zi_list)):
+                mm_h = mh[:, i] * mh[:, j] * mperm_h
+                if mm_h.sum() == 0:
+                    continue
+                idx += 1
+                mm = mask[:, i] * mask[:, j] * torch.cat([mask[1:, i], mask[0:1, i]], 0)
+                cosine = self.compute_cosine(zi, zi_list[j])
+                cosine_mix = self.compute_cosine(zi, zp)
+                loss = loss + (mm * torch.clamp_min(margin - cosine_mix + cosine, 0)).sum() / float(mm_h.sum())
+        return loss if idx == 0 else loss / idx
+
+    def compute_adversarial_loss(self, si_list, mask, mask_host=None):                           # :3559-3587
+        mh = _host_mask(mask, mask_host)
+        if len(si_list) == 2:
+            i, j = 0, 1
+        else:
+            sel = np.random.choice(len(si_list), 2, replace=False)
+            i, j = int(sel[0]), int(sel[1])
+        d0 = self.discrim_s(si_list[i]).squeeze(1)
+        d1 = self.discrim_s(si_list[j]).squeeze(1)
+        bce = lambda d, tgt: F.binary_cross_entropy_with_logits(d, tgt, reduction='none')
+        zero = torch.zeros((), device=self.device)
+
+        def wmean(m, mhc, v):
+            m = m.reshape((-1,) + (1,) * (v.dim() - 1)) if v.dim() > 1 else m
+            return (m * v).sum() / float(mhc.sum())
+        if mh[:, i].sum() == 0:
+            dl0 = gl0 = zero
+        else:
+            dl0 = wmean(mask[:, i], mh[:, i], bce(d0, torch.zeros_like(d0)))
+            gl0 = wmean(mask[:, i], mh[:, i], bce(d0, torch.ones_like(d0)))
+        if mh[:, j].sum() == 0:
+            dl1 = gl1 = zero
+        else:
+            dl1 = wmean(mask[:, j], mh[:, j], bce(d1, torch.ones_like(d1)))
+            gl1 = wmean(mask[:, j], mh[:, j], bce(d1, torch.ones_like(d1)))                      # QUIRK (sic) :3580
+        return 0.5 * (dl0 + dl1), 0.5 * (gl0 + gl1)
+
+
+def _host_mask(mask, mask_host):
+    if mask_host is None:
+        mask_host = mask.detach().cpu()        # one sync; pass mask_host to avoid it
+    if isinstance(mask_host, torch.Tensor):
+        mask_host = mask_host.numpy()
+    return np.asarray(mask_host, dtype=np.float32)

@@ -1,0 +1,228 @@
+"""Autograd surface of the HIP hot path, plus `torch.ops.mrdis.*` registrations.
+
+Each Function is a thin pairing of a forward and a backward entry point of
+libmrdis_hip.so (include/mrdis.h); there is no arithmetic here.  Tensors stay
+logically NCHW (reference interface) and physically NHWC (channels_last).
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+
+# --------------------------------------------------------------------------- expert mixing
+class _MixExperts(Function):
+    """model.py:2111-2113: kernel = sum_e r[e] * W[e]; emits both conv layouts."""
+
+    @staticmethod
+    def forward(ctx, W, r):
+        w_tck, w_tkc = hip.mix_experts_fwd(W, r)
+        ctx.save_for_backward(W, r)
+        ctx.mark_non_differentiable(w_tkc)
+        return w_tck, w_tkc
+
+    @staticmethod
+    def backward(ctx, g_tck, _g_tkc):
+        W, r = ctx.saved_tensors
+        dW, dr = hip.mix_experts_bwd(g_tck, W, r)
+        return dW, dr
+
+
+def mix_experts(W, r):
+    return _MixExperts.apply(W, r)
+
+
+# --------------------------------------------------------------------------- convolution
+class _Conv2d(Function):
+    """F.conv2d (model.py:2104) with optional fused LeakyReLU(0.2) epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
+        y = hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu)
+        ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3], bias is not None)
+        ctx.save_for_backward(x, w_tkc, y if lrelu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kh, kw, stride, pad, lrelu, H, W, has_bias = ctx.geom
+        x, w_tkc, y = ctx.saved_tensors
+        if lrelu:
+            dy = hip.lrelu_bwd(dy, y, 0.2)
+        dx = hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
+            dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=has_bias)
+        return dx, dw, None, db, None, None, None, None, None
+
+
+def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
+    return _Conv2d.apply(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
+
+
+# --------------------------------------------------------------------------- norms
+class _BatchNormTrain(Function):
+    """nn.BatchNorm2d in training mode (model.py:2151, 2191, 2776-2785)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum):
+        y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = hip.bn_train_bwd(dy, x, gamma, mean, rstd)
+        return dx, dg, db, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum)
+
+
+class _InstNormSpade(Function):
+    """InstanceNorm2d(z) * (1 + gamma) + beta  (model.py:2440, 2446)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps):
+        out, mean, rstd = hip.instnorm_spade_fwd(z, gamma, beta, eps)
+        ctx.save_for_backward(z, gamma, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, gamma, mean, rstd = ctx.saved_tensors
+        dz, dg = hip.instnorm_spade_bwd(dout, z, gamma, mean, rstd)
+        return dz, dg, dout, None
+
+
+def instnorm_spade(z, gamma, beta, eps=1e-5):
+    return _InstNormSpade.apply(z, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------- resize / softmax / losses
+class _Bilinear(Function):
+    @staticmethod
+    def forward(ctx, x, out_hw, align_corners):
+        ctx.geom = (x.shape[2], x.shape[3], align_corners)
+        return hip.bilinear_fwd(x, out_hw, align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Hi, Wi, ac = ctx.geom
+        return hip.bilinear_bwd(dy, (Hi, Wi), ac), None, None
+
+
+def bilinear(x, out_hw, align_corners):
+    """nn.Upsample(mode='bilinear'): model.py:2175 (align_corners=True), 2432/2501 (False)."""
+    return _Bilinear.apply(x, tuple(out_hw), bool(align_corners))
+
+
+class _SoftmaxMaskDrop(Function):
+    @staticmethod
+    def forward(ctx, s, mask_img, scale):
+        out = hip.softmax_mask_drop_fwd(s, mask_img, scale)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        return hip.softmax_mask_drop_bwd(dout, out), None, None
+
+
+def softmax_mask_drop(s, mask_img, scale=100.0):
+    """softmax(cat([scale*mask_img, s], 1), 1)[:, 1:]  (model.py:3150-3153)."""
+    return _SoftmaxMaskDrop.apply(s, mask_img, scale)
+
+
+class _ReconErr(Function):
+    @staticmethod
+    def forward(ctx, gt, x, p):
+        ctx.p = p
+        ctx.save_for_backward(gt, x)
+        return hip.recon_err_fwd(gt, x, p)
+
+    @staticmethod
+    def backward(ctx, w):
+        gt, x = ctx.saved_tensors
+        dx = hip.recon_err_bwd(gt, x, w, ctx.p)
+        return (-dx if ctx.needs_input_grad[0] else None), dx, None
+
+
+def recon_err(gt, x, p):
+    """per-sample mean over (C,H,W) of |gt-x|^p, p in {1,2}  (model.py:3260-3266)."""
+    return _ReconErr.apply(gt, x, int(p))
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        y, arg = hip.maxpool_fwd(x, k)
+        ctx.k, ctx.shape = k, tuple(x.shape)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        return hip.maxpool_bwd(dy, arg, ctx.shape, ctx.k), None
+
+
+def max_pool(x, k):
+    """F.max_pool2d(x, kernel_size=(k,k))  (model.py:3449)."""
+    return _MaxPool.apply(x, int(k))
+
+
+# --------------------------------------------------------------------------- mixed-kernel cache
+# The reference re-mixes the experts on every CondConv2d call.  Inside one training step the same
+# (layer, modality type) pair recurs (encoder passes 1 and 2, SPADEShared for every s_i), so the
+# trainer opens this scope and the mix node is shared -- autograd sums the kernel gradients of all
+# uses and runs the mix backward once.  Outside the scope nothing is cached.
+_MIX_CACHE = None
+
+
+@contextlib.contextmanager
+def mix_cache():
+    global _MIX_CACHE
+    prev, _MIX_CACHE = _MIX_CACHE, {}
+    try:
+        yield
+    finally:
+        _MIX_CACHE = prev
+
+
+def cached_mix(key, make):
+    if _MIX_CACHE is None or not torch.is_grad_enabled():
+        return make()
+    hit = _MIX_CACHE.get(key)
+    if hit is None:
+        hit = _MIX_CACHE[key] = make()
+    return hit
+
+
+# --------------------------------------------------------------------------- torch.ops.mrdis.*
+_LIB = None
+
+
+def register_torch_ops():
+    """Expose the raw (non-autograd) entry points as `torch.ops.mrdis.*` custom ops."""
+    global _LIB
+    if _LIB is not None:
+        return
+    _LIB = torch.library.Library('mrdis', 'DEF')
+    _LIB.define('mix_experts(Tensor W, Tensor r) -> (Tensor, Tensor)')
+    _LIB.define('conv2d_fwd(Tensor x, Tensor w_tck, Tensor? bias, int kh, int kw, int stride, int pad, bool lrelu) -> Tensor')
+    _LIB.define('conv2d_bwd_data(Tensor dy, Tensor w_tkc, int H, int W, int kh, int kw, int stride, int pad) -> Tensor')
+    _LIB.define('conv2d_bwd_weight(Tensor x, Tensor dy, int kh, int kw, int stride, int pad) -> (Tensor, Tensor)')
+    _LIB.define('bilinear(Tensor x, int Ho, int Wo, bool align_corners) -> Tensor')
+    _LIB.define('softmax_mask_drop(Tensor s, Tensor? mask_img, float scale) -> Tensor')
+    _LIB.impl('mix_experts', lambda W, r: hip.mix_experts_fwd(W, r), 'CUDA')
+    _LIB.impl('conv2d_fwd', lambda x, w, b, kh, kw, s, p, l: hip.conv2d_fwd(x, w, b, kh, kw, s, p, l), 'CUDA')
+    _LIB.impl('conv2d_bwd_data', lambda dy, w, H, W, kh, kw, s, p: hip.conv2d_bwd_data(dy, w, (H, W), kh, kw, s, p), 'CUDA')
+    _LIB.impl('conv2d_bwd_weight', lambda x, dy, kh, kw, s, p: hip.conv2d_bwd_weight(x, dy, kh, kw, s, p, True), 'CUDA')
+    _LIB.impl('bilinear', lambda x, Ho, Wo, ac: hip.bilinear_fwd(x, (Ho, Wo), ac), 'CUDA')
+    _LIB.impl('softmax_mask_drop', lambda s, m, sc: hip.softmax_mask_drop_fwd(s, m, sc), 'CUDA')

@@ -1,0 +1,212 @@
+"""GPU parity of the module mirror + training step: (1) against the golden vectors that
+oracle/gen_golden.py captured from the real reference at 160x192, (2) against the CPU oracle on
+seeded inputs at sizes the reference itself cannot run (64x64, 96x128)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_model as R                                   # noqa: E402
+from oracle.gen_golden import make_inputs, reinit_discriminator, seeded   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def mrdis():
+    import mrdis as m
+    assert torch.cuda.is_available()
+    m.hip.load()
+    return m
+
+
+DEV = torch.device('cuda:0')
+
+
+def cl(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def close(got, want, rtol=1e-3, what=''):
+    got = got.detach().float().cpu()
+    want = torch.as_tensor(want).float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - want).abs().max().item()
+    assert err <= rtol * float(want.abs().max()) + 1e-7, (what, err, float(want.abs().max()))
+
+
+@pytest.fixture(scope='module')
+def units(golden_dir):
+    return np.load(os.path.join(golden_dir, 'units.npz'))
+
+
+@pytest.mark.parametrize('name,ci,co,k,s,p,hw', [
+    ('c3s1', 5, 6, 3, 1, 1, (9, 11)), ('c4s2', 7, 8, 4, 2, 1, (12, 10)),
+    ('c3s2', 4, 6, 3, 2, 1, (11, 13)), ('c1s1', 6, 3, 1, 1, 0, (7, 5))])
+def test_condconv_golden_per_sample(mrdis, units, name, ci, co, k, s, p, hw):
+    """reference CondConv2d with a different type per sample -> per-sample path of the drop-in."""
+    torch.manual_seed(100)
+    m = mrdis.CondConv2d(ci, co, k, s, padding=p)
+    with torch.no_grad():
+        m.bias.copy_(seeded((co,), 7, 0.1))
+    m = m.to(DEV)
+    x = cl(seeded((3, ci) + hw, 1)).requires_grad_(True)
+    t = torch.tensor([[1.], [2.], [4.]], device=DEV)
+    y = m(x, t)
+    y.backward(cl(seeded(tuple(y.shape), 2)))
+    close(y, units[f'cond_{name}_y'], 1e-4, 'y')
+    close(x.grad, units[f'cond_{name}_dx'], 1e-4, 'dx')
+    close(m.weight.grad, units[f'cond_{name}_dw'], 2e-4, 'dW')
+    close(m.bias.grad, units[f'cond_{name}_db'], 2e-4, 'db')
+    close(m._routing_fn.fc.weight.grad, units[f'cond_{name}_dfcw'], 5e-4, 'dfc.w')
+    close(m._routing_fn.fc.bias.grad, units[f'cond_{name}_dfcb'], 5e-4, 'dfc.b')
+
+
+def test_condconv_uniform_equals_per_sample(mrdis):
+    torch.manual_seed(1)
+    m = mrdis.CondConv2d(8, 16, 3, 1, padding=1).to(DEV)
+    x = cl(seeded((4, 8, 12, 16), 3))
+    t_dense = 3 * torch.ones(4, 1, device=DEV)                  # per-sample path
+    t_exp = mrdis.expand_type(3.0, 4, DEV)                      # mixed once
+    close(m(x, t_exp), m(x, t_dense).detach().cpu(), 1e-6)
+
+
+def test_blocks_golden(mrdis, units):
+    torch.manual_seed(101)
+    m = mrdis.Conv_BN_Act_New(6, 8, is_cond=True).to(DEV).train()
+    x = cl(seeded((3, 6, 12, 16), 3)).requires_grad_(True)
+    y = m(x, mrdis.expand_type(2.0, 3, DEV)); y.backward(cl(seeded(tuple(y.shape), 4)))
+    close(y, units['cba_y'], 2e-4); close(x.grad, units['cba_dx'], 5e-4); close(m.conv.weight.grad, units['cba_dw'], 5e-4)
+    close(m.bn.weight.grad, units['cba_dbn_w'], 5e-4); close(m.bn.bias.grad, units['cba_dbn_b'], 5e-4)
+    close(m.bn.running_mean, units['cba_run_mean'], 1e-4); close(m.bn.running_var, units['cba_run_var'], 1e-4)
+
+    torch.manual_seed(102)
+    m = mrdis.Act_Deconv_BN_Concat_New(6, 5, is_cond=True).to(DEV).train()
+    xu = cl(seeded((2, 6, 5, 6), 5)).requires_grad_(True)
+    y = m(cl(seeded((2, 4, 10, 12), 6)), xu, mrdis.expand_type(3.0, 2, DEV)); y.backward(cl(seeded(tuple(y.shape), 7)))
+    close(y, units['adb_y'], 2e-4); close(xu.grad, units['adb_dx'], 5e-4); close(m.conv.weight.grad, units['adb_dw'], 5e-4)
+
+    torch.manual_seed(103)
+    m = mrdis.SPADEBlockNew((10, 12), in_num_ch=8, out_num_ch=6, s_num_ch=4, is_cond=True).to(DEV)
+    s = cl(torch.softmax(seeded((2, 4, 40, 48), 8), 1)).requires_grad_(True)
+    z = cl(seeded((2, 8, 10, 12), 9)).requires_grad_(True)
+    y = m(s, z, mrdis.expand_type(1.0, 2, DEV)); y.backward(cl(seeded(tuple(y.shape), 10)))
+    close(y, units['spade_y'], 2e-4); close(s.grad, units['spade_ds'], 5e-4); close(z.grad, units['spade_dz'], 5e-4)
+    close(m.gamma.weight.grad, units['spade_dw_gamma'], 5e-4)
+
+    torch.manual_seed(104)
+    m = mrdis.ModalityEncoderNew(img_num_ch=7, s_num_ch=0, first_num_ch=16, z_size=16, is_cond=True).to(DEV)
+    mu, lv = m(cl(seeded((2, 7, 160, 192), 11)), None, mrdis.expand_type(2.0, 2, DEV))
+    (mu.sum() + 2 * lv.sum()).backward()
+    close(mu, units['modenc_mu'], 2e-4); close(lv, units['modenc_lv'], 2e-4); close(m.conv1.weight.grad, units['modenc_dw1'], 5e-4)
+
+    for pg in (False, True):
+        torch.manual_seed(105)
+        m = mrdis.Discriminator(in_num_ch=4, inter_num_ch=16, is_patch_gan=pg).to(DEV).train()
+        y = m(cl(torch.softmax(seeded((2, 4, 160, 192), 12), 1)))
+        close(y, units[f'disc_{"patch" if pg else "dense"}_y'], 5e-4, f'disc pg={pg}')
+
+
+def _cfg(mrdis, M, H, W, B, adv=False):
+    cfg = dict(mrdis.DEFAULT_CONFIG)
+    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=max(B, 16),
+               lambda_adv_s=1.0 if adv else 0.0)
+    return mrdis.derive_config(cfg, DEV)
+
+
+@pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
+def test_train_step_golden(mrdis, golden_dir, tag):
+    """One full training step at the reference's own size vs vectors from the real reference."""
+    meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
+    arrs = np.load(os.path.join(golden_dir, f'step_{tag}.npz'))
+    B, M, adv = meta['B'], meta['M'], meta['adv']
+    cfg = _cfg(mrdis, M, 160, 192, B, adv)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()        # same constructor RNG order as the reference
+    if adv:
+        reinit_discriminator(model.discrim_s)
+    for k, v in meta['wsum_before'].items():
+        got = float(model.state_dict()[k].double().sum())
+        assert abs(got - v) <= 1e-6 * max(1.0, abs(v)), ('init', k)
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10, drop=meta['drop'])
+    step = mrdis.TrainStep(model, cfg)
+    torch.manual_seed(11); np.random.seed(11)
+    names = {id(p): n for n, p in model.named_parameters()}
+    with mrdis.ops.mix_cache():
+        loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+        loss.backward(retain_graph=adv)
+    assert abs(float(loss) - meta['loss']) <= 1e-3 * abs(meta['loss'])
+    for k, v in meta['parts'].items():
+        assert abs(float(parts[k]) - v) <= 1e-3 * abs(v) + 1e-6, (k, float(parts[k]), v)
+    close(torch.stack(aux['mu_list']), arrs['mu'], 1e-3, 'mu'); close(torch.stack(aux['zi_list']), arrs['z'], 1e-3, 'z')
+    close(F.avg_pool2d(aux['si_list'][0], 8), arrs['s0_pool8'], 1e-3, 's0')
+    close(F.avg_pool2d(aux['xi_fake_list'][0], 8), arrs['xf0_pool8'], 1e-3, 'xf0')
+    close(F.avg_pool2d(aux['xi_fake_mix_list'][0], 8), arrs['xmix0_pool8'], 1e-3, 'xmix0')
+    gn = {names[id(p)]: float(p.grad.double().norm()) for p in model.parameters() if p.grad is not None}
+    hot = {k: v for k, v in meta['grad_norms'].items() if not k.startswith('output_decoder')}
+    assert set(hot) == set(gn)
+    total = float(np.sqrt(sum(v * v for v in gn.values())))
+    ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
+    assert abs(total - ref_total) <= 1e-3 * ref_total, (total, ref_total)
+    for k, v in hot.items():
+        assert abs(gn[k] - v) <= 5e-3 * v + 2e-5 * ref_total, (k, gn[k], v)
+    # clip + Adam on the arena vs the reference's weights after optimizer.step()
+    step.optimizer.step(fused_clip=True)
+    for k, v in meta['wsum_after'].items():
+        if meta['grad_norms'].get(k, 1.0) < 1e-5 * meta['grad_norm']:
+            continue
+        got = float(model.state_dict()[k].double().sum())
+        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), ('after step', k, got, v)
+
+
+@pytest.mark.parametrize('B,M,H,W,drop,adv', [(3, 3, 64, 64, False, False), (2, 2, 96, 128, True, False), (2, 3, 64, 96, False, True)])
+def test_train_step_vs_oracle_other_sizes(mrdis, B, M, H, W, drop, adv):
+    """sizes the reference cannot run (hard-coded 5*6 grid): HIP vs the CPU oracle, same weights."""
+    cfg = _cfg(mrdis, M, H, W, B, adv)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    torch.manual_seed(10)
+    ref = R.RefMultimodalModel((H, W), M, is_discrim_s=adv).train()
+    if adv:
+        reinit_discriminator(ref.discrim_s)
+    assert not mrdis.load_checkpoint_model(model, ref.state_dict())
+    inputs, mask, mask_img = make_inputs(B, M, H, W, seed=5, drop=drop)
+    lam = dict(R.DEFAULT_LAMBDAS, adv_s=1.0 if adv else 0.0)
+    torch.manual_seed(11); np.random.seed(11)
+    rloss, rparts, raux = R.ref_forward_losses(ref, inputs, mask, mask_img, lam)
+    rloss.backward()
+    step = mrdis.TrainStep(model, cfg)
+    torch.manual_seed(11); np.random.seed(11)
+    with mrdis.ops.mix_cache():
+        loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+        loss.backward()
+    assert abs(float(loss) - float(rloss)) <= 1e-3 * abs(float(rloss))
+    for k, v in rparts.items():
+        assert abs(float(parts[k]) - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, k
+    for a, b in zip(aux['xi_fake_mix_list'], raux['xmix']):
+        close(a, b.detach(), 1e-3, 'xmix')
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in rg.values())))
+    for n, p in model.named_parameters():
+        if n in rg:
+            err = float((p.grad.detach().cpu() - rg[n]).double().norm())
+            assert err <= 2e-3 * float(rg[n].double().norm()) + 2e-5 * tot, (n, err, float(rg[n].norm()))
+        else:
+            assert p.grad is None, n
+
+
+def test_train_step_runs_twice_and_decreases_nothing_nan(mrdis):
+    cfg = _cfg(mrdis, 2, 64, 64, 2)
+    torch.manual_seed(0)
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg)
+    x, mask, mask_img = mrdis.synthetic_batch(2, 2, 64, 64, seed=1)
+    for _ in range(3):
+        loss, parts, _ = step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+        assert torch.isfinite(loss)
+    host = step.losses_to_host(parts)
+    assert set(host) == set(mrdis.LOSS_KEYS)

@@ -1,0 +1,253 @@
+"""GPU parity of every C-ABI entry point against plain fp32 torch on the CPU
+(the published primitives the reference's call sites dispatch to).
+Tolerance: BASELINE.json north_star -> 1e-3 relative; most checks are tighter."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def mrdis():
+    import mrdis as m
+    assert torch.cuda.is_available()
+    m.hip.load()
+    return m
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def cl(x):
+    return x.to(dev()).contiguous(memory_format=torch.channels_last)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, want, rtol=1e-4, atol=None, what=''):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if atol is None:
+        atol = rtol * float(want.abs().max()) + 1e-7
+    err = (got - want).abs().max().item()
+    assert torch.isfinite(got).all(), what
+    assert err <= atol + rtol * float(want.abs().max()), (what, err, float(want.abs().max()))
+
+
+def to_tck(w):   # (Co,Ci,kh,kw) -> [T][Ci][Co]
+    Co, Ci, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw, Ci, Co).contiguous()
+
+
+def to_tkc(w):   # -> [T][Co][Ci]
+    Co, Ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, Co, Ci).contiguous()
+
+
+# (N, Ci, Co, H, W, k, stride, pad): the path's layer geometries at reduced extents + ragged cases
+CONV_CASES = [
+    (2, 4, 32, 48, 40, 3, 1, 1),      # sp*.si_layers
+    (2, 7, 32, 32, 64, 4, 2, 1),      # ana_enc.down_1
+    (3, 7, 16, 32, 32, 3, 2, 1),      # mod_enc.conv1
+    (2, 32, 64, 16, 24, 4, 2, 1),     # ana_enc.down_2
+    (2, 64, 128, 10, 12, 4, 2, 1),    # down_3-like, ragged grid
+    (2, 16, 32, 20, 24, 3, 2, 1),     # mod_enc.conv2
+    (2, 128, 128, 5, 6, 3, 1, 1),     # sp1 gamma/beta at the 5x6 grid
+    (4, 128, 64, 10, 12, 3, 1, 1),    # sp4.out
+    (1, 256, 256, 10, 12, 3, 1, 1),   # ana_dec.up_4
+    (2, 96, 40, 20, 24, 3, 1, 1),     # channel counts that are not tile multiples
+    (2, 64, 4, 40, 48, 3, 1, 1),      # ana_dec.output (Cout = 4)
+    (2, 16, 7, 32, 48, 1, 1, 0),      # decoder 1x1 out conv
+    (2, 4, 16, 32, 32, 4, 2, 1),      # discriminator conv1
+    (2, 64, 1, 5, 6, 3, 1, 1),        # PatchGAN head
+    (1, 5, 6, 9, 11, 3, 1, 1),        # odd everything
+    (3, 4, 6, 11, 13, 3, 2, 1),       # odd extents, stride 2
+    (2, 32, 32, 33, 37, 3, 1, 1),     # ragged tiles
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_bwd(mrdis, case):
+    N, Ci, Co, H, W, k, s, p = case
+    x = rnd((N, Ci, H, W), 1).requires_grad_(True)
+    w = rnd((Co, Ci, k, k), 2, 0.2).requires_grad_(True)
+    b = rnd((Co,), 3, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, s, p)
+    gy = rnd(tuple(y.shape), 4)
+    y.backward(gy)
+    hip = mrdis.hip
+    got = hip.conv2d_fwd(cl(x.detach()), to_tck(w.detach()).to(dev()), b.detach().to(dev()), k, k, s, p)
+    close(got, y, what='fwd')
+    got_l = hip.conv2d_fwd(cl(x.detach()), to_tck(w.detach()).to(dev()), b.detach().to(dev()), k, k, s, p, lrelu=True)
+    close(got_l, F.leaky_relu(y, 0.2), what='fwd+lrelu')
+    dx = hip.conv2d_bwd_data(cl(gy), to_tkc(w.detach()).to(dev()), (H, W), k, k, s, p)
+    close(dx, x.grad, what='dgrad')
+    dw, db = hip.conv2d_bwd_weight(cl(x.detach()), cl(gy), k, k, s, p, need_bias=True)
+    close(dw, to_tck(w.grad), rtol=2e-4, what='wgrad')
+    close(db, b.grad, rtol=2e-4, what='dbias')
+
+
+def test_conv_strided_views(mrdis):
+    """channel slices of wider NHWC buffers as input and output (ld != C)."""
+    hip = mrdis.hip
+    N, H, W = 2, 24, 32
+    big = rnd((N, 28, H, W), 5)
+    w = rnd((32, 7, 4, 4), 6, 0.2); b = rnd((32,), 7, 0.1)
+    bigd = cl(big)
+    xs = bigd[:, 7:14]                                   # ld = 28, channel offset 7 (unaligned -> scalar path)
+    want = F.conv2d(big[:, 7:14], w, b, 2, 1)
+    out_big = torch.zeros((N, 48, H // 2, W // 2), device=dev()).contiguous(memory_format=torch.channels_last)
+    hip.conv2d_fwd(xs, to_tck(w).to(dev()), b.to(dev()), 4, 4, 2, 1, out=out_big[:, 16:48])
+    close(out_big[:, 16:48], want, what='strided fwd')
+    assert float(out_big[:, :16].abs().max()) == 0.0
+    gy = rnd(tuple(want.shape), 8)
+    gyd = torch.zeros((N, 40, H // 2, W // 2), device=dev()).contiguous(memory_format=torch.channels_last)
+    gyd[:, 8:40] = gy.to(dev())
+    xr = big[:, 7:14].clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, b, 2, 1).backward(gy)
+    dw, db = hip.conv2d_bwd_weight(xs, gyd[:, 8:40], 4, 4, 2, 1)
+    close(dw, to_tck(wr.grad), rtol=2e-4, what='strided wgrad')
+    dx = hip.conv2d_bwd_data(gyd[:, 8:40], to_tkc(w).to(dev()), (H, W), 4, 4, 2, 1)
+    close(dx, xr.grad, what='strided dgrad')
+
+
+def test_mix_experts(mrdis):
+    hip = mrdis.hip
+    W = rnd((3, 6, 5, 3, 3), 9).requires_grad_(True)
+    r = torch.tensor([0.3, 0.6, 0.9], requires_grad=True)
+    mixed = (r[:, None, None, None, None] * W).sum(0)
+    g = rnd((9, 5, 6), 10)
+    (to_tck(mixed) * g).sum().backward()
+    tck, tkc = hip.mix_experts_fwd(W.detach().to(dev()), r.detach().to(dev()))
+    close(tck, to_tck(mixed), rtol=1e-6); close(tkc, to_tkc(mixed), rtol=1e-6)
+    dW, dr = hip.mix_experts_bwd(g.to(dev()), W.detach().to(dev()), r.detach().to(dev()))
+    close(dW, W.grad, rtol=1e-6); close(dr, r.grad, rtol=1e-5)
+
+
+@pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 16), (32, 3, 9, 7), (256, 2, 5, 6), (16, 2, 8, 8), (48, 2, 6, 10)])
+def test_batchnorm(mrdis, C, N, H, W):
+    hip = mrdis.hip
+    x = (rnd((N, C, H, W), 11) * 2 + 0.5).requires_grad_(True)
+    gm = rnd((C,), 12).requires_grad_(True); bt = rnd((C,), 13).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.batch_norm(x, rm, rv, gm, bt, True, 0.1, 1e-5)
+    gy = rnd(tuple(y.shape), 14); y.backward(gy)
+    rmd, rvd = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    yd, mean, rstd = hip.bn_train_fwd(cl(x.detach()), gm.detach().to(dev()), bt.detach().to(dev()), rmd, rvd, 1e-5, 0.1)
+    close(yd, y); close(rmd, rm, rtol=1e-5); close(rvd, rv, rtol=1e-5)
+    dx, dg, db = hip.bn_train_bwd(cl(gy), cl(x.detach()), gm.detach().to(dev()), mean, rstd)
+    close(dx, x.grad, rtol=2e-4); close(dg, gm.grad, rtol=2e-4); close(db, bt.grad, rtol=2e-4)
+
+
+@pytest.mark.parametrize('C,N,H,W', [(128, 2, 5, 6), (32, 2, 16, 24), (64, 3, 10, 12)])
+def test_instnorm_spade(mrdis, C, N, H, W):
+    hip = mrdis.hip
+    z = (rnd((N, C, H, W), 15) * 1.5 + 0.3).requires_grad_(True)
+    g = rnd((N, C, H, W), 16).requires_grad_(True); b = rnd((N, C, H, W), 17).requires_grad_(True)
+    out = F.instance_norm(z, eps=1e-5) * (1 + g) + b
+    go = rnd(tuple(out.shape), 18); out.backward(go)
+    od, mean, rstd = hip.instnorm_spade_fwd(cl(z.detach()), cl(g.detach()), cl(b.detach()), 1e-5)
+    close(od, out)
+    dz, dg = hip.instnorm_spade_bwd(cl(go), cl(z.detach()), cl(g.detach()), mean, rstd)
+    close(dz, z.grad, rtol=2e-4); close(dg, g.grad, rtol=2e-4)
+
+
+@pytest.mark.parametrize('shape,out_hw,ac', [
+    ((2, 8, 5, 6), (10, 12), True), ((2, 8, 5, 6), (10, 12), False), ((2, 4, 32, 64), (5, 6), False),
+    ((2, 4, 40, 48), (40, 48), False), ((1, 3, 7, 9), (14, 18), True), ((2, 4, 32, 48), (16, 24), False),
+    ((2, 5, 6, 6), (12, 12), False)])
+def test_bilinear(mrdis, shape, out_hw, ac):
+    hip = mrdis.hip
+    x = rnd(shape, 19).requires_grad_(True)
+    y = F.interpolate(x, size=out_hw, mode='bilinear', align_corners=ac)
+    gy = rnd(tuple(y.shape), 20); y.backward(gy)
+    close(hip.bilinear_fwd(cl(x.detach()), out_hw, ac), y, rtol=1e-5)
+    close(hip.bilinear_bwd(cl(gy), shape[2:], ac), x.grad, rtol=1e-5)
+
+
+def test_bilinear_golden(mrdis, golden_dir):
+    import os
+    u = np.load(os.path.join(golden_dir, 'units.npz'))
+    hip = mrdis.hip
+    x = rnd((2, 3, 5, 6), 13)
+    close(hip.bilinear_fwd(cl(x), (10, 12), True), torch.from_numpy(u['bil_ac_true_x2']), rtol=1e-5)
+    close(hip.bilinear_fwd(cl(x), (10, 12), False), torch.from_numpy(u['bil_ac_false_x2']), rtol=1e-5)
+    xs = rnd((2, 4, 32, 64), 14)
+    close(hip.bilinear_fwd(cl(xs), (5, 6), False), torch.from_numpy(u['bil_down_to_5x6']), rtol=1e-5)
+
+
+def test_softmax_mask_drop(mrdis):
+    hip = mrdis.hip
+    s = rnd((2, 4, 9, 11), 21, 3.0).requires_grad_(True)
+    m = (rnd((2, 9, 11), 22) > 0.5).float()
+    out = F.softmax(torch.cat([100 * m.unsqueeze(1), s], 1), 1)[:, 1:]
+    go = rnd(tuple(out.shape), 23); out.backward(go)
+    od = hip.softmax_mask_drop_fwd(cl(s.detach()), m.to(dev()), 100.0)
+    close(od, out, rtol=1e-5)
+    close(hip.softmax_mask_drop_bwd(cl(go), od), s.grad, rtol=1e-4)
+
+
+@pytest.mark.parametrize('p', [1, 2])
+def test_recon_err(mrdis, p):
+    hip = mrdis.hip
+    gt = rnd((3, 7, 12, 10), 24); x = rnd((3, 7, 12, 10), 25).requires_grad_(True)
+    d = gt - x
+    e = d.abs().mean((1, 2, 3)) if p == 1 else d.pow(2).mean((1, 2, 3))
+    w = rnd((3,), 26); (e * w).sum().backward()
+    close(hip.recon_err_fwd(cl(gt), cl(x.detach()), p), e, rtol=1e-5)
+    close(hip.recon_err_bwd(cl(gt), cl(x.detach()), w.to(dev()), p), x.grad, rtol=1e-5)
+
+
+def test_maxpool(mrdis):
+    hip = mrdis.hip
+    x = rnd((2, 4, 32, 48), 27).requires_grad_(True)
+    y = F.max_pool2d(x, 16); gy = rnd(tuple(y.shape), 28); y.backward(gy)
+    yd, arg = hip.maxpool_fwd(cl(x.detach()), 16)
+    close(yd, y, rtol=0, atol=0)
+    close(hip.maxpool_bwd(cl(gy), arg, tuple(x.shape), 16), x.grad, rtol=0, atol=0)
+
+
+def test_lrelu_bwd(mrdis):
+    hip = mrdis.hip
+    x = rnd((2, 8, 5, 7), 29).requires_grad_(True)
+    y = F.leaky_relu(x, 0.2); gy = rnd(tuple(y.shape), 30); y.backward(gy)
+    close(hip.lrelu_bwd(cl(gy), cl(y.detach()), 0.2), x.grad, rtol=0, atol=0)
+
+
+def test_adam_amsgrad_clip(mrdis):
+    hip = mrdis.hip
+    n = 10007
+    p0 = rnd((n,), 31); grads = [rnd((n,), 32 + i, 3.0) for i in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    pd = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev()); vm = torch.zeros(n, device=dev())
+    nf = torch.zeros(2, device=dev())
+    for i, g in enumerate(grads):
+        pr.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = g.to(dev()); nf.zero_(); hip.sumsq_finite(gd, nf)
+        assert abs(float(nf[0].sqrt()) - float(tn)) <= 1e-5 * float(tn) and float(nf[1]) == 0
+        hip.adam_amsgrad_step(pd, gd, m, v, vm, 2e-4, 0.9, 0.999, 1e-8, 1e-5, i + 1, nf, 1.0)
+    close(pd, pr, rtol=1e-6, atol=1e-7)
+    # a non-finite gradient makes the device skip the step
+    gd = grads[0].to(dev()); gd[5] = float('nan'); nf.zero_(); hip.sumsq_finite(gd, nf)
+    before = pd.clone()
+    hip.adam_amsgrad_step(pd, gd, m, v, vm, 2e-4, 0.9, 0.999, 1e-8, 1e-5, 4, nf, 1.0)
+    assert float(nf[1]) == 1 and torch.equal(before, pd)
+
+
+def test_error_codes(mrdis):
+    hip = mrdis.hip
+    lib = hip.load()
+    assert lib.mrdis_strerror(-2) == b'unsupported geometry'
+    x = cl(rnd((1, 4, 8, 8), 40))
+    with pytest.raises(hip.MrdisError):
+        hip.conv2d_fwd(x, torch.zeros((25, 4, 8), device=dev()), None, 5, 5, 1, 2)    # 25 taps > MRDIS_MAX_TAPS
