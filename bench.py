@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]           # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W  # N > 1, one rank per GPU (RCCL)
+
+Metric (BASELINE.json): MR slices/sec of one full training step -- anatomy + modality
+encoders, 4 + 12 SPADE decodes, recon_x + recon_x_mix + latent_z cycle + sim_s + sim_z +
+adversarial losses, backward, clip, Adam(amsgrad) -- a "slice" being one batch element with
+all M modalities.  Workload at N = 1 is BASELINE.json configs[1]: 4-modality 240x240 fp32
+slices, batch 32 per GPU; 240 is not a multiple of 32 (the U-Net needs five stride-2 stages,
+reference model.py:2192), so each slice is padded with background to 256x256 -- no pixel of
+the named workload is dropped (the reference's own 160x192 crop is available with
+--fit crop).  Weak scaling: per-GPU batch fixed, gradients mean-all-reduced over RCCL.
+Inputs are synthetic BraTS-shaped slices already resident in HBM; weights random-init.
+
+One JSON line is printed by rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # dense f32-input MFMA peak
+# north-star conv x(32,4,240,240) -> y(32,32,240,240), W(32,4,3,3), fp32
+NS = dict(N=32, Ci=4, Co=32, H=240, W=240, k=3)
+NS_BYTES = 4 * (NS['N'] * NS['Ci'] * NS['H'] * NS['W'] + NS['N'] * NS['Co'] * NS['H'] * NS['W'] + NS['Co'] * NS['Ci'] * 9 + NS['Co'])
+# fwd+bwd conv FLOPs per slice at 160x192, M = 4 (torch FlopCounter on the reference)
+FLOP_PER_SLICE_160x192 = 2.784e11
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (slices)')
+    ap.add_argument('--modalities', type=int, default=4)
+    ap.add_argument('--slice', type=int, default=240, help='synthetic slice extent (BraTS: 240)')
+    ap.add_argument('--fit', choices=['pad', 'crop'], default='pad', help='240 -> 256x256 pad (default) or 160x192 crop')
+    ap.add_argument('--no-adv', action='store_true', help='lambda_adv_s = 0 (the shipped config.yaml)')
+    ap.add_argument('--drop', action='store_true', help='missing-modality batches (BASELINE configs[3])')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def roofline_conv(mrdis, dev, iters=20):
+    """Average duration of the north-star 3x3 conv forward, HIP events on the launch stream."""
+    hip = mrdis.hip
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(NS['N'], NS['Ci'], NS['H'], NS['W'], generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(9, NS['Ci'], NS['Co'], generator=g) * 0.1).to(dev)
+    b = torch.zeros(NS['Co'], device=dev)
+    y = hip.empty_nhwc(NS['N'], NS['Co'], NS['H'], NS['W'], dev)
+    for _ in range(3):
+        hip.conv2d_fwd(x, w, b, 3, 3, 1, 1, out=y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        hip.conv2d_fwd(x, w, b, 3, 3, 1, 1, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    achieved = NS_BYTES / (us * 1e-6) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'northstar_conv_pmc.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'hbm', 'kernel': 'tapconv_kernel (3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC)',
+            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': traffic, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us, 2),
+            'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us * 1e-6) / 1e12, 2)}
+
+
+def cpu_baseline(M, H, W, adv):
+    """The CPU restatement of the reference step (oracle, kind 'port'), bounded sample."""
+    from oracle import ref_model as R
+    import mrdis
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))        # the GPU box gives one GPU's job a 16-core share; more threads only thrash
+    torch.set_num_threads(cores)
+    print(f'[bench] cpu_baseline: {cores} threads, B=2, M={M}, {H}x{W}', file=sys.stderr, flush=True)
+    B = 2
+    torch.manual_seed(10); np.random.seed(10)
+    model = R.RefMultimodalModel((H, W), M, is_discrim_s=adv).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, H, W, seed=10)
+    lam = dict(R.DEFAULT_LAMBDAS, adv_s=1.0 if adv else 0.0)
+
+    def one():
+        loss, parts, _ = R.ref_forward_losses(model, x, mask, mask_img, lam)
+        loss.backward(retain_graph=adv)
+        gd = None
+        if adv:
+            g_main = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+            opt.zero_grad()
+            parts['adv_s_d'].backward()
+            for p, g in zip(model.parameters(), g_main):
+                p.grad = g
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step(); opt.zero_grad()
+    t0 = time.perf_counter()
+    one()
+    print(f'[bench] cpu_baseline warm-up step {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        one()
+        print(f'[bench] cpu_baseline step done at +{time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
+    dt = (time.perf_counter() - t0) / n
+    return {'value': round(B / dt, 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/ref_model.py train step, B={B}, M={M}, {H}x{W} fp32, 1 warm-up + {n} timed steps, '
+                      f'{dt:.2f} s/step'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback for the hot path)'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    import mrdis
+    mrdis.hip.load()
+
+    M, B = a.modalities, a.batch
+    H, W = (256, 256) if a.fit == 'pad' else (160, 192)
+    if a.slice != 240:
+        H = W = (a.slice + 31) // 32 * 32
+    adv = not a.no_adv
+    cfg = dict(mrdis.DEFAULT_CONFIG)
+    cfg.update(contrast_list=['T1', 'T1c', 'T2', 'T2_FLAIR'][:M] if M <= 4 else [f'm{i}' for i in range(M)],
+               input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0 if adv else 0.0)
+    cfg = mrdis.derive_config(cfg, dev)
+    torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21; same init on every rank
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, a.slice, a.slice, seed=10 + rank, drop=a.drop)
+    x = mrdis.fit_to_model(x, (H, W), fill=-10.0)
+    mask_img = (x[:, 0] == 0).float()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    maskd, mimgd = mask.to(dev), mask_img.to(dev)
+    torch.manual_seed(100 + rank); np.random.seed(100)               # eps per rank, sim_s pair identical on all ranks
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+    log(f'model built, batch {B}x{M}x{H}x{W}; warm-up')
+    for i in range(a.warmup):
+        step(xd, maskd, mimgd, mask)
+        torch.cuda.synchronize()
+        log(f'warm-up step {i} done, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, parts, _ = step(xd, maskd, mimgd, mask)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / a.steps * 1e3
+    value = B * world / (dt / a.steps)
+    host_losses = step.losses_to_host(parts)
+
+    if rank == 0:
+        out = {
+            'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
+            'value': round(value, 3), 'unit': 'slices/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BraTS-shaped {M}-modality {a.slice}x{a.slice} fp32 slices '
+                                   f'({"zero-padded with background to" if a.fit == "pad" else "centre-cropped to"} {H}x{W}), '
+                                   f'batch {B}/GPU, full train step (fwd, recon_x+recon_x_mix+latent_z+sim_s+sim_z'
+                                   f'{"+adv" if adv else ""}, bwd, clip, Adam amsgrad)',
+                       'global_batch': B * world, 'per_gpu_batch': B, 'modalities': M, 'input_hw': [H, W],
+                       'parallelism': f'dp{world}', 'missing_modality': bool(a.drop)},
+            'loss': round(host_losses['all'], 5),
+            'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
+            'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
+        }
+        log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s')
+        if not a.no_roofline:
+            out['roofline'] = roofline_conv(mrdis, dev)
+            log(f'roofline: {out["roofline"]}')
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(M, H, W, adv)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

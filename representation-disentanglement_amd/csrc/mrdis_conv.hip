@@ -369,6 +369,7 @@ struct WgradParams {
     int nCi, nCo, nG, base;       // ci chunks (32), co chunks (32), tap groups, base = nCi*nCo*nG
     int splits;
     int vec_x, vec_dy;
+    float* bias_slab;             // [splits][nCo*32] column sums of dy, or nullptr
 };
 
 #define WG_TAB_INTS 192   // tab_in[128] tap_xoff[16] + pad
@@ -427,6 +428,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const bool do_bias = (p.bias_slab != nullptr) && cic == 0 && g == 0;
+    float bsum = 0.f;
 
     for (int tile = split; tile < p.numTiles; tile += p.splits) {
         int tt = tile;
@@ -498,6 +501,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             }
         }
         __syncthreads();
+        if (do_bias) {   // fused bias gradient: column sums of the staged dy tile (block-uniform branch)
+            const int co_ = tid & 31, part = tid >> 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += dys[(part * 16 + r) * 32 + co_];
+        }
 #pragma unroll
         for (int pp = 0; pp < 16; ++pp) {
             const int m = 2 * (wave + 4 * pp) + half;
@@ -511,72 +519,91 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             }
         }
     }
-    // slab[(split*4 + wave)][b][j][32][32]
-    float* out = p.slab + ((((long long)split * 4 + wave) * p.base + (bid - split * p.base)) * J) * 1024;
+    // cross-wave reduction through LDS (fixed order), then slab[split][b][j][32][32]
+    float* red = dys;                     // 4 waves x 1024 floats
+    float* out = p.slab + (((long long)split * p.base + (bid - split * p.base)) * J) * 1024;
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+    for (int j = 0; j < J; ++j) {
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            out[j * 1024 + row * 32 + e] = acc[j][r];
+            red[wave * 1024 + row * 32 + e] = acc[j][r];
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            out[j * 1024 + i] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;                  // [part(8)][co(32)]
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+            p.bias_slab[((long long)split * p.nCo + coc) * 32 + tid] = t;
+        }
+    }
 }
 
-// dw_tck[t][ci][co] = sum over slabs, fixed order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ntaps, int Ci, int Co,
+// dw_tck[t][ci][co] = sum over slabs, fixed order, two parallel stages of <= 32 terms each
+#define WG_RCHUNK 32
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int ntaps, int Ci, int Co,
                                     int CW, int TPS, int J, int nCi, int nCo, int base, int nslab) {
     const long long total = (long long)ntaps * Ci * Co;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Co);
-        const long long r = i / Co;
-        const int ci = (int)(r % Ci), t = (int)(r / Ci);
-        const int coc = co >> 5, n = co & 31;
-        const int cic = (Ci >= 32) ? (ci >> 5) : 0;
-        const int cl = ci - cic * 32;
-        const int jj = t / TPS, m = (t - jj * TPS) * CW + cl;
-        const int g = jj / J, j = jj - g * J;
-        const int b = (g * nCi + cic) * nCo + coc;
-        const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n;
-        const long long stride = (long long)base * J * 1024;
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += src[k * stride];
-        dw[i] = s;
-    }
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int chunk = blockIdx.y;
+    const int co = (int)(i % Co);
+    const long long r = i / Co;
+    const int ci = (int)(r % Ci), t = (int)(r / Ci);
+    const int coc = co >> 5, n = co & 31;
+    const int cic = (Ci >= 32) ? (ci >> 5) : 0;
+    const int cl = ci - cic * 32;
+    const int jj = t / TPS, m = (t - jj * TPS) * CW + cl;
+    const int g = jj / J, j = jj - g * J;
+    const int b = (g * nCi + cic) * nCo + coc;
+    const long long stride = (long long)base * J * 1024;
+    const int k0 = chunk * WG_RCHUNK;
+    int k1 = k0 + WG_RCHUNK; if (k1 > nslab) k1 = nslab;
+    const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n + k0 * stride;
+    float s_ = 0.f;
+    for (int k = k0; k < k1; ++k, src += stride) s_ += *src;
+    dst[(long long)chunk * total + i] = s_;
 }
-
-// column sums of a (P, C) view -> out[C]  (bias gradient).  Two-level, fixed order.
-__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long long P, int C, float* __restrict__ part, int rows_per_blk) {
-    // blockDim = (64, 4): x threads cover channels, y threads rows
-    __shared__ float red[4][64];
-    const long long r0 = (long long)blockIdx.x * rows_per_blk;
-    long long r1 = r0 + rows_per_blk; if (r1 > P) r1 = P;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + threadIdx.x;
-        float s = 0.f;
-        if (c < C)
-            for (long long r = r0 + threadIdx.y; r < r1; r += 4) s += x[r * ld + c];
-        red[threadIdx.y][threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.y == 0 && c < C)
-            part[(long long)blockIdx.x * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        __syncthreads();
-    }
+__global__ void wgrad_reduce2_kernel(const float* __restrict__ part, float* __restrict__ dw, long long total, int nchunk) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s_ = 0.f;
+    for (int k = 0; k < nchunk; ++k) s_ += part[(long long)k * total + i];
+    dw[i] = s_;
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * C + c];
-    out[c] = (float)s;
+// dbias[co] = sum over splits of bias_slab[split][co]; block (32, 8)
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int splits, int nCo32, int Co, float* __restrict__ dbias) {
+    __shared__ float red[8][32];
+    const int co = blockIdx.x * 32 + threadIdx.x;
+    float s_ = 0.f;
+    for (int k = threadIdx.y; k < splits; k += 8) s_ += bslab[(long long)k * nCo32 + co];
+    red[threadIdx.y][threadIdx.x] = s_;
+    __syncthreads();
+    if (threadIdx.y == 0 && co < Co) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        dbias[co] = t;
+    }
 }
 
 struct WgradPlan {
     WgradParams p;
     int J;
     size_t lds;
-    long long slab_floats;
-    int colsum_blocks, colsum_rows;
-    long long colsum_floats;
+    long long slab_floats, part_floats, bias_floats;
+    int nchunk;
 };
 
 static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
@@ -631,13 +658,10 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
     if (splits > nt) splits = nt;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
-    pl.slab_floats = (long long)p.splits * 4 * p.base * J * 1024;
-    const long long P = (long long)N * Ho * Wo;
-    pl.colsum_rows = 256;
-    long long cb = (P + 255) / 256;
-    if (cb > 2048) { pl.colsum_rows = (int)((P + 2047) / 2048); cb = (P + pl.colsum_rows - 1) / pl.colsum_rows; }
-    pl.colsum_blocks = (int)cb;
-    pl.colsum_floats = cb * Co;
+    pl.slab_floats = (long long)p.splits * p.base * J * 1024;
+    pl.nchunk = mrdis_cdiv(p.splits, WG_RCHUNK);
+    pl.part_floats = pl.nchunk > 1 ? (long long)pl.nchunk * p.ntaps * Ci * Co : 0;
+    pl.bias_floats = (long long)p.splits * p.nCo * 32;
     return MRDIS_OK;
 }
 
@@ -645,7 +669,7 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
                                                     int kh, int kw, int stride, int pad) {
     WgradPlan pl;
     if (plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
-    return sizeof(float) * (size_t)(pl.slab_floats + pl.colsum_floats) + 256;
+    return sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
 }
 
 template <int J>
@@ -663,13 +687,15 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
     int rc = plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
-    const size_t need = sizeof(float) * (size_t)(pl.slab_floats + pl.colsum_floats) + 256;
+    const size_t need = sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
     if (workspace_bytes < need) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     WgradParams& p = pl.p;
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
     p.slab = reinterpret_cast<float*>(workspace);
+    float* part = p.slab + pl.slab_floats;
+    p.bias_slab = dbias ? part + pl.part_floats : nullptr;
     p.vec_x = (Ci % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0) && (p.CW % 4 == 0);
     p.vec_dy = (Co % 4 == 0) && (lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     switch (pl.J) {
@@ -684,16 +710,15 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
     }
     if (rc) return rc;
     const long long total = (long long)p.ntaps * Ci * Co;
-    int rblk = mrdis_cdiv(total, 256); if (rblk > 2048) rblk = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblk), dim3(256), 0, s, p.slab, dw_tck, p.ntaps, Ci, Co,
-                       p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits * 4);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mrdis_cdiv(total, 256), pl.nchunk), dim3(256), 0, s, p.slab,
+                       pl.nchunk > 1 ? part : dw_tck, p.ntaps, Ci, Co, p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits);
     MRDIS_CHECK_LAUNCH();
-    if (dbias) {
-        float* part = p.slab + pl.slab_floats;
-        const long long P = (long long)N * p.A * p.B;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(pl.colsum_blocks), dim3(64, 4), 0, s, dy, lddy, P, Co, part, pl.colsum_rows);
+    if (pl.nchunk > 1) {
+        hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(mrdis_cdiv(total, 256)), dim3(256), 0, s, part, dw_tck, total, pl.nchunk);
         MRDIS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(mrdis_cdiv(Co, 64)), dim3(64), 0, s, part, pl.colsum_blocks, Co, dbias);
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 8), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias);
         MRDIS_CHECK_LAUNCH();
     }
     return MRDIS_OK;
@@ -755,7 +780,7 @@ __global__ void mix_bwd_final_kernel(const float* __restrict__ part, int nblk, i
     dr[e] += (float)s;
 }
 
-static int mix_blocks(long long total) { int b = mrdis_cdiv(total, 256); return b > 512 ? 512 : (b < 1 ? 1 : b); }
+static int mix_blocks(long long total) { int b = mrdis_cdiv(total, 256); return b > 128 ? 128 : (b < 1 ? 1 : b); }
 
 extern "C" int mrdis_mix_experts_fwd(const float* W, const float* r, float* w_tck, float* w_tkc,
                                      int E, int Co, int Ci, int T, void* stream) {

@@ -30,7 +30,7 @@ static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; if (b 
 // rows of group g: [g*P, (g+1)*P).  part[((g*chunks + chunk)*2 + k)*C + c]
 struct StatPlan { int chunks, rpb; };
 static StatPlan stat_plan(int groups, long long P) {
-    long long maxc = 4096 / (groups > 0 ? groups : 1); if (maxc < 1) maxc = 1;
+    long long maxc = 1024 / (groups > 0 ? groups : 1); if (maxc < 1) maxc = 1;
     long long chunks = (P + 255) / 256; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
     StatPlan s; s.chunks = (int)chunks; s.rpb = (int)((P + chunks - 1) / chunks);
     return s;
@@ -85,18 +85,26 @@ __global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const 
 }
 
 // FIN 0: mean / rstd (+ optional running stats, BatchNorm semantics)   FIN 1: raw sums -> out0/out1
+// block (64, 4): x = output index, y = lane over the chunk list (fixed order: lane sums then y = 0..3)
 template <int FIN>
 __global__ void stat_final_kernel(const float* __restrict__ part, int chunks, int C, int groups, long long P, float eps,
                                   float momentum, float* __restrict__ out0, float* __restrict__ out1,
                                   float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    const int grp = i / C, c = i - grp * C;
+    __shared__ double red[2][4][64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool ok = i < groups * C;
+    const int grp = ok ? i / C : 0, c = ok ? i - grp * C : 0;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        const float* src = part + ((long long)(grp * chunks + k) * 2) * C;
-        s0 += (double)src[c]; s1 += (double)src[C + c];
-    }
+    if (ok)
+        for (int k = threadIdx.y; k < chunks; k += 4) {
+            const float* src = part + ((long long)(grp * chunks + k) * 2) * C;
+            s0 += (double)src[c]; s1 += (double)src[C + c];
+        }
+    red[0][threadIdx.y][threadIdx.x] = s0; red[1][threadIdx.y][threadIdx.x] = s1;
+    __syncthreads();
+    if (!ok || threadIdx.y != 0) return;
+    s0 = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
+    s1 = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
     if (FIN == 0) {
         const double m = s0 / (double)P;
         double var = s1 / (double)P - m * m; if (var < 0.0) var = 0.0;
@@ -149,7 +157,7 @@ extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, co
     int rc = launch_stats<0>(x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
                        save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
@@ -192,7 +200,7 @@ extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     // dbeta = sum dy ; dgamma = sum dy * xhat
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
@@ -233,7 +241,7 @@ extern "C" int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* ga
     int rc = launch_stats<0>(z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
                        save_mean, save_rstd, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
@@ -287,7 +295,7 @@ extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float
     int rc = launch_stats<2>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
     const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dz, lddz, C) &&

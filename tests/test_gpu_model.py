@@ -159,8 +159,12 @@ def test_train_step_golden(mrdis, golden_dir, tag):
     for k, v in meta['wsum_after'].items():
         if meta['grad_norms'].get(k, 1.0) < 1e-5 * meta['grad_norm']:
             continue
-        got = float(model.state_dict()[k].double().sum())
-        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), ('after step', k, got, v)
+        t = model.state_dict()[k]
+        got = float(t.double().sum())
+        # Adam's first step moves every element by ~lr*sign(g): allow 0.1 % of the elements (those whose
+        # gradient is rounding noise) to land on the other side, on top of the relative tolerance
+        flips = 2 * cfg['lr'] * np.ceil(1e-3 * t.numel())
+        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)) + flips, ('after step', k, got, v)
 
 
 @pytest.mark.parametrize('B,M,H,W,drop,adv', [(3, 3, 64, 64, False, False), (2, 2, 96, 128, True, False), (2, 3, 64, 96, False, True)])
