@@ -375,7 +375,7 @@ struct WgradParams {
 #define WG_TAB_INTS 192   // tab_in[128] tap_xoff[16] + pad
 
 template <int J>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* tab_in = reinterpret_cast<int*>(smem);
     int* tab_pos = tab_in + 128;          // packed (n,a,b) validity -> dy pixel index or -1 (per tile, rebuilt)
@@ -419,9 +419,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
     __syncthreads();
     // positions handled by this wave: pairs q = wave + 4*pp, position m = 2q + half
-    int aoff[16];
-#pragma unroll
-    for (int pp = 0; pp < 16; ++pp) aoff[pp] = tab_in[2 * (wave + 4 * pp) + half];
 
     f32x16 acc[J];
 #pragma unroll
@@ -506,11 +503,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) bsum += dys[(part * 16 + r) * 32 + co_];
         }
-#pragma unroll
+#pragma unroll 4
         for (int pp = 0; pp < 16; ++pp) {
             const int m = 2 * (wave + 4 * pp) + half;
             const float bv = dys[m * 32 + e];
-            const float* xr = xs + aoff[pp];
+            const float* xr = xs + tab_in[m];
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 float av = xr[loff[j]];

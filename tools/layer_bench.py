@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv entry points at the bench configuration (B=32, M=4, 256x256):
+every distinct (Ci, Co, k, stride, H, W) of the hot path, forward / data-gradient /
+weight-gradient, HIP events on the launch stream.  Prints a table sorted by the layer's
+share of one training step (calls/step from SURVEY.md Appendix A)."""
+import argparse
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mrdis  # noqa: E402
+
+hip = mrdis.hip
+
+
+def layers(B, H, W):
+    """(name, Ci, Co, k, stride, pad, Hin, Win, calls_per_step, needs_dgrad_calls)"""
+    L = []
+    # anatomy encoder (8 calls/step; first-layer dgrad only in pass 2 -> 4 calls)
+    c = 32
+    L.append(('ana.down_1', 7, c, 4, 2, 1, H, W, 8, 4))
+    chans = [(c, 2 * c), (2 * c, 4 * c), (4 * c, 8 * c), (8 * c, 8 * c)]
+    h, w = H // 2, W // 2
+    for i, (a, b) in enumerate(chans):
+        L.append((f'ana.down_{i + 2}', a, b, 4, 2, 1, h, w, 8, 8)); h //= 2; w //= 2
+    # anatomy decoder: conv on the x2-upsampled map
+    ups = [('up_4', 8 * c, 8 * c, H // 16), ('up_3', 16 * c, 4 * c, H // 8), ('up_2', 8 * c, 2 * c, H // 4),
+           ('up_1', 4 * c, c, H // 2), ('output', 2 * c, 4, H)]
+    for n, a, b, hh in ups:
+        L.append((f'ana.{n}', a, b, 3, 1, 1, hh, hh * W // H, 8, 8))
+    # modality encoder
+    me = [(7, 16), (16, 32), (32, 64), (64, 128), (128, 128)]
+    h, w = H, W
+    for i, (a, b) in enumerate(me):
+        L.append((f'mod.conv{i + 1}', a, b, 3, 2, 1, h, w, 8, 4 if i == 0 else 8)); h //= 2; w //= 2
+    # SPADE blocks (16 decoder calls/step)
+    sp = [(128, 128, 32), (128, 128, 16), (128, 128, 8), (128, 64, 4), (64, 32, 2), (32, 16, 1)]
+    for i, (ci, co, d) in enumerate(sp):
+        hh, ww = H // d, W // d
+        L.append((f'sp{i + 1}.si', 4, ci, 3, 1, 1, hh, ww, 16, 16))
+        L.append((f'sp{i + 1}.gamma/beta', ci, ci, 3, 1, 1, hh, ww, 32, 32))
+        L.append((f'sp{i + 1}.out', ci, co, 3, 1, 1, hh, ww, 16, 16))
+    L.append(('dec.out1x1', 16, 7, 1, 1, 0, H, W, 16, 16))
+    return L
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--hw', type=int, nargs=2, default=[256, 256])
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    B, (H, W) = a.batch, a.hw
+    rows = []
+    for name, ci, co, k, s, p, hi, wi, calls, dcalls in layers(B, H, W):
+        if a.only and a.only not in name:
+            continue
+        x = torch.randn(B, ci, hi, wi, device=dev).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(k * k, ci, co, device=dev) * 0.05
+        wk = wt.permute(0, 2, 1).contiguous()
+        bias = torch.zeros(co, device=dev)
+        ho, wo = hip.conv_out_hw(hi, wi, k, k, s, p)
+        dy = torch.randn(B, co, ho, wo, device=dev).contiguous(memory_format=torch.channels_last)
+        flop = 2.0 * k * k * ci * co * B * ho * wo
+        byts = 4.0 * (B * ci * hi * wi + B * co * ho * wo)
+        tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p), a.iters)
+        td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p), a.iters)
+        tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p), a.iters)
+        rows.append((name, ci, co, k, s, hi, wi, calls, flop, byts, tf, td, tw, dcalls))
+        del x, dy
+    tot = sum(r[10] * r[7] + r[11] * r[13] + r[12] * r[7] for r in rows)
+    print(f'{"layer":18s} {"Ci":>4s} {"Co":>4s} k s {"HxW":>9s} calls {"GF":>7s} | {"fwd us":>8s} {"TF/s":>6s} {"GB/s":>6s} | {"dgrad us":>8s} {"TF/s":>6s} | '
+          f'{"wgrad us":>8s} {"TF/s":>6s} | step ms  share')
+    for r in sorted(rows, key=lambda r: -(r[10] * r[7] + r[11] * r[13] + r[12] * r[7])):
+        name, ci, co, k, s, hi, wi, calls, flop, byts, tf, td, tw, dcalls = r
+        ms = (tf * calls + td * dcalls + tw * calls) / 1e3
+        print(f'{name:18s} {ci:4d} {co:4d} {k} {s} {hi:4d}x{wi:<4d} {calls:5d} {flop / 1e9:7.2f} | {tf:8.1f} {flop / tf / 1e6:6.1f} {byts / tf / 1e3:6.0f} | '
+              f'{td:8.1f} {flop / td / 1e6:6.1f} | {tw:8.1f} {flop / tw / 1e6:6.1f} | {ms:7.2f} {100 * ms * 1e3 / tot:5.1f}%')
+    print(f'conv total per step: {tot / 1e3:.1f} ms')
+
+
+if __name__ == '__main__':
+    main()
