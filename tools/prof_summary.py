@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into the small summaries committed under profiles/.
+
+  prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title]
+  prof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substr> <grid>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def stats(stats_csv, trace_csv, out, title):
+    rows = list(csv.DictReader(open(stats_csv)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    lines = [f'# {title}', '', f'total kernel time {tot / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in rows)} dispatches', '',
+             '## rocprofv3 --kernel-trace --stats (kernel_stats.csv, top 30)', '',
+             '| kernel | calls | total ms | avg us | min us | max us | % |', '|---|---|---|---|---|---|---|']
+    for r in rows[:30]:
+        lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
+                     f"{float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+    agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for r in csv.DictReader(open(trace_csv)):
+        name = r['Kernel_Name'].split('(')[0][:60]
+        key = (name, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['LDS_Block_Size'], r['VGPR_Count'])
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        a = agg[key]; a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    lines += ['', '## per (kernel, workgroups) from kernel_trace.csv (top 40 by total time)', '',
+              '| kernel | workgroups | LDS B | VGPR | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|---|---|---|']
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        lines.append(f'| `{k[0]}` | {k[1]} | {k[2]} | {k[3]} | {a[0]} | {a[1] / 1e3:.3f} | {a[1] / a[0]:.2f} | {a[2]:.2f} | {a[3]:.2f} |')
+    open(out, 'w').write('\n'.join(lines) + '\n')
+
+
+def pmc(fetch_csv, write_csv, out, substr, grid):
+    def mean(path, counter):
+        v = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
+             if r['Counter_Name'] == counter and substr in r['Kernel_Name'] and (not grid or r['Grid_Size'] == grid)]
+        return (sum(v) / len(v), len(v)) if v else (None, 0)
+    f, nf = mean(fetch_csv, 'FETCH_SIZE')
+    w, nw = mean(write_csv, 'WRITE_SIZE')
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half
+    # of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane and dword stores.
+    res = {'kernel': substr, 'grid_size': grid, 'launches_fetch': nf, 'launches_write': nw,
+           'FETCH_SIZE_KiB_per_launch': f, 'WRITE_SIZE_KiB_per_launch': w,
+           'hbm_read_bytes_per_launch': None if f is None else 2 * f * 1024,
+           'hbm_write_bytes_per_launch': None if w is None else w * 1024,
+           'hbm_bytes_per_launch': None if (f is None or w is None) else 2 * f * 1024 + w * 1024,
+           'correction': 'read = 2 x FETCH_SIZE x 1024 (gfx950 half-count), write = WRITE_SIZE x 1024'}
+    json.dump(res, open(out, 'w'), indent=1)
+    print(res)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 summary')
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else '')

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): collects the rocprofv3 summaries that profiles/ keeps.
+#   tools/profile_round.sh r01
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ns_fetch -- python tools/northstar_conv.py 10 > $OUT/ns_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ns_write -- python tools/northstar_conv.py 10 > $OUT/ns_write.log 2>&1
+python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py ($TAG)"
+python tools/prof_summary.py pmc $OUT/ns_fetch_counter_collection.csv $OUT/ns_write_counter_collection.csv $OUT/northstar_conv_pmc.json tapconv ""
+rm -f $OUT/*_kernel_trace.csv $OUT/*_counter_collection.csv
+ls -la $OUT
