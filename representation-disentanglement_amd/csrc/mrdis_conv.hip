@@ -26,6 +26,7 @@
 // workgroups and waves; partial 32x32 slabs are written once and summed in a
 // fixed order by a second kernel (bit-reproducible, no float atomics).
 #include "mrdis_common.h"
+#include <stdlib.h>
 
 #define TC_BM 128
 #define TC_TAB_INTS 320   // tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad
@@ -42,9 +43,10 @@ struct TapConvParams {
     int tilesA, tilesB, tilesN, coTiles;
     int epilogue;
     int vec_in, vec_w;
+    int prefetch;                 // register-prefetch pipeline usable (vector paths + item counts fit)
 };
 
-template <int KC, int BN>
+template <int KC, int BN, bool PF>
 __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     constexpr int S = KC + 1;
     constexpr int WAVES_N = (BN == 32) ? 1 : 2;
@@ -110,6 +112,153 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     const int npix_in = p.NB * tinHW;
     const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
 
+    // ---- one KC-chunk of MFMAs, every tap out of LDS.  Operands of the NEXT group of k-steps are read
+    // (register double buffer) before the MFMAs of the current group issue, and sched_barriers keep
+    // that order, so a 64-cycle MFMA never waits on an LDS round trip; the next tap's offset is
+    // fetched a whole tap ahead.
+    constexpr int MPS = MSUB * NSUB;                         // MFMAs per k-step
+    constexpr int G0 = MPS >= 4 ? 1 : (MPS == 2 ? 2 : 4);
+    constexpr int G = (KC / 2 < G0) ? KC / 2 : G0;           // k-steps per group (>= 256 MFMA cycles when possible)
+    constexpr int NG = (KC / 2) / G;
+    auto compute_chunk = [&]() {
+        float an[G][MSUB], bn[G][NSUB];
+        int toff = tap_xoff[0];
+        int toff_n = tap_xoff[p.ntaps > 1 ? 1 : 0];
+#pragma unroll
+        for (int s_ = 0; s_ < G; ++s_) {
+#pragma unroll
+            for (int i = 0; i < MSUB; ++i) an[s_][i] = xs[abase[i] + toff + 2 * s_];
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) bn[s_][j] = ws[bbase + 2 * s_ * BN + j * 32];
+        }
+        for (int t = 0; t < p.ntaps; ++t) {
+            const float* wt = ws + t * (KC * BN) + bbase;
+            const int tn = (t + 1 < p.ntaps) ? t + 1 : t;
+            const float* wtn = ws + tn * (KC * BN) + bbase;
+            const int toff_nn = tap_xoff[(t + 2 < p.ntaps) ? t + 2 : tn];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float av[G][MSUB], bv[G][NSUB];
+#pragma unroll
+                for (int s_ = 0; s_ < G; ++s_) {
+#pragma unroll
+                    for (int i = 0; i < MSUB; ++i) av[s_][i] = an[s_][i];
+#pragma unroll
+                    for (int j = 0; j < NSUB; ++j) bv[s_][j] = bn[s_][j];
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < G; ++s_) {
+                    if (g + 1 < NG) {
+                        const int kk = (g + 1) * G + s_;
+#pragma unroll
+                        for (int i = 0; i < MSUB; ++i) an[s_][i] = xs[abase[i] + toff + 2 * kk];
+#pragma unroll
+                        for (int j = 0; j < NSUB; ++j) bn[s_][j] = wt[2 * kk * BN + j * 32];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < MSUB; ++i) an[s_][i] = xs[abase[i] + toff_n + 2 * s_];
+#pragma unroll
+                        for (int j = 0; j < NSUB; ++j) bn[s_][j] = wtn[2 * s_ * BN + j * 32];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s_ = 0; s_ < G; ++s_)
+#pragma unroll
+                    for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NSUB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s_][i], bv[s_][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            toff = toff_n; toff_n = toff_nn;
+        }
+    };
+
+    auto compute_chunk_legacy = [&]() {
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = tap_xoff[t];
+            const float* wt = ws + t * (KC * BN) + bbase;
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                float av[MSUB], bv[NSUB];
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i) av[i] = xs[abase[i] + toff + 2 * kk];
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) bv[j] = wt[2 * kk * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NSUB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    const bool legacy = (p.epilogue & 0x400) != 0;
+
+    if constexpr (PF) {
+        // ---- software pipeline: the global loads of chunk c+1 are in flight (registers) while chunk c
+        // runs out of LDS; staging descriptors (tile geometry) are chunk-invariant and computed once.
+        constexpr int XR = 6, WR = 9, QX = KC / 4, QW = BN / 4;
+        const int nx = npix_in * QX, nw = p.ntaps * KC * QW;
+        long long xg[XR]; int xl[XR];
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + it * 256;
+            xg[it] = -1; xl[it] = -1;
+            if (idx < nx) {
+                const int pi = idx / QX, q = idx - pi * QX;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix;
+                xl[it] = pi * S + 4 * q;
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                    xg[it] = ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + 4 * q;
+            }
+        }
+        float4 xr[XR], wr[WR];
+        auto load_chunk = [&](int c0) {
+#pragma unroll
+            for (int it = 0; it < XR; ++it) {
+                const int q = (tid + it * 256) % QX;
+                xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xg[it] >= 0 && c0 + 4 * q < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
+            }
+#pragma unroll
+            for (int it = 0; it < WR; ++it) {
+                const int idx = tid + it * 256;
+                wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nw) {
+                    const int row = idx / QW, q = idx - row * QW;
+                    const int t = row / KC, k = row - t * KC;
+                    const int c = c0 + k, co = co0 + 4 * q;
+                    if (c < p.Cin && co < p.Cout)
+                        wr[it] = *reinterpret_cast<const float4*>(p.w + ((long long)tap_widx[t] * p.Cin + c) * p.Cout + co);
+                }
+            }
+        };
+        auto store_chunk = [&]() {
+#pragma unroll
+            for (int it = 0; it < XR; ++it)
+                if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+#pragma unroll
+            for (int it = 0; it < WR; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < nw) *reinterpret_cast<float4*>(ws + 4 * idx) = wr[it];
+            }
+        };
+        const bool ab_nostage = (p.epilogue & 0x100) != 0, ab_nomfma = (p.epilogue & 0x200) != 0;   // timing ablations (debug)
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+        for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+            const bool more = c0 + KC < p.Cin;
+            if (more && !ab_nostage) load_chunk(c0 + KC);
+            if (!ab_nomfma) { if (legacy) compute_chunk_legacy(); else compute_chunk(); }
+            if (more) { __syncthreads(); if (!ab_nostage) store_chunk(); __syncthreads(); }
+        }
+    } else
     for (int c0 = 0; c0 < p.Cin; c0 += KC) {
         if (c0) __syncthreads();
         // ---- stage the halo'd input tile: xs[pixel][KC+1]
@@ -165,24 +314,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
             }
         }
         __syncthreads();
-        // ---- every tap out of LDS
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = tap_xoff[t];
-            const float* wt = ws + t * (KC * BN) + bbase;
-#pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float av[MSUB], bv[NSUB];
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i) av[i] = xs[abase[i] + toff + 2 * kk];
-#pragma unroll
-                for (int j = 0; j < NSUB; ++j) bv[j] = wt[2 * kk * BN + j * 32];
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NSUB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-        }
+        if (legacy) compute_chunk_legacy(); else compute_chunk();
     }
 
     // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (position)
@@ -227,7 +359,8 @@ static TileChoice choose_tile(int N, int A, int B) {
 
 template <int KC, int BN>
 static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, hipStream_t s) {
-    hipLaunchKernelGGL((tapconv_kernel<KC, BN>), dim3(nblk), dim3(256), lds, s, p);
+    if (p.prefetch) hipLaunchKernelGGL((tapconv_kernel<KC, BN, true>), dim3(nblk), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, false>), dim3(nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -257,16 +390,24 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     int BN = p.Cout <= 32 ? 32 : (p.Cout <= 64 ? 64 : 128);
     if (BN == 128 && ptiles * mrdis_cdiv(p.Cout, 128) < 512) BN = 64;   // keep the chip full on small grids
     if (BN == 64 && p.Cout > 32 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
+    p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
+    p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
+    if (const char* e = getenv("MRDIS_DEBUG_KC")) { const int v = atoi(e); if ((v == 4 || v == 8 || v == 16) && v < KC) KC = v; }
     const size_t LDS_MAX = 64 * 1024;
-    while (tapconv_lds(p, KC, BN) > LDS_MAX && KC > 4) KC >>= 1;
+    const long long npix_in = (long long)p.NB * p.TinH * p.TinW;
+    auto fits_pf = [&](int kc, int bn) { return npix_in * (kc / 4) <= 6 * 256 && (long long)p.ntaps * kc * (bn / 4) <= 9 * 256; };
+    const bool want_pf = p.vec_in && p.vec_w;
+    while ((tapconv_lds(p, KC, BN) > LDS_MAX || (want_pf && !fits_pf(KC, BN))) && KC > 4) KC >>= 1;
     while (tapconv_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
     if (tapconv_lds(p, KC, BN) > LDS_MAX) return MRDIS_EUNSUPPORTED;
+    p.prefetch = want_pf && fits_pf(KC, BN) && p.Cin > KC;      // single-chunk layers keep the low-register kernel
+    if (const char* e = getenv("MRDIS_DEBUG_ABLATE")) p.epilogue |= (atoi(e) & 3) << 8;
+    if (const char* e = getenv("MRDIS_DEBUG_NOPF")) { if (atoi(e)) p.prefetch = 0; }
+    if (const char* e = getenv("MRDIS_DEBUG_LEGACY")) { if (atoi(e)) p.epilogue |= 0x400; }
     p.coTiles = mrdis_cdiv(p.Cout, BN);
     const long long nblk = ptiles * p.coTiles;
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
-    p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
-    p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     const size_t lds = tapconv_lds(p, KC, BN);
 #define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, s)
     TC_CASE(4, 32); TC_CASE(4, 64); TC_CASE(4, 128);
@@ -288,6 +429,257 @@ static int check_conv_geom(int N, int H, int W, int Ci, int Co, int kh, int kw, 
     return MRDIS_OK;
 }
 
+
+// =========================================================================== Cin = 4 direct conv (north star)
+// 3x3 / stride 1 / pad 1 convolution of a 4-channel map (the `si_layers` of every SPADE block,
+// reference model.py:2433; SURVEY.md 8d: x (32,4,240,240) -> y (32,32,240,240)).  K = 9 taps x 4
+// channels = 36 = 18 MFMA k-steps exactly, arithmetic intensity 16 FLOP/B: HBM and the fp32 MFMA
+// pipe are both near their floors, so nothing may be wasted:
+//   * no LDS, no barriers: a wave owns a strip of 32 output positions; lane (m, half) fetches its
+//     own 3x3 window as nine 8-byte loads (channels 2*half, 2*half+1) -- the two half-waves
+//     together read each 16-byte pixel exactly once per tap, re-reads of the halo are L1 hits;
+//   * the whole filter lives in registers (18 * NS VGPRs) for the lifetime of the wave;
+//   * persistent waves walk the strips with a grid stride; the loads of strip i+1 are issued
+//     before the 18*NS MFMAs of strip i;
+//   * accumulators start at the bias; every store instruction writes two full 128-byte lines.
+struct C4Params {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, H, W, ldx, Co, ldy;
+    int TW, TH;                  // strip shape: TW x TH = 32 positions (32x1 or 16x2)
+    int tilesW, tilesH;          // per image
+    long long ntiles;
+    int lrelu;
+    int dbg;                     // timing ablations: 1 no MFMA, 2 no stores, 4 no strip loads
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
+    const int ty = m / p.TW, tx = m - ty * p.TW;
+    // wave-uniform strip bookkeeping lives in SGPRs (readfirstlane makes the uniformity provable)
+    const int wave_in_blk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)gridDim.x * 4;
+    const int ntiles = (int)p.ntiles;
+    const int cot = blockIdx.y;                         // 32*NS couts per y-slice of the grid
+    // filter -> registers: b[t][j][ns] = w[t][2*half + j][co]
+    float b[9][2][NS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const int co = (cot * NS + ns) * 32 + m;
+                const int coc = co < p.Co ? co : p.Co - 1;
+                const float v = p.w[(t * 4 + 2 * half + j) * p.Co + coc];
+                b[t][j][ns] = co < p.Co ? v : 0.f;
+            }
+    // operands are swapped (A = filter, B = pixels), so D[cout][position]: a lane owns ONE position and
+    // 16 couts (r&3) + 8*(r>>2) + 4*half -> four 16-byte stores per strip instead of sixteen 4-byte ones.
+    f32x16 bv[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (cot * NS + ns) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int coc = co < p.Co ? co : p.Co - 1;
+            const float v = p.bias != nullptr ? p.bias[coc] : 0.f;
+            bv[ns][r] = co < p.Co ? v : 0.f;
+        }
+    const bool vec_st = (p.Co % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
+    const bool full_co = (p.Co % (32 * NS)) == 0;
+    const int tpi = p.tilesW * p.tilesH;
+    // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
+    const int d_n = nwaves / tpi, d_rem = nwaves - d_n * tpi, d_th = d_rem / p.tilesW, d_tw = d_rem - d_th * p.tilesW;
+    int tile = (int)blockIdx.x * 4 + wave_in_blk;
+    int cn = tile / tpi, c_rem = tile - cn * tpi, cth = c_rem / p.tilesW, ctw = c_rem - cth * p.tilesW;
+    auto advance = [&](int& n, int& th, int& tw) {
+        tw += d_tw; if (tw >= p.tilesW) { tw -= p.tilesW; th += 1; }
+        th += d_th; if (th >= p.tilesH) { th -= p.tilesH; n += 1; }
+        n += d_n;
+    };
+    // Address arithmetic is the hidden cost of this kernel (the waves are VALU-issue bound long before
+    // the matrix or memory pipes fill), so a strip computes 3 clamped row bases + 3 clamped columns
+    // once and forms the 9 tap offsets with one 32-bit add each; validity is a 3x3 outer product of
+    // row/column bits.  Loads are unconditional from the clamped address and zeroed at first use.
+    auto strip_setup = [&](int n, int th, int tw, const float*& img, int (&voff)[9], unsigned& okmask) {
+        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
+        int rb[3], cb[3];
+        unsigned rm = 0, cm = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hh = h + r - 1;
+            rm |= ((unsigned)hh < (unsigned)p.H ? 1u : 0u) << r;
+            rb[r] = (hh < 0 ? 0 : (hh >= p.H ? p.H - 1 : hh)) * p.W;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int ww = w_ + c - 1;
+            cm |= ((unsigned)ww < (unsigned)p.W ? 1u : 0u) << c;
+            cb[c] = ww < 0 ? 0 : (ww >= p.W ? p.W - 1 : ww);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) voff[3 * r + c] = (rb[r] + cb[c]) * p.ldx + 2 * half;
+        okmask = ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u);
+        img = p.x + (long long)n * p.H * p.W * p.ldx;      // wave-uniform
+    };
+    // (An inline-asm load with hand-counted vmcnt was tried here and rejected: hipcc may re-home the
+    // destination registers while the load is in flight, and a late write-back then clobbers whatever
+    // lives there -- store addresses included.  Compiler-tracked loads only.)
+    auto load_tap = [&](const float* img, int voff, float2& dst) {
+        dst = *reinterpret_cast<const float2*>(img + voff);
+    };
+#define C4_WAIT(N, r) do { } while (0)
+    auto store_group = [&](const f32x16 (&acc)[NS], int n, int th, int tw, int g) {
+        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
+        if (h < p.H && w_ < p.W && !(p.dbg & 2)) {
+            float* dst = p.y + ((long long)(n * p.H + h) * p.W + w_) * p.ldy;
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                const int co = (cot * NS + ns) * 32 + 8 * g + 4 * half;
+                float4 v = make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]);
+                if (p.lrelu) {
+                    v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+                }
+                if (vec_st && (full_co || co + 3 < p.Co)) *reinterpret_cast<float4*>(dst + co) = v;
+                else {
+                    if (co < p.Co) dst[co] = v.x;
+                    if (co + 1 < p.Co) dst[co + 1] = v.y;
+                    if (co + 2 < p.Co) dst[co + 2] = v.z;
+                    if (co + 3 < p.Co) dst[co + 3] = v.w;
+                }
+            }
+        }
+    };
+
+    // Register pipeline, two strips deep: a_cur (strip i, masked), and two raw buffers that alternate:
+    // iteration i loads strip i+2 into R[i&1] and afterwards consumes R[(i+1)&1] (strip i+1, loaded
+    // one iteration earlier).  No register copy ever touches a load that is still in flight, and all
+    // loads of an iteration are issued BEFORE its stores (vmcnt retires in order, so waiting for the
+    // older loads never waits for store completion).
+    float2 a_cur[9], r0[9], r1[9];
+    unsigned m0 = 0, m1 = 0;
+    if (tile >= ntiles) return;
+    int n1 = cn, th1 = cth, tw1 = ctw;
+    advance(n1, th1, tw1);
+    {
+        unsigned mc = 0;
+        const float* img; int vo[9];
+        strip_setup(cn, cth, ctw, img, vo, mc);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) load_tap(img, vo[t], a_cur[t]);
+        if (tile + nwaves < ntiles) {
+            strip_setup(n1, th1, tw1, img, vo, m1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) load_tap(img, vo[t], r1[t]);     // strip 1 -> R[(0+1)&1]
+        }
+        C4_WAIT(0, a_cur);
+        C4_WAIT(0, r1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) if (!((mc >> t) & 1u)) a_cur[t] = make_float2(0.f, 0.f);
+    }
+    f32x16 prev[NS];
+    int pn = 0, pth = 0, ptw = 0;
+    bool have_prev = false;
+
+    auto iteration = [&](float2 (&r_load)[9], unsigned& m_load, float2 (&r_use)[9], unsigned& m_use) {
+        int n2 = n1, th2 = th1, tw2 = tw1;
+        advance(n2, th2, tw2);
+        const bool have_n2 = (long long)tile + 2LL * nwaves < ntiles && !(p.dbg & 4);
+        m_load = 0;
+        const float* img2 = p.x; int vo2[9];
+        if (have_n2) strip_setup(n2, th2, tw2, img2, vo2, m_load);
+        f32x16 acc[NS];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ns] = bv[ns];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (!(p.dbg & 1))
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], a_cur[t].x, acc[ns], 0, 0, 0);
+                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][1][ns], a_cur[t].y, acc[ns], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 5 && have_n2) {
+                load_tap(img2, vo2[2 * t], r_load[2 * t]);
+                if (2 * t + 1 < 9) load_tap(img2, vo2[2 * t + 1], r_load[2 * t + 1]);
+            }
+            if (t >= 5 && have_prev) store_group(prev, pn, pth, ptw, t - 5);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) prev[ns] = acc[ns];
+        pn = cn; pth = cth; ptw = ctw; have_prev = true;
+        cn = n1; cth = th1; ctw = tw1;
+        n1 = n2; th1 = th2; tw1 = tw2;
+        // first use of the loads issued one iteration ago.  Younger than them are exactly this
+        // iteration's 9 loads (+ up to 4 stores behind those): vmcnt(9) can only over-wait.  Without new
+        // loads in this iteration the count would under-wait, so drain instead (wave-uniform branch).
+        if (have_n2) { C4_WAIT(9, r_use); } else { C4_WAIT(0, r_use); }
+        if (__all(m_use == 0x1ffu)) {          // interior strip: nothing to zero (wave-uniform branch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a_cur[t] = r_use[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a_cur[t] = ((m_use >> t) & 1u) ? r_use[t] : make_float2(0.f, 0.f);
+        }
+    };
+    while (tile < ntiles) {
+        iteration(r0, m0, r1, m1);
+        tile += nwaves;
+        if (tile >= ntiles) break;
+        iteration(r1, m1, r0, m0);
+        tile += nwaves;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store_group(prev, pn, pth, ptw, g);
+}
+
+static bool c4_eligible(const float* x, int ldx, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    return Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16;
+}
+
+static int run_c4conv(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                      int N, int H, int W, int Co, int epilogue, hipStream_t s) {
+    C4Params p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.ldx = ldx; p.Co = Co; p.ldy = ldy;
+    p.lrelu = (epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    if (const char* e = getenv("MRDIS_DEBUG_C4")) p.dbg = atoi(e);
+    // strip shape: 32x1 unless a 16x2 strip wastes fewer positions
+    const double u32 = (double)W / (mrdis_cdiv(W, 32) * 32.0);
+    const double u16 = ((double)W / (mrdis_cdiv(W, 16) * 16.0)) * ((double)H / (mrdis_cdiv(H, 2) * 2.0));
+    double best = u32; p.TW = 32; p.TH = 1;
+    if (u16 > best + 1e-9) { best = u16; p.TW = 16; p.TH = 2; }
+    if (W <= 8) { p.TW = 8; p.TH = 4; }
+    p.tilesW = mrdis_cdiv(W, p.TW); p.tilesH = mrdis_cdiv(H, p.TH);
+    p.ntiles = (long long)N * p.tilesW * p.tilesH;
+    const int co32 = mrdis_cdiv(Co, 32);
+    const int NS = (co32 % 2 == 0 && co32 >= 2) ? 2 : 1;
+    const int ny = co32 / NS;
+    long long blocks = (p.ntiles + 3) / 4;
+    // persistent grid: exactly the number of workgroups the chip holds at once (one wave of workgroups,
+    // no tail round); residency is queried once per instantiation.
+    static int occ[3] = {0, 0, 0}, ncu = 0;
+    if (!occ[NS]) {
+        int o = 0;
+        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2>, 256, 0);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1>, 256, 0);
+        occ[NS] = o > 0 ? o : 2;
+        hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev);
+        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    long long cap = (long long)ncu * occ[NS] / ny; if (cap < ncu) cap = ncu;
+    if (blocks > cap) blocks = cap;
+    if (NS == 2) hipLaunchKernelGGL((c4conv_kernel<2>), dim3((int)blocks, ny), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((c4conv_kernel<1>), dim3((int)blocks, ny), dim3(256), 0, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
                                 float* y, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, void* stream) {
@@ -295,6 +687,8 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
+    if (c4_eligible(x, ldx, Ci, Co, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
+        return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     TapConvParams p{};
     p.in = x; p.w = w_tck; p.bias = bias; p.out = y;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Ci; p.ldin = ldx;
@@ -503,16 +897,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) bsum += dys[(part * 16 + r) * 32 + co_];
         }
-#pragma unroll 4
-        for (int pp = 0; pp < 16; ++pp) {
-            const int m = 2 * (wave + 4 * pp) + half;
-            const float bv = dys[m * 32 + e];
-            const float* xr = xs + tab_in[m];
+        {   // software-pipelined over the wave's 16 position pairs: operands of pair pp+1 (and the LDS
+            // offset of pair pp+2) are fetched before the J MFMAs of pair pp issue.
+            float an[J], bn;
+            int ti_nn;
+            {
+                const int m0 = 2 * wave + half;
+                const int ti0 = tab_in[m0];
+                bn = dys[m0 * 32 + e];
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                float av = xr[loff[j]];
-                av = ((lvalid >> j) & 1u) ? av : 0.f;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+                for (int j = 0; j < J; ++j) an[j] = xs[ti0 + loff[j]];
+                ti_nn = tab_in[2 * (wave + 4) + half];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                float av[J];
+                const float bv = bn;
+#pragma unroll
+                for (int j = 0; j < J; ++j) av[j] = ((lvalid >> j) & 1u) ? an[j] : 0.f;
+                const int pn = pp + 1 < 16 ? pp + 1 : 15, pnn = pp + 2 < 16 ? pp + 2 : 15;
+                const int m1 = 2 * (wave + 4 * pn) + half;
+                bn = dys[m1 * 32 + e];
+#pragma unroll
+                for (int j = 0; j < J; ++j) an[j] = xs[ti_nn + loff[j]];
+                ti_nn = tab_in[2 * (wave + 4 * pnn) + half];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -94,6 +94,19 @@ def test_conv_fwd_bwd(mrdis, case):
     close(db, b.grad, rtol=2e-4, what='dbias')
 
 
+def test_conv_c4_persistent_pipeline(mrdis):
+    """Cin = 4 direct kernel with enough strips (> 2 per resident wave) to run its steady-state
+    register pipeline, ragged right edge included; with bias and fused LeakyReLU."""
+    hip = mrdis.hip
+    for (N, H, W, Co) in [(16, 128, 136, 32), (12, 120, 240, 64), (3, 250, 250, 128)]:
+        x = rnd((N, 4, H, W), 50); w = rnd((Co, 4, 3, 3), 51, 0.2); b = rnd((Co,), 52, 0.1)
+        want = F.conv2d(x, w, b, 1, 1)
+        got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
+        close(got, want, what=f'c4 {N}x{H}x{W}->{Co}')
+        got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1, lrelu=True)
+        close(got, F.leaky_relu(want, 0.2), what='c4 lrelu')
+
+
 def test_conv_strided_views(mrdis):
     """channel slices of wider NHWC buffers as input and output (ld != C)."""
     hip = mrdis.hip
