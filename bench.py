@@ -82,7 +82,7 @@ def roofline_conv(mrdis, dev, iters=20):
             traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
-    return {'bound': 'hbm', 'kernel': 'tapconv_kernel (3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC)',
+    return {'bound': 'hbm', 'kernel': 'c4conv_kernel<1> (3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC)',
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us, 2),
             'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us * 1e-6) / 1e12, 2)}

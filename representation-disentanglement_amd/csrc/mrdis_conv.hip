@@ -387,9 +387,11 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
     p.tilesA = mrdis_cdiv(p.A, p.TH); p.tilesB = mrdis_cdiv(p.B, p.TW); p.tilesN = mrdis_cdiv(p.N, p.NB);
     const long long ptiles = (long long)p.tilesA * p.tilesB * p.tilesN;
-    int BN = p.Cout <= 32 ? 32 : (p.Cout <= 64 ? 64 : 128);
-    if (BN == 128 && ptiles * mrdis_cdiv(p.Cout, 128) < 512) BN = 64;   // keep the chip full on small grids
-    if (BN == 64 && p.Cout > 32 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
+    // measured policy (tools/sweep.py, B=32 256x256 layer zoo): 64-wide cout tiles beat 128-wide ones on every
+    // layer (register pressure halves the residency of the 128 variant); small grids prefer 32.
+    int BN = p.Cout <= 32 ? 32 : 64;
+    if (BN == 64 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
+    if (const char* e = getenv("MRDIS_DEBUG_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
@@ -401,7 +403,9 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     while ((tapconv_lds(p, KC, BN) > LDS_MAX || (want_pf && !fits_pf(KC, BN))) && KC > 4) KC >>= 1;
     while (tapconv_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
     if (tapconv_lds(p, KC, BN) > LDS_MAX) return MRDIS_EUNSUPPORTED;
-    p.prefetch = want_pf && fits_pf(KC, BN) && p.Cin > KC;      // single-chunk layers keep the low-register kernel
+    // the register-prefetch pipeline pays once there are >= 8 channel chunks to pipeline over; with fewer
+    // chunks the extra VGPRs (lower residency) cost more than the hidden latency buys (tools/sweep.py)
+    p.prefetch = want_pf && fits_pf(KC, BN) && p.Cin >= 8 * KC;
     if (const char* e = getenv("MRDIS_DEBUG_ABLATE")) p.epilogue |= (atoi(e) & 3) << 8;
     if (const char* e = getenv("MRDIS_DEBUG_NOPF")) { if (atoi(e)) p.prefetch = 0; }
     if (const char* e = getenv("MRDIS_DEBUG_LEGACY")) { if (atoi(e)) p.epilogue |= 0x400; }
