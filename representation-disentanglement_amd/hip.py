@@ -252,15 +252,23 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
     return out, mean, rstd
 
 
-def instnorm_spade_bwd(dout, z, gamma, mean, rstd):
-    """returns (dz, dgamma); dbeta == dout and is not materialised."""
+def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False):
+    """returns (dz, dgamma); dbeta == dout and is not materialised.
+    fused_gb=True: returns (dz, dgb) with dgb (N,2C,H,W) = [dgamma | dout] in one buffer (the gradient of
+    a fused gamma+beta convolution output)."""
     lib = load()
     dout, lddo = nhwc(dout); z, ldz = nhwc(z); gamma, ldg = nhwc(gamma)
     N, C, H, W = z.shape
     dz = empty_nhwc(N, C, H, W, z.device)
-    dg = empty_nhwc(N, C, H, W, z.device)
     nb = lib.mrdis_instnorm_spade_bwd_workspace(N, H * W, C)
     ws = _ws(nb, z.device)
+    if fused_gb:
+        dgb = empty_nhwc(N, 2 * C, H, W, z.device)
+        _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
+                                          dgb.data_ptr(), 2 * C, dgb.data_ptr() + 4 * C, 2 * C, _ptr(ws), nb, N, H * W, C, _stream()),
+             'instnorm_spade_bwd')
+        return dz, dgb
+    dg = empty_nhwc(N, C, H, W, z.device)
     _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
                                       _ptr(dg), C, None, 0, _ptr(ws), nb, N, H * W, C, _stream()), 'instnorm_spade_bwd')
     return dz, dg

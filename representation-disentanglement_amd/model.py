@@ -269,12 +269,31 @@ class SPADEBlockNew(nn.Module):
         self.out = conv2d(in_num_ch, out_num_ch, 3, 1, padding=1)
 
     def forward(self, si, zi, inputs_type=None):
-        si = ops.bilinear(si, self.input_size, False)                     # :2432/:2441
+        # the resize depends on (s_i, scale) only, not on the modality type: one resize per step serves
+        # every decoder call that uses this s_i (autograd sums the gradients of all uses)
+        size = self.input_size
+        src = si                                   # the cache entry keeps `src` alive, so id(src) cannot be recycled
+        si = ops.step_cache(('bil', id(src), size), lambda: (src, ops.bilinear(src, size, False)))[1]     # :2432/:2441
         t = (inputs_type,) if self.is_cond else ()
         si_out = self.si_layers(si, *t)
-        gamma = self.gamma(si_out, *t)
-        beta = self.beta(si_out, *t)
-        mix = ops.instnorm_spade(zi, gamma, beta, self.zi_layers.eps)     # :2440 + :2446
+        if self.is_cond and (si_out.shape[0] == 1 or inputs_type.stride(0) == 0):
+            # gamma and beta read the same input with the same geometry: run them as ONE convolution with
+            # concatenated (mixed) filters -- one pass over si_out forward, one K-doubled pass backward
+            kh, kw = self.gamma.kernel_size
+            key = (id(self), 'gb', inputs_type.data_ptr(), inputs_type._version)
+
+            def fused():
+                g_tck, g_tkc = self.gamma._mixed(inputs_type[:1])
+                b_tck, b_tkc = self.beta._mixed(inputs_type[:1])
+                return (torch.cat([g_tck, b_tck], 2), torch.cat([g_tkc, b_tkc], 1),
+                        torch.cat([self.gamma.bias, self.beta.bias]))
+            w_tck, w_tkc, bias = ops.step_cache(key, fused)
+            gb = ops.conv2d(si_out, w_tck, w_tkc, bias, kh, kw, 1, self.gamma.padding[0])
+            mix = ops.instnorm_spade_gb(zi, gb, self.zi_layers.eps)       # :2440 + :2446
+        else:
+            gamma = self.gamma(si_out, *t)
+            beta = self.beta(si_out, *t)
+            mix = ops.instnorm_spade(zi, gamma, beta, self.zi_layers.eps)
         return self.out(mix, *t)
 
 

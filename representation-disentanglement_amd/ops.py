@@ -103,6 +103,29 @@ def instnorm_spade(z, gamma, beta, eps=1e-5):
     return _InstNormSpade.apply(z, gamma, beta, eps)
 
 
+class _InstNormSpadeGB(Function):
+    """Same op with gamma and beta delivered as the two channel halves of ONE tensor (the output of a
+    fused gamma+beta convolution); the backward writes [dgamma | dbeta] straight into one buffer."""
+
+    @staticmethod
+    def forward(ctx, z, gb, eps):
+        C = z.shape[1]
+        gamma, beta = gb[:, :C], gb[:, C:]
+        out, mean, rstd = hip.instnorm_spade_fwd(z, gamma, beta, eps)
+        ctx.save_for_backward(z, gb, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, gb, mean, rstd = ctx.saved_tensors
+        dz, dgb = hip.instnorm_spade_bwd(dout, z, gb[:, :z.shape[1]], mean, rstd, fused_gb=True)
+        return dz, dgb, None
+
+
+def instnorm_spade_gb(z, gb, eps=1e-5):
+    return _InstNormSpadeGB.apply(z, gb, eps)
+
+
 # --------------------------------------------------------------------------- resize / softmax / losses
 class _Bilinear(Function):
     @staticmethod
@@ -193,6 +216,12 @@ def mix_cache():
         yield
     finally:
         _MIX_CACHE = prev
+
+
+def step_cache(key, make):
+    """generic per-step memo (same scope as the mixed-kernel cache): e.g. the bilinear resizes of an
+    anatomy map s_i, which every SPADE block of every decoder call recomputes in the reference."""
+    return cached_mix(key, make)
 
 
 def cached_mix(key, make):
