@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
                     for (int i = 0; i < MSUB; ++i)
 #pragma unroll
                         for (int j = 0; j < NSUB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s_][i], bv[s_][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s_][j], av[s_][i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             toff = toff_n; toff_n = toff_nn;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
                 for (int i = 0; i < MSUB; ++i)
 #pragma unroll
                     for (int j = 0; j < NSUB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -317,23 +317,48 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
         if (legacy) compute_chunk_legacy(); else compute_chunk();
     }
 
-    // ---- epilogue: C/D layout col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (position)
+    // ---- epilogue.  The MFMA operands are swapped (A = filter, B = pixels), so D is [cout][position]:
+    // a lane owns ONE output position per M sub-tile (column lane&31) and the couts
+    // (r&3) + 8*(r>>2) + 4*(lane>>5) -> groups of four consecutive couts = one 16-byte store.  One address
+    // per lane and sub-tile, 4 stores per accumulator instead of 16 (the epilogue is issue-bound).
     const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+    const int half = lane >> 5;
+    const bool vec_out = (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0);
+    const bool vec_bias = p.bias != nullptr && (((uintptr_t)p.bias & 15) == 0);
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-        const int co = co0 + (wave_n * NSUB + j) * 32 + (lane & 31);
-        const bool cok = co < p.Cout;
-        const float bvv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+    for (int i = 0; i < MSUB; ++i) {
+        const int po = tab_out[(wave_m * MSUB + i) * 32 + (lane & 31)];
+        if (po < 0) continue;
+        float* dst = p.out + (long long)po * p.ldout;
 #pragma unroll
-        for (int i = 0; i < MSUB; ++i) {
+        for (int j = 0; j < NSUB; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int po = tab_out[(wave_m * MSUB + i) * 32 + row];
-                if (po >= 0 && cok) {
-                    float v = acc[i][j][r] + bvv;
-                    if (lrelu) v = v > 0.f ? v : 0.2f * v;
-                    p.out[(long long)po * p.ldout + co] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + (wave_n * NSUB + j) * 32 + 8 * g + 4 * half;
+                if (co >= p.Cout) continue;
+                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                const bool full = co + 3 < p.Cout;
+                if (p.bias != nullptr) {
+                    if (vec_bias && full) {
+                        const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
+                        v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    } else {
+                        v.x += p.bias[co];
+                        if (co + 1 < p.Cout) v.y += p.bias[co + 1];
+                        if (co + 2 < p.Cout) v.z += p.bias[co + 2];
+                        if (co + 3 < p.Cout) v.w += p.bias[co + 3];
+                    }
+                }
+                if (lrelu) {
+                    v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+                }
+                if (vec_out && full) *reinterpret_cast<float4*>(dst + co) = v;
+                else {
+                    dst[co] = v.x;
+                    if (co + 1 < p.Cout) dst[co + 1] = v.y;
+                    if (co + 2 < p.Cout) dst[co + 2] = v.z;
+                    if (co + 3 < p.Cout) dst[co + 3] = v.w;
                 }
             }
         }
