@@ -989,6 +989,197 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------- LDS-DMA variant (Ci % 32 == 0, Co % 32 == 0)
+// The plain kernel above is staging-bound: with 144+ accumulator registers only two workgroups fit
+// per CU and nothing hides the global->register->LDS round trip of the next tile.  Here both tiles
+// are rows of exactly 128 B ([pixel][32 ci] and [position][32 co]; for Ci >= 32 the A operand reads 32
+// consecutive channels of one pixel, so no padding is needed), which is the shape
+// `global_load_lds_dwordx4` wants: each wave-instruction lands 8 rows (1 KiB) straight in LDS with a
+// per-lane source address, out-of-image pixels / positions are redirected to a zero page.  The
+// tile after the current one is in flight (second LDS buffer, zero VGPRs) during the MFMAs; one barrier
+// per tile; all index arithmetic (divisions) is hoisted out of the tile loop.
+__device__ float g_mrdis_zero_page[64];
+
+#define WGD_XSLOTS 7
+template <int J>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, int XR /* staged x rows, multiple of 8 */) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tab_in = reinterpret_cast<int*>(smem);           // [128] position -> x row offset (floats)
+    float* dys0 = smem + 128;                             // [2][128*32]
+    float* xs0 = dys0 + 2 * 128 * 32;                     // [2][XR*32]
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, e = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int split = bid / p.base;
+    int b = bid - split * p.base;
+    const int coc = b % p.nCo; b /= p.nCo;
+    const int cic = b % p.nCi;
+    const int g = b / p.nCi;
+    const int c_lo = cic * 32, co_lo = coc * 32;
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
+    const int thw = p.TH * p.TW;
+
+    if (tid < 128) {
+        int tin = 0;
+        if (tid < npos) {
+            const int nb = tid / thw, rem = tid - nb * thw, ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * 32;
+        }
+        tab_in[tid] = tin;
+    }
+    // tile-invariant staging descriptors: which (image, row, col) of the tile this lane fetches per DMA slot
+    const int r8 = lane >> 3, c4 = (lane & 7) * 4;
+    int xd[WGD_XSLOTS], dd[4];
+#pragma unroll
+    for (int k = 0; k < WGD_XSLOTS; ++k) {
+        const int pi = 8 * (wave + 4 * k) + r8;
+        xd[k] = -1;
+        if (pi < npix_in) {
+            const int nb = pi / tinHW, rem = pi - nb * tinHW, iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            xd[k] = (nb << 20) | (iy << 10) | ix;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = 8 * (wave + 4 * k) + r8;
+        dd[k] = -1;
+        if (m < npos) {
+            const int nb = m / thw, rem = m - nb * thw, ty = rem / p.TW, tx = rem - ty * p.TW;
+            dd[k] = (nb << 20) | (ty << 10) | tx;
+        }
+    }
+    int loff[J];
+    unsigned lvalid = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int tap = g * J + j;
+        const bool ok = tap < p.ntaps;
+        loff[j] = ok ? ((p.dh[tap] - p.dh_min) * p.TinW + (p.dw[tap] - p.dw_min)) * 32 + e : 0;
+        lvalid |= (ok ? 1u : 0u) << j;
+    }
+    const float* zero = g_mrdis_zero_page + c4;
+    const int xslots = XR >> 3;
+
+    auto issue_tile = [&](int tile, int buf) {
+        int tt = tile;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int tn = tt / p.tilesA;
+        const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
+        const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+        float* xs = xs0 + buf * (XR * 32);
+        float* dys = dys0 + buf * (128 * 32);
+#pragma unroll
+        for (int k = 0; k < WGD_XSLOTS; ++k) {
+            const int q = wave + 4 * k;                 // wave-uniform slot
+            if (q < xslots) {
+                const float* src = zero;
+                if (xd[k] >= 0) {
+                    const int n = n0 + (xd[k] >> 20), h = h_org + ((xd[k] >> 10) & 1023), w_ = w_org + (xd[k] & 1023);
+                    if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                        src = p.x + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c_lo + c4;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + q * 256), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = wave + 4 * k;
+            const float* src = zero;
+            if (dd[k] >= 0) {
+                const int n = n0 + (dd[k] >> 20), a = a0 + ((dd[k] >> 10) & 1023), bb = b0 + (dd[k] & 1023);
+                if (n < p.N && a < p.A && bb < p.B) src = p.dy + ((long long)(n * p.A + a) * p.B + bb) * p.lddy + co_lo + c4;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dys + q * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const bool do_bias = (p.bias_slab != nullptr) && cic == 0 && g == 0;
+    float bsum = 0.f;
+
+    int tile = split, buf = 0;
+    if (tile < p.numTiles) issue_tile(tile, 0);
+    __syncthreads();                                     // (vmcnt(0) + barrier) first tile landed, tab_in visible
+    for (; tile < p.numTiles; tile += p.splits) {
+        if (tile + p.splits < p.numTiles) issue_tile(tile + p.splits, buf ^ 1);
+        const float* xs = xs0 + buf * (XR * 32);
+        const float* dys = dys0 + buf * (128 * 32);
+        if (do_bias) {
+            const int co_ = tid & 31, part = tid >> 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += dys[(part * 16 + r) * 32 + co_];
+        }
+        {
+            float an[J], bn;
+            int ti_nn;
+            {
+                const int m0 = 2 * wave + half;
+                const int ti0 = tab_in[m0];
+                bn = dys[m0 * 32 + e];
+#pragma unroll
+                for (int j = 0; j < J; ++j) an[j] = xs[ti0 + loff[j]];
+                ti_nn = tab_in[2 * (wave + 4) + half];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                float av[J];
+                const float bv = bn;
+#pragma unroll
+                for (int j = 0; j < J; ++j) av[j] = ((lvalid >> j) & 1u) ? an[j] : 0.f;
+                const int pn = pp + 1 < 16 ? pp + 1 : 15, pnn = pp + 2 < 16 ? pp + 2 : 15;
+                const int m1 = 2 * (wave + 4 * pn) + half;
+                bn = dys[m1 * 32 + e];
+#pragma unroll
+                for (int j = 0; j < J; ++j) an[j] = xs[ti_nn + loff[j]];
+                ti_nn = tab_in[2 * (wave + 4 * pnn) + half];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                 // drains this wave's DMA (vmcnt(0)) and orders the buffers
+        buf ^= 1;
+    }
+    float* red = dys0;
+    float* out = p.slab + (((long long)split * p.base + (bid - split * p.base)) * J) * 1024;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave * 1024 + row * 32 + e] = acc[j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            out[j * 1024 + i] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+            p.bias_slab[((long long)split * p.nCo + coc) * 32 + tid] = t;
+        }
+    }
+}
+
 // dw_tck[t][ci][co] = sum over slabs, fixed order, two parallel stages of <= 32 terms each
 #define WG_RCHUNK 32
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int ntaps, int Ci, int Co,
@@ -1043,6 +1234,8 @@ struct WgradPlan {
     size_t lds;
     long long slab_floats, part_floats, bias_floats;
     int nchunk;
+    int dma, XR;                  // LDS-DMA kernel usable; staged x rows (multiple of 8)
+    size_t lds_dma;
 };
 
 static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
@@ -1089,6 +1282,25 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
         if (pl.lds <= 64 * 1024) break;
         if (tc.TH > 1) tc.TH = (tc.TH + 1) / 2; else if (tc.NB > 1) tc.NB = (tc.NB + 1) / 2; else if (tc.TW > 1) tc.TW = (tc.TW + 1) / 2; else return MRDIS_EUNSUPPORTED;
     }
+    // LDS-DMA variant: full 32-channel chunks on both sides, J taps per group all real, and a double-buffered
+    // tile pair that still lets two workgroups share a CU (<= 80 KB each)
+    pl.dma = 0; pl.XR = 0; pl.lds_dma = 0;
+    if (Ci % 32 == 0 && Co % 32 == 0 && p.TPS == 1 && !getenv("MRDIS_DEBUG_NODMA")) {
+        TileChoice cand[2] = {tc, TileChoice{1, 8, 16}};
+        for (int c = 0; c < 2 && !pl.dma; ++c) {
+            const TileChoice t = cand[c];
+            if (c == 1 && !(Ho % 8 == 0 && Wo % 16 == 0)) break;
+            const int tinH = (t.TH - 1) * p.is + (dh_max - p.dh_min) + 1, tinW = (t.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+            const int npix = t.NB * tinH * tinW, XR = (npix + 7) / 8 * 8;
+            const size_t lds = sizeof(float) * (128 + 2 * 128 * 32 + 2 * (size_t)XR * 32);
+            if (lds <= 80 * 1024 && XR / 8 <= 4 * WGD_XSLOTS && t.NB < 1024 && tinH < 1024 && tinW < 1024) {
+                pl.dma = 1; pl.XR = XR; pl.lds_dma = lds;
+                p.NB = t.NB; p.TH = t.TH; p.TW = t.TW; p.TinH = tinH; p.TinW = tinW;
+                pl.lds = sizeof(float) * (256 + 128 * 32 + (size_t)npix * (CW + 1));   // same tile if the plain kernel has to run
+                if (pl.lds > 64 * 1024) { pl.dma = 0; }
+            }
+        }
+    }
     p.tilesA = mrdis_cdiv(Ho, p.TH); p.tilesB = mrdis_cdiv(Wo, p.TW); p.tilesN = mrdis_cdiv(N, p.NB);
     const long long nt = (long long)p.tilesA * p.tilesB * p.tilesN;
     if (nt > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
@@ -1113,6 +1325,21 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
 
 template <int J>
 static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
+    if (pl.dma) {
+        static bool attr_set = false;
+        if (!attr_set) {      // > 64 KB of dynamic LDS needs the opt-in once per instantiation
+            if (hipFuncSetAttribute((const void*)wgrad_dma_kernel<J>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return MRDIS_ELAUNCH;
+            attr_set = true;
+        }
+        const bool x_ok = (pl.p.ldx % 4 == 0) && (((uintptr_t)pl.p.x & 15) == 0);
+        const bool dy_ok = (pl.p.lddy % 4 == 0) && (((uintptr_t)pl.p.dy & 15) == 0);
+        if (x_ok && dy_ok) {
+            hipLaunchKernelGGL((wgrad_dma_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds_dma, s, pl.p, pl.XR);
+            MRDIS_CHECK_LAUNCH();
+            return MRDIS_OK;
+        }
+    }
     hipLaunchKernelGGL((wgrad_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
