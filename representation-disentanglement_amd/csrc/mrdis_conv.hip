@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// ---------------------------------------------------------------- LDS-DMA variant (Ci % 32 == 0, Co % 32 == 0)
+// ---------------------------------------------------------------- LDS-DMA variant (Ci % 32 == 0, Co % 4 == 0)
 // The plain kernel above is staging-bound: with 144+ accumulator registers only two workgroups fit
 // per CU and nothing hides the global->register->LDS round trip of the next tile.  Here both tiles
 // are rows of exactly 128 B ([pixel][32 ci] and [position][32 co]; for Ci >= 32 the A operand reads 32
@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
             const float* src = zero;
             if (dd[k] >= 0) {
                 const int n = n0 + (dd[k] >> 20), a = a0 + ((dd[k] >> 10) & 1023), bb = b0 + (dd[k] & 1023);
-                if (n < p.N && a < p.A && bb < p.B) src = p.dy + ((long long)(n * p.A + a) * p.B + bb) * p.lddy + co_lo + c4;
+                if (n < p.N && a < p.A && bb < p.B && co_lo + c4 < p.Co)      // couts beyond Co (Co % 4 == 0) read zeros
+                    src = p.dy + ((long long)(n * p.A + a) * p.B + bb) * p.lddy + co_lo + c4;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dys + q * 256), 16, 0, 0);
@@ -1285,7 +1286,7 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
     // LDS-DMA variant: full 32-channel chunks on both sides, J taps per group all real, and a double-buffered
     // tile pair that still lets two workgroups share a CU (<= 80 KB each)
     pl.dma = 0; pl.XR = 0; pl.lds_dma = 0;
-    if (Ci % 32 == 0 && Co % 32 == 0 && p.TPS == 1 && !getenv("MRDIS_DEBUG_NODMA")) {
+    if (Ci % 32 == 0 && Co % 4 == 0 && p.TPS == 1 && !getenv("MRDIS_DEBUG_NODMA")) {
         TileChoice cand[2] = {tc, TileChoice{1, 8, 16}};
         for (int c = 0; c < 2 && !pl.dma; ++c) {
             const TileChoice t = cand[c];

@@ -107,7 +107,8 @@ def test_conv_c4_persistent_pipeline(mrdis):
         close(got, F.leaky_relu(want, 0.2), what='c4 lrelu')
 
 
-@pytest.mark.parametrize('N,Ci,Co,H,W,k,st', [(24, 32, 32, 128, 144, 3, 1), (8, 64, 96, 72, 80, 3, 1), (16, 32, 64, 64, 64, 4, 2)])
+@pytest.mark.parametrize('N,Ci,Co,H,W,k,st', [(24, 32, 32, 128, 144, 3, 1), (8, 64, 96, 72, 80, 3, 1), (16, 32, 64, 64, 64, 4, 2),
+                                              (12, 32, 16, 96, 96, 3, 1), (6, 64, 4, 128, 128, 3, 1)])
 def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st):
     """weight gradient with several position tiles per workgroup: exercises the double-buffered LDS-DMA
     steady state (and its ragged last tiles), bias column sums included."""
