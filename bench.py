@@ -180,10 +180,14 @@ def main():
         log(f'warm-up step {i} done, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
     sync()
     t0 = time.perf_counter()
+    host_ms = 0.0
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         loss, parts, _ = step(xd, maskd, mimgd, mask)
+        host_ms += (time.perf_counter() - h0) * 1e3
     sync()
     dt = time.perf_counter() - t0
+    host_ms /= a.steps
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -208,7 +212,8 @@ def main():
             'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
             'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
         }
-        log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s')
+        log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
+        out['host_enqueue_ms_per_step'] = round(host_ms, 1)
         if not a.no_roofline:
             out['roofline'] = roofline_conv(mrdis, dev)
             log(f'roofline: {out["roofline"]}')

@@ -365,6 +365,140 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------- narrow-output variant (Cout <= 16)
+// Layers with 4 / 7 / 16 output channels (ana_dec.output, the data gradients of every `si_layers`,
+// sp6.out, the 1x1 decoder head, first-layer data gradients) waste 2-8x of a 32-wide cout tile.  This
+// variant uses v_mfma_f32_16x16x4_f32 (A = filter [16 couts x 4 ch], B = pixels [4 ch x 16 positions],
+// same FLOP rate, 32-cycle issue): workgroup = 128 positions x 16 couts, a wave owns two 16-position
+// sub-tiles that share the A operand.  D[cout][position]: lane = position, registers = 4 consecutive
+// couts -> one 16-byte store per sub-tile.
+template <int KC>
+__global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
+    constexpr int S = KC + 1, BN = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tab_in = reinterpret_cast<int*>(smem);
+    int* tab_out = tab_in + 128;
+    int* tap_xoff = tab_in + 256;
+    int* tap_widx = tab_in + 272;
+    float* ws = smem + TC_TAB_INTS;                  // [tap][KC][16]
+    float* xs = ws + p.ntaps * KC * BN;              // [pixel][KC+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+
+    int bid = mrdis_xcd_remap(blockIdx.x, gridDim.x);
+    int tile = bid;
+    const int tb = tile % p.tilesB; tile /= p.tilesB;
+    const int ta = tile % p.tilesA;
+    const int tn = tile / p.tilesA;
+    const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
+
+    if (tid < 128) {
+        const int m = tid, npos = p.NB * p.TH * p.TW;
+        int tin = 0, tout = -1;
+        if (m < npos) {
+            const int nb = m / (p.TH * p.TW);
+            const int rem = m - nb * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S;
+            const int n = n0 + nb, a = a0 + ty, b = b0 + tx;
+            if (n < p.N && a < p.A && b < p.B) tout = (n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0;
+        }
+        tab_in[m] = tin; tab_out[m] = tout;
+    } else if (tid < 128 + MRDIS_MAX_TAPS) {
+        const int t = tid - 128;
+        if (t < p.ntaps) {
+            tap_xoff[t] = ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * S;
+            tap_widx[t] = p.widx[t];
+        }
+    }
+    __syncthreads();
+    int bbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bbase[i] = tab_in[(wave * 2 + i) * 16 + l16] + kq;
+    const int abase = kq * BN + l16;
+
+    f32x4 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW;
+    const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        if (c0) __syncthreads();
+        if (p.vec_in) {
+            constexpr int Q = KC / 4;
+            for (int idx = tid; idx < npix_in * Q; idx += 256) {
+                const int pi = idx / Q, q = idx - pi * Q;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Cin)
+                    v = *reinterpret_cast<const float4*>(p.in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c);
+                float* d = xs + pi * S + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < npix_in * KC; idx += 256) {
+                const int pi = idx / KC, k = idx - pi * KC;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c0 + k;
+                float v = 0.f;
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Cin)
+                    v = p.in[((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c];
+                xs[pi * S + k] = v;
+            }
+        }
+        {
+            const int total = p.ntaps * KC * BN;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int row = idx >> 4, j = idx & 15;
+                const int t = row / KC, k = row - t * KC;
+                const int c = c0 + k;
+                float v = 0.f;
+                if (c < p.Cin && j < p.Cout) v = p.w[((long long)tap_widx[t] * p.Cin + c) * p.Cout + j];
+                ws[idx] = v;
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = tap_xoff[t];
+            const float* wt = ws + t * (KC * BN) + abase;
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                const float av = wt[4 * q * BN];
+                const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // D: col = lane&15 (position), row = (lane>>4)*4 + reg (cout)
+    const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+    const bool vec_out = (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0);
+    const int co = 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int po = tab_out[(wave * 2 + i) * 16 + l16];
+        if (po < 0 || co >= p.Cout) continue;
+        float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.bias != nullptr && co + r < p.Cout) v[r] += p.bias[co + r];
+            if (lrelu) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+        }
+        float* dst = p.out + (long long)po * p.ldout + co;
+        if (vec_out && co + 3 < p.Cout) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (co + r < p.Cout) dst[r] = v[r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct TileChoice { int NB, TH, TW; };
 
@@ -412,6 +546,20 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
     p.tilesA = mrdis_cdiv(p.A, p.TH); p.tilesB = mrdis_cdiv(p.B, p.TW); p.tilesN = mrdis_cdiv(p.N, p.NB);
     const long long ptiles = (long long)p.tilesA * p.tilesB * p.tilesN;
+    if (p.Cout <= 16 && !getenv("MRDIS_DEBUG_NO16")) {
+        p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
+        p.vec_w = 0; p.prefetch = 0; p.coTiles = 1;
+        int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
+        auto lds16 = [&](int kc) { return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * kc * 16 + (size_t)p.NB * p.TinH * p.TinW * (kc + 1)); };
+        while (lds16(KC) > 64 * 1024 && KC > 4) KC >>= 1;
+        if (lds16(KC) > 64 * 1024) return MRDIS_EUNSUPPORTED;
+        if (ptiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+        if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
+        else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
+        else hipLaunchKernelGGL((tapconv16_kernel<4>), dim3((int)ptiles), dim3(256), lds16(4), s, p);
+        MRDIS_CHECK_LAUNCH();
+        return MRDIS_OK;
+    }
     // measured policy (tools/sweep.py, B=32 256x256 layer zoo): 64-wide cout tiles beat 128-wide ones on every
     // layer (register pressure halves the residency of the 128 variant); small grids prefer 32.
     int BN = p.Cout <= 32 ? 32 : 64;
