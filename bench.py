@@ -95,8 +95,8 @@ def cpu_baseline(M, H, W, adv):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     cores = max(1, min(cores, 16))        # the GPU box gives one GPU's job a 16-core share; more threads only thrash
     torch.set_num_threads(cores)
-    print(f'[bench] cpu_baseline: {cores} threads, B=2, M={M}, {H}x{W}', file=sys.stderr, flush=True)
-    B = 2
+    print(f'[bench] cpu_baseline: {cores} threads, M={M}, {H}x{W}', file=sys.stderr, flush=True)
+    B = 4
     torch.manual_seed(10); np.random.seed(10)
     model = R.RefMultimodalModel((H, W), M, is_discrim_s=adv).train()
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
@@ -119,7 +119,7 @@ def cpu_baseline(M, H, W, adv):
     one()
     print(f'[bench] cpu_baseline warm-up step {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    n = 2
+    n = 3
     for _ in range(n):
         one()
         print(f'[bench] cpu_baseline step done at +{time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)

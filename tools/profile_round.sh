@@ -7,6 +7,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ns -- python tools/northstar_conv.py 20 > $OUT/ns_stats.log 2>&1
+python tools/prof_summary.py stats $OUT/ns_kernel_stats.csv $OUT/ns_kernel_trace.csv $OUT/${TAG}_northstar_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python tools/northstar_conv.py 20 ($TAG): north-star conv only"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ns_fetch -- python tools/northstar_conv.py 10 > $OUT/ns_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ns_write -- python tools/northstar_conv.py 10 > $OUT/ns_write.log 2>&1
 python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py ($TAG)"
