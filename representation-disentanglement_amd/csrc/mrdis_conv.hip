@@ -29,6 +29,8 @@
 #include <stdlib.h>
 
 #define TC_BM 128
+// 256 B of zeros: the source of LDS-DMA lanes that fall outside the image / channel range
+__device__ float g_mrdis_zero_page[64];
 #define TC_TAB_INTS 320   // tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad
 
 struct TapConvParams {
@@ -1146,8 +1148,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // per-lane source address, out-of-image pixels / positions are redirected to a zero page.  The
 // tile after the current one is in flight (second LDS buffer, zero VGPRs) during the MFMAs; one barrier
 // per tile; all index arithmetic (divisions) is hoisted out of the tile loop.
-__device__ float g_mrdis_zero_page[64];
-
 #define WGD_XSLOTS 7
 template <int J>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, int XR /* staged x rows, multiple of 8 */) {
