@@ -63,6 +63,15 @@ int mrdis_mix_experts_bwd(const float* dw_tck, const float* W, const float* r,
                           float* dW, float* dr, void* workspace, size_t workspace_bytes,
                           int E, int Co, int Ci, int T, void* stream);
 
+/* Routed forms: the routing r = sigmoid(fc_w @ type_row + fc_b) of `_routing.forward` (model.py:2071-2073) is
+ * evaluated inside the mix kernel (r_out (E) is kept for the backward), and the backward returns the
+ * gradients of the routing Linear directly: dfc_w (E,emb), dfc_b (E).  type_row: (emb) device floats. */
+int mrdis_mix_experts_routed_fwd(const float* W, const float* fc_w, const float* fc_b, const float* type_row, int emb,
+                                 float* r_out, float* w_tck, float* w_tkc, int E, int Co, int Ci, int T, void* stream);
+int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W, const float* r, const float* type_row, int emb,
+                                 float* dW, float* dfc_w, float* dfc_b, void* workspace, size_t workspace_bytes,
+                                 int E, int Co, int Ci, int T, void* stream);
+
 /* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and
  * nn.Conv2d of the discriminator model.py:2773-2789 ---------------------------
  * x : NHWC view (N,H,W,Ci) ld=ldx ; y : NHWC view (N,Ho,Wo,Co) ld=ldy

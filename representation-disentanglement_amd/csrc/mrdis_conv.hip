@@ -1595,6 +1595,43 @@ __global__ void mix_bwd_final_kernel(const float* __restrict__ part, int nblk, i
     dr[e] += (float)s;
 }
 
+// ---- routed variants: r = sigmoid(fc_w @ type + fc_b) (model.py:2071-2073) is evaluated inside the mix kernel
+// and its backward inside the mix-backward finalize, so a CondConv2d call costs two launches instead of
+// two plus ~9 tiny torch kernels (addmm, sigmoid, their backwards, zero fills).
+__global__ void mix_routed_fwd_kernel(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                      const float* __restrict__ t, int emb, float* __restrict__ r_out,
+                                      float* __restrict__ w_tck, float* __restrict__ w_tkc, int E, int Co, int Ci, int T) {
+    const long long total = (long long)Co * Ci * T;
+    float rr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float z = 0.f;
+        if (e < E) { z = fcb[e]; for (int k = 0; k < emb; ++k) z += fcw[e * emb + k] * t[k]; }
+        rr[e] = e < E ? 1.f / (1.f + expf(-z)) : 0.f;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < E) r_out[threadIdx.x] = rr[threadIdx.x];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tt = (int)(i % T);
+        const long long q = i / T;
+        const int ci = (int)(q % Ci), co = (int)(q / Ci);
+        float s_ = 0.f;
+        for (int e = 0; e < E; ++e) s_ += rr[e] * W[(long long)e * total + i];
+        w_tck[((long long)tt * Ci + ci) * Co + co] = s_;
+        w_tkc[((long long)tt * Co + co) * Ci + ci] = s_;
+    }
+}
+// dfcw[e][k] = dr[e] r[e](1-r[e]) t[k], dfcb[e] = dr[e] r[e](1-r[e])
+__global__ void mix_routed_bwd_final_kernel(const float* __restrict__ part, int nblk, int E, const float* __restrict__ r,
+                                            const float* __restrict__ t, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb) {
+    const int e = threadIdx.x;
+    if (e >= E) return;
+    double s_ = 0.0;
+    for (int b = 0; b < nblk; ++b) s_ += (double)part[(long long)b * 8 + e];
+    const float dz = (float)s_ * r[e] * (1.f - r[e]);
+    dfcb[e] = dz;
+    for (int k = 0; k < emb; ++k) dfcw[e * emb + k] = dz * t[k];
+}
+
 static int mix_blocks(long long total) { int b = mrdis_cdiv(total, 256); return b > 128 ? 128 : (b < 1 ? 1 : b); }
 
 extern "C" int mrdis_mix_experts_fwd(const float* W, const float* r, float* w_tck, float* w_tkc,
@@ -1623,6 +1660,32 @@ extern "C" int mrdis_mix_experts_bwd(const float* dw_tck, const float* W, const 
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, E, dr);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" int mrdis_mix_experts_routed_fwd(const float* W, const float* fc_w, const float* fc_b, const float* type_row, int emb,
+                                            float* r_out, float* w_tck, float* w_tkc, int E, int Co, int Ci, int T, void* stream) {
+    if (!W || !fc_w || !fc_b || !type_row || !r_out || !w_tck || !w_tkc || E < 1 || E > 8 || emb < 1 || emb > 16) return MRDIS_EINVAL;
+    const long long total = (long long)Co * Ci * T;
+    hipLaunchKernelGGL(mix_routed_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, type_row, emb,
+                       r_out, w_tck, w_tkc, E, Co, Ci, T);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W, const float* r, const float* type_row, int emb,
+                                            float* dW, float* dfc_w, float* dfc_b, void* workspace, size_t workspace_bytes,
+                                            int E, int Co, int Ci, int T, void* stream) {
+    if (!dw_tck || !W || !r || !type_row || !dW || !dfc_w || !dfc_b || !workspace || E < 1 || E > 8 || emb < 1 || emb > 16) return MRDIS_EINVAL;
+    const long long total = (long long)Co * Ci * T;
+    const int nb = mix_blocks(total);
+    if (workspace_bytes < sizeof(float) * 8 * (size_t)nb) return MRDIS_EWORKSPACE;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
+                       reinterpret_cast<float*>(workspace), E, Co, Ci, T);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mix_routed_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(workspace), nb, E, r, type_row, emb, dfc_w, dfc_b);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

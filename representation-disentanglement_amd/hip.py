@@ -33,6 +33,8 @@ _SIGS = {
     'mrdis_mix_experts_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_bwd_workspace': (_Z, [_I, _I, _I, _I]),
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -142,6 +144,36 @@ def mix_experts_bwd(dw_tck, W, r):
     _chk(lib.mrdis_mix_experts_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(dW), _ptr(dr), _ptr(ws), nb, E, Co, Ci, T, _stream()),
          'mix_experts_bwd')
     return dW, dr
+
+
+def mix_experts_routed_fwd(W, fcw, fcb, t_row):
+    """W (E,Co,Ci,kh,kw), routing Linear (fcw (E,emb), fcb (E)), t_row (1,emb) -> (w_tck, w_tkc, r)."""
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); fcw = fcw.contiguous(); fcb = fcb.contiguous(); t_row = t_row.contiguous()
+    emb = fcw.shape[1]
+    w_tck = torch.empty((T, Ci, Co), dtype=torch.float32, device=W.device)
+    w_tkc = torch.empty((T, Co, Ci), dtype=torch.float32, device=W.device)
+    r = torch.empty(E, dtype=torch.float32, device=W.device)
+    _chk(lib.mrdis_mix_experts_routed_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(t_row), emb, _ptr(r), _ptr(w_tck), _ptr(w_tkc),
+                                          E, Co, Ci, T, _stream()), 'mix_experts_routed_fwd')
+    return w_tck, w_tkc, r
+
+
+def mix_experts_routed_bwd(dw_tck, W, r, t_row, emb):
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); dw_tck = dw_tck.contiguous(); t_row = t_row.contiguous()
+    dW = torch.empty_like(W)
+    dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
+    dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
+    nb = lib.mrdis_mix_experts_bwd_workspace(E, Co, Ci, T)
+    ws = _ws(nb, W.device)
+    _chk(lib.mrdis_mix_experts_routed_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(t_row), emb, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
+                                          _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_bwd')
+    return dW, dfcw, dfcb
 
 
 # ---------------------------------------------------------------- convolution

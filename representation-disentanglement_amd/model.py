@@ -71,8 +71,7 @@ class CondConv2d(nn.Module):
 
     def _mixed(self, t_row):
         """t_row: (1, embeddings) -> (w_tck, w_tkc) for that type."""
-        r = torch.sigmoid(F.linear(t_row, self._routing_fn.fc.weight, self._routing_fn.fc.bias))[0]
-        return ops.mix_experts(self.weight, r)
+        return ops.mix_experts_routed(self.weight, self._routing_fn.fc.weight, self._routing_fn.fc.bias, t_row)
 
     def forward(self, inputs, inputs_type, lrelu=False):
         kh, kw = self.kernel_size

@@ -34,6 +34,28 @@ def mix_experts(W, r):
     return _MixExperts.apply(W, r)
 
 
+class _MixExpertsRouted(Function):
+    """routing (model.py:2071-2073) + expert mixing (:2113) in one forward and one backward launch pair."""
+
+    @staticmethod
+    def forward(ctx, W, fcw, fcb, t_row):
+        w_tck, w_tkc, r = hip.mix_experts_routed_fwd(W, fcw, fcb, t_row)
+        ctx.save_for_backward(W, r, t_row)
+        ctx.emb = fcw.shape[1]
+        ctx.mark_non_differentiable(w_tkc)
+        return w_tck, w_tkc
+
+    @staticmethod
+    def backward(ctx, g_tck, _g_tkc):
+        W, r, t_row = ctx.saved_tensors
+        dW, dfcw, dfcb = hip.mix_experts_routed_bwd(g_tck, W, r, t_row, ctx.emb)
+        return dW, dfcw, dfcb, None
+
+
+def mix_experts_routed(W, fcw, fcb, t_row):
+    return _MixExpertsRouted.apply(W, fcw, fcb, t_row)
+
+
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(Function):
     """F.conv2d (model.py:2104) with optional fused LeakyReLU(0.2) epilogue."""

@@ -158,6 +158,22 @@ def test_mix_experts(mrdis):
     close(dW, W.grad, rtol=1e-6); close(dr, r.grad, rtol=1e-5)
 
 
+def test_mix_experts_routed(mrdis):
+    """routing sigmoid(Linear(type)) fused into the mix kernels, gradients of the routing Linear included."""
+    hip = mrdis.hip
+    W = rnd((3, 6, 5, 3, 3), 70).requires_grad_(True)
+    fcw = rnd((3, 1), 71).requires_grad_(True); fcb = rnd((3,), 72).requires_grad_(True)
+    t = torch.tensor([[3.0]])
+    r = torch.sigmoid(F.linear(t, fcw, fcb))[0]
+    mixed = (r[:, None, None, None, None] * W).sum(0)
+    g = rnd((9, 5, 6), 73)
+    (to_tck(mixed) * g).sum().backward()
+    tck, tkc, rd = hip.mix_experts_routed_fwd(W.detach().to(dev()), fcw.detach().to(dev()), fcb.detach().to(dev()), t.to(dev()))
+    close(rd, r, rtol=1e-6); close(tck, to_tck(mixed), rtol=1e-6); close(tkc, to_tkc(mixed), rtol=1e-6)
+    dW, dfcw, dfcb = hip.mix_experts_routed_bwd(g.to(dev()), W.detach().to(dev()), rd, t.to(dev()), 1)
+    close(dW, W.grad, rtol=1e-6); close(dfcw, fcw.grad, rtol=1e-5); close(dfcb, fcb.grad, rtol=1e-5)
+
+
 @pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 16), (32, 3, 9, 7), (256, 2, 5, 6), (16, 2, 8, 8), (48, 2, 6, 10)])
 def test_batchnorm(mrdis, C, N, H, W):
     hip = mrdis.hip
