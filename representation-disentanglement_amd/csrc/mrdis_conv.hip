@@ -631,7 +631,7 @@ struct C4Params {
     int dbg;                     // timing ablations: 1 no MFMA, 2 no stores, 4 no strip loads
 };
 
-template <int NS>
+template <int NS, bool LRELU, bool FAST>   // FAST: Co % (32*NS) == 0 and 16-byte stores legal -> no per-store checks
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
     const int ty = m / p.TW, tx = m - ty * p.TW;
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             }
     // operands are swapped (A = filter, B = pixels), so D[cout][position]: a lane owns ONE position and
     // 16 couts (r&3) + 8*(r>>2) + 4*half -> four 16-byte stores per strip instead of sixteen 4-byte ones.
+    // The bias is the C operand of the first MFMA of every strip (no accumulator initialisation).
     f32x16 bv[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
@@ -666,7 +667,6 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             bv[ns][r] = co < p.Co ? v : 0.f;
         }
     const bool vec_st = (p.Co % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
-    const bool full_co = (p.Co % (32 * NS)) == 0;
     const int tpi = p.tilesW * p.tilesH;
     // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
     const int d_n = nwaves / tpi, d_rem = nwaves - d_n * tpi, d_th = d_rem / p.tilesW, d_tw = d_rem - d_th * p.tilesW;
@@ -679,51 +679,51 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     };
     // Address arithmetic is the hidden cost of this kernel (the waves are VALU-issue bound long before
     // the matrix or memory pipes fill), so a strip computes 3 clamped row bases + 3 clamped columns
-    // once and forms the 9 tap offsets with one 32-bit add each; validity is a 3x3 outer product of
-    // row/column bits.  Loads are unconditional from the clamped address and zeroed at first use.
-    auto strip_setup = [&](int n, int th, int tw, const float*& img, int (&voff)[9], unsigned& okmask) {
+    // once and forms the 9 tap BYTE offsets (32-bit, against a wave-uniform image base) with one add
+    // each; validity is a 3x3 outer product of row/column bits.  Loads are unconditional from the
+    // clamped address and zeroed at first use (edge strips only).
+    const unsigned lane_off = 8u * half;
+    auto strip_setup = [&](int n, int th, int tw, const char*& img, unsigned (&voff)[9], unsigned& okmask) {
         const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
-        int rb[3], cb[3];
+        unsigned rb[3], cb[3];
         unsigned rm = 0, cm = 0;
+        const unsigned pix = 4u * p.ldx;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int hh = h + r - 1;
             rm |= ((unsigned)hh < (unsigned)p.H ? 1u : 0u) << r;
-            rb[r] = (hh < 0 ? 0 : (hh >= p.H ? p.H - 1 : hh)) * p.W;
+            rb[r] = (unsigned)(hh < 0 ? 0 : (hh >= p.H ? p.H - 1 : hh)) * (unsigned)p.W * pix + lane_off;
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int ww = w_ + c - 1;
             cm |= ((unsigned)ww < (unsigned)p.W ? 1u : 0u) << c;
-            cb[c] = ww < 0 ? 0 : (ww >= p.W ? p.W - 1 : ww);
+            cb[c] = (unsigned)(ww < 0 ? 0 : (ww >= p.W ? p.W - 1 : ww)) * pix;
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) voff[3 * r + c] = (rb[r] + cb[c]) * p.ldx + 2 * half;
+            for (int c = 0; c < 3; ++c) voff[3 * r + c] = rb[r] + cb[c];
         okmask = ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u);
-        img = p.x + (long long)n * p.H * p.W * p.ldx;      // wave-uniform
+        img = reinterpret_cast<const char*>(p.x + (long long)n * p.H * p.W * p.ldx);      // wave-uniform
     };
     // (An inline-asm load with hand-counted vmcnt was tried here and rejected: hipcc may re-home the
     // destination registers while the load is in flight, and a late write-back then clobbers whatever
     // lives there -- store addresses included.  Compiler-tracked loads only.)
-    auto load_tap = [&](const float* img, int voff, float2& dst) {
+    auto load_tap = [&](const char* img, unsigned voff, float2& dst) {
         dst = *reinterpret_cast<const float2*>(img + voff);
     };
-#define C4_WAIT(N, r) do { } while (0)
-    auto store_group = [&](const f32x16 (&acc)[NS], int n, int th, int tw, int g) {
-        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
-        if (h < p.H && w_ < p.W && !(p.dbg & 2)) {
-            float* dst = p.y + ((long long)(n * p.H + h) * p.W + w_) * p.ldy;
+    auto store_group = [&](const f32x16 (&acc)[NS], float* dst, bool ok, int g) {
+        if (ok) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + 8 * g + 4 * half;
                 float4 v = make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]);
-                if (p.lrelu) {
+                if (LRELU) {
                     v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
                     v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
                 }
-                if (vec_st && (full_co || co + 3 < p.Co)) *reinterpret_cast<float4*>(dst + co) = v;
+                if (FAST || (vec_st && co + 3 < p.Co)) *reinterpret_cast<float4*>(dst + co) = v;
                 else {
                     if (co < p.Co) dst[co] = v.x;
                     if (co + 1 < p.Co) dst[co + 1] = v.y;
@@ -733,12 +733,18 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             }
         }
     };
+    auto out_ptr = [&](int n, int th, int tw, bool& ok) -> float* {
+        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
+        ok = h < p.H && w_ < p.W && !(p.dbg & 2);
+        return p.y + ((long long)(n * p.H + h) * p.W + w_) * p.ldy;
+    };
 
     // Register pipeline, two strips deep: a_cur (strip i, masked), and two raw buffers that alternate:
-    // iteration i loads strip i+2 into R[i&1] and afterwards consumes R[(i+1)&1] (strip i+1, loaded
-    // one iteration earlier).  No register copy ever touches a load that is still in flight, and all
-    // loads of an iteration are issued BEFORE its stores (vmcnt retires in order, so waiting for the
-    // older loads never waits for store completion).
+    // iteration i loads strip i+2 into R[i&1] and afterwards consumes R[(i+1)&1] (strip i+1, loaded one
+    // iteration earlier); likewise two accumulator sets alternate (the set of strip i-1 is stored while
+    // strip i computes), so no register copy ever touches a value still in flight.  All loads of an
+    // iteration are issued BEFORE its stores (vmcnt retires in order, so waiting for the older loads
+    // never waits for store completion).
     float2 a_cur[9], r0[9], r1[9];
     unsigned m0 = 0, m1 = 0;
     if (tile >= ntiles) return;
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     advance(n1, th1, tw1);
     {
         unsigned mc = 0;
-        const float* img; int vo[9];
+        const char* img; unsigned vo[9];
         strip_setup(cn, cth, ctw, img, vo, mc);
 #pragma unroll
         for (int t = 0; t < 9; ++t) load_tap(img, vo[t], a_cur[t]);
@@ -755,31 +761,30 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) load_tap(img, vo[t], r1[t]);     // strip 1 -> R[(0+1)&1]
         }
-        C4_WAIT(0, a_cur);
-        C4_WAIT(0, r1);
 #pragma unroll
         for (int t = 0; t < 9; ++t) if (!((mc >> t) & 1u)) a_cur[t] = make_float2(0.f, 0.f);
     }
-    f32x16 prev[NS];
-    int pn = 0, pth = 0, ptw = 0;
-    bool have_prev = false;
+    f32x16 accA[NS], accB[NS];
+    float* pdst = p.y; bool pok = false;
 
-    auto iteration = [&](float2 (&r_load)[9], unsigned& m_load, float2 (&r_use)[9], unsigned& m_use) {
+    auto iteration = [&](f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&r_load)[9], unsigned& m_load,
+                         float2 (&r_use)[9], unsigned& m_use) {
         int n2 = n1, th2 = th1, tw2 = tw1;
         advance(n2, th2, tw2);
         const bool have_n2 = (long long)tile + 2LL * nwaves < ntiles && !(p.dbg & 4);
         m_load = 0;
-        const float* img2 = p.x; int vo2[9];
+        const char* img2 = reinterpret_cast<const char*>(p.x); unsigned vo2[9];
         if (have_n2) strip_setup(n2, th2, tw2, img2, vo2, m_load);
-        f32x16 acc[NS];
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) acc[ns] = bv[ns];
+        bool cok; float* cdst = out_ptr(cn, cth, ctw, cok);
+        // 18*NS MFMAs of this strip; the 9 loads of strip i+2 go between the first MFMAs, the 4 stores of
+        // strip i-1 between the last ones: co-resident waves run this loop in lockstep, so overlap of the
+        // memory pipes with the matrix pipe has to come from inside each wave's own instruction stream.
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (!(p.dbg & 1))
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
-                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], a_cur[t].x, acc[ns], 0, 0, 0);
+                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], a_cur[t].x, t == 0 ? bv[ns] : acc[ns], 0, 0, 0);
                 acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][1][ns], a_cur[t].y, acc[ns], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -787,18 +792,13 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
                 load_tap(img2, vo2[2 * t], r_load[2 * t]);
                 if (2 * t + 1 < 9) load_tap(img2, vo2[2 * t + 1], r_load[2 * t + 1]);
             }
-            if (t >= 5 && have_prev) store_group(prev, pn, pth, ptw, t - 5);
+            if (t >= 5) store_group(prev, pdst, pok, t - 5);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) prev[ns] = acc[ns];
-        pn = cn; pth = cth; ptw = ctw; have_prev = true;
+        pdst = cdst; pok = cok;
         cn = n1; cth = th1; ctw = tw1;
         n1 = n2; th1 = th2; tw1 = tw2;
-        // first use of the loads issued one iteration ago.  Younger than them are exactly this
-        // iteration's 9 loads (+ up to 4 stores behind those): vmcnt(9) can only over-wait.  Without new
-        // loads in this iteration the count would under-wait, so drain instead (wave-uniform branch).
-        if (have_n2) { C4_WAIT(9, r_use); } else { C4_WAIT(0, r_use); }
+        // first use of the loads issued one iteration ago
         if (__all(m_use == 0x1ffu)) {          // interior strip: nothing to zero (wave-uniform branch)
 #pragma unroll
             for (int t = 0; t < 9; ++t) a_cur[t] = r_use[t];
@@ -807,15 +807,21 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             for (int t = 0; t < 9; ++t) a_cur[t] = ((m_use >> t) & 1u) ? r_use[t] : make_float2(0.f, 0.f);
         }
     };
+    bool last_is_A = true;
     while (tile < ntiles) {
-        iteration(r0, m0, r1, m1);
-        tile += nwaves;
+        iteration(accA, accB, r0, m0, r1, m1);
+        tile += nwaves; last_is_A = true;
         if (tile >= ntiles) break;
-        iteration(r1, m1, r0, m0);
-        tile += nwaves;
+        iteration(accB, accA, r1, m1, r0, m0);
+        tile += nwaves; last_is_A = false;
     }
+    if (last_is_A) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) store_group(prev, pn, pth, ptw, g);
+        for (int g = 0; g < 4; ++g) store_group(accA, pdst, pok, g);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_group(accB, pdst, pok, g);
+    }
 }
 
 static bool c4_eligible(const float* x, int ldx, int Ci, int Co, int kh, int kw, int stride, int pad) {
@@ -845,16 +851,25 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     static int occ[3] = {0, 0, 0}, ncu = 0;
     if (!occ[NS]) {
         int o = 0;
-        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2>, 256, 0);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1>, 256, 0);
+        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
         occ[NS] = o > 0 ? o : 2;
         hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     long long cap = (long long)ncu * occ[NS] / ny; if (cap < ncu) cap = ncu;
     if (blocks > cap) blocks = cap;
-    if (NS == 2) hipLaunchKernelGGL((c4conv_kernel<2>), dim3((int)blocks, ny), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((c4conv_kernel<1>), dim3((int)blocks, ny), dim3(256), 0, s, p);
+    const bool fast = (Co % (32 * NS) == 0) && (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
+    const dim3 grid((int)blocks, ny);
+#define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
+    if (NS == 2) {
+        if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
+        else { if (fast) C4_LAUNCH(2, false, true); else C4_LAUNCH(2, false, false); }
+    } else {
+        if (p.lrelu) { if (fast) C4_LAUNCH(1, true, true); else C4_LAUNCH(1, true, false); }
+        else { if (fast) C4_LAUNCH(1, false, true); else C4_LAUNCH(1, false, false); }
+    }
+#undef C4_LAUNCH
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
