@@ -111,6 +111,9 @@ int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* 
                        const float* beta, float* running_mean, float* running_var,
                        float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                        long long P, int C, float eps, float momentum, void* stream);
+/* inference mode (model.eval(), main_missing.py:338): y = (x - running_mean) * rsqrt(running_var + eps) * gamma + beta */
+int mrdis_bn_eval_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, long long P, int C, float eps, void* stream);
 int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
                        const float* save_mean, const float* save_rstd, float* dx, int lddx,
                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,

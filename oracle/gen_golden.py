@@ -260,6 +260,38 @@ def gen_step(ref, tag, B, M, drop=False, adv=False):
           {k: round(float(v), 7) for k, v in parts.items()})
 
 
+def gen_eval(ref, tag, B, M):
+    """evaluate() of the reference for one batch (main_missing.py:337-517): model.eval(), z = mu."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    from oracle.ref_model import perturb_bn_running_stats
+    torch.manual_seed(10); np.random.seed(10)
+    model = build_ref_model(ref, M, False)
+    perturb_bn_running_stats(model)
+    model.eval()
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=12)
+    torch.manual_seed(11); np.random.seed(11)
+    x_list = [inputs[:, i * 7:(i + 1) * 7] for i in range(M)]
+    with torch.no_grad():
+        s_list = model.compute_anatomy_encoding(x_list, mask_img)
+        z_list, mu_list, lv_list = model.compute_modality_encoding(x_list, s_list, phase='test')
+        xf = model.reconstruct_input_si_zi(s_list, z_list)
+        xmix = model.reconstruct_input_si_zj(s_list, z_list)
+        parts = {'recon_x': model.compute_recon_loss_x_list(x_list, xf, mask, p=1),
+                 'recon_x_mix': model.compute_recon_loss_x_mix_list(x_list, xmix, mask, p=1)}
+        s_new = model.compute_anatomy_encoding(xf, mask_img)
+        _, mu_new, _ = model.compute_modality_encoding(xf, s_new, phase='test')
+        parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask)
+        parts['sim_s'] = model.compute_similarity_s_loss(s_list, mask)
+        parts['sim_z'] = model.compute_similarity_z_loss(z_list, mask)
+        loss = 1.0 * parts['recon_x'] + 2.0 * parts['recon_x_mix'] + 0.1 * parts['latent_z'] + 10.0 * parts['sim_s'] + 2.0 * parts['sim_z']
+    meta = dict(B=B, M=M, loss=float(loss), parts={k: float(v) for k, v in parts.items()}, torch=torch.__version__)
+    with open(os.path.join(OUT, f'eval_{tag}.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, f'eval_{tag}.npz'), mu=torch.stack(mu_list).numpy(),
+                        s0_pool8=pool8(s_list[0]), xf0_pool8=pool8(xf[0]), xmix0_pool8=pool8(xmix[0]))
+    print(f'eval_{tag}: loss={float(loss):.7f}', {k: round(float(v), 7) for k, v in parts.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -273,6 +305,8 @@ def main():
         gen_step(ref, 'b2m4_drop', 2, 4, drop=True)
     if not only or 'adv' in only:
         gen_step(ref, 'b2m2_adv', 2, 2, adv=True)
+    if not only or 'eval' in only:
+        gen_eval(ref, 'b2m4', 2, 4)
 
 
 if __name__ == '__main__':

@@ -469,14 +469,15 @@ DEFAULT_LAMBDAS = dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, s
                        adv_s=0.0)        # config.yaml:27-33, 54-56
 
 
-def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1):
-    """main_missing.py:165-251 for the default loss set.  Returns (loss, parts, aux)."""
+def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1, phase='train'):
+    """main_missing.py:165-251 (phase='train') / :389-505 (phase='test', inside model.eval() + no_grad)
+    for the default loss set.  Returns (loss, parts, aux)."""
     lam = dict(DEFAULT_LAMBDAS); lam.update(lambdas or {})
     M = model.M
     c = inputs.shape[1] // M
     x_list = [inputs[:, i * c:(i + 1) * c] for i in range(M)]               # :166-168
     s_list = model.compute_anatomy_encoding(x_list, mask_img)               # :175
-    z_list, mu_list, lv_list = model.compute_modality_encoding(x_list)      # :176
+    z_list, mu_list, lv_list = model.compute_modality_encoding(x_list, phase)   # :176 / :400
     xf = model.reconstruct_input_si_zi(s_list, z_list)                      # :177
     xmix = model.reconstruct_input_si_zj(s_list, z_list)                    # :178
     parts = {}
@@ -489,7 +490,7 @@ def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1):
         loss = loss + lam['recon_x_mix'] * parts['recon_x_mix']
     if lam['latent_z'] > 0:                                                 # :228-233
         s_new = model.compute_anatomy_encoding(xf, mask_img)
-        _, mu_new, _ = model.compute_modality_encoding(xf)
+        _, mu_new, _ = model.compute_modality_encoding(xf, phase)
         parts['latent_z'] = model.latent_z(mu_list, mu_new, mask)
         loss = loss + lam['latent_z'] * parts['latent_z']
     if lam['sim_s'] > 0:
@@ -520,3 +521,25 @@ def ref_train_step(model, optimizer, inputs, mask, mask_img, lambdas=None, p=1,
             parts['adv_s_d'].backward()
             optimizer_d.step()
     return loss.detach(), {k: v.detach() for k, v in parts.items()}, gnorm, aux
+
+
+def perturb_bn_running_stats(model):
+    """Deterministic non-trivial BatchNorm running statistics (a freshly built model has mean 0 / var 1,
+    which would make inference-mode BN a no-op in the evaluate() fixtures)."""
+    with torch.no_grad():
+        for name, mod in sorted(model.named_modules()):
+            if isinstance(mod, nn.BatchNorm2d):
+                k = torch.arange(mod.num_features, dtype=torch.float32)
+                mod.running_mean.copy_(0.05 * torch.sin(0.7 * k + len(name)))
+                mod.running_var.copy_(1.0 + 0.4 * torch.cos(0.3 * k + len(name)))
+
+
+def ref_evaluate_batch(model, inputs, mask, mask_img, lambdas=None, p=1):
+    """main_missing.py:337-517 for one batch: model.eval(), no_grad, z = mu (phase='test')."""
+    was = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            return ref_forward_losses(model, inputs, mask, mask_img, lambdas, p, phase='test')
+    finally:
+        model.train(was)

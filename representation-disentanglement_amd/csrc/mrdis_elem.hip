@@ -168,6 +168,35 @@ extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, co
     return MRDIS_OK;
 }
 
+// inference-mode BatchNorm (evaluate(), main_missing.py:338): per-channel affine from the running statistics
+template <int V>
+__global__ void bn_eval_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ rmean, const float* __restrict__ rvar,
+                               float eps, long long P, int C) {
+    const int Q = C / V;
+    EW_LOOP(P * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        Vec<V> a, o; a.load(x + r * ldx + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float sc = rsqrtf(rvar[c + k] + eps) * (gamma ? gamma[c + k] : 1.f);
+            o.v[k] = (a.v[k] - rmean[c + k]) * sc + (beta ? beta[c + k] : 0.f);
+        }
+        o.store(y + r * ldy + c);
+    }
+}
+extern "C" int mrdis_bn_eval_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, long long P, int C, float eps, void* stream) {
+    if (!x || !y || !running_mean || !running_var || P < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
+        hipLaunchKernelGGL((bn_eval_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+    else
+        hipLaunchKernelGGL((bn_eval_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 template <int V>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,

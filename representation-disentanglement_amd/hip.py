@@ -42,6 +42,7 @@ _SIGS = {
     'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P]),
     'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
     'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _P]),
+    'mrdis_bn_eval_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _F, _P]),
     'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _L, _I, _P]),
     'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
@@ -253,6 +254,16 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=N
     _chk(lib.mrdis_bn_train_fwd(_ptr(x), ldx, _ptr(y), ldy, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                 _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _stream()), 'bn_train_fwd')
     return out, mean, rstd
+
+
+def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps):
+    lib = load()
+    x, ldx = nhwc(x)
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, H, W, x.device)
+    _chk(lib.mrdis_bn_eval_fwd(_ptr(x), ldx, _ptr(y), C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                               N * H * W, C, eps, _stream()), 'bn_eval_fwd')
+    return y
 
 
 def bn_train_bwd(dy, x, gamma, mean, rstd):

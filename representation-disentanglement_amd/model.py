@@ -114,6 +114,9 @@ class BatchNorm2d(nn.BatchNorm2d):
                 self.num_batches_tracked.add_(1)
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.eps, self.momentum)
+        if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            return ops.hip.bn_eval_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)   # evaluate()
+        # eval-mode BatchNorm under autograd (fine-tuning with frozen statistics) is not on the path: plain torch
         return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, self.eps)
 
 

@@ -247,7 +247,7 @@ def step_cache(key, make):
 
 
 def cached_mix(key, make):
-    if _MIX_CACHE is None or not torch.is_grad_enabled():
+    if _MIX_CACHE is None:
         return make()
     hit = _MIX_CACHE.get(key)
     if hit is None:

@@ -280,8 +280,9 @@ LOSS_KEYS = ('recon_y', 'recon_y_fused', 'recon_x', 'recon_x_mix', 'kl', 'latent
              'adv_s', 'adv_s_d', 'all')
 
 
-def forward_losses(model, config, inputs, mask, mask_img, mask_host):
-    """main_missing.py:165-251 for the loss set with non-zero weight in config.yaml."""
+def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='train'):
+    """main_missing.py:165-251 (phase='train') / :389-505 (phase='test') for the loss set with non-zero
+    weight in config.yaml."""
     M = len(config['contrast_list'])
     c = 2 * config['block_size'] + 1
     inputs_list = [inputs[:, i * c:(i + 1) * c] for i in range(M)]                               # :166-168 (views)
@@ -289,7 +290,7 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host):
     dev = inputs.device
     zero = torch.zeros((), device=dev)
     si_list = model.compute_anatomy_encoding(inputs_list, mask_img)                              # :175
-    zi_list, mu_list, lv_list = model.compute_modality_encoding(inputs_list, si_list, phase='train')   # :176
+    zi_list, mu_list, lv_list = model.compute_modality_encoding(inputs_list, si_list, phase=phase)     # :176 / :400
     xi_fake_list = model.reconstruct_input_si_zi(si_list, zi_list)                               # :177
     xi_fake_mix_list = model.reconstruct_input_si_zj(si_list, zi_list)                           # :178
     parts = {k: zero for k in LOSS_KEYS}
@@ -304,7 +305,7 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host):
         loss = loss + config['lambda_recon_x_mix'] * parts['recon_x_mix']
     if config['lambda_latent_z'] > 0:                                                            # :228-233
         si_new = model.compute_anatomy_encoding(xi_fake_list, mask_img)
-        _, mu_new, _ = model.compute_modality_encoding(xi_fake_list, si_new, phase='train')
+        _, mu_new, _ = model.compute_modality_encoding(xi_fake_list, si_new, phase=phase)
         parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask, mask_host)
         loss = loss + config['lambda_latent_z'] * parts['latent_z']
     if config['lambda_sim_s'] > 0:
@@ -399,6 +400,49 @@ class TrainStep:
         """the 11 scalars of main_missing.py:253-263 in one D2H copy."""
         vec = torch.stack([parts[k].float().reshape(()) for k in LOSS_KEYS]).cpu()
         return {k: float(vec[i]) for i, k in enumerate(LOSS_KEYS)}
+
+
+class EvalStep:
+    """evaluate() of the reference for one batch (main_missing.py:337-517): model.eval() (BatchNorm on
+    running statistics), no_grad, z = mu, the same loss set, plus reconstruction metrics of the
+    cross-modality (mix) reconstructions computed on the device (the reference ships them to skimage on
+    the CPU, util.py:311-333: NRMSE with euclidean normalisation, PSNR with skimage's float data range 2;
+    SSIM is not reproduced).  Returns (loss, parts, metrics, aux)."""
+
+    def __init__(self, model, config):
+        self.model, self.config = model, config
+
+    @torch.no_grad()
+    def __call__(self, inputs, mask, mask_img, mask_host=None):
+        model, cfg = self.model, self.config
+        if mask_host is None:
+            mask_host = mask.cpu()
+        was = model.training
+        model.eval()
+        try:
+            with ops.mix_cache():
+                loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, phase='test')
+                M = len(cfg['contrast_list'])
+                c = 2 * cfg['block_size'] + 1
+                mse, ref2 = [], []
+                k = 0
+                zeros = None
+                for i in range(M):
+                    for j in range(M):
+                        if i == j:
+                            continue
+                        real = inputs[:, j * c:(j + 1) * c]
+                        mse.append(ops.recon_err(real, aux['xi_fake_mix_list'][k], 2))           # (B,)
+                        if zeros is None:
+                            zeros = torch.zeros_like(real)
+                        ref2.append(ops.recon_err(real, zeros, 2))
+                        k += 1
+                mse = torch.cat(mse); ref2 = torch.cat(ref2)
+                metrics = {'mse': mse.mean(), 'rmse': (mse.sqrt() / ref2.sqrt().clamp_min(1e-12)).mean(),
+                           'psnr': (10.0 * torch.log10(4.0 / mse.clamp_min(1e-20))).mean()}
+        finally:
+            model.train(was)
+        return loss, parts, metrics, aux
 
 
 # --------------------------------------------------------------------------- checkpoint layout (util.py:148-153)

@@ -214,3 +214,31 @@ def test_train_step_runs_twice_and_decreases_nothing_nan(mrdis):
         assert torch.isfinite(loss)
     host = step.losses_to_host(parts)
     assert set(host) == set(mrdis.LOSS_KEYS)
+
+
+def test_evaluate_batch_golden(mrdis, golden_dir):
+    """inference path (reference evaluate(), main_missing.py:337-517): eval-mode BatchNorm kernel, z = mu."""
+    meta = json.load(open(os.path.join(golden_dir, 'eval_b2m4.json')))
+    arrs = np.load(os.path.join(golden_dir, 'eval_b2m4.npz'))
+    cfg = _cfg(mrdis, meta['M'], 160, 192, meta['B'])
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg)
+    R.perturb_bn_running_stats(model)
+    inputs, mask, mask_img = make_inputs(meta['B'], meta['M'], 160, 192, seed=12)
+    torch.manual_seed(11); np.random.seed(11)
+    ev = mrdis.EvalStep(model, cfg)
+    loss, parts, metrics, aux = ev(cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+    assert abs(float(loss) - meta['loss']) <= 1e-3 * abs(meta['loss'])
+    for k, v in meta['parts'].items():
+        assert abs(float(parts[k]) - v) <= 1e-3 * abs(v) + 1e-6, (k, float(parts[k]), v)
+    close(torch.stack(aux['mu_list']), arrs['mu'], 1e-3, 'mu')
+    close(F.avg_pool2d(aux['xi_fake_mix_list'][0], 8), arrs['xmix0_pool8'], 1e-3, 'xmix0')
+    # device metrics against their definitions evaluated on the host
+    M, c = meta['M'], 7
+    reals = torch.cat([inputs[:, j * c:(j + 1) * c] for i in range(M) for j in range(M) if i != j], 0)
+    fakes = torch.cat([t.cpu() for t in aux['xi_fake_mix_list']], 0)
+    mse = ((reals - fakes) ** 2).mean((1, 2, 3))
+    assert abs(float(metrics['mse']) - float(mse.mean())) <= 1e-4 * float(mse.mean())
+    want_psnr = float((10 * torch.log10(4.0 / mse)).mean())
+    assert abs(float(metrics['psnr']) - want_psnr) <= 1e-3 * abs(want_psnr)
+    assert model.training

@@ -189,6 +189,18 @@ def test_batchnorm(mrdis, C, N, H, W):
     close(dx, x.grad, rtol=2e-4); close(dg, gm.grad, rtol=2e-4); close(db, bt.grad, rtol=2e-4)
 
 
+@pytest.mark.parametrize('C,N,H,W', [(32, 2, 12, 10), (7, 3, 5, 6), (256, 2, 5, 6)])
+def test_batchnorm_eval(mrdis, C, N, H, W):
+    """running-statistics BatchNorm of the inference path (model.eval())."""
+    hip = mrdis.hip
+    x = rnd((N, C, H, W), 21) * 2 + 0.5
+    gm, bt = rnd((C,), 22), rnd((C,), 23)
+    rm, rv = rnd((C,), 24) * 0.3, rnd((C,), 25).abs() + 0.2
+    y = F.batch_norm(x, rm, rv, gm, bt, False, 0.1, 1e-5)
+    yd = hip.bn_eval_fwd(cl(x), gm.to(dev()), bt.to(dev()), rm.to(dev()), rv.to(dev()), 1e-5)
+    close(yd, y)
+
+
 @pytest.mark.parametrize('C,N,H,W', [(128, 2, 5, 6), (32, 2, 16, 24), (64, 3, 10, 12)])
 def test_instnorm_spade(mrdis, C, N, H, W):
     hip = mrdis.hip

@@ -140,3 +140,21 @@ def test_full_step(golden_dir, tag):
         if meta['grad_norms'].get(k, 1.0) < 1e-5 * meta['grad_norm']:
             continue
         assert abs(w1[k] - v) <= 5e-5 * max(1.0, abs(v)), (k, w1[k], v)
+
+
+def test_evaluate_batch(golden_dir):
+    """evaluate() of the reference (model.eval(), z = mu) for one batch."""
+    meta = json.load(open(os.path.join(golden_dir, 'eval_b2m4.json')))
+    arrs = np.load(os.path.join(golden_dir, 'eval_b2m4.npz'))
+    torch.manual_seed(10); np.random.seed(10)
+    model = R.RefMultimodalModel((160, 192), meta['M'])
+    R.perturb_bn_running_stats(model)
+    inputs, mask, mask_img = make_inputs(meta['B'], meta['M'], 160, 192, seed=12)
+    torch.manual_seed(11); np.random.seed(11)
+    loss, parts, aux = R.ref_evaluate_batch(model, inputs, mask, mask_img)
+    assert abs(float(loss) - meta['loss']) <= 2e-5 * abs(meta['loss'])
+    for k, v in meta['parts'].items():
+        assert abs(float(parts[k]) - v) <= 2e-5 * abs(v) + 1e-7, k
+    np.testing.assert_allclose(torch.stack(aux['mu_list']).numpy(), arrs['mu'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(F.avg_pool2d(aux['xmix'][0], 8).numpy(), arrs['xmix0_pool8'], rtol=1e-4, atol=1e-5)
+    assert model.training            # restored
