@@ -156,6 +156,17 @@ int mrdis_recon_err_fwd(const float* gt, int ldgt, const float* x, int ldx, floa
 int mrdis_recon_err_bwd(const float* gt, int ldgt, const float* x, int ldx, const float* w,
                         float* dx, int lddx, int N, long long HW, int C, int p, void* stream);
 
+/* ---- evaluate() reconstruction metrics on the device: util.py:935-978
+ * (compute_reconstruction_metrics[_single], called at main_missing.py:528).
+ * n_img images of H x W: image i, pixel p at target[(i*H*W + p) * ldt] (i.e. channel 0
+ * of an NHWC view).  Both images are shifted by their own minimum, data range = max of
+ * the shifted target.  out (n_img, 3) = { MSE (the reference's 'rmse' key), PSNR, SSIM }.
+ * SSIM follows skimage.metrics.structural_similarity defaults (7x7 uniform window,
+ * sample covariance, K1 0.01, K2 0.03, mean over the window-valid region).            */
+size_t mrdis_recon_metrics_workspace(int n_img, int H);
+int mrdis_recon_metrics(const float* target, int ldt, const float* pred, int ldp, float* out,
+                        void* workspace, size_t workspace_bytes, int n_img, int H, int W, void* stream);
+
 /* ---- max_pool2d(kernel k x k, stride k): model.py:3448-3451 ---------------- */
 int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* argmax, int N, int H, int W, int C,
                       int k, void* stream);

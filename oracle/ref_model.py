@@ -543,3 +543,31 @@ def ref_evaluate_batch(model, inputs, mask, mask_img, lambdas=None, p=1):
             return ref_forward_losses(model, inputs, mask, mask_img, lambdas, p, phase='test')
     finally:
         model.train(was)
+
+
+def ref_reconstruction_metrics(target, pred):
+    """compute_reconstruction_metrics (util.py:935-978) on numpy stacks (N, C, H, W): per sample, channel 0,
+    both images shifted by their own min, data_range = max of the shifted target.  skimage is not in this
+    image; its three functions are restated from their published definitions (skimage.metrics 0.16-0.19):
+    mean_squared_error = mean((a-b)^2) in float64; peak_signal_noise_ratio = 10 log10(R^2 / mse);
+    structural_similarity defaults = 7x7 uniform filter, sample covariance (NP/(NP-1)), K1 = 0.01,
+    K2 = 0.03, mean of the map cropped by (win-1)//2.  PARITY UNPINNED for these three (no skimage here)."""
+    from scipy.ndimage import uniform_filter
+    out = {'ssim': [], 'psnr': [], 'rmse': []}
+    for i in range(target.shape[0]):
+        t = target[i, 0].astype(np.float64); p = pred[i, 0].astype(np.float64)
+        t = t - t.min(); p = p - p.min()
+        R = t.max()
+        mse = np.mean((t - p) ** 2)
+        out['rmse'].append(mse)                                             # util.py:963 (sic: MSE under 'rmse')
+        out['psnr'].append(10 * np.log10(R * R / mse))
+        win, NP = 7, 49
+        cn = NP / (NP - 1.0)
+        ux, uy = uniform_filter(t, win), uniform_filter(p, win)
+        uxx, uyy, uxy = uniform_filter(t * t, win), uniform_filter(p * p, win), uniform_filter(t * p, win)
+        vx, vy, vxy = cn * (uxx - ux * ux), cn * (uyy - uy * uy), cn * (uxy - ux * uy)
+        C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        pad = (win - 1) // 2
+        out['ssim'].append(S[pad:-pad, pad:-pad].mean())
+    return out

@@ -510,6 +510,111 @@ extern "C" int mrdis_softmax_mask_drop_bwd(const float* dout, int lddo, const fl
     return MRDIS_OK;
 }
 
+// ------------------------------------------------------------------ reconstruction metrics (evaluate(), util.py:935-978)
+// One image = channel 0 of one sample.  Both images are shifted by their own minimum, data range R =
+// max of the shifted target; MSE, PSNR = 10 log10(R^2/MSE), SSIM = mean over the 7x7-valid region of
+// the structural-similarity map (uniform window, sample covariance NP/(NP-1), K1 = 0.01, K2 = 0.03).
+#define MET_WIN 7
+#define MET_MAXW 1024
+__global__ void metrics_minmax_kernel(const float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, long long HW,
+                                      float* __restrict__ mm) {
+    __shared__ float red[3][4];
+    const long long base = (long long)blockIdx.x * HW;
+    float tmin = INFINITY, tmax = -INFINITY, xmin = INFINITY;
+    for (long long e = threadIdx.x; e < HW; e += blockDim.x) {
+        const float a = t[(base + e) * ldt], b = x[(base + e) * ldx];
+        tmin = fminf(tmin, a); tmax = fmaxf(tmax, a); xmin = fminf(xmin, b);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, o)); tmax = fmaxf(tmax, __shfl_xor(tmax, o)); xmin = fminf(xmin, __shfl_xor(xmin, o));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = tmin; red[1][threadIdx.x >> 6] = tmax; red[2][threadIdx.x >> 6] = xmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[blockIdx.x * 3 + 0] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+        mm[blockIdx.x * 3 + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        mm[blockIdx.x * 3 + 2] = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
+    }
+}
+// grid (H, n_img): block y = one image row.  Row sums of squared error for every row; SSIM-map row
+// sums for the rows whose 7x7 window fits.  part[(img*H + row)*2 + {0,1}] (fp64).
+__global__ void metrics_rows_kernel(const float* __restrict__ t, int ldt, const float* __restrict__ x, int ldx, int H, int W,
+                                    const float* __restrict__ mm, double* __restrict__ part) {
+    extern __shared__ float rows[];                      // [MET_WIN][2][W]
+    __shared__ double red[2][4];
+    const int img = blockIdx.y, y = blockIdx.x;
+    const float tmin = mm[img * 3 + 0], xmin = mm[img * 3 + 2];
+    const double R = (double)mm[img * 3 + 1] - (double)tmin;
+    const long long base = (long long)img * H * W;
+    const int pad = MET_WIN / 2;
+    const bool has_win = (y >= pad) && (y < H - pad) && (W >= MET_WIN);
+    const int y0 = has_win ? y - pad : y, nrow = has_win ? MET_WIN : 1;
+    for (int e = threadIdx.x; e < nrow * W; e += blockDim.x) {
+        const int r = e / W, c = e - r * W;
+        const long long p = base + (long long)(y0 + r) * W + c;
+        rows[(r * 2 + 0) * W + c] = t[p * ldt] - tmin;
+        rows[(r * 2 + 1) * W + c] = x[p * ldx] - xmin;
+    }
+    __syncthreads();
+    const int rc = has_win ? pad : 0;                    // this row inside the staged window
+    double se = 0.0, ss = 0.0;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        const double d = (double)rows[(rc * 2 + 0) * W + c] - (double)rows[(rc * 2 + 1) * W + c];
+        se += d * d;
+        if (has_win && c >= pad && c < W - pad) {
+            double sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+            for (int r = 0; r < MET_WIN; ++r)
+                for (int k = -pad; k <= pad; ++k) {
+                    const double a = rows[(r * 2 + 0) * W + c + k], b = rows[(r * 2 + 1) * W + c + k];
+                    sa += a; sb += b; saa += a * a; sbb += b * b; sab += a * b;
+                }
+            const double NP = MET_WIN * MET_WIN, cn = NP / (NP - 1.0);
+            const double ua = sa / NP, ub = sb / NP;
+            const double va = cn * (saa / NP - ua * ua), vb = cn * (sbb / NP - ub * ub), vab = cn * (sab / NP - ua * ub);
+            const double C1 = (0.01 * R) * (0.01 * R), C2 = (0.03 * R) * (0.03 * R);
+            ss += ((2 * ua * ub + C1) * (2 * vab + C2)) / ((ua * ua + ub * ub + C1) * (va + vb + C2));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o); ss += __shfl_xor(ss, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = se; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long long)img * H + y) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part[((long long)img * H + y) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ void metrics_final_kernel(const double* __restrict__ part, const float* __restrict__ mm, int n_img, int H, int W,
+                                     float* __restrict__ out) {
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= n_img) return;
+    double se = 0.0, ss = 0.0;
+    for (int y = 0; y < H; ++y) { se += part[((long long)img * H + y) * 2]; ss += part[((long long)img * H + y) * 2 + 1]; }
+    const double R = (double)mm[img * 3 + 1] - (double)mm[img * 3 + 0];
+    const double mse = se / ((double)H * W);
+    out[img * 3 + 0] = (float)mse;
+    out[img * 3 + 1] = (float)(10.0 * log10(R * R / mse));
+    out[img * 3 + 2] = (H >= MET_WIN && W >= MET_WIN) ? (float)(ss / ((double)(H - MET_WIN + 1) * (W - MET_WIN + 1))) : NAN;
+}
+extern "C" size_t mrdis_recon_metrics_workspace(int n_img, int H) {
+    return sizeof(double) * 2 * (size_t)n_img * H + sizeof(float) * 4 * (size_t)n_img + 64;
+}
+extern "C" int mrdis_recon_metrics(const float* target, int ldt, const float* pred, int ldp, float* out,
+                                   void* workspace, size_t workspace_bytes, int n_img, int H, int W, void* stream) {
+    if (!target || !pred || !out || !workspace || n_img < 1 || H < 1 || W < 1 || ldt < 1 || ldp < 1) return MRDIS_EINVAL;
+    if (W > MET_MAXW || n_img > 65535) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes < mrdis_recon_metrics_workspace(n_img, H)) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(workspace);
+    float* mm = reinterpret_cast<float*>(part + 2 * (size_t)n_img * H);
+    hipLaunchKernelGGL(metrics_minmax_kernel, dim3(n_img), dim3(256), 0, s, target, ldt, pred, ldp, (long long)H * W, mm);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_rows_kernel, dim3(H, n_img), dim3(256), sizeof(float) * MET_WIN * 2 * W, s, target, ldt, pred, ldp, H, W, mm, part);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(metrics_final_kernel, dim3(mrdis_cdiv(n_img, 64)), dim3(64), 0, s, part, mm, n_img, H, W, out);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // ------------------------------------------------------------------ reconstruction error (per-sample mean)
 __global__ void recon_partial_kernel(const float* __restrict__ gt, int ldgt, const float* __restrict__ x, int ldx, long long HW, int C, int p,
                                      int epb, float* __restrict__ part) {

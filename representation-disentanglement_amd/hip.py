@@ -54,6 +54,8 @@ _SIGS = {
     'mrdis_recon_err_workspace': (_Z, [_I, _L, _I]),
     'mrdis_recon_err_fwd': (_I, [_P, _I, _P, _I, _P, _P, _Z, _I, _L, _I, _I, _P]),
     'mrdis_recon_err_bwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
+    'mrdis_recon_metrics_workspace': (_Z, [_I, _I]),
+    'mrdis_recon_metrics': (_I, [_P, _I, _P, _I, _P, _P, _Z, _I, _I, _I, _P]),
     'mrdis_maxpool_fwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mrdis_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_sumsq_workspace': (_Z, []),
@@ -365,6 +367,18 @@ def recon_err_fwd(gt, x, p):
     nb = lib.mrdis_recon_err_workspace(N, H * W, C)
     ws = _ws(nb, x.device)
     _chk(lib.mrdis_recon_err_fwd(_ptr(gt), ldgt, _ptr(x), ldx, _ptr(out), _ptr(ws), nb, N, H * W, C, p, _stream()), 'recon_err_fwd')
+    return out
+
+
+def recon_metrics(target, pred):
+    """(N, 3) = MSE / PSNR / SSIM of channel 0 of each sample (util.py:935-978)."""
+    lib = load()
+    target, ldt = nhwc(target); pred, ldp = nhwc(pred)
+    N, _, H, W = pred.shape
+    out = torch.empty(N, 3, dtype=torch.float32, device=pred.device)
+    nb = lib.mrdis_recon_metrics_workspace(N, H)
+    ws = _ws(nb, pred.device)
+    _chk(lib.mrdis_recon_metrics(_ptr(target), ldt, _ptr(pred), ldp, _ptr(out), _ptr(ws), nb, N, H, W, _stream()), 'recon_metrics')
     return out
 
 

@@ -404,10 +404,11 @@ class TrainStep:
 
 class EvalStep:
     """evaluate() of the reference for one batch (main_missing.py:337-517): model.eval() (BatchNorm on
-    running statistics), no_grad, z = mu, the same loss set, plus reconstruction metrics of the
-    cross-modality (mix) reconstructions computed on the device (the reference ships them to skimage on
-    the CPU, util.py:311-333: NRMSE with euclidean normalisation, PSNR with skimage's float data range 2;
-    SSIM is not reproduced).  Returns (loss, parts, metrics, aux)."""
+    running statistics), no_grad, z = mu, the same loss set, plus the reconstruction metrics of the
+    cross-modality (mix) reconstructions (:520-528) computed on the device instead of shipping both
+    stacks to skimage on the host (util.py:935-978): per image (channel 0 of each sample) min-shifted,
+    data range = max of the shifted target; keys as in the reference ('rmse' holds the MSE, as there).
+    Returns (loss, parts, metrics, aux); metrics values are (M(M-1)B,) device tensors in the reference order."""
 
     def __init__(self, model, config):
         self.model, self.config = model, config
@@ -424,22 +425,15 @@ class EvalStep:
                 loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, phase='test')
                 M = len(cfg['contrast_list'])
                 c = 2 * cfg['block_size'] + 1
-                mse, ref2 = [], []
-                k = 0
-                zeros = None
-                for i in range(M):
+                rows, k = [], 0
+                for i in range(M):                                                   # main_missing.py:520-528
                     for j in range(M):
                         if i == j:
                             continue
-                        real = inputs[:, j * c:(j + 1) * c]
-                        mse.append(ops.recon_err(real, aux['xi_fake_mix_list'][k], 2))           # (B,)
-                        if zeros is None:
-                            zeros = torch.zeros_like(real)
-                        ref2.append(ops.recon_err(real, zeros, 2))
+                        rows.append(hip.recon_metrics(inputs[:, j * c:(j + 1) * c], aux['xi_fake_mix_list'][k]))
                         k += 1
-                mse = torch.cat(mse); ref2 = torch.cat(ref2)
-                metrics = {'mse': mse.mean(), 'rmse': (mse.sqrt() / ref2.sqrt().clamp_min(1e-12)).mean(),
-                           'psnr': (10.0 * torch.log10(4.0 / mse.clamp_min(1e-20))).mean()}
+                rows = torch.cat(rows, 0)                                            # (M(M-1)B, 3), reference order
+                metrics = {'rmse': rows[:, 0], 'psnr': rows[:, 1], 'ssim': rows[:, 2]}
         finally:
             model.train(was)
         return loss, parts, metrics, aux

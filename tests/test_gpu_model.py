@@ -233,12 +233,12 @@ def test_evaluate_batch_golden(mrdis, golden_dir):
         assert abs(float(parts[k]) - v) <= 1e-3 * abs(v) + 1e-6, (k, float(parts[k]), v)
     close(torch.stack(aux['mu_list']), arrs['mu'], 1e-3, 'mu')
     close(F.avg_pool2d(aux['xi_fake_mix_list'][0], 8), arrs['xmix0_pool8'], 1e-3, 'xmix0')
-    # device metrics against their definitions evaluated on the host
+    # device metrics against the host restatement of util.py:935-978, reference order (pair-major)
     M, c = meta['M'], 7
     reals = torch.cat([inputs[:, j * c:(j + 1) * c] for i in range(M) for j in range(M) if i != j], 0)
     fakes = torch.cat([t.cpu() for t in aux['xi_fake_mix_list']], 0)
-    mse = ((reals - fakes) ** 2).mean((1, 2, 3))
-    assert abs(float(metrics['mse']) - float(mse.mean())) <= 1e-4 * float(mse.mean())
-    want_psnr = float((10 * torch.log10(4.0 / mse)).mean())
-    assert abs(float(metrics['psnr']) - want_psnr) <= 1e-3 * abs(want_psnr)
+    want = R.ref_reconstruction_metrics(reals.numpy(), fakes.numpy())
+    for k in ('rmse', 'psnr', 'ssim'):
+        assert metrics[k].shape == (M * (M - 1) * meta['B'],)
+        np.testing.assert_allclose(metrics[k].cpu().numpy(), want[k], rtol=1e-4, atol=1e-6, err_msg=k)
     assert model.training

@@ -306,3 +306,19 @@ def test_error_codes(mrdis):
     x = cl(rnd((1, 4, 8, 8), 40))
     with pytest.raises(hip.MrdisError):
         hip.conv2d_fwd(x, torch.zeros((25, 4, 8), device=dev()), None, 5, 5, 1, 2)    # 25 taps > MRDIS_MAX_TAPS
+
+
+@pytest.mark.parametrize('N,C,Ct,H,W', [(3, 7, 28, 20, 24), (2, 1, 1, 160, 192), (2, 7, 7, 9, 300)])
+def test_recon_metrics(mrdis, N, C, Ct, H, W):
+    """evaluate() metrics (util.py:935-978) on the device vs the host restatement; target is a channel
+    slice of a wider NHWC tensor as in EvalStep."""
+    from oracle import ref_model as R
+    tfull = rnd((N, Ct, H, W), 31); tfull[:, :, :3] = -10.0
+    c0 = Ct - C
+    t = tfull[:, c0:c0 + C]
+    p = t + 0.25 * rnd((N, C, H, W), 32)
+    want = R.ref_reconstruction_metrics(t.numpy(), p.numpy())
+    got = mrdis.hip.recon_metrics(cl(tfull)[:, c0:c0 + C], cl(p)).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], want['rmse'], rtol=1e-5)
+    np.testing.assert_allclose(got[:, 1], want['psnr'], rtol=1e-5)
+    np.testing.assert_allclose(got[:, 2], want['ssim'], rtol=1e-5, atol=1e-6)

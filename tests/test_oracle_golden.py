@@ -158,3 +158,27 @@ def test_evaluate_batch(golden_dir):
     np.testing.assert_allclose(torch.stack(aux['mu_list']).numpy(), arrs['mu'], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(F.avg_pool2d(aux['xmix'][0], 8).numpy(), arrs['xmix0_pool8'], rtol=1e-4, atol=1e-5)
     assert model.training            # restored
+
+
+def test_reconstruction_metrics_definitions():
+    """util.py:935-978 restated (skimage absent): check against brute-force definitions."""
+    rng = np.random.RandomState(3)
+    t = rng.randn(2, 3, 20, 24).astype(np.float32); t[:, :, :4] = -10
+    p = (t + 0.3 * rng.randn(*t.shape)).astype(np.float32)
+    m = R.ref_reconstruction_metrics(t, p)
+    for i in range(2):
+        a = t[i, 0].astype(np.float64) - t[i, 0].min(); b = p[i, 0].astype(np.float64) - p[i, 0].min()
+        Rg = a.max(); C1, C2 = (0.01 * Rg) ** 2, (0.03 * Rg) ** 2
+        acc = []
+        for y in range(3, 17):
+            for x in range(3, 21):
+                wa, wb = a[y - 3:y + 4, x - 3:x + 4].ravel(), b[y - 3:y + 4, x - 3:x + 4].ravel()
+                ua, ub = wa.mean(), wb.mean()
+                va, vb = wa.var(ddof=1), wb.var(ddof=1)
+                vab = ((wa - ua) * (wb - ub)).sum() / 48
+                acc.append((2 * ua * ub + C1) * (2 * vab + C2) / ((ua * ua + ub * ub + C1) * (va + vb + C2)))
+        assert abs(m['ssim'][i] - np.mean(acc)) < 1e-9
+        assert abs(m['rmse'][i] - ((a - b) ** 2).mean()) < 1e-12
+        assert abs(m['psnr'][i] - 10 * np.log10(Rg ** 2 / ((a - b) ** 2).mean())) < 1e-9
+    same = R.ref_reconstruction_metrics(t, t + 5.0)          # min-shift invariance: identical after the shift
+    assert all(abs(v - 1) < 1e-6 for v in same['ssim'])
