@@ -27,6 +27,7 @@
 // fixed order by a second kernel (bit-reproducible, no float atomics).
 #include "mrdis_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define TC_BM 128
 // 256 B of zeros: the source of LDS-DMA lanes that fall outside the image / channel range
@@ -628,10 +629,15 @@ struct C4Params {
     int tilesW, tilesH;          // per image
     long long ntiles;
     int lrelu;
-    int dbg;                     // timing ablations: 1 no MFMA, 2 no stores, 4 no strip loads
 };
 
-template <int NS, bool LRELU, bool FAST>   // FAST: Co % (32*NS) == 0 and 16-byte stores legal -> no per-store checks
+// FAST: Co % (32*NS) == 0 and 16-byte stores legal -> no per-store checks.  FULL: the strips tile the image
+// exactly -> stores need no lane mask.  The strip loop is STRAIGHT-LINE code on purpose: every conditional
+// block inside it is a control-flow join at which hipcc's wait-count pass forgets which loads are pending and
+// falls back to `s_waitcnt vmcnt(0)` -- which also waits for the stores of the previous strip (vmcnt retires
+// in order), serialising the write stream against the read stream.  So: prefetches past the end are redirected
+// to strip 0 instead of skipped, edge zeroing is a select, the first (store-less) iteration is peeled.
+template <int NS, bool LRELU, bool FAST, bool FULL>
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
     const int ty = m / p.TW, tx = m - ty * p.TW;
@@ -649,22 +655,23 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + m;
-                const int coc = co < p.Co ? co : p.Co - 1;
+                const int coc = (FAST || co < p.Co) ? co : p.Co - 1;
                 const float v = p.w[(t * 4 + 2 * half + j) * p.Co + coc];
-                b[t][j][ns] = co < p.Co ? v : 0.f;
+                b[t][j][ns] = (FAST || co < p.Co) ? v : 0.f;
             }
     // operands are swapped (A = filter, B = pixels), so D[cout][position]: a lane owns ONE position and
     // 16 couts (r&3) + 8*(r>>2) + 4*half -> four 16-byte stores per strip instead of sixteen 4-byte ones.
     // The bias is the C operand of the first MFMA of every strip (no accumulator initialisation).
     f32x16 bv[NS];
+    const float* bias = p.bias != nullptr ? p.bias : g_mrdis_zero_page;     // no bias: all indices clamp to 0 below
+    const int bmax = p.bias != nullptr ? p.Co - 1 : 0;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = (cot * NS + ns) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int coc = co < p.Co ? co : p.Co - 1;
-            const float v = p.bias != nullptr ? p.bias[coc] : 0.f;
-            bv[ns][r] = co < p.Co ? v : 0.f;
+            const float v = bias[co < bmax ? co : bmax];
+            bv[ns][r] = (co < p.Co && p.bias != nullptr) ? v : 0.f;
         }
     const bool vec_st = (p.Co % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
     const int tpi = p.tilesW * p.tilesH;
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     // the matrix or memory pipes fill), so a strip computes 3 clamped row bases + 3 clamped columns
     // once and forms the 9 tap BYTE offsets (32-bit, against a wave-uniform image base) with one add
     // each; validity is a 3x3 outer product of row/column bits.  Loads are unconditional from the
-    // clamped address and zeroed at first use (edge strips only).
+    // clamped address and zeroed at first use.
     const unsigned lane_off = 8u * half;
     auto strip_setup = [&](int n, int th, int tw, const char*& img, unsigned (&voff)[9], unsigned& okmask) {
         const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
         dst = *reinterpret_cast<const float2*>(img + voff);
     };
     auto store_group = [&](const f32x16 (&acc)[NS], float* dst, bool ok, int g) {
-        if (ok) {
+        if (FULL || ok) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + 8 * g + 4 * half;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     };
     auto out_ptr = [&](int n, int th, int tw, bool& ok) -> float* {
         const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
-        ok = h < p.H && w_ < p.W && !(p.dbg & 2);
+        ok = h < p.H && w_ < p.W;
         return p.y + ((long long)(n * p.H + h) * p.W + w_) * p.ldy;
     };
 
@@ -756,64 +763,60 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
         strip_setup(cn, cth, ctw, img, vo, mc);
 #pragma unroll
         for (int t = 0; t < 9; ++t) load_tap(img, vo[t], a_cur[t]);
-        if (tile + nwaves < ntiles) {
-            strip_setup(n1, th1, tw1, img, vo, m1);
+        const bool have1 = tile + nwaves < ntiles;
+        strip_setup(have1 ? n1 : 0, have1 ? th1 : 0, have1 ? tw1 : 0, img, vo, m1);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) load_tap(img, vo[t], r1[t]);     // strip 1 -> R[(0+1)&1]
-        }
+        for (int t = 0; t < 9; ++t) load_tap(img, vo[t], r1[t]);         // strip 1 -> R[(0+1)&1]
 #pragma unroll
-        for (int t = 0; t < 9; ++t) if (!((mc >> t) & 1u)) a_cur[t] = make_float2(0.f, 0.f);
+        for (int t = 0; t < 9; ++t) a_cur[t] = ((mc >> t) & 1u) ? a_cur[t] : make_float2(0.f, 0.f);
     }
     f32x16 accA[NS], accB[NS];
     float* pdst = p.y; bool pok = false;
 
-    auto iteration = [&](f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&r_load)[9], unsigned& m_load,
+    auto iteration = [&](auto first, f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&r_load)[9], unsigned& m_load,
                          float2 (&r_use)[9], unsigned& m_use) {
+        constexpr bool FIRST = decltype(first)::value;
         int n2 = n1, th2 = th1, tw2 = tw1;
         advance(n2, th2, tw2);
-        const bool have_n2 = (long long)tile + 2LL * nwaves < ntiles && !(p.dbg & 4);
-        m_load = 0;
-        const char* img2 = reinterpret_cast<const char*>(p.x); unsigned vo2[9];
-        if (have_n2) strip_setup(n2, th2, tw2, img2, vo2, m_load);
+        const bool have_n2 = (long long)tile + 2LL * nwaves < ntiles;
+        const char* img2; unsigned vo2[9];
+        strip_setup(have_n2 ? n2 : 0, have_n2 ? th2 : 0, have_n2 ? tw2 : 0, img2, vo2, m_load);
         bool cok; float* cdst = out_ptr(cn, cth, ctw, cok);
         // 18*NS MFMAs of this strip; the 9 loads of strip i+2 go between the first MFMAs, the 4 stores of
         // strip i-1 between the last ones: co-resident waves run this loop in lockstep, so overlap of the
         // memory pipes with the matrix pipe has to come from inside each wave's own instruction stream.
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (!(p.dbg & 1))
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], a_cur[t].x, t == 0 ? bv[ns] : acc[ns], 0, 0, 0);
                 acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][1][ns], a_cur[t].y, acc[ns], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t < 5 && have_n2) {
+            if (t < 5) {
                 load_tap(img2, vo2[2 * t], r_load[2 * t]);
                 if (2 * t + 1 < 9) load_tap(img2, vo2[2 * t + 1], r_load[2 * t + 1]);
             }
-            if (t >= 5) store_group(prev, pdst, pok, t - 5);
+            if (!FIRST && t >= 5) store_group(prev, pdst, pok, t - 5);
             __builtin_amdgcn_sched_barrier(0);
         }
         pdst = cdst; pok = cok;
         cn = n1; cth = th1; ctw = tw1;
         n1 = n2; th1 = th2; tw1 = tw2;
-        // first use of the loads issued one iteration ago
-        if (__all(m_use == 0x1ffu)) {          // interior strip: nothing to zero (wave-uniform branch)
+        // first use of the loads issued one iteration ago; edge taps become zeros (a select costs what the
+        // plain register copy would)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) a_cur[t] = r_use[t];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a_cur[t] = ((m_use >> t) & 1u) ? r_use[t] : make_float2(0.f, 0.f);
-        }
+        for (int t = 0; t < 9; ++t) a_cur[t] = ((m_use >> t) & 1u) ? r_use[t] : make_float2(0.f, 0.f);
     };
     bool last_is_A = true;
+    iteration(std::true_type{}, accA, accB, r0, m0, r1, m1);
+    tile += nwaves;
     while (tile < ntiles) {
-        iteration(accA, accB, r0, m0, r1, m1);
-        tile += nwaves; last_is_A = true;
-        if (tile >= ntiles) break;
-        iteration(accB, accA, r1, m1, r0, m0);
+        iteration(std::false_type{}, accB, accA, r1, m1, r0, m0);
         tile += nwaves; last_is_A = false;
+        if (tile >= ntiles) break;
+        iteration(std::false_type{}, accA, accB, r0, m0, r1, m1);
+        tile += nwaves; last_is_A = true;
     }
     if (last_is_A) {
 #pragma unroll
@@ -833,7 +836,6 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     C4Params p{};
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.ldx = ldx; p.Co = Co; p.ldy = ldy;
     p.lrelu = (epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
-    if (const char* e = getenv("MRDIS_DEBUG_C4")) p.dbg = atoi(e);
     // strip shape: 32x1 unless a 16x2 strip wastes fewer positions
     const double u32 = (double)W / (mrdis_cdiv(W, 32) * 32.0);
     const double u16 = ((double)W / (mrdis_cdiv(W, 16) * 16.0)) * ((double)H / (mrdis_cdiv(H, 2) * 2.0));
@@ -851,8 +853,8 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     static int occ[3] = {0, 0, 0}, ncu = 0;
     if (!occ[NS]) {
         int o = 0;
-        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
+        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true, true>, 256, 0);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true, true>, 256, 0);
         occ[NS] = o > 0 ? o : 2;
         hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -861,7 +863,9 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     if (blocks > cap) blocks = cap;
     const bool fast = (Co % (32 * NS) == 0) && (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
     const dim3 grid((int)blocks, ny);
-#define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
+    const bool full = (W % p.TW == 0) && (H % p.TH == 0);
+#define C4_LAUNCH(ns, lr, fa) do { if (full) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa, true>), grid, dim3(256), 0, s, p); \
+                                   else hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa, false>), grid, dim3(256), 0, s, p); } while (0)
     if (NS == 2) {
         if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
         else { if (fast) C4_LAUNCH(2, false, true); else C4_LAUNCH(2, false, false); }
