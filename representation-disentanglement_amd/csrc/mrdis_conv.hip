@@ -619,28 +619,39 @@ static int check_conv_geom(int N, int H, int W, int Ci, int Co, int kh, int kw, 
 //     own 3x3 window as nine 8-byte loads (channels 2*half, 2*half+1) -- the two half-waves
 //     together read each 16-byte pixel exactly once per tap, re-reads of the halo are L1 hits;
 //   * the whole filter lives in registers (18 * NS VGPRs) for the lifetime of the wave;
-//   * persistent waves walk the strips with a grid stride; the loads of strip i+1 are issued
-//     before the 18*NS MFMAs of strip i;
-//   * accumulators start at the bias; every store instruction writes two full 128-byte lines.
+//   * persistent waves walk the strips with a grid stride, prefetching TWO strips ahead: tap t of
+//     strip i+2 is loaded into the register pair the MFMAs of tap t of strip i have just read;
+//   * all global traffic goes through per-image buffer descriptors with 32-bit offsets: a tap outside
+//     the image (or a position of a ragged strip) gets an offset beyond `num_records`, so the hardware
+//     range check returns zeros / drops the store -- zero padding and ragged edges cost no branch,
+//     no select at use and no exec masking;
+//   * the strip loop is STRAIGHT-LINE code on purpose: every conditional block inside it is a
+//     control-flow join at which hipcc's wait-count pass forgets which loads are pending and falls back
+//     to `s_waitcnt vmcnt(0)` -- which also waits for the stores of the previous strip (vmcnt retires
+//     in order), serialising the write stream against the read stream;
+//   * accumulators start at the bias (C operand of the first MFMA, kept in its own accumulator set);
+//   * D[position][cout]: lane (m, half) owns cout m of 16 positions, so every store instruction writes
+//     two complete 128-byte lines (32 couts x 4 B for two positions).  The swapped layout (a lane owns 16
+//     couts of one position, four 16-byte stores per strip) issues a quarter of the instructions but
+//     reaches L2 as 32-byte partial-line requests -- 7.4 M requests per launch instead of 1.8 M, and the L2
+//     request rate, not HBM, then bounds the kernel (measured: 58.6 -> 52.2 us in-cache, 106 -> 89 us
+//     beyond the 256 MB Infinity Cache).
 struct C4Params {
     const float* x; const float* w; const float* bias; float* y;
     int N, H, W, ldx, Co, ldy;
-    int TW, TH;                  // strip shape: TW x TH = 32 positions (32x1 or 16x2)
+    int TW, TH;                  // strip shape: TW x TH = 32 positions (32x1, 16x2 or 8x4)
     int tilesW, tilesH;          // per image
     long long ntiles;
     int lrelu;
 };
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define C4_OOB 0x40000000u       // any offset >= this is outside every descriptor this kernel builds
 
-// FAST: Co % (32*NS) == 0 and 16-byte stores legal -> no per-store checks.  FULL: the strips tile the image
-// exactly -> stores need no lane mask.  The strip loop is STRAIGHT-LINE code on purpose: every conditional
-// block inside it is a control-flow join at which hipcc's wait-count pass forgets which loads are pending and
-// falls back to `s_waitcnt vmcnt(0)` -- which also waits for the stores of the previous strip (vmcnt retires
-// in order), serialising the write stream against the read stream.  So: prefetches past the end are redirected
-// to strip 0 instead of skipped, edge zeroing is a select, the first (store-less) iteration is peeled.
-template <int NS, bool LRELU, bool FAST, bool FULL>
+template <int NS, bool LRELU, bool FULL>   // FULL: the strips tile the image exactly (no per-store position checks)
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
-    const int ty = m / p.TW, tx = m - ty * p.TW;
+    const unsigned ty = m / p.TW, tx = m - ty * p.TW;
     // wave-uniform strip bookkeeping lives in SGPRs (readfirstlane makes the uniformity provable)
     const int wave_in_blk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)gridDim.x * 4;
@@ -655,180 +666,181 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + m;
-                const int coc = (FAST || co < p.Co) ? co : p.Co - 1;
+                const int coc = co < p.Co ? co : p.Co - 1;
                 const float v = p.w[(t * 4 + 2 * half + j) * p.Co + coc];
-                b[t][j][ns] = (FAST || co < p.Co) ? v : 0.f;
+                b[t][j][ns] = co < p.Co ? v : 0.f;
             }
-    // operands are swapped (A = filter, B = pixels), so D[cout][position]: a lane owns ONE position and
-    // 16 couts (r&3) + 8*(r>>2) + 4*half -> four 16-byte stores per strip instead of sixteen 4-byte ones.
-    // The bias is the C operand of the first MFMA of every strip (no accumulator initialisation).
+    // bias in the accumulator layout (every register of a lane belongs to cout m).  Passing it once through
+    // the matrix pipe (0*0 + bias) gives the compiler an accumulator-class value it can keep resident.
     f32x16 bv[NS];
-    const float* bias = p.bias != nullptr ? p.bias : g_mrdis_zero_page;     // no bias: all indices clamp to 0 below
-    const int bmax = p.bias != nullptr ? p.Co - 1 : 0;
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns)
+    for (int ns = 0; ns < NS; ++ns) {
+        const int co = (cot * NS + ns) * 32 + m;
+        const float v = (p.bias != nullptr && co < p.Co) ? p.bias[co < p.Co ? co : 0] : 0.f;
+        f32x16 t16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (cot * NS + ns) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = bias[co < bmax ? co : bmax];
-            bv[ns][r] = (co < p.Co && p.bias != nullptr) ? v : 0.f;
-        }
-    const bool vec_st = (p.Co % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.y & 15) == 0);
+        for (int r = 0; r < 16; ++r) t16[r] = v;
+        bv[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, t16, 0, 0, 0);
+    }
     const int tpi = p.tilesW * p.tilesH;
     // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
     const int d_n = nwaves / tpi, d_rem = nwaves - d_n * tpi, d_th = d_rem / p.tilesW, d_tw = d_rem - d_th * p.tilesW;
     int tile = (int)blockIdx.x * 4 + wave_in_blk;
-    int cn = tile / tpi, c_rem = tile - cn * tpi, cth = c_rem / p.tilesW, ctw = c_rem - cth * p.tilesW;
+    if (tile >= ntiles) return;
     auto advance = [&](int& n, int& th, int& tw) {
         tw += d_tw; if (tw >= p.tilesW) { tw -= p.tilesW; th += 1; }
         th += d_th; if (th >= p.tilesH) { th -= p.tilesH; n += 1; }
         n += d_n;
     };
-    // Address arithmetic is the hidden cost of this kernel (the waves are VALU-issue bound long before
-    // the matrix or memory pipes fill), so a strip computes 3 clamped row bases + 3 clamped columns
-    // once and forms the 9 tap BYTE offsets (32-bit, against a wave-uniform image base) with one add
-    // each; validity is a 3x3 outer product of row/column bits.  Loads are unconditional from the
-    // clamped address and zeroed at first use.
+    // geometry in bytes (host guarantees: image bytes < C4_OOB, every 24-bit multiply operand < 2^24)
+    const unsigned pix = 4u * p.ldx, rowbytes = pix * (unsigned)p.W, imgbytes = rowbytes * (unsigned)p.H;
+    const unsigned opix = 4u * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
     const unsigned lane_off = 8u * half;
-    auto strip_setup = [&](int n, int th, int tw, const char*& img, unsigned (&voff)[9], unsigned& okmask) {
-        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
+    const unsigned st_lane = 4u * m + 128u * NS * cot;             // cout m of this y-slice
+    const unsigned uH = p.H, uW = p.W;
+    // timing-only builds (-DC4_ABL_NOLOAD / _NOSTORE / _NOMFMA): a zero-record descriptor drops the traffic
+    // while the instruction stream and the waits stay
+#ifdef C4_ABL_NOLOAD
+    const unsigned xrec = 0;
+#else
+    const unsigned xrec = imgbytes;
+#endif
+#ifdef C4_ABL_NOSTORE
+    const unsigned yrec = 0;
+#else
+    const unsigned yrec = oimgbytes;
+#endif
+    auto x_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * (imgbytes / 4)), 0, xrec, 0x00020000); };
+    auto y_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)n * (oimgbytes / 4)), 0, yrec, 0x00020000); };
+    // 9 tap byte offsets of a strip: 3 row bases x 3 column offsets, each either valid or C4_OOB.
+    auto strip_offsets = [&](int th, int tw, unsigned (&voff)[9]) {
+        const unsigned h = (unsigned)(th * p.TH) + ty, w_ = (unsigned)(tw * p.TW) + tx;
+        const unsigned r1 = __umul24(h, rowbytes) + lane_off, c1 = __umul24(w_, pix);
         unsigned rb[3], cb[3];
-        unsigned rm = 0, cm = 0;
-        const unsigned pix = 4u * p.ldx;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int hh = h + r - 1;
-            rm |= ((unsigned)hh < (unsigned)p.H ? 1u : 0u) << r;
-            rb[r] = (unsigned)(hh < 0 ? 0 : (hh >= p.H ? p.H - 1 : hh)) * (unsigned)p.W * pix + lane_off;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int ww = w_ + c - 1;
-            cm |= ((unsigned)ww < (unsigned)p.W ? 1u : 0u) << c;
-            cb[c] = (unsigned)(ww < 0 ? 0 : (ww >= p.W ? p.W - 1 : ww)) * pix;
-        }
+        rb[0] = (h - 1u < uH) ? r1 - rowbytes : C4_OOB;
+        rb[1] = (h < uH) ? r1 : C4_OOB;
+        rb[2] = (h + 1u < uH) ? r1 + rowbytes : C4_OOB;
+        cb[0] = (w_ - 1u < uW) ? c1 - pix : C4_OOB;
+        cb[1] = (w_ < uW) ? c1 : C4_OOB;
+        cb[2] = (w_ + 1u < uW) ? c1 + pix : C4_OOB;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) voff[3 * r + c] = rb[r] + cb[c];
-        okmask = ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u);
-        img = reinterpret_cast<const char*>(p.x + (long long)n * p.H * p.W * p.ldx);      // wave-uniform
     };
-    // (An inline-asm load with hand-counted vmcnt was tried here and rejected: hipcc may re-home the
-    // destination registers while the load is in flight, and a late write-back then clobbers whatever
-    // lives there -- store addresses included.  Compiler-tracked loads only.)
-    auto load_tap = [&](const char* img, unsigned voff, float2& dst) {
-        dst = *reinterpret_cast<const float2*>(img + voff);
+    // accumulator register r of a lane is strip position P(r) + 4*half, P(r) = (r&3) + 8*(r>>2): row P/TW,
+    // column P%TW (+4*half never crosses a strip row: TW >= 8).  The per-register part of the store offset is
+    // wave-uniform and goes into the scalar offset operand; the lane part is the strip origin + half + cout.
+    auto store_offset = [&](int th, int tw) -> unsigned {             // strip origin + lane part, or OOB
+        const unsigned o = __umul24(__umul24((unsigned)(th * p.TH), uW) + (unsigned)(tw * p.TW) + 4u * half, opix) + st_lane;
+        return o;
     };
-    auto store_group = [&](const f32x16 (&acc)[NS], float* dst, bool ok, int g) {
-        if (FULL || ok) {
+    auto load_tap = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, float2& dst) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0);
+        dst = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    };
+    unsigned lane_ok_off[NS];                          // C4_OOB for lanes whose cout does not exist
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) lane_ok_off[ns] = ((cot * NS + ns) * 32 + m < p.Co) ? 0u : C4_OOB;
+    auto store_group = [&](const f32x16 (&acc)[NS], __amdgpu_buffer_rsrc_t rs, unsigned so, int th, int tw, int g) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 4 * g + k;
+            const int P = (r & 3) + 8 * (r >> 2);
+            const int pty = P / p.TW, ptx = P - pty * p.TW;                       // wave-uniform
+            const unsigned soff = ((unsigned)pty * uW + (unsigned)ptx) * opix;       // scalar operand
+            unsigned vo = so;
+            if (!FULL) {
+                const unsigned h = (unsigned)(th * p.TH + pty), w_ = (unsigned)(tw * p.TW + ptx) + 4u * half;
+                vo = ((int)(h < uH) & (int)(w_ < uW)) ? so : C4_OOB;
+            }
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
-                const int co = (cot * NS + ns) * 32 + 8 * g + 4 * half;
-                float4 v = make_float4(acc[ns][4 * g], acc[ns][4 * g + 1], acc[ns][4 * g + 2], acc[ns][4 * g + 3]);
-                if (LRELU) {
-                    v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-                    v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-                }
-                if (FAST || (vec_st && co + 3 < p.Co)) *reinterpret_cast<float4*>(dst + co) = v;
-                else {
-                    if (co < p.Co) dst[co] = v.x;
-                    if (co + 1 < p.Co) dst[co + 1] = v.y;
-                    if (co + 2 < p.Co) dst[co + 2] = v.z;
-                    if (co + 3 < p.Co) dst[co + 3] = v.w;
-                }
+                float v = acc[ns][r];
+                if (LRELU) v = fmaxf(v, 0.2f * v);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)((vo | lane_ok_off[ns]) + 128u * ns), (int)soff, 0);
             }
         }
     };
-    auto out_ptr = [&](int n, int th, int tw, bool& ok) -> float* {
-        const int h = th * p.TH + ty, w_ = tw * p.TW + tx;
-        ok = h < p.H && w_ < p.W;
-        return p.y + ((long long)(n * p.H + h) * p.W + w_) * p.ldy;
-    };
 
-    // Register pipeline, two strips deep: a_cur (strip i, masked), and two raw buffers that alternate:
-    // iteration i loads strip i+2 into R[i&1] and afterwards consumes R[(i+1)&1] (strip i+1, loaded one
-    // iteration earlier); likewise two accumulator sets alternate (the set of strip i-1 is stored while
-    // strip i computes), so no register copy ever touches a value still in flight.  All loads of an
-    // iteration are issued BEFORE its stores (vmcnt retires in order, so waiting for the older loads
-    // never waits for store completion).
-    float2 a_cur[9], r0[9], r1[9];
-    unsigned m0 = 0, m1 = 0;
-    if (tile >= ntiles) return;
-    int n1 = cn, th1 = cth, tw1 = ctw;
-    advance(n1, th1, tw1);
-    {
-        unsigned mc = 0;
-        const char* img; unsigned vo[9];
-        strip_setup(cn, cth, ctw, img, vo, mc);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) load_tap(img, vo[t], a_cur[t]);
-        const bool have1 = tile + nwaves < ntiles;
-        strip_setup(have1 ? n1 : 0, have1 ? th1 : 0, have1 ? tw1 : 0, img, vo, m1);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) load_tap(img, vo[t], r1[t]);         // strip 1 -> R[(0+1)&1]
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a_cur[t] = ((mc >> t) & 1u) ? a_cur[t] : make_float2(0.f, 0.f);
-    }
+    // Register pipeline: two strip buffers alternate (X0: even strips of this wave, X1: odd); iteration i
+    // runs the MFMAs of tap t from its buffer and immediately refills that pair with tap t of strip i+2.
+    // Two accumulator sets alternate as well (the set of strip i-1 is stored while strip i computes).
+    // Loads are issued BEFORE the stores of an iteration slot, so waiting for a load never waits for a
+    // younger store (vmcnt retires in order).
+    float2 X0[9], X1[9];
+    int cn = tile / tpi, c_rem = tile - cn * tpi, cth = c_rem / p.tilesW, ctw = c_rem - cth * p.tilesW;
+    int ln = cn, lth = cth, ltw = ctw;                  // strip the next loads belong to
+    int ltile = tile;
     f32x16 accA[NS], accB[NS];
-    float* pdst = p.y; bool pok = false;
-
-    auto iteration = [&](auto first, f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&r_load)[9], unsigned& m_load,
-                         float2 (&r_use)[9], unsigned& m_use) {
-        constexpr bool FIRST = decltype(first)::value;
-        int n2 = n1, th2 = th1, tw2 = tw1;
-        advance(n2, th2, tw2);
-        const bool have_n2 = (long long)tile + 2LL * nwaves < ntiles;
-        const char* img2; unsigned vo2[9];
-        strip_setup(have_n2 ? n2 : 0, have_n2 ? th2 : 0, have_n2 ? tw2 : 0, img2, vo2, m_load);
-        bool cok; float* cdst = out_ptr(cn, cth, ctw, cok);
-        // 18*NS MFMAs of this strip; the 9 loads of strip i+2 go between the first MFMAs, the 4 stores of
-        // strip i-1 between the last ones: co-resident waves run this loop in lockstep, so overlap of the
-        // memory pipes with the matrix pipe has to come from inside each wave's own instruction stream.
+    unsigned pso = C4_OOB; int pn = 0, pth = 0, ptw = 0; // store offset / image / strip of the previous strip (none yet:
+                                                        // the first stores are dropped by the range check)
+    // One pipeline step.  PRO (prologue) steps issue exactly the memory instructions of a real step -- nine
+    // loads and four (dropped) stores -- and no MFMAs, so the wait-count pass sees the same number of
+    // outstanding operations on the loop-entry path as on the back edge and keeps the two-strip prefetch
+    // distance instead of clamping it to the shorter path.
+    auto step = [&](auto pro, f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&X)[9]) {
+        constexpr bool PRO = decltype(pro)::value;
+        const bool have_l = ltile < ntiles;                               // prefetch past the end -> strip 0
+        unsigned vo[9];
+        strip_offsets(have_l ? lth : 0, have_l ? ltw : 0, vo);
+        const __amdgpu_buffer_rsrc_t rsx = x_desc(have_l ? ln : 0);
+        const __amdgpu_buffer_rsrc_t rsy = y_desc(pn);
+        const unsigned cso = PRO ? C4_OOB : store_offset(cth, ctw);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+            if (!PRO) {
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) {
-                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], a_cur[t].x, t == 0 ? bv[ns] : acc[ns], 0, 0, 0);
-                acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][1][ns], a_cur[t].y, acc[ns], 0, 0, 0);
+                for (int ns = 0; ns < NS; ++ns) {
+#ifdef C4_ABL_NOMFMA
+                    if (t == 0) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t][0][ns], X[t].x, bv[ns], 0, 0, 0);
+                    else asm volatile("" :: "v"(X[t].x), "v"(X[t].y));
+#else
+                    acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[t].x, b[t][0][ns], t == 0 ? bv[ns] : acc[ns], 0, 0, 0);
+                    acc[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(X[t].y, b[t][1][ns], acc[ns], 0, 0, 0);
+#endif
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t < 5) {
-                load_tap(img2, vo2[2 * t], r_load[2 * t]);
-                if (2 * t + 1 < 9) load_tap(img2, vo2[2 * t + 1], r_load[2 * t + 1]);
-            }
-            if (!FIRST && t >= 5) store_group(prev, pdst, pok, t - 5);
+            load_tap(rsx, vo[t], X[t]);
+            if (t >= 5) store_group(prev, rsy, pso, pth, ptw, t - 5);
             __builtin_amdgcn_sched_barrier(0);
         }
-        pdst = cdst; pok = cok;
-        cn = n1; cth = th1; ctw = tw1;
-        n1 = n2; th1 = th2; tw1 = tw2;
-        // first use of the loads issued one iteration ago; edge taps become zeros (a select costs what the
-        // plain register copy would)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a_cur[t] = ((m_use >> t) & 1u) ? r_use[t] : make_float2(0.f, 0.f);
+        if (!PRO) {
+            pso = cso; pn = cn; pth = cth; ptw = ctw;
+            advance(cn, cth, ctw);
+        }
+        advance(ln, lth, ltw);
+        ltile += nwaves;
     };
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) { accA[ns] = bv[ns]; accB[ns] = bv[ns]; }
+    step(std::true_type{}, accA, accB, X0);             // strip 0 -> X0
+    step(std::true_type{}, accB, accA, X1);             // strip 1 -> X1
     bool last_is_A = true;
-    iteration(std::true_type{}, accA, accB, r0, m0, r1, m1);
-    tile += nwaves;
-    while (tile < ntiles) {
-        iteration(std::false_type{}, accB, accA, r1, m1, r0, m0);
+    while (true) {
+        step(std::false_type{}, accA, accB, X0);
+        tile += nwaves; last_is_A = true;
+        if (tile >= ntiles) break;
+        step(std::false_type{}, accB, accA, X1);
         tile += nwaves; last_is_A = false;
         if (tile >= ntiles) break;
-        iteration(std::false_type{}, accA, accB, r0, m0, r1, m1);
-        tile += nwaves; last_is_A = true;
     }
+    const __amdgpu_buffer_rsrc_t rsy = y_desc(pn);
     if (last_is_A) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) store_group(accA, pdst, pok, g);
+        for (int g = 0; g < 4; ++g) store_group(accA, rsy, pso, pth, ptw, g);
     } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) store_group(accB, pdst, pok, g);
+        for (int g = 0; g < 4; ++g) store_group(accB, rsy, pso, pth, ptw, g);
     }
 }
 
-static bool c4_eligible(const float* x, int ldx, int Ci, int Co, int kh, int kw, int stride, int pad) {
-    return Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16;
+static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    if (!(Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16)) return false;
+    // 32-bit offsets against per-image buffer descriptors, 24-bit multiplies
+    const long long xin = 4LL * ldx * W * H, yout = 4LL * ldy * W * H;
+    return xin < 0x40000000LL && yout < 0x40000000LL && 4LL * ldx * W < (1 << 24) && (long long)H * W < (1 << 24) && 4LL * ldy < (1 << 24);
 }
 
 static int run_c4conv(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
@@ -842,6 +854,7 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     double best = u32; p.TW = 32; p.TH = 1;
     if (u16 > best + 1e-9) { best = u16; p.TW = 16; p.TH = 2; }
     if (W <= 8) { p.TW = 8; p.TH = 4; }
+    if (const char* e = getenv("MRDIS_DEBUG_C4_TW")) { p.TW = atoi(e); p.TH = 32 / p.TW; }
     p.tilesW = mrdis_cdiv(W, p.TW); p.tilesH = mrdis_cdiv(H, p.TH);
     p.ntiles = (long long)N * p.tilesW * p.tilesH;
     const int co32 = mrdis_cdiv(Co, 32);
@@ -853,19 +866,17 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     static int occ[3] = {0, 0, 0}, ncu = 0;
     if (!occ[NS]) {
         int o = 0;
-        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true, true>, 256, 0);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true, true>, 256, 0);
+        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
         occ[NS] = o > 0 ? o : 2;
         hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     long long cap = (long long)ncu * occ[NS] / ny; if (cap < ncu) cap = ncu;
     if (blocks > cap) blocks = cap;
-    const bool fast = (Co % (32 * NS) == 0) && (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
+    const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
-    const bool full = (W % p.TW == 0) && (H % p.TH == 0);
-#define C4_LAUNCH(ns, lr, fa) do { if (full) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa, true>), grid, dim3(256), 0, s, p); \
-                                   else hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa, false>), grid, dim3(256), 0, s, p); } while (0)
+#define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
     if (NS == 2) {
         if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
         else { if (fast) C4_LAUNCH(2, false, true); else C4_LAUNCH(2, false, false); }
@@ -885,7 +896,7 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
-    if (c4_eligible(x, ldx, Ci, Co, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
+    if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     TapConvParams p{};
     p.in = x; p.w = w_tck; p.bias = bias; p.out = y;

@@ -7,7 +7,7 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-for mb in (59, 236, 472, 944):
+for mb in (59, 118, 200, 236, 252, 268, 300, 472, 944, 1888):
     n = mb * 1000 * 1000 // 4
     y = torch.empty(n, device=dev); x = torch.randn(n, device=dev)
     tf = t(lambda: y.fill_(1.0)); tc = t(lambda: y.copy_(x)); tr = t(lambda: x.sum())
