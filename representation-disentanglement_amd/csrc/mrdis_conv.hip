@@ -866,10 +866,10 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     static int occ[3] = {0, 0, 0}, ncu = 0;
     if (!occ[NS]) {
         int o = 0;
-        if (NS == 2) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
-        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
+        if (NS == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
         occ[NS] = o > 0 ? o : 2;
-        hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev);
+        hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     long long cap = (long long)ncu * occ[NS] / ny; if (cap < ncu) cap = ncu;
@@ -960,19 +960,25 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
 }
 
 // =========================================================================== weight gradient
+#define WG_MAX_SLOTS 32
+#define WG_MAX_GROUPS 4
 struct WgradParams {
     const float* x; const float* dy; float* slab;
     int N, Hin, Win, Ci, ldx;
     int A, B, Co, lddy;           // dy extents (Ho, Wo)
-    int is, ntaps;
-    int dh[MRDIS_MAX_TAPS], dw[MRDIS_MAX_TAPS];
-    int dh_min, dw_min;
+    int is, ntaps;                // ntaps = tap SLOTS (nG * J * TPS); slot_ok marks the real ones
+    int dh[WG_MAX_SLOTS], dw[WG_MAX_SLOTS];
+    unsigned slot_ok;
+    // per tap group g: the input view it reads (stride-2 layers: one parity class per group)
+    long long g_off[WG_MAX_GROUPS];
+    int g_Hin[WG_MAX_GROUPS], g_Win[WG_MAX_GROUPS], g_dhmin[WG_MAX_GROUPS], g_dwmin[WG_MAX_GROUPS];
     int NB, TH, TW, TinH, TinW, tilesA, tilesB, tilesN, numTiles;
     int CW, TPS;                  // channels per M sub-tile row group (<=32), taps per sub-tile
     int nCi, nCo, nG, base;       // ci chunks (32), co chunks (32), tap groups, base = nCi*nCo*nG
     int splits;
     int vec_x, vec_dy;
     float* bias_slab;             // [splits][nCo*32] column sums of dy, or nullptr
+    long long x_img; int x_row, x_pix;   // element pitches of the input view (image, row, pixel)
 };
 
 #define WG_TAB_INTS 192   // tab_in[128] tap_xoff[16] + pad
@@ -993,6 +999,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int coc = b % p.nCo; b /= p.nCo;
     const int cic = b % p.nCi;
     const int g = b / p.nCi;
+    const float* __restrict__ xg = p.x + p.g_off[g];
+    const int gHin = p.g_Hin[g], gWin = p.g_Win[g], g_dh_min = p.g_dhmin[g], g_dw_min = p.g_dwmin[g];
     const int c_lo = cic * 32, co_lo = coc * 32;
 
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
@@ -1015,8 +1023,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int tap = (g * J + j) * p.TPS + tl;
-            const bool ok = tap < p.ntaps && (c_lo + cl) < p.Ci;
-            loff[j] = ok ? ((p.dh[tap] - p.dh_min) * p.TinW + (p.dw[tap] - p.dw_min)) * S + cl : 0;
+            const bool ok = tap < p.ntaps && ((p.slot_ok >> tap) & 1u) && (c_lo + cl) < p.Ci;
+            loff[j] = ok ? ((p.dh[tap] - g_dh_min) * p.TinW + (p.dw[tap] - g_dw_min)) * S + cl : 0;
             lvalid |= (ok ? 1u : 0u) << j;
         }
     }
@@ -1037,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         const int ta = tt % p.tilesA;
         const int tn = tt / p.tilesA;
         const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
-        const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+        const int h_org = a0 * p.is + g_dh_min, w_org = b0 * p.is + g_dw_min;
         __syncthreads();
         if (tid < 128) {
             const int m = tid;
@@ -1061,8 +1069,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                 const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
                 const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Ci)
-                    v = *reinterpret_cast<const float4*>(p.x + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c);
+                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
+                    v = *reinterpret_cast<const float4*>(xg + (long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c);
                 float* d = xs + pi * S + 4 * q;
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
@@ -1074,8 +1082,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                 const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
                 const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + k;
                 float v = 0.f;
-                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win && c < p.Ci)
-                    v = p.x[((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c];
+                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
+                    v = xg[(long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c];
                 xs[pi * S + k] = v;
             }
         }
@@ -1194,6 +1202,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
     const int coc = b % p.nCo; b /= p.nCo;
     const int cic = b % p.nCi;
     const int g = b / p.nCi;
+    const float* __restrict__ xg = p.x + p.g_off[g];
+    const int gHin = p.g_Hin[g], gWin = p.g_Win[g], g_dh_min = p.g_dhmin[g], g_dw_min = p.g_dwmin[g];
     const int c_lo = cic * 32, co_lo = coc * 32;
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
     const int thw = p.TH * p.TW;
@@ -1232,8 +1242,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int tap = g * J + j;
-        const bool ok = tap < p.ntaps;
-        loff[j] = ok ? ((p.dh[tap] - p.dh_min) * p.TinW + (p.dw[tap] - p.dw_min)) * 32 + e : 0;
+        const bool ok = tap < p.ntaps && ((p.slot_ok >> tap) & 1u);
+        loff[j] = ok ? ((p.dh[tap] - g_dh_min) * p.TinW + (p.dw[tap] - g_dw_min)) * 32 + e : 0;
         lvalid |= (ok ? 1u : 0u) << j;
     }
     const float* zero = g_mrdis_zero_page + c4;
@@ -1245,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
         const int ta = tt % p.tilesA;
         const int tn = tt / p.tilesA;
         const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
-        const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
+        const int h_org = a0 * p.is + g_dh_min, w_org = b0 * p.is + g_dw_min;
         float* xs = xs0 + buf * (XR * 32);
         float* dys = dys0 + buf * (128 * 32);
 #pragma unroll
@@ -1255,8 +1265,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
                 const float* src = zero;
                 if (xd[k] >= 0) {
                     const int n = n0 + (xd[k] >> 20), h = h_org + ((xd[k] >> 10) & 1023), w_ = w_org + (xd[k] & 1023);
-                    if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
-                        src = p.x + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldx + c_lo + c4;
+                    if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin)
+                        src = xg + (long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c_lo + c4;
                 }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(xs + q * 256), 16, 0, 0);
@@ -1361,8 +1371,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
 
 // dw_tck[t][ci][co] = sum over slabs, fixed order, two parallel stages of <= 32 terms each
 #define WG_RCHUNK 32
+struct WgradTapMap { int slot[MRDIS_MAX_TAPS]; };    // tap row of dw_tck -> tap slot of the launch (stride-2: grouped by parity class)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int ntaps, int Ci, int Co,
-                                    int CW, int TPS, int J, int nCi, int nCo, int base, int nslab) {
+                                    int CW, int TPS, int J, int nCi, int nCo, int base, int nslab, WgradTapMap map) {
     const long long total = (long long)ntaps * Ci * Co;
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -1373,7 +1384,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int coc = co >> 5, n = co & 31;
     const int cic = (Ci >= 32) ? (ci >> 5) : 0;
     const int cl = ci - cic * 32;
-    const int jj = t / TPS, m = (t - jj * TPS) * CW + cl;
+    const int sl = map.slot[t];
+    const int jj = sl / TPS, m = (sl - jj * TPS) * CW + cl;
     const int g = jj / J, j = jj - g * J;
     const int b = (g * nCi + cic) * nCo + coc;
     const long long stride = (long long)base * J * 1024;
@@ -1414,40 +1426,78 @@ struct WgradPlan {
     long long slab_floats, part_floats, bias_floats;
     int nchunk;
     int dma, XR;                  // LDS-DMA kernel usable; staged x rows (multiple of 8)
+    int out_taps;                 // kh*kw rows of dw_tck
+    WgradTapMap map;
     size_t lds_dma;
 };
 
-static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+// Tap groups.  A stride-1 layer has one input view and its kh*kw taps are cut into groups of J sub-tiles.
+// A stride-2 layer is split into the four parity classes of the input (x[2a+p][2b+q]): inside a class every
+// tap is a STRIDE-1 tap on the subsampled view, so the staged tile holds only pixels that are used (a
+// stride-2 tile is 4x larger than what each tap reads), LDS reads are conflict-free and the LDS-DMA kernel
+// applies (its double-buffered stride-2 tile would not fit).  One class = one tap group of the same launch.
+static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int Co, int kh, int kw, int stride, int pad) {
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     WgradParams& p = pl.p;
     p = WgradParams{};
-    p.N = N; p.Hin = H; p.Win = W; p.Ci = Ci; p.A = Ho; p.B = Wo; p.Co = Co; p.is = stride;
-    p.ntaps = kh * kw;
-    int dh_max = -pad, dw_max = -pad;
-    p.dh_min = -pad; p.dw_min = -pad;
-    for (int r = 0; r < kh; ++r)
-        for (int s_ = 0; s_ < kw; ++s_) {
-            const int t = r * kw + s_;
-            p.dh[t] = r - pad; p.dw[t] = s_ - pad;
-            if (p.dh[t] > dh_max) dh_max = p.dh[t];
-            if (p.dw[t] > dw_max) dw_max = p.dw[t];
-        }
-    // M sub-tiles
+    p.N = N; p.Hin = H; p.Win = W; p.Ci = Ci; p.A = Ho; p.B = Wo; p.Co = Co; p.is = 1;
+    p.x_img = (long long)H * W * ldx;
     int CW = 32;
     if (Ci < 32) { CW = 4; while (CW < Ci) CW <<= 1; }
     p.CW = CW; p.TPS = 32 / CW;
-    const int subtiles = mrdis_cdiv(p.ntaps, p.TPS);
-    int J = subtiles, nG = 1;
-    if (subtiles > 9) { nG = mrdis_cdiv(subtiles, 8); J = mrdis_cdiv(subtiles, nG); }
-    // round J up to an instantiated size
     static const int JS[] = {1, 2, 3, 4, 5, 8, 9};
-    int Jr = 9;
-    for (int k = 0; k < 7; ++k) if (JS[k] >= J) { Jr = JS[k]; break; }
-    J = Jr;
+    auto round_J = [&](int J) { for (int k = 0; k < 7; ++k) if (JS[k] >= J) return JS[k]; return 9; };
+    int J, ext_h = 0, ext_w = 0;                        // tile halo extents (max over groups)
+    for (int t = 0; t < MRDIS_MAX_TAPS; ++t) pl.map.slot[t] = 0;
+    if (stride == 1) {
+        p.x_row = W * ldx; p.x_pix = ldx;
+        const int subtiles = mrdis_cdiv(kh * kw, p.TPS);
+        int nG = 1; J = subtiles;
+        if (subtiles > 9) { nG = mrdis_cdiv(subtiles, 8); J = mrdis_cdiv(subtiles, nG); }
+        J = round_J(J);
+        p.nG = mrdis_cdiv(subtiles, J);
+        if (p.nG > WG_MAX_GROUPS || p.nG * J * p.TPS > WG_MAX_SLOTS) return MRDIS_EUNSUPPORTED;
+        for (int g = 0; g < p.nG; ++g) { p.g_off[g] = 0; p.g_Hin[g] = H; p.g_Win[g] = W; p.g_dhmin[g] = -pad; p.g_dwmin[g] = -pad; }
+        for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) {
+            const int t = r * kw + s_;
+            p.dh[t] = r - pad; p.dw[t] = s_ - pad; p.slot_ok |= 1u << t; pl.map.slot[t] = t;
+        }
+        ext_h = kh - 1; ext_w = kw - 1;
+    } else {
+        p.x_row = 2 * W * ldx; p.x_pix = 2 * ldx;
+        int cnt[4] = {0, 0, 0, 0}, maxc = 0;
+        for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) { const int c = (((r - pad) & 1) << 1) | ((s_ - pad) & 1); if (++cnt[c] > maxc) maxc = cnt[c]; }
+        J = round_J(mrdis_cdiv(maxc, p.TPS));
+        if (mrdis_cdiv(maxc, p.TPS) > 9 || 4 * J * p.TPS > WG_MAX_SLOTS) return MRDIS_EUNSUPPORTED;
+        p.nG = 4;
+        int fill[4] = {0, 0, 0, 0};
+        for (int c = 0; c < 4; ++c) {
+            const int pp = c >> 1, qq = c & 1;
+            p.g_off[c] = ((long long)pp * W + qq) * ldx;
+            p.g_Hin[c] = (H - pp + 1) / 2; p.g_Win[c] = (W - qq + 1) / 2;
+            p.g_dhmin[c] = 1 << 20; p.g_dwmin[c] = 1 << 20;
+        }
+        int dhmax[4] = {-(1 << 20), -(1 << 20), -(1 << 20), -(1 << 20)}, dwmax[4] = {-(1 << 20), -(1 << 20), -(1 << 20), -(1 << 20)};
+        for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) {
+            const int u = r - pad, v = s_ - pad, pp = u & 1, qq = v & 1, c = (pp << 1) | qq;
+            const int slot = c * J * p.TPS + fill[c]++;
+            p.dh[slot] = (u - pp) / 2; p.dw[slot] = (v - qq) / 2; p.slot_ok |= 1u << slot; pl.map.slot[r * kw + s_] = slot;
+            if (p.dh[slot] < p.g_dhmin[c]) p.g_dhmin[c] = p.dh[slot];
+            if (p.dw[slot] < p.g_dwmin[c]) p.g_dwmin[c] = p.dw[slot];
+            if (p.dh[slot] > dhmax[c]) dhmax[c] = p.dh[slot];
+            if (p.dw[slot] > dwmax[c]) dwmax[c] = p.dw[slot];
+        }
+        for (int c = 0; c < 4; ++c) {
+            if (cnt[c] == 0) { p.g_dhmin[c] = 0; p.g_dwmin[c] = 0; continue; }
+            if (dhmax[c] - p.g_dhmin[c] > ext_h) ext_h = dhmax[c] - p.g_dhmin[c];
+            if (dwmax[c] - p.g_dwmin[c] > ext_w) ext_w = dwmax[c] - p.g_dwmin[c];
+        }
+    }
     pl.J = J;
-    p.nG = mrdis_cdiv(subtiles, J);
+    p.ntaps = p.nG * J * p.TPS;
+    pl.out_taps = kh * kw;
     p.nCi = (Ci >= 32) ? mrdis_cdiv(Ci, 32) : 1;
     p.nCo = mrdis_cdiv(Co, 32);
     p.base = p.nCi * p.nCo * p.nG;
@@ -1455,8 +1505,8 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
     TileChoice tc = choose_tile(N, Ho, Wo);
     for (;;) {
         p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
-        p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
-        p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+        p.TinH = (p.TH - 1) * p.is + ext_h + 1;
+        p.TinW = (p.TW - 1) * p.is + ext_w + 1;
         pl.lds = sizeof(float) * (256 + 128 * 32 + (size_t)p.NB * p.TinH * p.TinW * (CW + 1));
         if (pl.lds <= 64 * 1024) break;
         if (tc.TH > 1) tc.TH = (tc.TH + 1) / 2; else if (tc.NB > 1) tc.NB = (tc.NB + 1) / 2; else if (tc.TW > 1) tc.TW = (tc.TW + 1) / 2; else return MRDIS_EUNSUPPORTED;
@@ -1469,7 +1519,7 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
         for (int c = 0; c < 2 && !pl.dma; ++c) {
             const TileChoice t = cand[c];
             if (c == 1 && !(Ho % 8 == 0 && Wo % 16 == 0)) break;
-            const int tinH = (t.TH - 1) * p.is + (dh_max - p.dh_min) + 1, tinW = (t.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+            const int tinH = (t.TH - 1) * p.is + ext_h + 1, tinW = (t.TW - 1) * p.is + ext_w + 1;
             const int npix = t.NB * tinH * tinW, XR = (npix + 7) / 8 * 8;
             const size_t lds = sizeof(float) * (128 + 2 * 128 * 32 + 2 * (size_t)XR * 32);
             if (lds <= 80 * 1024 && XR / 8 <= 4 * WGD_XSLOTS && t.NB < 1024 && tinH < 1024 && tinW < 1024) {
@@ -1490,16 +1540,20 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh
     p.splits = (int)splits;
     pl.slab_floats = (long long)p.splits * p.base * J * 1024;
     pl.nchunk = mrdis_cdiv(p.splits, WG_RCHUNK);
-    pl.part_floats = pl.nchunk > 1 ? (long long)pl.nchunk * p.ntaps * Ci * Co : 0;
+    pl.part_floats = pl.nchunk > 1 ? (long long)pl.nchunk * pl.out_taps * Ci * Co : 0;
     pl.bias_floats = (long long)p.splits * p.nCo * 32;
     return MRDIS_OK;
+}
+
+static size_t wgrad_need(const WgradPlan& pl) {
+    return sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
 }
 
 extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
                                                     int kh, int kw, int stride, int pad) {
     WgradPlan pl;
-    if (plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
-    return sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
+    if (plan_wgrad(pl, N, H, W, Ci, Ci, Co, kh, kw, stride, pad)) return 0;
+    return wgrad_need(pl);
 }
 
 template <int J>
@@ -1529,11 +1583,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
                                        int N, int H, int W, int Ci, int Co,
                                        int kh, int kw, int stride, int pad, void* stream) {
     WgradPlan pl;
-    int rc = plan_wgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
+    int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
-    const size_t need = sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
-    if (workspace_bytes < need) return MRDIS_EWORKSPACE;
+    if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     WgradParams& p = pl.p;
@@ -1554,9 +1607,9 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         default: return MRDIS_EUNSUPPORTED;
     }
     if (rc) return rc;
-    const long long total = (long long)p.ntaps * Ci * Co;
+    const long long total = (long long)pl.out_taps * Ci * Co;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mrdis_cdiv(total, 256), pl.nchunk), dim3(256), 0, s, p.slab,
-                       pl.nchunk > 1 ? part : dw_tck, p.ntaps, Ci, Co, p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits);
+                       pl.nchunk > 1 ? part : dw_tck, pl.out_taps, Ci, Co, p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits, pl.map);
     MRDIS_CHECK_LAUNCH();
     if (pl.nchunk > 1) {
         hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(mrdis_cdiv(total, 256)), dim3(256), 0, s, part, dw_tck, total, pl.nchunk);

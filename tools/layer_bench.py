@@ -67,7 +67,7 @@ def main():
     B, (H, W) = a.batch, a.hw
     rows = []
     for name, ci, co, k, s, p, hi, wi, calls, dcalls in layers(B, H, W):
-        if a.only and a.only not in name:
+        if a.only and not any(k_ in name for k_ in a.only.split(',')):
             continue
         x = torch.randn(B, ci, hi, wi, device=dev).contiguous(memory_format=torch.channels_last)
         wt = torch.randn(k * k, ci, co, device=dev) * 0.05
