@@ -1177,6 +1177,205 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------- thin variant (Co <= 8 or Ci <= 8)
+// ana_dec.output (64 -> 4), the decoder head (16 -> 7), every `si_layers` (4 -> C) and the two first
+// encoder layers (7 -> C) have one side of the weight-gradient product at most 8 wide: a 32x32 MFMA tile
+// is then 75-88 % padding and the kernels above run at 3-28 TF/s while the layer is really a streaming
+// reduction (its floor is the HBM read of x and dy).  Here the narrow side stays a per-thread register
+// vector and the product is plain FMAs: thread = (wide channel e, position slot), 8 slots x 16 positions per
+// 128-position tile, acc[tap][narrow] += wide[e] * narrow[k] with the narrow operand read as an LDS
+// broadcast.  Same tiles, tap groups and slab layout as wgrad_kernel, so the fixed-order reduce is shared.
+//   NARROW_X = false:  wide = x channels (chunk of 32), narrow = dy couts   (dW[t][ci=e][co=k])
+//   NARROW_X = true :  wide = dy couts (chunk of 32),  narrow = x channels (dW[t][ci=k][co=e])
+template <int NT, int NN, bool NARROW_X>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const WgradParams p, int J) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tab_in = reinterpret_cast<int*>(smem);
+    int* tab_pos = tab_in + 128;
+    float* dys = smem + 256;              // [128][32]
+    float* xs = dys + 128 * 32;           // [npix_in][S]
+    const int S = NARROW_X ? p.CW : p.CW + 1;      // narrow x rows are read as broadcasts: no padding, 16-byte rows
+
+    const int tid = threadIdx.x, e = tid & 31, slot8 = tid >> 5;
+    const int bid = blockIdx.x;
+    const int split = bid / p.base;
+    int b = bid - split * p.base;
+    const int coc = b % p.nCo; b /= p.nCo;
+    const int cic = b % p.nCi;
+    const int g = b / p.nCi;
+    const float* __restrict__ xg = p.x + p.g_off[g];
+    const int gHin = p.g_Hin[g], gWin = p.g_Win[g], g_dh_min = p.g_dhmin[g], g_dw_min = p.g_dwmin[g];
+    const int c_lo = cic * 32, co_lo = coc * 32;
+    const int slot0 = g * J * p.TPS;
+
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
+    if (tid < 128) {
+        const int m = tid;
+        int tin = 0;
+        if (m < npos) {
+            const int nb = m / (p.TH * p.TW);
+            const int rem = m - nb * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S;
+        }
+        tab_in[m] = tin;
+    }
+    int toff[NT];
+    unsigned tvalid = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int sl = slot0 + t;
+        const bool ok = t < J * p.TPS && sl < p.ntaps && ((p.slot_ok >> sl) & 1u);
+        toff[t] = ok ? ((p.dh[sl] - g_dh_min) * p.TinW + (p.dw[sl] - g_dw_min)) * S : 0;
+        tvalid |= (ok ? 1u : 0u) << t;
+    }
+    const bool wide_ok = NARROW_X ? (co_lo + e < p.Co) : (e < p.CW && c_lo + e < p.Ci);
+    float acc[NT][NN];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < NN; ++k) acc[t][k] = 0.f;
+    const bool do_bias = (p.bias_slab != nullptr) && cic == 0 && g == 0;
+    float bsum = 0.f;
+    __syncthreads();
+
+    for (int tile = split; tile < p.numTiles; tile += p.splits) {
+        int tt = tile;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int tn = tt / p.tilesA;
+        const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
+        const int h_org = a0 * p.is + g_dh_min, w_org = b0 * p.is + g_dw_min;
+        __syncthreads();
+        if (tid < 128) {
+            const int m = tid;
+            int pos = -1;
+            if (m < npos) {
+                const int nb = m / (p.TH * p.TW);
+                const int rem = m - nb * p.TH * p.TW;
+                const int ty = rem / p.TW, tx = rem - ty * p.TW;
+                const int n = n0 + nb, a = a0 + ty, bb = b0 + tx;
+                if (n < p.N && a < p.A && bb < p.B) pos = (n * p.A + a) * p.B + bb;
+            }
+            tab_pos[m] = pos;
+        }
+        if (p.vec_x) {
+            const int Q = p.CW >> 2;
+            for (int idx = tid; idx < npix_in * Q; idx += 256) {
+                const int pi = idx / Q, q = idx - pi * Q;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
+                    v = *reinterpret_cast<const float4*>(xg + (long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c);
+                float* d = xs + pi * S + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < npix_in * p.CW; idx += 256) {
+                const int pi = idx / p.CW, k = idx - pi * p.CW;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + k;
+                float v = 0.f;
+                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
+                    v = xg[(long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c];
+                xs[pi * S + k] = v;
+            }
+        }
+        __syncthreads();   // tab_pos visible
+        if (p.vec_dy) {
+            for (int idx = tid; idx < 128 * 8; idx += 256) {
+                const int m = idx >> 3, q = idx & 7;
+                const int pos = tab_pos[m], co = co_lo + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pos >= 0 && co < p.Co)
+                    v = *reinterpret_cast<const float4*>(p.dy + (long long)pos * p.lddy + co);
+                *reinterpret_cast<float4*>(dys + m * 32 + 4 * q) = v;
+            }
+        } else {
+            for (int idx = tid; idx < 128 * 32; idx += 256) {
+                const int m = idx >> 5, q = idx & 31;
+                const int pos = tab_pos[m], co = co_lo + q;
+                float v = 0.f;
+                if (pos >= 0 && co < p.Co) v = p.dy[(long long)pos * p.lddy + co];
+                dys[idx] = v;
+            }
+        }
+        __syncthreads();
+        if (do_bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += dys[(slot8 * 16 + r) * 32 + e];
+        }
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int m = slot8 + 8 * i;
+            const int ti = tab_in[m];
+            if (NARROW_X) {
+                const float wv = dys[m * 32 + e];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float* xr = xs + ti + toff[t];
+#pragma unroll
+                    for (int k = 0; k < NN; k += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(xr + k);
+                        acc[t][k] += wv * q.x; acc[t][k + 1] += wv * q.y; acc[t][k + 2] += wv * q.z; acc[t][k + 3] += wv * q.w;
+                    }
+                }
+            } else {
+                float nv[NN];
+#pragma unroll
+                for (int k = 0; k < NN; k += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(dys + m * 32 + k);
+                    nv[k] = q.x; nv[k + 1] = q.y; nv[k + 2] = q.z; nv[k + 3] = q.w;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float wv = xs[ti + toff[t] + e];
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) acc[t][k] += wv * nv[k];
+                }
+            }
+        }
+    }
+    // fixed-order reduction over the 8 position slots, one tap at a time; slab[split][b][j][32][32]
+    float* red = dys;                     // [8][NN][32]
+    float* out = p.slab + (((long long)split * p.base + (bid - split * p.base)) * J) * 1024;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NN; ++k) red[(slot8 * NN + k) * 32 + e] = (wide_ok && ((tvalid >> t) & 1u)) ? acc[t][k] : 0.f;
+        __syncthreads();
+        if (t < J * p.TPS) {
+            const int jj = t / p.TPS, tl = t - jj * p.TPS;
+            for (int i = tid; i < NN * 32; i += 256) {
+                const int k = i >> 5, ee = i & 31;
+                float s_ = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s_ += red[(q * NN + k) * 32 + ee];
+                // W1: row = ci = ee (CW == 32 or ee < CW), col = co = k.   W2: row = tl*CW + ci(k), col = co = ee
+                if (NARROW_X) { if (k < p.CW) out[jj * 1024 + (tl * p.CW + k) * 32 + ee] = s_; }
+                else if (ee < p.CW) out[jj * 1024 + (tl * p.CW + ee) * 32 + k] = s_;
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;                  // [slot8][co(32)]
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+            p.bias_slab[((long long)split * p.nCo + coc) * 32 + tid] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- LDS-DMA variant (Ci % 32 == 0, Co % 4 == 0)
 // The plain kernel above is staging-bound: with 144+ accumulator registers only two workgroups fit
 // per CU and nothing hides the global->register->LDS round trip of the next tile.  Here both tiles
@@ -1369,6 +1568,260 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
     }
 }
 
+// ---------------------------------------------------------------- thin variant on the LDS-DMA staging
+// Same product as wgrad_thin_kernel, but the tiles arrive by `global_load_lds` into a double buffer with all
+// index arithmetic hoisted out of the tile loop (the register-staged version spends more time computing
+// addresses than multiplying).  NARROW_X = false needs Ci % 32 == 0 (x rows of 128 B, as wgrad_dma_kernel);
+// NARROW_X = true needs Ci == 4 (x rows of 16 B: one DMA instruction lands 64 pixels).  Co % 4 == 0 in both.
+template <int NT, int NN, bool NARROW_X>
+__global__ __launch_bounds__(256) void wgrad_thin_dma_kernel(const WgradParams p, int J, int XR /* staged x rows */) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int XW = NARROW_X ? 4 : 32;                 // floats per staged x row
+    constexpr int RPI = NARROW_X ? 64 : 8;                // x rows one DMA wave-instruction lands
+    constexpr int DYW = NARROW_X ? 32 : 4;                // floats per staged dy row (narrow dy: the 4 real couts only)
+    constexpr int RPD = NARROW_X ? 8 : 64;                // dy rows per DMA wave-instruction
+    constexpr int DSLOTS = 128 / RPD / 4 > 0 ? 128 / RPD / 4 : 1;   // dy DMA instructions per wave
+    int* tab_in = reinterpret_cast<int*>(smem);           // [128] position -> x row offset (floats)
+    float* dys0 = smem + 128;                             // [2][128*DYW]
+    float* xs0 = dys0 + 2 * 128 * DYW;                    // [2][XR*XW]
+
+    const int tid = threadIdx.x, lane = tid & 63, e = tid & 31, slot8 = tid >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int split = bid / p.base;
+    int b = bid - split * p.base;
+    const int coc = b % p.nCo; b /= p.nCo;
+    const int cic = b % p.nCi;
+    const int g = b / p.nCi;
+    const float* __restrict__ xg = p.x + p.g_off[g];
+    const int gHin = p.g_Hin[g], gWin = p.g_Win[g], g_dh_min = p.g_dhmin[g], g_dw_min = p.g_dwmin[g];
+    const int c_lo = cic * 32, co_lo = coc * 32;
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
+    const int thw = p.TH * p.TW;
+    const int slot0 = g * J * p.TPS;
+
+    if (tid < 128) {
+        int tin = 0;
+        if (tid < npos) {
+            const int nb = tid / thw, rem = tid - nb * thw, ty = rem / p.TW, tx = rem - ty * p.TW;
+            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * XW;
+        }
+        tab_in[tid] = tin;
+    }
+    // tile-invariant staging descriptors
+    const int xrow_l = NARROW_X ? lane : (lane >> 3);     // x row inside a DMA instruction
+    const int xc4 = NARROW_X ? 0 : (lane & 7) * 4;        // float offset inside the row
+    const int r8 = NARROW_X ? (lane >> 3) : lane, c4 = NARROW_X ? (lane & 7) * 4 : 0;   // dy row / float offset inside a DMA instruction
+    int xd[WGD_XSLOTS], dd[DSLOTS];
+#pragma unroll
+    for (int k = 0; k < WGD_XSLOTS; ++k) {
+        const int pi = RPI * (wave + 4 * k) + xrow_l;
+        xd[k] = -1;
+        if (pi < npix_in) {
+            const int nb = pi / tinHW, rem = pi - nb * tinHW, iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            xd[k] = (nb << 20) | (iy << 10) | ix;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DSLOTS; ++k) {
+        const int m = RPD * (wave + 4 * k) + r8;
+        dd[k] = -1;
+        if (m < npos) {
+            const int nb = m / thw, rem = m - nb * thw, ty = rem / p.TW, tx = rem - ty * p.TW;
+            dd[k] = (nb << 20) | (ty << 10) | tx;
+        }
+    }
+    int toff[NT];
+    unsigned tvalid = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int sl = slot0 + t;
+        const bool ok = t < J * p.TPS && sl < p.ntaps && ((p.slot_ok >> sl) & 1u);
+        toff[t] = ok ? ((p.dh[sl] - g_dh_min) * p.TinW + (p.dw[sl] - g_dw_min)) * XW : 0;
+        tvalid |= (ok ? 1u : 0u) << t;
+    }
+    const float* zero = g_mrdis_zero_page + (NARROW_X ? 0 : c4);
+    const float* zero_dy = g_mrdis_zero_page + c4;
+    const int xslots = XR / RPI;
+
+    auto issue_tile = [&](int tile, int buf) {
+        int tt = tile;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int tn = tt / p.tilesA;
+        const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
+        const int h_org = a0 * p.is + g_dh_min, w_org = b0 * p.is + g_dw_min;
+        float* xs = xs0 + buf * (XR * XW);
+        float* dys = dys0 + buf * (128 * DYW);
+#pragma unroll
+        for (int k = 0; k < WGD_XSLOTS; ++k) {
+            const int q = wave + 4 * k;                 // wave-uniform slot
+            if (q < xslots) {
+                const float* src = zero;
+                if (xd[k] >= 0) {
+                    const int n = n0 + (xd[k] >> 20), h = h_org + ((xd[k] >> 10) & 1023), w_ = w_org + (xd[k] & 1023);
+                    if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin)
+                        src = xg + (long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + (NARROW_X ? 0 : c_lo + xc4);
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + q * 256), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DSLOTS; ++k) {
+            const int q = wave + 4 * k;
+            if (q * RPD >= 128) continue;               // wave-uniform
+            const float* src = zero_dy;
+            if (dd[k] >= 0) {
+                const int n = n0 + (dd[k] >> 20), a = a0 + ((dd[k] >> 10) & 1023), bb = b0 + (dd[k] & 1023);
+                if (n < p.N && a < p.A && bb < p.B && co_lo + c4 < p.Co)
+                    src = p.dy + ((long long)(n * p.A + a) * p.B + bb) * p.lddy + co_lo + c4;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dys + q * 256), 16, 0, 0);
+        }
+    };
+
+    const bool wide_ok = NARROW_X ? (co_lo + e < p.Co) : (c_lo + e < p.Ci);
+    // the tap slots of a 3x3 stride-1 layer are r*3+c with unit offsets: the sliding-window loop applies
+    // (a thread's 16 positions slot8*16 .. +15 never straddle a tile row when TW is a multiple of 16)
+    const bool slide = NT == 9 && p.TW % 16 == 0 && npos == 128 && p.TinW == p.TW + 2 && p.TinH == p.TH + 2 && p.is == 1 && p.nG == 1 && tvalid == 0x1ffu;
+    float acc[NT][NN];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < NN; ++k) acc[t][k] = 0.f;
+    const bool do_bias = (p.bias_slab != nullptr) && cic == 0 && g == 0;
+    float bsum = 0.f;
+
+    int tile = split, buf = 0;
+    if (tile < p.numTiles) issue_tile(tile, 0);
+    __syncthreads();                                     // (vmcnt(0) + barrier) first tile landed, tab_in visible
+    for (; tile < p.numTiles; tile += p.splits) {
+        if (tile + p.splits < p.numTiles) issue_tile(tile + p.splits, buf ^ 1);
+        const float* xs = xs0 + buf * (XR * XW);
+        const float* dys = dys0 + buf * (128 * DYW);
+        if (do_bias && e < DYW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += dys[(slot8 * 16 + r) * DYW + e];
+        }
+        if (NT == 9 && slide) {
+            // 3x3 taps, tile rows of 16 positions: thread (e, slot8) walks its row left to right and keeps
+            // the 3x3 window in registers -- one new window column (3 LDS reads) per position instead of 9
+            const int rowbase = tab_in[slot8 * 16];
+            if (NARROW_X) {
+                float4 col[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) col[c][r] = *reinterpret_cast<const float4*>(xs + rowbase + (r * p.TinW + c) * XW);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float wv = dys[(slot8 * 16 + i) * DYW + e];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float4 q = col[(i + c) % 3][r];
+                            acc[r * 3 + c][0] += wv * q.x; acc[r * 3 + c][1] += wv * q.y;
+                            acc[r * 3 + c][2] += wv * q.z; acc[r * 3 + c][3] += wv * q.w;
+                        }
+                    if (i + 3 < 18) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) col[i % 3][r] = *reinterpret_cast<const float4*>(xs + rowbase + (r * p.TinW + i + 3) * XW);
+                    }
+                }
+            } else {
+                float win[3][3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) win[c][r] = xs[rowbase + (r * p.TinW + c) * XW + e];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float nv[NN];
+#pragma unroll
+                    for (int k = 0; k < NN; k += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(dys + (slot8 * 16 + i) * DYW + k);
+                        nv[k] = q.x; nv[k + 1] = q.y; nv[k + 2] = q.z; nv[k + 3] = q.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float wv = win[(i + c) % 3][r];
+#pragma unroll
+                            for (int k = 0; k < NN; ++k) acc[r * 3 + c][k] += wv * nv[k];
+                        }
+                    if (i + 3 < 18) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) win[i % 3][r] = xs[rowbase + (r * p.TinW + i + 3) * XW + e];
+                    }
+                }
+            }
+        } else
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int m = slot8 + 8 * i;
+            const int ti = tab_in[m];
+            if (NARROW_X) {
+                const float wv = dys[m * DYW + e];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 q = *reinterpret_cast<const float4*>(xs + ti + toff[t]);
+                    acc[t][0] += wv * q.x; acc[t][1] += wv * q.y; acc[t][2] += wv * q.z; acc[t][3] += wv * q.w;
+                }
+            } else {
+                float nv[NN];
+#pragma unroll
+                for (int k = 0; k < NN; k += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(dys + m * DYW + k);
+                    nv[k] = q.x; nv[k + 1] = q.y; nv[k + 2] = q.z; nv[k + 3] = q.w;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float wv = xs[ti + toff[t] + e];
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) acc[t][k] += wv * nv[k];
+                }
+            }
+        }
+        __syncthreads();                                 // drains this wave's DMA (vmcnt(0)) and orders the buffers
+        buf ^= 1;
+    }
+    float* red = xs0;                     // [8][NN][32] (>= 4 KB: the x double buffer)
+    float* out = p.slab + (((long long)split * p.base + (bid - split * p.base)) * J) * 1024;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NN; ++k) red[(slot8 * NN + k) * 32 + e] = (wide_ok && ((tvalid >> t) & 1u)) ? acc[t][k] : 0.f;
+        __syncthreads();
+        if (t < J * p.TPS) {
+            const int jj = t / p.TPS, tl = t - jj * p.TPS;
+            for (int i = tid; i < NN * 32; i += 256) {
+                const int k = i >> 5, ee = i & 31;
+                float s_ = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s_ += red[(q * NN + k) * 32 + ee];
+                if (NARROW_X) { if (k < p.CW) out[jj * 1024 + (tl * p.CW + k) * 32 + ee] = s_; }
+                else out[jj * 1024 + ee * 32 + k] = s_;
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+            p.bias_slab[((long long)split * p.nCo + coc) * 32 + tid] = t;
+        }
+    }
+}
+
 // dw_tck[t][ci][co] = sum over slabs, fixed order, two parallel stages of <= 32 terms each
 #define WG_RCHUNK 32
 struct WgradTapMap { int slot[MRDIS_MAX_TAPS]; };    // tap row of dw_tck -> tap slot of the launch (stride-2: grouped by parity class)
@@ -1403,18 +1856,19 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ part, float* __re
     for (int k = 0; k < nchunk; ++k) s_ += part[(long long)k * total + i];
     dw[i] = s_;
 }
-// dbias[co] = sum over splits of bias_slab[split][co]; block (32, 8)
+// dbias[co] = sum over splits of bias_slab[split][co]; block (32, 32): 32 interleaved partial sums per cout, then a
+// fixed-order sum of the partials
 __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int splits, int nCo32, int Co, float* __restrict__ dbias) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][33];
     const int co = blockIdx.x * 32 + threadIdx.x;
     float s_ = 0.f;
-    for (int k = threadIdx.y; k < splits; k += 8) s_ += bslab[(long long)k * nCo32 + co];
+    for (int k = threadIdx.y; k < splits; k += 32) s_ += bslab[(long long)k * nCo32 + co];
     red[threadIdx.y][threadIdx.x] = s_;
     __syncthreads();
     if (threadIdx.y == 0 && co < Co) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
         dbias[co] = t;
     }
 }
@@ -1428,6 +1882,9 @@ struct WgradPlan {
     int dma, XR;                  // LDS-DMA kernel usable; staged x rows (multiple of 8)
     int out_taps;                 // kh*kw rows of dw_tck
     WgradTapMap map;
+    int thin, thin_nt, thin_nn;   // 0 | 1 (narrow dy) | 2 (narrow x); tap slots per group; narrow width
+    int thin_dma;
+    size_t lds_thin;
     size_t lds_dma;
 };
 
@@ -1465,11 +1922,13 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
             p.dh[t] = r - pad; p.dw[t] = s_ - pad; p.slot_ok |= 1u << t; pl.map.slot[t] = t;
         }
         ext_h = kh - 1; ext_w = kw - 1;
+        pl.thin_nt = (p.nG == 1) ? kh * kw : 99;
     } else {
         p.x_row = 2 * W * ldx; p.x_pix = 2 * ldx;
         int cnt[4] = {0, 0, 0, 0}, maxc = 0;
         for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) { const int c = (((r - pad) & 1) << 1) | ((s_ - pad) & 1); if (++cnt[c] > maxc) maxc = cnt[c]; }
         J = round_J(mrdis_cdiv(maxc, p.TPS));
+        pl.thin_nt = maxc;
         if (mrdis_cdiv(maxc, p.TPS) > 9 || 4 * J * p.TPS > WG_MAX_SLOTS) return MRDIS_EUNSUPPORTED;
         p.nG = 4;
         int fill[4] = {0, 0, 0, 0};
@@ -1527,6 +1986,33 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
                 p.NB = t.NB; p.TH = t.TH; p.TW = t.TW; p.TinH = tinH; p.TinW = tinW;
                 pl.lds = sizeof(float) * (256 + 128 * 32 + (size_t)npix * (CW + 1));   // same tile if the plain kernel has to run
                 if (pl.lds > 64 * 1024) { pl.dma = 0; }
+            }
+        }
+    }
+    // thin product (one side <= 8 channels): plain FMAs instead of a padded MFMA tile
+    {
+        const int want = pl.thin_nt;
+        pl.thin = 0; pl.thin_nn = 0; pl.thin_nt = 0;
+        if (!getenv("MRDIS_DEBUG_NOTHIN")) {
+            if (Co <= 8 && Ci >= 16) { pl.thin = 1; pl.thin_nn = Co <= 4 ? 4 : 8; pl.thin_nt = want <= 1 ? 1 : (want <= 9 ? 9 : 0); }
+            else if (Ci <= 8 && Co >= 16) { pl.thin = 2; pl.thin_nn = p.CW; pl.thin_nt = want <= 4 ? 4 : (want <= 9 ? 9 : 0); }
+            if (pl.thin && (pl.thin_nt == 0 || (pl.thin == 2 && pl.thin_nn != 4 && pl.thin_nn != 8))) pl.thin = 0;
+        }
+        if (pl.thin) {
+            pl.dma = 0;
+            const int S = pl.thin == 2 ? p.CW : p.CW + 1;
+            pl.lds_thin = sizeof(float) * (256 + 128 * 32 + (size_t)p.NB * p.TinH * p.TinW * S);
+            // LDS-DMA staging: x rows of 128 B (Ci % 32 == 0) or 16 B (Ci == 4); dy rows of 128 B need Co % 4 == 0
+            pl.thin_dma = 0;
+            const int npix = p.NB * p.TinH * p.TinW;
+            const bool shape_ok = (pl.thin == 1) ? (Ci % 32 == 0 && pl.thin_nn == 4 && pl.thin_nt == 9) : (Ci == 4 && p.CW == 4);
+            if (shape_ok && Co % 4 == 0 && !getenv("MRDIS_DEBUG_NODMA") && p.NB < 1024 && p.TinH < 1024 && p.TinW < 1024) {
+                const int rpi = pl.thin == 2 ? 64 : 8, xw = pl.thin == 2 ? 4 : 32;
+                const int XR = (npix + rpi - 1) / rpi * rpi;
+                const int dyw = pl.thin == 2 ? 32 : 4;
+                size_t lds = sizeof(float) * (128 + 2 * 128 * dyw + 2 * (size_t)XR * xw);
+                if (lds < sizeof(float) * (128 + 2 * 128 * dyw + 8 * 4 * 32 + 256)) lds = sizeof(float) * (128 + 2 * 128 * dyw + 8 * 4 * 32 + 256);   // epilogue scratch
+                if (lds <= 80 * 1024 && XR / rpi <= 4 * WGD_XSLOTS) { pl.thin_dma = 1; pl.XR = XR; pl.lds_dma = lds; }
             }
         }
     }
@@ -1596,6 +2082,33 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
     p.bias_slab = dbias ? part + pl.part_floats : nullptr;
     p.vec_x = (Ci % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0) && (p.CW % 4 == 0);
     p.vec_dy = (Co % 4 == 0) && (lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    const bool x_al = (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0), dy_al = (lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    if (pl.thin && pl.thin_dma && x_al && dy_al) {
+        static bool attr_set = false;
+        if (!attr_set) {      // > 64 KB of dynamic LDS needs the opt-in
+            if (hipFuncSetAttribute((const void*)wgrad_thin_dma_kernel<9, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return MRDIS_ELAUNCH;
+            attr_set = true;
+        }
+        if (pl.thin == 1) hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, false>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        else if (pl.thin_nt == 4) hipLaunchKernelGGL((wgrad_thin_dma_kernel<4, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        else hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        MRDIS_CHECK_LAUNCH();
+        rc = MRDIS_OK;
+    } else
+    if (pl.thin) {
+#define THIN_LAUNCH(nt, nn, nx) hipLaunchKernelGGL((wgrad_thin_kernel<nt, nn, nx>), dim3(p.splits * p.base), dim3(256), pl.lds_thin, s, p, pl.J)
+        if (pl.thin == 1) {
+            if (pl.thin_nt == 1) { if (pl.thin_nn == 4) THIN_LAUNCH(1, 4, false); else THIN_LAUNCH(1, 8, false); }
+            else { if (pl.thin_nn == 4) THIN_LAUNCH(9, 4, false); else THIN_LAUNCH(9, 8, false); }
+        } else {
+            if (pl.thin_nt == 4) { if (pl.thin_nn == 4) THIN_LAUNCH(4, 4, true); else THIN_LAUNCH(4, 8, true); }
+            else { if (pl.thin_nn == 4) THIN_LAUNCH(9, 4, true); else THIN_LAUNCH(9, 8, true); }
+        }
+#undef THIN_LAUNCH
+        MRDIS_CHECK_LAUNCH();
+        rc = MRDIS_OK;
+    } else
     switch (pl.J) {
         case 1: rc = launch_wgrad_t<1>(pl, s); break;
         case 2: rc = launch_wgrad_t<2>(pl, s); break;
@@ -1616,7 +2129,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         MRDIS_CHECK_LAUNCH();
     }
     if (dbias) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 8), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias);
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 32), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias);
         MRDIS_CHECK_LAUNCH();
     }
     return MRDIS_OK;

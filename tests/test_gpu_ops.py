@@ -108,16 +108,19 @@ def test_conv_c4_persistent_pipeline(mrdis):
 
 
 @pytest.mark.parametrize('N,Ci,Co,H,W,k,st', [(24, 32, 32, 128, 144, 3, 1), (8, 64, 96, 72, 80, 3, 1), (16, 32, 64, 64, 64, 4, 2),
-                                              (12, 32, 16, 96, 96, 3, 1), (6, 64, 4, 128, 128, 3, 1)])
+                                              (12, 32, 16, 96, 96, 3, 1), (6, 64, 4, 128, 128, 3, 1),
+                                              (16, 4, 64, 96, 96, 3, 1), (8, 7, 32, 128, 128, 4, 2), (8, 16, 7, 128, 96, 1, 1),
+                                              (8, 4, 128, 64, 64, 3, 1)])
 def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st):
     """weight gradient with several position tiles per workgroup: exercises the double-buffered LDS-DMA
     steady state (and its ragged last tiles), bias column sums included."""
     hip = mrdis.hip
     x = rnd((N, Ci, H, W), 60).requires_grad_(False)
     w = rnd((Co, Ci, k, k), 61, 0.1).requires_grad_(True); b = rnd((Co,), 62, 0.1).requires_grad_(True)
-    y = F.conv2d(x, w, b, st, 1)
+    pad = 0 if k == 1 else 1
+    y = F.conv2d(x, w, b, st, pad)
     gy = rnd(tuple(y.shape), 63); y.backward(gy)
-    dw, db = hip.conv2d_bwd_weight(cl(x), cl(gy), k, k, st, 1, need_bias=True)
+    dw, db = hip.conv2d_bwd_weight(cl(x), cl(gy), k, k, st, pad, need_bias=True)
     close(dw, to_tck(w.grad), rtol=3e-4, what='wgrad dma'); close(db, b.grad, rtol=3e-4, what='dbias dma')
 
 

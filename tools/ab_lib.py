@@ -29,18 +29,35 @@ def main():
     ap.add_argument('--shape', type=int, nargs=5, default=[32, 4, 240, 240, 32])
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--op', default='fwd', choices=['fwd', 'wgrad'])
+    ap.add_argument('--k', type=int, default=3)
+    ap.add_argument('--stride', type=int, default=1)
     a = ap.parse_args()
     N, Ci, H, W, Co = a.shape
     dev = torch.device('cuda:0')
     x = torch.randn(N, Ci, H, W, device=dev).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(9, Ci, Co, device=dev) * 0.1
+    w = torch.randn(a.k * a.k, Ci, Co, device=dev) * 0.1
     b = torch.randn(Co, device=dev)
     y = hip.empty_nhwc(N, Co, H, W, dev)
     libs = [bind(p) for p in a.libs]
     st = torch.cuda.current_stream().cuda_stream
 
+    k, sd = a.k, a.stride
+    pad = 0 if k == 1 else 1
+    Ho, Wo = (H + 2 * pad - k) // sd + 1, (W + 2 * pad - k) // sd + 1
+    if a.op == 'wgrad':
+        dy = torch.randn(N, Co, Ho, Wo, device=dev).contiguous(memory_format=torch.channels_last)
+        dw = torch.empty(k * k, Ci, Co, device=dev); db = torch.empty(Co, device=dev)
+        nb = max(int(l.mrdis_conv2d_bwd_weight_workspace(N, H, W, Ci, Co, k, k, sd, pad)) for l in libs)
+        ws = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+        y = dw
+
     def run(lib):
-        rc = lib.mrdis_conv2d_fwd(x.data_ptr(), Ci, w.data_ptr(), b.data_ptr(), y.data_ptr(), Co, N, H, W, Ci, Co, 3, 3, 1, 1, 0, st)
+        if a.op == 'wgrad':
+            rc = lib.mrdis_conv2d_bwd_weight(x.data_ptr(), Ci, dy.data_ptr(), Co, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb + 256,
+                                             N, H, W, Ci, Co, k, k, sd, pad, st)
+        else:
+            rc = lib.mrdis_conv2d_fwd(x.data_ptr(), Ci, w.data_ptr(), b.data_ptr(), y.data_ptr(), Co, N, H, W, Ci, Co, k, k, sd, pad, 0, st)
         assert rc == 0, rc
     outs = []
     for lib in libs:
