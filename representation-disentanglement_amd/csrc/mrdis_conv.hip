@@ -1177,205 +1177,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// ---------------------------------------------------------------- thin variant (Co <= 8 or Ci <= 8)
-// ana_dec.output (64 -> 4), the decoder head (16 -> 7), every `si_layers` (4 -> C) and the two first
-// encoder layers (7 -> C) have one side of the weight-gradient product at most 8 wide: a 32x32 MFMA tile
-// is then 75-88 % padding and the kernels above run at 3-28 TF/s while the layer is really a streaming
-// reduction (its floor is the HBM read of x and dy).  Here the narrow side stays a per-thread register
-// vector and the product is plain FMAs: thread = (wide channel e, position slot), 8 slots x 16 positions per
-// 128-position tile, acc[tap][narrow] += wide[e] * narrow[k] with the narrow operand read as an LDS
-// broadcast.  Same tiles, tap groups and slab layout as wgrad_kernel, so the fixed-order reduce is shared.
-//   NARROW_X = false:  wide = x channels (chunk of 32), narrow = dy couts   (dW[t][ci=e][co=k])
-//   NARROW_X = true :  wide = dy couts (chunk of 32),  narrow = x channels (dW[t][ci=k][co=e])
-template <int NT, int NN, bool NARROW_X>
-__global__ __launch_bounds__(256) void wgrad_thin_kernel(const WgradParams p, int J) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* tab_in = reinterpret_cast<int*>(smem);
-    int* tab_pos = tab_in + 128;
-    float* dys = smem + 256;              // [128][32]
-    float* xs = dys + 128 * 32;           // [npix_in][S]
-    const int S = NARROW_X ? p.CW : p.CW + 1;      // narrow x rows are read as broadcasts: no padding, 16-byte rows
-
-    const int tid = threadIdx.x, e = tid & 31, slot8 = tid >> 5;
-    const int bid = blockIdx.x;
-    const int split = bid / p.base;
-    int b = bid - split * p.base;
-    const int coc = b % p.nCo; b /= p.nCo;
-    const int cic = b % p.nCi;
-    const int g = b / p.nCi;
-    const float* __restrict__ xg = p.x + p.g_off[g];
-    const int gHin = p.g_Hin[g], gWin = p.g_Win[g], g_dh_min = p.g_dhmin[g], g_dw_min = p.g_dwmin[g];
-    const int c_lo = cic * 32, co_lo = coc * 32;
-    const int slot0 = g * J * p.TPS;
-
-    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
-    if (tid < 128) {
-        const int m = tid;
-        int tin = 0;
-        if (m < npos) {
-            const int nb = m / (p.TH * p.TW);
-            const int rem = m - nb * p.TH * p.TW;
-            const int ty = rem / p.TW, tx = rem - ty * p.TW;
-            tin = ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S;
-        }
-        tab_in[m] = tin;
-    }
-    int toff[NT];
-    unsigned tvalid = 0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int sl = slot0 + t;
-        const bool ok = t < J * p.TPS && sl < p.ntaps && ((p.slot_ok >> sl) & 1u);
-        toff[t] = ok ? ((p.dh[sl] - g_dh_min) * p.TinW + (p.dw[sl] - g_dw_min)) * S : 0;
-        tvalid |= (ok ? 1u : 0u) << t;
-    }
-    const bool wide_ok = NARROW_X ? (co_lo + e < p.Co) : (e < p.CW && c_lo + e < p.Ci);
-    float acc[NT][NN];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < NN; ++k) acc[t][k] = 0.f;
-    const bool do_bias = (p.bias_slab != nullptr) && cic == 0 && g == 0;
-    float bsum = 0.f;
-    __syncthreads();
-
-    for (int tile = split; tile < p.numTiles; tile += p.splits) {
-        int tt = tile;
-        const int tb = tt % p.tilesB; tt /= p.tilesB;
-        const int ta = tt % p.tilesA;
-        const int tn = tt / p.tilesA;
-        const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB;
-        const int h_org = a0 * p.is + g_dh_min, w_org = b0 * p.is + g_dw_min;
-        __syncthreads();
-        if (tid < 128) {
-            const int m = tid;
-            int pos = -1;
-            if (m < npos) {
-                const int nb = m / (p.TH * p.TW);
-                const int rem = m - nb * p.TH * p.TW;
-                const int ty = rem / p.TW, tx = rem - ty * p.TW;
-                const int n = n0 + nb, a = a0 + ty, bb = b0 + tx;
-                if (n < p.N && a < p.A && bb < p.B) pos = (n * p.A + a) * p.B + bb;
-            }
-            tab_pos[m] = pos;
-        }
-        if (p.vec_x) {
-            const int Q = p.CW >> 2;
-            for (int idx = tid; idx < npix_in * Q; idx += 256) {
-                const int pi = idx / Q, q = idx - pi * Q;
-                const int nb = pi / tinHW;
-                const int rem = pi - nb * tinHW;
-                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
-                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
-                    v = *reinterpret_cast<const float4*>(xg + (long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c);
-                float* d = xs + pi * S + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int idx = tid; idx < npix_in * p.CW; idx += 256) {
-                const int pi = idx / p.CW, k = idx - pi * p.CW;
-                const int nb = pi / tinHW;
-                const int rem = pi - nb * tinHW;
-                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
-                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix, c = c_lo + k;
-                float v = 0.f;
-                if (n < p.N && (unsigned)h < (unsigned)gHin && (unsigned)w_ < (unsigned)gWin && c < p.Ci)
-                    v = xg[(long long)n * p.x_img + (long long)h * p.x_row + (long long)w_ * p.x_pix + c];
-                xs[pi * S + k] = v;
-            }
-        }
-        __syncthreads();   // tab_pos visible
-        if (p.vec_dy) {
-            for (int idx = tid; idx < 128 * 8; idx += 256) {
-                const int m = idx >> 3, q = idx & 7;
-                const int pos = tab_pos[m], co = co_lo + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pos >= 0 && co < p.Co)
-                    v = *reinterpret_cast<const float4*>(p.dy + (long long)pos * p.lddy + co);
-                *reinterpret_cast<float4*>(dys + m * 32 + 4 * q) = v;
-            }
-        } else {
-            for (int idx = tid; idx < 128 * 32; idx += 256) {
-                const int m = idx >> 5, q = idx & 31;
-                const int pos = tab_pos[m], co = co_lo + q;
-                float v = 0.f;
-                if (pos >= 0 && co < p.Co) v = p.dy[(long long)pos * p.lddy + co];
-                dys[idx] = v;
-            }
-        }
-        __syncthreads();
-        if (do_bias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bsum += dys[(slot8 * 16 + r) * 32 + e];
-        }
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int m = slot8 + 8 * i;
-            const int ti = tab_in[m];
-            if (NARROW_X) {
-                const float wv = dys[m * 32 + e];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float* xr = xs + ti + toff[t];
-#pragma unroll
-                    for (int k = 0; k < NN; k += 4) {
-                        const float4 q = *reinterpret_cast<const float4*>(xr + k);
-                        acc[t][k] += wv * q.x; acc[t][k + 1] += wv * q.y; acc[t][k + 2] += wv * q.z; acc[t][k + 3] += wv * q.w;
-                    }
-                }
-            } else {
-                float nv[NN];
-#pragma unroll
-                for (int k = 0; k < NN; k += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(dys + m * 32 + k);
-                    nv[k] = q.x; nv[k + 1] = q.y; nv[k + 2] = q.z; nv[k + 3] = q.w;
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float wv = xs[ti + toff[t] + e];
-#pragma unroll
-                    for (int k = 0; k < NN; ++k) acc[t][k] += wv * nv[k];
-                }
-            }
-        }
-    }
-    // fixed-order reduction over the 8 position slots, one tap at a time; slab[split][b][j][32][32]
-    float* red = dys;                     // [8][NN][32]
-    float* out = p.slab + (((long long)split * p.base + (bid - split * p.base)) * J) * 1024;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NN; ++k) red[(slot8 * NN + k) * 32 + e] = (wide_ok && ((tvalid >> t) & 1u)) ? acc[t][k] : 0.f;
-        __syncthreads();
-        if (t < J * p.TPS) {
-            const int jj = t / p.TPS, tl = t - jj * p.TPS;
-            for (int i = tid; i < NN * 32; i += 256) {
-                const int k = i >> 5, ee = i & 31;
-                float s_ = 0.f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s_ += red[(q * NN + k) * 32 + ee];
-                // W1: row = ci = ee (CW == 32 or ee < CW), col = co = k.   W2: row = tl*CW + ci(k), col = co = ee
-                if (NARROW_X) { if (k < p.CW) out[jj * 1024 + (tl * p.CW + k) * 32 + ee] = s_; }
-                else if (ee < p.CW) out[jj * 1024 + (tl * p.CW + ee) * 32 + k] = s_;
-            }
-        }
-    }
-    if (do_bias) {
-        __syncthreads();
-        red[tid] = bsum;                  // [slot8][co(32)]
-        __syncthreads();
-        if (tid < 32) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
-            p.bias_slab[((long long)split * p.nCo + coc) * 32 + tid] = t;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- LDS-DMA variant (Ci % 32 == 0, Co % 4 == 0)
 // The plain kernel above is staging-bound: with 144+ accumulator registers only two workgroups fit
 // per CU and nothing hides the global->register->LDS round trip of the next tile.  Here both tiles
@@ -1568,11 +1369,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradParams p, 
     }
 }
 
-// ---------------------------------------------------------------- thin variant on the LDS-DMA staging
-// Same product as wgrad_thin_kernel, but the tiles arrive by `global_load_lds` into a double buffer with all
-// index arithmetic hoisted out of the tile loop (the register-staged version spends more time computing
-// addresses than multiplying).  NARROW_X = false needs Ci % 32 == 0 (x rows of 128 B, as wgrad_dma_kernel);
-// NARROW_X = true needs Ci == 4 (x rows of 16 B: one DMA instruction lands 64 pixels).  Co % 4 == 0 in both.
+// ---------------------------------------------------------------- thin variant (Co == 4 or Ci == 4)
+// ana_dec.output (64 -> 4) and every `si_layers` (4 -> C) have one side of the weight-gradient product only 4
+// wide: a 32x32 MFMA tile is then 75-88 % padding and the kernels above run at 13-28 TF/s while the layer is
+// really a streaming reduction (its floor is the HBM read of x and dy).  Here the narrow side stays a
+// per-thread register vector and the product is packed FMAs: thread = (wide channel e, position slot), 8
+// slots x 16 positions per 128-position tile, acc[tap][narrow] += wide[e] * narrow[k], the narrow operand
+// read as an LDS broadcast; 3x3 layers keep the window in registers while a thread walks its 16 positions
+// along a tile row (3 LDS reads per position instead of 9).  Tiles arrive by `global_load_lds` into a
+// double buffer as in wgrad_dma_kernel, all index arithmetic hoisted out of the tile loop (a register-staged
+// version of this kernel spent more time computing addresses than multiplying and lost to the MFMA kernels).
+// Same tap groups and slab layout as the other kernels, so the fixed-order reduce is shared.
+//   NARROW_X = false:  wide = x channels (chunk of 32, Ci % 32 == 0), narrow = 4 couts   (dW[t][ci=e][co=k])
+//   NARROW_X = true :  wide = couts (chunk of 32), narrow = the 4 channels of x            (dW[t][ci=k][co=e])
 template <int NT, int NN, bool NARROW_X>
 __global__ __launch_bounds__(256) void wgrad_thin_dma_kernel(const WgradParams p, int J, int XR /* staged x rows */) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1882,9 +1691,8 @@ struct WgradPlan {
     int dma, XR;                  // LDS-DMA kernel usable; staged x rows (multiple of 8)
     int out_taps;                 // kh*kw rows of dw_tck
     WgradTapMap map;
-    int thin, thin_nt, thin_nn;   // 0 | 1 (narrow dy) | 2 (narrow x); tap slots per group; narrow width
-    int thin_dma;
-    size_t lds_thin;
+    int thin, thin_nt, thin_dma;  // 0 | 1 (narrow dy) | 2 (narrow x); tap slots per group; staging fits
+
     size_t lds_dma;
 };
 
@@ -1989,31 +1797,25 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
             }
         }
     }
-    // thin product (one side <= 8 channels): plain FMAs instead of a padded MFMA tile
+    // thin product (one side 4 channels wide): packed FMAs instead of a padded MFMA tile.  Worth it only on the
+    // large maps (launch + reduce overheads dominate the small ones either way).
     {
         const int want = pl.thin_nt;
-        pl.thin = 0; pl.thin_nn = 0; pl.thin_nt = 0;
-        if (!getenv("MRDIS_DEBUG_NOTHIN")) {
-            if (Co <= 8 && Ci >= 16) { pl.thin = 1; pl.thin_nn = Co <= 4 ? 4 : 8; pl.thin_nt = want <= 1 ? 1 : (want <= 9 ? 9 : 0); }
-            else if (Ci <= 8 && Co >= 16) { pl.thin = 2; pl.thin_nn = p.CW; pl.thin_nt = want <= 4 ? 4 : (want <= 9 ? 9 : 0); }
-            if (pl.thin && (pl.thin_nt == 0 || (pl.thin == 2 && pl.thin_nn != 4 && pl.thin_nn != 8))) pl.thin = 0;
+        pl.thin = 0; pl.thin_nt = 0; pl.thin_dma = 0;
+        const bool big = (long long)N * Ho * Wo >= 100000;
+        if (big && !getenv("MRDIS_DEBUG_NOTHIN") && !getenv("MRDIS_DEBUG_NODMA") && Co % 4 == 0 && p.NB < 1024 && p.TinH < 1024 && p.TinW < 1024) {
+            if (Co == 4 && Ci % 32 == 0 && want == 9) { pl.thin = 1; pl.thin_nt = 9; }
+            else if (Ci == 4 && p.CW == 4 && Co >= 16 && want <= 9) { pl.thin = 2; pl.thin_nt = want <= 4 ? 4 : 9; }
         }
         if (pl.thin) {
-            pl.dma = 0;
-            const int S = pl.thin == 2 ? p.CW : p.CW + 1;
-            pl.lds_thin = sizeof(float) * (256 + 128 * 32 + (size_t)p.NB * p.TinH * p.TinW * S);
-            // LDS-DMA staging: x rows of 128 B (Ci % 32 == 0) or 16 B (Ci == 4); dy rows of 128 B need Co % 4 == 0
-            pl.thin_dma = 0;
             const int npix = p.NB * p.TinH * p.TinW;
-            const bool shape_ok = (pl.thin == 1) ? (Ci % 32 == 0 && pl.thin_nn == 4 && pl.thin_nt == 9) : (Ci == 4 && p.CW == 4);
-            if (shape_ok && Co % 4 == 0 && !getenv("MRDIS_DEBUG_NODMA") && p.NB < 1024 && p.TinH < 1024 && p.TinW < 1024) {
-                const int rpi = pl.thin == 2 ? 64 : 8, xw = pl.thin == 2 ? 4 : 32;
-                const int XR = (npix + rpi - 1) / rpi * rpi;
-                const int dyw = pl.thin == 2 ? 32 : 4;
-                size_t lds = sizeof(float) * (128 + 2 * 128 * dyw + 2 * (size_t)XR * xw);
-                if (lds < sizeof(float) * (128 + 2 * 128 * dyw + 8 * 4 * 32 + 256)) lds = sizeof(float) * (128 + 2 * 128 * dyw + 8 * 4 * 32 + 256);   // epilogue scratch
-                if (lds <= 80 * 1024 && XR / rpi <= 4 * WGD_XSLOTS) { pl.thin_dma = 1; pl.XR = XR; pl.lds_dma = lds; }
-            }
+            const int rpi = pl.thin == 2 ? 64 : 8, xw = pl.thin == 2 ? 4 : 32, dyw = pl.thin == 2 ? 32 : 4;
+            const int XR = (npix + rpi - 1) / rpi * rpi;
+            size_t lds = sizeof(float) * (128 + 2 * 128 * dyw + 2 * (size_t)XR * xw);
+            const size_t lds_min = sizeof(float) * (128 + 2 * 128 * dyw + 8 * 4 * 32 + 256);    // epilogue scratch
+            if (lds < lds_min) lds = lds_min;
+            if (lds <= 80 * 1024 && XR / rpi <= 4 * WGD_XSLOTS) { pl.thin_dma = 1; pl.XR = XR; pl.lds_dma = lds; pl.dma = 0; }
+            else pl.thin = 0;
         }
     }
     p.tilesA = mrdis_cdiv(Ho, p.TH); p.tilesB = mrdis_cdiv(Wo, p.TW); p.tilesN = mrdis_cdiv(N, p.NB);
@@ -2093,19 +1895,6 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         if (pl.thin == 1) hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, false>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
         else if (pl.thin_nt == 4) hipLaunchKernelGGL((wgrad_thin_dma_kernel<4, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
         else hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
-        MRDIS_CHECK_LAUNCH();
-        rc = MRDIS_OK;
-    } else
-    if (pl.thin) {
-#define THIN_LAUNCH(nt, nn, nx) hipLaunchKernelGGL((wgrad_thin_kernel<nt, nn, nx>), dim3(p.splits * p.base), dim3(256), pl.lds_thin, s, p, pl.J)
-        if (pl.thin == 1) {
-            if (pl.thin_nt == 1) { if (pl.thin_nn == 4) THIN_LAUNCH(1, 4, false); else THIN_LAUNCH(1, 8, false); }
-            else { if (pl.thin_nn == 4) THIN_LAUNCH(9, 4, false); else THIN_LAUNCH(9, 8, false); }
-        } else {
-            if (pl.thin_nt == 4) { if (pl.thin_nn == 4) THIN_LAUNCH(4, 4, true); else THIN_LAUNCH(4, 8, true); }
-            else { if (pl.thin_nn == 4) THIN_LAUNCH(9, 4, true); else THIN_LAUNCH(9, 8, true); }
-        }
-#undef THIN_LAUNCH
         MRDIS_CHECK_LAUNCH();
         rc = MRDIS_OK;
     } else
