@@ -72,6 +72,17 @@ int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W, const floa
                                  float* dW, float* dfc_w, float* dfc_b, void* workspace, size_t workspace_bytes,
                                  int E, int Co, int Ci, int T, void* stream);
 
+/* All M type rows of a layer at once (types (M, emb); a step calls every CondConv2d with each modality
+ * label, model.py:3138).  w_tck / w_tkc / dw_tck are HOST arrays of M device pointers; a NULL dw_tck[m]
+ * means "type m received no gradient".  r_out (M, E).  dW, dfc_w, dfc_b are the sums over the types.     */
+int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const float* fc_b, const float* types, int emb, int M,
+                                       float* r_out, float* const* w_tck, float* const* w_tkc,
+                                       int E, int Co, int Ci, int T, void* stream);
+size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int Co, int Ci, int T);
+int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
+                                       int emb, int M, float* dW, float* dfc_w, float* dfc_b,
+                                       void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream);
+
 /* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and
  * nn.Conv2d of the discriminator model.py:2773-2789 ---------------------------
  * x : NHWC view (N,H,W,Ci) ld=ldx ; y : NHWC view (N,Ho,Wo,Co) ld=ldy

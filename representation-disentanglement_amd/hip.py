@@ -35,6 +35,9 @@ _SIGS = {
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
+    'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -176,6 +179,41 @@ def mix_experts_routed_bwd(dw_tck, W, r, t_row, emb):
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_routed_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(t_row), emb, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
                                           _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_bwd')
+    return dW, dfcw, dfcb
+
+
+def mix_experts_routed_multi_fwd(W, fcw, fcb, types):
+    """all M type rows at once: -> ([w_tck_m], [w_tkc_m], r (M,E))."""
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); fcw = fcw.contiguous(); fcb = fcb.contiguous(); types = types.contiguous()
+    M, emb = types.shape
+    tck = [torch.empty((T, Ci, Co), dtype=torch.float32, device=W.device) for _ in range(M)]
+    tkc = [torch.empty((T, Co, Ci), dtype=torch.float32, device=W.device) for _ in range(M)]
+    r = torch.empty((M, E), dtype=torch.float32, device=W.device)
+    a = (_c.c_void_p * M)(*[t.data_ptr() for t in tck]); b = (_c.c_void_p * M)(*[t.data_ptr() for t in tkc])
+    _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, E, Co, Ci, T, _stream()),
+         'mix_experts_routed_multi_fwd')
+    return tck, tkc, r
+
+
+def mix_experts_routed_multi_bwd(dw_list, W, r, types):
+    """dw_list: M tensors (T,Ci,Co) or None -> (dW, dfcw, dfcb) summed over the types."""
+    lib = load()
+    E, Co, Ci, kh, kw = W.shape
+    T = kh * kw
+    W = W.contiguous(); types = types.contiguous()
+    M, emb = types.shape
+    dw_list = [None if g is None else g.contiguous() for g in dw_list]
+    a = (_c.c_void_p * M)(*[None if g is None else g.data_ptr() for g in dw_list])
+    dW = torch.empty_like(W)
+    dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
+    dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
+    nb = lib.mrdis_mix_experts_routed_multi_bwd_workspace(M, E, Co, Ci, T)
+    ws = _ws(nb, W.device)
+    _chk(lib.mrdis_mix_experts_routed_multi_bwd(a, _ptr(W), _ptr(r), _ptr(types), emb, M, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
+                                                _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
     return dW, dfcw, dfcb
 
 

@@ -77,8 +77,16 @@ class CondConv2d(nn.Module):
         kh, kw = self.kernel_size
         B = inputs.shape[0]
         if B == 1 or inputs_type.stride(0) == 0:
-            key = (id(self), inputs_type.data_ptr(), inputs_type._version)
-            w_tck, w_tkc = ops.cached_mix(key, lambda: self._mixed(inputs_type[:1]))
+            hit = ops.lookup_type_row(inputs_type) if ops.mix_cache_active() else None
+            if hit is not None:        # one of the model's modality labels: all labels are mixed in one launch per step
+                table, row = hit
+                key = (id(self), 'all', table.data_ptr(), table._version)
+                allw = ops.cached_mix(key, lambda: ops.mix_experts_routed_all(
+                    self.weight, self._routing_fn.fc.weight, self._routing_fn.fc.bias, table))
+                w_tck, w_tkc = allw[2 * row], allw[2 * row + 1]
+            else:
+                key = (id(self), inputs_type.data_ptr(), inputs_type._version)
+                w_tck, w_tkc = ops.cached_mix(key, lambda: self._mixed(inputs_type[:1]))
             return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
         outs = []                                    # per-sample path, model.py:2114-2117
         for i in range(B):
@@ -435,13 +443,16 @@ class MultimodalModel(nn.Module):
             self.discrim_s = Discriminator(s_num_ch, 16, (H, W), is_patch_gan)                    # :2966-2967
         self.to(device)
         self._types = {}
+        # modality labels 1..M (model.py:3138) as one table, so CondConv2d can mix all of them at once
+        self._type_table = ops.register_type_table(
+            torch.arange(1, modality_num + 1, dtype=torch.float32, device=device).view(modality_num, 1))
 
     # ---- helpers
     def _type(self, i, B):
         key = (i, B)
         t = self._types.get(key)
         if t is None:
-            t = self._types[key] = expand_type(1 + i, B, self.device)
+            t = self._types[key] = self._type_table[i:i + 1].expand(B, 1)
         return t
 
     # ---- model.py:3135-3157

@@ -56,6 +56,53 @@ def mix_experts_routed(W, fcw, fcb, t_row):
     return _MixExpertsRouted.apply(W, fcw, fcb, t_row)
 
 
+class _MixExpertsRoutedAll(Function):
+    """_MixExpertsRouted for every modality type of the step in one launch pair: returns
+    (w_tck_0, w_tkc_0, ..., w_tck_{M-1}, w_tkc_{M-1}); the backward sums dW / dfc over the types in-kernel."""
+
+    @staticmethod
+    def forward(ctx, W, fcw, fcb, types):
+        tck, tkc, r = hip.mix_experts_routed_multi_fwd(W, fcw, fcb, types)
+        ctx.save_for_backward(W, r, types)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*tkc)
+        out = []
+        for a, b in zip(tck, tkc):
+            out += [a, b]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        W, r, types = ctx.saved_tensors
+        dW, dfcw, dfcb = hip.mix_experts_routed_multi_bwd(list(grads[0::2]), W, r, types)
+        return dW, dfcw, dfcb, None
+
+
+def mix_experts_routed_all(W, fcw, fcb, types):
+    return _MixExpertsRoutedAll.apply(W, fcw, fcb, types)
+
+
+# registry of the per-model type tables: storage pointer -> (M, emb) tensor whose rows are the modality labels
+_TYPE_TABLES = {}
+
+
+def register_type_table(table):
+    _TYPE_TABLES[table.untyped_storage().data_ptr()] = table
+    return table
+
+
+def lookup_type_row(inputs_type):
+    """(table, row index) if `inputs_type` is a stride-0 expand of one row of a registered table, else None."""
+    table = _TYPE_TABLES.get(inputs_type.untyped_storage().data_ptr())
+    if table is None or inputs_type.dim() != 2 or inputs_type.shape[1] != table.shape[1]:
+        return None
+    emb = table.shape[1]
+    off = inputs_type.storage_offset()
+    if off % emb != 0 or off // emb >= table.shape[0] or (emb > 1 and inputs_type.stride(1) != 1):
+        return None
+    return table, off // emb
+
+
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(Function):
     """F.conv2d (model.py:2104) with optional fused LeakyReLU(0.2) epilogue."""
@@ -244,6 +291,10 @@ def step_cache(key, make):
     """generic per-step memo (same scope as the mixed-kernel cache): e.g. the bilinear resizes of an
     anatomy map s_i, which every SPADE block of every decoder call recomputes in the reference."""
     return cached_mix(key, make)
+
+
+def mix_cache_active():
+    return _MIX_CACHE is not None
 
 
 def cached_mix(key, make):

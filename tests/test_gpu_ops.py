@@ -177,6 +177,34 @@ def test_mix_experts_routed(mrdis):
     close(dW, W.grad, rtol=1e-6); close(dfcw, fcw.grad, rtol=1e-5); close(dfcb, fcb.grad, rtol=1e-5)
 
 
+def test_mix_experts_routed_multi(mrdis):
+    """all modality labels of a layer in one launch pair; a label without gradient (None) contributes nothing."""
+    hip = mrdis.hip
+    W = rnd((3, 40, 24, 3, 3), 80).requires_grad_(True)
+    fcw = rnd((3, 1), 81).requires_grad_(True); fcb = rnd((3,), 82).requires_grad_(True)
+    types = torch.tensor([[1.0], [2.0], [3.0], [4.0]])
+    gs = [rnd((9, 24, 40), 83), None, rnd((9, 24, 40), 84), rnd((9, 24, 40), 85)]
+    loss = 0
+    mixed_ref = []
+    for m in range(4):
+        r = torch.sigmoid(F.linear(types[m:m + 1], fcw, fcb))[0]
+        mixed = (r[:, None, None, None, None] * W).sum(0)
+        mixed_ref.append(mixed)
+        if gs[m] is not None:
+            loss = loss + (to_tck(mixed) * gs[m]).sum()
+    loss.backward()
+    tck, tkc, rd = hip.mix_experts_routed_multi_fwd(W.detach().to(dev()), fcw.detach().to(dev()), fcb.detach().to(dev()), types.to(dev()))
+    for m in range(4):
+        close(tck[m], to_tck(mixed_ref[m]), rtol=1e-6); close(tkc[m], to_tkc(mixed_ref[m]), rtol=1e-6)
+    dW, dfcw, dfcb = hip.mix_experts_routed_multi_bwd([None if g is None else g.to(dev()) for g in gs], W.detach().to(dev()), rd, types.to(dev()))
+    close(dW, W.grad, rtol=1e-5); close(dfcw, fcw.grad, rtol=1e-5); close(dfcb, fcb.grad, rtol=1e-5)
+    # the autograd op: same numbers through torch.autograd, unused labels allowed
+    Wd = W.detach().to(dev()).requires_grad_(True); fwd_ = fcw.detach().to(dev()).requires_grad_(True); fbd = fcb.detach().to(dev()).requires_grad_(True)
+    outs = mrdis.ops.mix_experts_routed_all(Wd, fwd_, fbd, types.to(dev()))
+    sum((outs[2 * m] * gs[m].to(dev())).sum() for m in range(4) if gs[m] is not None).backward()
+    close(Wd.grad, W.grad, rtol=1e-5); close(fwd_.grad, fcw.grad, rtol=1e-5); close(fbd.grad, fcb.grad, rtol=1e-5)
+
+
 @pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 16), (32, 3, 9, 7), (256, 2, 5, 6), (16, 2, 8, 8), (48, 2, 6, 10)])
 def test_batchnorm(mrdis, C, N, H, W):
     hip = mrdis.hip
