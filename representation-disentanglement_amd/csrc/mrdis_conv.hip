@@ -46,10 +46,10 @@ struct TapConvParams {
     int tilesA, tilesB, tilesN, coTiles;
     int epilogue;
     int vec_in, vec_w;
-    int prefetch;                 // register-prefetch pipeline usable (vector paths + item counts fit)
+    int prefetch;                 // staging mode of tapconv_kernel: 0 generic | 1 hoisted descriptors + register prefetch
 };
 
-template <int KC, int BN, bool PF>
+template <int KC, int BN, int MODE>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch
 __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     constexpr int S = KC + 1;
     constexpr int WAVES_N = (BN == 32) ? 1 : 2;
@@ -178,33 +178,16 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
         }
     };
 
-    auto compute_chunk_legacy = [&]() {
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = tap_xoff[t];
-            const float* wt = ws + t * (KC * BN) + bbase;
-#pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float av[MSUB], bv[NSUB];
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i) av[i] = xs[abase[i] + toff + 2 * kk];
-#pragma unroll
-                for (int j = 0; j < NSUB; ++j) bv[j] = wt[2 * kk * BN + j * 32];
-#pragma unroll
-                for (int i = 0; i < MSUB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NSUB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-    const bool legacy = (p.epilogue & 0x400) != 0;
 
-    if constexpr (PF) {
-        // ---- software pipeline: the global loads of chunk c+1 are in flight (registers) while chunk c
-        // runs out of LDS; staging descriptors (tile geometry) are chunk-invariant and computed once.
+    if constexpr (MODE != 0) {
+        // ---- hoisted staging: what each thread fetches (tile geometry, filter rows) is chunk-invariant, so the
+        // divisions and 64-bit address arithmetic run once per workgroup and a chunk costs one add per item
+        // (the generic loops below spend ~3 VALU instructions per MFMA on it); the global loads of chunk c+1 are
+        // in flight (registers) while chunk c runs out of LDS.  Measured against the generic loops: 7-16 %
+        // faster on every layer shape of the step (tools/ab_lib.py, MRDIS_DEBUG_MODE=0).
         constexpr int XR = 6, WR = 9, QX = KC / 4, QW = BN / 4;
         const int nx = npix_in * QX, nw = p.ntaps * KC * QW;
-        long long xg[XR]; int xl[XR];
+        int xg[XR], xl[XR], wg[WR];
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             const int idx = tid + it * 256;
@@ -217,7 +200,18 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
                 const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix;
                 xl[it] = pi * S + 4 * q;
                 if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
-                    xg[it] = ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + 4 * q;
+                    xg[it] = ((n * p.Hin + h) * p.Win + w_) * p.ldin + 4 * q;       // host: < 2^31 elements
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WR; ++it) {
+            const int idx = tid + it * 256;
+            wg[it] = -1;
+            if (idx < nw) {
+                const int row = idx / QW, q = idx - row * QW;
+                const int t = row / KC, k = row - t * KC;
+                const int co = co0 + 4 * q;
+                if (co < p.Cout) wg[it] = (tap_widx[t] * p.Cin + k) * p.Cout + co;
             }
         }
         float4 xr[XR], wr[WR];
@@ -228,17 +222,12 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
                 xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (xg[it] >= 0 && c0 + 4 * q < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
             }
+            const float* wc = p.w + (long long)c0 * p.Cout;
 #pragma unroll
             for (int it = 0; it < WR; ++it) {
-                const int idx = tid + it * 256;
+                const int k = ((tid + it * 256) / QW) % KC;
                 wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nw) {
-                    const int row = idx / QW, q = idx - row * QW;
-                    const int t = row / KC, k = row - t * KC;
-                    const int c = c0 + k, co = co0 + 4 * q;
-                    if (c < p.Cin && co < p.Cout)
-                        wr[it] = *reinterpret_cast<const float4*>(p.w + ((long long)tap_widx[t] * p.Cin + c) * p.Cout + co);
-                }
+                if (wg[it] >= 0 && c0 + k < p.Cin) wr[it] = *reinterpret_cast<const float4*>(wc + wg[it]);
             }
         };
         auto store_chunk = [&]() {
@@ -251,15 +240,14 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
                 if (idx < nw) *reinterpret_cast<float4*>(ws + 4 * idx) = wr[it];
             }
         };
-        const bool ab_nostage = (p.epilogue & 0x100) != 0, ab_nomfma = (p.epilogue & 0x200) != 0;   // timing ablations (debug)
         load_chunk(0);
         store_chunk();
         __syncthreads();
         for (int c0 = 0; c0 < p.Cin; c0 += KC) {
             const bool more = c0 + KC < p.Cin;
-            if (more && !ab_nostage) load_chunk(c0 + KC);
-            if (!ab_nomfma) { if (legacy) compute_chunk_legacy(); else compute_chunk(); }
-            if (more) { __syncthreads(); if (!ab_nostage) store_chunk(); __syncthreads(); }
+            if (more) load_chunk(c0 + KC);
+            compute_chunk();
+            if (more) { __syncthreads(); store_chunk(); __syncthreads(); }
         }
     } else
     for (int c0 = 0; c0 < p.Cin; c0 += KC) {
@@ -317,7 +305,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
             }
         }
         __syncthreads();
-        if (legacy) compute_chunk_legacy(); else compute_chunk();
+        compute_chunk();
     }
 
     // ---- epilogue.  The MFMA operands are swapped (A = filter, B = pixels), so D is [cout][position]:
@@ -521,8 +509,8 @@ static TileChoice choose_tile(int N, int A, int B) {
 
 template <int KC, int BN>
 static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, hipStream_t s) {
-    if (p.prefetch) hipLaunchKernelGGL((tapconv_kernel<KC, BN, true>), dim3(nblk), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, false>), dim3(nblk), dim3(256), lds, s, p);
+    if (p.prefetch == 1) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1>), dim3(nblk), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, 0>), dim3(nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -567,7 +555,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     // layer (register pressure halves the residency of the 128 variant); small grids prefer 32.
     int BN = p.Cout <= 32 ? 32 : 64;
     if (BN == 64 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
-    if (const char* e = getenv("MRDIS_DEBUG_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) BN = v; }
+    if (const char* e = getenv("MRDIS_DEBUG_BN")) { const int v = atoi(e); if (v == 32 || v == 64) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
@@ -579,20 +567,18 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     while ((tapconv_lds(p, KC, BN) > LDS_MAX || (want_pf && !fits_pf(KC, BN))) && KC > 4) KC >>= 1;
     while (tapconv_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
     if (tapconv_lds(p, KC, BN) > LDS_MAX) return MRDIS_EUNSUPPORTED;
-    // the register-prefetch pipeline pays once there are >= 8 channel chunks to pipeline over; with fewer
-    // chunks the extra VGPRs (lower residency) cost more than the hidden latency buys (tools/sweep.py)
-    p.prefetch = want_pf && fits_pf(KC, BN) && p.Cin >= 8 * KC;
-    if (const char* e = getenv("MRDIS_DEBUG_ABLATE")) p.epilogue |= (atoi(e) & 3) << 8;
-    if (const char* e = getenv("MRDIS_DEBUG_NOPF")) { if (atoi(e)) p.prefetch = 0; }
-    if (const char* e = getenv("MRDIS_DEBUG_LEGACY")) { if (atoi(e)) p.epilogue |= 0x400; }
+    // 32-bit element offsets in the hoisted descriptors
+    const bool small = (long long)p.N * p.Hin * p.Win * p.ldin < 0x7fffffffLL && (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout < 0x7fffffffLL;
+    p.prefetch = (want_pf && fits_pf(KC, BN) && small) ? 1 : 0;
+    if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
     p.coTiles = mrdis_cdiv(p.Cout, BN);
     const long long nblk = ptiles * p.coTiles;
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     const size_t lds = tapconv_lds(p, KC, BN);
 #define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, s)
-    TC_CASE(4, 32); TC_CASE(4, 64); TC_CASE(4, 128);
-    TC_CASE(8, 32); TC_CASE(8, 64); TC_CASE(8, 128);
-    TC_CASE(16, 32); TC_CASE(16, 64); TC_CASE(16, 128);
+    TC_CASE(4, 32); TC_CASE(4, 64);
+    TC_CASE(8, 32); TC_CASE(8, 64);
+    TC_CASE(16, 32); TC_CASE(16, 64);
 #undef TC_CASE
     return MRDIS_EUNSUPPORTED;
 }
