@@ -414,6 +414,87 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW;
     const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
 
+    auto compute_chunk = [&]() {
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = tap_xoff[t];
+            const float* wt = ws + t * (KC * BN) + abase;
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                const float av = wt[4 * q * BN];
+                const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
+            }
+        }
+    };
+    if (p.prefetch) {
+        // hoisted staging descriptors + register prefetch of the next chunk (as tapconv_kernel MODE 1); the filter
+        // slab is fetched as 16-byte pieces (Cout % 4 == 0) and scattered into its [tap][KC][16] rows
+        constexpr int XR = 6, WR = 3, QX = KC / 4;
+        const int nx = npix_in * QX, cq = p.Cout >> 2, nw = p.ntaps * KC * cq;
+        int xg[XR], xl[XR], wg[WR], wl[WR], wk[WR];
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + it * 256;
+            xg[it] = -1; xl[it] = -1;
+            if (idx < nx) {
+                const int pi = idx / QX, q = idx - pi * QX;
+                const int nb = pi / tinHW;
+                const int rem = pi - nb * tinHW;
+                const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+                const int n = n0 + nb, h = h_org + iy, w_ = w_org + ix;
+                xl[it] = pi * S + 4 * q;
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                    xg[it] = ((n * p.Hin + h) * p.Win + w_) * p.ldin + 4 * q;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WR; ++it) {
+            const int idx = tid + it * 256;
+            wg[it] = -1; wl[it] = 0; wk[it] = 0;
+            if (idx < nw) {
+                const int row = idx / cq, q = idx - row * cq;
+                const int t = row / KC, k = row - t * KC;
+                wg[it] = (tap_widx[t] * p.Cin + k) * p.Cout + 4 * q;
+                wl[it] = row * BN + 4 * q; wk[it] = k;
+            }
+        }
+        float4 xr[XR], wr[WR];
+        auto load_chunk = [&](int c0) {
+#pragma unroll
+            for (int it = 0; it < XR; ++it) {
+                const int q = (tid + it * 256) % QX;
+                xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xg[it] >= 0 && c0 + 4 * q < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
+            }
+            const float* wc = p.w + (long long)c0 * p.Cout;
+#pragma unroll
+            for (int it = 0; it < WR; ++it) {
+                wr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wg[it] >= 0 && c0 + wk[it] < p.Cin) wr[it] = *reinterpret_cast<const float4*>(wc + wg[it]);
+            }
+        };
+        auto store_chunk = [&]() {
+#pragma unroll
+            for (int it = 0; it < XR; ++it)
+                if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+#pragma unroll
+            for (int it = 0; it < WR; ++it)
+                if (wg[it] >= 0) *reinterpret_cast<float4*>(ws + wl[it]) = wr[it];
+        };
+        // columns >= Cout of the filter slab stay zero for the whole kernel
+        for (int idx = tid; idx < p.ntaps * KC * BN; idx += 256) ws[idx] = 0.f;
+        __syncthreads();
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+        for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+            const bool more = c0 + KC < p.Cin;
+            if (more) load_chunk(c0 + KC);
+            compute_chunk();
+            if (more) { __syncthreads(); store_chunk(); __syncthreads(); }
+        }
+    } else
     for (int c0 = 0; c0 < p.Cin; c0 += KC) {
         if (c0) __syncthreads();
         if (p.vec_in) {
@@ -455,17 +536,7 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
             }
         }
         __syncthreads();
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = tap_xoff[t];
-            const float* wt = ws + t * (KC * BN) + abase;
-#pragma unroll
-            for (int q = 0; q < KC / 4; ++q) {
-                const float av = wt[4 * q * BN];
-                const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
-            }
-        }
+        compute_chunk();
     }
     // D: col = lane&15 (position), row = (lane>>4)*4 + reg (cout)
     const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
@@ -544,6 +615,15 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
         auto lds16 = [&](int kc) { return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * kc * 16 + (size_t)p.NB * p.TinH * p.TinW * (kc + 1)); };
         while (lds16(KC) > 64 * 1024 && KC > 4) KC >>= 1;
         if (lds16(KC) > 64 * 1024) return MRDIS_EUNSUPPORTED;
+        // hoisted descriptors + register prefetch: vector paths on both operands, item counts within the register arrays,
+        // 32-bit element offsets
+        {
+            const long long npix = (long long)p.NB * p.TinH * p.TinW;
+            const bool vec_w16 = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
+            const bool small = (long long)p.N * p.Hin * p.Win * p.ldin < 0x7fffffffLL && (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout < 0x7fffffffLL;
+            p.prefetch = (p.vec_in && vec_w16 && small && npix * (KC / 4) <= 6 * 256 && (long long)p.ntaps * KC * (p.Cout / 4) <= 3 * 256) ? 1 : 0;
+            if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
+        }
         if (ptiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
         if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
         else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
