@@ -84,6 +84,76 @@ __global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const 
     }
 }
 
+// Vector form of stat_partial_kernel (C % 4 == 0, 16-byte aligned views): a thread owns 4 consecutive channels
+// and walks rows with float4 loads, `rows_pp` = 256 / (C/4) rows per pass of the block, 4 rows in flight per
+// thread.  The scalar kernel keeps 4 bytes per lane in flight and reached 1.9 TB/s on the 268 MB maps; the
+// statistics passes are pure streaming reads.  Block reduction in LDS, fixed order.
+template <int MODE>
+__global__ __launch_bounds__(256) void stat_partial_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                               const float* __restrict__ g, int ldg, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, int stat_per_group,
+                                                               long long P, int C, int rpb, float* __restrict__ part) {
+    __shared__ float red[256][9];                      // [thread][8 sums], padded
+    const int grp = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const long long r0 = (long long)chunk * rpb;
+    long long r1 = r0 + rpb; if (r1 > P) r1 = P;
+    const long long gbase = (long long)grp * P;
+    const int cg_all = C >> 2;
+    const int cg = cg_all < 256 ? cg_all : 256;        // channel groups handled per sweep
+    const int rows_pp = 256 / cg;                      // rows per pass
+    const int tid = threadIdx.x;
+    const int rsub = tid / cg, cgi = tid - rsub * cg;
+    const bool lane_ok = rsub < rows_pp;
+    for (int cg0 = 0; cg0 < cg_all; cg0 += cg) {
+        const int c = 4 * (cg0 + cgi);
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane_ok && c < C) {
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MODE != 0) {
+                const int si = stat_per_group ? grp * C + c : c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { mu[k] = mean[si + k]; rs[k] = rstd[si + k]; }
+            }
+            auto one = [&](long long r) {
+                const long long row = gbase + r;
+                const float4 av = *reinterpret_cast<const float4*>(a + row * lda + c);
+                const float aa[4] = {av.x, av.y, av.z, av.w};
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s0[k] += aa[k]; s1[k] += aa[k] * aa[k]; }
+                } else {
+                    const float4 bv = *reinterpret_cast<const float4*>(b + row * ldb + c);
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    float gg[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 2) { const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + c); gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float d = (MODE == 2) ? aa[k] * (1.f + gg[k]) : aa[k];
+                        const float xh = (bb[k] - mu[k]) * rs[k];
+                        s0[k] += d; s1[k] += d * xh;
+                    }
+                }
+            };
+            long long r = r0 + rsub;
+            for (; r + 3LL * rows_pp < r1; r += 4LL * rows_pp) { one(r); one(r + rows_pp); one(r + 2LL * rows_pp); one(r + 3LL * rows_pp); }
+            for (; r < r1; r += rows_pp) one(r);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[tid][k] = s0[k]; red[tid][4 + k] = s1[k]; }
+        __syncthreads();
+        if (rsub == 0 && c < C) {
+            float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < rows_pp; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] += red[u * cg + cgi][k];
+            float* dst = part + ((long long)(grp * chunks + chunk) * 2) * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst[c + k] = t[k]; dst[C + c + k] = t[4 + k]; }
+        }
+        __syncthreads();
+    }
+}
+
 // FIN 0: mean / rstd (+ optional running stats, BatchNorm semantics)   FIN 1: raw sums -> out0/out1
 // block (64, 4): x = output index, y = lane over the chunk list (fixed order: lane sums then y = 0..3)
 template <int FIN>
@@ -122,6 +192,12 @@ template <int MODE>
 static int launch_stats(const float* a, int lda, const float* b, int ldb, const float* g, int ldg, const float* mean,
                         const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s) {
     const StatPlan sp = stat_plan(groups, P);
+    const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || vec4_ok(b, ldb, C)) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
+                     ((C >> 2) >= 256 ? (C >> 2) % 256 == 0 : 256 % (C >> 2) == 0);
+    if (vec)
+        hipLaunchKernelGGL((stat_partial_vec_kernel<MODE>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+                           stat_per_group, P, C, sp.rpb, part);
+    else
     hipLaunchKernelGGL((stat_partial_kernel<MODE>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                        stat_per_group, P, C, sp.rpb, part);
     MRDIS_CHECK_LAUNCH();
