@@ -103,10 +103,11 @@ int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc,
  * dw_tck: [T][Ci][Co] ; dbias (Co) or NULL.                                   */
 size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
                                          int kh, int kw, int stride, int pad);
+/* accumulate_bias != 0: dbias += column sums of dy (instead of =), e.g. straight into the parameter's gradient */
 int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
                             float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                             int N, int H, int W, int Ci, int Co,
-                            int kh, int kw, int stride, int pad, void* stream);
+                            int kh, int kw, int stride, int pad, int accumulate_bias, void* stream);
 
 /* ---- LeakyReLU backward (model.py:2227/2240, 2375-2394): dx = dy * (y>0 ? 1 : slope),
  * y being the activation OUTPUT (sign-preserving for slope > 0).              */
@@ -125,10 +126,12 @@ int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* 
 /* inference mode (model.eval(), main_missing.py:338): y = (x - running_mean) * rsqrt(running_var + eps) * gamma + beta */
 int mrdis_bn_eval_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long long P, int C, float eps, void* stream);
+/* acc_dgamma / acc_dbeta (both or neither): running parameter-gradient sums this call's dgamma / dbeta are
+ * added to in the same launch (a module called several times per step needs no separate accumulation).   */
 int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
                        const float* save_mean, const float* save_rstd, float* dx, int lddx,
-                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                       long long P, int C, void* stream);
+                       float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
+                       void* workspace, size_t workspace_bytes, long long P, int C, void* stream);
 
 /* ---- InstanceNorm2d(affine=False) fused with the SPADE modulation:
  * model.py:2431/2440 + 2446:  out = IN(z) * (1 + gamma) + beta ---------------

@@ -1733,7 +1733,7 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ part, float* __re
 }
 // dbias[co] = sum over splits of bias_slab[split][co]; block (32, 32): 32 interleaved partial sums per cout, then a
 // fixed-order sum of the partials
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int splits, int nCo32, int Co, float* __restrict__ dbias) {
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int splits, int nCo32, int Co, float* __restrict__ dbias, int accumulate) {
     __shared__ float red[32][33];
     const int co = blockIdx.x * 32 + threadIdx.x;
     float s_ = 0.f;
@@ -1744,7 +1744,7 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int sp
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
-        dbias[co] = t;
+        dbias[co] = accumulate ? dbias[co] + t : t;
     }
 }
 
@@ -1935,7 +1935,7 @@ static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
 extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
-                                       int kh, int kw, int stride, int pad, void* stream) {
+                                       int kh, int kw, int stride, int pad, int accumulate_bias, void* stream) {
     WgradPlan pl;
     int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
@@ -1984,7 +1984,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         MRDIS_CHECK_LAUNCH();
     }
     if (dbias) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 32), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias);
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 32), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias, accumulate_bias ? 1 : 0);
         MRDIS_CHECK_LAUNCH();
     }
     return MRDIS_OK;

@@ -277,9 +277,11 @@ template <int V>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ sdy, const float* __restrict__ sdyxh, float* __restrict__ dx, int lddx,
-                                    long long P, int C) {
+                                    long long P, int C, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
     const int Q = C / V;
     const float invP = 1.f / (float)P;
+    if (acc_dgamma != nullptr && blockIdx.x == 0)          // fold this call's parameter gradients into the running sums
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { acc_dgamma[c] += sdyxh[c]; acc_dbeta[c] += sdy[c]; }
     EW_LOOP(P * Q) {
         const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
         Vec<V> d, a, o; d.load(dy + r * lddy + c); a.load(x + r * ldx + c);
@@ -295,9 +297,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, cons
 
 extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
                                   const float* save_mean, const float* save_rstd, float* dx, int lddx,
-                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                  long long P, int C, void* stream) {
+                                  float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
+                                  void* workspace, size_t workspace_bytes, long long P, int C, void* stream) {
     if (!dy || !x || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || P < 1 || C < 1) return MRDIS_EINVAL;
+    if ((acc_dgamma == nullptr) != (acc_dbeta == nullptr)) return MRDIS_EINVAL;
     if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
@@ -309,9 +312,9 @@ extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

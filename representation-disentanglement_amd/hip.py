@@ -41,12 +41,12 @@ _SIGS = {
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
-    'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 9 + [_P]),
+    'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 10 + [_P]),
     'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P]),
     'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
     'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _P]),
     'mrdis_bn_eval_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _F, _P]),
-    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _L, _I, _P]),
+    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _L, _I, _P]),
     'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
     'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _P]),
@@ -251,20 +251,23 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad):
     return dx
 
 
-def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True):
+def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None):
+    """-> (dw_tck, dbias).  bias_sink: a (Co,) buffer the bias gradient is ADDED to in the reduce launch
+    (then dbias is returned as None)."""
     lib = load()
     x, ldx = nhwc(x)
     dy, lddy = nhwc(dy)
     N, Ci, H, W = x.shape
     Co = dy.shape[1]
     dw = torch.empty((kh * kw, Ci, Co), dtype=torch.float32, device=x.device)
-    db = torch.empty(Co, dtype=torch.float32, device=x.device) if need_bias else None
+    db = torch.empty(Co, dtype=torch.float32, device=x.device) if (need_bias and bias_sink is None) else None
     nb = lib.mrdis_conv2d_bwd_weight_workspace(N, H, W, Ci, Co, kh, kw, stride, pad)
     if nb == 0:
         raise MrdisError('conv2d_bwd_weight: unsupported geometry')
     ws = _ws(nb, x.device)
-    _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(db), _ptr(ws), nb, N, H, W, Ci, Co,
-                                     kh, kw, stride, pad, _stream()), 'conv2d_bwd_weight')
+    sink = bias_sink if (need_bias and bias_sink is not None) else None
+    _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
+                                     N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _stream()), 'conv2d_bwd_weight')
     return dw, db
 
 
@@ -306,7 +309,8 @@ def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps):
     return y
 
 
-def bn_train_bwd(dy, x, gamma, mean, rstd):
+def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None):
+    """-> (dx, dgamma, dbeta).  sink = (acc_dgamma, acc_dbeta): buffers this call's parameter gradients are also added to."""
     lib = load()
     dy, lddy = nhwc(dy); x, ldx = nhwc(x)
     N, C, H, W = x.shape
@@ -316,8 +320,9 @@ def bn_train_bwd(dy, x, gamma, mean, rstd):
     db = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = lib.mrdis_norm_workspace(1, P, C)
     ws = _ws(nb, x.device)
+    ag, ab = sink if sink is not None else (None, None)
     _chk(lib.mrdis_bn_train_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), C, _ptr(dg), _ptr(db),
-                                _ptr(ws), nb, P, C, _stream()), 'bn_train_bwd')
+                                _ptr(ag), _ptr(ab), _ptr(ws), nb, P, C, _stream()), 'bn_train_bwd')
     return dx, dg, db
 
 

@@ -68,6 +68,7 @@ class CondConv2d(nn.Module):
         nn.init.xavier_normal_(self.weight)
         if bias:
             nn.init.constant_(self.bias, 0)
+            self.bias._mrdis_sink = True           # gradient accumulated in-kernel (ops._grad_sink)
 
     def _mixed(self, t_row):
         """t_row: (1, embeddings) -> (w_tck, w_tkc) for that type."""
@@ -99,6 +100,11 @@ class HipConv2d(nn.Conv2d):
     """nn.Conv2d whose forward/backward run in the HIP kernels (discriminator,
     model.py:2773-2789).  Keeps nn.Conv2d's parameters, init and state_dict."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.bias is not None:
+            self.bias._mrdis_sink = True           # gradient accumulated in-kernel (ops._grad_sink)
+
     def forward(self, x, lrelu=False):
         if self.dilation != (1, 1) or self.groups != 1 or self.padding_mode != 'zeros':
             raise NotImplementedError
@@ -115,6 +121,12 @@ def Conv2d(is_cond):
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d; training-mode forward/backward in HIP."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.affine:
+            self.weight._mrdis_sink = True         # gradients accumulated in-kernel (ops._grad_sink)
+            self.bias._mrdis_sink = True
 
     def forward(self, x):
         if self.training:

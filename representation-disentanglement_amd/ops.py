@@ -103,6 +103,30 @@ def lookup_type_row(inputs_type):
     return table, off // emb
 
 
+# --------------------------------------------------------------------------- parameter-gradient sinks
+# A conv bias / BatchNorm affine parameter of a module that runs 8-16 times per step receives that many
+# gradients; autograd adds them with one tiny kernel each (~1000 launches of ~5 us per step).  Once the
+# optimizer owns a persistent gradient buffer for the parameter (`p.grad` is a view of the arena, zeroed
+# per step), the backward kernels add their contribution to it directly and hand autograd `None`.
+# Parameters opt in with `p._mrdis_sink = True` (set by the modules of model.py).
+import os as _os
+_GRAD_SINK = _os.environ.get('MRDIS_GRAD_SINK', '1') != '0'
+
+
+def _grad_sink(p):
+    if not _GRAD_SINK or p is None or not getattr(p, '_mrdis_sink', False):
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        return None
+    return g
+
+
+def set_grad_sink(enabled):
+    global _GRAD_SINK
+    _GRAD_SINK = bool(enabled)
+
+
 # --------------------------------------------------------------------------- convolution
 class _Conv2d(Function):
     """F.conv2d (model.py:2104) with optional fused LeakyReLU(0.2) epilogue."""
@@ -111,6 +135,7 @@ class _Conv2d(Function):
     def forward(ctx, x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
         y = hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu)
         ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3], bias is not None)
+        ctx.bias_param = bias
         ctx.save_for_backward(x, w_tkc, y if lrelu else None)
         return y
 
@@ -123,7 +148,8 @@ class _Conv2d(Function):
         dx = hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
-            dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=has_bias)
+            sink = _grad_sink(ctx.bias_param) if has_bias else None
+            dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=has_bias, bias_sink=sink)
         return dx, dw, None, db, None, None, None, None, None
 
 
@@ -139,11 +165,16 @@ class _BatchNormTrain(Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum):
         y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
+        sg, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
+        if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dx, _, _ = hip.bn_train_bwd(dy, x, gamma, mean, rstd, sink=(sg, sb))
+            return dx, None, None, None, None, None, None
         dx, dg, db = hip.bn_train_bwd(dy, x, gamma, mean, rstd)
         return dx, dg, db, None, None, None, None
 

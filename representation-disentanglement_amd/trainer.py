@@ -133,6 +133,10 @@ class ArenaAdam:
         used = [p for p in self.params if p.grad is not None]
         if not used:
             raise RuntimeError('ArenaAdam.step() before any backward()')
+        # parameters whose gradient the backward kernels add to in place (ops._grad_sink) never pass through autograd's
+        # accumulation, so their post-accumulate hooks do not fire: keep them together at the end of the arena, i.e. in
+        # the last all-reduce bucket (GradAllReduce.finish() reduces it after backward; the others keep overlapping)
+        used.sort(key=lambda p: 1 if getattr(p, '_mrdis_sink', False) else 0)
         dev = used[0].device
         # 16-byte align every tensor inside the arena (vectorised kernels read params in place)
         offs, n = [], 0

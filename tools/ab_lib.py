@@ -55,7 +55,7 @@ def main():
     def run(lib):
         if a.op == 'wgrad':
             rc = lib.mrdis_conv2d_bwd_weight(x.data_ptr(), Ci, dy.data_ptr(), Co, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb + 256,
-                                             N, H, W, Ci, Co, k, k, sd, pad, st)
+                                             N, H, W, Ci, Co, k, k, sd, pad, 0, st)
         else:
             rc = lib.mrdis_conv2d_fwd(x.data_ptr(), Ci, w.data_ptr(), b.data_ptr(), y.data_ptr(), Co, N, H, W, Ci, Co, k, k, sd, pad, 0, st)
         assert rc == 0, rc
