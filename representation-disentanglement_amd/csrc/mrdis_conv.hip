@@ -1697,54 +1697,45 @@ __global__ __launch_bounds__(256) void wgrad_thin_dma_kernel(const WgradParams p
     }
 }
 
-// dw_tck[t][ci][co] = sum over slabs, fixed order, two parallel stages of <= 32 terms each
-#define WG_RCHUNK 32
+// dw_tck[t][ci][co] = sum over the split-K slabs and dbias[co] = sum over the per-split column sums, ONE launch:
+// block (64, SL): 64 consecutive outputs x SL slab lanes; lane y adds slabs y, y+SL, ... in order, the SL partial
+// sums are then added in lane order -- a fixed summation tree, so the result is bit-reproducible (no atomics).
+// Outputs [0, total) are weight elements, [total, total + Co) the bias gradient.
 struct WgradTapMap { int slot[MRDIS_MAX_TAPS]; };    // tap row of dw_tck -> tap slot of the launch (stride-2: grouped by parity class)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int ntaps, int Ci, int Co,
-                                    int CW, int TPS, int J, int nCi, int nCo, int base, int nslab, WgradTapMap map) {
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ntaps, int Ci, int Co,
+                                    int CW, int TPS, int J, int nCi, int nCo, int base, int nslab, WgradTapMap map,
+                                    const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
+    __shared__ float red[16][65];
     const long long total = (long long)ntaps * Ci * Co;
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int chunk = blockIdx.y;
-    const int co = (int)(i % Co);
-    const long long r = i / Co;
-    const int ci = (int)(r % Ci), t = (int)(r / Ci);
-    const int coc = co >> 5, n = co & 31;
-    const int cic = (Ci >= 32) ? (ci >> 5) : 0;
-    const int cl = ci - cic * 32;
-    const int sl = map.slot[t];
-    const int jj = sl / TPS, m = (sl - jj * TPS) * CW + cl;
-    const int g = jj / J, j = jj - g * J;
-    const int b = (g * nCi + cic) * nCo + coc;
-    const long long stride = (long long)base * J * 1024;
-    const int k0 = chunk * WG_RCHUNK;
-    int k1 = k0 + WG_RCHUNK; if (k1 > nslab) k1 = nslab;
-    const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n + k0 * stride;
+    const long long nout = total + (dbias != nullptr ? Co : 0);
+    const long long i = blockIdx.x * 64LL + threadIdx.x;
+    const int SL = blockDim.y, y = threadIdx.y;
     float s_ = 0.f;
-    for (int k = k0; k < k1; ++k, src += stride) s_ += *src;
-    dst[(long long)chunk * total + i] = s_;
-}
-__global__ void wgrad_reduce2_kernel(const float* __restrict__ part, float* __restrict__ dw, long long total, int nchunk) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    float s_ = 0.f;
-    for (int k = 0; k < nchunk; ++k) s_ += part[(long long)k * total + i];
-    dw[i] = s_;
-}
-// dbias[co] = sum over splits of bias_slab[split][co]; block (32, 32): 32 interleaved partial sums per cout, then a
-// fixed-order sum of the partials
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bslab, int splits, int nCo32, int Co, float* __restrict__ dbias, int accumulate) {
-    __shared__ float red[32][33];
-    const int co = blockIdx.x * 32 + threadIdx.x;
-    float s_ = 0.f;
-    for (int k = threadIdx.y; k < splits; k += 32) s_ += bslab[(long long)k * nCo32 + co];
-    red[threadIdx.y][threadIdx.x] = s_;
+    if (i < total) {
+        const int co = (int)(i % Co);
+        const long long r = i / Co;
+        const int ci = (int)(r % Ci), t = (int)(r / Ci);
+        const int coc = co >> 5, n = co & 31;
+        const int cic = (Ci >= 32) ? (ci >> 5) : 0;
+        const int cl = ci - cic * 32;
+        const int sl = map.slot[t];
+        const int jj = sl / TPS, m = (sl - jj * TPS) * CW + cl;
+        const int g = jj / J, j = jj - g * J;
+        const int b = (g * nCi + cic) * nCo + coc;
+        const long long stride = (long long)base * J * 1024;
+        const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n + (long long)y * stride;
+        for (int k = y; k < nslab; k += SL, src += (long long)SL * stride) s_ += *src;
+    } else if (i < nout) {
+        const int co = (int)(i - total);
+        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * (nCo * 32) + co];
+    }
+    red[y][threadIdx.x] = s_;
     __syncthreads();
-    if (threadIdx.y == 0 && co < Co) {
+    if (y == 0 && i < nout) {
         float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
-        dbias[co] = accumulate ? dbias[co] + t : t;
+        for (int k = 0; k < SL; ++k) t += red[k][threadIdx.x];
+        if (i < total) dw[i] = t;
+        else { const int co = (int)(i - total); dbias[co] = accumulate_bias ? dbias[co] + t : t; }
     }
 }
 
@@ -1893,8 +1884,8 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
     pl.slab_floats = (long long)p.splits * p.base * J * 1024;
-    pl.nchunk = mrdis_cdiv(p.splits, WG_RCHUNK);
-    pl.part_floats = pl.nchunk > 1 ? (long long)pl.nchunk * pl.out_taps * Ci * Co : 0;
+    pl.nchunk = 1;
+    pl.part_floats = 0;
     pl.bias_floats = (long long)p.splits * p.nCo * 32;
     return MRDIS_OK;
 }
@@ -1975,18 +1966,12 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         default: return MRDIS_EUNSUPPORTED;
     }
     if (rc) return rc;
-    const long long total = (long long)pl.out_taps * Ci * Co;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mrdis_cdiv(total, 256), pl.nchunk), dim3(256), 0, s, p.slab,
-                       pl.nchunk > 1 ? part : dw_tck, pl.out_taps, Ci, Co, p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits, pl.map);
+    const long long nout = (long long)pl.out_taps * Ci * Co + (dbias ? Co : 0);
+    int SL = 1;
+    while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;           // >= 8 slabs per lane before another lane is added
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, pl.out_taps, Ci, Co,
+                       p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits, pl.map, p.bias_slab, dbias, accumulate_bias ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
-    if (pl.nchunk > 1) {
-        hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(mrdis_cdiv(total, 256)), dim3(256), 0, s, part, dw_tck, total, pl.nchunk);
-        MRDIS_CHECK_LAUNCH();
-    }
-    if (dbias) {
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(p.nCo), dim3(32, 32), 0, s, p.bias_slab, p.splits, p.nCo * 32, Co, dbias, accumulate_bias ? 1 : 0);
-        MRDIS_CHECK_LAUNCH();
-    }
     return MRDIS_OK;
 }
 
