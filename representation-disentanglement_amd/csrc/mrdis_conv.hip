@@ -32,7 +32,7 @@
 #define TC_BM 128
 // 256 B of zeros: the source of LDS-DMA lanes that fall outside the image / channel range
 __device__ float g_mrdis_zero_page[64];
-#define TC_TAB_INTS 320   // tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad
+#define TC_TAB_INTS 320   // tapconv16: tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad (tapconv_kernel: 2*BM + 64)
 
 struct TapConvParams {
     const float* in; const float* w; const float* bias; float* out;
@@ -49,19 +49,19 @@ struct TapConvParams {
     int prefetch;                 // staging mode of tapconv_kernel: 0 generic | 1 hoisted descriptors + register prefetch
 };
 
-template <int KC, int BN, int MODE>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch
+template <int KC, int BN, int MODE, int BM>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch; BM positions per workgroup
 __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     constexpr int S = KC + 1;
     constexpr int WAVES_N = (BN == 32) ? 1 : 2;
     constexpr int WAVES_M = 4 / WAVES_N;
-    constexpr int MSUB = (TC_BM / 32) / WAVES_M;
+    constexpr int MSUB = (BM / 32) / WAVES_M;
     constexpr int NSUB = (BN / 32) / WAVES_N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* tab_in = reinterpret_cast<int*>(smem);
-    int* tab_out = tab_in + 128;
-    int* tap_xoff = tab_in + 256;
-    int* tap_widx = tab_in + 272;
-    float* ws = smem + TC_TAB_INTS;
+    int* tab_out = tab_in + BM;
+    int* tap_xoff = tab_in + 2 * BM;
+    int* tap_widx = tab_in + 2 * BM + 16;
+    float* ws = smem + (2 * BM + 64);
     float* xs = ws + p.ntaps * KC * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     const int tn = tile / p.tilesA;
     const int a0 = ta * p.TH, b0 = tb * p.TW, n0 = tn * p.NB, co0 = cot * BN;
 
-    if (tid < 128) {
-        const int m = tid, npos = p.NB * p.TH * p.TW;
+    for (int m = tid; m < BM; m += 256) {
+        const int npos = p.NB * p.TH * p.TW;
         int tin = 0, tout = -1;
         if (m < npos) {
             const int nb = m / (p.TH * p.TW);
@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
         }
         tab_in[m] = tin;
         tab_out[m] = tout;
-    } else if (tid < 128 + MRDIS_MAX_TAPS) {
-        const int t = tid - 128;
+    }
+    if (tid >= 256 - MRDIS_MAX_TAPS) {
+        const int t = tid - (256 - MRDIS_MAX_TAPS);
         if (t < p.ntaps) {
             tap_xoff[t] = ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * S;
             tap_widx[t] = p.widx[t];
@@ -564,14 +565,14 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
 // ------------------------------------------------------------------ host side
 struct TileChoice { int NB, TH, TW; };
 
-static TileChoice choose_tile(int N, int A, int B) {
+static TileChoice choose_tile(int N, int A, int B, int BMv = TC_BM) {
     TileChoice best{1, 1, 1};
     double best_u = -1.0;
     for (int tw = 1; tw <= 32 && tw <= B; ++tw) {
-        int th = TC_BM / tw; if (th > A) th = A;
-        int nb = TC_BM / (tw * th); if (nb > N) nb = N; if (nb < 1) nb = 1;
+        int th = BMv / tw; if (th > A) th = A;
+        int nb = BMv / (tw * th); if (nb > N) nb = N; if (nb < 1) nb = 1;
         const double u = ((double)B / ((double)mrdis_cdiv(B, tw) * tw)) * ((double)A / ((double)mrdis_cdiv(A, th) * th)) *
-                         ((double)N / ((double)mrdis_cdiv(N, nb) * nb)) * ((double)(tw * th * nb) / TC_BM);
+                         ((double)N / ((double)mrdis_cdiv(N, nb) * nb)) * ((double)(tw * th * nb) / BMv);
         // prefer wide rows (coalesced staging, conflict-free LDS reads) on ties
         if (u > best_u + 1e-9 || (u > best_u - 1e-9 && tw > best.TW)) { best_u = u; best = {nb, th, tw}; }
     }
@@ -579,15 +580,16 @@ static TileChoice choose_tile(int N, int A, int B) {
 }
 
 template <int KC, int BN>
-static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, hipStream_t s) {
-    if (p.prefetch == 1) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1>), dim3(nblk), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, 0>), dim3(nblk), dim3(256), lds, s, p);
+static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM, hipStream_t s) {
+    if (BM == 256) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 256>), dim3(nblk), dim3(256), lds, s, p);      // BM 256 only with MODE 1
+    else if (p.prefetch == 1) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 128>), dim3(nblk), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, 0, 128>), dim3(nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-static size_t tapconv_lds(const TapConvParams& p, int KC, int BN) {
-    return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * KC * BN + (size_t)p.NB * p.TinH * p.TinW * (KC + 1));
+static size_t tapconv_lds(const TapConvParams& p, int KC, int BN, int BM = TC_BM) {
+    return sizeof(float) * ((size_t)(2 * BM + 64) + (size_t)p.ntaps * KC * BN + (size_t)p.NB * p.TinH * p.TinW * (KC + 1));
 }
 
 // fills tiling fields and launches.  `p` must have geometry + taps set.
@@ -652,10 +654,32 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     p.prefetch = (want_pf && fits_pf(KC, BN) && small) ? 1 : 0;
     if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
     p.coTiles = mrdis_cdiv(p.Cout, BN);
-    const long long nblk = ptiles * p.coTiles;
+    long long nblk = ptiles * p.coTiles;
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
-    const size_t lds = tapconv_lds(p, KC, BN);
-#define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, s)
+    size_t lds = tapconv_lds(p, KC, BN);
+    int BM = 128;
+    // 256-position workgroups: twice the MFMA work per staged filter slab.  Pays on the 32-cout layers (8-10 %, a
+    // 32-wide tile reuses each staged pixel only once per wave); with 64 couts the second accumulator pair costs a
+    // resident workgroup and it is a wash (tools/ab_lib.py, MRDIS_DEBUG_BM: 0 never, 1 BN=32 layers, 2 all).  Only
+    // where the grid stays large and the hoisted staging still fits its register arrays.
+    {
+        int want = 1;
+        if (const char* e = getenv("MRDIS_DEBUG_BM")) want = atoi(e);
+        const bool cand = p.prefetch == 1 && KC == 16 && nblk >= 4096 && ((want == 1 && BN == 32) || want == 2);
+        if (cand) {
+            TapConvParams q = p;
+            const TileChoice t2 = choose_tile(q.N, q.A, q.B, 256);
+            q.NB = t2.NB; q.TH = t2.TH; q.TW = t2.TW;
+            q.TinH = (q.TH - 1) * q.is + (dh_max - q.dh_min) + 1;
+            q.TinW = (q.TW - 1) * q.is + (dw_max - q.dw_min) + 1;
+            q.tilesA = mrdis_cdiv(q.A, q.TH); q.tilesB = mrdis_cdiv(q.B, q.TW); q.tilesN = mrdis_cdiv(q.N, q.NB);
+            const long long npix2 = (long long)q.NB * q.TinH * q.TinW;
+            const long long nblk2 = (long long)q.tilesA * q.tilesB * q.tilesN * q.coTiles;
+            const size_t lds2 = tapconv_lds(q, KC, BN, 256);
+            if (q.NB * q.TH * q.TW == 256 && npix2 * (KC / 4) <= 6 * 256 && lds2 <= LDS_MAX) { p = q; nblk = nblk2; lds = lds2; BM = 256; }
+        }
+    }
+#define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, BM, s)
     TC_CASE(4, 32); TC_CASE(4, 64);
     TC_CASE(8, 32); TC_CASE(8, 64);
     TC_CASE(16, 32); TC_CASE(16, 64);

@@ -124,6 +124,27 @@ def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st):
     close(dw, to_tck(w.grad), rtol=3e-4, what='wgrad dma'); close(db, b.grad, rtol=3e-4, what='dbias dma')
 
 
+def test_conv_large_grid_256_position_tiles(mrdis):
+    """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
+    and data gradient), ragged in both image dimensions."""
+    hip = mrdis.hip
+    N, Ci, Co, H, W = 12, 64, 32, 200, 216
+    x = rnd((N, Ci, H, W), 90); w = rnd((Co, Ci, 3, 3), 91, 0.1); b = rnd((Co,), 92, 0.1)
+    want = F.conv2d(x, w, b, 1, 1)
+    got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
+    close(got, want, what='fwd BM256')
+    gy = rnd((N, Co, H, W), 93)
+    w2 = rnd((Co, Ci, 3, 3), 94, 0.1)                       # dgrad of a Ci=64 <- Co=32 layer is a 32 -> 64 conv: use the transpose
+    want_dx = torch.nn.grad.conv2d_input((N, Ci, H, W), w2, gy, 1, 1)
+    dx = hip.conv2d_bwd_data(cl(gy), to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
+    close(dx, want_dx, what='dgrad')
+    x2 = rnd((N, Co, H, W), 95); w3 = rnd((Ci, Co, 3, 3), 96, 0.1)       # 32 <- 64 data gradient: Cout' = 32 -> BM 256 path
+    gy2 = rnd((N, Ci, H, W), 97)
+    want_dx2 = torch.nn.grad.conv2d_input((N, Co, H, W), w3, gy2, 1, 1)
+    dx2 = hip.conv2d_bwd_data(cl(gy2), to_tkc(w3).to(dev()), (H, W), 3, 3, 1, 1)
+    close(dx2, want_dx2, what='dgrad BM256')
+
+
 def test_conv_strided_views(mrdis):
     """channel slices of wider NHWC buffers as input and output (ld != C)."""
     hip = mrdis.hip
