@@ -364,7 +364,11 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
 // same FLOP rate, 32-cycle issue): workgroup = 128 positions x 16 couts, a wave owns two 16-position
 // sub-tiles that share the A operand.  D[cout][position]: lane = position, registers = 4 consecutive
 // couts -> one 16-byte store per sub-tile.
-template <int KC>
+// THIN4 (Cout <= 4: ana_dec.output, the data gradients of every si_layers): even a 16-wide MFMA tile is 75 % padding
+// there, so the product runs as packed FMAs instead -- thread = (position, channel half of the chunk), the pixel's
+// channels come out of the same padded LDS tile (conflict-free across positions), the 4 filter values of a
+// (tap, channel) are one wave-uniform 16-byte LDS read.
+template <int KC, bool THIN4>
 __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
     constexpr int S = KC + 1, BN = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -415,16 +419,35 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW;
     const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
 
-    auto compute_chunk = [&]() {
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = tap_xoff[t];
-            const float* wt = ws + t * (KC * BN) + abase;
+    // THIN4 thread roles: position tid & 127, channel half tid >> 7 (wave-uniform)
+    const int tpos = tid & 127, tpart = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int tbase = tab_in[tpos] + tpart * (KC / 2);
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    // (reading the filter values as scalar loads from global memory instead of the LDS broadcast was tried: slower, the
+    // scalar and LDS counters share lgkmcnt and the waits serialise)
+    auto compute_chunk = [&](int) {
+        if constexpr (THIN4) {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const float* xr = xs + tbase + tap_xoff[t];
+                const float* wr = ws + (t * KC + tpart * (KC / 2)) * BN;
 #pragma unroll
-            for (int q = 0; q < KC / 4; ++q) {
-                const float av = wt[4 * q * BN];
-                const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    const float xv = xr[kk];
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + kk * BN);
+                    acc4[0] += xv * w4.x; acc4[1] += xv * w4.y; acc4[2] += xv * w4.z; acc4[3] += xv * w4.w;
+                }
+            }
+        } else {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int toff = tap_xoff[t];
+                const float* wt = ws + t * (KC * BN) + abase;
+#pragma unroll
+                for (int q = 0; q < KC / 4; ++q) {
+                    const float av = wt[4 * q * BN];
+                    const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
+                }
             }
         }
     };
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
         for (int c0 = 0; c0 < p.Cin; c0 += KC) {
             const bool more = c0 + KC < p.Cin;
             if (more) load_chunk(c0 + KC);
-            compute_chunk();
+            compute_chunk(c0);
             if (more) { __syncthreads(); store_chunk(); __syncthreads(); }
         }
     } else
@@ -537,7 +560,34 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
             }
         }
         __syncthreads();
-        compute_chunk();
+        compute_chunk(c0);
+    }
+    if constexpr (THIN4) {
+        // the two channel halves of a position meet in LDS (fixed order: half 0 + half 1)
+        __syncthreads();
+        float* red = xs;                                  // [128][4]
+        if (tpart == 1) { red[tpos * 4 + 0] = acc4[0]; red[tpos * 4 + 1] = acc4[1]; red[tpos * 4 + 2] = acc4[2]; red[tpos * 4 + 3] = acc4[3]; }
+        __syncthreads();
+        if (tpart == 0) {
+            const int po = tab_out[tpos];
+            if (po >= 0) {
+                const bool lrelu_ = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc4[r] + red[tpos * 4 + r];
+                    if (p.bias != nullptr && r < p.Cout) v[r] += p.bias[r];
+                    if (lrelu_) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                }
+                float* dst = p.out + (long long)po * p.ldout;
+                if (p.Cout == 4 && (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (r < p.Cout) dst[r] = v[r];
+                }
+            }
+        }
+        return;
     }
     // D: col = lane&15 (position), row = (lane>>4)*4 + reg (cout)
     const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
@@ -627,9 +677,11 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
             if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
         }
         if (ptiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
-        if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
-        else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
-        else hipLaunchKernelGGL((tapconv16_kernel<4>), dim3((int)ptiles), dim3(256), lds16(4), s, p);
+        const bool thin4 = p.Cout <= 4 && KC == 16 && !getenv("MRDIS_DEBUG_NOTHIN");
+        if (thin4) hipLaunchKernelGGL((tapconv16_kernel<16, true>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
+        else if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16, false>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
+        else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8, false>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
+        else hipLaunchKernelGGL((tapconv16_kernel<4, false>), dim3((int)ptiles), dim3(256), lds16(4), s, p);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
