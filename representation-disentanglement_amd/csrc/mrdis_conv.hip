@@ -1775,6 +1775,65 @@ __global__ __launch_bounds__(256) void wgrad_thin_dma_kernel(const WgradParams p
     }
 }
 
+// ---------------------------------------------------------------- 1x1 convolution with few channels on both sides
+// The decoder head (16 -> 7, model.py:2568) has 112 weights and 2.1 M positions: its weight gradient is a streaming
+// reduction of outer products (floor: reading x and dy once, ~40 us), for which the tiled kernels above spend their
+// time on padding (157 us).  Tiles of 512 positions are staged with coalesced loads, thread (half, ci, co) walks half
+// of the tile with two LDS reads (both mostly broadcasts) per FMA; sums stay in registers across the tiles of the
+// workgroup and leave through the common slab layout ([32][32] block: row = ci, column = co).
+#define WGP_TILE 512
+__global__ __launch_bounds__(256) void wgrad_pointwise_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                              long long P, int Ci, int Co, float* __restrict__ slab,
+                                                              float* __restrict__ bias_slab, int vec_x) {
+    __shared__ float xs[WGP_TILE * 16];
+    __shared__ float dys[WGP_TILE * 8];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int half = tid >> 7, ci = (tid >> 3) & 15, co = tid & 7;
+    const long long ntiles = (P + WGP_TILE - 1) / WGP_TILE;
+    float acc = 0.f, bsum = 0.f;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long p0 = tile * WGP_TILE;
+        __syncthreads();
+        if (vec_x) {                                     // Ci == 16, 16-byte rows
+            for (int i = tid; i < WGP_TILE * 4; i += 256) {
+                const long long pp = p0 + (i >> 2);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pp < P) v = *reinterpret_cast<const float4*>(x + pp * ldx + 4 * (i & 3));
+                *reinterpret_cast<float4*>(xs + 4 * i) = v;
+            }
+        } else {
+            for (int i = tid; i < WGP_TILE * 16; i += 256) {
+                const long long pp = p0 + (i >> 4);
+                const int c = i & 15;
+                xs[i] = (pp < P && c < Ci) ? x[pp * ldx + c] : 0.f;
+            }
+        }
+        for (int i = tid; i < WGP_TILE * 8; i += 256) {
+            const long long pp = p0 + (i >> 3);
+            const int k = i & 7;
+            dys[i] = (pp < P && k < Co) ? dy[pp * lddy + k] : 0.f;
+        }
+        __syncthreads();
+        const float* xr = xs + half * (WGP_TILE / 2) * 16 + ci;
+        const float* dr = dys + half * (WGP_TILE / 2) * 8 + co;
+#pragma unroll 8
+        for (int q = 0; q < WGP_TILE / 2; ++q) {
+            const float d = dr[q * 8];
+            acc += xr[q * 16] * d;
+            if (ci == 0) bsum += d;
+        }
+    }
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    if (half == 0) slab[(long long)blockIdx.x * 1024 + ci * 32 + co] = red[tid] + red[tid + 128];
+    __syncthreads();
+    red[tid] = bsum;
+    __syncthreads();
+    if (bias_slab != nullptr && tid < 8) bias_slab[(long long)blockIdx.x * 32 + tid] = red[tid] + red[tid + 128];
+}
+
 // dw_tck[t][ci][co] = sum over the split-K slabs and dbias[co] = sum over the per-split column sums, ONE launch:
 // block (64, SL): 64 consecutive outputs x SL slab lanes; lane y adds slabs y, y+SL, ... in order, the SL partial
 // sums are then added in lane order -- a fixed summation tree, so the result is bit-reproducible (no atomics).
@@ -1827,6 +1886,7 @@ struct WgradPlan {
     int out_taps;                 // kh*kw rows of dw_tck
     WgradTapMap map;
     int thin, thin_nt, thin_dma;  // 0 | 1 (narrow dy) | 2 (narrow x); tap slots per group; staging fits
+    int pointwise;                // 1x1 s1 p0 with Ci <= 16, Co <= 8: streaming outer-product kernel
 
     size_t lds_dma;
 };
@@ -1961,6 +2021,13 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
     if (splits > nt) splits = nt;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
+    pl.pointwise = 0;
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ci <= 16 && Co <= 8 && p.CW == 16 && p.nG == 1 && J == 1 &&
+        (long long)N * Ho * Wo >= 50000 && !getenv("MRDIS_DEBUG_NOTHIN")) {
+        pl.pointwise = 1; pl.dma = 0; pl.thin = 0;
+        long long tiles = ((long long)N * Ho * Wo + WGP_TILE - 1) / WGP_TILE;
+        p.splits = (int)(tiles < 768 ? tiles : 768);
+    }
     pl.slab_floats = (long long)p.splits * p.base * J * 1024;
     pl.nchunk = 1;
     pl.part_floats = 0;
@@ -2030,6 +2097,13 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
         if (pl.thin == 1) hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, false>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
         else if (pl.thin_nt == 4) hipLaunchKernelGGL((wgrad_thin_dma_kernel<4, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
         else hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        MRDIS_CHECK_LAUNCH();
+        rc = MRDIS_OK;
+    } else
+    if (pl.pointwise) {
+        const int vx = (Ci == 16) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+        hipLaunchKernelGGL(wgrad_pointwise_kernel, dim3(p.splits), dim3(256), 0, s, x, ldx, dy, lddy, (long long)N * H * W, Ci, Co,
+                           p.slab, p.bias_slab, vx);
         MRDIS_CHECK_LAUNCH();
         rc = MRDIS_OK;
     } else
