@@ -181,6 +181,15 @@ size_t mrdis_recon_metrics_workspace(int n_img, int H);
 int mrdis_recon_metrics(const float* target, int ldt, const float* pred, int ldp, float* out,
                         void* workspace, size_t workspace_bytes, int n_img, int H, int W, void* stream);
 
+/* ---- batch assembly from HBM-resident volumes: ZeroDoseDataset.__getitem__ + default collate
+ * (util.py:471-566).  vol_ptrs (B, M): device pointers (as 64-bit integers, 0 = contrast missing for that subject)
+ * to volumes stored as [D][H][W] planes; slice_idx (B): centre slice, already clamped to [block, D-1-block];
+ * drop (B): contrast zeroed by the drop-off augmentation or -1.  All three live in device memory.
+ * inputs: NHWC view (B,H,W,ld_in), channel m*(2*block+1)+k = slice slice_idx-block+k of contrast m;
+ * mask (B, M); mask_img (B,H,W) = (inputs[:,0] == 0).                                              */
+int mrdis_slice_gather(const void* vol_ptrs, const int* slice_idx, const int* drop, float* inputs, int ld_in,
+                       float* mask, float* mask_img, int B, int M, int H, int W, int D, int block, void* stream);
+
 /* ---- max_pool2d(kernel k x k, stride k): model.py:3448-3451 ---------------- */
 int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* argmax, int N, int H, int W, int C,
                       int k, void* stream);

@@ -292,6 +292,51 @@ def gen_eval(ref, tag, B, M):
     print(f'eval_{tag}: loss={float(loss):.7f}', {k: round(float(v), 7) for k, v in parts.items()})
 
 
+# ---------------------------------------------------------------- batch assembly (util.py:444-566, 706)
+DATA_CFG = dict(n_subj=6, contrasts=['T1', 'T1c', 'T2', 'T2_FLAIR'], H=40, W=48, D=155, seed=21, missing_every=5)
+DATA_SLICES = [0, 1, 2, 3, 77, 100, 151, 150, 149, 120, 30, 64]     # (>= 152 gives the reference a 6-slice item: util.py:483 allows 155-block)
+
+
+def data_lists():
+    subj, idx = [], []
+    for s in range(DATA_CFG['n_subj']):
+        for k in range(4):
+            subj.append(f'BraTS20_Training_{s:03d}'); idx.append(DATA_SLICES[(3 * s + 5 * k) % len(DATA_SLICES)])
+    return subj, idx
+
+
+def gen_data():
+    """batches of the reference's own ZeroDoseDataset + DataLoader (shuffle, drop-off) over synthetic volumes."""
+    import_reference()
+    import util as ref_util          # noqa  (needs the same stubs as model.py)
+    from torch.utils.data import DataLoader
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.ref_data import synthetic_volumes
+    c = DATA_CFG
+    data = synthetic_volumes(c['n_subj'], c['contrasts'], c['H'], c['W'], c['D'], c['seed'], c['missing_every'])
+    subj, idx = data_lists()
+    ds = ref_util.ZeroDoseDataset('BraTS', data, np.array(subj), np.array(idx), None, block_size=3,
+                                  contrast_list=c['contrasts'], aug=False, dropoff=True, skull_strip=False)
+    ds.image_size = [c['H'], c['W']]                    # the class hard-codes 160x192 for its zero fill (util.py:462)
+    np.random.seed(5); torch.manual_seed(7)
+    out = {}
+    for bi, batch in enumerate(DataLoader(ds, batch_size=4, shuffle=True, num_workers=0)):
+        out[f'subj_{bi}'] = np.array(batch['subj_id'])
+        out[f'slice_{bi}'] = batch['slice_idx'].numpy()
+        out[f'mask_{bi}'] = batch['mask'].numpy()
+        x = batch['inputs'].numpy().astype(np.float32)
+        out[f'insum_{bi}'] = np.array([x.astype(np.float64).sum(), np.abs(x).astype(np.float64).sum()])
+        out[f'mimg_{bi}'] = batch['mask_img'].numpy().astype(np.float32).sum((1, 2))
+        out[f'tsum_{bi}'] = batch['targets'].numpy().astype(np.float64).sum((1, 2, 3))
+        if bi < 2:
+            out[f'inputs_{bi}'] = x
+            out[f'targets_{bi}'] = batch['targets'].numpy().astype(np.float32)
+    out['n_batches'] = np.array(bi + 1)
+    np.savez_compressed(os.path.join(OUT, 'data_b4.npz'), **out)
+    print('data_b4:', bi + 1, 'batches; dropped contrasts per batch', [int((out[f'mask_{k}'] == 0).sum()) for k in range(bi + 1)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -307,6 +352,8 @@ def main():
         gen_step(ref, 'b2m2_adv', 2, 2, adv=True)
     if not only or 'eval' in only:
         gen_eval(ref, 'b2m4', 2, 4)
+    if not only or 'data' in only:
+        gen_data()
 
 
 if __name__ == '__main__':

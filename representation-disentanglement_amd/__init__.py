@@ -23,4 +23,6 @@ from .trainer import (TrainStep, EvalStep, ArenaAdam, GradAllReduce, DEFAULT_CON
                       derive_config, build_model, synthetic_batch, fit_to_model, forward_losses,
                       save_checkpoint, load_checkpoint_model, LOSS_KEYS)
 
+from .data import VolumeStore, SliceDataset, BatchLoader, load_idx_list   # noqa: F401
+
 __version__ = '0.1.0'

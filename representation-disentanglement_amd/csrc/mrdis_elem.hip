@@ -643,6 +643,96 @@ extern "C" int mrdis_softmax_mask_drop_bwd(const float* dout, int lddo, const fl
     return MRDIS_OK;
 }
 
+// ------------------------------------------------------------------ batch assembly (ZeroDoseDataset.__getitem__, util.py:471-566)
+// Volumes stay resident in HBM as [D][H][W] planes (a BraTS fold is ~28 GB of fp32: 10 % of one MI355X), so a batch
+// is a device-side gather instead of h5 reads + numpy concatenation + a 110 MB host-to-device copy per step:
+//   inputs[b][h][w][m*(2*block+1) + k] = vol(b, m)[slice_b - block + k][h][w]   (zeros if the contrast is missing
+//                                         for that subject or was dropped, util.py:523-525 / :540-542)
+//   mask[b][m] = contrast present and not dropped;   mask_img[b][h][w] = (inputs[b][0][h][w] == 0)  (:563)
+// vol_ptrs: (B, M) device pointers (0 = missing); slice_idx already clamped to [block, D-1-block] (:476-484).
+__global__ void slice_gather_kernel(const unsigned long long* __restrict__ vol_ptrs, const int* __restrict__ slice_idx,
+                                    const int* __restrict__ drop, float* __restrict__ inputs, int ld, float* __restrict__ mask,
+                                    float* __restrict__ mask_img, int B, int M, int H, int W, int D, int block) {
+    const int c7 = 2 * block + 1;
+    const long long HW = (long long)H * W;
+    const int b = blockIdx.y;
+    const int s0 = slice_idx[b] - block;
+    const int dm = drop[b];
+    if (blockIdx.x == 0 && blockIdx.z == 0 && (int)threadIdx.x < M) {
+        const int mm = threadIdx.x;
+        mask[b * M + mm] = (vol_ptrs[b * M + mm] != 0ull && mm != dm) ? 1.f : 0.f;
+    }
+    // grid (x, B, M): a wave reads 64 consecutive pixels of one plane (coalesced) and writes their 2*block+1 channels
+    const int m = blockIdx.z;
+    const float* vol = reinterpret_cast<const float*>(vol_ptrs[b * M + m]);
+    const bool live = vol != nullptr && m != dm;
+    for (long long px = blockIdx.x * (long long)blockDim.x + threadIdx.x; px < HW; px += (long long)gridDim.x * blockDim.x) {
+        float* dst = inputs + ((long long)b * HW + px) * ld + m * c7;
+        float first = 0.f;
+        for (int k = 0; k < c7; ++k) {
+            const int sk = s0 + k;
+            const float v = (live && sk >= 0 && sk < D) ? vol[(long long)sk * HW + px] : 0.f;
+            dst[k] = v;
+            if (k == 0) first = v;
+        }
+        if (m == 0) mask_img[(long long)b * HW + px] = (first == 0.f) ? 1.f : 0.f;
+    }
+}
+// all channels of a pixel in one thread (C = M*(2*block+1) <= 32, C % 4 == 0, 16-byte rows): every plane read is a
+// coalesced 256-byte wave access and the pixel leaves as C/4 16-byte stores, consecutive lanes writing consecutive
+// pixels -- the per-contrast version above writes 28-byte pieces at a 112-byte stride (0.6 TB/s).
+template <int CMAX>
+__global__ void slice_gather_px_kernel(const unsigned long long* __restrict__ vol_ptrs, const int* __restrict__ slice_idx,
+                                       const int* __restrict__ drop, float* __restrict__ inputs, int ld, float* __restrict__ mask,
+                                       float* __restrict__ mask_img, int B, int M, int H, int W, int D, int block) {
+    const int c7 = 2 * block + 1, C = M * c7;
+    const long long HW = (long long)H * W;
+    const int b = blockIdx.y;
+    const int s0 = slice_idx[b] - block;
+    const int dm = drop[b];
+    if (blockIdx.x == 0 && (int)threadIdx.x < M) {
+        const int mm = threadIdx.x;
+        mask[b * M + mm] = (vol_ptrs[b * M + mm] != 0ull && mm != dm) ? 1.f : 0.f;
+    }
+    for (long long px = blockIdx.x * (long long)blockDim.x + threadIdx.x; px < HW; px += (long long)gridDim.x * blockDim.x) {
+        float v[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            v[c] = 0.f;
+            if (c < C) {
+                const int m = c / c7, k = c - m * c7;
+                const float* vol = reinterpret_cast<const float*>(vol_ptrs[b * M + m]);       // wave-uniform
+                const int sk = s0 + k;
+                if (vol != nullptr && m != dm && sk >= 0 && sk < D) v[c] = vol[(long long)sk * HW + px];
+            }
+        }
+        float* dst = inputs + ((long long)b * HW + px) * ld;
+#pragma unroll
+        for (int c = 0; c < CMAX; c += 4)
+            if (c < C) *reinterpret_cast<float4*>(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+        mask_img[(long long)b * HW + px] = (v[0] == 0.f) ? 1.f : 0.f;
+    }
+}
+extern "C" int mrdis_slice_gather(const void* vol_ptrs, const int* slice_idx, const int* drop, float* inputs, int ld_in,
+                                  float* mask, float* mask_img, int B, int M, int H, int W, int D, int block, void* stream) {
+    if (!vol_ptrs || !slice_idx || !drop || !inputs || !mask || !mask_img || B < 1 || M < 1 || M > 64 || H < 1 || W < 1 || D < 1 ||
+        block < 0 || 2 * block + 1 > D || ld_in < M * (2 * block + 1)) return MRDIS_EINVAL;
+    if (B > 65535) return MRDIS_EUNSUPPORTED;
+    const long long items = (long long)H * W;
+    int gx = (int)((items + 255) / 256); if (gx > 1024) gx = 1024;
+    const int C = M * (2 * block + 1);
+    if (C % 4 == 0 && C <= 32 && ld_in % 4 == 0 && (((uintptr_t)inputs & 15) == 0)) {
+        hipLaunchKernelGGL(slice_gather_px_kernel<32>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const unsigned long long*>(vol_ptrs), slice_idx, drop, inputs, ld_in, mask, mask_img, B, M, H, W, D, block);
+        MRDIS_CHECK_LAUNCH();
+        return MRDIS_OK;
+    }
+    hipLaunchKernelGGL(slice_gather_kernel, dim3(gx, B, M), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(vol_ptrs), slice_idx, drop, inputs, ld_in, mask, mask_img, B, M, H, W, D, block);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // ------------------------------------------------------------------ reconstruction metrics (evaluate(), util.py:935-978)
 // One image = channel 0 of one sample.  Both images are shifted by their own minimum, data range R =
 // max of the shifted target; MSE, PSNR = 10 log10(R^2/MSE), SSIM = mean over the 7x7-valid region of

@@ -59,6 +59,7 @@ _SIGS = {
     'mrdis_recon_err_bwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
     'mrdis_recon_metrics_workspace': (_Z, [_I, _I]),
     'mrdis_recon_metrics': (_I, [_P, _I, _P, _I, _P, _P, _Z, _I, _I, _I, _P]),
+    'mrdis_slice_gather': (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_maxpool_fwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mrdis_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_sumsq_workspace': (_Z, []),
@@ -423,6 +424,20 @@ def recon_metrics(target, pred):
     ws = _ws(nb, pred.device)
     _chk(lib.mrdis_recon_metrics(_ptr(target), ldt, _ptr(pred), ldp, _ptr(out), _ptr(ws), nb, N, H, W, _stream()), 'recon_metrics')
     return out
+
+
+def slice_gather(vol_ptrs, slice_idx, drop, H, W, D, block):
+    """vol_ptrs (B,M) int64, slice_idx (B) int32, drop (B) int32 on the device -> inputs (B,(2b+1)M,H,W) NHWC, mask (B,M),
+    mask_img (B,H,W)."""
+    lib = load()
+    B, M = vol_ptrs.shape
+    C = M * (2 * block + 1)
+    inputs = empty_nhwc(B, C, H, W, vol_ptrs.device)
+    mask = torch.empty((B, M), dtype=torch.float32, device=vol_ptrs.device)
+    mask_img = torch.empty((B, H, W), dtype=torch.float32, device=vol_ptrs.device)
+    _chk(lib.mrdis_slice_gather(_ptr(vol_ptrs), _ptr(slice_idx), _ptr(drop), _ptr(inputs), C, _ptr(mask), _ptr(mask_img),
+                                B, M, H, W, D, block, _stream()), 'slice_gather')
+    return inputs, mask, mask_img
 
 
 def recon_err_bwd(gt, x, w, p):

@@ -16,3 +16,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='module')
+def mrdis():
+    """the product package on a GPU box; loading fails loudly when libmrdis_hip.so is missing."""
+    import torch
+    import mrdis as m
+    assert torch.cuda.is_available()
+    m.hip.load()
+    return m
