@@ -787,6 +787,7 @@ struct C4Params {
     int tilesW, tilesH;          // per image
     long long ntiles;
     int lrelu;
+    int flip;                    // taps in reverse order: the stride-1 data gradient of a C -> 4 layer is this same convolution
 };
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + m;
                 const int coc = co < p.Co ? co : p.Co - 1;
-                const float v = p.w[(t * 4 + 2 * half + j) * p.Co + coc];
+                const float v = p.w[((p.flip ? 8 - t : t) * 4 + 2 * half + j) * p.Co + coc];
                 b[t][j][ns] = co < p.Co ? v : 0.f;
             }
     // bias in the accumulator layout (every register of a lane belongs to cout m).  Passing it once through
@@ -988,8 +989,9 @@ static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, i
 }
 
 static int run_c4conv(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                      int N, int H, int W, int Co, int epilogue, hipStream_t s) {
+                      int N, int H, int W, int Co, int epilogue, hipStream_t s, int flip = 0) {
     C4Params p{};
+    p.flip = flip;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.ldx = ldx; p.Co = Co; p.ldy = ldy;
     p.lrelu = (epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
     // strip shape: 32x1 unless a 16x2 strip wastes fewer positions
@@ -1070,6 +1072,10 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
     base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
     base.is = 1; base.epilogue = 0;
     if (stride == 1) {
+        // dx of a Ci <- 4 layer (ana_dec.output): a 4 -> Ci convolution of dy with the taps reversed; [tap][Co=4][Ci] is
+        // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
+        if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
+            return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         TapConvParams p = base;
         p.A = H; p.B = W; p.os = 1; p.oh0 = 0; p.ow0 = 0;
         p.ntaps = kh * kw;
