@@ -510,8 +510,8 @@ class MultimodalModel(nn.Module):
             mids = {}
             for j in range(M):
                 mid = self.input_decoder_list[-1](s_cat, zi_list[j].repeat(M, 1), self._type(j, M * B))
-                for i in range(M):
-                    mids[(i, j)] = mid[i * B:(i + 1) * B]
+                for i, part in enumerate(ops.split_batch(mid, M)):        # one-pass adjoint instead of M zero-fills + adds
+                    mids[(i, j)] = part
             return (list(si_list), list(zi_list), mids)       # inputs kept alive with the cache entry
         return ops.step_cache(key, make)[2]
 

@@ -103,6 +103,33 @@ def lookup_type_row(inputs_type):
     return table, off // emb
 
 
+# --------------------------------------------------------------------------- batch split with a one-pass adjoint
+class _SplitBatch(Function):
+    """x (parts*B, ...) -> parts views of B samples.  autograd's own slicing adjoint materialises one full-size zero
+    tensor per slice, copies the slice gradient in and then adds the full-size tensors pairwise (for the 268 MB output
+    of the shared SPADE blocks: 4 fills + 4 copies + 3 adds per modality type); here the adjoint is ONE concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, parts):
+        ctx.parts = parts
+        ctx.shape = tuple(x.shape)
+        B = x.shape[0] // parts
+        return tuple(x[k * B:(k + 1) * B] for k in range(parts))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B = ctx.shape[0] // ctx.parts
+        ref = next(g for g in grads if g is not None)
+        gs = [g if g is not None else torch.zeros_like(ref) for g in grads]
+        return torch.cat(gs, 0), None
+
+
+def split_batch(x, parts):
+    if x.shape[0] % parts != 0:
+        raise ValueError('batch not divisible')
+    return _SplitBatch.apply(x, parts)
+
+
 # --------------------------------------------------------------------------- parameter-gradient sinks
 # A conv bias / BatchNorm affine parameter of a module that runs 8-16 times per step receives that many
 # gradients; autograd adds them with one tiny kernel each (~1000 launches of ~5 us per step).  Once the
