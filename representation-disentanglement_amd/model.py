@@ -74,20 +74,23 @@ class CondConv2d(nn.Module):
         """t_row: (1, embeddings) -> (w_tck, w_tkc) for that type."""
         return ops.mix_experts_routed(self.weight, self._routing_fn.fc.weight, self._routing_fn.fc.bias, t_row)
 
+    def mixed_uniform(self, inputs_type):
+        """(w_tck, w_tkc) for a batch-constant `inputs_type` (stride-0 expand of one row), memoised for the step."""
+        hit = ops.lookup_type_row(inputs_type) if ops.mix_cache_active() else None
+        if hit is not None:            # one of the model's modality labels: all labels are mixed in one launch per step
+            table, row = hit
+            key = (id(self), 'all', table.data_ptr(), table._version)
+            allw = ops.cached_mix(key, lambda: ops.mix_experts_routed_all(
+                self.weight, self._routing_fn.fc.weight, self._routing_fn.fc.bias, table))
+            return allw[2 * row], allw[2 * row + 1]
+        key = (id(self), inputs_type.data_ptr(), inputs_type._version)
+        return ops.cached_mix(key, lambda: self._mixed(inputs_type[:1]))
+
     def forward(self, inputs, inputs_type, lrelu=False):
         kh, kw = self.kernel_size
         B = inputs.shape[0]
         if B == 1 or inputs_type.stride(0) == 0:
-            hit = ops.lookup_type_row(inputs_type) if ops.mix_cache_active() else None
-            if hit is not None:        # one of the model's modality labels: all labels are mixed in one launch per step
-                table, row = hit
-                key = (id(self), 'all', table.data_ptr(), table._version)
-                allw = ops.cached_mix(key, lambda: ops.mix_experts_routed_all(
-                    self.weight, self._routing_fn.fc.weight, self._routing_fn.fc.bias, table))
-                w_tck, w_tkc = allw[2 * row], allw[2 * row + 1]
-            else:
-                key = (id(self), inputs_type.data_ptr(), inputs_type._version)
-                w_tck, w_tkc = ops.cached_mix(key, lambda: self._mixed(inputs_type[:1]))
+            w_tck, w_tkc = self.mixed_uniform(inputs_type)
             return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
         outs = []                                    # per-sample path, model.py:2114-2117
         for i in range(B):
@@ -305,8 +308,8 @@ class SPADEBlockNew(nn.Module):
             key = (id(self), 'gb', inputs_type.data_ptr(), inputs_type._version)
 
             def fused():
-                g_tck, g_tkc = self.gamma._mixed(inputs_type[:1])
-                b_tck, b_tkc = self.beta._mixed(inputs_type[:1])
+                g_tck, g_tkc = self.gamma.mixed_uniform(inputs_type)
+                b_tck, b_tkc = self.beta.mixed_uniform(inputs_type)
                 return (torch.cat([g_tck, b_tck], 2), torch.cat([g_tkc, b_tkc], 1),
                         torch.cat([self.gamma.bias, self.beta.bias]))
             w_tck, w_tkc, bias = ops.step_cache(key, fused)
