@@ -547,20 +547,31 @@ class MultimodalModel(nn.Module):
     def compute_recon_loss(self, gt, output, p=2):                                               # :3260-3266
         return ops.recon_err(gt, output, p)
 
+    # The loss heads below are the reference's loops with the per-term scalar arithmetic folded into ONE weighted
+    # reduction: the weights (mask / count / number of terms) come from the host copy of the mask, so a term costs its
+    # HIP reduction and nothing else (the loop form issued ~1000 one-workgroup torch kernels per step, forward and
+    # backward).  Term order, the skip rules and the quirks are unchanged.
+    def _weights(self, rows):
+        """rows: list of numpy (B,) weight vectors -> (T, B) device tensor (one H2D copy)."""
+        return torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device, non_blocking=True)
+
     def compute_recon_loss_x_list(self, gt_list, x_list, mask, p=2, mask_host=None):             # :3315-3325
         mh = _host_mask(mask, mask_host)
-        loss, idx = torch.zeros((), device=self.device), 0
+        errs, rows = [], []
         for i in range(len(x_list)):
             if mh[:, i].sum() == 0:
                 continue
-            idx += 1
-            loss = loss + (mask[:, i] * self.compute_recon_loss(gt_list[i], x_list[i], p)).sum() / float(mh[:, i].sum())
-        return loss if idx == 0 else loss / idx
+            errs.append(self.compute_recon_loss(gt_list[i], x_list[i], p))
+            rows.append(mh[:, i] / float(mh[:, i].sum()))
+        if not errs:
+            return torch.zeros((), device=self.device)
+        return (torch.stack(errs) * self._weights(rows)).sum() / len(errs)
 
     def compute_recon_loss_x_mix_list(self, gt_list, x_list, mask, p=2, mask_host=None):         # :3327-3341
         mh = _host_mask(mask, mask_host)
-        loss, idx = torch.zeros((), device=self.device), 0
+        errs, rows = [], []
         M = mh.shape[1]
+        idx = 0
         for i in range(M):
             for j in range(M):
                 if i == j:
@@ -568,21 +579,23 @@ class MultimodalModel(nn.Module):
                 mm_h = mh[:, i] * mh[:, j]
                 if mm_h.sum() == 0:
                     continue
-                mm = mask[:, i] * mask[:, j]
                 # QUIRK (:3337-3338): x_list is indexed by a counter that only advances on non-empty pairs
-                loss = loss + (mm * self.compute_recon_loss(gt_list[j], x_list[idx], p)).sum() / float(mm_h.sum())
+                errs.append(self.compute_recon_loss(gt_list[j], x_list[idx], p))
+                rows.append(mm_h / float(mm_h.sum()))
                 idx += 1
-        return loss if idx == 0 else loss / idx
+        if not errs:
+            return torch.zeros((), device=self.device)
+        return (torch.stack(errs) * self._weights(rows)).sum() / idx
 
     def compute_latent_z_loss(self, zi_mean_list, zi_mean_list_new, mask, mask_host=None):       # :3384-3394
         mh = _host_mask(mask, mask_host)
-        loss, idx = torch.zeros((), device=self.device), 0
-        for i in range(len(zi_mean_list)):
-            if mh[:, i].sum() == 0:
-                continue
-            idx += 1
-            loss = loss + (mask[:, i].unsqueeze(1) * torch.abs(zi_mean_list[i] - zi_mean_list_new[i])).sum() / float(mh[:, i].sum())
-        return loss if idx == 0 else loss / idx
+        terms = [i for i in range(len(zi_mean_list)) if mh[:, i].sum() != 0]
+        if not terms:
+            return torch.zeros((), device=self.device)
+        z0 = torch.stack([zi_mean_list[i] for i in terms])                       # (T, B, Z)
+        z1 = torch.stack([zi_mean_list_new[i] for i in terms])
+        w = self._weights([mh[:, i] / float(mh[:, i].sum()) for i in terms])      # (T, B)
+        return (torch.abs(z0 - z1).sum(2) * w).sum() / len(terms)
 
     def compute_cosine(self, x, y):                                                              # :3407-3415
         xn = torch.sqrt(torch.sum(x * x, 1) + 1e-8).clamp_min(1e-8)
@@ -619,23 +632,28 @@ class MultimodalModel(nn.Module):
 
     def compute_similarity_z_loss(self, zi_list, mask, margin=0.1, mask_host=None):              # :3537-3557
         mh = _host_mask(mask, mask_host)
-        loss, idx = torch.zeros((), device=self.device), 0
         if len(zi_list) == 1:
-            return loss
+            return torch.zeros((), device=self.device)
+        I, J, rows = [], [], []
         for i in range(len(zi_list) - 1):
-            zi = zi_list[i]
-            zp = torch.cat([zi[1:], zi[0:1]], 0)
             mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
             for j in range(i + 1, len(zi_list)):
                 mm_h = mh[:, i] * mh[:, j] * mperm_h
                 if mm_h.sum() == 0:
                     continue
-                idx += 1
-                mm = mask[:, i] * mask[:, j] * torch.cat([mask[1:, i], mask[0:1, i]], 0)
-                cosine = self.compute_cosine(zi, zi_list[j])
-                cosine_mix = self.compute_cosine(zi, zp)
-                loss = loss + (mm * torch.clamp_min(margin - cosine_mix + cosine, 0)).sum() / float(mm_h.sum())
-        return loss if idx == 0 else loss / idx
+                I.append(i); J.append(j); rows.append(mm_h / float(mm_h.sum()))
+        if not I:
+            return torch.zeros((), device=self.device)
+        Z = torch.stack(list(zi_list))                                            # (M, B, Z)
+        Zp = torch.cat([Z[:, 1:], Z[:, 0:1]], 1)                                  # roll by one sample, per modality
+        zi, zj, zp = Z[I], Z[J], Zp[I]                                            # (P, B, Z)
+
+        def cos(x, y):                                                            # compute_cosine on the last axis
+            xn = torch.sqrt(torch.sum(x * x, 2) + 1e-8).clamp_min(1e-8)
+            yn = torch.sqrt(torch.sum(y * y, 2) + 1e-8).clamp_min(1e-8)
+            return torch.sum(x * y, 2) / (xn * yn)
+        hinge = torch.clamp_min(margin - cos(zi, zp) + cos(zi, zj), 0)             # (P, B)
+        return (hinge * self._weights(rows)).sum() / len(I)
 
     def compute_adversarial_loss(self, si_list, mask, mask_host=None):                           # :3559-3587
         mh = _host_mask(mask, mask_host)
