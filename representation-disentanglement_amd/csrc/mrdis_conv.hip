@@ -1849,15 +1849,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
                                     int CW, int TPS, int J, int nCi, int nCo, int base, int nslab, WgradTapMap map,
                                     const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
     __shared__ float red[16][65];
-    const long long total = (long long)ntaps * Ci * Co;
-    const long long nout = total + (dbias != nullptr ? Co : 0);
-    const long long i = blockIdx.x * 64LL + threadIdx.x;
+    const int total = ntaps * Ci * Co;                   // < 2^31 (host: kh*kw*Ci*Co elements of one filter)
+    const int nout = total + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 64 + threadIdx.x;
     const int SL = blockDim.y, y = threadIdx.y;
     float s_ = 0.f;
     if (i < total) {
-        const int co = (int)(i % Co);
-        const long long r = i / Co;
-        const int ci = (int)(r % Ci), t = (int)(r / Ci);
+        const int co = i % Co;
+        const int r = i / Co;
+        const int ci = r % Ci, t = r / Ci;
         const int coc = co >> 5, n = co & 31;
         const int cic = (Ci >= 32) ? (ci >> 5) : 0;
         const int cl = ci - cic * 32;
@@ -1867,9 +1867,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         const int b = (g * nCi + cic) * nCo + coc;
         const long long stride = (long long)base * J * 1024;
         const float* src = slab + ((long long)b * J + j) * 1024 + m * 32 + n + (long long)y * stride;
-        for (int k = y; k < nslab; k += SL, src += (long long)SL * stride) s_ += *src;
+        const long long step = (long long)SL * stride;
+        int k = y;
+        for (; k + 3 * SL < nslab; k += 4 * SL, src += 4 * step) {        // four loads in flight, summed in slab order
+            const float a = src[0], b = src[step], c = src[2 * step], d = src[3 * step];
+            s_ += a; s_ += b; s_ += c; s_ += d;
+        }
+        for (; k < nslab; k += SL, src += step) s_ += *src;
     } else if (i < nout) {
-        const int co = (int)(i - total);
+        const int co = i - total;
         for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * (nCo * 32) + co];
     }
     red[y][threadIdx.x] = s_;
@@ -1878,7 +1884,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         float t = 0.f;
         for (int k = 0; k < SL; ++k) t += red[k][threadIdx.x];
         if (i < total) dw[i] = t;
-        else { const int co = (int)(i - total); dbias[co] = accumulate_bias ? dbias[co] + t : t; }
+        else { const int co = i - total; dbias[co] = accumulate_bias ? dbias[co] + t : t; }
     }
 }
 
@@ -2023,7 +2029,12 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
     const long long nt = (long long)p.tilesA * p.tilesB * p.tilesN;
     if (nt > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     p.numTiles = (int)nt;
-    long long splits = mrdis_cdiv(1024, p.base);
+    // split-K: one workgroup per resident slot.  The MFMA kernels hold two workgroups per CU (accumulators), so 512
+    // workgroups run as one full round and write half the slab volume a 1024-workgroup launch would
+    // (1-7 % faster on the big layers, tools/ab_lib.py); the thin FMA kernels fit 3-4 per CU and keep 1024
+    int wg_target = pl.thin ? 1024 : 512;
+    if (const char* e = getenv("MRDIS_DEBUG_WGSPLIT")) wg_target = atoi(e);
+    long long splits = mrdis_cdiv(wg_target, p.base);
     if (splits > nt) splits = nt;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
