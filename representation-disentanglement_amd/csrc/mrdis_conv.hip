@@ -712,14 +712,14 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     int BM = 128;
     // 256-position workgroups: twice the MFMA work per staged filter slab.  Pays on the 32-cout layers (8-10 %, a
     // 32-wide tile reuses each staged pixel only once per wave); with 64 couts the second accumulator pair costs a
-    // resident workgroup (2 instead of 3 per CU) and it is a wash on big grids -- but on grids of 1024-4096 workgroups
+    // resident workgroup (2 instead of 3 per CU) and it is a wash on big grids -- but on grids of 1024-8192 workgroups
     // 2 x 256 slots divide the grid evenly where 3 x 256 leave a ragged last round: +2-7 % there (tools/ab_lib.py,
     // MRDIS_DEBUG_BM: 0 never, 1 BN=32 layers, 2 all, 3 = default policy).  Only where the hoisted staging still fits
     // its register arrays.
     {
         int want = 3;
         if (const char* e = getenv("MRDIS_DEBUG_BM")) want = atoi(e);
-        const bool cand = p.prefetch == 1 && KC == 16 && ((nblk >= 4096 && (want == 1 || want == 3) && BN == 32) || (want == 2 && nblk >= 1024) || (want == 3 && BN == 64 && nblk >= 1024 && nblk <= 4096));
+        const bool cand = p.prefetch == 1 && KC == 16 && ((nblk >= 4096 && (want == 1 || want == 3) && BN == 32) || (want == 2 && nblk >= 1024) || (want == 3 && BN == 64 && nblk >= 1024 && nblk <= 8192));
         if (cand) {
             TapConvParams q = p;
             const TileChoice t2 = choose_tile(q.N, q.A, q.B, 256);
