@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--fit', choices=['pad', 'crop'], default='pad', help='240 -> 256x256 pad (default) or 160x192 crop')
     ap.add_argument('--no-adv', action='store_true', help='lambda_adv_s = 0 (the shipped config.yaml)')
     ap.add_argument('--drop', action='store_true', help='missing-modality batches (BASELINE configs[3])')
+    ap.add_argument('--recon-y', action='store_true', help="lambda_recon_y = 1: adds the 'U+SA' output decoder + segmentation loss (not the headline config)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -153,6 +154,8 @@ def main():
     cfg = dict(mrdis.DEFAULT_CONFIG)
     cfg.update(contrast_list=['T1', 'T1c', 'T2', 'T2_FLAIR'][:M] if M <= 4 else [f'm{i}' for i in range(M)],
                input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0 if adv else 0.0)
+    if a.recon_y:
+        cfg.update(lambda_recon_y=1.0, out_num_ch=4)
     cfg = mrdis.derive_config(cfg, dev)
     torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21; same init on every rank
     model = mrdis.build_model(cfg).train()
@@ -162,6 +165,8 @@ def main():
     mask_img = (x[:, 0] == 0).float()
     xd = x.to(dev).contiguous(memory_format=torch.channels_last)
     maskd, mimgd = mask.to(dev), mask_img.to(dev)
+    tgt = torch.randint(0, 4, (B, 1, H, W), generator=torch.Generator().manual_seed(13 + rank)).float().to(dev) \
+        if a.recon_y else None
     torch.manual_seed(100 + rank); np.random.seed(100)               # eps per rank, sim_s pair identical on all ranks
 
     def sync():
@@ -175,7 +180,7 @@ def main():
 
     log(f'model built, batch {B}x{M}x{H}x{W}; warm-up')
     for i in range(a.warmup):
-        step(xd, maskd, mimgd, mask)
+        step(xd, maskd, mimgd, mask, targets=tgt)
         torch.cuda.synchronize()
         log(f'warm-up step {i} done, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
     sync()
@@ -183,7 +188,7 @@ def main():
     host_ms = 0.0
     for _ in range(a.steps):
         h0 = time.perf_counter()
-        loss, parts, _ = step(xd, maskd, mimgd, mask)
+        loss, parts, _ = step(xd, maskd, mimgd, mask, targets=tgt)
         host_ms += (time.perf_counter() - h0) * 1e3
     sync()
     dt = time.perf_counter() - t0
@@ -207,7 +212,8 @@ def main():
                                    f'batch {B}/GPU, full train step (fwd, recon_x+recon_x_mix+latent_z+sim_s+sim_z'
                                    f'{"+adv" if adv else ""}, bwd, clip, Adam amsgrad)',
                        'global_batch': B * world, 'per_gpu_batch': B, 'modalities': M, 'input_hw': [H, W],
-                       'parallelism': f'dp{world}', 'missing_modality': bool(a.drop)},
+                       'parallelism': f'dp{world}', 'missing_modality': bool(a.drop),
+                       'output_decoder': bool(a.recon_y)},
             'loss': round(host_losses['all'], 5),
             'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
             'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,

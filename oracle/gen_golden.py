@@ -162,9 +162,9 @@ def make_inputs(B, M, H, W, seed, drop=False):
     return x, mask, mask_img
 
 
-def build_ref_model(ref, M, adv=False):
+def build_ref_model(ref, M, adv=False, out_num_ch=1):
     return quiet(
-        ref.MultimodalModel, input_size=(160, 192), modality_num=M, in_num_ch=7, out_num_ch=1,
+        ref.MultimodalModel, input_size=(160, 192), modality_num=M, in_num_ch=7, out_num_ch=out_num_ch,
         s_num_ch=4, z_size=16, is_cond=True, is_discrim_s=adv, is_distri_z=False,
         s_compact_method='max', s_sim_method='cosine', z_sim_method='cosine', shared_ana_enc=True,
         shared_mod_enc=True, shared_inp_dec=False, device=torch.device('cpu'),
@@ -188,11 +188,17 @@ def reinit_discriminator(module, seed=777):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.01)
 
 
-def gen_step(ref, tag, B, M, drop=False, adv=False):
+def make_seg_targets(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 4, (B, 1, H, W), generator=g).float()
+
+
+def gen_step(ref, tag, B, M, drop=False, adv=False, recon_y=False):
     lam = dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, sim_z=2.0,
-               adv_s=(1.0 if adv else 0.0))
+               adv_s=(1.0 if adv else 0.0), recon_y=(1.0 if recon_y else 0.0))
     torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21
-    model = build_ref_model(ref, M, adv)
+    model = build_ref_model(ref, M, adv, out_num_ch=4 if recon_y else 1)
+    prefixes = HOT_PREFIXES + (('output_decoder.',) if recon_y else ())
     if adv:
         reinit_discriminator(model.discrim_s)
     model.train()
@@ -204,7 +210,7 @@ def gen_step(ref, tag, B, M, drop=False, adv=False):
     # sim_s pair choice (model.py:3485) are reproducible on both sides.
     torch.manual_seed(11); np.random.seed(11)
     w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items()
-          if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point}
+          if k.startswith(prefixes) and v.dtype.is_floating_point}
 
     x_list = [inputs[:, i * 7:(i + 1) * 7] for i in range(M)]
     # ---- main_missing.py:175-251 call order
@@ -213,9 +219,16 @@ def gen_step(ref, tag, B, M, drop=False, adv=False):
     xf = model.reconstruct_input_si_zi(s_list, z_list)
     xmix = model.reconstruct_input_si_zj(s_list, z_list)
     parts = {}
+    loss = 0
+    y_list = None
+    if recon_y:                                                       # main_missing.py:187-198, BraTS -> segmentation loss
+        targets = make_seg_targets(B, 160, 192, seed=13)
+        y_list = model.reconstruct_output_si(s_list)
+        parts['recon_y'] = model.compute_segmentation_loss_y_list(targets, y_list, mask)
+        loss = loss + lam['recon_y'] * parts['recon_y']
     parts['recon_x'] = model.compute_recon_loss_x_list(x_list, xf, mask, p=1)
     parts['recon_x_mix'] = model.compute_recon_loss_x_mix_list(x_list, xmix, mask, p=1)
-    loss = lam['recon_x'] * parts['recon_x'] + lam['recon_x_mix'] * parts['recon_x_mix']
+    loss = loss + lam['recon_x'] * parts['recon_x'] + lam['recon_x_mix'] * parts['recon_x_mix']
     s_new = model.compute_anatomy_encoding(xf, mask_img)
     _, mu_new, _ = model.compute_modality_encoding(xf, s_new, phase='train')
     parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask)
@@ -233,7 +246,7 @@ def gen_step(ref, tag, B, M, drop=False, adv=False):
     gnorm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
     opt.step(); opt.zero_grad()
     w1 = {k: float(v.double().sum()) for k, v in model.state_dict().items()
-          if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point}
+          if k.startswith(prefixes) and v.dtype.is_floating_point}
     d_step_error = None
     if adv:
         # main_missing.py:286-289 as written.  Under torch >= 1.5 the in-place
@@ -255,6 +268,8 @@ def gen_step(ref, tag, B, M, drop=False, adv=False):
                 lv=torch.stack(lv_list).detach().numpy(),
                 s0_pool8=pool8(s_list[0].detach()), xf0_pool8=pool8(xf[0].detach()),
                 xmix0_pool8=pool8(xmix[0].detach()), mask=mask.numpy())
+    if y_list is not None:
+        arrs['y0_pool8'] = pool8(y_list[0].detach()); arrs['y1_pool8'] = pool8(y_list[-1].detach())
     np.savez_compressed(os.path.join(OUT, f'step_{tag}.npz'), **arrs)
     print(f'step_{tag}: loss={float(loss):.7f} gnorm={gnorm:.4f}',
           {k: round(float(v), 7) for k, v in parts.items()})
@@ -350,6 +365,8 @@ def main():
         gen_step(ref, 'b2m4_drop', 2, 4, drop=True)
     if not only or 'adv' in only:
         gen_step(ref, 'b2m2_adv', 2, 2, adv=True)
+    if not only or 'recon_y' in only:
+        gen_step(ref, 'b2m2_y', 2, 2, recon_y=True)
     if not only or 'eval' in only:
         gen_eval(ref, 'b2m4', 2, 4)
     if not only or 'data' in only:

@@ -275,6 +275,85 @@ class RefDiscriminator(nn.Module):
 # --------------------------------------------------------------------------
 # orchestration + losses: model.py:2916-2970, 3086-3224, 3260-3587
 # --------------------------------------------------------------------------
+# ----------------------------------------------------------------------------- output decoder 'U+SA' (model.py:117-168, 341-390, 1303-1327)
+class RefLegacyConvBNAct(nn.Module):
+    """Conv_BN_Act (model.py:117-139).  QUIRK: the if/if/if-else chain leaves `act` = identity unless 'elu'."""
+
+    def __init__(self, cin, cout, activation='lrelu'):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(cin, cout, 4, 2, padding=1), nn.BatchNorm2d(cout))
+        self.act = nn.ELU(inplace=True) if activation == 'elu' else nn.Sequential()
+
+    def forward(self, x):
+        return self.act(self.conv(x))
+
+
+class RefLegacyUpConcat(nn.Module):
+    """Act_Deconv_BN_Concat (model.py:141-174), same identity-activation quirk; the BatchNorm exists (and draws no
+    RNG) even when is_last."""
+
+    def __init__(self, cin, cout, is_last=False):
+        super().__init__()
+        self.act = nn.Sequential()
+        self.is_last = is_last
+        self.up = nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                                nn.Conv2d(cin, cout, 3, 1, padding=1))
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x_down, x_up):
+        x_up = self.up(self.act(x_up))
+        if self.is_last:
+            return x_up
+        return torch.cat([x_down, self.bn(x_up)], 1)
+
+
+class RefSpatialAttention(nn.Module):
+    """SpatialAttentionLayer (model.py:1303-1327)."""
+
+    def __init__(self, cin, cgate, cinter):
+        super().__init__()
+        self.W_x = nn.Conv2d(cin, cinter, (2, 2), (2, 2), bias=False)
+        self.W_g = nn.Conv2d(cgate, cinter, 1, 1)
+        self.W_psi = nn.Conv2d(cinter, 1, 1, 1)
+        self.W_out = nn.Sequential(nn.Conv2d(cin, cin, 1, 1), nn.BatchNorm2d(cin))
+
+    def forward(self, x, g):
+        x_post = self.W_x(x)
+        g_post = F.interpolate(self.W_g(g), size=x_post.shape[2:], mode='bilinear', align_corners=False)   # F.upsample default
+        alpha = torch.sigmoid(self.W_psi(F.relu(x_post + g_post)))
+        alpha_up = F.interpolate(alpha, size=x.shape[2:], mode='bilinear', align_corners=False)
+        return self.W_out(alpha_up * x), alpha_up
+
+
+class RefOutputDecoderUSA(nn.Module):
+    """GANShortGeneratorWithSpatialAttention (model.py:341-390), output_activation 'no' (BraTS / z-score, main_missing.py:80)."""
+
+    def __init__(self, in_num_ch, out_num_ch, c=64):
+        super().__init__()
+        self.down_1 = nn.Sequential(nn.Conv2d(in_num_ch, c, 4, 2, padding=1), nn.LeakyReLU(0.2, inplace=True))
+        self.down_2 = RefLegacyConvBNAct(c, 2 * c)
+        self.down_3 = RefLegacyConvBNAct(2 * c, 4 * c)
+        self.down_4 = RefLegacyConvBNAct(4 * c, 8 * c)
+        self.down_5 = RefLegacyConvBNAct(8 * c, 8 * c, activation='no')
+        self.att_4 = RefSpatialAttention(8 * c, 8 * c, 8 * c)
+        self.up_4 = RefLegacyUpConcat(8 * c, 8 * c)
+        self.att_3 = RefSpatialAttention(4 * c, 16 * c, 4 * c)
+        self.up_3 = RefLegacyUpConcat(16 * c, 4 * c)
+        self.att_2 = RefSpatialAttention(2 * c, 8 * c, 2 * c)
+        self.up_2 = RefLegacyUpConcat(8 * c, 2 * c)
+        self.att_1 = RefSpatialAttention(c, 4 * c, c)
+        self.up_1 = RefLegacyUpConcat(4 * c, c)
+        self.output = RefLegacyUpConcat(2 * c, out_num_ch, is_last=True)
+
+    def forward(self, x):
+        d1 = self.down_1(x); d2 = self.down_2(d1); d3 = self.down_3(d2); d4 = self.down_4(d3); d5 = self.down_5(d4)
+        c4, _ = self.att_4(d4, d5); u4 = self.up_4(c4, d5)
+        c3, _ = self.att_3(d3, u4); u3 = self.up_3(c3, u4)
+        c2, _ = self.att_2(d2, u3); u2 = self.up_2(c2, u3)
+        c1, _ = self.att_1(d1, u2); u1 = self.up_1(c1, u2)
+        return self.output(None, u1)
+
+
 class RefMultimodalModel(nn.Module):
     """Default-config graph (config.yaml: is_cond, shared_ana_enc,
     shared_mod_enc, shared_inp_dec=False, mod_enc_s=False,
@@ -289,7 +368,7 @@ class RefMultimodalModel(nn.Module):
     """
 
     def __init__(self, input_size=(160, 192), modality_num=4, in_num_ch=7, s_num_ch=4,
-                 z_size=16, is_discrim_s=False, is_patch_gan=False):
+                 z_size=16, is_discrim_s=False, is_patch_gan=False, out_num_ch=0):
         super().__init__()
         H, W = input_size
         self.input_size, self.M = (H, W), modality_num
@@ -300,6 +379,8 @@ class RefMultimodalModel(nn.Module):
         dec = [RefSPADENotShared((H, W), in_num_ch, 128, s_num_ch) for _ in range(modality_num)]
         dec.append(RefSPADEShared((H, W), z_size, 128, s_num_ch))
         self.input_decoder_list = nn.ModuleList(dec)
+        if out_num_ch > 0:                                                   # model.py:2957-2958 ('U+SA', fuse 'mean')
+            self.output_decoder = RefOutputDecoderUSA(s_num_ch, out_num_ch)
         if is_discrim_s:
             self.discrim_s = RefDiscriminator(s_num_ch, 16, (H, W), is_patch_gan)
 
@@ -331,6 +412,48 @@ class RefMultimodalModel(nn.Module):
                 z = mu
             zs.append(z); mus.append(mu); lvs.append(lv)
         return zs, mus, lvs
+
+    # model.py:3230-3258.  QUIRK: `si_cat[mask == 1]` flattens (batch, modality) into one axis, so the "fused" map is
+    # NOT a per-sample mean over modalities: every present (b, m) anatomy map becomes its own sample (the mean runs over
+    # a singleton axis) and the output has sum(mask) rows, b-major.
+    def reconstruct_output_si_fused(self, s_list, mask):
+        s_cat = torch.stack(s_list, 1)
+        sel = s_cat[mask == 1]
+        if sel.dim() != s_cat.dim():
+            sel = sel.unsqueeze(1)
+        return self.output_decoder(torch.mean(sel, 1))
+
+    def reconstruct_output_si(self, s_list):
+        B = s_list[0].shape[0]
+        return [self.reconstruct_output_si_fused([s_list[i]], torch.ones(B, 1)) for i in range(self.M)]
+
+    def recon_y_list(self, gt, y_list, mask, p=2):                          # :3268-3278
+        loss, idx = torch.tensor(0.), 0
+        for i in range(len(y_list)):
+            if mask[:, i].sum() == 0:
+                continue
+            idx += 1
+            loss = loss + (mask[:, i] * self.recon(gt, y_list[i], p)).sum() / mask[:, i].sum()
+        return loss if idx == 0 else loss / idx
+
+    # model.py:3287-3313 (F.softmax without dim on a 4-D tensor = dim 1)
+    def segmentation_loss_y(self, gt, y, weight=(1., 5., 5., 5.)):
+        loss_seg = F.cross_entropy(y, gt.squeeze(1).long(), weight=torch.tensor(weight))
+        y_act = F.softmax(y, dim=1)
+        dice = 0
+        for i in range(1, 4):
+            gt_i = (gt[:, 0] == i).float()
+            dice = dice + 1 - 2 * torch.sum(y_act[:, i] * gt_i) / (torch.sum(y_act[:, i] ** 2 + gt_i ** 2) + 1e-6)
+        return loss_seg + dice / 3
+
+    def segmentation_loss_y_list(self, gt, y_list, mask):
+        loss, idx = torch.tensor(0.), 0
+        for i in range(len(y_list)):
+            if mask[:, i].sum() == 0:
+                continue
+            idx += 1
+            loss = loss + self.segmentation_loss_y(gt, y_list[i])
+        return loss if idx == 0 else loss / idx
 
     # model.py:3187-3203
     def reconstruct_input_si_zi(self, s_list, z_list):
@@ -466,10 +589,10 @@ class RefMultimodalModel(nn.Module):
 
 
 DEFAULT_LAMBDAS = dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, sim_z=2.0,
-                       adv_s=0.0)        # config.yaml:27-33, 54-56
+                       adv_s=0.0, recon_y=0.0)        # config.yaml:27-33, 54-56
 
 
-def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1, phase='train'):
+def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1, phase='train', targets=None, dataset_name='BraTS'):
     """main_missing.py:165-251 (phase='train') / :389-505 (phase='test', inside model.eval() + no_grad)
     for the default loss set.  Returns (loss, parts, aux)."""
     lam = dict(DEFAULT_LAMBDAS); lam.update(lambdas or {})
@@ -482,6 +605,14 @@ def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1, phase='
     xmix = model.reconstruct_input_si_zj(s_list, z_list)                    # :178
     parts = {}
     loss = 0
+    y_list = None
+    if lam['recon_y'] > 0:                                                  # :187-198 (the *_fused variant cannot run for
+        y_list = model.reconstruct_output_si(s_list)                        #  M > 1: its output has sum(mask) rows)
+        if dataset_name == 'BraTS':
+            parts['recon_y'] = model.segmentation_loss_y_list(targets, y_list, mask)
+        else:
+            parts['recon_y'] = model.recon_y_list(targets, y_list, mask, p)
+        loss = loss + lam['recon_y'] * parts['recon_y']
     if lam['recon_x'] > 0:
         parts['recon_x'] = model.recon_x_list(x_list, xf, mask, p)
         loss = loss + lam['recon_x'] * parts['recon_x']
@@ -502,7 +633,7 @@ def ref_forward_losses(model, inputs, mask, mask_img, lambdas=None, p=1, phase='
     if lam['adv_s'] > 0:
         parts['adv_s_d'], parts['adv_s'] = model.adversarial(s_list, mask)
         loss = loss + lam['adv_s'] * parts['adv_s']
-    aux = dict(s_list=s_list, z_list=z_list, mu_list=mu_list, lv_list=lv_list, xf=xf, xmix=xmix)
+    aux = dict(s_list=s_list, z_list=z_list, mu_list=mu_list, lv_list=lv_list, xf=xf, xmix=xmix, y_list=y_list)
     return loss, parts, aux
 
 

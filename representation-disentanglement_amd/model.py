@@ -417,6 +417,93 @@ class Discriminator(nn.Module):
 # =============================================================================
 # orchestration + losses: model.py:2916-2970, 3086-3224, 3260-3587
 # =============================================================================
+# =============================================================================
+# output decoder 'U+SA' (lambda_recon_y > 0): model.py:117-174, 341-390, 1303-1327
+# =============================================================================
+class LegacyConvBNAct(nn.Module):
+    """Conv_BN_Act (model.py:117-139).  QUIRK: the if/if/if-else chain leaves `act` = identity unless 'elu'."""
+
+    def __init__(self, in_num_ch, out_num_ch, activation='lrelu'):
+        super().__init__()
+        self.conv = nn.Sequential(HipConv2d(in_num_ch, out_num_ch, 4, 2, padding=1), BatchNorm2d(out_num_ch))
+        self.act = nn.ELU(inplace=True) if activation == 'elu' else nn.Sequential()
+
+    def forward(self, x):
+        return self.act(self.conv(x))
+
+
+class LegacyUpConcat(nn.Module):
+    """Act_Deconv_BN_Concat (model.py:141-174): identity activation (same quirk), x2 bilinear (align_corners=True),
+    3x3 conv, BatchNorm, concat with the gated skip; `bn` exists even when is_last (state_dict keys)."""
+
+    def __init__(self, in_num_ch, out_num_ch, is_last=False):
+        super().__init__()
+        self.act = nn.Sequential()
+        self.is_last = is_last
+        self.up = nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                                HipConv2d(in_num_ch, out_num_ch, 3, 1, padding=1))
+        self.bn = BatchNorm2d(out_num_ch)
+
+    def forward(self, x_down, x_up):
+        x_up = ops.bilinear(self.act(x_up), (2 * x_up.shape[2], 2 * x_up.shape[3]), True)
+        x_up = self.up[1](x_up)
+        if self.is_last:
+            return x_up
+        return torch.cat([x_down, self.bn(x_up)], 1)
+
+
+class SpatialAttentionLayer(nn.Module):
+    """model.py:1303-1327 (F.upsample bilinear = align_corners False)."""
+
+    def __init__(self, in_num_ch, gate_num_ch, inter_num_ch, sample_factor=(2, 2)):
+        super().__init__()
+        self.W_x = HipConv2d(in_num_ch, inter_num_ch, sample_factor, sample_factor, bias=False)
+        self.W_g = HipConv2d(gate_num_ch, inter_num_ch, 1, 1)
+        self.W_psi = HipConv2d(inter_num_ch, 1, 1, 1)
+        self.W_out = nn.Sequential(HipConv2d(in_num_ch, in_num_ch, 1, 1), BatchNorm2d(in_num_ch))
+
+    def forward(self, x, g):
+        x_post = self.W_x(x)
+        g_post = ops.bilinear(self.W_g(g), tuple(x_post.shape[2:]), False)
+        alpha = torch.sigmoid(self.W_psi(F.relu(x_post + g_post)))
+        alpha_up = ops.bilinear(alpha, tuple(x.shape[2:]), False)
+        return self.W_out(alpha_up * x), alpha_up
+
+
+class GANShortGeneratorWithSpatialAttention(nn.Module):
+    """model.py:341-390, `output_activation='no'` (BraTS / z-score data, main_missing.py:80) -> empty Sequential."""
+
+    def __init__(self, in_num_ch, out_num_ch, first_num_ch=64, output_activation='no'):
+        super().__init__()
+        if output_activation != 'no':
+            raise NotImplementedError("only target_output_act 'no' (main_missing.py:80 for BraTS / z-score) is on the path")
+        c = first_num_ch
+        self.down_1 = nn.Sequential(HipConv2d(in_num_ch, c, 4, 2, padding=1), nn.LeakyReLU(0.2, inplace=True))
+        self.down_2 = LegacyConvBNAct(c, 2 * c)
+        self.down_3 = LegacyConvBNAct(2 * c, 4 * c)
+        self.down_4 = LegacyConvBNAct(4 * c, 8 * c)
+        self.down_5 = LegacyConvBNAct(8 * c, 8 * c, activation='no')
+        self.att_4 = SpatialAttentionLayer(8 * c, 8 * c, 8 * c)
+        self.up_4 = LegacyUpConcat(8 * c, 8 * c)
+        self.att_3 = SpatialAttentionLayer(4 * c, 16 * c, 4 * c)
+        self.up_3 = LegacyUpConcat(16 * c, 4 * c)
+        self.att_2 = SpatialAttentionLayer(2 * c, 8 * c, 2 * c)
+        self.up_2 = LegacyUpConcat(8 * c, 2 * c)
+        self.att_1 = SpatialAttentionLayer(c, 4 * c, c)
+        self.up_1 = LegacyUpConcat(4 * c, c)
+        self.output = LegacyUpConcat(2 * c, out_num_ch, is_last=True)
+        self.output_act = nn.Sequential()
+
+    def forward(self, x):
+        d1 = self.down_1[0](x, lrelu=True)                 # conv + LeakyReLU(0.2) fused in the epilogue
+        d2 = self.down_2(d1); d3 = self.down_3(d2); d4 = self.down_4(d3); d5 = self.down_5(d4)
+        c4, a4 = self.att_4(d4, d5); u4 = self.up_4(c4, d5)
+        c3, a3 = self.att_3(d3, u4); u3 = self.up_3(c3, u4)
+        c2, a2 = self.att_2(d2, u3); u2 = self.up_2(c2, u3)
+        c1, a1 = self.att_1(d1, u2); u1 = self.up_1(c1, u2)
+        return self.output_act(self.output(None, u1)), {'alpha_4': a4, 'alpha_3': a3, 'alpha_2': a2, 'alpha_1': a1}
+
+
 class MultimodalModel(nn.Module):
     """model.py:2916-3587 for the configuration the reference ships
     (config.yaml: is_cond, shared_ana_enc, shared_mod_enc, shared_inp_dec=False,
@@ -427,7 +514,7 @@ class MultimodalModel(nn.Module):
                  is_discrim_s=False, is_distri_z=False, shared_ana_enc=False, shared_mod_enc=True, shared_inp_dec=True,
                  s_compact_method='max', s_sim_method='cosine', z_sim_method='cosine', is_cond=True,
                  input_output_act='softplus', target_output_act='softplus', target_model_name='U', fuse_method='mean',
-                 device=torch.device('cuda:0'), others=None, is_patch_gan=False):
+                 device=torch.device('cuda:0'), others=None, is_patch_gan=False, build_output_decoder=False):
         super().__init__()
         others = dict(others or {'mod_enc_s': True, 'ana_dec_act': 'softmax'})
         others.setdefault('old', False)
@@ -453,7 +540,13 @@ class MultimodalModel(nn.Module):
                for _ in range(modality_num)]
         dec.append(SPADENewShared((H, W), in_num_ch, z_size, 128, s_num_ch, is_cond))            # :3129-3131
         self.input_decoder_list = nn.ModuleList(dec)
-        # output_decoder (lambda_recon_y = 0, config.yaml:27-28) is outside the hot path: not built.
+        # output_decoder: only when a lambda_recon_y* weight is set (config.yaml:27-28 ships 0); built in the reference's
+        # position (after the input decoders, before the discriminator, model.py:2955-2967) so seeds give the same init
+        self.fuse_method = fuse_method
+        if build_output_decoder:
+            if target_model_name != 'U+SA' or fuse_method != 'mean':
+                raise NotImplementedError("output decoder: only target_model_name 'U+SA' with fuse_method 'mean' (config.yaml:64, 66)")
+            self.output_decoder = GANShortGeneratorWithSpatialAttention(s_num_ch, out_num_ch, 64, target_output_act)
         if is_discrim_s:
             self.discrim_s = Discriminator(s_num_ch, 16, (H, W), is_patch_gan)                    # :2966-2967
         self.to(device)
@@ -538,6 +631,56 @@ class MultimodalModel(nn.Module):
                     continue
                 out.append(self.input_decoder_list[i](si_list[i], mids[(i, j)], self._type(j, B)))
         return out
+
+    # ---- model.py:3230-3258.  QUIRK: `si_cat[mask == 1]` flattens (batch, modality) into ONE axis, so "fusion" is a
+    # mean over a singleton axis: every present (b, m) anatomy map becomes its own sample and the output has sum(mask)
+    # rows (b-major).  Only the per-modality caller (mask = ones(B, 1)) gives B rows; main_missing.py:203 with M > 1
+    # cannot run in the reference either.  The row selection uses the host mask (no device sync).
+    def reconstruct_output_si_fused(self, si_list, mask, mask_host=None):
+        mh = _host_mask(mask, mask_host)
+        si_cat = torch.stack(si_list, 1)                                  # (B, K, C, H, W)
+        rows = np.flatnonzero(mh.reshape(-1) == 1)
+        flat = si_cat.reshape((-1,) + tuple(si_cat.shape[2:]))
+        if len(rows) != flat.shape[0]:
+            flat = flat[torch.from_numpy(rows).to(flat.device)]
+        return self.output_decoder(flat.contiguous(memory_format=torch.channels_last))[0]
+
+    def reconstruct_output_si(self, si_list):
+        B = si_list[0].shape[0]
+        ones = np.ones((B, 1), dtype=np.float32)
+        return [self.reconstruct_output_si_fused([si_list[i]], None, ones) for i in range(self.modality_num)]
+
+    def compute_recon_loss_y_list(self, gt, y_list, mask, p=2, mask_host=None):                 # :3268-3278
+        mh = _host_mask(mask, mask_host)
+        errs, rows = [], []
+        for i in range(len(y_list)):
+            if mh[:, i].sum() == 0:
+                continue
+            errs.append(self.compute_recon_loss(gt, y_list[i], p))
+            rows.append(mh[:, i] / float(mh[:, i].sum()))
+        if not errs:
+            return torch.zeros((), device=self.device)
+        return (torch.stack(errs) * self._weights(rows)).sum() / len(errs)
+
+    def compute_segmentation_loss_y(self, gt, y, weight=(1., 5., 5., 5.)):                      # :3287-3297
+        w = torch.tensor(weight, dtype=torch.float32, device=y.device)
+        loss_seg = F.cross_entropy(y, gt.squeeze(1).long(), weight=w)
+        y_act = F.softmax(y, dim=1)                                       # F.softmax(y) on a 4-D tensor: dim 1
+        dice = 0
+        for i in range(1, 4):
+            gt_i = (gt[:, 0] == i).float()
+            dice = dice + 1 - 2 * torch.sum(y_act[:, i] * gt_i) / (torch.sum(y_act[:, i] ** 2 + gt_i ** 2) + 1e-6)
+        return loss_seg + dice / 3
+
+    def compute_segmentation_loss_y_list(self, gt, y_list, mask, mask_host=None):               # :3299-3313
+        mh = _host_mask(mask, mask_host)
+        loss, idx = torch.zeros((), device=self.device), 0
+        for i in range(len(y_list)):
+            if mh[:, i].sum() == 0:
+                continue
+            idx += 1
+            loss = loss + self.compute_segmentation_loss_y(gt, y_list[i])
+        return loss if idx == 0 else loss / idx
 
     # ---------------------------------------------------------------- losses
     # The reference branches on `mask[:, i].sum() == 0` on the device (a host sync per branch,

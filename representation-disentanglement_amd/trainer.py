@@ -71,7 +71,8 @@ def build_model(config):
         shared_inp_dec=config['shared_inp_dec'], device=config['device'],
         input_output_act=config['input_output_act'], target_output_act=config['target_output_act'],
         target_model_name=config['target_model_name'], fuse_method=config['fuse_method'], others=config['others'],
-        is_patch_gan=config.get('is_patch_gan', False))
+        is_patch_gan=config.get('is_patch_gan', False),
+        build_output_decoder=config['lambda_recon_y'] > 0 or config['lambda_recon_y_fused'] > 0)
 
 
 # --------------------------------------------------------------------------- synthetic BraTS-shaped data
@@ -284,7 +285,7 @@ LOSS_KEYS = ('recon_y', 'recon_y_fused', 'recon_x', 'recon_x_mix', 'kl', 'latent
              'adv_s', 'adv_s_d', 'all')
 
 
-def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='train'):
+def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='train', targets=None):
     """main_missing.py:165-251 (phase='train') / :389-505 (phase='test') for the loss set with non-zero
     weight in config.yaml."""
     M = len(config['contrast_list'])
@@ -299,8 +300,22 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
     xi_fake_mix_list = model.reconstruct_input_si_zj(si_list, zi_list)                           # :178
     parts = {k: zero for k in LOSS_KEYS}
     loss = zero
-    if config['lambda_recon_y'] > 0 or config['lambda_recon_y_fused'] > 0 or config['lambda_kl'] > 0:
-        raise NotImplementedError('recon_y / kl losses are outside the hot path (lambda = 0 in config.yaml)')
+    if config['lambda_kl'] > 0:
+        raise NotImplementedError('the kl loss is outside the hot path (lambda_kl = 0 in config.yaml)')
+    if config['lambda_recon_y_fused'] > 0:
+        # main_missing.py:201-208: reconstruct_output_si_fused returns sum(mask) rows (boolean-index quirk), so the
+        # loss against B targets raises in the reference for every M > 1
+        raise NotImplementedError('lambda_recon_y_fused: the reference path raises a shape error for M > 1')
+    y_list = None
+    if config['lambda_recon_y'] > 0:                                                             # :187-198
+        if targets is None:
+            raise ValueError('lambda_recon_y > 0 needs targets')
+        y_list = model.reconstruct_output_si(si_list)
+        if config['dataset_name'] == 'BraTS':
+            parts['recon_y'] = model.compute_segmentation_loss_y_list(targets, y_list, mask, mask_host)
+        else:
+            parts['recon_y'] = model.compute_recon_loss_y_list(targets, y_list, mask, p, mask_host)
+        loss = loss + config['lambda_recon_y'] * parts['recon_y']
     if config['lambda_recon_x'] > 0:
         parts['recon_x'] = model.compute_recon_loss_x_list(inputs_list, xi_fake_list, mask, p, mask_host)
         loss = loss + config['lambda_recon_x'] * parts['recon_x']
@@ -323,7 +338,7 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
         loss = loss + config['lambda_adv_s'] * parts['adv_s']
     parts['all'] = loss
     aux = dict(si_list=si_list, zi_list=zi_list, mu_list=mu_list, lv_list=lv_list, xi_fake_list=xi_fake_list,
-               xi_fake_mix_list=xi_fake_mix_list)
+               xi_fake_mix_list=xi_fake_mix_list, y_list=y_list)
     return loss, parts, aux
 
 
@@ -349,13 +364,13 @@ class TrainStep:
         self.iter = 0
         self._stash = None
 
-    def __call__(self, inputs, mask, mask_img, mask_host=None):
+    def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None):
         cfg, model = self.config, self.model
         adv = cfg['lambda_adv_s'] > 0
         if mask_host is None:
             mask_host = mask.cpu()
         with ops.mix_cache():
-            loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host)
+            loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, targets=targets)
             if self.reducer:
                 self.reducer.begin()
             loss.backward(retain_graph=adv)                                                      # :268-271
@@ -418,7 +433,7 @@ class EvalStep:
         self.model, self.config = model, config
 
     @torch.no_grad()
-    def __call__(self, inputs, mask, mask_img, mask_host=None):
+    def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None):
         model, cfg = self.model, self.config
         if mask_host is None:
             mask_host = mask.cpu()
@@ -426,7 +441,7 @@ class EvalStep:
         model.eval()
         try:
             with ops.mix_cache():
-                loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, phase='test')
+                loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, phase='test', targets=targets)
                 M = len(cfg['contrast_list'])
                 c = 2 * cfg['block_size'] + 1
                 rows, k = [], 0

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_model as R                                   # noqa: E402
-from oracle.gen_golden import make_inputs, reinit_discriminator, seeded   # noqa: E402
+from oracle.gen_golden import make_inputs, make_seg_targets, reinit_discriminator, seeded   # noqa: E402
 
 
 @pytest.fixture(scope='module')
@@ -165,6 +165,57 @@ def test_train_step_golden(mrdis, golden_dir, tag):
         # gradient is rounding noise) to land on the other side, on top of the relative tolerance
         flips = 2 * cfg['lr'] * np.ceil(1e-3 * t.numel())
         assert abs(got - v) <= 2e-4 * max(1.0, abs(v)) + flips, ('after step', k, got, v)
+
+
+def test_train_step_golden_with_output_decoder(mrdis, golden_dir):
+    """lambda_recon_y = 1 (SURVEY 8(f).4): the 'U+SA' output decoder + BraTS segmentation loss join the step;
+    vectors from the real reference (oracle/gen_golden.py recon_y)."""
+    meta = json.load(open(os.path.join(golden_dir, 'step_b2m2_y.json')))
+    arrs = np.load(os.path.join(golden_dir, 'step_b2m2_y.npz'))
+    B, M = meta['B'], meta['M']
+    cfg = dict(mrdis.DEFAULT_CONFIG)
+    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=160, input_width=192, batch_size=16,
+               lambda_recon_y=meta['lambdas']['recon_y'], out_num_ch=4)
+    cfg = mrdis.derive_config(cfg, DEV)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    assert set(meta['wsum_before']) <= set(model.state_dict())
+    for k, v in meta['wsum_before'].items():
+        got = float(model.state_dict()[k].double().sum())
+        assert abs(got - v) <= 1e-6 * max(1.0, abs(v)), ('init', k)
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10, drop=False)
+    targets = make_seg_targets(B, 160, 192, seed=13)
+    step = mrdis.TrainStep(model, cfg)
+    torch.manual_seed(11); np.random.seed(11)
+    names = {id(p): n for n, p in model.named_parameters()}
+    with mrdis.ops.mix_cache():
+        loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask,
+                                                targets=targets.to(DEV))
+        loss.backward()
+    assert abs(float(loss) - meta['loss']) <= 1e-3 * abs(meta['loss'])
+    for k, v in meta['parts'].items():
+        assert abs(float(parts[k]) - v) <= 1e-3 * abs(v) + 1e-6, (k, float(parts[k]), v)
+    for i in range(M):
+        close(F.avg_pool2d(aux['y_list'][i], 8), arrs[f'y{i}_pool8'], 2e-3, f'y{i}')
+    gn = {names[id(p)]: float(p.grad.double().norm()) for p in model.parameters() if p.grad is not None}
+    assert set(meta['grad_norms']) == set(gn)
+    assert any(k.startswith('output_decoder.') for k in gn)
+    total = float(np.sqrt(sum(v * v for v in gn.values())))
+    assert abs(total - meta['grad_norm']) <= 1e-3 * meta['grad_norm'], (total, meta['grad_norm'])
+    for k, v in meta['grad_norms'].items():
+        assert abs(gn[k] - v) <= 5e-3 * v + 2e-5 * meta['grad_norm'], (k, gn[k], v)
+    step.optimizer.step(fused_clip=True)
+    for k, v in meta['wsum_after'].items():
+        if meta['grad_norms'].get(k, 1.0) < 1e-5 * meta['grad_norm']:
+            continue
+        t = model.state_dict()[k]
+        got = float(t.double().sum())
+        flips = 2 * cfg['lr'] * np.ceil(1e-3 * t.numel())
+        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)) + flips, ('after step', k, got, v)
+    # the whole step through TrainStep (targets plumbed) runs and moves the decoder
+    before = model.output_decoder.down_1[0].weight.detach().clone()
+    step(cl(inputs), mask.to(DEV), mask_img.to(DEV), mask, targets=targets.to(DEV))
+    assert not torch.equal(before, model.output_decoder.down_1[0].weight)
 
 
 @pytest.mark.parametrize('B,M,H,W,drop,adv', [(3, 3, 64, 64, False, False), (2, 2, 96, 128, True, False), (2, 3, 64, 96, False, True)])

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_model as R
-from oracle.gen_golden import make_inputs, reinit_discriminator, seeded
+from oracle.gen_golden import make_inputs, make_seg_targets, reinit_discriminator, seeded
 
 TOL = dict(rtol=2e-5, atol=2e-6)
 
@@ -98,8 +98,9 @@ def _run_step(golden_dir, tag):
     meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
     arrs = np.load(os.path.join(golden_dir, f'step_{tag}.npz'))
     B, M, adv = meta['B'], meta['M'], meta['adv']
+    ry = meta['lambdas'].get('recon_y', 0.0) > 0
     torch.manual_seed(10); np.random.seed(10)
-    model = R.RefMultimodalModel((160, 192), M, is_discrim_s=adv).train()
+    model = R.RefMultimodalModel((160, 192), M, is_discrim_s=adv, out_num_ch=4 if ry else 0).train()
     if adv:
         reinit_discriminator(model.discrim_s)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
@@ -108,7 +109,8 @@ def _run_step(golden_dir, tag):
     w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
     for k, v in meta['wsum_before'].items():       # identical init under the seed
         assert abs(w0[k] - v) <= 1e-9 * max(1, abs(v)), k
-    loss, parts, aux = R.ref_forward_losses(model, inputs, mask, mask_img, meta['lambdas'])
+    targets = make_seg_targets(B, 160, 192, seed=13) if ry else None
+    loss, parts, aux = R.ref_forward_losses(model, inputs, mask, mask_img, meta['lambdas'], targets=targets)
     loss.backward(retain_graph=adv)
     gn = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None}
     gnorm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))
@@ -116,7 +118,7 @@ def _run_step(golden_dir, tag):
     return meta, arrs, model, loss, parts, aux, gn, gnorm
 
 
-@pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
+@pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv', 'b2m2_y'])
 def test_full_step(golden_dir, tag):
     meta, arrs, model, loss, parts, aux, gn, gnorm = _run_step(golden_dir, tag)
     assert abs(float(loss) - meta['loss']) <= 2e-5 * abs(meta['loss'])
@@ -129,7 +131,11 @@ def test_full_step(golden_dir, tag):
     np.testing.assert_allclose(F.avg_pool2d(aux['xmix'][0].detach(), 8).numpy(), arrs['xmix0_pool8'], rtol=1e-4, atol=1e-5)
     assert abs(gnorm - meta['grad_norm']) <= 1e-3 * meta['grad_norm']
     # same set of parameters receives a gradient, same per-tensor norms
-    hot = {k: v for k, v in meta['grad_norms'].items() if not k.startswith('output_decoder')}
+    with_y = meta['lambdas'].get('recon_y', 0.0) > 0                  # output decoder ('U+SA') on the path: its tensors are checked too
+    if with_y:
+        np.testing.assert_allclose(F.avg_pool2d(aux['y_list'][0].detach(), 8).numpy(), arrs['y0_pool8'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(F.avg_pool2d(aux['y_list'][-1].detach(), 8).numpy(), arrs['y1_pool8'], rtol=1e-4, atol=1e-5)
+    hot = {k: v for k, v in meta['grad_norms'].items() if with_y or not k.startswith('output_decoder')}
     assert set(hot) == set(gn)
     for k, v in hot.items():
         assert abs(gn[k] - v) <= 2e-3 * v + 1e-6 * meta['grad_norm'], (k, gn[k], v)
