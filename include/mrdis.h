@@ -210,6 +210,44 @@ int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float*
                             float weight_decay, int step_count, const float* norm_finite,
                             float max_norm, float grad_scale, void* stream);
 
+/* ==== 3-D path: the Conv3d / GroupNorm / Upsample layers of BasicBlock, UNet3D, VAEBranch and
+ * NVNet3D (src/model.py:1856-2060).  Tensors are NDHWC fp32 views (torch.channels_last_3d); 1x1x1 convolutions go
+ * through mrdis_conv2d_* on the (N*D, H, W) view. -------------------------------------------------------------- */
+
+/* nn.Conv3d(k = 3, padding = 1, stride in {1,2}) (model.py:1861, 1864, 1969-1984): x (N,D,H,W,Ci) ld=ldx ->
+ * y (N,Do,Ho,Wo,Co) ld=ldy.  w_tck [27][Ci][Co] with tap = (kd*3 + kh)*3 + kw (mrdis_mix_experts_fwd, E = 1, T = 27).
+ * residual (same extents as y, ld=ldres) or NULL: y = conv + bias + residual -- BasicBlock's `x + residul`
+ * (model.py:1873) in the epilogue.                                                                             */
+int mrdis_conv3d_fwd(const float* x, int ldx, const float* w_tck, const float* bias, const float* residual, int ldres,
+                     float* y, int ldy, int N, int D, int H, int W, int Ci, int Co,
+                     int k, int stride, int pad, void* stream);
+/* data gradient: dy (N,Do,Ho,Wo,Co) -> dx (N,D,H,W,Ci); w_tkc [27][Co][Ci] */
+int mrdis_conv3d_bwd_data(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx,
+                          int N, int D, int H, int W, int Ci, int Co, int k, int stride, int pad, void* stream);
+/* weight (+ bias) gradient: split-K slabs in `workspace`, ordered reduction; dw_tck [27][Ci][Co], dbias (Co) or NULL */
+size_t mrdis_conv3d_bwd_weight_workspace(int N, int D, int H, int W, int Ci, int Co, int k, int stride, int pad);
+int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias,
+                            void* workspace, size_t workspace_bytes,
+                            int N, int D, int H, int W, int Ci, int Co, int k, int stride, int pad, void* stream);
+
+/* nn.GroupNorm(G, C) followed by nn.ReLU (model.py:1859-1860, 1862-1863, 1889-1890) on (N, P = D*H*W, C) rows:
+ * y = relu?((x - mean[n,g]) * rstd[n,g] * gamma + beta); biased variance, eps inside the sqrt.  save_mean /
+ * save_rstd: (N, G).  The backward takes dy w.r.t. the ReLU output and recomputes the ReLU mask from x.          */
+size_t mrdis_groupnorm_workspace(int N, long long P, int C, int G);
+int mrdis_groupnorm_relu_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                             float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                             int N, long long P, int C, int G, float eps, int relu, void* stream);
+int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_rstd, float* dx, int lddx,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                             int N, long long P, int C, int G, int relu, void* stream);
+
+/* nn.Upsample(scale_factor=2) (nearest, model.py:1995-2003, 1898-1911) fused with the skip addition of
+ * UNet3D.forward (model.py:2029-2040): y (N,2D,2H,2W,C) = x[d/2,h/2,w/2] + skip (skip may be NULL); contiguous NDHWC.
+ * Backward: dx = sum of the 8 children of dy (d skip = dy needs no kernel).                                       */
+int mrdis_upsample2x_add_fwd(const float* x, const float* skip, float* y, int N, int D, int H, int W, int C, void* stream);
+int mrdis_upsample2x_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,6 +352,37 @@ def gen_data():
     print('data_b4:', bi + 1, 'batches; dropped contrasts per batch', [int((out[f'mask_{k}'] == 0).sum()) for k in range(bi + 1)])
 
 
+NV3D_CASES = {'a': dict(B=2, shape=(32, 16, 48), c=8), 'b': dict(B=2, shape=(16, 16, 16), c=16)}
+
+
+def gen_nv3d(ref, tag):
+    """NVNet3D (reference model.py:2050-2060) forward + gradients of oracle.ref_model3d.nvnet_loss; p = 0 (dropout's
+    random mask has no cross-device counterpart), eps from the CPU generator seeded with 11."""
+    sys.path.insert(0, ROOT)
+    from oracle.ref_model3d import nvnet_loss, make_inputs3d
+    cfg = NV3D_CASES[tag]
+    torch.manual_seed(10); np.random.seed(10)
+    model = ref.NVNet3D(cfg['shape'], in_channels=4, out_channels=3, init_channels=cfg['c'], p=0.0).train()
+    w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items()}
+    x, t = make_inputs3d(cfg['B'], 4, cfg['shape'], seed=10)
+    torch.manual_seed(11); np.random.seed(11)
+    uout, vout, mu, logvar = model(x)
+    loss, parts = nvnet_loss(uout, vout, mu, logvar, x, t)
+    loss.backward()
+    gn = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None}
+    gnorm = float(np.sqrt(sum(v * v for v in gn.values())))
+    meta = dict(B=cfg['B'], shape=list(cfg['shape']), init_channels=cfg['c'], loss=float(loss),
+                parts={k: float(v) for k, v in parts.items()}, grad_norm=gnorm, grad_norms=gn, wsum_before=w0,
+                torch=torch.__version__)
+    with open(os.path.join(OUT, f'nvnet3d_{tag}.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, f'nvnet3d_{tag}.npz'), mu=mu.detach().numpy(), logvar=logvar.detach().numpy(),
+                        uout_pool4=F.avg_pool3d(uout.detach(), 4).numpy(), vout_pool4=F.avg_pool3d(vout.detach(), 4).numpy(),
+                        uout_corner=uout.detach()[:, :, :4, :4, :4].numpy(),
+                        g_conv1a=model.unet.conv1a.weight.grad.numpy(), g_ds2=model.unet.ds2.weight.grad[:8, :8].numpy())
+    print(f'nvnet3d_{tag}: loss={float(loss):.7f} gnorm={gnorm:.5f}', {k: round(float(v), 7) for k, v in parts.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -371,6 +402,9 @@ def main():
         gen_eval(ref, 'b2m4', 2, 4)
     if not only or 'data' in only:
         gen_data()
+    if not only or 'nv3d' in only:
+        gen_nv3d(ref, 'a')
+        gen_nv3d(ref, 'b')
 
 
 if __name__ == '__main__':

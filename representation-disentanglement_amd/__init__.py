@@ -13,7 +13,7 @@ binding), ops.py (autograd pairing + torch.ops.mrdis.*), model.py (mirror of the
 reference's module interface), trainer.py (train step, flat-arena Adam, gradient
 all-reduce).  No CPU fallback exists for the hot path.
 """
-from . import hip, ops, model, trainer                        # noqa: F401
+from . import hip, ops, model, model3d, trainer               # noqa: F401
 from .hip import MrdisError, MrdisLibraryError, LIB_PATH      # noqa: F401
 from .model import (CondConv2d, Conv2d, HipConv2d, BatchNorm2d, Conv_BN_Act_New,          # noqa: F401
                     Act_Deconv_BN_Concat_New, AnatomyEncoderEncNew, AnatomyEncoderDecNew,
@@ -23,6 +23,7 @@ from .trainer import (TrainStep, EvalStep, ArenaAdam, GradAllReduce, DEFAULT_CON
                       derive_config, build_model, synthetic_batch, fit_to_model, forward_losses,
                       save_checkpoint, load_checkpoint_model, LOSS_KEYS)
 
+from .model3d import BasicBlock, VAEBranch, UNet3D, NVNet3D, HipConv3d, nvnet_loss   # noqa: F401
 from .data import VolumeStore, SliceDataset, BatchLoader, load_idx_list   # noqa: F401
 
 __version__ = '0.1.0'

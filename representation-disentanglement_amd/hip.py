@@ -65,6 +65,15 @@ _SIGS = {
     'mrdis_sumsq_workspace': (_Z, []),
     'mrdis_sumsq_finite': (_I, [_P, _L, _P, _P, _Z, _P]),
     'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+    'mrdis_conv3d_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I] + [_I] * 9 + [_P]),
+    'mrdis_conv3d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
+    'mrdis_conv3d_bwd_weight_workspace': (_Z, [_I] * 9),
+    'mrdis_conv3d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 9 + [_P]),
+    'mrdis_groupnorm_workspace': (_Z, [_I, _L, _I, _I]),
+    'mrdis_groupnorm_relu_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _I, _F, _I, _P]),
+    'mrdis_groupnorm_relu_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _I, _I, _P]),
+    'mrdis_upsample2x_add_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mrdis_upsample2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -483,3 +492,113 @@ def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, ste
     lib = load()
     _chk(lib.mrdis_adam_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay,
                                      step, _ptr(norm_finite), max_norm, grad_scale, _stream()), 'adam_amsgrad_step')
+
+
+# ================================================================ 3-D path (NDHWC, torch.channels_last_3d)
+def ndhwc(t):
+    """(tensor, ld) of a logical (N,C,D,H,W) fp32 tensor stored NDHWC (channels_last_3d); copies if it is not."""
+    assert t.dim() == 5 and t.dtype == torch.float32, (t.shape, t.dtype)
+    N, C, D, H, W = t.shape
+    want = (D * H * W * C, 1, H * W * C, W * C, C)
+    if any(t.shape[i] > 1 and t.stride()[i] != want[i] for i in range(5)):
+        t = t.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return t, C
+
+
+def empty_ndhwc(N, C, D, H, W, device):
+    return torch.empty((N, D, H, W, C), dtype=torch.float32, device=device).permute(0, 4, 1, 2, 3)
+
+
+def _out3(D, H, W, k, stride, pad):
+    return tuple((v + 2 * pad - k) // stride + 1 for v in (D, H, W))
+
+
+def conv3d_fwd(x, w_tck, bias, k, stride, pad, residual=None):
+    x, ldx = ndhwc(x)
+    N, Ci, D, H, W = x.shape
+    Co = w_tck.shape[2]
+    Do, Ho, Wo = _out3(D, H, W, k, stride, pad)
+    y = empty_ndhwc(N, Co, Do, Ho, Wo, x.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = ndhwc(residual)
+        assert tuple(residual.shape) == tuple(y.shape)
+    _chk(load().mrdis_conv3d_fwd(x.data_ptr(), ldx, w_tck.data_ptr(), _ptr(bias), _ptr(residual), ldr, y.data_ptr(), Co,
+                                 N, D, H, W, Ci, Co, k, stride, pad, _stream()), 'conv3d_fwd')
+    return y
+
+
+def conv3d_bwd_data(dy, w_tkc, in_shape, k, stride, pad):
+    dy, lddy = ndhwc(dy)
+    N, Ci, D, H, W = in_shape
+    Co = dy.shape[1]
+    dx = empty_ndhwc(N, Ci, D, H, W, dy.device)
+    _chk(load().mrdis_conv3d_bwd_data(dy.data_ptr(), lddy, w_tkc.data_ptr(), dx.data_ptr(), Ci,
+                                      N, D, H, W, Ci, Co, k, stride, pad, _stream()), 'conv3d_bwd_data')
+    return dx
+
+
+def conv3d_bwd_weight(x, dy, k, stride, pad, want_bias):
+    x, ldx = ndhwc(x)
+    dy, lddy = ndhwc(dy)
+    N, Ci, D, H, W = x.shape
+    Co = dy.shape[1]
+    lib = load()
+    need = lib.mrdis_conv3d_bwd_weight_workspace(N, D, H, W, Ci, Co, k, stride, pad)
+    if need == 0:
+        raise MrdisError('conv3d_bwd_weight: unsupported geometry')
+    ws = _ws(need, x.device)
+    dw = torch.empty((k * k * k, Ci, Co), dtype=torch.float32, device=x.device)
+    db = torch.empty((Co,), dtype=torch.float32, device=x.device) if want_bias else None
+    _chk(lib.mrdis_conv3d_bwd_weight(x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(),
+                                     N, D, H, W, Ci, Co, k, stride, pad, _stream()), 'conv3d_bwd_weight')
+    return dw, db
+
+
+def groupnorm_relu_fwd(x, gamma, beta, G, eps, relu):
+    x, ld = ndhwc(x)
+    N, C, D, H, W = x.shape
+    P = D * H * W
+    y = empty_ndhwc(N, C, D, H, W, x.device)
+    mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib = load()
+    ws = _ws(lib.mrdis_groupnorm_workspace(N, P, C, G), x.device)
+    _chk(lib.mrdis_groupnorm_relu_fwd(x.data_ptr(), ld, y.data_ptr(), C, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), ws.data_ptr(), ws.numel(), N, P, C, G, eps, int(relu), _stream()), 'groupnorm_relu_fwd')
+    return y, mean, rstd
+
+
+def groupnorm_relu_bwd(dy, x, gamma, beta, mean, rstd, G, relu):
+    x, ld = ndhwc(x)
+    dy, lddy = ndhwc(dy)
+    N, C, D, H, W = x.shape
+    P = D * H * W
+    dx = empty_ndhwc(N, C, D, H, W, x.device)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    lib = load()
+    ws = _ws(lib.mrdis_groupnorm_workspace(N, P, C, G), x.device)
+    _chk(lib.mrdis_groupnorm_relu_bwd(dy.data_ptr(), lddy, x.data_ptr(), ld, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      N, P, C, G, int(relu), _stream()), 'groupnorm_relu_bwd')
+    return dx, dgamma, dbeta
+
+
+def upsample2x_add_fwd(x, skip):
+    x, _ = ndhwc(x)
+    N, C, D, H, W = x.shape
+    if skip is not None:
+        skip, _ = ndhwc(skip)
+        assert tuple(skip.shape) == (N, C, 2 * D, 2 * H, 2 * W)
+    y = empty_ndhwc(N, C, 2 * D, 2 * H, 2 * W, x.device)
+    _chk(load().mrdis_upsample2x_add_fwd(x.data_ptr(), _ptr(skip), y.data_ptr(), N, D, H, W, C, _stream()), 'upsample2x_add_fwd')
+    return y
+
+
+def upsample2x_bwd(dy):
+    dy, _ = ndhwc(dy)
+    N, C, D2, H2, W2 = dy.shape
+    dx = empty_ndhwc(N, C, D2 // 2, H2 // 2, W2 // 2, dy.device)
+    _chk(load().mrdis_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), N, D2 // 2, H2 // 2, W2 // 2, C, _stream()), 'upsample2x_bwd')
+    return dx

@@ -188,3 +188,30 @@ def test_reconstruction_metrics_definitions():
         assert abs(m['psnr'][i] - 10 * np.log10(Rg ** 2 / ((a - b) ** 2).mean())) < 1e-9
     same = R.ref_reconstruction_metrics(t, t + 5.0)          # min-shift invariance: identical after the shift
     assert all(abs(v - 1) < 1e-6 for v in same['ssim'])
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_nvnet3d_oracle_vs_reference_golden(golden_dir, tag):
+    """oracle/ref_model3d.py against vectors of the real reference NVNet3D (model.py:2050-2060), SURVEY 8(f).2."""
+    from oracle import ref_model3d as R3
+    meta = json.load(open(os.path.join(golden_dir, f'nvnet3d_{tag}.json')))
+    arrs = np.load(os.path.join(golden_dir, f'nvnet3d_{tag}.npz'))
+    shape = tuple(meta['shape'])
+    torch.manual_seed(10); np.random.seed(10)
+    model = R3.RefNVNet3D(shape, 4, 3, meta['init_channels'], p=0.0).train()
+    assert set(model.state_dict()) == set(meta['wsum_before'])
+    for k, v in meta['wsum_before'].items():
+        assert abs(float(model.state_dict()[k].double().sum()) - v) <= 1e-9 * max(1.0, abs(v)), k
+    x, t = R3.make_inputs3d(meta['B'], 4, shape, seed=10)
+    torch.manual_seed(11); np.random.seed(11)
+    uout, vout, mu, logvar = model(x)
+    loss, parts = R3.nvnet_loss(uout, vout, mu, logvar, x, t)
+    loss.backward()
+    assert abs(float(loss) - meta['loss']) <= 2e-5 * abs(meta['loss'])
+    np.testing.assert_allclose(mu.detach().numpy(), arrs['mu'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(F.avg_pool3d(uout.detach(), 4).numpy(), arrs['uout_pool4'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(F.avg_pool3d(vout.detach(), 4).numpy(), arrs['vout_pool4'], rtol=1e-4, atol=1e-6)
+    gn = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None}
+    assert set(gn) == set(meta['grad_norms'])
+    for k, v in meta['grad_norms'].items():
+        assert abs(gn[k] - v) <= 1e-3 * v + 1e-6 * meta['grad_norm'], k
