@@ -321,6 +321,165 @@ static int launch_tapconv3d_t(const Conv3dParams& p, size_t lds, int nblk, hipSt
     return MRDIS_OK;
 }
 
+// ---------------------------------------------------------------- narrow-output variant (Cout <= 16, Cin <= 32)
+// The full-resolution levels of the 3-D nets have 16 channels (BasicBlock 16 -> 16 six times per step at 128^3, conv1a
+// 4 -> 16, vconv1 32 -> 16, the data gradient of ds1 32 -> 16): a 32-wide cout tile is half padding there.  This variant
+// uses v_mfma_f32_16x16x4_f32 (A = filter [16 couts x 4 ch], B = pixels [4 ch x 16 positions]) and is PERSISTENT: the
+// whole [27][Cin][16] filter is staged in LDS once per workgroup, then the workgroup walks boxes of 128 positions with a
+// grid stride -- all input channels of the halo'd box in one LDS tile -- while the global loads of the next box are in
+// flight in registers.  Everything a thread needs per box (which pixels it stages, where its positions sit in the tile)
+// is box-invariant and computed once; a box costs an origin add and three range checks per staged item.
+template <int KC>
+__global__ __launch_bounds__(256) void conv3d16_kernel(const Conv3dParams p, int nboxes) {
+    constexpr int S = KC + 1, BN = 16, QX = KC / 4;
+    constexpr int XR = (KC == 32) ? 12 : 6;            // float4 items per thread; host: npix_in * QX <= XR * 256
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* tap_xoff = reinterpret_cast<int*>(smem);    // [32]
+    float* ws = smem + 32;                           // [tap][KC][16]
+    float* xs = ws + p.ntaps * KC * BN;              // [pixel][KC+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int tinHW = p.TinH * p.TinW, npix_in = p.TinD * tinHW;
+
+    if (tid < p.ntaps)
+        tap_xoff[tid] = (((p.dd[tid] - p.dd_min) * p.TinH + (p.dh[tid] - p.dh_min)) * p.TinW + (p.dw[tid] - p.dw_min)) * S;
+    for (int idx = tid; idx < p.ntaps * KC * BN; idx += 256) {
+        const int row = idx >> 4, j = idx & 15;
+        const int t = row / KC, k = row - t * KC;
+        float v = 0.f;
+        if (k < p.Cin && j < p.Cout) v = p.w[((long long)p.widx[t] * p.Cin + k) * p.Cout + j];
+        ws[idx] = v;
+    }
+    // box-invariant roles
+    int bbase[2], pz_[2], ty_[2], tx_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (wave * 2 + i) * 16 + l16;
+        const int thw = p.TH * p.TW;
+        int pz = m / thw; const int rem = m - pz * thw;
+        int ty = rem / p.TW, tx = rem - ty * p.TW;
+        if (pz >= p.TD) { pz = 0; ty = 0; tx = 0; pz_[i] = 1 << 20; } else pz_[i] = pz;      // beyond the box: never stored
+        ty_[i] = ty; tx_[i] = tx;
+        bbase[i] = (((pz * p.is) * p.TinH + ty * p.is) * p.TinW + tx * p.is) * S + kq;
+    }
+    int xl[XR], xc[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 256;
+        xl[it] = -1; xc[it] = 0;
+        if (idx < npix_in * QX) {
+            const int pi = idx / QX, q = idx - pi * QX;
+            const int iz = pi / tinHW;
+            const int rem = pi - iz * tinHW;
+            const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            xl[it] = pi * S + 4 * q;
+            xc[it] = (iz << 20) | (iy << 10) | ix;
+        }
+    }
+    const int qx = (tid % QX) * 4;                     // 256 % QX == 0: the channel quad of every item of this thread
+    const bool q_ok = qx < p.Cin;
+    const int abase = kq * BN + l16;
+    const int co = 4 * kq;
+    const bool vec_out = (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0);
+    const bool vec_res = p.res != nullptr && (p.ldres % 4 == 0) && (((uintptr_t)p.res & 15) == 0);
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < p.Cout) bq[r] = p.bias[co + r];
+    }
+
+    float4 xr[XR];
+    auto load_box = [&](int box) {
+        int tt = box;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA; tt /= p.tilesA;
+        const int tz = tt % p.tilesZ;
+        const int n = tt / p.tilesZ;
+        const int d_org = tz * p.TD * p.is + p.dd_min, h_org = ta * p.TH * p.is + p.dh_min, w_org = tb * p.TW * p.is + p.dw_min;
+        const float* __restrict__ in_n = p.in + (long long)n * p.Din * p.Hin * p.Win * p.ldin + qx;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int d = d_org + (xc[it] >> 20), h = h_org + ((xc[it] >> 10) & 1023), w_ = w_org + (xc[it] & 1023);
+            if (xl[it] >= 0 && q_ok && (unsigned)d < (unsigned)p.Din && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                xr[it] = *reinterpret_cast<const float4*>(in_n + ((long long)(d * p.Hin + h) * p.Win + w_) * p.ldin);
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it)
+            if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+    };
+
+    int box = blockIdx.x;
+    if (box < nboxes) load_box(box);
+    store_box();
+    __syncthreads();
+    for (; box < nboxes; box += gridDim.x) {
+        const int nxt = box + gridDim.x;
+        if (nxt < nboxes) load_box(nxt);
+        f32x4 acc[2];
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = tap_xoff[t];
+            const float* wt = ws + t * (KC * BN) + abase;
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                const float av = wt[4 * q * BN];
+                const float b0v = xs[bbase[0] + toff + 4 * q], b1v = xs[bbase[1] + toff + 4 * q];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v, acc[1], 0, 0, 0);
+            }
+        }
+        // epilogue: D col = lane & 15 (position), rows 4 * (lane >> 4) + r (couts)
+        {
+            int tt = box;
+            const int tb = tt % p.tilesB; tt /= p.tilesB;
+            const int ta = tt % p.tilesA; tt /= p.tilesA;
+            const int tz = tt % p.tilesZ;
+            const int n = tt / p.tilesZ;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int z = tz * p.TD + pz_[i], a = ta * p.TH + ty_[i], b = tb * p.TW + tx_[i];
+                if (z >= p.Z || a >= p.A || b >= p.B || co >= p.Cout) continue;
+                const long long po = ((long long)(n * p.Dout + z * p.os + p.od0) * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0;
+                float v[4] = {acc[i][0] + bq[0], acc[i][1] + bq[1], acc[i][2] + bq[2], acc[i][3] + bq[3]};
+                const bool full = co + 3 < p.Cout;
+                if (p.res != nullptr) {
+                    const float* rsd = p.res + po * p.ldres + co;
+                    if (vec_res && full) {
+                        const float4 rq = *reinterpret_cast<const float4*>(rsd);
+                        v[0] += rq.x; v[1] += rq.y; v[2] += rq.z; v[3] += rq.w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (co + r < p.Cout) v[r] += rsd[r];
+                    }
+                }
+                float* dst = p.out + po * p.ldout + co;
+                if (vec_out && full) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co + r < p.Cout) dst[r] = v[r];
+                }
+            }
+        }
+        if (nxt < nboxes) { __syncthreads(); store_box(); __syncthreads(); }
+    }
+}
+
+template <int KC>
+static int launch_conv3d16_t(const Conv3dParams& p, size_t lds, int nblk, int nboxes, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3d16_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d16_kernel<KC>), dim3(nblk), dim3(256), lds, s, p, nboxes);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 static int run_tapconv3d(Conv3dParams p, hipStream_t s) {
     if (p.ntaps < 1 || p.ntaps > T3_TAPS) return MRDIS_EUNSUPPORTED;
     if (p.Z <= 0 || p.A <= 0 || p.B <= 0 || p.N <= 0) return MRDIS_OK;
@@ -349,6 +508,23 @@ static int run_tapconv3d(Conv3dParams p, hipStream_t s) {
     if (const char* e = getenv("MRDIS_DEBUG_BN3")) { const int v = atoi(e); if (v == 32 || v == 64) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
+    if (p.Cout <= 16 && p.Cin <= 32 && p.vec_in && ptiles <= 0x7fffffffLL && !getenv("MRDIS_DEBUG_NO16_3D")) {
+        const int KC16 = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : (p.Cin <= 16 ? 16 : 32));
+        const long long npix = (long long)p.TinD * p.TinH * p.TinW;
+        const size_t lds16 = sizeof(float) * ((size_t)32 + (size_t)p.ntaps * KC16 * 16 + (size_t)npix * (KC16 + 1));
+        const int xr = KC16 == 32 ? 12 : 6;
+        if (npix * (KC16 / 4) <= (long long)xr * 256 && lds16 <= 128 * 1024 && p.TinD < 1024 && p.TinH < 1024 && p.TinW < 1024) {
+            const int per_cu = lds16 <= 52 * 1024 ? 3 : (lds16 <= 80 * 1024 ? 2 : 1);
+            long long nblk = 256LL * per_cu;
+            if (nblk > ptiles) nblk = ptiles;
+            switch (KC16) {
+                case 4: return launch_conv3d16_t<4>(p, lds16, (int)nblk, (int)ptiles, s);
+                case 8: return launch_conv3d16_t<8>(p, lds16, (int)nblk, (int)ptiles, s);
+                case 16: return launch_conv3d16_t<16>(p, lds16, (int)nblk, (int)ptiles, s);
+                default: return launch_conv3d16_t<32>(p, lds16, (int)nblk, (int)ptiles, s);
+            }
+        }
+    }
     int KC = p.Cin <= 4 ? 4 : 8;
     if (const char* e = getenv("MRDIS_DEBUG_KC3")) { const int v = atoi(e); if ((v == 4 || v == 8) && v < KC) KC = v; }
     const size_t LDS_MAX = 80 * 1024;        // two workgroups per CU
@@ -798,10 +974,241 @@ static int plan_wgrad3d(Wgrad3dPlan& pl, int N, int D, int H, int W, int ldx, in
     return MRDIS_OK;
 }
 
+// ---------------------------------------------------------------- narrow weight gradient (Co <= 16, stride 1)
+// With 16 couts a 32x32 MFMA tile is half empty; here the product runs on v_mfma_f32_16x16x4_f32 -- A = 16 rows
+// (tap, ci) x 4 positions, B = 4 positions x 16 couts -- and a wave keeps the accumulators of ALL 27 taps (27 x 4
+// registers for Ci = 16), so one B read (dy) feeds 27 MFMAs and every A read is one ds_read of the halo'd x box.  The
+// waves of a workgroup split the 128 positions of a box; boxes are walked with a grid stride (split-K over workgroups)
+// with the next box's x / dy in flight in registers.  Ci > 16 runs as 16-channel slices (one workgroup column each).
+struct Wgrad3d16Params {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, D, H, W, Ci, ldx, Co, lddy;
+    int TD, TH, TW, TinD, TinH, TinW, tilesZ, tilesA, tilesB, numTiles;
+    int nCi, splits;
+};
+
+template <int CW>
+__global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p) {
+    constexpr int S = CW + 1, TPS = 16 / CW, NST = (T3_TAPS + TPS - 1) / TPS, QX = CW / 4;
+    constexpr int XR = 6;                               // host: npix_in * QX <= 6 * 256
+    constexpr int RS = CW == 16 ? 7 : (CW == 8 ? 5 : 3);   // sub-tiles per reduction round (host sizes the LDS for it)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dys = smem;                                  // [128][16]
+    int* tab_in = reinterpret_cast<int*>(smem + 2048);  // [128] position -> offset of its pixel in the x tile
+    float* xs = smem + 2048 + 128;                      // [pixel][CW+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int cic = blockIdx.x % p.nCi, split = blockIdx.x / p.nCi;
+    const int c_lo = cic * 16;
+    const int tinHW = p.TinH * p.TinW, npix_in = p.TinD * tinHW, thw = p.TH * p.TW;
+
+    // A rows: e = l16 -> (tap slot tl, channel cl)
+    const int tl = l16 / CW, cl = l16 - tl * CW;
+    int loff[NST];
+    unsigned lvalid = 0;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int tap = st * TPS + tl;
+        const bool ok = tap < T3_TAPS && (c_lo + cl) < p.Ci;
+        const int r = tap / 9, s_ = (tap / 3) % 3, q = tap % 3;
+        loff[st] = ok ? ((r * p.TinH + s_) * p.TinW + q) * S + cl : 0;
+        lvalid |= (ok ? 1u : 0u) << st;
+    }
+    if (tid < 128) {
+        const int m = tid;
+        int pz = m / thw; const int rem = m - pz * thw;
+        int ty = rem / p.TW, tx = rem - ty * p.TW;
+        if (pz >= p.TD) { pz = 0; ty = 0; tx = 0; }         // dy row is zero there
+        tab_in[m] = ((pz * p.TinH + ty) * p.TinW + tx) * S;
+    }
+    // staging roles (box-invariant)
+    int xl[XR], xc[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 256;
+        xl[it] = -1; xc[it] = 0;
+        if (idx < npix_in * QX) {
+            const int pi = idx / QX, q = idx - pi * QX;
+            const int iz = pi / tinHW;
+            const int rem = pi - iz * tinHW;
+            const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            xl[it] = pi * S + 4 * q;
+            xc[it] = (iz << 20) | (iy << 10) | ix;
+        }
+    }
+    const int qx = c_lo + (tid % QX) * 4;
+    const bool qx_ok = qx < p.Ci;
+    int yc[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int m = (tid + it * 256) >> 2;
+        const int pz = m / thw; const int rem = m - pz * thw;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        yc[it] = pz < p.TD ? ((pz << 20) | (ty << 10) | tx) : -1;
+    }
+    const int qy = (tid & 3) * 4;
+    const bool qy_ok = qy < p.Co;
+
+    f32x4 acc[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) acc[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    float4 xr[XR], yr[2];
+    auto load_box = [&](int box) {
+        int tt = box;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA; tt /= p.tilesA;
+        const int tz = tt % p.tilesZ;
+        const int n = tt / p.tilesZ;
+        const int z0 = tz * p.TD, a0 = ta * p.TH, b0 = tb * p.TW;
+        const float* __restrict__ xn = p.x + (long long)n * p.D * p.H * p.W * p.ldx + qx;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int d = z0 - 1 + (xc[it] >> 20), h = a0 - 1 + ((xc[it] >> 10) & 1023), w_ = b0 - 1 + (xc[it] & 1023);
+            if (xl[it] >= 0 && qx_ok && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                xr[it] = *reinterpret_cast<const float4*>(xn + ((long long)(d * p.H + h) * p.W + w_) * p.ldx);
+        }
+        const float* __restrict__ dyn = p.dy + (long long)n * p.D * p.H * p.W * p.lddy + qy;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            yr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int z = z0 + (yc[it] >> 20), a = a0 + ((yc[it] >> 10) & 1023), b = b0 + (yc[it] & 1023);
+            if (yc[it] >= 0 && qy_ok && z < p.D && a < p.H && b < p.W)
+                yr[it] = *reinterpret_cast<const float4*>(dyn + ((long long)(z * p.H + a) * p.W + b) * p.lddy);
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it)
+            if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) *reinterpret_cast<float4*>(dys + 4 * (tid + it * 256)) = yr[it];
+    };
+
+    int box = split;
+    if (box < p.numTiles) load_box(box);
+    store_box();
+    __syncthreads();
+    for (; box < p.numTiles; box += p.splits) {
+        const int nxt = box + p.splits;
+        if (nxt < p.numTiles) load_box(nxt);
+#pragma unroll 1
+        for (int g = 0; g < 8; ++g) {
+            const int m = wave * 32 + g * 4 + kq;
+            const float bv = dys[m * 16 + l16];
+            bsum += bv;
+            const float* xa = xs + tab_in[m];
+            float av[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) av[st] = ((lvalid >> st) & 1u) ? xa[loff[st]] : 0.f;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) acc[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv, acc[st], 0, 0, 0);
+        }
+        if (nxt < p.numTiles) { __syncthreads(); store_box(); __syncthreads(); }
+    }
+    // cross-wave reduction through LDS in rounds of RS sub-tiles (fixed order), then slab[split][cic][st][16][16]
+    float* red = smem;                                  // [4 waves][RS][256]
+    float* out = p.slab + ((long long)blockIdx.x * NST) * 256;
+#pragma unroll
+    for (int r0 = 0; r0 < NST; r0 += RS) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            if (r0 + j < NST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * RS + j) * 256 + (4 * kq + r) * 16 + l16] = acc[r0 + j][r];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < RS * 256; i += 256) {
+            const int j = i >> 8;
+            if (r0 + j < NST)
+                out[(r0 + j) * 256 + (i & 255)] = (red[i] + red[RS * 256 + i]) + (red[2 * RS * 256 + i] + red[3 * RS * 256 + i]);
+        }
+    }
+    if (p.bias_slab != nullptr && cic == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        __syncthreads();
+        if (kq == 0) red[wave * 16 + l16] = bsum;
+        __syncthreads();
+        if (tid < 16) p.bias_slab[(long long)split * 16 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+    }
+}
+
+__global__ void wgrad3d16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int CW, int nCi, int nslab,
+                                        const float* __restrict__ bslab, float* __restrict__ dbias) {
+    __shared__ float red[16][65];
+    const int TPS = 16 / CW, NST = (T3_TAPS + TPS - 1) / TPS;
+    const int total = T3_TAPS * Ci * Co;
+    const int nout = total + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int SL = blockDim.y, y = threadIdx.y;
+    float s_ = 0.f;
+    if (i < total) {
+        const int co = i % Co;
+        const int r = i / Co;
+        const int ci = r % Ci, t = r / Ci;
+        const int cic = ci >> 4, cl = ci & 15;
+        const int st = t / TPS, row = (t - st * TPS) * CW + cl;
+        const long long stride = (long long)nCi * NST * 256;
+        const float* src = slab + ((long long)cic * NST + st) * 256 + row * 16 + co + (long long)y * stride;
+        for (int k = y; k < nslab; k += SL, src += (long long)SL * stride) s_ += *src;
+    } else if (i < nout) {
+        const int co = i - total;
+        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * 16 + co];
+    }
+    red[y][threadIdx.x] = s_;
+    __syncthreads();
+    if (y == 0 && i < nout) {
+        float t = 0.f;
+        for (int k = 0; k < SL; ++k) t += red[k][threadIdx.x];
+        if (i < total) dw[i] = t;
+        else dbias[i - total] = t;
+    }
+}
+
+struct Wgrad3d16Plan { Wgrad3d16Params p; int CW; size_t lds; long long slab_floats, bias_floats; bool ok; };
+
+static void plan_wgrad3d16(Wgrad3d16Plan& pl, int N, int D, int H, int W, int ldx, int Ci, int Co, int stride) {
+    pl.ok = false;
+    if (stride != 1 || Co > 16 || Co % 4 != 0 || Ci % 4 != 0 || (Ci > 16 && Ci % 16 != 0) || getenv("MRDIS_DEBUG_NO16_3D")) return;
+    Wgrad3d16Params& p = pl.p;
+    p = Wgrad3d16Params{};
+    p.N = N; p.D = D; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.Co = Co;
+    pl.CW = Ci <= 4 ? 4 : (Ci <= 8 ? 8 : 16);
+    p.nCi = Ci > 16 ? Ci / 16 : 1;
+    const Box3 bx = choose_box(D, H, W);
+    p.TD = bx.TD; p.TH = bx.TH; p.TW = bx.TW;
+    p.TinD = p.TD + 2; p.TinH = p.TH + 2; p.TinW = p.TW + 2;
+    const long long npix = (long long)p.TinD * p.TinH * p.TinW;
+    if (npix * (pl.CW / 4) > 6 * 256 || p.TinD >= 1024 || p.TinH >= 1024 || p.TinW >= 1024) return;
+    p.tilesZ = mrdis_cdiv(D, p.TD); p.tilesA = mrdis_cdiv(H, p.TH); p.tilesB = mrdis_cdiv(W, p.TW);
+    const long long nt = (long long)N * p.tilesZ * p.tilesA * p.tilesB;
+    if (nt > 0x7fffffffLL || (long long)D * H * W >= 0x7fffffffLL) return;
+    p.numTiles = (int)nt;
+    int splits = 512 / p.nCi;
+    if (splits > p.numTiles) splits = p.numTiles;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    const int TPS = 16 / pl.CW, NST = (T3_TAPS + TPS - 1) / TPS, RS = pl.CW == 16 ? 7 : (pl.CW == 8 ? 5 : 3);
+    size_t fl = (size_t)2048 + 128 + (size_t)npix * (pl.CW + 1);
+    if (fl < (size_t)4 * RS * 256) fl = (size_t)4 * RS * 256;
+    pl.lds = sizeof(float) * fl;
+    pl.slab_floats = (long long)splits * p.nCi * NST * 256;
+    pl.bias_floats = (long long)splits * 16;
+    pl.ok = true;
+}
+
 extern "C" size_t mrdis_conv3d_bwd_weight_workspace(int N, int D, int H, int W, int Ci, int Co, int k, int stride, int pad) {
     Wgrad3dPlan pl;
     if (plan_wgrad3d(pl, N, D, H, W, Ci, Ci, Co, k, stride, pad)) return 0;
-    return sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
+    size_t need = sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
+    Wgrad3d16Plan p16;
+    plan_wgrad3d16(p16, N, D, H, W, Ci, Ci, Co, stride);
+    if (p16.ok) { const size_t n16 = sizeof(float) * (size_t)(p16.slab_floats + p16.bias_floats) + 256; if (n16 > need) need = n16; }
+    return need;
 }
 
 template <int J>
@@ -827,6 +1234,29 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
     if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     hipStream_t s = (hipStream_t)stream;
+    {
+        Wgrad3d16Plan p16;
+        plan_wgrad3d16(p16, N, D, H, W, ldx, Ci, Co, stride);
+        const bool al = (ldx % 4 == 0) && (lddy % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+        if (p16.ok && al && workspace_bytes >= sizeof(float) * (size_t)(p16.slab_floats + p16.bias_floats)) {
+            Wgrad3d16Params& q = p16.p;
+            q.x = x; q.dy = dy; q.lddy = lddy;
+            q.slab = reinterpret_cast<float*>(workspace);
+            q.bias_slab = dbias ? q.slab + p16.slab_floats : nullptr;
+            const int nblk = q.splits * q.nCi;
+            if (p16.CW == 16) hipLaunchKernelGGL((wgrad3d16_kernel<16>), dim3(nblk), dim3(256), p16.lds, s, q);
+            else if (p16.CW == 8) hipLaunchKernelGGL((wgrad3d16_kernel<8>), dim3(nblk), dim3(256), p16.lds, s, q);
+            else hipLaunchKernelGGL((wgrad3d16_kernel<4>), dim3(nblk), dim3(256), p16.lds, s, q);
+            MRDIS_CHECK_LAUNCH();
+            const long long nout16 = (long long)T3_TAPS * Ci * Co + (dbias ? Co : 0);
+            int SL = 1;
+            while (SL < 16 && SL * 8 <= q.splits) SL <<= 1;
+            hipLaunchKernelGGL(wgrad3d16_reduce_kernel, dim3(mrdis_cdiv(nout16, 64)), dim3(64, SL), 0, s, q.slab, dw_tck, Ci, Co, p16.CW,
+                               q.nCi, q.splits, q.bias_slab, dbias);
+            MRDIS_CHECK_LAUNCH();
+            return MRDIS_OK;
+        }
+    }
     Wgrad3dParams& p = pl.p;
     p.x = x; p.dy = dy; p.lddy = lddy;
     p.slab = reinterpret_cast<float*>(workspace);

@@ -44,6 +44,8 @@ def close(got, want, rtol=1e-3, what=''):
     (1, 32, 32, 5, 7, 9, 1),         # odd extents
     (1, 16, 32, 7, 9, 11, 2),        # odd extents, stride 2
     (2, 32, 32, 1, 1, 1, 1),         # 1^3 volumes (input 16^3 at the bottom)
+    (1, 32, 16, 6, 8, 10, 1),        # vconv1: narrow kernels with two 16-channel input slices
+    (1, 16, 16, 9, 9, 9, 1),         # narrow kernels, ragged boxes, several boxes per workgroup
 ])
 def test_conv3d_fwd_bwd(mrdis, N, Ci, Co, D, H, W, stride):
     x = seeded((N, Ci, D, H, W), 1)
