@@ -984,7 +984,7 @@ struct Wgrad3d16Params {
     const float* x; const float* dy; float* slab; float* bias_slab;
     int N, D, H, W, Ci, ldx, Co, lddy;
     int TD, TH, TW, TinD, TinH, TinW, tilesZ, tilesA, tilesB, numTiles;
-    int nCi, splits;
+    int nCi, nCo, splits;
 };
 
 template <int CW>
@@ -997,8 +997,8 @@ __global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p)
     int* tab_in = reinterpret_cast<int*>(smem + 2048);  // [128] position -> offset of its pixel in the x tile
     float* xs = smem + 2048 + 128;                      // [pixel][CW+1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
-    const int cic = blockIdx.x % p.nCi, split = blockIdx.x / p.nCi;
-    const int c_lo = cic * 16;
+    const int coc = blockIdx.x % p.nCo, cic = (blockIdx.x / p.nCo) % p.nCi, split = blockIdx.x / (p.nCo * p.nCi);
+    const int c_lo = cic * 16, co_lo = coc * 16;
     const int tinHW = p.TinH * p.TinW, npix_in = p.TinD * tinHW, thw = p.TH * p.TW;
 
     // A rows: e = l16 -> (tap slot tl, channel cl)
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p)
         const int ty = rem / p.TW, tx = rem - ty * p.TW;
         yc[it] = pz < p.TD ? ((pz << 20) | (ty << 10) | tx) : -1;
     }
-    const int qy = (tid & 3) * 4;
+    const int qy = co_lo + (tid & 3) * 4;
     const bool qy_ok = qy < p.Co;
 
     f32x4 acc[NST];
@@ -1133,11 +1133,11 @@ __global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p)
         __syncthreads();
         if (kq == 0) red[wave * 16 + l16] = bsum;
         __syncthreads();
-        if (tid < 16) p.bias_slab[(long long)split * 16 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+        if (tid < 16) p.bias_slab[((long long)split * p.nCo + coc) * 16 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
     }
 }
 
-__global__ void wgrad3d16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int CW, int nCi, int nslab,
+__global__ void wgrad3d16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int CW, int nCi, int nCo, int nslab,
                                         const float* __restrict__ bslab, float* __restrict__ dbias) {
     __shared__ float red[16][65];
     const int TPS = 16 / CW, NST = (T3_TAPS + TPS - 1) / TPS;
@@ -1152,12 +1152,12 @@ __global__ void wgrad3d16_reduce_kernel(const float* __restrict__ slab, float* _
         const int ci = r % Ci, t = r / Ci;
         const int cic = ci >> 4, cl = ci & 15;
         const int st = t / TPS, row = (t - st * TPS) * CW + cl;
-        const long long stride = (long long)nCi * NST * 256;
-        const float* src = slab + ((long long)cic * NST + st) * 256 + row * 16 + co + (long long)y * stride;
+        const long long stride = (long long)nCi * nCo * NST * 256;
+        const float* src = slab + ((long long)(cic * nCo + (co >> 4)) * NST + st) * 256 + row * 16 + (co & 15) + (long long)y * stride;
         for (int k = y; k < nslab; k += SL, src += (long long)SL * stride) s_ += *src;
     } else if (i < nout) {
         const int co = i - total;
-        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * 16 + co];
+        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * (nCo * 16) + co];
     }
     red[y][threadIdx.x] = s_;
     __syncthreads();
@@ -1173,12 +1173,13 @@ struct Wgrad3d16Plan { Wgrad3d16Params p; int CW; size_t lds; long long slab_flo
 
 static void plan_wgrad3d16(Wgrad3d16Plan& pl, int N, int D, int H, int W, int ldx, int Ci, int Co, int stride) {
     pl.ok = false;
-    if (stride != 1 || Co > 16 || Co % 4 != 0 || Ci % 4 != 0 || (Ci > 16 && Ci % 16 != 0) || getenv("MRDIS_DEBUG_NO16_3D")) return;
+    if (stride != 1 || Co % 4 != 0 || (Co > 16 && Co % 16 != 0) || Ci % 4 != 0 || (Ci > 16 && Ci % 16 != 0) || getenv("MRDIS_DEBUG_NO16_3D")) return;
     Wgrad3d16Params& p = pl.p;
     p = Wgrad3d16Params{};
     p.N = N; p.D = D; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.Co = Co;
     pl.CW = Ci <= 4 ? 4 : (Ci <= 8 ? 8 : 16);
     p.nCi = Ci > 16 ? Ci / 16 : 1;
+    p.nCo = Co > 16 ? Co / 16 : 1;
     const Box3 bx = choose_box(D, H, W);
     p.TD = bx.TD; p.TH = bx.TH; p.TW = bx.TW;
     p.TinD = p.TD + 2; p.TinH = p.TH + 2; p.TinW = p.TW + 2;
@@ -1188,7 +1189,7 @@ static void plan_wgrad3d16(Wgrad3d16Plan& pl, int N, int D, int H, int W, int ld
     const long long nt = (long long)N * p.tilesZ * p.tilesA * p.tilesB;
     if (nt > 0x7fffffffLL || (long long)D * H * W >= 0x7fffffffLL) return;
     p.numTiles = (int)nt;
-    int splits = 512 / p.nCi;
+    int splits = 512 / (p.nCi * p.nCo);
     if (splits > p.numTiles) splits = p.numTiles;
     if (splits < 1) splits = 1;
     p.splits = splits;
@@ -1196,8 +1197,8 @@ static void plan_wgrad3d16(Wgrad3d16Plan& pl, int N, int D, int H, int W, int ld
     size_t fl = (size_t)2048 + 128 + (size_t)npix * (pl.CW + 1);
     if (fl < (size_t)4 * RS * 256) fl = (size_t)4 * RS * 256;
     pl.lds = sizeof(float) * fl;
-    pl.slab_floats = (long long)splits * p.nCi * NST * 256;
-    pl.bias_floats = (long long)splits * 16;
+    pl.slab_floats = (long long)splits * p.nCi * p.nCo * NST * 256;
+    pl.bias_floats = (long long)splits * p.nCo * 16;
     pl.ok = true;
 }
 
@@ -1243,7 +1244,7 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
             q.x = x; q.dy = dy; q.lddy = lddy;
             q.slab = reinterpret_cast<float*>(workspace);
             q.bias_slab = dbias ? q.slab + p16.slab_floats : nullptr;
-            const int nblk = q.splits * q.nCi;
+            const int nblk = q.splits * q.nCi * q.nCo;
             if (p16.CW == 16) hipLaunchKernelGGL((wgrad3d16_kernel<16>), dim3(nblk), dim3(256), p16.lds, s, q);
             else if (p16.CW == 8) hipLaunchKernelGGL((wgrad3d16_kernel<8>), dim3(nblk), dim3(256), p16.lds, s, q);
             else hipLaunchKernelGGL((wgrad3d16_kernel<4>), dim3(nblk), dim3(256), p16.lds, s, q);
@@ -1252,7 +1253,7 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
             int SL = 1;
             while (SL < 16 && SL * 8 <= q.splits) SL <<= 1;
             hipLaunchKernelGGL(wgrad3d16_reduce_kernel, dim3(mrdis_cdiv(nout16, 64)), dim3(64, SL), 0, s, q.slab, dw_tck, Ci, Co, p16.CW,
-                               q.nCi, q.splits, q.bias_slab, dbias);
+                               q.nCi, q.nCo, q.splits, q.bias_slab, dbias);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }

@@ -65,15 +65,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-// chan[n][c][2] = sum over chunks (double, chunk order)
-__global__ void gn_chan_kernel(const float* __restrict__ partial, double* __restrict__ chan, int N, int nchunk, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
+// chan[n][c][2] = sum over chunks: one wave per (n, c), lane-strided partial sums in double, then a shuffle tree (fixed order)
+__global__ __launch_bounds__(64) void gn_chan_kernel(const float* __restrict__ partial, double* __restrict__ chan, int N, int nchunk, int C) {
+    const int i = blockIdx.x;
     const int n = i / C, c = i - n * C;
     double a = 0.0, b = 0.0;
     const float* src = partial + ((long long)n * nchunk * C + c) * 2;
-    for (int k = 0; k < nchunk; ++k, src += 2 * C) { a += src[0]; b += src[1]; }
-    chan[2 * i] = a; chan[2 * i + 1] = b;
+    for (int k = threadIdx.x; k < nchunk; k += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(src + (long long)k * 2 * C);
+        a += v.x; b += v.y;
+    }
+    a = mrdis_wave_sum_d(a); b = mrdis_wave_sum_d(b);
+    if (threadIdx.x == 0) { chan[2 * i] = a; chan[2 * i + 1] = b; }
 }
 
 __global__ void gn_stat_kernel(const double* __restrict__ chan, float* __restrict__ mean, float* __restrict__ rstd,
@@ -192,7 +195,7 @@ extern "C" int mrdis_groupnorm_relu_fwd(const float* x, int ldx, float* y, int l
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                        partial, P, C, G, 0);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_chan_kernel, dim3(mrdis_cdiv((long long)N * C, 64)), dim3(64), 0, s, partial, chan, N, nchunk, C);
+    hipLaunchKernelGGL(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_stat_kernel, dim3(mrdis_cdiv((long long)N * G, 64)), dim3(64), 0, s, chan, save_mean, save_rstd, N, C, G, P, eps);
     MRDIS_CHECK_LAUNCH();
@@ -220,7 +223,7 @@ extern "C" int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* 
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, dy, lddy, gamma, beta, save_mean, save_rstd,
                        partial, P, C, G, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_chan_kernel, dim3(mrdis_cdiv((long long)N * C, 64)), dim3(64), 0, s, partial, chan, N, nchunk, C);
+    hipLaunchKernelGGL(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(mrdis_cdiv((long long)N * G + C, 64)), dim3(64), 0, s, chan, gamma, coef, dgamma, dbeta, N, C, G, P);
     MRDIS_CHECK_LAUNCH();
