@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float xh = (xv[k] - mu[k]) * rs[k];
-                    const float dz = (relu && !(xh * ga[k] + be[k] > 0.f)) ? 0.f : dv[k];
+                    const float dz = (relu && !(xh * ga[k] + be[k] > 0.f)) ? 0.f : dv[k];       // the forward's expression: same mask
                     a[k] += dz; b[k] += dz * xh;
                 }
             }
@@ -93,26 +93,44 @@ __global__ void gn_stat_kernel(const double* __restrict__ chan, float* __restric
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// y = relu?((x - mean) * rstd * gamma + beta) (the centred form: x * sc + sh cancels badly when |mean| >> std).  grid (row
+// blocks, N): a thread keeps its channel quad, so the per-channel constants live in registers and a block streams rows
+// with four 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       long long P, int C, int G, int N, int relu) {
-    const int C4 = C >> 2, cg = C / G;
-    const long long total = (long long)N * P * C4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long long row = i / C4;
-        const int n = (int)(row / P);
-        const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * q);
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
+                                                       long long P, int C, int G, int rpb, int relu) {
+    const int C4 = C >> 2, RL = 256 / C4, cg = C / G;
+    const int tid = threadIdx.x, q = tid % C4, rl = tid / C4, n = blockIdx.y;
+    float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * q + k, g = c / cg;
-            const float t = (xv[k] - mean[n * G + g]) * rstd[n * G + g] * gamma[c] + beta[c];
-            o[k] = (relu && !(t > 0.f)) ? 0.f : t;
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k, g = c / cg;
+        mu[k] = mean[n * G + g]; rs[k] = rstd[n * G + g]; ga[k] = gamma[c]; be[k] = beta[c];
+    }
+    const long long r0 = (long long)blockIdx.x * rpb;
+    long long r1 = r0 + rpb; if (r1 > P) r1 = P;
+    const float* xb = x + (long long)n * P * ldx + 4 * q;
+    float* yb = y + (long long)n * P * ldy + 4 * q;
+    for (long long r = r0 + rl; r < r1; r += 4 * RL) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + (long long)u * RL;
+            v[u] = rr < r1 ? *reinterpret_cast<const float4*>(xb + rr * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(y + row * ldy + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long rr = r + (long long)u * RL;
+            if (rr >= r1) continue;
+            float o[4] = {(v[u].x - mu[0]) * rs[0] * ga[0] + be[0], (v[u].y - mu[1]) * rs[1] * ga[1] + be[1],
+                          (v[u].z - mu[2]) * rs[2] * ga[2] + be[2], (v[u].w - mu[3]) * rs[3] * ga[3] + be[3]};
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+            }
+            *reinterpret_cast<float4*>(yb + rr * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -142,32 +160,59 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, int lddx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
-                                                           long long P, int C, int G, int N, int relu) {
-    const int C4 = C >> 2, cg = C / G;
-    const long long total = (long long)N * P * C4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const long long row = i / C4;
-        const int n = (int)(row / P);
-        const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * q);
-        const float4 d = *reinterpret_cast<const float4*>(dy + row * lddy + 4 * q);
-        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
-        float o[4];
+                                                           long long P, int C, int G, int rpb, int relu) {
+    const int C4 = C >> 2, RL = 256 / C4, cg = C / G;
+    const int tid = threadIdx.x, q = tid % C4, rl = tid / C4, n = blockIdx.y;
+    float be[4], rs[4], mu[4], c1[4], c2[4], ga[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * q + k, g = c / cg;
-            const float rs = rstd[n * G + g];
-            const float xh = (xv[k] - mean[n * G + g]) * rs;
-            const float dz = (relu && !(xh * gamma[c] + beta[c] > 0.f)) ? 0.f : dv[k];
-            o[k] = rs * (dz * gamma[c] - coef[2 * (n * G + g)] - xh * coef[2 * (n * G + g) + 1]);
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k, g = c / cg;
+        rs[k] = rstd[n * G + g]; mu[k] = mean[n * G + g]; ga[k] = gamma[c]; be[k] = beta[c];
+        c1[k] = coef[2 * (n * G + g)]; c2[k] = coef[2 * (n * G + g) + 1];
+    }
+    const long long r0 = (long long)blockIdx.x * rpb;
+    long long r1 = r0 + rpb; if (r1 > P) r1 = P;
+    const float* xb = x + (long long)n * P * ldx + 4 * q;
+    const float* dyb = dy + (long long)n * P * lddy + 4 * q;
+    float* dxb = dx + (long long)n * P * lddx + 4 * q;
+    for (long long r = r0 + rl; r < r1; r += 2 * RL) {
+        float4 v[2], d[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long rr = r + (long long)u * RL;
+            v[u] = rr < r1 ? *reinterpret_cast<const float4*>(xb + rr * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[u] = rr < r1 ? *reinterpret_cast<const float4*>(dyb + rr * lddy) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(dx + row * lddx + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long rr = r + (long long)u * RL;
+            if (rr >= r1) continue;
+            const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - mu[k]) * rs[k];
+                const float dz = (relu && !(xh * ga[k] + be[k] > 0.f)) ? 0.f : dv[k];
+                o[k] = rs[k] * (dz * ga[k] - c1[k] - xh * c2[k]);
+            }
+            *reinterpret_cast<float4*>(dxb + rr * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
 static bool gn_ok(int C, int G, int ldx, int ldy) {
     const int C4 = C / 4;
     return C > 0 && G > 0 && C % G == 0 && C % 4 == 0 && C4 <= 256 && 256 % C4 == 0 && ldx % 4 == 0 && ldy % 4 == 0;
+}
+// rows per block (a multiple of the rows one pass of a block covers) for ~4096 blocks per launch
+static int gn_row_blocks(long long P, int C, int N, int unroll, int* rpb) {
+    const int pass = (256 / (C / 4)) * unroll;
+    long long want = 4096 / (N > 0 ? N : 1); if (want < 1) want = 1;
+    long long r = (P + want - 1) / want;
+    r = ((r + pass - 1) / pass) * pass;
+    if (r > 0x3fffffff) r = 0x3fffffff / pass * pass;
+    *rpb = (int)r;
+    return (int)((P + r - 1) / r);
 }
 static int gn_chunks(long long P) { return mrdis_cdiv(P, GN_CHUNK_ROWS); }
 static int ew_blocks(long long total) { long long b = (total + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
@@ -199,8 +244,9 @@ extern "C" int mrdis_groupnorm_relu_fwd(const float* x, int ldx, float* y, int l
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_stat_kernel, dim3(mrdis_cdiv((long long)N * G, 64)), dim3(64), 0, s, chan, save_mean, save_rstd, N, C, G, P, eps);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_blocks((long long)N * P * (C / 4))), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta,
-                       save_mean, save_rstd, P, C, G, N, relu ? 1 : 0);
+    int rpb; const int nb = gn_row_blocks(P, C, N, 4, &rpb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, N), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta,
+                       save_mean, save_rstd, P, C, G, rpb, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -227,8 +273,9 @@ extern "C" int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* 
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(mrdis_cdiv((long long)N * G + C, 64)), dim3(64), 0, s, chan, gamma, coef, dgamma, dbeta, N, C, G, P);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((long long)N * P * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, dx, lddx,
-                       gamma, beta, save_mean, save_rstd, coef, P, C, G, N, relu ? 1 : 0);
+    int rpb; const int nb = gn_row_blocks(P, C, N, 2, &rpb);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, N), dim3(256), 0, s, dy, lddy, x, ldx, dx, lddx,
+                       gamma, beta, save_mean, save_rstd, coef, P, C, G, rpb, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
