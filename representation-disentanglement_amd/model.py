@@ -577,7 +577,7 @@ class MultimodalModel(nn.Module):
 
     # ---- model.py:3159-3162: eps is drawn from the CPU generator, then moved
     def sample(self, z_mean, z_log_var):
-        eps = torch.normal(0, 1, size=(z_mean.shape[0], z_mean.shape[1])).to(self.device, non_blocking=True)
+        eps = ops.to_device(torch.normal(0, 1, size=(z_mean.shape[0], z_mean.shape[1])), self.device)
         return z_mean + eps * torch.exp(0.5 * z_log_var)
 
     # ---- model.py:3164-3185
@@ -642,7 +642,7 @@ class MultimodalModel(nn.Module):
         rows = np.flatnonzero(mh.reshape(-1) == 1)
         flat = si_cat.reshape((-1,) + tuple(si_cat.shape[2:]))
         if len(rows) != flat.shape[0]:
-            flat = flat[torch.from_numpy(rows).to(flat.device)]
+            flat = flat.index_select(0, ops.to_device(torch.from_numpy(rows), flat.device))
         return self.output_decoder(flat.contiguous(memory_format=torch.channels_last))[0]
 
     def reconstruct_output_si(self, si_list):
@@ -696,7 +696,7 @@ class MultimodalModel(nn.Module):
     # backward).  Term order, the skip rules and the quirks are unchanged.
     def _weights(self, rows):
         """rows: list of numpy (B,) weight vectors -> (T, B) device tensor (one H2D copy)."""
-        return torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device, non_blocking=True)
+        return ops.to_device(torch.from_numpy(np.stack(rows).astype(np.float32)), self.device)
 
     def compute_recon_loss_x_list(self, gt_list, x_list, mask, p=2, mask_host=None):             # :3315-3325
         mh = _host_mask(mask, mask_host)
@@ -789,7 +789,8 @@ class MultimodalModel(nn.Module):
             return torch.zeros((), device=self.device)
         Z = torch.stack(list(zi_list))                                            # (M, B, Z)
         Zp = torch.cat([Z[:, 1:], Z[:, 0:1]], 1)                                  # roll by one sample, per modality
-        zi, zj, zp = Z[I], Z[J], Zp[I]                                            # (P, B, Z)
+        idx = ops.to_device(torch.tensor([I, J], dtype=torch.long), self.device)   # list indexing would be a blocking H2D copy
+        zi, zj, zp = Z.index_select(0, idx[0]), Z.index_select(0, idx[1]), Zp.index_select(0, idx[0])   # (P, B, Z)
 
         def cos(x, y):                                                            # compute_cosine on the last axis
             xn = torch.sqrt(torch.sum(x * x, 2) + 1e-8).clamp_min(1e-8)

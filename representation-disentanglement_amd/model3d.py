@@ -153,7 +153,7 @@ class VAEBranch(nn.Module):
 
     def reparameterize(self, mu, logvar):
         std = torch.exp(0.5 * logvar)
-        eps = torch.randn(std.shape, dtype=std.dtype).to(std.device)      # CPU generator, as the reference on its CPU path
+        eps = ops.to_device(torch.randn(std.shape, dtype=std.dtype), std.device)   # CPU generator, as the reference on its CPU path
         return eps.mul(std).add_(mu)
 
     def forward(self, x):
