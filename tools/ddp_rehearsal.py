@@ -1,0 +1,66 @@
+"""Rehearsal of the data-parallel TrainStep on the real HIP path with world_size > 1 on ONE GPU box: every rank uses
+cuda:0 and the exchange runs over gloo (RCCL needs one device per rank).  Every rank feeds the SAME batch with the same
+seeds, so the averaged gradients equal the single-process ones bit for bit ((g + g) / 2 == g in fp32) and, the kernels
+being bit-reproducible, the weights after k steps must be IDENTICAL to a single-process run and across ranks.  That
+pins the parts the CPU gloo test cannot reach: gradient sinks written inside backward kernels, hook-driven bucket
+launches racing the rest of the backward pass, the adversarial second backward, the first (arena-less) step.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_rehearsal.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mrdis  # noqa: E402
+
+
+def run(steps, B, M, H, W, dev):
+    cfg = dict(mrdis.DEFAULT_CONFIG)
+    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=16, lambda_adv_s=1.0)
+    cfg = mrdis.derive_config(cfg, dev)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg, ddp_buckets=4)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, H, W, seed=3, drop=True)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    torch.manual_seed(100); np.random.seed(100)
+    losses = []
+    for _ in range(steps):
+        loss, parts, _ = step(xd, mask.to(dev), mask_img.to(dev), mask)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    return flat, losses, step
+
+
+def main():
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    mrdis.hip.load()
+    steps, B, M, H, W = 3, 4, 3, 64, 96
+    ref, ref_losses, _ = run(steps, B, M, H, W, dev)                     # single process: no reducer
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    got, losses, step = run(steps, B, M, H, W, dev)
+    assert step.reducer is not None and step.reducer.world == world
+    same = bool(torch.equal(ref, got))
+    maxdiff = float((ref - got).abs().max())
+    sums = [None] * world
+    dist.all_gather_object(sums, (float(got.double().sum()), float(got.double().abs().sum())))
+    across = all(s == sums[0] for s in sums)
+    if rank == 0:
+        print(f'[ddp rehearsal] world {world}: weights after {steps} steps identical to single-process: {same} '
+              f'(max |diff| {maxdiff:.3e}); identical across ranks: {across}; losses {losses} vs {ref_losses}', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not (same and across):
+        sys.exit(1)
+
+
+if __name__ == '__main__':
+    main()
