@@ -1035,6 +1035,23 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     return MRDIS_OK;
 }
 
+// fused Winograd F(2x2, 3x3) kernel (mrdis_wino.hip)
+int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                   int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
+// MRDIS_WINO: 0 never | 1 (default) measured policy | 2 wherever the kernel applies.  Policy (tools/layer_bench.py, B = 32
+// layer zoo): Winograd wins for Cout >= 32 and Cin >= 16 once the grid fills the chip (>= 256 workgroups): 1.13x on
+// 32 -> 32, 1.3-1.5x on the 64..512-channel layers; a 16-cout layer wastes half of its 32-wide cout tile (slower).
+static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("MRDIS_WINO"); mode = e ? atoi(e) : 1; }
+    if (mode == 0 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
+    if (mode == 2) return Ci >= 8 && Co >= 8;
+    if (Ci < 16 || Co < 32) return false;
+    const int cg = Co > 32 ? 2 : 1;
+    const long long nblk = (long long)N * mrdis_cdiv((H + 1) / 2, 8) * mrdis_cdiv((W + 1) / 2, cg == 2 ? 8 : 16) * mrdis_cdiv(Co, 32 * cg);
+    return nblk >= 256;
+}
+
 extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
                                 float* y, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, void* stream) {
@@ -1044,6 +1061,10 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
     if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
+    if (wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
+        rc = mrdis_run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     TapConvParams p{};
     p.in = x; p.w = w_tck; p.bias = bias; p.out = y;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Ci; p.ldin = ldx;
@@ -1076,6 +1097,10 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
         // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
         if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
+        if (wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
+            rc = mrdis_run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
+            if (rc != MRDIS_EUNSUPPORTED) return rc;
+        }
         TapConvParams p = base;
         p.A = H; p.B = W; p.os = 1; p.oh0 = 0; p.ow0 = 0;
         p.ntaps = kh * kw;

@@ -1,0 +1,245 @@
+// mrdis_wino.hip -- fused Winograd F(2x2, 3x3) convolution for gfx950 (MI355X), fp32, NHWC.
+//
+// The 3x3 / stride 1 / pad 1 layers are 95 % of the step's FLOPs.  F(2x2, 3x3) computes a 2x2
+// output tile from a 4x4 input tile with 16 multiplies per (ci, co) instead of 36:
+//
+//      Y = A^T [ (G g G^T) .* (B^T d B) ] A          (Lavin & Gray 2016; the transforms are exact in binary fp: +-, x0.5)
+//
+// so the MFMA work drops 2.25x; the price is the two transforms, which run on the VALU out of LDS.  Everything is
+// fused in ONE kernel (no transformed tensors in HBM, same C ABI as the direct kernel):
+//
+//   workgroup (8 waves) = T tiles (T = 64: 8x8 tiles = 16x16 outputs, or T = 128: 8x16 tiles) x BN couts (64 or 32)
+//   per 8-channel chunk:
+//     1. the halo'd raw input block ((2TBH+2) x (2TBW+2) pixels x 8 ch) and the 9 filter taps of each (ci, co) pair of
+//        the chunk were prefetched into registers during the previous chunk's MFMAs; they go to LDS -- the filter
+//        THROUGH G g G^T, i.e. as U[xi][ci][co], xi = 0..15
+//     2. every thread transforms tile-channels: 16 raw reads -> B^T d B -> V[xi][ci][tile]
+//     3. 16 independent products D_xi[co][tile] += U_xi[co][ci] V_xi[ci][tile] on v_mfma_f32_16x16x4_f32: a wave owns
+//        16 tiles x 32 couts for ALL 16 xi (128 accumulator registers), so the output transform is lane-local
+//   epilogue: Y = A^T M A per lane (24 adds per 2x2 tile and cout), + bias (+ LeakyReLU), 16-byte stores.
+//
+// The data gradient of such a layer is the same convolution with the taps reversed and [tap][Co][Ci] filters.
+// Results differ from the direct kernel by fp32 rounding of the transforms (~1e-6 relative; parity bar 1e-3).
+#include "mrdis_common.h"
+#include <stdlib.h>
+
+struct WinoParams {
+    const float* in; const float* w; const float* bias; float* out;
+    int N, H, W, Cin, ldin, Cout, ldout;
+    int flip, lrelu;
+    int TBH, TBW;                 // tile-block shape in tiles
+    int nby, nbx, coTiles;        // tile blocks per image, cout tiles
+};
+
+template <int CG>                 // cout groups of 32 per workgroup: BN = 32 * CG, tiles T = 128 / CG
+__global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
+    constexpr int KC = 8, RS = KC + 1;
+    constexpr int BN = 32 * CG, TG = 8 / CG, T = 16 * TG;
+    constexpr int TS = T + 16, US = BN + 16;          // row pitches: the 4 k-rows of an MFMA operand land 16 banks apart
+    constexpr int XR = CG == 2 ? 2 : 3;               // raw float4 items per thread (host: RH * RW * 2 <= XR * 512)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* U = smem;                                  // [16][KC][US]
+    float* V = U + 16 * KC * US;                      // [16][KC][TS]
+    float* raw = V + 16 * KC * TS;                    // [RH * RW][RS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int cg = wave % CG, tg = wave / CG;
+    const int RH = 2 * p.TBH + 2, RW = 2 * p.TBW + 2, npix = RH * RW;
+
+    int bid = mrdis_xcd_remap(blockIdx.x, gridDim.x);
+    const int cot = bid % p.coTiles; bid /= p.coTiles;
+    const int bx = bid % p.nbx; bid /= p.nbx;
+    const int by = bid % p.nby;
+    const int n = bid / p.nby;
+    const int co0 = cot * BN;
+    const int oy0 = 2 * by * p.TBH, ox0 = 2 * bx * p.TBW;      // output origin of the block; raw origin is (oy0 - 1, ox0 - 1)
+
+    // ---- chunk-invariant staging roles
+    int xg[XR], xl[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 512;
+        xg[it] = -1; xl[it] = -1;
+        if (idx < npix * 2) {
+            const int pi = idx >> 1, q = idx & 1;
+            const int ry = pi / RW, rx = pi - ry * RW;
+            const int h = oy0 - 1 + ry, w_ = ox0 - 1 + rx;
+            xl[it] = pi * RS + 4 * q;
+            if ((unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                xg[it] = ((n * p.H + h) * p.W + w_) * p.ldin + 4 * q;            // host: < 2^31 elements
+        }
+    }
+    const int fk = tid / BN, fco = tid - fk * BN;                                   // filter pair of this thread
+    const bool f_on = tid < KC * BN && (co0 + fco) < p.Cout;
+    float4 xr[XR];
+    float gr[9];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int q4 = 4 * ((tid + it * 512) & 1);
+            if (xg[it] >= 0 && c0 + q4 < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
+        }
+        const bool on = f_on && (c0 + fk) < p.Cin;
+        const float* wp = p.w + ((long long)(c0 + fk)) * p.Cout + co0 + fco;
+        const long long tstride = (long long)p.Cin * p.Cout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gr[t] = on ? wp[(p.flip ? 8 - t : t) * tstride] : 0.f;
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it)
+            if (xl[it] >= 0) { float* d = raw + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+        if (tid < KC * BN) {
+            // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+            float t_[4][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float g0 = gr[j], g1 = gr[3 + j], g2 = gr[6 + j];
+                t_[0][j] = g0; t_[1][j] = 0.5f * (g0 + g1 + g2); t_[2][j] = 0.5f * (g0 - g1 + g2); t_[3][j] = g2;
+            }
+            float* up = U + fk * US + fco;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float u0 = t_[a][0], u3 = t_[a][2];
+                const float u1 = 0.5f * (t_[a][0] + t_[a][1] + t_[a][2]), u2 = 0.5f * (t_[a][0] - t_[a][1] + t_[a][2]);
+                up[(4 * a + 0) * KC * US] = u0; up[(4 * a + 1) * KC * US] = u1;
+                up[(4 * a + 2) * KC * US] = u2; up[(4 * a + 3) * KC * US] = u3;
+            }
+        }
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int a_off = kq * US + 32 * cg + l16;        // + (xi * KC + 4 * ks) * US (+ 16 for the second block)
+    const int b_off = kq * TS + 16 * tg + l16;        // + (xi * KC + 4 * ks) * TS
+
+    load_chunk(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        if (c0) __syncthreads();                      // the previous chunk's MFMAs have read U / V
+        store_chunk();
+        __syncthreads();
+        // ---- V = B^T d B per (tile, channel): B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+#pragma unroll
+        for (int rep = 0; rep < (T * KC) / 512; ++rep) {
+            const int tc = tid + rep * 512;
+            const int tile = tc % T, ch = tc / T;
+            const int ty = tile / p.TBW, tx = tile - ty * p.TBW;
+            const float* rp = raw + ((2 * ty) * RW + 2 * tx) * RS + ch;
+            float d[4][4], r[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = rp[(i * RW + j) * RS];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[0][j] = d[0][j] - d[2][j]; r[1][j] = d[1][j] + d[2][j];
+                r[2][j] = d[2][j] - d[1][j]; r[3][j] = d[1][j] - d[3][j];
+            }
+            float* vp = V + ch * TS + tile;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                vp[(4 * a + 0) * KC * TS] = r[a][0] - r[a][2];
+                vp[(4 * a + 1) * KC * TS] = r[a][1] + r[a][2];
+                vp[(4 * a + 2) * KC * TS] = r[a][2] - r[a][1];
+                vp[(4 * a + 3) * KC * TS] = r[a][1] - r[a][3];
+            }
+        }
+        __syncthreads();
+        if (c0 + KC < p.Cin) load_chunk(c0 + KC);      // global loads in flight during the MFMAs
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const float a0 = U[(x * KC + 4 * ks) * US + a_off], a1 = U[(x * KC + 4 * ks) * US + a_off + 16];
+                const float b = V[(x * KC + 4 * ks) * TS + b_off];
+                acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[x][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane = tile (16 * tg + l16), couts co0 + 32 cg + 16 b + 4 kq + r; Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]
+    const int tile = 16 * tg + l16;
+    const int ty = tile / p.TBW, tx = tile - ty * p.TBW;
+    const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
+    if (ty >= p.TBH || oy >= p.H || ox >= p.W) return;
+    const bool vec_out = (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int co = co0 + 32 * cg + 16 * b + 4 * kq;
+        if (co >= p.Cout) continue;
+        float y[2][2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = acc[4 * i][b][r], m1 = acc[4 * i + 1][b][r], m2 = acc[4 * i + 2][b][r], m3 = acc[4 * i + 3][b][r];
+                t0[i] = m0 + m1 + m2; t1[i] = m1 - m2 - m3;
+            }
+            y[0][0][r] = t0[0] + t0[1] + t0[2]; y[0][1][r] = t1[0] + t1[1] + t1[2];
+            y[1][0][r] = t0[1] - t0[2] - t0[3]; y[1][1][r] = t1[1] - t1[2] - t1[3];
+        }
+        float bq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (co + r < p.Cout) bq[r] = p.bias[co + r];
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                if (oy + dy >= p.H || ox + dx >= p.W) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = y[dy][dx][r] + bq[r];
+                    if (p.lrelu) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                }
+                float* dst = p.out + ((long long)(n * p.H + oy + dy) * p.W + ox + dx) * p.ldout + co;
+                if (vec_out && co + 3 < p.Cout) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co + r < p.Cout) dst[r] = v[r];
+                }
+            }
+    }
+}
+
+template <int CG>
+static size_t wino_lds(int TBH, int TBW) {
+    constexpr int KC = 8, BN = 32 * CG, T = 128 / CG;
+    return sizeof(float) * ((size_t)16 * KC * (BN + 16) + (size_t)16 * KC * (T + 16) + (size_t)(2 * TBH + 2) * (2 * TBW + 2) * (KC + 1));
+}
+
+// returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers (caller falls back to the direct kernel)
+int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                   int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s) {
+    if (Ci % 4 != 0 || ldx % 4 != 0 || (((uintptr_t)x) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W * ldx >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    WinoParams p{};
+    p.in = x; p.w = w; p.bias = bias; p.out = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
+    p.flip = flip; p.lrelu = lrelu;
+    const int CG = Co > 32 ? 2 : 1;
+    p.TBH = 8; p.TBW = CG == 2 ? 8 : 16;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    p.nby = mrdis_cdiv(th, p.TBH); p.nbx = mrdis_cdiv(tw, p.TBW);
+    p.coTiles = mrdis_cdiv(Co, 32 * CG);
+    const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wino_conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_conv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2>), dim3((int)nblk), dim3(512), wino_lds<2>(p.TBH, p.TBW), s, p);
+    else hipLaunchKernelGGL((wino_conv_kernel<1>), dim3((int)nblk), dim3(512), wino_lds<1>(p.TBH, p.TBW), s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
