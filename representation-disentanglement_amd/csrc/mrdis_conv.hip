@@ -1048,8 +1048,8 @@ static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int
     if (mode == 2) return Ci >= 8 && Co >= 8;
     if (Ci < 16 || Co < 32) return false;
     const int cg = Co > 32 ? 2 : 1;
-    const long long nblk = (long long)N * mrdis_cdiv((H + 1) / 2, 8) * mrdis_cdiv((W + 1) / 2, cg == 2 ? 8 : 16) * mrdis_cdiv(Co, 32 * cg);
-    return nblk >= 256;
+    const long long nblk = (long long)N * mrdis_cdiv((H + 1) / 2, 8) * mrdis_cdiv((W + 1) / 2, 8) * mrdis_cdiv(Co, 32 * cg);
+    return nblk >= (cg == 2 ? 256 : 512);
 }
 
 extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,

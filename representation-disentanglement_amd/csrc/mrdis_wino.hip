@@ -31,12 +31,21 @@ struct WinoParams {
     int nby, nbx, coTiles;        // tile blocks per image, cout tiles
 };
 
-template <int CG>                 // cout groups of 32 per workgroup: BN = 32 * CG, tiles T = 128 / CG
-__global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
-    constexpr int KC = 8, RS = KC + 1;
-    constexpr int BN = 32 * CG, TG = 8 / CG, T = 16 * TG;
+// CG cout groups of 32 x TG tile groups of 16 = waves per workgroup, all on 8x8 tile blocks (16x16 outputs):
+//   <2,4>: 8 waves, 64 tiles x 64 couts, one workgroup per CU (Cout > 32)
+//   <1,4>: 4 waves, 64 tiles x 32 couts, two workgroups per CU (Cout <= 32): one transforms while the other multiplies
+// Timing-only builds (-DWINO_ABL_NOV / _NOU / _NOMFMA) on a 128 -> 128 layer at 64x64, B = 32: 218 us = 103 us of
+// MFMA (the matrix pipe at its peak rate) + 40 us V transform + 28 us U transform + 47 us staging, barriers,
+// epilogue -- the phases of one workgroup run back to back.  Splitting the 64-cout workgroup into two 4-wave ones
+// (32 tiles x 64 couts, or 64 tiles x 32 couts) to overlap them doubles one of the transforms and was slower
+// (243 us); for Cout = 32 nothing is duplicated and the overlap is worth 6 %.
+template <int CG, int TG>
+__global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
+    constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
+    constexpr int BN = 32 * CG, T = 16 * TG;
     constexpr int TS = T + 16, US = BN + 16;          // row pitches: the 4 k-rows of an MFMA operand land 16 banks apart
-    constexpr int XR = CG == 2 ? 2 : 3;               // raw float4 items per thread (host: RH * RW * 2 <= XR * 512)
+    constexpr int XR = NT == 512 ? 2 : 3;             // raw float4 items per thread (host: RH * RW * 2 <= XR * NT)
+    constexpr int UR = (KC * BN) / NT;                // filter (ci, co) pairs per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* U = smem;                                  // [16][KC][US]
     float* V = U + 16 * KC * US;                      // [16][KC][TS]
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
     int xg[XR], xl[XR];
 #pragma unroll
     for (int it = 0; it < XR; ++it) {
-        const int idx = tid + it * 512;
+        const int idx = tid + it * NT;
         xg[it] = -1; xl[it] = -1;
         if (idx < npix * 2) {
             const int pi = idx >> 1, q = idx & 1;
@@ -69,36 +78,42 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
                 xg[it] = ((n * p.H + h) * p.W + w_) * p.ldin + 4 * q;            // host: < 2^31 elements
         }
     }
-    const int fk = tid / BN, fco = tid - fk * BN;                                   // filter pair of this thread
-    const bool f_on = tid < KC * BN && (co0 + fco) < p.Cout;
+    const int fk = tid / BN, fco = tid - fk * BN;                                   // filter pairs of this thread: (fk + u * NT / BN, fco)
+    const bool f_on = (co0 + fco) < p.Cout;
     float4 xr[XR];
-    float gr[9];
+    float gr[UR][9];
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int q4 = 4 * ((tid + it * 512) & 1);
+            const int q4 = 4 * ((tid + it * NT) & 1);
             if (xg[it] >= 0 && c0 + q4 < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
         }
-        const bool on = f_on && (c0 + fk) < p.Cin;
-        const float* wp = p.w + ((long long)(c0 + fk)) * p.Cout + co0 + fco;
         const long long tstride = (long long)p.Cin * p.Cout;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) gr[t] = on ? wp[(p.flip ? 8 - t : t) * tstride] : 0.f;
+        for (int u = 0; u < UR; ++u) {
+            const int k = fk + u * (NT / BN);
+            const bool on = f_on && (c0 + k) < p.Cin;
+            const float* wp = p.w + ((long long)(c0 + k)) * p.Cout + co0 + fco;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gr[u][t] = on ? wp[(p.flip ? 8 - t : t) * tstride] : 0.f;
+        }
     };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < XR; ++it)
             if (xl[it] >= 0) { float* d = raw + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
-        if (tid < KC * BN) {
+#ifndef WINO_ABL_NOU
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
             // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
             float t_[4][3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float g0 = gr[j], g1 = gr[3 + j], g2 = gr[6 + j];
+                const float g0 = gr[u][j], g1 = gr[u][3 + j], g2 = gr[u][6 + j];
                 t_[0][j] = g0; t_[1][j] = 0.5f * (g0 + g1 + g2); t_[2][j] = 0.5f * (g0 - g1 + g2); t_[3][j] = g2;
             }
-            float* up = U + fk * US + fco;
+            float* up = U + (fk + u * (NT / BN)) * US + fco;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const float u0 = t_[a][0], u3 = t_[a][2];
@@ -107,6 +122,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
                 up[(4 * a + 2) * KC * US] = u2; up[(4 * a + 3) * KC * US] = u3;
             }
         }
+#endif
     };
 
     f32x4 acc[16][2];
@@ -121,10 +137,11 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
         if (c0) __syncthreads();                      // the previous chunk's MFMAs have read U / V
         store_chunk();
         __syncthreads();
+#ifndef WINO_ABL_NOV
         // ---- V = B^T d B per (tile, channel): B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #pragma unroll
-        for (int rep = 0; rep < (T * KC) / 512; ++rep) {
-            const int tc = tid + rep * 512;
+        for (int rep = 0; rep < (T * KC) / NT; ++rep) {
+            const int tc = tid + rep * NT;
             const int tile = tc % T, ch = tc / T;
             const int ty = tile / p.TBW, tx = tile - ty * p.TBW;
             const float* rp = raw + ((2 * ty) * RW + 2 * tx) * RS + ch;
@@ -147,18 +164,35 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
                 vp[(4 * a + 3) * KC * TS] = r[a][1] - r[a][3];
             }
         }
+#endif
         __syncthreads();
         if (c0 + KC < p.Cin) load_chunk(c0 + KC);      // global loads in flight during the MFMAs
+#ifndef WINO_ABL_NOMFMA
+        // 32 steps (xi, 4-channel group), operands fetched two steps ahead of the MFMAs that use them (three rotating
+        // register sets; the sched_barriers keep hipcc from sinking the reads back next to their use -- left alone it
+        // emits read, wait, 2 MFMAs, wait, 2 MFMAs and every pair of MFMAs eats a full LDS round trip)
+        {
+            constexpr int NS = 16 * (KC / 4);
+            float a0[3], a1[3], bv[3];
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int row = ((s_ / (KC / 4)) * KC + 4 * (s_ % (KC / 4)));
+                a0[s_] = U[row * US + a_off]; a1[s_] = U[row * US + a_off + 16]; bv[s_] = V[row * TS + b_off];
+            }
 #pragma unroll
-            for (int ks = 0; ks < KC / 4; ++ks) {
-                const float a0 = U[(x * KC + 4 * ks) * US + a_off], a1 = U[(x * KC + 4 * ks) * US + a_off + 16];
-                const float b = V[(x * KC + 4 * ks) * TS + b_off];
-                acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[x][0], 0, 0, 0);
-                acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[x][1], 0, 0, 0);
+            for (int s_ = 0; s_ < NS; ++s_) {
+                if (s_ + 2 < NS) {
+                    const int row = (((s_ + 2) / (KC / 4)) * KC + 4 * ((s_ + 2) % (KC / 4)));
+                    a0[(s_ + 2) % 3] = U[row * US + a_off]; a1[(s_ + 2) % 3] = U[row * US + a_off + 16]; bv[(s_ + 2) % 3] = V[row * TS + b_off];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int x = s_ / (KC / 4);
+                acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s_ % 3], bv[s_ % 3], acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s_ % 3], bv[s_ % 3], acc[x][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
     }
 
     // ---- epilogue: lane = tile (16 * tg + l16), couts co0 + 32 cg + 16 b + 4 kq + r; Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]
@@ -209,9 +243,9 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoParams p) {
     }
 }
 
-template <int CG>
+template <int CG, int TG>
 static size_t wino_lds(int TBH, int TBW) {
-    constexpr int KC = 8, BN = 32 * CG, T = 128 / CG;
+    constexpr int KC = 8, BN = 32 * CG, T = 16 * TG;
     return sizeof(float) * ((size_t)16 * KC * (BN + 16) + (size_t)16 * KC * (T + 16) + (size_t)(2 * TBH + 2) * (2 * TBW + 2) * (KC + 1));
 }
 
@@ -225,7 +259,7 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
     p.flip = flip; p.lrelu = lrelu;
     const int CG = Co > 32 ? 2 : 1;
-    p.TBH = 8; p.TBW = CG == 2 ? 8 : 16;
+    p.TBH = 8; p.TBW = 8;
     const int th = (H + 1) / 2, tw = (W + 1) / 2;
     p.nby = mrdis_cdiv(th, p.TBH); p.nbx = mrdis_cdiv(tw, p.TBW);
     p.coTiles = mrdis_cdiv(Co, 32 * CG);
@@ -233,13 +267,14 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wino_conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wino_conv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wino_conv_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_conv_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2>), dim3((int)nblk), dim3(512), wino_lds<2>(p.TBH, p.TBW), s, p);
-    else hipLaunchKernelGGL((wino_conv_kernel<1>), dim3((int)nblk), dim3(512), wino_lds<1>(p.TBH, p.TBW), s, p);
+    const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
+    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), dim3((int)nblk), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((wino_conv_kernel<1, 4>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
