@@ -1042,8 +1042,8 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
 // layer zoo): Winograd wins for Cout >= 32 and Cin >= 16 once the grid fills the chip (>= 256 workgroups): 1.13x on
 // 32 -> 32, 1.3-1.5x on the 64..512-channel layers; a 16-cout layer wastes half of its 32-wide cout tile (slower).
 static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("MRDIS_WINO"); mode = e ? atoi(e) : 1; }
+    const char* e = getenv("MRDIS_WINO");          // read per call: the parity tests switch it inside one process
+    const int mode = e ? atoi(e) : 1;
     if (mode == 0 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
     if (mode == 2) return Ci >= 8 && Co >= 8;
     if (Ci < 16 || Co < 32) return false;

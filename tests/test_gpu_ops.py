@@ -94,6 +94,43 @@ def test_conv_fwd_bwd(mrdis, case):
     close(db, b.grad, rtol=2e-4, what='dbias')
 
 
+WINO_CASES = [
+    (2, 32, 32, 40, 56),      # 32-cout variant (two 4-wave workgroups per CU), several tile blocks
+    (1, 64, 64, 31, 45),      # odd extents: half tiles at the bottom / right edges
+    (2, 128, 64, 16, 16),     # 64-cout variant, one tile block per image
+    (1, 16, 48, 20, 20),      # cout tail inside a 64-wide tile
+    (1, 24, 96, 18, 34),      # channel tail inside the last 8-channel chunk
+    (3, 512, 128, 8, 8),      # deep reduction (64 chunks)
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
+def test_conv_winograd_forced(mrdis, case, monkeypatch):
+    """mrdis_wino.hip (fused Winograd F(2x2,3x3)) forced on (MRDIS_WINO=2) for shapes the size policy would send to the
+    direct kernel: forward (+ bias, + LeakyReLU), data gradient, and a strided (channel-slice) input view; and the two
+    kernels against each other."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    x = rnd((N, Ci, H, W), 1).requires_grad_(True)
+    w = rnd((Co, Ci, 3, 3), 2, 0.2).requires_grad_(True)
+    b = rnd((Co,), 3, 0.1)
+    y = F.conv2d(x, w, b, 1, 1)
+    gy = rnd(tuple(y.shape), 4)
+    y.backward(gy)
+    w_tck, w_tkc = to_tck(w.detach()).to(dev()), to_tkc(w.detach()).to(dev())
+    monkeypatch.setenv('MRDIS_WINO', '0')
+    y_direct = hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1)
+    monkeypatch.setenv('MRDIS_WINO', '2')
+    y_w = hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1)
+    assert not torch.equal(y_w, y_direct)                      # really another kernel
+    close(y_w, y, rtol=1e-4, what='winograd fwd')
+    close(y_w, y_direct, rtol=1e-4, what='winograd vs direct')
+    close(hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True), F.leaky_relu(y, 0.2), rtol=1e-4, what='fwd+lrelu')
+    close(hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), 3, 3, 1, 1), x.grad, rtol=1e-4, what='winograd dgrad')
+    wide = cl(torch.cat([rnd((N, 8, H, W), 9), x.detach()], 1))          # channel slice: ld = Ci + 8
+    close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
+
+
 def test_conv_c4_persistent_pipeline(mrdis):
     """Cin = 4 direct kernel with enough strips (> 2 per resident wave) to run its steady-state
     register pipeline, ragged right edge included; with bias and fused LeakyReLU."""
