@@ -278,3 +278,306 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
+
+// =========================================================================== Winograd weight gradient
+// dW of a 3x3 / stride 1 / pad 1 layer through the same F(2x2, 3x3) factorisation: with M = U .* V and Y = A^T M A,
+//
+//      dU_xi[ci][co] = sum over tiles  V_xi[ci][tile] * Z_xi[tile][co],   Z = A dY A^T  (4x4 from the 2x2 dy tile)
+//      dg = G^T dU G                                                      (3x3 from 4x4)
+//
+// i.e. 16 small GEMMs whose reduction axis is the TILE index -- 16/36 of the direct kernel's multiplies.  One kernel:
+// a workgroup owns a (CIB x COB) block of (ci, co) and a grid-stride share of the tile blocks (split-K); per block of
+// 8 tiles (2x4) the halo'd x block goes to LDS, every thread transforms one (tile, ci) to V and one (tile, co) -- dy read
+// straight from global, prefetched -- to Z, then v_mfma_f32_16x16x4_f32 with A = V_xi[16 ci x 4 tiles],
+// B = Z_xi[4 tiles x 16 co]; a wave owns 16 ci x 32 co for all 16 xi (128 accumulators), so G^T dU G is lane-local
+// and a workgroup writes nine [ci][co] planes (not sixteen) into its split-K slab; a fixed-order sum over the slabs
+// finishes dw_tck (bit-reproducible).  The bias gradient (column sums of dy) rides along in the Z pass.
+struct WinoWgradParams {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, Ci, ldx, Co, lddy;
+    int nby, nbx, nblocks;        // tile blocks (2 x 4 tiles) per image row / column, total
+    int nCiB, nCoB, splits;
+};
+
+template <int WCI, int WCO>       // waves along ci (16 each) x waves along co (32 each)
+__global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino_wgrad_kernel(const WinoWgradParams p) {
+    constexpr int NT = 64 * WCI * WCO, CIB = 16 * WCI, COB = 32 * WCO, TB = 8, TBW = 4;
+    constexpr int RH = 6, RW = 10, NPX = RH * RW;
+    constexpr int RP = CIB + 4, VP = CIB + 16, ZP = COB + 16;
+    constexpr int XQ = CIB / 4;                                   // float4 per raw pixel
+    constexpr int XR = (NPX * XQ + NT - 1) / NT;
+    constexpr int VR = (TB * CIB) / NT > 0 ? (TB * CIB) / NT : 1; // V items per thread
+    constexpr int ZR = (TB * COB) / NT > 0 ? (TB * COB) / NT : 1; // Z items per thread
+    static_assert((TB * CIB) % NT == 0 || TB * CIB < NT, "V items");
+    static_assert((TB * COB) % NT == 0 || TB * COB < NT, "Z items");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* V = smem;                                              // [16][TB][VP]
+    float* Z = V + 16 * TB * VP;                                  // [16][TB][ZP]
+    float* raw = Z + 16 * TB * ZP;                                // [NPX][RP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int wi = wave % WCI, wo = wave / WCI;
+    int b_ = blockIdx.x;
+    const int cob = b_ % p.nCoB; b_ /= p.nCoB;
+    const int cib = b_ % p.nCiB;
+    const int split = b_ / p.nCiB;
+    const int ci0 = cib * CIB, co0 = cob * COB;
+
+    // block-invariant roles
+    int xoff[XR];                                                 // (ry << 16) | (rx << 8) | q, or -1
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * NT;
+        xoff[it] = -1;
+        if (idx < NPX * XQ) { const int pi = idx / XQ, q = idx - pi * XQ; xoff[it] = ((pi / RW) << 16) | ((pi % RW) << 8) | q; }
+    }
+    float4 xr[XR];
+    float dr[ZR][4];
+    auto load_block = [&](int blk) {
+        int t = blk;
+        const int bx = t % p.nbx; t /= p.nbx;
+        const int by = t % p.nby;
+        const int n = t / p.nby;
+        const int oy0 = 4 * by, ox0 = 8 * bx;                     // output origin of the 2 x 4 tile block
+        const float* xn = p.x + (long long)n * p.H * p.W * p.ldx + ci0;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xoff[it] >= 0) {
+                const int h = oy0 - 1 + (xoff[it] >> 16), w_ = ox0 - 1 + ((xoff[it] >> 8) & 255), q = xoff[it] & 255;
+                if ((unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                    xr[it] = *reinterpret_cast<const float4*>(xn + ((long long)h * p.W + w_) * p.ldx + 4 * q);
+            }
+        }
+        const float* dn = p.dy + (long long)n * p.H * p.W * p.lddy + co0;
+#pragma unroll
+        for (int z = 0; z < ZR; ++z) {
+            const int item = tid + z * NT;
+            const int co = item % COB, tile = item / COB;
+            const int oy = oy0 + 2 * (tile / TBW), ox = ox0 + 2 * (tile % TBW);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    dr[z][2 * a + b] = (item < TB * COB && oy + a < p.H && ox + b < p.W) ? dn[((long long)(oy + a) * p.W + ox + b) * p.lddy + co] : 0.f;
+        }
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float bsum[ZR];
+#pragma unroll
+    for (int z = 0; z < ZR; ++z) bsum[z] = 0.f;
+
+    const int a_off = kq * VP + 16 * wi + l16;                    // + (xi * TB + 4 * ks) * VP
+    const int b_off = kq * ZP + 32 * wo + l16;                    // + (xi * TB + 4 * ks) * ZP (+ 16 for the second block)
+
+    int blk = split;
+    if (blk < p.nblocks) load_block(blk);
+    for (; blk < p.nblocks; blk += p.splits) {
+        __syncthreads();                                          // the previous block's MFMAs have read V / Z; its V pass has read raw
+        // raw x block -> LDS; Z = A dY A^T straight from the prefetched registers
+#pragma unroll
+        for (int it = 0; it < XR; ++it)
+            if (xoff[it] >= 0) {
+                const int pi = (xoff[it] >> 16) * RW + ((xoff[it] >> 8) & 255), q = xoff[it] & 255;
+                *reinterpret_cast<float4*>(raw + pi * RP + 4 * q) = xr[it];
+            }
+#pragma unroll
+        for (int z = 0; z < ZR; ++z) {
+            const int item = tid + z * NT;
+            if (item < TB * COB) {
+                const int co = item % COB, tile = item / COB;
+                const float d00 = dr[z][0], d01 = dr[z][1], d10 = dr[z][2], d11 = dr[z][3];
+                bsum[z] += (d00 + d01) + (d10 + d11);
+                const float t_[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+                float* zp = Z + tile * ZP + co;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    zp[(4 * i + 0) * TB * ZP] = t_[i][0];
+                    zp[(4 * i + 1) * TB * ZP] = t_[i][0] + t_[i][1];
+                    zp[(4 * i + 2) * TB * ZP] = t_[i][0] - t_[i][1];
+                    zp[(4 * i + 3) * TB * ZP] = -t_[i][1];
+                }
+            }
+        }
+        __syncthreads();
+        // V = B^T d B per (tile, ci)
+#pragma unroll
+        for (int v = 0; v < VR; ++v) {
+            const int item = tid + v * NT;
+            if (item < TB * CIB) {
+                const int ci = item % CIB, tile = item / CIB;
+                const float* rp = raw + ((2 * (tile / TBW)) * RW + 2 * (tile % TBW)) * RP + ci;
+                float d[4][4], r[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[i][j] = rp[(i * RW + j) * RP];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r[0][j] = d[0][j] - d[2][j]; r[1][j] = d[1][j] + d[2][j];
+                    r[2][j] = d[2][j] - d[1][j]; r[3][j] = d[1][j] - d[3][j];
+                }
+                float* vp = V + tile * VP + ci;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    vp[(4 * a + 0) * TB * VP] = r[a][0] - r[a][2];
+                    vp[(4 * a + 1) * TB * VP] = r[a][1] + r[a][2];
+                    vp[(4 * a + 2) * TB * VP] = r[a][2] - r[a][1];
+                    vp[(4 * a + 3) * TB * VP] = r[a][1] - r[a][3];
+                }
+            }
+        }
+        __syncthreads();
+        if (blk + p.splits < p.nblocks) load_block(blk + p.splits);          // in flight during the MFMAs
+        {
+            constexpr int NS = 16 * (TB / 4);
+            float av[3], b0[3], b1[3];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int row = (s_ / (TB / 4)) * TB + 4 * (s_ % (TB / 4));
+                av[s_] = V[row * VP + a_off]; b0[s_] = Z[row * ZP + b_off]; b1[s_] = Z[row * ZP + b_off + 16];
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                if (s_ + 2 < NS) {
+                    const int row = ((s_ + 2) / (TB / 4)) * TB + 4 * ((s_ + 2) % (TB / 4));
+                    av[(s_ + 2) % 3] = V[row * VP + a_off]; b0[(s_ + 2) % 3] = Z[row * ZP + b_off]; b1[(s_ + 2) % 3] = Z[row * ZP + b_off + 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int x = s_ / (TB / 4);
+                acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_ % 3], b0[s_ % 3], acc[x][0], 0, 0, 0);
+                acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_ % 3], b1[s_ % 3], acc[x][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: dg = G^T dU G per lane; D rows (4 kq + r) = ci, col l16 = co
+    float* out = p.slab + (long long)split * 9 * p.Ci * p.Co;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int co = co0 + 32 * wo + 16 * b + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ci0 + 16 * wi + 4 * kq + r;
+            // rows: G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+            float t_[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u0 = acc[j][b][r], u1 = acc[4 + j][b][r], u2 = acc[8 + j][b][r], u3 = acc[12 + j][b][r];
+                t_[0][j] = u0 + 0.5f * (u1 + u2); t_[1][j] = 0.5f * (u1 - u2); t_[2][j] = 0.5f * (u1 + u2) + u3;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float g0 = t_[a][0] + 0.5f * (t_[a][1] + t_[a][2]);
+                const float g1 = 0.5f * (t_[a][1] - t_[a][2]);
+                const float g2 = 0.5f * (t_[a][1] + t_[a][2]) + t_[a][3];
+                out[((long long)(3 * a + 0) * p.Ci + ci) * p.Co + co] = g0;
+                out[((long long)(3 * a + 1) * p.Ci + ci) * p.Co + co] = g1;
+                out[((long long)(3 * a + 2) * p.Ci + ci) * p.Co + co] = g2;
+            }
+        }
+    }
+    if (p.bias_slab != nullptr && cib == 0) {
+        // items of a thread share the channel (NT % COB == 0): reduce over the threads with the same co through LDS
+        __syncthreads();
+        float s_ = 0.f;
+#pragma unroll
+        for (int z = 0; z < ZR; ++z) s_ += bsum[z];
+        float* red = smem;                                        // [NT]
+        red[tid] = (tid < TB * COB || ZR > 1) ? s_ : 0.f;
+        __syncthreads();
+        if (tid < COB) {
+            float t = 0.f;
+            for (int k = tid; k < NT; k += COB) t += red[k];
+            p.bias_slab[(long long)split * p.Co + co0 + tid] = t;
+        }
+    }
+}
+
+__global__ void wino_sum_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nslab,
+                                      const float* __restrict__ bslab, float* __restrict__ dbias, int Co, int accumulate_bias) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float s_ = 0.f;
+        const float* src = slab + i;
+        int k = 0;
+        for (; k + 3 < nslab; k += 4, src += 4 * n) { const float a = src[0], b = src[n], c = src[2 * n], d = src[3 * n]; s_ += a; s_ += b; s_ += c; s_ += d; }
+        for (; k < nslab; ++k, src += n) s_ += *src;
+        dw[i] = s_;
+    } else if (dbias != nullptr && i < n + Co) {
+        const int co = (int)(i - n);
+        float s_ = 0.f;
+        for (int k = 0; k < nslab; ++k) s_ += bslab[(long long)k * Co + co];
+        dbias[co] = accumulate_bias ? dbias[co] + s_ : s_;
+    }
+}
+
+struct WinoWgradPlan { WinoWgradParams p; int wci, wco; size_t lds; bool ok; };
+
+static void plan_wino_wgrad(WinoWgradPlan& pl, int N, int H, int W, int Ci, int Co) {
+    pl.ok = false;
+    int wci, wco;
+    if (Ci % 64 == 0 && Co % 64 == 0) { wci = 4; wco = 2; }
+    else if (Ci % 64 == 0 && Co % 32 == 0) { wci = 4; wco = 1; }
+    else if (Ci % 32 == 0 && Co % 64 == 0) { wci = 2; wco = 2; }
+    else return;
+    WinoWgradParams& p = pl.p;
+    p = WinoWgradParams{};
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
+    p.nby = mrdis_cdiv((H + 1) / 2, 2); p.nbx = mrdis_cdiv((W + 1) / 2, 4);
+    const long long nb = (long long)N * p.nby * p.nbx;
+    if (nb > 0x7fffffffLL) return;
+    p.nblocks = (int)nb;
+    const int CIB = 16 * wci, COB = 32 * wco;
+    p.nCiB = Ci / CIB; p.nCoB = Co / COB;
+    const int target = (wci * wco == 8) ? 256 : 512;
+    int splits = target / (p.nCiB * p.nCoB);
+    if (splits < 1) splits = 1;
+    if (splits > p.nblocks) splits = p.nblocks;
+    p.splits = splits;
+    pl.wci = wci; pl.wco = wco;
+    pl.lds = sizeof(float) * ((size_t)16 * 8 * (CIB + 16) + (size_t)16 * 8 * (COB + 16) + (size_t)60 * (CIB + 4));
+    pl.ok = true;
+}
+
+size_t mrdis_wino_wgrad_workspace(int N, int H, int W, int Ci, int Co) {
+    WinoWgradPlan pl;
+    plan_wino_wgrad(pl, N, H, W, Ci, Co);
+    if (!pl.ok) return 0;
+    return sizeof(float) * ((size_t)pl.p.splits * 9 * Ci * Co + (size_t)pl.p.splits * Co) + 256;
+}
+
+// returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers
+int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                         size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+    WinoWgradPlan pl;
+    plan_wino_wgrad(pl, N, H, W, Ci, Co);
+    if (!pl.ok || ldx % 4 != 0 || (((uintptr_t)x) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes < mrdis_wino_wgrad_workspace(N, H, W, Ci, Co) - 256) return MRDIS_EUNSUPPORTED;
+    WinoWgradParams& p = pl.p;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + (size_t)p.splits * 9 * Ci * Co : nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_wgrad_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_wgrad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    const int nblk = p.splits * p.nCiB * p.nCoB;
+    if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p);
+    else if (pl.wci == 4) hipLaunchKernelGGL((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p);
+    else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    const long long n = 9LL * Ci * Co;
+    hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 256)), dim3(256), 0, s, p.slab, dw_tck, n, p.splits,
+                       p.bias_slab, dbias, Co, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

@@ -101,6 +101,9 @@ WINO_CASES = [
     (1, 16, 48, 20, 20),      # cout tail inside a 64-wide tile
     (1, 24, 96, 18, 34),      # channel tail inside the last 8-channel chunk
     (3, 512, 128, 8, 8),      # deep reduction (64 chunks)
+    (2, 64, 32, 22, 30),      # weight gradient: 64 x 32 blocks (4 waves)
+    (2, 32, 64, 17, 21),      # weight gradient: 32 x 64 blocks, odd extents
+    (4, 128, 128, 32, 32),    # weight gradient: several (ci, co) blocks, several tile blocks per split
 ]
 
 
@@ -127,6 +130,9 @@ def test_conv_winograd_forced(mrdis, case, monkeypatch):
     close(y_w, y_direct, rtol=1e-4, what='winograd vs direct')
     close(hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True), F.leaky_relu(y, 0.2), rtol=1e-4, what='fwd+lrelu')
     close(hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), 3, 3, 1, 1), x.grad, rtol=1e-4, what='winograd dgrad')
+    dw, db = hip.conv2d_bwd_weight(cl(x.detach()), cl(gy), 3, 3, 1, 1, need_bias=True)     # Winograd where Ci / Co are 32 / 64 multiples
+    close(dw, to_tck(w.grad), rtol=2e-4, what='winograd wgrad')
+    close(db, gy.sum((0, 2, 3)), rtol=2e-4, what='dbias')
     wide = cl(torch.cat([rnd((N, 8, H, W), 9), x.detach()], 1))          # channel slice: ld = Ci + 8
     close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
 
