@@ -38,7 +38,9 @@ struct WinoParams {
 // MFMA (the matrix pipe at its peak rate) + 40 us V transform + 28 us U transform + 47 us staging, barriers,
 // epilogue -- the phases of one workgroup run back to back.  Splitting the 64-cout workgroup into two 4-wave ones
 // (32 tiles x 64 couts, or 64 tiles x 32 couts) to overlap them doubles one of the transforms and was slower
-// (243 us); for Cout = 32 nothing is duplicated and the overlap is worth 6 %.
+// (243 us); for Cout = 32 nothing is duplicated and the overlap is worth 6 %.  Transforming the filters once per call
+// in a pre-pass (16 loads per pair instead of 9 + G g G^T) was not faster either: the U phase is its loads and LDS
+// writes, not the arithmetic.
 template <int CG, int TG>
 __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
     constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
@@ -498,21 +500,31 @@ __global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino
     }
 }
 
+// dw[i] = sum over the split-K slabs, fixed order: block (64, SL) -- lane y sums slabs y, y + SL, ... with four loads in
+// flight, the SL partial sums meet in LDS in lane order (the first version walked all slabs in one thread: 0.3 TB/s)
 __global__ void wino_sum_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nslab,
                                       const float* __restrict__ bslab, float* __restrict__ dbias, int Co, int accumulate_bias) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[16][65];
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int SL = blockDim.y, y = threadIdx.y;
+    float s_ = 0.f;
     if (i < n) {
-        float s_ = 0.f;
-        const float* src = slab + i;
-        int k = 0;
-        for (; k + 3 < nslab; k += 4, src += 4 * n) { const float a = src[0], b = src[n], c = src[2 * n], d = src[3 * n]; s_ += a; s_ += b; s_ += c; s_ += d; }
-        for (; k < nslab; ++k, src += n) s_ += *src;
-        dw[i] = s_;
+        const float* src = slab + i + (long long)y * n;
+        const long long step = (long long)SL * n;
+        int k = y;
+        for (; k + 3 * SL < nslab; k += 4 * SL, src += 4 * step) { const float a = src[0], b = src[step], c = src[2 * step], d = src[3 * step]; s_ += a; s_ += b; s_ += c; s_ += d; }
+        for (; k < nslab; k += SL, src += step) s_ += *src;
     } else if (dbias != nullptr && i < n + Co) {
         const int co = (int)(i - n);
-        float s_ = 0.f;
-        for (int k = 0; k < nslab; ++k) s_ += bslab[(long long)k * Co + co];
-        dbias[co] = accumulate_bias ? dbias[co] + s_ : s_;
+        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * Co + co];
+    }
+    red[y][threadIdx.x] = s_;
+    __syncthreads();
+    if (y == 0) {
+        float t = 0.f;
+        for (int k = 0; k < SL; ++k) t += red[k][threadIdx.x];
+        if (i < n) dw[i] = t;
+        else if (dbias != nullptr && i < n + Co) { const int co = (int)(i - n); dbias[co] = accumulate_bias ? dbias[co] + t : t; }
     }
 }
 
@@ -576,7 +588,9 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
     else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p);
     MRDIS_CHECK_LAUNCH();
     const long long n = 9LL * Ci * Co;
-    hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 256)), dim3(256), 0, s, p.slab, dw_tck, n, p.splits,
+    int SL = 1;
+    while (SL < 16 && SL * 4 <= p.splits) SL <<= 1;
+    hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck, n, p.splits,
                        p.bias_slab, dbias, Co, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
