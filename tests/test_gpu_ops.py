@@ -104,6 +104,8 @@ WINO_CASES = [
     (2, 64, 32, 22, 30),      # weight gradient: 64 x 32 blocks (4 waves)
     (2, 32, 64, 17, 21),      # weight gradient: 32 x 64 blocks, odd extents
     (4, 128, 128, 32, 32),    # weight gradient: several (ci, co) blocks, several tile blocks per split
+    (1, 64, 64, 1, 1),        # a single pixel: every tile is partial
+    (2, 64, 64, 3, 5),        # smaller than one tile block
 ]
 
 
