@@ -160,21 +160,32 @@ template <int FIN>
 __global__ void stat_final_kernel(const float* __restrict__ part, int chunks, int C, int groups, long long P, float eps,
                                   float momentum, float* __restrict__ out0, float* __restrict__ out1,
                                   float* __restrict__ run_mean, float* __restrict__ run_var) {
-    __shared__ double red[2][4][64];
+    // block (64, SY <= 16): lane y sums chunks y, y + SY, ... (two loads pairs in flight), the SY partials meet in LDS in lane
+    // order.  With 4 lanes the 2 M-row BatchNorm layers (1000+ chunks) spent 70 us here on a serial chain of loads.
+    __shared__ double red[2][16][64];
     const int i = blockIdx.x * 64 + threadIdx.x;
+    const int SY = blockDim.y;
     const bool ok = i < groups * C;
     const int grp = ok ? i / C : 0, c = ok ? i - grp * C : 0;
     double s0 = 0.0, s1 = 0.0;
-    if (ok)
-        for (int k = threadIdx.y; k < chunks; k += 4) {
+    if (ok) {
+        int k = threadIdx.y;
+        for (; k + SY < chunks; k += 2 * SY) {
+            const float* a = part + ((long long)(grp * chunks + k) * 2) * C;
+            const float* b = part + ((long long)(grp * chunks + k + SY) * 2) * C;
+            const float a0 = a[c], a1 = a[C + c], b0 = b[c], b1 = b[C + c];
+            s0 += (double)a0; s1 += (double)a1; s0 += (double)b0; s1 += (double)b1;
+        }
+        for (; k < chunks; k += SY) {
             const float* src = part + ((long long)(grp * chunks + k) * 2) * C;
             s0 += (double)src[c]; s1 += (double)src[C + c];
         }
+    }
     red[0][threadIdx.y][threadIdx.x] = s0; red[1][threadIdx.y][threadIdx.x] = s1;
     __syncthreads();
     if (!ok || threadIdx.y != 0) return;
-    s0 = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
-    s1 = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    s0 = 0.0; s1 = 0.0;
+    for (int y = 0; y < SY; ++y) { s0 += red[0][y][threadIdx.x]; s1 += red[1][y][threadIdx.x]; }
     if (FIN == 0) {
         const double m = s0 / (double)P;
         double var = s1 / (double)P - m * m; if (var < 0.0) var = 0.0;
@@ -187,6 +198,8 @@ __global__ void stat_final_kernel(const float* __restrict__ part, int chunks, in
         }
     } else { out0[i] = (float)s0; out1[i] = (float)s1; }
 }
+
+static int stat_final_lanes(int chunks) { int y = 4; while (y < 16 && y * 8 < chunks) y <<= 1; return y; }
 
 template <int MODE>
 static int launch_stats(const float* a, int lda, const float* b, int ldb, const float* g, int ldg, const float* mean,
@@ -233,7 +246,7 @@ extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, co
     int rc = launch_stats<0>(x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
                        save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
@@ -308,7 +321,7 @@ extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     // dbeta = sum dy ; dgamma = sum dy * xhat
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
@@ -349,7 +362,7 @@ extern "C" int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* ga
     int rc = launch_stats<0>(z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
                        save_mean, save_rstd, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
@@ -403,7 +416,7 @@ extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float
     int rc = launch_stats<2>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, 4), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
     const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dz, lddz, C) &&
