@@ -216,6 +216,7 @@ def main():
                        'output_decoder': bool(a.recon_y)},
             'loss': round(host_losses['all'], 5),
             'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
+            'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)',
             'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
         }
         log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
