@@ -40,7 +40,8 @@ struct WinoParams {
 // (32 tiles x 64 couts, or 64 tiles x 32 couts) to overlap them doubles one of the transforms and was slower
 // (243 us); for Cout = 32 nothing is duplicated and the overlap is worth 6 %.  Transforming the filters once per call
 // in a pre-pass (16 loads per pair instead of 9 + G g G^T) was not faster either: the U phase is its loads and LDS
-// writes, not the arithmetic.
+// writes, not the arithmetic.  Two barriers per chunk instead of three (raw block of chunk c+1 written during the
+// MFMAs of chunk c) was 8 % slower (tools/ab_lib.py, same process).
 template <int CG, int TG>
 __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
     constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
