@@ -41,7 +41,10 @@ struct WinoParams {
 // (243 us); for Cout = 32 nothing is duplicated and the overlap is worth 6 %.  Transforming the filters once per call
 // in a pre-pass (16 loads per pair instead of 9 + G g G^T) was not faster either: the U phase is its loads and LDS
 // writes, not the arithmetic.  Two barriers per chunk instead of three (raw block of chunk c+1 written during the
-// MFMAs of chunk c) was 8 % slower (tools/ab_lib.py, same process).
+// MFMAs of chunk c) was 8 % slower (tools/ab_lib.py, same process).  Wave specialisation -- 8 multiplying waves + 4
+// transforming waves per workgroup, double-buffered XOR-swizzled U / V, producers fed straight from global memory,
+// one LDS-only barrier per chunk -- was parity-green but 25 % slower (283 us): the consumers alone took 148 us, the
+// producers alone 167 us, and together they ran almost back to back instead of side by side.
 template <int CG, int TG>
 __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
     constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
