@@ -780,6 +780,10 @@ static int check_conv_geom(int N, int H, int W, int Ci, int Co, int kh, int kw, 
 //     reaches L2 as 32-byte partial-line requests -- 7.4 M requests per launch instead of 1.8 M, and the L2
 //     request rate, not HBM, then bounds the kernel (measured: 58.6 -> 52.2 us in-cache, 106 -> 89 us
 //     beyond the 256 MB Infinity Cache).
+// cache policy of the output stores: bit 1 = NT (non-temporal).  The 236-268 MB output stream is not re-read by this
+// kernel and is as large as the Infinity Cache; marking it streaming keeps the halo rows of x resident: 53.5 -> 49.3 us at
+// 240x240, 68.0 -> 58.3 us at 256x256 (tools/ab_lib.py, 8 rounds).  SC0 / SC1 on top made no further difference.
+#define C4_STORE_NT 2
 struct C4Params {
     const float* x; const float* w; const float* bias; float* y;
     int N, H, W, ldx, Co, ldy;
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             for (int ns = 0; ns < NS; ++ns) {
                 float v = acc[ns][r];
                 if (LRELU) v = fmaxf(v, 0.2f * v);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)((vo | lane_ok_off[ns]) + 128u * ns), (int)soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)((vo | lane_ok_off[ns]) + 128u * ns), (int)soff, C4_STORE_NT);
             }
         }
     };

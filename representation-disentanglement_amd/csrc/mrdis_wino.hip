@@ -26,7 +26,7 @@
 struct WinoParams {
     const float* in; const float* w; const float* bias; float* out;
     int N, H, W, Cin, ldin, Cout, ldout;
-    int flip, lrelu;
+    int flip, lrelu, nt_out;      // nt_out: output stream larger than the caches can keep for its consumer -> non-temporal stores
     int TBH, TBW;                 // tile-block shape in tiles
     int nby, nbx, coTiles;        // tile blocks per image, cout tiles
 };
@@ -240,7 +240,10 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
                     if (p.lrelu) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                 }
                 float* dst = p.out + ((long long)(n * p.H + oy + dy) * p.W + ox + dx) * p.ldout + co;
-                if (vec_out && co + 3 < p.Cout) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (vec_out && co + 3 < p.Cout) {
+                    if (p.nt_out) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (co + r < p.Cout) dst[r] = v[r];
@@ -264,6 +267,7 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     p.in = x; p.w = w; p.bias = bias; p.out = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
     p.flip = flip; p.lrelu = lrelu;
+    { const char* e = getenv("MRDIS_NT_MB"); const long long mb = e ? atoll(e) : 128; p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
     const int CG = Co > 32 ? 2 : 1;
     p.TBH = 8; p.TBW = 8;
     const int th = (H + 1) / 2, tw = (W + 1) / 2;
