@@ -834,7 +834,9 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const int tpi = p.tilesW * p.tilesH;
     // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
     const int d_n = nwaves / tpi, d_rem = nwaves - d_n * tpi, d_th = d_rem / p.tilesW, d_tw = d_rem - d_th * p.tilesW;
-    int tile = (int)blockIdx.x * 4 + wave_in_blk;
+    // XCD-aware: workgroups b and b + 8 share an XCD (and its L2); give each XCD a contiguous run of strips per grid-stride round so
+    // that the strips above / below a strip (whose halo rows it re-reads) are fetched into the same L2
+    int tile = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wave_in_blk;
     if (tile >= ntiles) return;
     auto advance = [&](int& n, int& th, int& tw) {
         tw += d_tw; if (tw >= p.tilesW) { tw -= p.tilesW; th += 1; }
