@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void conv3d16_kernel(const Conv3dParams p, int
             if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
     };
 
-    int box = blockIdx.x;
+    int box = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // neighbouring boxes (shared halos) on the same XCD / L2
     if (box < nboxes) load_box(box);
     store_box();
     __syncthreads();
@@ -997,7 +997,8 @@ __global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p)
     int* tab_in = reinterpret_cast<int*>(smem + 2048);  // [128] position -> offset of its pixel in the x tile
     float* xs = smem + 2048 + 128;                      // [pixel][CW+1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
-    const int coc = blockIdx.x % p.nCo, cic = (blockIdx.x / p.nCo) % p.nCi, split = blockIdx.x / (p.nCo * p.nCi);
+    const int lb = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // the (cic, coc) workgroups of a split share x / dy boxes: same XCD
+    const int coc = lb % p.nCo, cic = (lb / p.nCo) % p.nCi, split = lb / (p.nCo * p.nCi);
     const int c_lo = cic * 16, co_lo = coc * 16;
     const int tinHW = p.TinH * p.TinW, npix_in = p.TinD * tinHW, thw = p.TH * p.TW;
 
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(256) void wgrad3d16_kernel(const Wgrad3d16Params p)
     }
     // cross-wave reduction through LDS in rounds of RS sub-tiles (fixed order), then slab[split][cic][st][16][16]
     float* red = smem;                                  // [4 waves][RS][256]
-    float* out = p.slab + ((long long)blockIdx.x * NST) * 256;
+    float* out = p.slab + ((long long)lb * NST) * 256;
 #pragma unroll
     for (int r0 = 0; r0 < NST; r0 += RS) {
         __syncthreads();

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
     const int wi = wave % WCI, wo = wave / WCI;
-    int b_ = blockIdx.x;
+    int b_ = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // the (cib, cob) workgroups of a split read the same x / dy tiles: same XCD, same L2
     const int cob = b_ % p.nCoB; b_ /= p.nCoB;
     const int cib = b_ % p.nCiB;
     const int split = b_ / p.nCiB;
