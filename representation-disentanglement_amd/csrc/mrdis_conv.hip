@@ -2087,6 +2087,9 @@ static size_t wgrad_need(const WgradPlan& pl) {
     return sizeof(float) * (size_t)(pl.slab_floats + pl.part_floats + pl.bias_floats) + 256;
 }
 
+size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
+int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                      size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 size_t mrdis_wino_wgrad_workspace(int N, int H, int W, int Ci, int Co);
 int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
                          size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
@@ -2111,6 +2114,8 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1) {           // either kernel may run (MRDIS_WINO is read per call)
         const size_t nw = mrdis_wino_wgrad_workspace(N, H, W, Ci, Co);
         if (nw > need) need = nw;
+        const size_t n16 = mrdis_wgrad16_workspace(N, H, W, Ci, Co);
+        if (n16 > need) need = n16;
     }
     return need;
 }
@@ -2147,6 +2152,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy,
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
     if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
+    if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
+        rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     if (wino_wgrad_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
         rc = mrdis_run_wino_wgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;

@@ -1,0 +1,205 @@
+// mrdis_wgrad16.hip -- weight (+ bias) gradient of a 3x3 / stride 1 / pad 1 layer with Cout <= 16 (sp6.out 32 -> 16 at
+// full resolution: 16 calls per step).  A 32x32 MFMA tile is half empty there (wgrad_dma_kernel: 50 TF/s); this is the
+// 2-D form of wgrad3d16_kernel (mrdis_conv3d.hip): v_mfma_f32_16x16x4_f32 with A = 16 input channels x 4 positions,
+// B = 4 positions x 16 couts; a wave keeps the accumulators of all 9 taps (36 registers), so one dy read feeds 9 MFMAs
+// and every A operand is one ds_read of the halo'd x box.  The waves of a workgroup split the 128 positions (8 x 16) of a
+// box; boxes are walked with a grid stride (split-K) with the next box's x / dy in flight in registers; Ci > 16 runs as
+// 16-channel slices (one workgroup column each); in-block wave reduction, fixed-order slab reduction.
+#include "mrdis_common.h"
+#include <stdlib.h>
+
+struct Wgrad16Params {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, Ci, ldx, Co, lddy;
+    int tilesA, tilesB, numTiles, nCi, splits;
+};
+
+#define W16_TH 8
+#define W16_TW 16
+#define W16_RW (W16_TW + 2)
+#define W16_NPX ((W16_TH + 2) * W16_RW)
+
+__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
+    constexpr int S = 17, XR = (W16_NPX * 4 + 255) / 256;          // 180 pixels x 4 float4 = 720 items
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dys = smem;                                  // [128][16]
+    float* xs = smem + 2048;                            // [pixel][17]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int lb = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int cic = lb % p.nCi, split = lb / p.nCi;
+    const int c_lo = cic * 16;
+
+    int loff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) loff[t] = ((t / 3) * W16_RW + (t % 3)) * S + l16;
+    const bool ci_ok = (c_lo + l16) < p.Ci;
+    int tin[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int m = wave * 32 + g * 4 + kq;
+        tin[g] = ((m / W16_TW) * W16_RW + (m % W16_TW)) * S;
+    }
+    int xl[XR], xc[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 256;
+        xl[it] = -1; xc[it] = 0;
+        if (idx < W16_NPX * 4) { const int pi = idx >> 2, q = idx & 3; xl[it] = pi * S + 4 * q; xc[it] = ((pi / W16_RW) << 10) | (pi % W16_RW); }
+    }
+    const int qx = c_lo + (tid & 3) * 4;
+    const bool qx_ok = qx < p.Ci;
+    int yc[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { const int m = (tid + it * 256) >> 2; yc[it] = ((m / W16_TW) << 10) | (m % W16_TW); }
+    const int qy = (tid & 3) * 4;
+    const bool qy_ok = qy < p.Co;
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    float4 xr[XR], yr[2];
+    auto load_box = [&](int box) {
+        int tt = box;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int n = tt / p.tilesA;
+        const int a0 = ta * W16_TH, b0 = tb * W16_TW;
+        const float* __restrict__ xn = p.x + (long long)n * p.H * p.W * p.ldx + qx;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int h = a0 - 1 + (xc[it] >> 10), w_ = b0 - 1 + (xc[it] & 1023);
+            if (xl[it] >= 0 && qx_ok && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                xr[it] = *reinterpret_cast<const float4*>(xn + ((long long)h * p.W + w_) * p.ldx);
+        }
+        const float* __restrict__ dyn = p.dy + (long long)n * p.H * p.W * p.lddy + qy;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            yr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int a = a0 + (yc[it] >> 10), b = b0 + (yc[it] & 1023);
+            if (qy_ok && a < p.H && b < p.W) yr[it] = *reinterpret_cast<const float4*>(dyn + ((long long)a * p.W + b) * p.lddy);
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it)
+            if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) *reinterpret_cast<float4*>(dys + 4 * (tid + it * 256)) = yr[it];
+    };
+
+    int box = split;
+    if (box < p.numTiles) load_box(box);
+    store_box();
+    __syncthreads();
+    for (; box < p.numTiles; box += p.splits) {
+        const int nxt = box + p.splits;
+        if (nxt < p.numTiles) load_box(nxt);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float bv = dys[(wave * 32 + g * 4 + kq) * 16 + l16];
+            bsum += bv;
+            const float* xa = xs + tin[g];
+            float av[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) av[t] = ci_ok ? xa[loff[t]] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[t], 0, 0, 0);
+        }
+        if (nxt < p.numTiles) { __syncthreads(); store_box(); __syncthreads(); }
+    }
+    // cross-wave reduction through LDS (fixed order), then slab[split][cic][tap][16 ci][16 co]
+    float* red = smem;                                  // [4 waves][9][256] = 9216 floats (host sizes the LDS for it)
+    float* out = p.slab + ((long long)lb * 9) * 256;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 9 + t) * 256 + (4 * kq + r) * 16 + l16] = acc[t][r];
+    __syncthreads();
+    for (int i = tid; i < 9 * 256; i += 256)
+        out[i] = (red[i] + red[9 * 256 + i]) + (red[2 * 9 * 256 + i] + red[3 * 9 * 256 + i]);
+    if (p.bias_slab != nullptr && cic == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        __syncthreads();
+        if (kq == 0) red[wave * 16 + l16] = bsum;
+        __syncthreads();
+        if (tid < 16) p.bias_slab[(long long)split * 16 + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+    }
+}
+
+__global__ void wgrad16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int nCi, int nslab,
+                                      const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
+    __shared__ float red[16][65];
+    const int total = 9 * Ci * Co;
+    const int nout = total + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int SL = blockDim.y, y = threadIdx.y;
+    float s_ = 0.f;
+    if (i < total) {
+        const int co = i % Co;
+        const int r = i / Co;
+        const int ci = r % Ci, t = r / Ci;
+        const long long stride = (long long)nCi * 9 * 256;
+        const float* src = slab + ((long long)(ci >> 4) * 9 + t) * 256 + (ci & 15) * 16 + co + (long long)y * stride;
+        for (int k = y; k < nslab; k += SL, src += (long long)SL * stride) s_ += *src;
+    } else if (i < nout) {
+        const int co = i - total;
+        for (int k = y; k < nslab; k += SL) s_ += bslab[(long long)k * 16 + co];
+    }
+    red[y][threadIdx.x] = s_;
+    __syncthreads();
+    if (y == 0 && i < nout) {
+        float t = 0.f;
+        for (int k = 0; k < SL; ++k) t += red[k][threadIdx.x];
+        if (i < total) dw[i] = t;
+        else { const int co = i - total; dbias[co] = accumulate_bias ? dbias[co] + t : t; }
+    }
+}
+
+static bool plan_wgrad16(Wgrad16Params& p, int N, int H, int W, int Ci, int Co) {
+    if (Co > 16 || Co <= 4 || Co % 4 != 0 || Ci % 16 != 0) return false;               // Cout <= 4: wgrad_thin_dma_kernel
+    if ((long long)N * H * W < 100000 || getenv("MRDIS_DEBUG_NOW16")) return false;       // small maps: the generic kernel's slabs are cheaper
+    p = Wgrad16Params{};
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
+    p.tilesA = mrdis_cdiv(H, W16_TH); p.tilesB = mrdis_cdiv(W, W16_TW);
+    const long long nt = (long long)N * p.tilesA * p.tilesB;
+    if (nt > 0x7fffffffLL) return false;
+    p.numTiles = (int)nt;
+    p.nCi = Ci / 16;
+    int splits = 1024 / p.nCi;
+    if (splits > p.numTiles) splits = p.numTiles;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    return true;
+}
+
+size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co) {
+    Wgrad16Params p;
+    if (!plan_wgrad16(p, N, H, W, Ci, Co)) return 0;
+    return sizeof(float) * ((size_t)p.splits * p.nCi * 9 * 256 + (size_t)p.splits * 16) + 256;
+}
+
+// returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers
+int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                      size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+    Wgrad16Params p;
+    if (!plan_wgrad16(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    if (ldx % 4 != 0 || lddy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wgrad16_workspace(N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + (size_t)p.splits * p.nCi * 9 * 256 : nullptr;
+    const size_t lds = sizeof(float) * (size_t)(4 * 9 * 256);           // reduction buffer (36 KB) >= dys + x box (20 KB)
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(p.splits * p.nCi), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    const long long nout = 9LL * Ci * Co + (dbias ? Co : 0);
+    int SL = 1;
+    while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;
+    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co, p.nCi, p.splits,
+                       p.bias_slab, dbias, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

@@ -139,6 +139,19 @@ def test_conv_winograd_forced(mrdis, case, monkeypatch):
     close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
 
 
+@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 32, 16, 240, 232), (1, 16, 8, 321, 333), (3, 48, 12, 200, 180)])
+def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
+    """mrdis_wgrad16.hip: weight / bias gradient of 3x3 s1 layers with 8..16 couts on large maps (sp6.out), 16-channel input
+    slices, ragged boxes at the right / bottom edges, a cout count that is not 16."""
+    x = rnd((N, Ci, H, W), 1); gy = rnd((N, Co, H, W), 2)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    F.conv2d(x, w, b, 1, 1).backward(gy)
+    dw, db = mrdis.hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+    close(dw, to_tck(w.grad), rtol=2e-4, what='wgrad16')
+    close(db, b.grad, rtol=2e-4, what='dbias')
+
+
 def test_conv_c4_persistent_pipeline(mrdis):
     """Cin = 4 direct kernel with enough strips (> 2 per resident wave) to run its steady-state
     register pipeline, ragged right edge included; with bias and fused LeakyReLU."""
