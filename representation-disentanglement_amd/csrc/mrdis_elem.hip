@@ -481,7 +481,7 @@ template <int V>
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N, int Hi, int Wi, int Ho, int Wo,
                                     int C, int align, float sh, float sw) {
     const int Q = C / V;
-    const int ho = blockIdx.x, n = blockIdx.y;
+    const int ho = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;   // XCD-aware: neighbouring output rows read the same two input rows -> same L2
     const BilAxis ah = bil_axis(ho, sh, align, Hi);
     const float* r0 = x + ((long long)n * Hi + ah.i0) * Wi * ldx;
     const float* r1 = x + ((long long)n * Hi + ah.i1) * Wi * ldx;
@@ -519,7 +519,7 @@ template <int V>
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo,
                                     int C, int align, float sh, float sw) {
     const int Q = C / V;
-    const int hi = blockIdx.x, n = blockIdx.y;
+    const int hi = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;   // XCD-aware: neighbouring input rows gather from the same output rows
     int hlo, hhi;
     bil_range(hi, sh, align, Ho, &hlo, &hhi);
     const float* base = dy + (long long)n * Ho * Wo * lddy;
