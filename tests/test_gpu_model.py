@@ -254,6 +254,36 @@ def test_train_step_vs_oracle_other_sizes(mrdis, B, M, H, W, drop, adv):
             assert p.grad is None, n
 
 
+def test_train_step_winograd_vs_direct_kernels(mrdis, monkeypatch):
+    """The whole step with every eligible 3x3 layer forced through the Winograd kernels (MRDIS_WINO=2: forward, data and
+    weight gradients) against the same step on the direct kernels (MRDIS_WINO=0): loss, loss parts and every parameter
+    gradient.  The size policy (MRDIS_WINO=1) only picks per layer between these two."""
+    B, M, H, W = 2, 3, 96, 128
+    res = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('MRDIS_WINO', mode)
+        cfg = _cfg(mrdis, M, H, W, B, adv=True)
+        torch.manual_seed(10); np.random.seed(10)
+        model = mrdis.build_model(cfg).train()
+        inputs, mask, mask_img = make_inputs(B, M, H, W, seed=4, drop=True)
+        torch.manual_seed(11); np.random.seed(11)
+        with mrdis.ops.mix_cache():
+            loss, parts, _ = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+            loss.backward()
+        res[mode] = (float(loss), {k: float(v) for k, v in parts.items()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, p0, g0), (l2, p2, g2) = res['0'], res['2']
+    assert l0 != l2 or any(not torch.equal(g0[n], g2[n]) for n in g0), 'MRDIS_WINO=2 did not change the kernels'
+    assert abs(l0 - l2) <= 1e-4 * abs(l0)
+    for k in p0:
+        assert abs(p0[k] - p2[k]) <= 1e-4 * abs(p0[k]) + 1e-7, k
+    assert set(g0) == set(g2)
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g0.values())))
+    for n in g0:
+        err = float((g0[n] - g2[n]).abs().max())
+        assert err <= 1e-3 * float(g0[n].abs().max()) + 1e-6 * tot, (n, err)
+
+
 def test_train_step_runs_twice_and_decreases_nothing_nan(mrdis):
     cfg = _cfg(mrdis, 2, 64, 64, 2)
     torch.manual_seed(0)
