@@ -152,6 +152,39 @@ def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
     close(db, b.grad, rtol=2e-4, what='dbias')
 
 
+@pytest.mark.parametrize('wino', ['1', '2'])
+def test_conv_random_shapes(mrdis, wino, monkeypatch):
+    """Seeded sweep over the dispatcher (direct MFMA / narrow / Cin = 4 / thin / Winograd / narrow-cout weight gradient):
+    random channel counts (tile multiples and not), extents down to 1x1, kernels 1 / 3 / 4, strides 1 / 2 -- forward,
+    data gradient, weight and bias gradient against torch fp32 on the CPU."""
+    monkeypatch.setenv('MRDIS_WINO', wino)
+    g = np.random.RandomState(1234 + int(wino))
+    hip = mrdis.hip
+    chans = [1, 3, 4, 7, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128]
+    for case in range(36):
+        k = int(g.choice([1, 3, 3, 3, 4]))
+        stride = int(g.choice([1, 1, 2]))
+        pad = 0 if k == 1 else 1
+        if k == 1:
+            stride = 1              # 1x1 stride 2 is not a geometry of the reference; its data gradient reports MRDIS_EUNSUPPORTED
+        N = int(g.randint(1, 4)); Ci = int(g.choice(chans)); Co = int(g.choice(chans))
+        H = int(g.randint(k if pad == 0 else max(1, k - 2), 48)); W = int(g.randint(k if pad == 0 else max(1, k - 2), 60))
+        if (H + 2 * pad - k) // stride + 1 <= 0 or (W + 2 * pad - k) // stride + 1 <= 0:
+            continue
+        x = rnd((N, Ci, H, W), 10 + case).requires_grad_(True)
+        w = rnd((Co, Ci, k, k), 100 + case, 0.2).requires_grad_(True)
+        b = rnd((Co,), 200 + case, 0.1).requires_grad_(True)
+        y = F.conv2d(x, w, b, stride, pad)
+        gy = rnd(tuple(y.shape), 300 + case)
+        y.backward(gy)
+        tag = f'case {case}: N{N} {Ci}->{Co} {H}x{W} k{k} s{stride}'
+        close(hip.conv2d_fwd(cl(x.detach()), to_tck(w.detach()).to(dev()), b.detach().to(dev()), k, k, stride, pad), y, rtol=2e-4, what=tag + ' fwd')
+        close(hip.conv2d_bwd_data(cl(gy), to_tkc(w.detach()).to(dev()), (H, W), k, k, stride, pad), x.grad, rtol=2e-4, what=tag + ' dgrad')
+        dw, db = hip.conv2d_bwd_weight(cl(x.detach()), cl(gy), k, k, stride, pad, need_bias=True)
+        close(dw, to_tck(w.grad), rtol=3e-4, what=tag + ' wgrad')
+        close(db, b.grad, rtol=3e-4, what=tag + ' dbias')
+
+
 def test_conv_c4_persistent_pipeline(mrdis):
     """Cin = 4 direct kernel with enough strips (> 2 per resident wave) to run its steady-state
     register pipeline, ragged right edge included; with bias and fused LeakyReLU."""
