@@ -552,6 +552,21 @@ static int check_conv3d_geom(int N, int D, int H, int W, int Ci, int Co, int k, 
     return MRDIS_OK;
 }
 
+// hybrid Winograd path (mrdis_wino.hip): F(2x2,3x3) in (h, w), direct in depth
+int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias, const float* res, int ldres, float* y, int ldy,
+                     int N, int D, int H, int W, int Ci, int Co, int flip, hipStream_t s);
+// measured policy (tools/bench3d.py --layers): MRDIS_WINO = 0 never | 1 where it wins | 2 wherever it applies
+static bool wino3d_wanted(int N, int D, int H, int W, int Ci, int Co, int stride) {
+    const char* e = getenv("MRDIS_WINO");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || stride != 1) return false;
+    if (mode == 2) return Ci >= 8 && Co >= 8;
+    if (Ci < 16 || Co < 32) return false;
+    const int cg = Co > 32 ? 2 : 1;
+    const long long nblk = (long long)N * D * mrdis_cdiv((H + 1) / 2, 8) * mrdis_cdiv((W + 1) / 2, 8) * mrdis_cdiv(Co, 32 * cg);
+    return nblk >= (cg == 2 ? 256 : 512);
+}
+
 extern "C" int mrdis_conv3d_fwd(const float* x, int ldx, const float* w_tck, const float* bias, const float* residual, int ldres,
                                 float* y, int ldy, int N, int D, int H, int W, int Ci, int Co,
                                 int k, int stride, int pad, void* stream) {
@@ -559,6 +574,10 @@ extern "C" int mrdis_conv3d_fwd(const float* x, int ldx, const float* w_tck, con
     int rc = check_conv3d_geom(N, D, H, W, Ci, Co, k, stride, pad, &Do, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co || (residual && ldres < Co)) return MRDIS_EINVAL;
+    if (wino3d_wanted(N, D, H, W, Ci, Co, stride)) {
+        rc = mrdis_run_wino3d(x, ldx, w_tck, bias, residual, ldres, y, ldy, N, D, H, W, Ci, Co, 0, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     Conv3dParams p{};
     p.in = x; p.w = w_tck; p.bias = bias; p.res = residual; p.out = y;
     p.N = N; p.Din = D; p.Hin = H; p.Win = W; p.Cin = Ci; p.ldin = ldx;
@@ -586,6 +605,10 @@ extern "C" int mrdis_conv3d_bwd_data(const float* dy, int lddy, const float* w_t
     base.Dout = D; base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
     base.is = 1;
     if (stride == 1) {
+        if (wino3d_wanted(N, D, H, W, Co, Ci, stride)) {
+            rc = mrdis_run_wino3d(dy, lddy, w_tkc, nullptr, nullptr, 0, dx, lddx, N, D, H, W, Co, Ci, 1, (hipStream_t)stream);
+            if (rc != MRDIS_EUNSUPPORTED) return rc;
+        }
         Conv3dParams p = base;
         p.Z = D; p.A = H; p.B = W; p.os = 1;
         p.ntaps = k * k * k;

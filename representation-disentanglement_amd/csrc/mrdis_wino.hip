@@ -25,6 +25,8 @@
 
 struct WinoParams {
     const float* in; const float* w; const float* bias; float* out;
+    const float* res; int ldres;   // D3: residual added in the epilogue (BasicBlock), or nullptr
+    int D;                        // D3: planes per sample; N counts output planes (samples x D), the filter has 27 taps
     int N, H, W, Cin, ldin, Cout, ldout;
     int flip, lrelu, nt_out;      // nt_out: output stream larger than the caches can keep for its consumer -> non-temporal stores
     int TBH, TBW;                 // tile-block shape in tiles
@@ -45,7 +47,10 @@ struct WinoParams {
 // transforming waves per workgroup, double-buffered XOR-swizzled U / V, producers fed straight from global memory,
 // one LDS-only barrier per chunk -- was parity-green but 25 % slower (283 us): the consumers alone took 148 us, the
 // producers alone 167 us, and together they ran almost back to back instead of side by side.
-template <int CG, int TG>
+// D3: the 3x3x3 layers of the 3-D nets as a hybrid -- Winograd F(2x2,3x3) in (h, w), direct in depth: an output plane d is
+// sum over kd of the 2-D Winograd convolution of input plane d + kd - 1 with the 3x3 slice kd of the filter, i.e. the same
+// kernel with (kd, ci) as the reduction axis (a chunk whose plane lies outside the volume contributes zeros).
+template <int CG, int TG, bool D3 = false>
 __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
     constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
     constexpr int BN = 32 * CG, T = 16 * TG;
@@ -88,21 +93,31 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
     const bool f_on = (co0 + fco) < p.Cout;
     float4 xr[XR];
     float gr[UR][9];
-    auto load_chunk = [&](int c0) {
+    const int nch = (p.Cin + KC - 1) / KC, nchunks = D3 ? 3 * nch : nch;
+    const int dpl = D3 ? n % p.D : 0;                  // depth of this workgroup's output plane
+    const int plane_pitch = p.H * p.W * p.ldin;
+    auto load_chunk = [&](int cc) {
+        const int kd = D3 ? cc / nch : 1;
+        const int c0 = (D3 ? cc - kd * nch : cc) * KC;
+        const bool plane_ok = !D3 || (unsigned)(dpl + kd - 1) < (unsigned)p.D;
+        const int xshift = D3 ? (kd - 1) * plane_pitch : 0;
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int q4 = 4 * ((tid + it * NT) & 1);
-            if (xg[it] >= 0 && c0 + q4 < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + c0);
+            if (plane_ok && xg[it] >= 0 && c0 + q4 < p.Cin) xr[it] = *reinterpret_cast<const float4*>(p.in + xg[it] + xshift + c0);
         }
         const long long tstride = (long long)p.Cin * p.Cout;
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const int k = fk + u * (NT / BN);
-            const bool on = f_on && (c0 + k) < p.Cin;
+            const bool on = f_on && plane_ok && (c0 + k) < p.Cin;
             const float* wp = p.w + ((long long)(c0 + k)) * p.Cout + co0 + fco;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) gr[u][t] = on ? wp[(p.flip ? 8 - t : t) * tstride] : 0.f;
+            for (int t = 0; t < 9; ++t) {
+                const int ti = D3 ? kd * 9 + t : t;
+                gr[u][t] = on ? wp[(p.flip ? (D3 ? 26 : 8) - ti : ti) * tstride] : 0.f;
+            }
         }
     };
     auto store_chunk = [&]() {
@@ -139,8 +154,8 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
     const int b_off = kq * TS + 16 * tg + l16;        // + (xi * KC + 4 * ks) * TS
 
     load_chunk(0);
-    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
-        if (c0) __syncthreads();                      // the previous chunk's MFMAs have read U / V
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc) __syncthreads();                      // the previous chunk's MFMAs have read U / V
         store_chunk();
         __syncthreads();
 #ifndef WINO_ABL_NOV
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
         }
 #endif
         __syncthreads();
-        if (c0 + KC < p.Cin) load_chunk(c0 + KC);      // global loads in flight during the MFMAs
+        if (cc + 1 < nchunks) load_chunk(cc + 1);      // global loads in flight during the MFMAs
 #ifndef WINO_ABL_NOMFMA
         // 32 steps (xi, 4-channel group), operands fetched two steps ahead of the MFMAs that use them (three rotating
         // register sets; the sched_barriers keep hipcc from sinking the reads back next to their use -- left alone it
@@ -239,6 +254,11 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
                     v[r] = y[dy][dx][r] + bq[r];
                     if (p.lrelu) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                 }
+                if (D3 && p.res != nullptr) {
+                    const float* rs = p.res + ((long long)(n * p.H + oy + dy) * p.W + ox + dx) * p.ldres + co;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co + r < p.Cout) v[r] += rs[r];
+                }
                 float* dst = p.out + ((long long)(n * p.H + oy + dy) * p.W + ox + dx) * p.ldout + co;
                 if (vec_out && co + 3 < p.Cout) {
                     if (p.nt_out) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(dst));
@@ -285,6 +305,36 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
     if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), dim3((int)nblk), dim3(512), lds, s, p);
     else hipLaunchKernelGGL((wino_conv_kernel<1, 4>), dim3((int)nblk), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// hybrid 3-D entry (see wino_conv_kernel D3): x (N, D, H, W, Ci) -> y (N, D, H, W, Co), 27-tap filter [27][Ci][Co]
+int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias, const float* res, int ldres, float* y, int ldy,
+                     int N, int D, int H, int W, int Ci, int Co, int flip, hipStream_t s) {
+    if (Ci % 4 != 0 || ldx % 4 != 0 || (((uintptr_t)x) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * D * H * W * ldx >= 0x7fffffffLL || (long long)N * D * H * W * ldy >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    WinoParams p{};
+    p.in = x; p.w = w; p.bias = bias; p.out = y; p.res = res; p.ldres = ldres;
+    p.D = D; p.N = N * D; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
+    p.flip = flip; p.lrelu = 0;
+    { const char* e = getenv("MRDIS_NT_MB"); const long long mb = e ? atoll(e) : 128; p.nt_out = (long long)N * D * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
+    const int CG = Co > 32 ? 2 : 1;
+    p.TBH = 8; p.TBW = 8;
+    p.nby = mrdis_cdiv((H + 1) / 2, p.TBH); p.nbx = mrdis_cdiv((W + 1) / 2, p.TBW);
+    p.coTiles = mrdis_cdiv(Co, 32 * CG);
+    const long long nblk = (long long)p.N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wino_conv_kernel<1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_conv_kernel<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
+    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4, true>), dim3((int)nblk), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((wino_conv_kernel<1, 4, true>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

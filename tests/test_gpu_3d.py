@@ -71,6 +71,34 @@ def test_conv3d_fwd_bwd(mrdis, N, Ci, Co, D, H, W, stride):
     close(conv.bias.grad, br.grad, 1e-3, 'bgrad')
 
 
+@pytest.mark.parametrize('N,Ci,Co,D,H,W', [(1, 32, 32, 6, 20, 24), (2, 64, 64, 3, 9, 11), (1, 16, 48, 5, 16, 16), (1, 128, 32, 2, 8, 8)])
+def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W, monkeypatch):
+    """3x3x3 stride-1 layers through the hybrid kernel (Winograd F(2x2,3x3) in (h, w), direct in depth; mrdis_wino.hip D3)
+    forced on for shapes the size policy would leave to the direct kernel: forward with bias + fused residual, data
+    gradient (reversed 27-tap filter), planes at the volume boundary, odd extents, cout / channel tails."""
+    x = seeded((N, Ci, D, H, W), 1); w = seeded((Co, Ci, 3, 3, 3), 2, 0.1); b = seeded((Co,), 3)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, b, padding=1)
+    res = seeded(tuple(y_ref.shape), 4)
+    y_ref = y_ref + res
+    dy = seeded(tuple(y_ref.shape), 5)
+    y_ref.backward(dy)
+    conv = mrdis.HipConv3d(Ci, Co, (3, 3, 3), padding=(1, 1, 1)).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+    outs = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('MRDIS_WINO', mode)
+        xg = cl3(x).requires_grad_(True)
+        y = conv(xg, residual=cl3(res))
+        y.backward(cl3(dy))
+        outs[mode] = (y.detach(), xg.grad.detach())
+        close(y, y_ref, 1e-3, f'fwd mode {mode}'); close(xg.grad, xr.grad, 1e-3, f'dgrad mode {mode}')
+        conv.zero_grad()
+    assert not torch.equal(outs['0'][0], outs['2'][0])          # really another kernel
+    close(outs['2'][0], outs['0'][0], 1e-4, 'hybrid vs direct fwd'); close(outs['2'][1], outs['0'][1], 1e-4, 'hybrid vs direct dgrad')
+
+
 def test_conv3d_pointwise(mrdis):
     x = seeded((2, 32, 4, 6, 8), 1); w = seeded((16, 32, 1, 1, 1), 2, 0.2); b = seeded((16,), 3)
     xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
