@@ -555,6 +555,17 @@ static int check_conv3d_geom(int N, int D, int H, int W, int Ci, int Co, int k, 
 // hybrid Winograd path (mrdis_wino.hip): F(2x2,3x3) in (h, w), direct in depth
 int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias, const float* res, int ldres, float* y, int ldy,
                      int N, int D, int H, int W, int Ci, int Co, int flip, hipStream_t s);
+size_t mrdis_wino_wgrad3d_workspace(int N, int D, int H, int W, int Ci, int Co);
+int mrdis_run_wino_wgrad3d(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                           size_t workspace_bytes, int N, int D, int H, int W, int Ci, int Co, hipStream_t s);
+static bool wino3d_wgrad_wanted(int N, int D, int H, int W, int Ci, int Co, int stride) {
+    const char* e = getenv("MRDIS_WINO");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || stride != 1 || mrdis_wino_wgrad3d_workspace(N, D, H, W, Ci, Co) == 0) return false;
+    if (mode == 2) return true;
+    if (Co % 64 != 0 && Ci < 128) return false;
+    return (long long)N * D * ((H + 3) / 4) * ((W + 7) / 8) >= 256;
+}
 // measured policy (tools/bench3d.py --layers): MRDIS_WINO = 0 never | 1 where it wins | 2 wherever it applies
 static bool wino3d_wanted(int N, int D, int H, int W, int Ci, int Co, int stride) {
     const char* e = getenv("MRDIS_WINO");
@@ -1233,6 +1244,7 @@ extern "C" size_t mrdis_conv3d_bwd_weight_workspace(int N, int D, int H, int W, 
     Wgrad3d16Plan p16;
     plan_wgrad3d16(p16, N, D, H, W, Ci, Ci, Co, stride);
     if (p16.ok) { const size_t n16 = sizeof(float) * (size_t)(p16.slab_floats + p16.bias_floats) + 256; if (n16 > need) need = n16; }
+    if (stride == 1) { const size_t nw = mrdis_wino_wgrad3d_workspace(N, D, H, W, Ci, Co); if (nw > need) need = nw; }
     return need;
 }
 
@@ -1259,6 +1271,10 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
     if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     hipStream_t s = (hipStream_t)stream;
+    if (wino3d_wgrad_wanted(N, D, H, W, Ci, Co, stride)) {
+        rc = mrdis_run_wino_wgrad3d(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, D, H, W, Ci, Co, s);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     {
         Wgrad3d16Plan p16;
         plan_wgrad3d16(p16, N, D, H, W, ldx, Ci, Co, stride);

@@ -357,9 +357,11 @@ struct WinoWgradParams {
     int N, H, W, Ci, ldx, Co, lddy;
     int nby, nbx, nblocks;        // tile blocks (2 x 4 tiles) per image row / column, total
     int nCiB, nCoB, splits;
+    int D, kd;                    // hybrid 3-D form: N counts planes (samples x D); x is read from plane + kd - 1 of the same sample
 };
 
-template <int WCI, int WCO>       // waves along ci (16 each) x waves along co (32 each)
+// D3: slice kd of a 3x3x3 filter gradient = the 2-D gradient between dy plane d and x plane d + kd - 1 (three launches)
+template <int WCI, int WCO, bool D3 = false>       // waves along ci (16 each) x waves along co (32 each)
 __global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino_wgrad_kernel(const WinoWgradParams p) {
     constexpr int NT = 64 * WCI * WCO, CIB = 16 * WCI, COB = 32 * WCO, TB = 8, TBW = 4;
     constexpr int RH = 6, RW = 10, NPX = RH * RW;
@@ -399,11 +401,12 @@ __global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino
         const int by = t % p.nby;
         const int n = t / p.nby;
         const int oy0 = 4 * by, ox0 = 8 * bx;                     // output origin of the 2 x 4 tile block
-        const float* xn = p.x + (long long)n * p.H * p.W * p.ldx + ci0;
+        const bool plane_ok = !D3 || (unsigned)(n % p.D + p.kd - 1) < (unsigned)p.D;
+        const float* xn = p.x + (long long)(D3 ? n + p.kd - 1 : n) * p.H * p.W * p.ldx + ci0;
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             xr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xoff[it] >= 0) {
+            if (plane_ok && xoff[it] >= 0) {
                 const int h = oy0 - 1 + (xoff[it] >> 16), w_ = ox0 - 1 + ((xoff[it] >> 8) & 255), q = xoff[it] & 255;
                 if ((unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
                     xr[it] = *reinterpret_cast<const float4*>(xn + ((long long)h * p.W + w_) * p.ldx + 4 * q);
@@ -651,5 +654,45 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
     hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck, n, p.splits,
                        p.bias_slab, dbias, Co, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// hybrid 3-D weight gradient: dw_tck [27][Ci][Co], three launches of the 2-D kernel (one per depth tap)
+size_t mrdis_wino_wgrad3d_workspace(int N, int D, int H, int W, int Ci, int Co) { return mrdis_wino_wgrad_workspace(N * D, H, W, Ci, Co); }
+
+int mrdis_run_wino_wgrad3d(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                           size_t workspace_bytes, int N, int D, int H, int W, int Ci, int Co, hipStream_t s) {
+    WinoWgradPlan pl;
+    plan_wino_wgrad(pl, N * D, H, W, Ci, Co);
+    if (!pl.ok || ldx % 4 != 0 || (((uintptr_t)x) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wino_wgrad3d_workspace(N, D, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    WinoWgradParams& p = pl.p;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy; p.D = D;
+    p.slab = reinterpret_cast<float*>(workspace);
+    float* bias_slab = p.slab + (size_t)p.splits * 9 * Ci * Co;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wino_wgrad_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_wgrad_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wino_wgrad_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    const int nblk = p.splits * p.nCiB * p.nCoB;
+    const long long n = 9LL * Ci * Co;
+    int SL = 1;
+    while (SL < 16 && SL * 4 <= p.splits) SL <<= 1;
+    for (int kd = 0; kd < 3; ++kd) {
+        p.kd = kd;
+        p.bias_slab = (dbias && kd == 1) ? bias_slab : nullptr;
+        if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2, true>), dim3(nblk), dim3(512), pl.lds, s, p);
+        else if (pl.wci == 4) hipLaunchKernelGGL((wino_wgrad_kernel<4, 1, true>), dim3(nblk), dim3(256), pl.lds, s, p);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2, true>), dim3(nblk), dim3(256), pl.lds, s, p);
+        MRDIS_CHECK_LAUNCH();
+        float* db = p.bias_slab ? dbias : nullptr;
+        hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (db ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck + kd * n, n, p.splits,
+                           p.bias_slab, db, Co, 0);
+        MRDIS_CHECK_LAUNCH();
+    }
     return MRDIS_OK;
 }

@@ -75,10 +75,11 @@ def test_conv3d_fwd_bwd(mrdis, N, Ci, Co, D, H, W, stride):
 def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W, monkeypatch):
     """3x3x3 stride-1 layers through the hybrid kernel (Winograd F(2x2,3x3) in (h, w), direct in depth; mrdis_wino.hip D3)
     forced on for shapes the size policy would leave to the direct kernel: forward with bias + fused residual, data
-    gradient (reversed 27-tap filter), planes at the volume boundary, odd extents, cout / channel tails."""
+    gradient (reversed 27-tap filter), weight gradient (one 2-D Winograd launch per depth tap where Ci / Co are 32 / 64
+    multiples), planes at the volume boundary, odd extents, cout / channel tails."""
     x = seeded((N, Ci, D, H, W), 1); w = seeded((Co, Ci, 3, 3, 3), 2, 0.1); b = seeded((Co,), 3)
-    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
-    y_ref = F.conv3d(xr, wr, b, padding=1)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, br, padding=1)
     res = seeded(tuple(y_ref.shape), 4)
     y_ref = y_ref + res
     dy = seeded(tuple(y_ref.shape), 5)
@@ -94,6 +95,7 @@ def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W, monkeypatch):
         y.backward(cl3(dy))
         outs[mode] = (y.detach(), xg.grad.detach())
         close(y, y_ref, 1e-3, f'fwd mode {mode}'); close(xg.grad, xr.grad, 1e-3, f'dgrad mode {mode}')
+        close(conv.weight.grad, wr.grad, 1e-3, f'wgrad mode {mode}'); close(conv.bias.grad, br.grad, 1e-3, f'bgrad mode {mode}')
         conv.zero_grad()
     assert not torch.equal(outs['0'][0], outs['2'][0])          # really another kernel
     close(outs['2'][0], outs['0'][0], 1e-4, 'hybrid vs direct fwd'); close(outs['2'][1], outs['0'][1], 1e-4, 'hybrid vs direct dgrad')
