@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
 // (tap, channel) are one wave-uniform 16-byte LDS read.
 template <int KC, bool THIN4>
 __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
-    constexpr int S = KC + 1, BN = 16;
+    constexpr int S = THIN4 ? KC + 4 : KC + 1, BN = 16;      // THIN4 reads pixels as 16-byte quads: pitch 20 floats (aligned, conflict-free)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* tab_in = reinterpret_cast<int*>(smem);
     int* tab_out = tab_in + 128;
@@ -419,22 +419,27 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW;
     const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min;
 
-    // THIN4 thread roles: position tid & 127, channel half tid >> 7 (wave-uniform)
-    const int tpos = tid & 127, tpart = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int tbase = tab_in[tpos] + tpart * (KC / 2);
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    // THIN4 thread roles: positions (tid & 63) and (tid & 63) + 64, channel quarter = wave (4 channels of the 16-channel chunk):
+    // one 16-byte filter read (wave-uniform) now feeds two positions and a pixel's four channels are one 16-byte read --
+    // 54 LDS instructions per chunk and thread instead of 144 (the kernel was LDS-issue bound)
+    const int tq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb0 = tab_in[tid & 63] + 4 * tq, tb1 = tab_in[(tid & 63) + 64] + 4 * tq;
+    float acc4[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // (reading the filter values as scalar loads from global memory instead of the LDS broadcast was tried: slower, the
     // scalar and LDS counters share lgkmcnt and the waits serialise)
     auto compute_chunk = [&](int) {
         if constexpr (THIN4) {
             for (int t = 0; t < p.ntaps; ++t) {
-                const float* xr = xs + tbase + tap_xoff[t];
-                const float* wr = ws + (t * KC + tpart * (KC / 2)) * BN;
+                const int toff = tap_xoff[t];
+                const float4 x0 = *reinterpret_cast<const float4*>(xs + tb0 + toff);
+                const float4 x1 = *reinterpret_cast<const float4*>(xs + tb1 + toff);
+                const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+                const float* wr = ws + (t * KC + 4 * tq) * BN;
 #pragma unroll
-                for (int kk = 0; kk < KC / 2; ++kk) {
-                    const float xv = xr[kk];
+                for (int kk = 0; kk < 4; ++kk) {
                     const float4 w4 = *reinterpret_cast<const float4*>(wr + kk * BN);
-                    acc4[0] += xv * w4.x; acc4[1] += xv * w4.y; acc4[2] += xv * w4.z; acc4[3] += xv * w4.w;
+                    acc4[0][0] += xa[kk] * w4.x; acc4[0][1] += xa[kk] * w4.y; acc4[0][2] += xa[kk] * w4.z; acc4[0][3] += xa[kk] * w4.w;
+                    acc4[1][0] += xb[kk] * w4.x; acc4[1][1] += xb[kk] * w4.y; acc4[1][2] += xb[kk] * w4.z; acc4[1][3] += xb[kk] * w4.w;
                 }
             }
         } else {
@@ -563,19 +568,22 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
         compute_chunk(c0);
     }
     if constexpr (THIN4) {
-        // the two channel halves of a position meet in LDS (fixed order: half 0 + half 1)
+        // the four channel quarters of a position meet in LDS (fixed order: q0 + q1 + q2 + q3)
         __syncthreads();
-        float* red = xs;                                  // [128][4]
-        if (tpart == 1) { red[tpos * 4 + 0] = acc4[0]; red[tpos * 4 + 1] = acc4[1]; red[tpos * 4 + 2] = acc4[2]; red[tpos * 4 + 3] = acc4[3]; }
+        float* red = xs;                                  // [4 quarters][128 positions][4]
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<float4*>(red + ((tq * 128 + (tid & 63) + 64 * h) * 4)) = make_float4(acc4[h][0], acc4[h][1], acc4[h][2], acc4[h][3]);
         __syncthreads();
-        if (tpart == 0) {
+        if (tid < 128) {
+            const int tpos = tid;
             const int po = tab_out[tpos];
             if (po >= 0) {
                 const bool lrelu_ = (p.epilogue & MRDIS_EPI_LRELU) != 0;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc4[r] + red[tpos * 4 + r];
+                    v[r] = ((red[tpos * 4 + r] + red[(128 + tpos) * 4 + r]) + red[(256 + tpos) * 4 + r]) + red[(384 + tpos) * 4 + r];
                     if (p.bias != nullptr && r < p.Cout) v[r] += p.bias[r];
                     if (lrelu_) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                 }
@@ -664,7 +672,13 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
         p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
         p.vec_w = 0; p.prefetch = 0; p.coTiles = 1;
         int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
-        auto lds16 = [&](int kc) { return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * kc * 16 + (size_t)p.NB * p.TinH * p.TinW * (kc + 1)); };
+        const bool thin4_want = p.Cout <= 4 && !getenv("MRDIS_DEBUG_NOTHIN");
+        auto lds16 = [&](int kc) {
+            const bool t4 = thin4_want && kc == 16;
+            size_t xs_floats = (size_t)p.NB * p.TinH * p.TinW * (kc + (t4 ? 4 : 1));
+            if (t4 && xs_floats < 4 * 128 * 4) xs_floats = 4 * 128 * 4;          // the quarter-sum buffer of the THIN4 epilogue reuses the tile
+            return sizeof(float) * ((size_t)TC_TAB_INTS + (size_t)p.ntaps * kc * 16 + xs_floats);
+        };
         while (lds16(KC) > 64 * 1024 && KC > 4) KC >>= 1;
         if (lds16(KC) > 64 * 1024) return MRDIS_EUNSUPPORTED;
         // hoisted descriptors + register prefetch: vector paths on both operands, item counts within the register arrays,
