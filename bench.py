@@ -213,7 +213,9 @@ def main():
                                    f'{"+adv" if adv else ""}, bwd, clip, Adam amsgrad)',
                        'global_batch': B * world, 'per_gpu_batch': B, 'modalities': M, 'input_hw': [H, W],
                        'parallelism': f'dp{world}', 'missing_modality': bool(a.drop),
-                       'output_decoder': bool(a.recon_y)},
+                       'output_decoder': bool(a.recon_y),
+                       'conv_algorithms': 'fp32 throughout; direct MFMA kernels + fused Winograd F(2x2,3x3) for the big 3x3 stride-1 layers '
+                                          f'(MRDIS_WINO={os.environ.get("MRDIS_WINO", "1")}; 0 = direct only)'},
             'loss': round(host_losses['all'], 5),
             'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
             'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)',
