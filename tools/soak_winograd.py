@@ -1,0 +1,29 @@
+"""25 training steps of the bench model (B = 16, M = 4, 256x256, drop-off masks, adversarial loss) with the default kernel
+policy (MRDIS_WINO=1) and with the direct kernels only (MRDIS_WINO=0) from the same seeds: prints both loss
+trajectories and their largest relative difference (r01j: 19.18 -> 15.62 vs 15.61, max difference 1.5e-3 after 25
+Adam steps -- rounding-level differences amplified by the optimiser, no drift)."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import mrdis
+dev = torch.device('cuda:0'); mrdis.hip.load()
+B, M, H, W = 16, 4, 256, 256
+cfg = dict(mrdis.DEFAULT_CONFIG); cfg.update(contrast_list=['T1','T1c','T2','T2_FLAIR'], input_height=H, input_width=W, batch_size=16, lambda_adv_s=1.0)
+cfg = mrdis.derive_config(cfg, dev)
+res = {}
+for mode in ('1', '0'):
+    os.environ['MRDIS_WINO'] = mode
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, 240, 240, seed=10, drop=True)
+    x = mrdis.fit_to_model(x, (H, W), fill=-10.0); mask_img = (x[:, 0] == 0).float()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    torch.manual_seed(100); np.random.seed(100)
+    ls = []
+    for i in range(25):
+        loss, parts, _ = step(xd, mask.to(dev), mask_img.to(dev), mask)
+        ls.append(float(loss))
+    res[mode] = ls
+    print('MRDIS_WINO=' + mode, ' '.join(f'{v:.4f}' for v in ls[::3]), flush=True)
+d = max(abs(a - b) / abs(b) for a, b in zip(res['1'], res['0']))
+print('finite:', all(np.isfinite(res['1'])), ' max rel loss diff winograd vs direct over 25 steps:', f'{d:.2e}')
