@@ -360,7 +360,9 @@ def test_instnorm_spade(mrdis, C, N, H, W):
 @pytest.mark.parametrize('shape,out_hw,ac', [
     ((2, 8, 5, 6), (10, 12), True), ((2, 8, 5, 6), (10, 12), False), ((2, 4, 32, 64), (5, 6), False),
     ((2, 4, 40, 48), (40, 48), False), ((1, 3, 7, 9), (14, 18), True), ((2, 4, 32, 48), (16, 24), False),
-    ((2, 5, 6, 6), (12, 12), False)])
+    ((2, 5, 6, 6), (12, 12), False),
+    # >= 6 M elements: the branch-free backward kernel (x2 up-sampling both conventions: 5x5 support; down-sampling: 3x3)
+    ((4, 32, 224, 224), (448, 448), True), ((4, 32, 224, 216), (448, 432), False), ((2, 32, 320, 328), (160, 164), False)])
 def test_bilinear(mrdis, shape, out_hw, ac):
     hip = mrdis.hip
     x = rnd(shape, 19).requires_grad_(True)
