@@ -487,16 +487,28 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float*
     const float* r1 = x + ((long long)n * Hi + ah.i1) * Wi * ldx;
     float* yo = y + ((long long)n * Ho + ho) * Wo * ldy;
     const int items = Wo * Q;
-    for (int j = threadIdx.x; j < items; j += blockDim.x) {
-        const int wo = j / Q, q = j - wo * Q;
-        const BilAxis aw = bil_axis(wo, sw, align, Wi);
-        Vec<V> p00, p01, p10, p11, o;
-        p00.load(r0 + (long long)aw.i0 * ldx + q * V); p01.load(r0 + (long long)aw.i1 * ldx + q * V);
-        p10.load(r1 + (long long)aw.i0 * ldx + q * V); p11.load(r1 + (long long)aw.i1 * ldx + q * V);
+    // two items per trip: eight 16-byte loads in flight per thread (the tail item is clamped to the last one and not stored)
+    for (int j = threadIdx.x; j < items; j += 2 * blockDim.x) {
+        const int j1 = j + blockDim.x;
+        const bool has1 = j1 < items;
+        const int jb = has1 ? j1 : j;
+        const int wo0 = j / Q, q0 = j - wo0 * Q, wo1 = jb / Q, q1 = jb - wo1 * Q;
+        const BilAxis a0 = bil_axis(wo0, sw, align, Wi), a1 = bil_axis(wo1, sw, align, Wi);
+        Vec<V> p00, p01, p10, p11, s00, s01, s10, s11, o;
+        p00.load(r0 + (long long)a0.i0 * ldx + q0 * V); p01.load(r0 + (long long)a0.i1 * ldx + q0 * V);
+        p10.load(r1 + (long long)a0.i0 * ldx + q0 * V); p11.load(r1 + (long long)a0.i1 * ldx + q0 * V);
+        s00.load(r0 + (long long)a1.i0 * ldx + q1 * V); s01.load(r0 + (long long)a1.i1 * ldx + q1 * V);
+        s10.load(r1 + (long long)a1.i0 * ldx + q1 * V); s11.load(r1 + (long long)a1.i1 * ldx + q1 * V);
 #pragma unroll
         for (int k = 0; k < V; ++k)
-            o.v[k] = ah.l0 * (aw.l0 * p00.v[k] + aw.l1 * p01.v[k]) + ah.l1 * (aw.l0 * p10.v[k] + aw.l1 * p11.v[k]);
-        o.store(yo + (long long)wo * ldy + q * V);
+            o.v[k] = ah.l0 * (a0.l0 * p00.v[k] + a0.l1 * p01.v[k]) + ah.l1 * (a0.l0 * p10.v[k] + a0.l1 * p11.v[k]);
+        o.store(yo + (long long)wo0 * ldy + q0 * V);
+        if (has1) {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                o.v[k] = ah.l0 * (a1.l0 * s00.v[k] + a1.l1 * s01.v[k]) + ah.l1 * (a1.l0 * s10.v[k] + a1.l1 * s11.v[k]);
+            o.store(yo + (long long)wo1 * ldy + q1 * V);
+        }
     }
 }
 
