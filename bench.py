@@ -54,39 +54,75 @@ def parse():
     ap.add_argument('--recon-y', action='store_true', help="lambda_recon_y = 1: adds the 'U+SA' output decoder + segmentation loss (not the headline config)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
     return ap.parse_args()
 
 
-def roofline_conv(mrdis, dev, iters=20):
-    """Average duration of the north-star 3x3 conv forward, HIP events on the launch stream."""
-    hip = mrdis.hip
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(NS['N'], NS['Ci'], NS['H'], NS['W'], generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(9, NS['Ci'], NS['Co'], generator=g) * 0.1).to(dev)
-    b = torch.zeros(NS['Co'], device=dev)
-    y = hip.empty_nhwc(NS['N'], NS['Co'], NS['H'], NS['W'], dev)
-    for _ in range(3):
-        hip.conv2d_fwd(x, w, b, 3, 3, 1, 1, out=y)
+def _time_conv(hip, xs, w, b, ys, iters):
+    """average launch duration (us) over `iters` launches cycling through the (x, y) buffer pairs; HIP events on the launch
+    stream (torch's current stream is the stream the C ABI is handed)."""
+    n = len(xs)
+    for i in range(max(3, n)):
+        hip.conv2d_fwd(xs[i % n], w, b, 3, 3, 1, 1, out=ys[i % n])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        hip.conv2d_fwd(x, w, b, 3, 3, 1, 1, out=y)
+    for i in range(iters):
+        hip.conv2d_fwd(xs[i % n], w, b, 3, 3, 1, 1, out=ys[i % n])
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    achieved = NS_BYTES / (us * 1e-6) / 1e9
-    traffic = None
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def roofline_conv(mrdis, dev, iters=24):
+    """The north-star 3x3 conv forward.  Its output is checked against torch fp32 on the host first.  Timed
+    three ways: `achieved` = ROTATING buffers (4 x/y pairs, 1.06 GB > the 256 MiB Infinity Cache, so every launch reads and
+    writes HBM), `single_buffer` = one x/y pair re-used (the 236 MB output partly lives in the Infinity Cache between
+    launches), `in_step_256` = the same layer at the size it has inside the timed training step (256x256 padded, 302 MB)."""
+    import torch.nn.functional as F
+    hip = mrdis.hip
+    g = torch.Generator().manual_seed(1)
+    x_cpu = torch.randn(NS['N'], NS['Ci'], NS['H'], NS['W'], generator=g)
+    w_cpu = torch.randn(NS['Co'], NS['Ci'], 3, 3, generator=g) * 0.1
+    b_cpu = torch.randn(NS['Co'], generator=g) * 0.1
+    w = w_cpu.permute(2, 3, 1, 0).reshape(9, NS['Ci'], NS['Co']).contiguous().to(dev)
+    b = b_cpu.to(dev)
+    nrot = 4
+    xs = [x_cpu.roll(i, 0).to(dev).contiguous(memory_format=torch.channels_last) for i in range(nrot)]
+    ys = [hip.empty_nhwc(NS['N'], NS['Co'], NS['H'], NS['W'], dev) for _ in range(nrot)]
+    hip.conv2d_fwd(xs[0], w, b, 3, 3, 1, 1, out=ys[0])
+    want = F.conv2d(x_cpu, w_cpu, b_cpu, 1, 1)
+    err = float((ys[0].cpu() - want).abs().max()) / float(want.abs().max())
+    assert err <= 1e-5, f'north-star conv output differs from torch fp32: rel {err:.2e}'
+    us_rot = _time_conv(hip, xs, w, b, ys, iters)
+    us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
+    del xs, ys
+    n6 = NS['N'] * 256 * 256
+    bytes6 = 4 * (n6 * NS['Ci'] + n6 * NS['Co'] + NS['Co'] * NS['Ci'] * 9 + NS['Co'])
+    xs6 = [torch.randn(NS['N'], NS['Ci'], 256, 256, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(nrot)]
+    ys6 = [hip.empty_nhwc(NS['N'], NS['Co'], 256, 256, dev) for _ in range(nrot)]
+    us6 = _time_conv(hip, xs6, w, b, ys6, iters)
+    del xs6, ys6
+    achieved = NS_BYTES / (us_rot * 1e-6) / 1e9
+    traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, 'profiles', 'northstar_conv_pmc.json')
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            rec = json.load(open(pmc))
+            traffic = rec.get('hbm_bytes_per_launch')
+            traffic_src = f"profiles/northstar_conv_pmc.json ({rec.get('tag', 'r01j')}, commit {rec.get('commit', 'n/a')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run"
         except Exception:
             traffic = None
+    gbs = lambda nbytes, us: round(nbytes / (us * 1e-6) / 1e9, 1)
     return {'bound': 'hbm', 'kernel': 'c4conv_kernel<1> (3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC)',
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': traffic, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us, 2),
-            'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us * 1e-6) / 1e12, 2)}
+            'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us_rot, 2),
+            'timing': f'{iters} launches over {nrot} rotating x/y pairs (1.06 GB, beyond the 256 MiB Infinity Cache), HIP events',
+            'output_checked': f'vs torch fp32 conv2d on the host, max rel err {err:.1e}',
+            'single_buffer': {'us_per_launch': round(us_one, 2), 'achieved': gbs(NS_BYTES, us_one), 'frac': round(gbs(NS_BYTES, us_one) / HBM_PEAK_GBS, 4)},
+            'in_step_256': {'shape': '32x4x256x256 -> 32ch', 'algorithmic_bytes': bytes6, 'us_per_launch': round(us6, 2),
+                            'achieved': gbs(bytes6, us6), 'frac': round(gbs(bytes6, us6) / HBM_PEAK_GBS, 4)},
+            'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us_rot * 1e-6) / 1e12, 2)}
 
 
 def cpu_baseline(M, H, W, adv):
@@ -200,6 +236,25 @@ def main():
     ms = dt / a.steps * 1e3
     value = B * world / (dt / a.steps)
     host_losses = step.losses_to_host(parts)
+    # the same step on the direct-convolution kernels only (north_star describes a direct conv; the default policy runs
+    # fused Winograd on the big 3x3 layers): reported beside the headline, never as `value`
+    ms_direct = None
+    if not a.no_direct and mrdis.hip.get_option('wino') != 0:
+        prev = mrdis.hip.get_option('wino')
+        mrdis.hip.set_option('wino', 0)
+        nd = max(2, min(a.steps, 5))
+        step(xd, maskd, mimgd, mask, targets=tgt)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nd):
+            step(xd, maskd, mimgd, mask, targets=tgt)
+        sync()
+        ms_direct = (time.perf_counter() - t0) / nd * 1e3
+        mrdis.hip.set_option('wino', prev)
+        if world > 1:
+            t = torch.tensor([ms_direct], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_direct = float(t)
 
     if rank == 0:
         out = {
@@ -215,11 +270,14 @@ def main():
                        'parallelism': f'dp{world}', 'missing_modality': bool(a.drop),
                        'output_decoder': bool(a.recon_y),
                        'conv_algorithms': 'fp32 throughout; direct MFMA kernels + fused Winograd F(2x2,3x3) for the big 3x3 stride-1 layers '
-                                          f'(MRDIS_WINO={os.environ.get("MRDIS_WINO", "1")}; 0 = direct only)'},
+                                          f'(option wino = {mrdis.hip.get_option("wino")}; 0 = direct only)'},
             'loss': round(host_losses['all'], 5),
             'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
             'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)',
             'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
+            'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),
+            'step_tflops_f32_direct_only': None if ms_direct is None else round(
+                FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
         }
         log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
         out['host_enqueue_ms_per_step'] = round(host_ms, 1)

@@ -44,6 +44,17 @@ extern "C" {
 const char* mrdis_strerror(int code);
 int mrdis_version(void);
 
+/* Process-wide switches.  Each one is initialised from its environment variable when the library is first used and is
+ * changed afterwards only through mrdis_set_option (nothing on the launch path calls getenv):
+ *   "wino"  (MRDIS_WINO, default 1): 0 = direct convolution kernels only, 1 = fused Winograd F(2x2,3x3) where it measured
+ *           faster (csrc/mrdis_conv.hip wino_wanted), 2 = Winograd wherever the kernel applies (tests);
+ *   "nt_mb" (MRDIS_NT_MB, default 128): Winograd outputs of at least this many MB are written with non-temporal stores;
+ *   "debug_*": kernel-selection overrides used by tools/ (see csrc/mrdis_elem.hip OPT_DEFS).
+ * set: 0 or MRDIS_EINVAL (unknown name); get: the value, or MRDIS_EINVAL for an unknown name.  Not synchronised with launches
+ * in flight on other threads. */
+int mrdis_set_option(const char* name, long long value);
+long long mrdis_get_option(const char* name);
+
 /* ---- expert mixing: model.py:2111-2113 --------------------------------------
  * W   : (E, Co, Ci, kh, kw) checkpoint layout (OIHW with leading expert dim)
  * r   : (E) routing weights sigmoid(fc(type)) -- one row; the reference's
@@ -202,13 +213,21 @@ int mrdis_maxpool_bwd(const float* dy, const int32_t* argmax, float* dx, int ldd
 size_t mrdis_sumsq_workspace(void);
 int mrdis_sumsq_finite(const float* g, long long n, float* out, void* workspace, size_t workspace_bytes,
                        void* stream);
-/* One fused step.  clip_coef_src points at the device scalar pair written by
- * mrdis_sumsq_finite: coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); the step is
- * skipped on device when the non-finite count is > 0.  step_count: 1-based.   */
+/* One fused step.  norm_finite points at the device scalar pair written by mrdis_sumsq_finite (or NULL): with
+ * max_norm > 0 the gradient is scaled by coef = min(1, max_norm / (sqrt(sumsq) * grad_scale + 1e-6)) (clip_grad_norm_,
+ * main_missing.py:272); the step is skipped on the device when the non-finite count is > 0 (the reference stops in pdb
+ * there, :273-278), with max_norm = 0 the pair only gates.
+ * step_count / step_state: bias correction uses the 1-based host `step_count`, or -- when step_state (device float[2]) is
+ * given -- a device-side counter: [0] = steps applied (incremented by this call unless it is skipped), [1] = steps skipped
+ * as non-finite; a skipped step does not advance the bias correction.
+ * gates (n_gates <= 32): HOST arrays gate_ranges[2k], [2k+1] = index range [lo, hi) of the arena, gate_flag_index[k] = entry
+ * of the DEVICE array gate_flags that gates it: a range whose flag is 0 is left untouched (torch's Adam skips parameters
+ * whose grad is None: a decoder whose modality is absent from the whole batch).                                      */
 int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                             long long n, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, int step_count, const float* norm_finite,
-                            float max_norm, float grad_scale, void* stream);
+                            float weight_decay, int step_count, float* step_state, const float* norm_finite,
+                            float max_norm, float grad_scale, const long long* gate_ranges, const int* gate_flag_index,
+                            int n_gates, const float* gate_flags, void* stream);
 
 /* ==== 3-D path: the Conv3d / GroupNorm / Upsample layers of BasicBlock, UNet3D, VAEBranch and
  * NVNet3D (src/model.py:1856-2060).  Tensors are NDHWC fp32 views (torch.channels_last_3d); 1x1x1 convolutions go

@@ -275,6 +275,98 @@ def gen_step(ref, tag, B, M, drop=False, adv=False, recon_y=False):
           {k: round(float(v), 7) for k, v in parts.items()})
 
 
+def ref_loss(model, inputs, mask, mask_img, lam, M):
+    """main_missing.py:166-251 for the shipped loss set (no adversarial / target terms)."""
+    x_list = [inputs[:, i * 7:(i + 1) * 7] for i in range(M)]
+    s_list = model.compute_anatomy_encoding(x_list, mask_img)
+    z_list, mu_list, lv_list = model.compute_modality_encoding(x_list, s_list, phase='train')
+    xf = model.reconstruct_input_si_zi(s_list, z_list)
+    xmix = model.reconstruct_input_si_zj(s_list, z_list)
+    parts = {'recon_x': model.compute_recon_loss_x_list(x_list, xf, mask, p=1),
+             'recon_x_mix': model.compute_recon_loss_x_mix_list(x_list, xmix, mask, p=1)}
+    s_new = model.compute_anatomy_encoding(xf, mask_img)
+    _, mu_new, _ = model.compute_modality_encoding(xf, s_new, phase='train')
+    parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask)
+    parts['sim_s'] = model.compute_similarity_s_loss(s_list, mask)
+    parts['sim_z'] = model.compute_similarity_z_loss(z_list, mask)
+    loss = sum(lam[k] * parts[k] for k in parts)
+    return loss, parts
+
+
+def gen_accum(ref, tag='accum_b2m2', B=2, M=2, iters=4, batch_size=8):
+    """The reference's DEFAULT optimizer schedule (config.yaml:17 `batch_size: 8` -> 16 // 8 = 2 micro-batches):
+    main_missing.py:268-284 as written -- backward() accumulates, clip_grad_norm_ runs on the ACCUMULATING gradient every
+    iteration (:272), optimizer.step() + zero_grad() on every second iteration (:282-284).  `iters` iterations = two
+    optimizer steps on different micro-batches (seeds 10 + it), drop-off masks on the odd ones."""
+    lam = dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, sim_z=2.0)
+    accum = 16 // batch_size
+    torch.manual_seed(10); np.random.seed(10)
+    model = build_ref_model(ref, M, False)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    torch.manual_seed(11); np.random.seed(11)
+    w0 = {k: float(v.double().sum()) for k, v in model.state_dict().items()
+          if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point}
+    rec = []
+    for it in range(iters):
+        inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10 + it, drop=bool(it % 2))
+        loss, parts = ref_loss(model, inputs, mask, mask_img, lam, M)
+        loss.backward()                                                              # :268-271
+        pre_clip = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0))    # :272 (norm BEFORE scaling)
+        post_clip = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+        stepped = (it + 1) % accum == 0                                              # :282
+        if stepped:
+            opt.step(); opt.zero_grad()                                              # :283-284
+        rec.append(dict(loss=float(loss), parts={k: float(v) for k, v in parts.items()}, grad_norm_before_clip=pre_clip,
+                        grad_norm_after_clip=post_clip, stepped=stepped,
+                        wsum={k: float(v.double().sum()) for k, v in model.state_dict().items()
+                              if k.startswith(HOT_PREFIXES) and v.dtype.is_floating_point} if stepped else None))
+    meta = dict(B=B, M=M, H=160, W=192, batch_size=batch_size, accum=accum, lambdas=lam, iters=rec, wsum_before=w0,
+                torch=torch.__version__)
+    with open(os.path.join(OUT, f'{tag}.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, [(round(r['loss'], 6), round(r['grad_norm_before_clip'], 4), r['stepped']) for r in rec])
+
+
+def gen_ckpt_layout(ref, tag='ckpt_layout_m2'):
+    """Checkpoint dict of the reference after one epoch-end (main_missing.py:330-335) as a LAYOUT fixture: every
+    state_dict key with shape / dtype / sum, the torch optimizer and ReduceLROnPlateau state_dict structure, and the
+    stat.csv row format of util.py:854-866 -- data only, no tensors of 140 MB and no source text."""
+    M = 2
+    torch.manual_seed(10); np.random.seed(10)
+    model = build_ref_model(ref, M, True)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.1, patience=5, min_lr=1e-5)   # main_missing.py:119
+    sd = model.state_dict()
+    layout = {k: dict(shape=list(v.shape), dtype=str(v.dtype).replace('torch.', ''),
+                      sum=float(v.double().sum()) if v.dtype.is_floating_point else int(v.sum())) for k, v in sd.items()}
+    inputs, mask, mask_img = make_inputs(2, M, 160, 192, seed=10)
+    torch.manual_seed(11); np.random.seed(11)
+    loss, _ = ref_loss(model, inputs, mask, mask_img, dict(recon_x=1.0, recon_x_mix=2.0, latent_z=0.1, sim_s=10.0, sim_z=2.0), M)
+    loss.backward(); torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0); opt.step()
+    monitor = [0.50, 0.40, 0.45, 0.41, 0.42, 0.43, 0.44, 0.46, 0.47, 0.39]
+    lrs = []
+    for v in monitor:                                                                # scheduler.step(monitor_metric), :322
+        sched.step(v); lrs.append(opt.param_groups[0]['lr'])
+    osd, ssd = opt.state_dict(), sched.state_dict()
+    params = list(model.parameters())
+    names = {id(p): n for n, p in model.named_parameters()}
+    opt_layout = dict(param_group_keys=sorted(k for k in osd['param_groups'][0] if k != 'params'),
+                      n_params=len(osd['param_groups'][0]['params']),
+                      state_index_to_name={str(i): names[id(params[i])] for i in osd['state']},
+                      state_entry_keys=sorted(next(iter(osd['state'].values())).keys()),
+                      step_dtype=str(next(iter(osd['state'].values()))['step'].dtype).replace('torch.', ''),
+                      step_shape=list(next(iter(osd['state'].values()))['step'].shape))
+    sched_layout = {k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(type(v).__name__)) for k, v in ssd.items()}
+    meta = dict(M=M, model=layout, optimizer=opt_layout, scheduler=sched_layout, monitor=monitor, lr_trajectory=lrs,
+                ckpt_keys=['epoch', 'monitor_metric', 'stat', 'optimizer', 'scheduler', 'model', 'optimizer_d_s'],
+                torch=torch.__version__)
+    with open(os.path.join(OUT, f'{tag}.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, len(layout), 'state_dict entries;', len(osd['state']), 'optimizer state entries; lr', lrs)
+
+
 def gen_eval(ref, tag, B, M):
     """evaluate() of the reference for one batch (main_missing.py:337-517): model.eval(), z = mu."""
     sys.path.insert(0, ROOT) if ROOT not in sys.path else None
@@ -398,6 +490,10 @@ def main():
         gen_step(ref, 'b2m2_adv', 2, 2, adv=True)
     if not only or 'recon_y' in only:
         gen_step(ref, 'b2m2_y', 2, 2, recon_y=True)
+    if not only or 'accum' in only:
+        gen_accum(ref)
+    if not only or 'ckpt' in only:
+        gen_ckpt_layout(ref)
     if not only or 'eval' in only:
         gen_eval(ref, 'b2m4', 2, 4)
     if not only or 'data' in only:

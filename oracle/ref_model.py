@@ -654,6 +654,23 @@ def ref_train_step(model, optimizer, inputs, mask, mask_img, lambdas=None, p=1,
     return loss.detach(), {k: v.detach() for k, v in parts.items()}, gnorm, aux
 
 
+def ref_train_iterations(model, optimizer, batches, batch_size, lambdas=None, p=1, on_iter=None):
+    """The inner loop of train() (main_missing.py:155-305) over `batches` = [(inputs, mask, mask_img), ...] with the
+    reference's accumulation rule: gradients accumulate in p.grad across iterations, clip_grad_norm_ acts on the
+    accumulating gradient EVERY iteration (:272), `optimizer.step(); optimizer.zero_grad()` when
+    (iter + 1) % (16 // batch_size) == 0 (:282-284).  Returns one record per iteration."""
+    accum = 16 // batch_size
+    out = []
+    for it, (inputs, mask, mask_img) in enumerate(batches):
+        stepped = (it + 1) % accum == 0
+        loss, parts, gnorm, _ = ref_train_step(model, optimizer, inputs, mask, mask_img, lambdas, p, step_optimizer=stepped)
+        out.append(dict(loss=float(loss), parts={k: float(v) for k, v in parts.items()}, grad_norm_before_clip=float(gnorm),
+                        stepped=stepped))
+        if on_iter is not None:
+            on_iter(it, out[-1])
+    return out
+
+
 def perturb_bn_running_stats(model):
     """Deterministic non-trivial BatchNorm running statistics (a freshly built model has mean 0 / var 1,
     which would make inference-mode BN a no-op in the evaluate() fixtures)."""

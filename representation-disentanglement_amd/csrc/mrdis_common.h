@@ -13,6 +13,16 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Process-wide switches.  Each is read from its environment variable ONCE (first use) and afterwards only changes through
+// mrdis_set_option(): no getenv() on the launch path.  Boolean debug switches: variable present = 1.  Value switches: -1 = unset.
+enum {
+    MRDIS_OPT_WINO, MRDIS_OPT_NT_MB,
+    MRDIS_OPT_NO16, MRDIS_OPT_NOTHIN, MRDIS_OPT_NOC4, MRDIS_OPT_NODMA, MRDIS_OPT_NO16_3D, MRDIS_OPT_BILGEN, MRDIS_OPT_NOW16,
+    MRDIS_OPT_MODE, MRDIS_OPT_BN, MRDIS_OPT_KC, MRDIS_OPT_BM, MRDIS_OPT_C4_TW, MRDIS_OPT_WGSPLIT, MRDIS_OPT_BN3, MRDIS_OPT_KC3,
+    MRDIS_OPT_COUNT
+};
+long long mrdis_opt(int id);      // mrdis_elem.hip
+
 static inline int mrdis_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Bijective XCD-aware remap (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD, so

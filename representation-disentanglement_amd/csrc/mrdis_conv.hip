@@ -668,11 +668,11 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
     p.tilesA = mrdis_cdiv(p.A, p.TH); p.tilesB = mrdis_cdiv(p.B, p.TW); p.tilesN = mrdis_cdiv(p.N, p.NB);
     const long long ptiles = (long long)p.tilesA * p.tilesB * p.tilesN;
-    if (p.Cout <= 16 && !getenv("MRDIS_DEBUG_NO16")) {
+    if (p.Cout <= 16 && !mrdis_opt(MRDIS_OPT_NO16)) {
         p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
         p.vec_w = 0; p.prefetch = 0; p.coTiles = 1;
         int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
-        const bool thin4_want = p.Cout <= 4 && !getenv("MRDIS_DEBUG_NOTHIN");
+        const bool thin4_want = p.Cout <= 4 && !mrdis_opt(MRDIS_OPT_NOTHIN);
         auto lds16 = [&](int kc) {
             const bool t4 = thin4_want && kc == 16;
             size_t xs_floats = (size_t)p.NB * p.TinH * p.TinW * (kc + (t4 ? 4 : 1));
@@ -688,10 +688,10 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
             const bool vec_w16 = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
             const bool small = (long long)p.N * p.Hin * p.Win * p.ldin < 0x7fffffffLL && (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout < 0x7fffffffLL;
             p.prefetch = (p.vec_in && vec_w16 && small && npix * (KC / 4) <= 6 * 256 && (long long)p.ntaps * KC * (p.Cout / 4) <= 3 * 256) ? 1 : 0;
-            if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
+            if (mrdis_opt(MRDIS_OPT_MODE) >= 0 && p.prefetch) p.prefetch = mrdis_opt(MRDIS_OPT_MODE) ? 1 : 0;
         }
         if (ptiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
-        const bool thin4 = p.Cout <= 4 && KC == 16 && !getenv("MRDIS_DEBUG_NOTHIN");
+        const bool thin4 = p.Cout <= 4 && KC == 16 && !mrdis_opt(MRDIS_OPT_NOTHIN);
         if (thin4) hipLaunchKernelGGL((tapconv16_kernel<16, true>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
         else if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16, false>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
         else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8, false>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
@@ -703,11 +703,11 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     // layer (register pressure halves the residency of the 128 variant); small grids prefer 32.
     int BN = p.Cout <= 32 ? 32 : 64;
     if (BN == 64 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
-    if (const char* e = getenv("MRDIS_DEBUG_BN")) { const int v = atoi(e); if (v == 32 || v == 64) BN = v; }
+    { const int v = (int)mrdis_opt(MRDIS_OPT_BN); if (v == 32 || v == 64) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
-    if (const char* e = getenv("MRDIS_DEBUG_KC")) { const int v = atoi(e); if ((v == 4 || v == 8 || v == 16) && v < KC) KC = v; }
+    { const int v = (int)mrdis_opt(MRDIS_OPT_KC); if ((v == 4 || v == 8 || v == 16) && v < KC) KC = v; }
     const size_t LDS_MAX = 64 * 1024;
     const long long npix_in = (long long)p.NB * p.TinH * p.TinW;
     auto fits_pf = [&](int kc, int bn) { return npix_in * (kc / 4) <= 6 * 256 && (long long)p.ntaps * kc * (bn / 4) <= 9 * 256; };
@@ -718,7 +718,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     // 32-bit element offsets in the hoisted descriptors
     const bool small = (long long)p.N * p.Hin * p.Win * p.ldin < 0x7fffffffLL && (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout < 0x7fffffffLL;
     p.prefetch = (want_pf && fits_pf(KC, BN) && small) ? 1 : 0;
-    if (const char* e = getenv("MRDIS_DEBUG_MODE")) { if (p.prefetch) p.prefetch = atoi(e) ? 1 : 0; }
+    if (mrdis_opt(MRDIS_OPT_MODE) >= 0 && p.prefetch) p.prefetch = mrdis_opt(MRDIS_OPT_MODE) ? 1 : 0;
     p.coTiles = mrdis_cdiv(p.Cout, BN);
     long long nblk = ptiles * p.coTiles;
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
@@ -732,7 +732,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
     // its register arrays.
     {
         int want = 3;
-        if (const char* e = getenv("MRDIS_DEBUG_BM")) want = atoi(e);
+        if (mrdis_opt(MRDIS_OPT_BM) >= 0) want = (int)mrdis_opt(MRDIS_OPT_BM);
         const bool cand = p.prefetch == 1 && KC == 16 && ((nblk >= 4096 && (want == 1 || want == 3) && BN == 32) || (want == 2 && nblk >= 1024) || (want == 3 && BN == 64 && nblk >= 1024 && nblk <= 8192));
         if (cand) {
             TapConvParams q = p;
@@ -1020,7 +1020,7 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     double best = u32; p.TW = 32; p.TH = 1;
     if (u16 > best + 1e-9) { best = u16; p.TW = 16; p.TH = 2; }
     if (W <= 8) { p.TW = 8; p.TH = 4; }
-    if (const char* e = getenv("MRDIS_DEBUG_C4_TW")) { p.TW = atoi(e); p.TH = 32 / p.TW; }
+    if (mrdis_opt(MRDIS_OPT_C4_TW) > 0) { p.TW = (int)mrdis_opt(MRDIS_OPT_C4_TW); p.TH = 32 / p.TW; }
     p.tilesW = mrdis_cdiv(W, p.TW); p.tilesH = mrdis_cdiv(H, p.TH);
     p.ntiles = (long long)N * p.tilesW * p.tilesH;
     const int co32 = mrdis_cdiv(Co, 32);
@@ -1062,8 +1062,7 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
 // layer zoo): Winograd wins for Cout >= 32 and Cin >= 16 once the grid fills the chip (>= 256 workgroups): 1.13x on
 // 32 -> 32, 1.3-1.5x on the 64..512-channel layers; a 16-cout layer wastes half of its 32-wide cout tile (slower).
 static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
-    const char* e = getenv("MRDIS_WINO");          // read per call: the parity tests switch it inside one process
-    const int mode = e ? atoi(e) : 1;
+    const int mode = (int)mrdis_opt(MRDIS_OPT_WINO);          // MRDIS_WINO at load; mrdis_set_option("wino", v) afterwards
     if (mode == 0 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
     if (mode == 2) return Ci >= 8 && Co >= 8;
     if (Ci < 16 || Co < 32) return false;
@@ -1079,7 +1078,7 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
-    if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
+    if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     if (wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
         rc = mrdis_run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
@@ -1115,7 +1114,7 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
     if (stride == 1) {
         // dx of a Ci <- 4 layer (ana_dec.output): a 4 -> Ci convolution of dy with the taps reversed; [tap][Co=4][Ci] is
         // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
-        if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !getenv("MRDIS_DEBUG_NOC4"))
+        if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         if (wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
             rc = mrdis_run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
@@ -2033,7 +2032,7 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
     // LDS-DMA variant: full 32-channel chunks on both sides, J taps per group all real, and a double-buffered
     // tile pair that still lets two workgroups share a CU (<= 80 KB each)
     pl.dma = 0; pl.XR = 0; pl.lds_dma = 0;
-    if (Ci % 32 == 0 && Co % 4 == 0 && p.TPS == 1 && !getenv("MRDIS_DEBUG_NODMA")) {
+    if (Ci % 32 == 0 && Co % 4 == 0 && p.TPS == 1 && !mrdis_opt(MRDIS_OPT_NODMA)) {
         TileChoice cand[2] = {tc, TileChoice{1, 8, 16}};
         for (int c = 0; c < 2 && !pl.dma; ++c) {
             const TileChoice t = cand[c];
@@ -2055,7 +2054,7 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
         const int want = pl.thin_nt;
         pl.thin = 0; pl.thin_nt = 0; pl.thin_dma = 0;
         const bool big = (long long)N * Ho * Wo >= 100000;
-        if (big && !getenv("MRDIS_DEBUG_NOTHIN") && !getenv("MRDIS_DEBUG_NODMA") && Co % 4 == 0 && p.NB < 1024 && p.TinH < 1024 && p.TinW < 1024) {
+        if (big && !mrdis_opt(MRDIS_OPT_NOTHIN) && !mrdis_opt(MRDIS_OPT_NODMA) && Co % 4 == 0 && p.NB < 1024 && p.TinH < 1024 && p.TinW < 1024) {
             if (Co == 4 && Ci % 32 == 0 && want == 9) { pl.thin = 1; pl.thin_nt = 9; }
             else if (Ci == 4 && p.CW == 4 && Co >= 16 && want <= 9) { pl.thin = 2; pl.thin_nt = want <= 4 ? 4 : 9; }
         }
@@ -2078,14 +2077,14 @@ static int plan_wgrad(WgradPlan& pl, int N, int H, int W, int ldx, int Ci, int C
     // workgroups run as one full round and write half the slab volume a 1024-workgroup launch would
     // (1-7 % faster on the big layers, tools/ab_lib.py); the thin FMA kernels fit 3-4 per CU and keep 1024
     int wg_target = pl.thin ? 1024 : 512;
-    if (const char* e = getenv("MRDIS_DEBUG_WGSPLIT")) wg_target = atoi(e);
+    if (mrdis_opt(MRDIS_OPT_WGSPLIT) >= 0) wg_target = (int)mrdis_opt(MRDIS_OPT_WGSPLIT);
     long long splits = mrdis_cdiv(wg_target, p.base);
     if (splits > nt) splits = nt;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
     pl.pointwise = 0;
     if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ci <= 16 && Co <= 8 && p.CW == 16 && p.nG == 1 && J == 1 &&
-        (long long)N * Ho * Wo >= 50000 && !getenv("MRDIS_DEBUG_NOTHIN")) {
+        (long long)N * Ho * Wo >= 50000 && !mrdis_opt(MRDIS_OPT_NOTHIN)) {
         pl.pointwise = 1; pl.dma = 0; pl.thin = 0;
         long long tiles = ((long long)N * Ho * Wo + WGP_TILE - 1) / WGP_TILE;
         p.splits = (int)(tiles < 768 ? tiles : 768);
@@ -2109,8 +2108,7 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
                          size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 // Winograd weight gradient (mrdis_wino.hip): 3x3 s1 p1 layers with Ci, Co multiples of 32 / 64 and enough tiles per split
 static bool wino_wgrad_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
-    const char* e = getenv("MRDIS_WINO");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = (int)mrdis_opt(MRDIS_OPT_WINO);          // MRDIS_WINO at load; mrdis_set_option("wino", v) afterwards
     if (mode == 0 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
     if (mrdis_wino_wgrad_workspace(N, H, W, Ci, Co) == 0) return false;
     if (mode == 2) return true;

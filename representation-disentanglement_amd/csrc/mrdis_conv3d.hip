@@ -505,10 +505,10 @@ static int run_tapconv3d(Conv3dParams p, hipStream_t s) {
     if ((long long)p.Din * p.Hin * p.Win >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     int BN = p.Cout <= 32 ? 32 : 64;
     if (BN == 64 && ptiles * mrdis_cdiv(p.Cout, 64) < 256) BN = 32;
-    if (const char* e = getenv("MRDIS_DEBUG_BN3")) { const int v = atoi(e); if (v == 32 || v == 64) BN = v; }
+    { const int v = (int)mrdis_opt(MRDIS_OPT_BN3); if (v == 32 || v == 64) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
-    if (p.Cout <= 16 && p.Cin <= 32 && p.vec_in && ptiles <= 0x7fffffffLL && !getenv("MRDIS_DEBUG_NO16_3D")) {
+    if (p.Cout <= 16 && p.Cin <= 32 && p.vec_in && ptiles <= 0x7fffffffLL && !mrdis_opt(MRDIS_OPT_NO16_3D)) {
         const int KC16 = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : (p.Cin <= 16 ? 16 : 32));
         const long long npix = (long long)p.TinD * p.TinH * p.TinW;
         const size_t lds16 = sizeof(float) * ((size_t)32 + (size_t)p.ntaps * KC16 * 16 + (size_t)npix * (KC16 + 1));
@@ -526,7 +526,7 @@ static int run_tapconv3d(Conv3dParams p, hipStream_t s) {
         }
     }
     int KC = p.Cin <= 4 ? 4 : 8;
-    if (const char* e = getenv("MRDIS_DEBUG_KC3")) { const int v = atoi(e); if ((v == 4 || v == 8) && v < KC) KC = v; }
+    { const int v = (int)mrdis_opt(MRDIS_OPT_KC3); if ((v == 4 || v == 8) && v < KC) KC = v; }
     const size_t LDS_MAX = 80 * 1024;        // two workgroups per CU
     while (tapconv3d_lds(p, KC, BN) > LDS_MAX && KC > 4) KC >>= 1;
     while (tapconv3d_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
@@ -559,8 +559,7 @@ size_t mrdis_wino_wgrad3d_workspace(int N, int D, int H, int W, int Ci, int Co);
 int mrdis_run_wino_wgrad3d(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
                            size_t workspace_bytes, int N, int D, int H, int W, int Ci, int Co, hipStream_t s);
 static bool wino3d_wgrad_wanted(int N, int D, int H, int W, int Ci, int Co, int stride) {
-    const char* e = getenv("MRDIS_WINO");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = (int)mrdis_opt(MRDIS_OPT_WINO);          // MRDIS_WINO at load; mrdis_set_option("wino", v) afterwards
     if (mode == 0 || stride != 1 || mrdis_wino_wgrad3d_workspace(N, D, H, W, Ci, Co) == 0) return false;
     if (mode == 2) return true;
     if (Co % 64 != 0 && Ci < 128) return false;
@@ -568,8 +567,7 @@ static bool wino3d_wgrad_wanted(int N, int D, int H, int W, int Ci, int Co, int 
 }
 // measured policy (tools/bench3d.py --layers): MRDIS_WINO = 0 never | 1 where it wins | 2 wherever it applies
 static bool wino3d_wanted(int N, int D, int H, int W, int Ci, int Co, int stride) {
-    const char* e = getenv("MRDIS_WINO");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = (int)mrdis_opt(MRDIS_OPT_WINO);          // MRDIS_WINO at load; mrdis_set_option("wino", v) afterwards
     if (mode == 0 || stride != 1) return false;
     if (mode == 2) return Ci >= 8 && Co >= 8;
     if (Ci < 16 || Co < 32) return false;
@@ -1208,7 +1206,7 @@ struct Wgrad3d16Plan { Wgrad3d16Params p; int CW; size_t lds; long long slab_flo
 
 static void plan_wgrad3d16(Wgrad3d16Plan& pl, int N, int D, int H, int W, int ldx, int Ci, int Co, int stride) {
     pl.ok = false;
-    if (stride != 1 || Co % 4 != 0 || (Co > 16 && Co % 16 != 0) || Ci % 4 != 0 || (Ci > 16 && Ci % 16 != 0) || getenv("MRDIS_DEBUG_NO16_3D")) return;
+    if (stride != 1 || Co % 4 != 0 || (Co > 16 && Co % 16 != 0) || Ci % 4 != 0 || (Ci > 16 && Ci % 16 != 0) || mrdis_opt(MRDIS_OPT_NO16_3D)) return;
     Wgrad3d16Params& p = pl.p;
     p = Wgrad3d16Params{};
     p.N = N; p.D = D; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.Co = Co;

@@ -5,6 +5,8 @@
 // Reductions are two-level with a fixed summation order (partials in fp32 over
 // short runs, combination in fp64) so every result is bit-reproducible.
 #include "mrdis_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 // ------------------------------------------------------------------ small vector helper
 template <int V> struct Vec;
@@ -685,8 +687,8 @@ extern "C" int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx
     // support of an input pixel along one axis: < 2 / scale + 1 output pixels (scale = input step per output pixel)
     const float smin = sh < sw ? sh : sw;
     const bool big = (long long)N * Hi * Wi * C >= 6000000LL;          // measured: 108 vs 129 us at 16 M elements, a wash below 6 M
-    const bool tight3 = big && sh >= 1.f && sw >= 1.f, tight5 = big && smin > 0.4975f && !getenv("MRDIS_DEBUG_BILGEN");
-    if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight3 && !getenv("MRDIS_DEBUG_BILGEN"))
+    const bool tight3 = big && sh >= 1.f && sw >= 1.f, tight5 = big && smin > 0.4975f && !mrdis_opt(MRDIS_OPT_BILGEN);
+    if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight3 && !mrdis_opt(MRDIS_OPT_BILGEN))
         hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 3, 3>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight5)
         hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 5, 5>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
@@ -1084,9 +1086,20 @@ extern "C" int mrdis_sumsq_finite(const float* g, long long n, float* out, void*
 // torch.optim.Adam(amsgrad=True, weight_decay=wd) single-tensor rule, fp32:
 //   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; vmax = max(vmax, v)
 //   p -= (lr / (1-b1^t)) * m / (sqrt(vmax)/sqrt(1-b2^t) + eps)
+// Segment gates: torch's Adam skips a parameter whose gradient is None (a decoder whose modality is absent from the whole
+// batch); in the arena that is an index range, gated by a device flag (0 = no gradient arrived: leave p, m, v, vmax alone).
+#define ADAM_MAX_GATES 32
+struct AdamGates { int n; long long lo[ADAM_MAX_GATES], hi[ADAM_MAX_GATES]; int flag[ADAM_MAX_GATES]; };
+
+// step_state[0] = optimizer steps applied so far, [1] = steps skipped because a gradient was non-finite
+__global__ void adam_advance_kernel(float* __restrict__ step_state, const float* __restrict__ norm_finite) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (norm_finite && norm_finite[1] > 0.f) step_state[1] += 1.f; else step_state[0] += 1.f;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sbc2,
-                            const float* __restrict__ norm_finite, float max_norm, float gscale) {
+                            const float* __restrict__ norm_finite, float max_norm, float gscale,
+                            const float* __restrict__ step_state, const float* __restrict__ gate_flags, AdamGates gates) {
     float coef = gscale;
     if (norm_finite) {
         if (norm_finite[1] > 0.f) return;                       // non-finite gradient: skip the step (main_missing.py:273-278)
@@ -1096,8 +1109,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             coef = gscale * (cc < 1.f ? cc : 1.f);
         }
     }
+    if (step_state) {                                           // bias corrections from the device-side step counter
+        const float t = step_state[0];
+        bc1 = 1.f - powf(b1, t); sbc2 = sqrtf(1.f - powf(b2, t));
+    }
     const float step = lr / bc1;
     EW_LOOP(n) {
+        if (gate_flags) {
+            bool off = false;
+            for (int k = 0; k < gates.n; ++k) off |= (idx >= gates.lo[k] && idx < gates.hi[k] && gate_flags[gates.flag[k]] == 0.f);
+            if (off) continue;
+        }
         const float pv = p[idx];
         const float gv = g[idx] * coef + wd * pv;
         const float mv = b1 * m[idx] + (1.f - b1) * gv;
@@ -1109,18 +1131,73 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                                        long long n, float lr, float beta1, float beta2, float eps,
-                                       float weight_decay, int step_count, const float* norm_finite,
-                                       float max_norm, float grad_scale, void* stream) {
-    if (!p || !g || !m || !v || !vmax || n < 1 || step_count < 1) return MRDIS_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step_count);
-    const float sbc2 = sqrtf(1.f - powf(beta2, (float)step_count));
+                                       float weight_decay, int step_count, float* step_state, const float* norm_finite,
+                                       float max_norm, float grad_scale, const long long* gate_ranges, const int* gate_flag_index,
+                                       int n_gates, const float* gate_flags, void* stream) {
+    if (!p || !g || !m || !v || !vmax || n < 1 || (!step_state && step_count < 1)) return MRDIS_EINVAL;
+    if (n_gates < 0 || n_gates > ADAM_MAX_GATES || (n_gates > 0 && (!gate_ranges || !gate_flag_index || !gate_flags))) return MRDIS_EINVAL;
+    AdamGates gates{};
+    gates.n = n_gates;
+    for (int k = 0; k < n_gates; ++k) { gates.lo[k] = gate_ranges[2 * k]; gates.hi[k] = gate_ranges[2 * k + 1]; gates.flag[k] = gate_flag_index[k]; }
+    float bc1 = 1.f, sbc2 = 1.f;
+    if (step_state) {
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, norm_finite);
+        MRDIS_CHECK_LAUNCH();
+    } else {
+        bc1 = 1.f - powf(beta1, (float)step_count);
+        sbc2 = sqrtf(1.f - powf(beta2, (float)step_count));
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, sbc2, norm_finite, max_norm, grad_scale);
+                       weight_decay, bc1, sbc2, norm_finite, max_norm, grad_scale, (const float*)step_state,
+                       n_gates > 0 ? gate_flags : (const float*)nullptr, gates);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 // ------------------------------------------------------------------ misc
+// ---------------------------------------------------------------------------------------------- process-wide switches
+namespace {
+struct OptDef { const char* name; const char* env; int is_flag; long long dflt; };
+const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
+    {"wino", "MRDIS_WINO", 0, 1},            // 0 direct kernels only | 1 measured policy | 2 Winograd wherever it applies
+    {"nt_mb", "MRDIS_NT_MB", 0, 128},        // outputs of at least this many MB leave the Winograd kernel with non-temporal stores
+    {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
+    {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
+    {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},
+    {"debug_mode", "MRDIS_DEBUG_MODE", 0, -1}, {"debug_bn", "MRDIS_DEBUG_BN", 0, -1}, {"debug_kc", "MRDIS_DEBUG_KC", 0, -1},
+    {"debug_bm", "MRDIS_DEBUG_BM", 0, -1}, {"debug_c4_tw", "MRDIS_DEBUG_C4_TW", 0, -1}, {"debug_wgsplit", "MRDIS_DEBUG_WGSPLIT", 0, -1},
+    {"debug_bn3", "MRDIS_DEBUG_BN3", 0, -1}, {"debug_kc3", "MRDIS_DEBUG_KC3", 0, -1},
+};
+long long* opt_table() {
+    static long long* table = [] {
+        static long long v[MRDIS_OPT_COUNT];
+        for (int i = 0; i < MRDIS_OPT_COUNT; ++i) {
+            const char* e = getenv(OPT_DEFS[i].env);
+            v[i] = !e ? OPT_DEFS[i].dflt : (OPT_DEFS[i].is_flag ? 1 : atoll(e));
+        }
+        return v;
+    }();
+    return table;
+}
+int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < MRDIS_OPT_COUNT; ++i)
+        if (!strcmp(name, OPT_DEFS[i].name)) return i;
+    return -1;
+}
+}  // namespace
+long long mrdis_opt(int id) { return opt_table()[id]; }
+extern "C" int mrdis_set_option(const char* name, long long value) {
+    const int i = opt_index(name);
+    if (i < 0) return MRDIS_EINVAL;
+    opt_table()[i] = value;
+    return MRDIS_OK;
+}
+extern "C" long long mrdis_get_option(const char* name) {
+    const int i = opt_index(name);
+    return i < 0 ? (long long)MRDIS_EINVAL : opt_table()[i];
+}
+
 extern "C" const char* mrdis_strerror(int code) {
     switch (code) {
         case MRDIS_OK: return "ok";
@@ -1132,4 +1209,4 @@ extern "C" const char* mrdis_strerror(int code) {
         default: return "unknown error";
     }
 }
-extern "C" int mrdis_version(void) { return 100; }
+extern "C" int mrdis_version(void) { return 110; }

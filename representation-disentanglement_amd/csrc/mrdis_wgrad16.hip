@@ -161,7 +161,7 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ slab, float* __r
 
 static bool plan_wgrad16(Wgrad16Params& p, int N, int H, int W, int Ci, int Co) {
     if (Co > 16 || Co <= 4 || Co % 4 != 0 || Ci % 16 != 0) return false;               // Cout <= 4: wgrad_thin_dma_kernel
-    if ((long long)N * H * W < 100000 || getenv("MRDIS_DEBUG_NOW16")) return false;       // small maps: the generic kernel's slabs are cheaper
+    if ((long long)N * H * W < 100000 || mrdis_opt(MRDIS_OPT_NOW16)) return false;       // small maps: the generic kernel's slabs are cheaper
     p = Wgrad16Params{};
     p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
     p.tilesA = mrdis_cdiv(H, W16_TH); p.tilesB = mrdis_cdiv(W, W16_TW);

@@ -287,7 +287,7 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     p.in = x; p.w = w; p.bias = bias; p.out = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
     p.flip = flip; p.lrelu = lrelu;
-    { const char* e = getenv("MRDIS_NT_MB"); const long long mb = e ? atoll(e) : 128; p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
+    { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
     const int CG = Co > 32 ? 2 : 1;
     p.TBH = 8; p.TBW = 8;
     const int th = (H + 1) / 2, tw = (W + 1) / 2;
@@ -318,7 +318,7 @@ int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias,
     p.in = x; p.w = w; p.bias = bias; p.out = y; p.res = res; p.ldres = ldres;
     p.D = D; p.N = N * D; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
     p.flip = flip; p.lrelu = 0;
-    { const char* e = getenv("MRDIS_NT_MB"); const long long mb = e ? atoll(e) : 128; p.nt_out = (long long)N * D * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
+    { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * D * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
     const int CG = Co > 32 ? 2 : 1;
     p.TBH = 8; p.TBW = 8;
     p.nby = mrdis_cdiv((H + 1) / 2, p.TBH); p.nbx = mrdis_cdiv((W + 1) / 2, p.TBW);

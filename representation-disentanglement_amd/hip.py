@@ -30,6 +30,8 @@ _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_float, _c.c_size
 _SIGS = {
     'mrdis_strerror': (_c.c_char_p, [_I]),
     'mrdis_version': (_I, []),
+    'mrdis_set_option': (_I, [_c.c_char_p, _L]),
+    'mrdis_get_option': (_L, [_c.c_char_p]),
     'mrdis_mix_experts_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_bwd_workspace': (_Z, [_I, _I, _I, _I]),
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
@@ -64,7 +66,7 @@ _SIGS = {
     'mrdis_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_sumsq_workspace': (_Z, []),
     'mrdis_sumsq_finite': (_I, [_P, _L, _P, _P, _Z, _P]),
-    'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+    'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P]),
     'mrdis_conv3d_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv3d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv3d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -99,6 +101,29 @@ def load(path=None):
 def _chk(rc, what):
     if rc != 0:
         raise MrdisError(f'{what}: {load().mrdis_strerror(rc).decode()} ({rc})')
+
+
+def set_option(name, value):
+    """process-wide kernel-selection switch (include/mrdis.h: "wino", "nt_mb", "debug_*")."""
+    _chk(load().mrdis_set_option(name.encode(), int(value)), f'set_option({name})')
+
+
+def get_option(name):
+    return int(load().mrdis_get_option(name.encode()))
+
+
+class option:
+    """`with hip.option('wino', 0): ...` -- set a switch for a scope (tests, A/B timing)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
 
 
 def _stream():
@@ -488,10 +513,22 @@ def sumsq_finite(g, out):
     _chk(lib.mrdis_sumsq_finite(_ptr(g), g.numel(), _ptr(out), _ptr(ws), nb, _stream()), 'sumsq_finite')
 
 
-def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, norm_finite, max_norm, grad_scale=1.0):
+def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, norm_finite, max_norm, grad_scale=1.0,
+                      step_state=None, gates=None):
+    """step: 1-based host count, ignored when `step_state` (device float[2]: applied, skipped) is given.
+    gates: (ranges [(lo, hi), ...], flag_index [...], flags device tensor) or None."""
     lib = load()
+    if gates is not None and len(gates[0]):
+        ranges, fidx, flags = gates
+        n_g = len(ranges)
+        ra = (_c.c_longlong * (2 * n_g))(*[int(x) for r in ranges for x in r])
+        fa = (_c.c_int * n_g)(*[int(i) for i in fidx])
+        fl = flags.data_ptr()
+    else:
+        n_g, ra, fa, fl = 0, None, None, None
     _chk(lib.mrdis_adam_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                                     step, _ptr(norm_finite), max_norm, grad_scale, _stream()), 'adam_amsgrad_step')
+                                     int(step), _ptr(step_state), _ptr(norm_finite), max_norm, grad_scale, ra, fa, n_g, fl, _stream()),
+         'adam_amsgrad_step')
 
 
 # ================================================================ 3-D path (NDHWC, torch.channels_last_3d)

@@ -555,6 +555,48 @@ class MultimodalModel(nn.Module):
         self._type_table = ops.register_type_table(
             torch.arange(1, modality_num + 1, dtype=torch.float32, device=device).view(modality_num, 1))
 
+    # ---- which parameters the step can reach
+    _DEAD = ('.convs.',)                               # ModalityEncoderNew.convs: built, never called (model.py:2346-2357)
+    _DEAD_LAST_BN = ('anatomy_encoder_dec.output.bn.', 'output_decoder.output.bn.')      # is_last: bn created, not applied (:2189)
+
+    def trainable_parameters(self):
+        """The static list of parameters that receive a gradient in a training step: everything that requires grad
+        except the reference's dead modules (their state_dict keys and RNG draws exist, their gradients never do).
+        Pinned against the reference by the step goldens (same set of tensors with a gradient)."""
+        out = []
+        for n, p in self.named_parameters():
+            if not p.requires_grad:
+                continue
+            if n.startswith('modality_encoder_list.') and any(d in n for d in self._DEAD):
+                continue
+            if n.startswith(self._DEAD_LAST_BN):
+                continue
+            out.append(p)
+        return out
+
+    def gated_parameter_groups(self):
+        """group i = the parameters of input decoder i (SPADENewNotShared): they get a gradient only from batches in which
+        modality i is present (every loss term through decoder i is masked by mask[:, i], model.py:3319-3341, 3388);
+        torch's Adam leaves such a parameter alone (grad None), and so does the arena step (ArenaAdam.set_gates)."""
+        return [list(self.input_decoder_list[i].parameters()) for i in range(self.modality_num)]
+
+    def active_decoders(self, mask_host):
+        """(M,) 0/1 numpy vector: which input decoders a batch with this mask sends a gradient to -- the host-side twin of
+        the masking in compute_recon_loss_x_list / _x_mix_list / compute_latent_z_loss (model.py:3315-3341, 3384-3394),
+        including the QUIRK of the mix loss: its output index only advances on non-empty pairs (:3335-3338), so after a
+        skipped pair a term reads the reconstruction of an EARLIER (decoder, type) pair and that decoder gets the gradient."""
+        mh = _host_mask(None, mask_host)
+        M = self.modality_num
+        act = (mh.sum(0) > 0).astype(np.float32)                           # recon_x / latent_z terms of modality i
+        pairs = [(i, j) for i in range(M) for j in range(M) if i != j]      # order of reconstruct_input_si_zj's outputs
+        idx = 0
+        for i, j in pairs:
+            if (mh[:, i] * mh[:, j]).sum() == 0:
+                continue
+            act[pairs[idx][0]] = 1.0
+            idx += 1
+        return act
+
     # ---- helpers
     def _type(self, i, B):
         key = (i, B)

@@ -113,117 +113,251 @@ def fit_to_model(x, size, fill=-10.0):
 
 
 # --------------------------------------------------------------------------- flat parameter arena + Adam
-class ArenaAdam:
+class ArenaAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, weight_decay=wd, amsgrad=True) (main_missing.py:118) with
     clip_grad_norm_(1.0) (:272) and the finite check (:273-278) folded into the step.
 
-    Built lazily at the first step from the parameters that actually carry a gradient (43 % of
-    the reference's parameters never do; torch's Adam skips those, so do we).
-    Afterwards `p.data` / `p.grad` are views into the arena.
+    The parameters that can receive a gradient live in ONE flat fp32 arena (weights, grads, Adam m / v / vmax);
+    `p.data` / `p.grad` are views.  Membership is STATIC when `used` is given (TrainStep passes the model's
+    `trainable_parameters()`: 43 % of the reference's parameters never get a gradient; torch's Adam skips
+    those, so do we) and identical on every data-parallel rank; without `used` it is taken from the first backward
+    (generic use).  A torch.optim.Optimizer subclass, so ReduceLROnPlateau (main_missing.py:119) attaches to it and
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's checkpoint format (:126, :330-335).
+
+    * `step_state` (device float[2]): optimizer steps applied / skipped as non-finite.  The bias correction reads the
+      device counter, so a skipped step does not advance it; `skipped_steps()` exposes the count (one D2H copy).
+    * gates: groups of parameters that receive no gradient when their modality is absent from the whole batch
+      (`set_gates`); the per-group activity flags ride at the tail of the gradient buffer (so a data-parallel sum
+      all-reduce ORs them across ranks) and the Adam kernel leaves a gated-off range untouched, as torch's Adam does
+      for `grad is None`.
     """
 
-    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_norm=1.0):
-        self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.step_count = 0
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_norm=1.0, used=None,
+                 share_weights_of=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
+        super().__init__(list(params), defaults)
+        self.params = [p for p in self.param_groups[0]['params']]
+        self.max_norm = max_norm
+        self.step_count = 0                     # host-side count of step() calls (the device counter is authoritative)
         self.flat_p = self.flat_g = self.m = self.v = self.vmax = None
         self.used = None
-        self.norm_finite = None
+        self.norm_finite = self.step_state = None
+        self.gate_ranges, self.gate_flag_index, self.gate_flags, self.n_flags = [], [], None, 0
+        self._share = share_weights_of
+        if share_weights_of is not None:
+            self._build(share_weights_of.used)
+        elif used is not None:
+            self._build(list(used))
 
-    def _build(self):
-        used = [p for p in self.params if p.grad is not None]
-        if not used:
-            raise RuntimeError('ArenaAdam.step() before any backward()')
+    # convenience views of the single param group (the scheduler writes group['lr'])
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @property
+    def betas(self):
+        return self.param_groups[0]['betas']
+
+    @property
+    def eps(self):
+        return self.param_groups[0]['eps']
+
+    @property
+    def wd(self):
+        return self.param_groups[0]['weight_decay']
+
+    TAIL = 32                                   # floats reserved behind the gradients for the gate flags
+
+    def _build(self, used=None):
+        if used is None:
+            used = [p for p in self.params if p.requires_grad and p.grad is not None]
+            if not used:
+                raise RuntimeError('ArenaAdam.step() before any backward()')
+        used = [p for p in used if p.requires_grad]
         # parameters whose gradient the backward kernels add to in place (ops._grad_sink) never pass through autograd's
         # accumulation, so their post-accumulate hooks do not fire: keep them together at the end of the arena, i.e. in
         # the last all-reduce bucket (GradAllReduce.finish() reduces it after backward; the others keep overlapping)
         used.sort(key=lambda p: 1 if getattr(p, '_mrdis_sink', False) else 0)
         dev = used[0].device
-        # 16-byte align every tensor inside the arena (vectorised kernels read params in place)
-        offs, n = [], 0
-        for p in used:
-            offs.append(n); n += (p.numel() + 3) // 4 * 4
-        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        share = self._share
+        if share is not None:                   # second optimizer over the same weights (optimizer_d_s, main_missing.py:121-122)
+            self.offsets, self.numel, self.flat_p = share.offsets, share.numel, share.flat_p
+            n = self.numel
+        else:
+            # 16-byte align every tensor inside the arena (vectorised kernels read params in place)
+            offs, n = [], 0
+            for p in used:
+                offs.append(n); n += (p.numel() + 3) // 4 * 4
+            self.offsets, self.numel = offs, n
+            self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._g_full = torch.zeros(n + self.TAIL, dtype=torch.float32, device=dev)
+        self.flat_g = self._g_full[:n]
+        self.grad_views = []
         with torch.no_grad():
-            for p, o in zip(used, offs):
+            for p, o in zip(used, self.offsets):
                 k = p.numel()
-                self.flat_p[o:o + k].copy_(p.data.reshape(-1))
-                self.flat_g[o:o + k].copy_(p.grad.reshape(-1))
-                p.data = self.flat_p[o:o + k].view(p.shape)
-                p.grad = self.flat_g[o:o + k].view(p.shape)
+                gv = self.flat_g[o:o + k].view(p.shape)
+                if share is None:
+                    self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+                    if p.grad is not None:
+                        gv.copy_(p.grad)
+                    p.data = self.flat_p[o:o + k].view(p.shape)
+                    p.grad = gv
+                self.grad_views.append(gv)
         self.m = torch.zeros_like(self.flat_p); self.v = torch.zeros_like(self.flat_p); self.vmax = torch.zeros_like(self.flat_p)
-        self.used, self.offsets, self.numel = used, offs, n
+        self.used = used
         self.used_ids = {id(p) for p in used}
         self.norm_finite = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.step_state = torch.zeros(2, dtype=torch.float32, device=dev)
 
-    def grad_norm_sq(self):
+    def attach_grads(self):
+        """make `p.grad` of every arena parameter a view of THIS optimizer's gradient buffer (two optimizers over one
+        set of weights take turns: generator loss, then discriminator loss)."""
+        for p, gv in zip(self.used, self.grad_views):
+            p.grad = gv
+
+    def set_gates(self, groups):
+        """groups: list of parameter lists; group k's parameters are stepped only while flag k is non-zero."""
+        off = {id(p): (o, p.numel()) for p, o in zip(self.used, self.offsets)}
+        ranges, fidx = [], []
+        for k, group in enumerate(groups):
+            spans = sorted(off[id(p)] for p in group if id(p) in off)
+            cur = None
+            for o, n in spans:                  # merge neighbours (alignment padding between them belongs to nobody)
+                if cur is not None and o <= cur[1] + 3:
+                    cur[1] = o + n
+                else:
+                    if cur is not None:
+                        ranges.append(tuple(cur)); fidx.append(k)
+                    cur = [o, o + n]
+            if cur is not None:
+                ranges.append(tuple(cur)); fidx.append(k)
+        if len(ranges) > 32 or len(groups) > self.TAIL:
+            raise NotImplementedError('more gated segments than the Adam kernel takes (32)')
+        self.gate_ranges, self.gate_flag_index, self.n_flags = ranges, fidx, len(groups)
+        self.gate_flags = self._g_full[self.numel:self.numel + self.n_flags]
+
+    def mark_active(self, flags):
+        """flags: (n_groups,) device tensor, > 0 where the group receives a gradient from this (micro-)batch."""
+        if self.n_flags:
+            self.gate_flags.add_(flags.to(self.gate_flags.dtype))
+
+    def _gates(self):
+        return (self.gate_ranges, self.gate_flag_index, self.gate_flags) if self.gate_ranges else None
+
+    def grad_norm_sq(self, g=None):
         """device tensor [sum g^2, #non-finite] over the arena."""
         self.norm_finite.zero_()
-        hip.sumsq_finite(self.flat_g, self.norm_finite)
+        hip.sumsq_finite(self.flat_g if g is None else g, self.norm_finite)
         return self.norm_finite
 
-    def clip_in_place(self):
+    def clip_in_place(self, g=None):
         """clip_grad_norm_ semantics on the accumulated gradient (used between micro-batches when
-        accumulating, main_missing.py:272 runs every iteration)."""
-        nf = self.grad_norm_sq()
+        accumulating, main_missing.py:272 runs every iteration).  Leaves [sum g^2, #non-finite] of the UNCLIPPED
+        gradient in `norm_finite`, which then gates the Adam step (non-finite => skipped)."""
+        g = self.flat_g if g is None else g
+        nf = self.grad_norm_sq(g)
         coef = torch.clamp(self.max_norm / (torch.sqrt(nf[0]) + 1e-6), max=1.0)
-        self.flat_g.mul_(coef)
+        g.mul_(coef)
+        return nf
 
     def check_new_grads(self):
         for p in self.params:
             if p.grad is not None and id(p) not in self.used_ids:
-                raise RuntimeError('a parameter outside the arena received a gradient; rebuild the optimizer')
+                raise RuntimeError('a parameter outside the arena received a gradient: the static trainable-parameter list '
+                                   'of the model is out of date (MultimodalModel.trainable_parameters)')
 
-    def step(self, fused_clip=True, grad_scale=1.0):
+    def step(self, fused_clip=True, grad_scale=1.0, g=None, gate_only=False, use_gates=False):
+        """fused_clip: norm + clip + finite gate inside the step (accum == 1).  gate_only: `norm_finite` already holds the
+        pair of the (clipped-in-place) gradient: only the non-finite gate is applied.  use_gates: honour the activity flags
+        of `set_gates` (the caller marked this step's active groups with `mark_active`)."""
         if self.used is None:
             self._build()
         self.step_count += 1
+        g = self.flat_g if g is None else g
         nf = None
         if fused_clip:
-            nf = self.grad_norm_sq()
-        hip.adam_amsgrad_step(self.flat_p, self.flat_g, self.m, self.v, self.vmax, self.lr, self.betas[0], self.betas[1],
-                              self.eps, self.wd, self.step_count, nf, self.max_norm if fused_clip else 0.0, grad_scale)
+            nf = self.grad_norm_sq(g)
+        elif gate_only:
+            nf = self.norm_finite
+        hip.adam_amsgrad_step(self.flat_p, g, self.m, self.v, self.vmax, self.lr, self.betas[0], self.betas[1],
+                              self.eps, self.wd, self.step_count, nf, self.max_norm if fused_clip else 0.0, grad_scale,
+                              step_state=self.step_state, gates=self._gates() if use_gates else None)
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=True):
         if self.used is None:
             for p in self.params:
                 p.grad = None
         else:
-            self.flat_g.zero_()
+            self._g_full.zero_()
 
-    # torch.optim-compatible checkpoint payload (main_missing.py:330-335 stores optimizer.state_dict())
+    def skipped_steps(self):
+        """number of optimizer steps the device skipped because the gradient was non-finite (one D2H copy)."""
+        return 0 if self.step_state is None else int(self.step_state[1].item())
+
+    # torch.optim.Adam-compatible checkpoint payload (main_missing.py:330-335 stores optimizer.state_dict())
     def state_dict(self):
-        if self.used is None:
-            return {'state': {}, 'param_groups': [{'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
-                                                   'weight_decay': self.wd, 'amsgrad': True}]}
-        idx = {id(p): i for i, p in enumerate(self.params)}
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        group['params'] = list(range(len(self.params)))
         state = {}
-        for p, o in zip(self.used, self.offsets):
-            k = p.numel()
-            state[idx[id(p)]] = {'step': torch.tensor(float(self.step_count)),
-                                 'exp_avg': self.m[o:o + k].view(p.shape).clone(),
-                                 'exp_avg_sq': self.v[o:o + k].view(p.shape).clone(),
-                                 'max_exp_avg_sq': self.vmax[o:o + k].view(p.shape).clone()}
-        return {'state': state, 'param_groups': [{'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
-                                                  'weight_decay': self.wd, 'amsgrad': True,
-                                                  'params': list(range(len(self.params)))}]}
+        if self.used is not None:
+            applied = float(self.step_state[0].item())
+            if applied > 0:
+                idx = {id(p): i for i, p in enumerate(self.params)}
+                for p, o in zip(self.used, self.offsets):
+                    k = p.numel()
+                    state[idx[id(p)]] = {'step': torch.tensor(applied, dtype=torch.float32),
+                                         'exp_avg': self.m[o:o + k].view(p.shape).clone(),
+                                         'exp_avg_sq': self.v[o:o + k].view(p.shape).clone(),
+                                         'max_exp_avg_sq': self.vmax[o:o + k].view(p.shape).clone()}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, state_dict):
+        """accepts what torch.optim.Adam(model.parameters(), amsgrad=True).state_dict() / our own state_dict() wrote."""
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.params):
+            raise ValueError('optimizer state_dict does not match: expected one param group over model.parameters()')
+        for k, v in groups[0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        if self.used is None:
+            if state_dict['state']:
+                raise RuntimeError('load_state_dict() needs a built arena (construct with used=...)')
+            return
+        off = {id(p): (o, p.numel()) for p, o in zip(self.used, self.offsets)}
+        applied = 0.0
+        self.m.zero_(); self.v.zero_(); self.vmax.zero_()
+        with torch.no_grad():
+            for i, st in state_dict['state'].items():
+                p = self.params[int(i)]
+                if id(p) not in off:
+                    raise ValueError(f'optimizer state for parameter #{i}, which is outside the arena')
+                o, k = off[id(p)]
+                self.m[o:o + k].copy_(st['exp_avg'].reshape(-1)); self.v[o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
+                if 'max_exp_avg_sq' in st:
+                    self.vmax[o:o + k].copy_(st['max_exp_avg_sq'].reshape(-1))
+                applied = max(applied, float(st['step']))
+        self.step_state.zero_(); self.step_state[0] = applied
+        self.step_count = int(applied)
 
 
 # --------------------------------------------------------------------------- data-parallel exchange
 class GradAllReduce:
-    """Mean-all-reduce of the gradient arena over the data-parallel group (RCCL over xGMI on
-    the GPU box, gloo in the CPU tests).  The arena is cut into `buckets` contiguous slices in
-    reverse-execution order; each slice is reduced asynchronously as soon as autograd has
-    produced every gradient in it (post-accumulate hooks), so the exchange overlaps the rest of
-    the backward pass.  BatchNorm statistics stay per replica (the reference has no SyncBN)."""
+    """Sum-all-reduce of a gradient arena over the data-parallel group (RCCL over xGMI on the GPU box, gloo in the CPU
+    tests); the 1/world scale is folded into the optimizer step.  The arena is cut into `buckets` contiguous slices; a
+    slice is reduced asynchronously as soon as autograd has produced every gradient in it (post-accumulate hooks), so
+    the exchange overlaps the rest of the backward pass; the slice that holds the in-kernel gradient sinks and the
+    gate flags goes last, from finish().  BatchNorm statistics stay per replica (the reference has no SyncBN).
+    One reducer serves every optimizer that shares the arena layout: begin(optimizer) names the buffer to reduce."""
 
     def __init__(self, optim, group=None, buckets=6):
         self.optim, self.group, self.nbuckets = optim, group, buckets
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.ready = None
+        self.target = optim
         self.handles = []
         self.hooks = []
+        self.armed = False
 
     def _setup(self):
         o = self.optim
@@ -243,6 +377,8 @@ class GradAllReduce:
         self.pending = list(self.pending0)
 
     def _hook(self, p):
+        if not self.armed:
+            return
         b, last = self.bucket_of[id(p)]
         for bb in range(b, last + 1):
             self.pending[bb] -= 1
@@ -250,31 +386,36 @@ class GradAllReduce:
                 self._launch(bb)
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 or self.launched[b]:
             return
-        sl = self.optim.flat_g[self.edges[b]:self.edges[b + 1]]
-        self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched[b] = True
+        t = self.target
+        hi = self.edges[b + 1] if b + 1 < self.nbuckets else t._g_full.numel()      # last bucket: + the gate flags
+        self.handles.append(dist.all_reduce(t._g_full[self.edges[b]:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def begin(self):
-        """call before backward()."""
+    def begin(self, target=None):
+        """call before backward(); `target`: the optimizer whose gradient buffer receives this backward pass."""
+        self.target = target or self.optim
         if self.optim.used is not None and not self.hooks:
             self._setup()
         if self.hooks:
             self.pending = list(self.pending0)
+            self.launched = [False] * self.nbuckets
         self.handles = []
+        self.armed = True
 
     def finish(self):
         """call after backward(); returns the scale (1/world) the optimizer must apply."""
+        self.armed = False
         if self.world == 1:
             return 1.0
-        if not self.hooks:                       # first step: arena not built yet -> reduce per tensor
+        if not self.hooks:                       # arena built lazily, first step: reduce per tensor
             for p in self.optim.params:
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            for b in range(self.nbuckets):       # buckets whose hooks never completed (unused grads this step)
-                if self.pending[b] != 0:
-                    self._launch(b)
+            for b in range(self.nbuckets):       # buckets whose hooks never completed (sinks, unused grads this step)
+                self._launch(b)
             for h in self.handles:
                 h.wait()
         return 1.0 / self.world
@@ -345,74 +486,87 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
 class TrainStep:
     """Owns the optimizers and runs main_missing.py:165-289 for one batch.
 
+    Accumulation (`accum = 16 // batch_size`, :282; the shipped config.yaml has batch_size 8 -> 2): every iteration
+    adds its gradient to the accumulated one and clips the ACCUMULATED gradient in place (:272 runs each iteration);
+    every `accum`-th iteration steps and zeroes.  The micro-batch gradient lands in its own buffer first, so under
+    data parallelism each iteration's gradient is summed over the ranks exactly once before it joins the accumulator.
+
     Adversarial d-step: the reference calls `loss_adv_s_d.backward()` AFTER
     `optimizer.step()` on a retained graph (:283-289); under torch >= 1.5 that raises
     (weights were modified in place) -- see tests/golden/step_b2m2_adv.json.  The
     executable order used here is: both backward passes on the un-stepped graph
-    (generator gradients first, stashed; then discriminator-loss gradients), then both
-    Adam steps; `optimizer_d_s` spans ALL parameters as in the reference (:122).
+    (generator gradients first; then the discriminator-loss gradients into the second optimizer's own
+    gradient buffer -- `p.grad` is re-pointed, nothing is cloned), then both
+    Adam steps; `optimizer_d_s` spans ALL parameters as in the reference (:122).  Like the reference (:286-289) the
+    discriminator step uses the d-loss of the iteration on which the optimizers step.
     """
 
     def __init__(self, model, config, ddp_group=None, ddp_buckets=6):
         self.model, self.config = model, config
         self.accum = max(1, 16 // config['batch_size'])                                          # :282 (guarded for B > 16)
-        self.optimizer = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=1e-5)       # :118
-        self.optimizer_d_s = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=0.0) \
-            if config['lambda_adv_s'] > 0 else None                                              # :121-122
+        used = model.trainable_parameters() if hasattr(model, 'trainable_parameters') else None
+        self.optimizer = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=1e-5, used=used)   # :118
+        if used is not None and hasattr(model, 'gated_parameter_groups'):
+            self.optimizer.set_gates(model.gated_parameter_groups())
+        self.optimizer_d_s = None
+        if config['lambda_adv_s'] > 0:                                                            # :121-122
+            if used is None:
+                raise RuntimeError('the adversarial step needs a model with a static trainable-parameter list')
+            self.optimizer_d_s = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=0.0, share_weights_of=self.optimizer)
         self.reducer = GradAllReduce(self.optimizer, ddp_group, ddp_buckets) \
             if (dist.is_available() and dist.is_initialized()) else None
+        self.acc = None                          # accumulated (already reduced, clipped) gradient when accum > 1
         self.iter = 0
-        self._stash = None
+        self.last_grad_norm_sq = None            # device [sum g^2, #non-finite] of the gradient the last clip saw
 
     def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None):
-        cfg, model = self.config, self.model
+        cfg, model, opt = self.config, self.model, self.optimizer
         adv = cfg['lambda_adv_s'] > 0
         if mask_host is None:
             mask_host = mask.cpu()
+        self.iter += 1
+        do_step = (self.iter % self.accum) == 0                                                  # :282
         with ops.mix_cache():
             loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, targets=targets)
+            if opt.used is not None and opt.n_flags:
+                opt.mark_active(ops.to_device(torch.from_numpy(model.active_decoders(mask_host)), mask.device))
             if self.reducer:
-                self.reducer.begin()
-            loss.backward(retain_graph=adv)                                                      # :268-271
+                self.reducer.begin(opt)
+            loss.backward(retain_graph=adv and do_step)                                          # :268-271
             scale = self.reducer.finish() if self.reducer else 1.0
-            self.iter += 1
-            do_step = (self.iter % self.accum) == 0                                              # :282
-            if adv:
-                # stash generator grads, get discriminator-loss grads on the same (un-stepped) graph
-                if self.optimizer.used is None:
-                    self.optimizer._build()
-                g_main = self.optimizer.flat_g.clone()
-                self.optimizer.flat_g.zero_()
+            if adv and do_step:
+                # discriminator-loss gradients on the same (un-stepped) graph, into optimizer_d_s' own buffer
+                od = self.optimizer_d_s
+                od.attach_grads()
+                if self.reducer:
+                    self.reducer.begin(od)
                 parts['adv_s_d'].backward()
-                if self.reducer and self.reducer.world > 1:
-                    dist.all_reduce(self.optimizer.flat_g, group=self.reducer.group)
-                g_d = self.optimizer.flat_g.clone()
-                self.optimizer.flat_g.copy_(g_main)
+                if self.reducer:
+                    self.reducer.finish()
+                opt.attach_grads()
+        if opt.used is None:
+            opt._build()
+        opt.check_new_grads()
         if self.accum == 1:
-            self.optimizer.step(fused_clip=True, grad_scale=scale)                               # :272 + :283
-            self.optimizer.zero_grad()                                                           # :284
+            opt.step(fused_clip=True, grad_scale=scale, use_gates=True)                          # :272 + :283
+            self.last_grad_norm_sq = opt.norm_finite
+            opt.zero_grad()                                                                      # :284
         else:
-            if scale != 1.0:
-                self.optimizer.flat_g.mul_(scale) if self.optimizer.used is not None else None
-            if self.optimizer.used is None:
-                self.optimizer._build()
-            self.optimizer.clip_in_place()
+            if self.acc is None:
+                self.acc = torch.zeros_like(opt._g_full)
+            self.acc.add_(opt._g_full, alpha=scale)                                              # += this iteration's (mean) gradient
+            opt.zero_grad()
+            n = opt.numel
+            self.last_grad_norm_sq = opt.clip_in_place(self.acc[:n]).clone()                     # :272, every iteration
             if do_step:
-                self.optimizer.step(fused_clip=False)
-                self.optimizer.zero_grad()
+                if opt.n_flags:
+                    opt.gate_flags.copy_(self.acc[n:n + opt.n_flags])
+                opt.step(fused_clip=False, gate_only=True, g=self.acc[:n], use_gates=True)       # :283; non-finite => skipped
+                opt.zero_grad(); self.acc.zero_()                                                # :284
         if adv and do_step:
             od = self.optimizer_d_s
-            if od.used is None:      # share the weight arena; own gradient / moment buffers
-                od.used, od.offsets, od.numel = self.optimizer.used, self.optimizer.offsets, self.optimizer.numel
-                od.used_ids = self.optimizer.used_ids
-                od.flat_p = self.optimizer.flat_p
-                od.flat_g = torch.zeros_like(self.optimizer.flat_g)
-                od.m = torch.zeros_like(od.flat_p); od.v = torch.zeros_like(od.flat_p); od.vmax = torch.zeros_like(od.flat_p)
-                od.norm_finite = torch.zeros(2, dtype=torch.float32, device=od.flat_p.device)
-            od.flat_g.copy_(g_d)
-            od.step_count += 1
-            hip.adam_amsgrad_step(od.flat_p, od.flat_g, od.m, od.v, od.vmax, od.lr, od.betas[0], od.betas[1], od.eps,
-                                  od.wd, od.step_count, None, 0.0, scale)                        # :287-289 (no clip on the d-step)
+            od.step(fused_clip=False, grad_scale=scale)                                          # :287-289 (no clip on the d-step)
+            od.zero_grad()
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
 
     def losses_to_host(self, parts):

@@ -26,3 +26,13 @@ def mrdis():
     assert torch.cuda.is_available()
     m.hip.load()
     return m
+
+
+@pytest.fixture(autouse=True)
+def _restore_library_options():
+    """tests switch kernel-selection options (hip.set_option) in-process: put the defaults back after each test."""
+    yield
+    m = sys.modules.get('mrdis')
+    if m is not None and getattr(m.hip, '_lib', None) is not None:
+        m.hip.set_option('wino', int(os.environ.get('MRDIS_WINO', '1')))
+        m.hip.set_option('nt_mb', int(os.environ.get('MRDIS_NT_MB', '128')))

@@ -72,7 +72,7 @@ def test_conv3d_fwd_bwd(mrdis, N, Ci, Co, D, H, W, stride):
 
 
 @pytest.mark.parametrize('N,Ci,Co,D,H,W', [(1, 32, 32, 6, 20, 24), (2, 64, 64, 3, 9, 11), (1, 16, 48, 5, 16, 16), (1, 128, 32, 2, 8, 8)])
-def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W, monkeypatch):
+def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W):
     """3x3x3 stride-1 layers through the hybrid kernel (Winograd F(2x2,3x3) in (h, w), direct in depth; mrdis_wino.hip D3)
     forced on for shapes the size policy would leave to the direct kernel: forward with bias + fused residual, data
     gradient (reversed 27-tap filter), weight gradient (one 2-D Winograd launch per depth tap where Ci / Co are 32 / 64
@@ -89,7 +89,7 @@ def test_conv3d_winograd_hybrid_forced(mrdis, N, Ci, Co, D, H, W, monkeypatch):
         conv.weight.copy_(w); conv.bias.copy_(b)
     outs = {}
     for mode in ('0', '2'):
-        monkeypatch.setenv('MRDIS_WINO', mode)
+        mrdis.hip.set_option('wino', int(mode))
         xg = cl3(x).requires_grad_(True)
         y = conv(xg, residual=cl3(res))
         y.backward(cl3(dy))

@@ -254,14 +254,14 @@ def test_train_step_vs_oracle_other_sizes(mrdis, B, M, H, W, drop, adv):
             assert p.grad is None, n
 
 
-def test_train_step_winograd_vs_direct_kernels(mrdis, monkeypatch):
+def test_train_step_winograd_vs_direct_kernels(mrdis):
     """The whole step with every eligible 3x3 layer forced through the Winograd kernels (MRDIS_WINO=2: forward, data and
     weight gradients) against the same step on the direct kernels (MRDIS_WINO=0): loss, loss parts and every parameter
     gradient.  The size policy (MRDIS_WINO=1) only picks per layer between these two."""
     B, M, H, W = 2, 3, 96, 128
     res = {}
     for mode in ('0', '2'):
-        monkeypatch.setenv('MRDIS_WINO', mode)
+        mrdis.hip.set_option('wino', int(mode))
         cfg = _cfg(mrdis, M, H, W, B, adv=True)
         torch.manual_seed(10); np.random.seed(10)
         model = mrdis.build_model(cfg).train()
@@ -323,3 +323,137 @@ def test_evaluate_batch_golden(mrdis, golden_dir):
         assert metrics[k].shape == (M * (M - 1) * meta['B'],)
         np.testing.assert_allclose(metrics[k].cpu().numpy(), want[k], rtol=1e-4, atol=1e-6, err_msg=k)
     assert model.training
+
+
+def test_train_step_accumulation_golden(mrdis, golden_dir):
+    """The reference's DEFAULT schedule (config.yaml:17 batch_size 8 -> accum = 16 // 8 = 2) through TrainStep: gradient
+    accumulation, clip_grad_norm_ on the accumulating gradient every iteration (main_missing.py:272), optimizer step on
+    every second iteration (:282-284); four iterations = two optimizer steps, vs vectors from the real reference."""
+    meta = json.load(open(os.path.join(golden_dir, 'accum_b2m2.json')))
+    B, M = meta['B'], meta['M']
+    cfg = dict(mrdis.DEFAULT_CONFIG)
+    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=160, input_width=192, batch_size=meta['batch_size'])
+    cfg = mrdis.derive_config(cfg, DEV)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg)
+    assert step.accum == meta['accum'] == 2
+    torch.manual_seed(11); np.random.seed(11)
+    for it, want in enumerate(meta['iters']):
+        inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10 + it, drop=bool(it % 2))
+        loss, parts, _ = step(cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+        assert abs(float(loss) - want['loss']) <= 1e-3 * abs(want['loss']), (it, float(loss), want['loss'])
+        for k, v in want['parts'].items():
+            assert abs(float(parts[k]) - v) <= 1e-3 * abs(v) + 1e-6, (it, k)
+        gn = float(step.last_grad_norm_sq[0].sqrt())
+        assert float(step.last_grad_norm_sq[1]) == 0
+        assert abs(gn - want['grad_norm_before_clip']) <= 2e-3 * want['grad_norm_before_clip'], (it, gn, want['grad_norm_before_clip'])
+        if want['stepped']:
+            bad = []
+            for k, v in want['wsum'].items():
+                t = model.state_dict()[k]
+                flips = 2 * cfg['lr'] * np.ceil(1e-3 * t.numel())
+                if abs(float(t.double().sum()) - v) > 2e-4 * max(1.0, abs(v)) + flips:
+                    bad.append(k)
+            assert len(bad) <= 0.02 * len(want['wsum']), (it, bad[:5])
+    assert step.optimizer.skipped_steps() == 0 and float(step.optimizer.step_state[0]) == 2
+
+
+def test_nonfinite_gradient_skips_the_step_in_both_schedules(mrdis):
+    """main_missing.py:273-278 stops on a non-finite gradient; here the device skips the optimizer step, counts it, and does
+    not advance the bias correction -- with and without accumulation (the accum path had no guard)."""
+    for bs in (16, 8):
+        cfg = dict(mrdis.DEFAULT_CONFIG); cfg.update(contrast_list=['a', 'b'], input_height=64, input_width=64, batch_size=bs)
+        cfg = mrdis.derive_config(cfg, DEV)
+        torch.manual_seed(10); np.random.seed(10)
+        model = mrdis.build_model(cfg).train()
+        step = mrdis.TrainStep(model, cfg)
+        x, mask, mask_img = mrdis.synthetic_batch(2, 2, 64, 64, seed=3)
+        bad = x.clone(); bad[0, 0, 5, 5] = float('inf')
+        before = step.optimizer.flat_p.clone()
+        for _ in range(step.accum):
+            step(cl(bad), mask.to(DEV), mask_img.to(DEV), mask)
+        assert torch.equal(before, step.optimizer.flat_p), bs
+        assert step.optimizer.skipped_steps() == 1 and float(step.optimizer.step_state[0]) == 0
+        assert float(step.optimizer.m.abs().max()) == 0
+        for _ in range(step.accum):
+            step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+        assert not torch.equal(before, step.optimizer.flat_p) and torch.isfinite(step.optimizer.flat_p).all()
+        assert float(step.optimizer.step_state[0]) == 1
+
+
+def test_absent_modality_leaves_its_decoder_untouched(mrdis):
+    """torch's Adam skips a parameter whose grad is None: a decoder whose modality is absent from the whole batch gets no
+    weight decay and no moment update; the arena step gates that range off.  Also checks the static arena membership."""
+    M, B, H, W = 3, 2, 64, 64
+    cfg = dict(mrdis.DEFAULT_CONFIG); cfg.update(contrast_list=['a', 'b', 'c'], input_height=H, input_width=W, batch_size=16)
+    cfg = mrdis.derive_config(cfg, DEV)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    step = mrdis.TrainStep(model, cfg)
+    opt = step.optimizer
+    assert len(opt.used) == len(model.trainable_parameters()) and all(p.grad is not None for p in opt.used)
+    assert all(p.grad is None for n, p in model.named_parameters() if '.convs.' in n)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, H, W, seed=3)
+    mask[:, 1] = 0; x[:, 7:14] = 0                                      # modality 1 absent from the whole batch
+    assert list(model.active_decoders(mask)) == [1.0, 0.0, 1.0]
+    dec1 = [p.detach().clone() for p in model.input_decoder_list[1].parameters()]
+    dec0 = [p.detach().clone() for p in model.input_decoder_list[0].parameters()]
+    torch.manual_seed(11); np.random.seed(11)
+    step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+    assert all(torch.equal(a, b) for a, b in zip(dec1, model.input_decoder_list[1].parameters()))
+    assert not all(torch.equal(a, b) for a, b in zip(dec0, model.input_decoder_list[0].parameters()))
+    # the QUIRK of the mix loss (non-advancing index) can route a gradient to the decoder of an absent modality
+    mh = np.ones((2, 4), dtype=np.float32); mh[:, 1] = 0
+    cfg4 = dict(mrdis.DEFAULT_CONFIG); cfg4.update(input_height=H, input_width=W)
+    m4 = mrdis.build_model(mrdis.derive_config(cfg4, DEV))
+    assert list(m4.active_decoders(mh)) == [1.0, 1.0, 1.0, 1.0]
+
+
+def test_optimizer_state_dict_round_trip_with_torch_adam(mrdis, golden_dir):
+    """ArenaAdam.state_dict() has torch.optim.Adam's layout (keys pinned by tests/golden/ckpt_layout_m2.json from the real
+    reference run) and loads into torch.optim.Adam; torch.optim.Adam's state loads back into the arena; a step after the
+    round trip is bit-identical to a step without it; ReduceLROnPlateau (main_missing.py:119) drives the arena's lr."""
+    lay = json.load(open(os.path.join(golden_dir, 'ckpt_layout_m2.json')))
+    cfg = dict(mrdis.DEFAULT_CONFIG); cfg.update(contrast_list=['a', 'b'], input_height=64, input_width=64, batch_size=16)
+    cfg = mrdis.derive_config(cfg, DEV)
+
+    def fresh():
+        torch.manual_seed(10); np.random.seed(10)
+        model = mrdis.build_model(cfg).train()
+        return model, mrdis.TrainStep(model, cfg)
+    x, mask, mask_img = mrdis.synthetic_batch(2, 2, 64, 64, seed=3)
+    args = (cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+    model, step = fresh()
+    torch.manual_seed(11); np.random.seed(11)
+    step(*args); step(*args)
+    sd = step.optimizer.state_dict()
+    g = sd['param_groups'][0]
+    assert sorted(k for k in g if k != 'params') == lay['optimizer']['param_group_keys']
+    assert g['params'] == list(range(len(list(model.parameters()))))
+    st = next(iter(sd['state'].values()))
+    assert sorted(st) == lay['optimizer']['state_entry_keys'] and float(st['step']) == 2.0
+    assert str(st['step'].dtype).replace('torch.', '') == lay['optimizer']['step_dtype'] and list(st['step'].shape) == lay['optimizer']['step_shape']
+    names = [n for n, _ in model.named_parameters()]
+    ours = {names[i] for i in sd['state']}
+    theirs = {n for n in lay['optimizer']['state_index_to_name'].values() if not n.startswith('discrim_s.')}
+    assert ours == theirs                                     # the same tensors carry optimizer state as in the reference
+    tadam = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    tadam.load_state_dict(sd)                                  # torch accepts it
+    back = tadam.state_dict()
+    wsave = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rng, nrng = torch.get_rng_state(), np.random.get_state()
+    step(*args)
+    want = step.optimizer.flat_p.clone()
+    model2, step2 = fresh()                                    # continue_train: weights + optimizer from the checkpoint dicts
+    assert not mrdis.load_checkpoint_model(model2, wsave)
+    step2.optimizer.load_state_dict(back)
+    torch.set_rng_state(rng); np.random.set_state(nrng)       # same eps draws as the third step above
+    step2(*args)
+    # BatchNorm running statistics came with the state_dict; identical weights, moments and step count => identical update
+    assert torch.equal(want, step2.optimizer.flat_p)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(step2.optimizer, mode='min', factor=0.1, patience=5, min_lr=1e-5)
+    lrs = []
+    for v in lay['monitor']:
+        sched.step(v); lrs.append(step2.optimizer.lr)
+    assert lrs == lay['lr_trajectory']

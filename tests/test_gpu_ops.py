@@ -110,7 +110,7 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
-def test_conv_winograd_forced(mrdis, case, monkeypatch):
+def test_conv_winograd_forced(mrdis, case):
     """mrdis_wino.hip (fused Winograd F(2x2,3x3)) forced on (MRDIS_WINO=2) for shapes the size policy would send to the
     direct kernel: forward (+ bias, + LeakyReLU), data gradient, and a strided (channel-slice) input view; and the two
     kernels against each other."""
@@ -123,9 +123,9 @@ def test_conv_winograd_forced(mrdis, case, monkeypatch):
     gy = rnd(tuple(y.shape), 4)
     y.backward(gy)
     w_tck, w_tkc = to_tck(w.detach()).to(dev()), to_tkc(w.detach()).to(dev())
-    monkeypatch.setenv('MRDIS_WINO', '0')
+    hip.set_option('wino', 0)
     y_direct = hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1)
-    monkeypatch.setenv('MRDIS_WINO', '2')
+    hip.set_option('wino', 2)
     y_w = hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1)
     assert not torch.equal(y_w, y_direct)                      # really another kernel
     close(y_w, y, rtol=1e-4, what='winograd fwd')
@@ -153,11 +153,11 @@ def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
 
 
 @pytest.mark.parametrize('wino', ['1', '2'])
-def test_conv_random_shapes(mrdis, wino, monkeypatch):
+def test_conv_random_shapes(mrdis, wino):
     """Seeded sweep over the dispatcher (direct MFMA / narrow / Cin = 4 / thin / Winograd / narrow-cout weight gradient):
     random channel counts (tile multiples and not), extents down to 1x1, kernels 1 / 3 / 4, strides 1 / 2 -- forward,
     data gradient, weight and bias gradient against torch fp32 on the CPU."""
-    monkeypatch.setenv('MRDIS_WINO', wino)
+    mrdis.hip.set_option('wino', int(wino))
     g = np.random.RandomState(1234 + int(wino))
     hip = mrdis.hip
     chans = [1, 3, 4, 7, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128]
@@ -202,10 +202,14 @@ def test_conv_c4_persistent_pipeline(mrdis):
                                               (12, 32, 16, 96, 96, 3, 1), (6, 64, 4, 128, 128, 3, 1),
                                               (16, 4, 64, 96, 96, 3, 1), (8, 7, 32, 128, 128, 4, 2), (8, 16, 7, 128, 96, 1, 1),
                                               (8, 4, 128, 64, 64, 3, 1)])
-def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st):
+@pytest.mark.parametrize('wino', [0, 1])
+def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st, wino):
     """weight gradient with several position tiles per workgroup: exercises the double-buffered LDS-DMA
-    steady state (and its ragged last tiles), bias column sums included."""
+    steady state (and its ragged last tiles), bias column sums included.  wino=0 pins the direct kernels
+    (`wgrad_dma_kernel` and friends: the fallback of every big layer); wino=1 is the default policy, which sends
+    the 32/64-blocked 3x3 cases to `wino_wgrad_kernel`."""
     hip = mrdis.hip
+    hip.set_option('wino', wino)
     x = rnd((N, Ci, H, W), 60).requires_grad_(False)
     w = rnd((Co, Ci, k, k), 61, 0.1).requires_grad_(True); b = rnd((Co,), 62, 0.1).requires_grad_(True)
     pad = 0 if k == 1 else 1
@@ -217,8 +221,10 @@ def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st):
 
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
-    and data gradient), ragged in both image dimensions."""
+    and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
+    Winograd kernel and the BM=256 direct variant (the fallback on every big layer) would not run at all."""
     hip = mrdis.hip
+    hip.set_option('wino', 0)
     N, Ci, Co, H, W = 12, 64, 32, 200, 216
     x = rnd((N, Ci, H, W), 90); w = rnd((Co, Ci, 3, 3), 91, 0.1); b = rnd((Co,), 92, 0.1)
     want = F.conv2d(x, w, b, 1, 1)

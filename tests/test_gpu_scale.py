@@ -1,0 +1,198 @@
+"""Parity AT THE BENCHMARKED SCALE (BASELINE.json configs[1]: B=32, M=4, 240x240 padded to 256x256, fp32).
+
+The small-shape tests of test_gpu_ops.py cannot reach the code paths that only exist at this size: the grid-size
+policy that picks the Winograd kernels (option "wino" = 1, the default), their non-temporal-store epilogue (outputs
+>= 128 MB, csrc/mrdis_wino.hip `nt_out`), the 256-position tiles of the direct kernel, the persistent Cin = 4 kernel
+beyond the Infinity Cache.  Every conv geometry of the step is run here at the batch the step uses (SPADENewShared
+runs at 4B = 128) under the default policy and checked
+  * against torch fp32 on the CPU on a sampled sub-batch (forward, data gradient; the weight gradient through a
+    cotangent that is zero outside the sampled images, which every workgroup still walks), and
+  * against the direct kernels (wino = 0) on the full tensors (all three directions).
+Reference geometry: /root/reference/src/model.py:2218-2296 (U-Net), :2332-2400 (modality encoder), :2424-2454,
+:2584-2632 (SPADE blocks), :2769-2800 (discriminator).  Tolerance: 1e-3 relative (north_star); asserted tighter."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+B, HW = 32, 256
+
+
+def zoo():
+    """(name, N, Ci, Co, k, stride, pad, H, W) -- every distinct convolution of one B=32, M=4, 256x256 step as the
+    step issues it (gamma+beta fused into one Co = 2 Ci convolution; sp1-sp3 on the 4B batch)."""
+    c, H = 32, HW
+    L = [('ana.down_1', B, 7, c, 4, 2, 1, H, H), ('ana.down_2', B, c, 2 * c, 4, 2, 1, H // 2, H // 2),
+         ('ana.down_3', B, 2 * c, 4 * c, 4, 2, 1, H // 4, H // 4), ('ana.down_4', B, 4 * c, 8 * c, 4, 2, 1, H // 8, H // 8),
+         ('ana.down_5', B, 8 * c, 8 * c, 4, 2, 1, H // 16, H // 16),
+         ('ana.up_4', B, 8 * c, 8 * c, 3, 1, 1, H // 16, H // 16), ('ana.up_3', B, 16 * c, 4 * c, 3, 1, 1, H // 8, H // 8),
+         ('ana.up_2', B, 8 * c, 2 * c, 3, 1, 1, H // 4, H // 4), ('ana.up_1', B, 4 * c, c, 3, 1, 1, H // 2, H // 2),
+         ('ana.output', B, 2 * c, 4, 3, 1, 1, H, H)]
+    h = H
+    for i, (a, b) in enumerate([(7, 16), (16, 32), (32, 64), (64, 128), (128, 128)]):
+        L.append((f'mod.conv{i + 1}', B, a, b, 3, 2, 1, h, h)); h //= 2
+    for i, (ci, co, d, n) in enumerate([(128, 128, 32, 4 * B), (128, 128, 16, 4 * B), (128, 128, 8, 4 * B),
+                                        (128, 64, 4, B), (64, 32, 2, B), (32, 16, 1, B)]):
+        hh = H // d
+        L.append((f'sp{i + 1}.si', n, 4, ci, 3, 1, 1, hh, hh))
+        L.append((f'sp{i + 1}.gamma+beta', n, ci, 2 * ci, 3, 1, 1, hh, hh))
+        L.append((f'sp{i + 1}.out', n, ci, co, 3, 1, 1, hh, hh))
+    L.append(('dec.out1x1', B, 16, 7, 1, 1, 0, H, H))
+    h = H
+    for i, (a, b) in enumerate([(4, 16), (16, 32), (32, 64), (64, 128), (128, 64)]):
+        L.append((f'disc.conv{i + 1}', B, a, b, 4, 2, 1, h, h)); h //= 2
+    return L
+
+
+ZOO = zoo()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def cl(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def rel(got, want):
+    got = got.detach().float().cpu(); want = want.detach().float().cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    return float((got - want).abs().max()) / (float(want.abs().max()) + 1e-30)
+
+
+def to_tck(w):
+    Co, Ci, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw, Ci, Co).contiguous()
+
+
+def to_tkc(w):
+    Co, Ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, Co, Ci).contiguous()
+
+
+@pytest.mark.parametrize('case', ZOO, ids=[c[0] for c in ZOO])
+def test_layer_zoo_at_bench_scale(mrdis, case):
+    name, N, Ci, Co, k, s, p, H, W = case
+    hip = mrdis.hip
+    assert hip.get_option('wino') == 1                    # the policy the benchmark runs under
+    S = sorted({0, N // 2 + 1, N - 1})                    # sampled images for the CPU reference
+    w = rnd((Co, Ci, k, k), 2, 0.5 / np.sqrt(Ci * k * k)); b = rnd((Co,), 3, 0.1)
+    Ho, Wo = hip.conv_out_hw(H, W, k, k, s, p)
+    gen = torch.Generator(device=DEV).manual_seed(1)      # the big tensors are drawn on the device; the samples go to the host
+    xd = torch.randn((N, Ci, H, W), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    dyd = torch.randn((N, Co, Ho, Wo), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    bd = b.to(DEV)
+    w_tck, w_tkc = to_tck(w).to(DEV), to_tkc(w).to(DEV)
+    # CPU fp32 on the sampled images
+    xs = xd[S].cpu().contiguous().requires_grad_(True); ws = w.clone().requires_grad_(True)
+    dy_s = dyd[S].cpu().contiguous()
+    ys = F.conv2d(xs, ws, b, s, p)
+    ys.backward(dy_s)
+    # default policy
+    y = hip.conv2d_fwd(xd, w_tck, bd, k, k, s, p)
+    dx = hip.conv2d_bwd_data(dyd, w_tkc, (H, W), k, k, s, p)
+    dw, db = hip.conv2d_bwd_weight(xd, dyd, k, k, s, p, need_bias=True)
+    assert rel(y[S], ys) <= 1e-4, ('fwd vs torch', name)
+    assert rel(dx[S], xs.grad) <= 1e-4, ('dgrad vs torch', name)
+    dys = torch.zeros_like(dyd); dys[S] = dyd[S]
+    dw_s, db_s = hip.conv2d_bwd_weight(xd, dys, k, k, s, p, need_bias=True)
+    assert rel(dw_s, to_tck(ws.grad)) <= 2e-4, ('wgrad vs torch', name)
+    assert rel(db_s, dy_s.sum((0, 2, 3))) <= 2e-4, ('dbias vs torch', name)
+    del dys
+    # direct kernels on the full tensors
+    hip.set_option('wino', 0)
+    y0 = hip.conv2d_fwd(xd, w_tck, bd, k, k, s, p)
+    dx0 = hip.conv2d_bwd_data(dyd, w_tkc, (H, W), k, k, s, p)
+    dw0, db0 = hip.conv2d_bwd_weight(xd, dyd, k, k, s, p, need_bias=True)
+    hip.set_option('wino', 1)
+    for what, a, c, tol in (('fwd', y, y0, 1e-4), ('dgrad', dx, dx0, 1e-4), ('wgrad', dw, dw0, 2e-4), ('dbias', db, db0, 2e-4)):
+        err = float((a - c).abs().max()) / float(c.abs().max())
+        assert err <= tol, (what + ' default policy vs direct', name, err)
+    # the fused LeakyReLU epilogue at this size
+    yl = hip.conv2d_fwd(xd, w_tck, bd, k, k, s, p, lrelu=True)
+    assert torch.equal(yl, F.leaky_relu(y, 0.2)) or rel(yl, F.leaky_relu(y, 0.2)) <= 1e-6, ('lrelu', name)
+
+
+def test_winograd_nontemporal_store_path_runs(mrdis):
+    """outputs >= 128 MB leave wino_conv_kernel through the non-temporal-store epilogue (csrc/mrdis_wino.hip nt_out):
+    same kernel with the threshold moved (option "nt_mb") must give bit-identical results."""
+    hip = mrdis.hip
+    N, Ci, Co, H = B, 32, 64, HW                          # sp6.gamma+beta: 537 MB output
+    x = cl(rnd((N, Ci, H, H), 7)); w = to_tck(rnd((Co, Ci, 3, 3), 8, 0.05)).to(DEV); b = rnd((Co,), 9).to(DEV)
+    y_nt = hip.conv2d_fwd(x, w, b, 3, 3, 1, 1)
+    hip.set_option('nt_mb', 1 << 40)
+    y_plain = hip.conv2d_fwd(x, w, b, 3, 3, 1, 1)
+    hip.set_option('nt_mb', 128)
+    hip.set_option('wino', 0)
+    y_direct = hip.conv2d_fwd(x, w, b, 3, 3, 1, 1)
+    assert torch.equal(y_nt, y_plain)
+    assert not torch.equal(y_nt, y_direct)                # the default policy really ran the Winograd kernel here
+    assert float((y_nt - y_direct).abs().max()) <= 1e-4 * float(y_direct.abs().max())
+
+
+def test_north_star_conv_output(mrdis):
+    """BASELINE.json north star: 3x3 s1 conv, x (32,4,240,240) -> (32,32,240,240) fp32, every output value vs torch."""
+    hip = mrdis.hip
+    x = rnd((32, 4, 240, 240), 11); w = rnd((32, 4, 3, 3), 12, 0.2); b = rnd((32,), 13, 0.1)
+    want = F.conv2d(x, w, b, 1, 1)
+    got = hip.conv2d_fwd(cl(x), to_tck(w).to(DEV), b.to(DEV), 3, 3, 1, 1)
+    assert rel(got, want) <= 1e-5
+    x6 = rnd((32, 4, 256, 256), 14)                        # the same layer at the in-step size (268 MB out)
+    want6 = F.conv2d(x6, w, b, 1, 1)
+    got6 = hip.conv2d_fwd(cl(x6), to_tck(w).to(DEV), b.to(DEV), 3, 3, 1, 1)
+    assert rel(got6, want6) <= 1e-5
+
+
+def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
+    """One B=32, M=4, 256x256 training step (the headline workload, adversarial loss on) under the default policy vs
+    the direct kernels only: loss, every loss part, every parameter gradient, and the weights after Adam."""
+    m = mrdis
+    H = W = HW
+    res = {}
+    for mode in (1, 0):
+        m.hip.set_option('wino', mode)
+        cfg = dict(m.DEFAULT_CONFIG); cfg.update(input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0, is_patch_gan=True)
+        cfg = m.derive_config(cfg, DEV)
+        torch.manual_seed(10); np.random.seed(10)
+        model = m.build_model(cfg).train()
+        x, mask, mask_img = m.synthetic_batch(B, 4, 240, 240, seed=10)
+        x = m.fit_to_model(x, (H, W), fill=-10.0); mask_img = (x[:, 0] == 0).float()
+        step = m.TrainStep(model, cfg)
+        torch.manual_seed(11); np.random.seed(11)
+        grads = {}
+        # first step: the arena does not exist yet, so every gradient passes through autograd's accumulation; with the
+        # adversarial loss there are two backward passes (generator, then discriminator loss) -> keep both
+        hooks = [p.register_post_accumulate_grad_hook(lambda p_, n=n: grads.setdefault(n, []).append(p_.grad.detach().clone()))
+                 for n, p in model.named_parameters()]
+        loss, parts, _ = step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+        for h in hooks:
+            h.remove()
+        res[mode] = (float(loss), {k_: float(v) for k_, v in parts.items()}, grads,
+                     {n: p.detach().clone() for n, p in model.named_parameters()})
+        del model, step
+        torch.cuda.empty_cache()
+    (l1, p1, g1, w1), (l0, p0, g0, w0) = res[1], res[0]
+    assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
+    for k_ in p0:
+        assert abs(p1[k_] - p0[k_]) <= 2e-4 * abs(p0[k_]) + 1e-7, (k_, p1[k_], p0[k_])
+    assert set(g0) == set(g1) and len(g0) > 200
+    assert any(not torch.equal(g0[n][0], g1[n][0]) for n in g0), 'the default policy did not change any kernel'
+    for pass_ in (0, 1):
+        names = [n for n in g0 if len(g0[n]) > pass_]
+        tot = float(torch.sqrt(sum((g0[n][pass_].double() ** 2).sum() for n in names)))
+        for n in names:
+            a, c = g0[n][pass_], g1[n][pass_]
+            err = float((a - c).double().norm())
+            assert err <= 2e-3 * float(a.double().norm()) + 2e-5 * tot, (pass_, n, err, float(a.norm()))
+    # an Adam step moves a weight by at most ~lr = 2e-4 (the sign of a noise-level gradient, e.g. of a conv bias in front of
+    # BatchNorm, may flip): bound the worst case
+    # and require the bulk to agree
+    for n in w0:
+        d = (w0[n] - w1[n]).abs()
+        assert float(d.max()) <= 8.4e-4, n          # two Adam steps (generator + discriminator optimizer), each <= ~lr per element
+    num = sum(float((w0[n] - w1[n]).abs().sum()) for n in w0); den = sum(w0[n].numel() for n in w0)
+    assert num / den <= 2e-6, num / den

@@ -148,6 +148,31 @@ def test_full_step(golden_dir, tag):
         assert abs(w1[k] - v) <= 5e-5 * max(1.0, abs(v)), (k, w1[k], v)
 
 
+def test_accumulation_schedule(golden_dir):
+    """the reference's default optimizer schedule (config.yaml batch_size 8 -> two micro-batches per optimizer step, clip
+    on the accumulating gradient every iteration, main_missing.py:268-284): oracle vs tests/golden/accum_b2m2.json."""
+    meta = json.load(open(os.path.join(golden_dir, 'accum_b2m2.json')))
+    B, M = meta['B'], meta['M']
+    torch.manual_seed(10); np.random.seed(10)
+    model = R.RefMultimodalModel((160, 192), M).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5, amsgrad=True)
+    torch.manual_seed(11); np.random.seed(11)
+    batches = [make_inputs(B, M, 160, 192, seed=10 + it, drop=bool(it % 2)) for it in range(len(meta['iters']))]
+    wsums = {}
+
+    def snap(it, rec):
+        if rec['stepped']:
+            wsums[it] = {k: float(v.double().sum()) for k, v in model.state_dict().items() if k in meta['wsum_before']}
+    got = R.ref_train_iterations(model, opt, batches, meta['batch_size'], meta['lambdas'], on_iter=snap)
+    for it, (g, want) in enumerate(zip(got, meta['iters'])):
+        assert g['stepped'] == want['stepped']
+        assert abs(g['loss'] - want['loss']) <= 5e-5 * abs(want['loss']), it
+        assert abs(g['grad_norm_before_clip'] - want['grad_norm_before_clip']) <= 1e-3 * want['grad_norm_before_clip'], it
+        if want['stepped']:
+            bad = [k for k, v in want['wsum'].items() if abs(wsums[it][k] - v) > 1e-4 * max(1.0, abs(v))]
+            assert len(bad) <= 0.02 * len(want['wsum']), (it, bad[:5])    # noise-level gradients may flip Adam's first +-lr move
+
+
 def test_evaluate_batch(golden_dir):
     """evaluate() of the reference (model.eval(), z = mu) for one batch."""
     meta = json.load(open(os.path.join(golden_dir, 'eval_b2m4.json')))

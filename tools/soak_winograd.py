@@ -11,7 +11,7 @@ cfg = dict(mrdis.DEFAULT_CONFIG); cfg.update(contrast_list=['T1','T1c','T2','T2_
 cfg = mrdis.derive_config(cfg, dev)
 res = {}
 for mode in ('1', '0'):
-    os.environ['MRDIS_WINO'] = mode
+    mrdis.hip.set_option('wino', int(mode))
     torch.manual_seed(10); np.random.seed(10)
     model = mrdis.build_model(cfg).train()
     step = mrdis.TrainStep(model, cfg)

@@ -26,13 +26,13 @@ for name, ci, co, k, s, p, hi, wi, calls, dcalls in layers(B, H, W):
             cout = co if kind == 'fwd' else ci
             if bn > 32 and bn // 2 >= cout:
                 continue
-            os.environ['MRDIS_DEBUG_BN'] = str(bn); os.environ['MRDIS_DEBUG_KC'] = str(kc); os.environ['MRDIS_DEBUG_MODE'] = str(pf); os.environ['MRDIS_DEBUG_BM'] = str(bm)
+            hip.set_option('debug_bn', bn); hip.set_option('debug_kc', kc); hip.set_option('debug_mode', pf); hip.set_option('debug_bm', bm)
             try:
                 res.append((timeit(fn, 3), bn, kc, pf, bm))
             except Exception as e:
                 pass
-        for v in ('MRDIS_DEBUG_BN', 'MRDIS_DEBUG_KC', 'MRDIS_DEBUG_MODE', 'MRDIS_DEBUG_BM'):
-            os.environ.pop(v, None)
+        for v in ('debug_bn', 'debug_kc', 'debug_mode', 'debug_bm'):
+            hip.set_option(v, -1)
         dflt = timeit(fn, 3)
         res.sort()
         flop = 2.0 * k * k * ci * co * B * ho * wo
