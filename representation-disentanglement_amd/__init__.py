@@ -11,7 +11,7 @@ import it through the `mrdis` alias at the repository root:
 Layout: csrc/ (hand-written HIP kernels + C ABI, include/mrdis.h), hip.py (ctypes
 binding), ops.py (autograd pairing + torch.ops.mrdis.*), model.py (mirror of the
 reference's module interface), trainer.py (train step, flat-arena Adam, gradient
-all-reduce).  No CPU fallback exists for the hot path.
+all-reduce), train.py (the runnable main_missing.py-equivalent: epoch loop, scheduler, stat.csv, checkpoints).  No CPU fallback exists for the hot path.
 """
 from . import hip, ops, model, model3d, trainer               # noqa: F401
 from .hip import MrdisError, MrdisLibraryError, LIB_PATH      # noqa: F401
@@ -25,5 +25,6 @@ from .trainer import (TrainStep, EvalStep, ArenaAdam, GradAllReduce, DEFAULT_CON
 
 from .model3d import BasicBlock, VAEBranch, UNet3D, NVNet3D, HipConv3d, nvnet_loss   # noqa: F401
 from .data import VolumeStore, SliceDataset, BatchLoader, load_idx_list   # noqa: F401
+from . import train   # noqa: F401,E402
 
 __version__ = '0.1.0'

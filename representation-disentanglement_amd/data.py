@@ -148,9 +148,11 @@ class BatchLoader:
             metas = [ds.meta(i) for i in idxs]
             B = len(metas)
             host = torch.empty((B, M + 3), dtype=torch.int64).pin_memory() if dev.type == 'cuda' else torch.empty((B, M + 3), dtype=torch.int64)
+            mask_host = np.zeros((B, M), dtype=np.float32)                 # host twin of `mask`: the losses branch on it without a sync
             for r, (_, s, ptrs, drop, tptr) in enumerate(metas):
                 host[r, :M] = torch.tensor(ptrs, dtype=torch.int64)
                 host[r, M], host[r, M + 1], host[r, M + 2] = s, drop, tptr
+                mask_host[r] = [1.0 if (p and m != drop) else 0.0 for m, p in enumerate(ptrs)]
             d = host.to(dev, non_blocking=True)                       # one small H2D copy per batch
             vol_ptrs = d[:, :M].contiguous()
             slice_idx = d[:, M].to(torch.int32)
@@ -161,4 +163,4 @@ class BatchLoader:
             if ds.dataset_name == 'BraTS':
                 targets = torch.where(targets == 4, torch.full_like(targets, 3.0), targets)      # util.py:533
             yield {'inputs': inputs, 'targets': targets, 'subj_id': [m[0] for m in metas],
-                   'slice_idx': slice_idx.to(torch.int64), 'mask': mask, 'mask_img': mask_img}
+                   'slice_idx': slice_idx.to(torch.int64), 'mask': mask, 'mask_img': mask_img, 'mask_host': mask_host}

@@ -90,6 +90,11 @@ class CondConv2d(nn.Module):
         kh, kw = self.kernel_size
         B = inputs.shape[0]
         if B == 1 or inputs_type.stride(0) == 0:
+            if not ops.mix_cache_active():
+                # the seam as ONE dispatcher-visible op (mix + conv, torch.ops.mrdis.cond_conv2d): plain module use
+                return torch.ops.mrdis.cond_conv2d(inputs, inputs_type[:1], self.weight, self._routing_fn.fc.weight,
+                                                   self._routing_fn.fc.bias, self.bias, self.stride[0], self.padding[0], lrelu)
+            # inside a training step the mixed kernels of all modality labels are cached and shared by every call
             w_tck, w_tkc = self.mixed_uniform(inputs_type)
             return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
         outs = []                                    # per-sample path, model.py:2114-2117

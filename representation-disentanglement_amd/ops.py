@@ -155,33 +155,9 @@ def set_grad_sink(enabled):
 
 
 # --------------------------------------------------------------------------- convolution
-class _Conv2d(Function):
-    """F.conv2d (model.py:2104) with optional fused LeakyReLU(0.2) epilogue."""
-
-    @staticmethod
-    def forward(ctx, x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
-        y = hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu)
-        ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3], bias is not None)
-        ctx.bias_param = bias
-        ctx.save_for_backward(x, w_tkc, y if lrelu else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        kh, kw, stride, pad, lrelu, H, W, has_bias = ctx.geom
-        x, w_tkc, y = ctx.saved_tensors
-        if lrelu:
-            dy = hip.lrelu_bwd(dy, y, 0.2)
-        dx = hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
-            sink = _grad_sink(ctx.bias_param) if has_bias else None
-            dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=has_bias, bias_sink=sink)
-        return dx, dw, None, db, None, None, None, None, None
-
-
 def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
-    return _Conv2d.apply(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
+    """-> torch.ops.mrdis.conv2d (registered at the bottom of this file: CUDA kernel, fake kernel, autograd formula)."""
+    return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
 
 
 # --------------------------------------------------------------------------- norms
@@ -374,24 +350,173 @@ def cached_mix(key, make):
 
 
 # --------------------------------------------------------------------------- torch.ops.mrdis.*
-_LIB = None
+# Dispatcher-visible custom ops over the C ABI: schema, CUDA kernel (ctypes -> libmrdis_hip.so), fake
+# (meta) kernel and autograd formula for each, so `torch.ops.mrdis.*` composes with torch's tooling (opcheck,
+# FakeTensor shape propagation, AOT tracing).  The seam op is `mrdis::cond_conv2d` = CondConv2d.forward of the reference
+# (model.py:2108-2117) for a batch-constant type; `mrdis::conv2d` is the same convolution on an already mixed kernel
+# (what the model calls inside a training step, where one mix serves 8-16 calls).
+_lib = torch.library.Library('mrdis', 'DEF')
+_lib.define('conv2d(Tensor x, Tensor w_tck, Tensor w_tkc, Tensor? bias, int kh, int kw, int stride, int pad, bool lrelu) -> Tensor')
+_lib.define('conv2d_bwd_data(Tensor dy, Tensor w_tkc, int H, int W, int kh, int kw, int stride, int pad) -> Tensor')
+_lib.define('conv2d_bwd_weight(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, bool need_bias) -> (Tensor, Tensor)')
+_lib.define('conv2d_bwd_weight_sink(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, Tensor(a!) bias_grad) -> Tensor')
+_lib.define('lrelu_bwd(Tensor dy, Tensor y, float slope) -> Tensor')
+_lib.define('mix_experts_routed(Tensor W, Tensor fc_w, Tensor fc_b, Tensor type_row) -> (Tensor, Tensor, Tensor)')
+_lib.define('mix_experts_routed_bwd(Tensor dw_tck, Tensor W, Tensor r, Tensor type_row) -> (Tensor, Tensor, Tensor)')
+_lib.define('cond_conv2d(Tensor x, Tensor type_row, Tensor weight, Tensor fc_w, Tensor fc_b, Tensor? bias, int stride, int pad, bool lrelu) -> Tensor')
 
 
-def register_torch_ops():
-    """Expose the raw (non-autograd) entry points as `torch.ops.mrdis.*` custom ops."""
-    global _LIB
-    if _LIB is not None:
-        return
-    _LIB = torch.library.Library('mrdis', 'DEF')
-    _LIB.define('mix_experts(Tensor W, Tensor r) -> (Tensor, Tensor)')
-    _LIB.define('conv2d_fwd(Tensor x, Tensor w_tck, Tensor? bias, int kh, int kw, int stride, int pad, bool lrelu) -> Tensor')
-    _LIB.define('conv2d_bwd_data(Tensor dy, Tensor w_tkc, int H, int W, int kh, int kw, int stride, int pad) -> Tensor')
-    _LIB.define('conv2d_bwd_weight(Tensor x, Tensor dy, int kh, int kw, int stride, int pad) -> (Tensor, Tensor)')
-    _LIB.define('bilinear(Tensor x, int Ho, int Wo, bool align_corners) -> Tensor')
-    _LIB.define('softmax_mask_drop(Tensor s, Tensor? mask_img, float scale) -> Tensor')
-    _LIB.impl('mix_experts', lambda W, r: hip.mix_experts_fwd(W, r), 'CUDA')
-    _LIB.impl('conv2d_fwd', lambda x, w, b, kh, kw, s, p, l: hip.conv2d_fwd(x, w, b, kh, kw, s, p, l), 'CUDA')
-    _LIB.impl('conv2d_bwd_data', lambda dy, w, H, W, kh, kw, s, p: hip.conv2d_bwd_data(dy, w, (H, W), kh, kw, s, p), 'CUDA')
-    _LIB.impl('conv2d_bwd_weight', lambda x, dy, kh, kw, s, p: hip.conv2d_bwd_weight(x, dy, kh, kw, s, p, True), 'CUDA')
-    _LIB.impl('bilinear', lambda x, Ho, Wo, ac: hip.bilinear_fwd(x, (Ho, Wo), ac), 'CUDA')
-    _LIB.impl('softmax_mask_drop', lambda s, m, sc: hip.softmax_mask_drop_fwd(s, m, sc), 'CUDA')
+def _nhwc_like(x, N, C, H, W):
+    return torch.empty((N, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+
+
+def _out_hw(x, kh, kw, stride, pad):
+    return hip.conv_out_hw(x.shape[2], x.shape[3], kh, kw, stride, pad)
+
+
+# ---- kernels (CUDA = the HIP device under PyTorch-ROCm)
+def _k_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
+    return hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu)
+
+
+def _k_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad):
+    return hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad)
+
+
+def _k_bwd_weight(x, dy, kh, kw, stride, pad, need_bias):
+    dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=need_bias)
+    return dw, (db if db is not None else dw.new_zeros(dy.shape[1]))
+
+
+def _k_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad):
+    return hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=bias_grad)[0]
+
+
+def _k_mix(W, fc_w, fc_b, type_row):
+    return hip.mix_experts_routed_fwd(W, fc_w, fc_b, type_row)
+
+
+def _k_mix_bwd(dw_tck, W, r, type_row):
+    return hip.mix_experts_routed_bwd(dw_tck, W, r, type_row, type_row.shape[-1])
+
+
+def _k_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu):
+    w_tck, _, _ = hip.mix_experts_routed_fwd(weight, fc_w, fc_b, type_row)
+    return hip.conv2d_fwd(x, w_tck, bias, weight.shape[3], weight.shape[4], stride, pad, lrelu)
+
+
+for _name, _fn in (('conv2d', _k_conv2d), ('conv2d_bwd_data', _k_bwd_data), ('conv2d_bwd_weight', _k_bwd_weight),
+                   ('conv2d_bwd_weight_sink', _k_bwd_weight_sink), ('lrelu_bwd', lambda dy, y, slope: hip.lrelu_bwd(dy, y, slope)),
+                   ('mix_experts_routed', _k_mix), ('mix_experts_routed_bwd', _k_mix_bwd), ('cond_conv2d', _k_cond_conv2d)):
+    _lib.impl(_name, _fn, 'CUDA')
+
+
+# ---- fake kernels: shapes / strides only
+@torch.library.register_fake('mrdis::conv2d')
+def _f_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
+    Ho, Wo = _out_hw(x, kh, kw, stride, pad)
+    return _nhwc_like(x, x.shape[0], w_tck.shape[2], Ho, Wo)
+
+
+@torch.library.register_fake('mrdis::conv2d_bwd_data')
+def _f_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad):
+    return _nhwc_like(dy, dy.shape[0], w_tkc.shape[2], H, W)
+
+
+@torch.library.register_fake('mrdis::conv2d_bwd_weight')
+def _f_bwd_weight(x, dy, kh, kw, stride, pad, need_bias):
+    return x.new_empty((kh * kw, x.shape[1], dy.shape[1])), x.new_empty((dy.shape[1],))
+
+
+@torch.library.register_fake('mrdis::conv2d_bwd_weight_sink')
+def _f_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad):
+    return x.new_empty((kh * kw, x.shape[1], dy.shape[1]))
+
+
+@torch.library.register_fake('mrdis::lrelu_bwd')
+def _f_lrelu_bwd(dy, y, slope):
+    return _nhwc_like(y, *y.shape)
+
+
+@torch.library.register_fake('mrdis::mix_experts_routed')
+def _f_mix(W, fc_w, fc_b, type_row):
+    E, Co, Ci, kh, kw = W.shape
+    return W.new_empty((kh * kw, Ci, Co)), W.new_empty((kh * kw, Co, Ci)), W.new_empty((E,))
+
+
+@torch.library.register_fake('mrdis::mix_experts_routed_bwd')
+def _f_mix_bwd(dw_tck, W, r, type_row):
+    return torch.empty_like(W, memory_format=torch.contiguous_format), W.new_empty((W.shape[0], type_row.shape[-1])), W.new_empty((W.shape[0],))
+
+
+@torch.library.register_fake('mrdis::cond_conv2d')
+def _f_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu):
+    Ho, Wo = _out_hw(x, weight.shape[3], weight.shape[4], stride, pad)
+    return _nhwc_like(x, x.shape[0], weight.shape[1], Ho, Wo)
+
+
+# ---- autograd formulas (backward = other mrdis ops, so it traces too)
+def _conv2d_setup(ctx, inputs, output):
+    x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu = inputs
+    ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3])
+    ctx.bias_param = bias                         # the Parameter object: its .grad may be an in-kernel gradient sink
+    ctx.save_for_backward(x, w_tkc, output if lrelu else None)
+
+
+def _conv2d_backward(ctx, dy):
+    kh, kw, stride, pad, lrelu, H, W = ctx.geom
+    x, w_tkc, y = ctx.saved_tensors
+    if lrelu:
+        dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
+    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
+    dw = db = None
+    has_bias = ctx.bias_param is not None
+    if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
+        sink = _grad_sink(ctx.bias_param) if has_bias else None
+        if sink is not None:
+            dw = torch.ops.mrdis.conv2d_bwd_weight_sink(x, dy, kh, kw, stride, pad, sink)
+        else:
+            dw, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, has_bias)
+            if not has_bias:
+                db = None
+    return dx, dw, None, db, None, None, None, None, None
+
+
+torch.library.register_autograd('mrdis::conv2d', _conv2d_backward, setup_context=_conv2d_setup)
+
+
+def _mix_setup(ctx, inputs, output):
+    W, fc_w, fc_b, type_row = inputs
+    ctx.save_for_backward(W, output[2], type_row)
+
+
+def _mix_backward(ctx, g_tck, _g_tkc, _g_r):
+    W, r, type_row = ctx.saved_tensors
+    dW, dfcw, dfcb = torch.ops.mrdis.mix_experts_routed_bwd(g_tck.contiguous(), W, r, type_row)
+    return dW, dfcw, dfcb, None
+
+
+torch.library.register_autograd('mrdis::mix_experts_routed', _mix_backward, setup_context=_mix_setup)
+
+
+def _cond_setup(ctx, inputs, output):
+    x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu = inputs
+    ctx.geom = (stride, pad, lrelu)
+    ctx.has_bias = bias is not None
+    ctx.save_for_backward(x, type_row, weight, fc_w, fc_b, output if lrelu else None)
+
+
+def _cond_backward(ctx, dy):
+    stride, pad, lrelu = ctx.geom
+    x, type_row, weight, fc_w, fc_b, y = ctx.saved_tensors
+    kh, kw = weight.shape[3], weight.shape[4]
+    if lrelu:
+        dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
+    _, w_tkc, r = torch.ops.mrdis.mix_experts_routed(weight, fc_w, fc_b, type_row)          # re-mixed: nothing but x is kept alive
+    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, x.shape[2], x.shape[3], kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
+    dw_tck, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, ctx.has_bias)
+    dW, dfcw, dfcb = torch.ops.mrdis.mix_experts_routed_bwd(dw_tck, weight, r, type_row)
+    return dx, None, dW, dfcw, dfcb, (db if ctx.has_bias else None), None, None, None
+
+
+torch.library.register_autograd('mrdis::cond_conv2d', _cond_backward, setup_context=_cond_setup)

@@ -519,12 +519,14 @@ class TrainStep:
         self.iter = 0
         self.last_grad_norm_sq = None            # device [sum g^2, #non-finite] of the gradient the last clip saw
 
-    def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None):
+    def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None, it=None):
+        """`it`: the loader index of this batch inside its epoch -- the reference steps on (it + 1) % accum == 0 with `it`
+        restarting every epoch (:155, :282), a pending accumulation carries over; None = count iterations here."""
         cfg, model, opt = self.config, self.model, self.optimizer
         adv = cfg['lambda_adv_s'] > 0
         if mask_host is None:
             mask_host = mask.cpu()
-        self.iter += 1
+        self.iter = self.iter + 1 if it is None else it + 1
         do_step = (self.iter % self.accum) == 0                                                  # :282
         with ops.mix_cache():
             loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, targets=targets)

@@ -62,6 +62,95 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_two_optimizers(rank, world, port, q):
+    """The data-parallel plumbing of TrainStep with the adversarial second backward and accum == 2, on a CPU model:
+    static arena (built before the first backward, identical on every rank even when a rank's batch leaves a parameter
+    without gradient), a second optimizer sharing the weights with its own gradient buffer (p.grad re-pointed, no clones),
+    both reduced through the same bucketed reducer, gate flags OR-ed across ranks by the same sum all-reduce, and the
+    accumulation rule (each micro-batch gradient reduced exactly once, then added to the accumulator)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mrdis
+        torch.manual_seed(0)
+        model = Tiny()
+        used = [p for n, p in model.named_parameters() if 'unused' not in n]
+        opt = mrdis.ArenaAdam(model.parameters(), lr=1e-3, used=used)
+        opt.set_gates([[model.c.weight, model.c.bias], [model.a.weight]])
+        od = mrdis.ArenaAdam(model.parameters(), lr=1e-3, weight_decay=0.0, share_weights_of=opt)
+        red = mrdis.GradAllReduce(opt, buckets=3)
+        assert od.flat_p.data_ptr() == opt.flat_p.data_ptr() and od.flat_g.data_ptr() != opt.flat_g.data_ptr()
+        errs = []
+        pos = {id(p): k for k, p in enumerate(opt.used)}
+        acc = torch.zeros_like(opt._g_full)
+        acc_ref = [torch.zeros_like(p) for p in used]
+        for it in range(4):
+            g = torch.Generator().manual_seed(100 * it + rank)
+            x = torch.randn(4, 7, generator=g)
+
+            def losses():
+                y = model(x)
+                return y.pow(2).sum(), (y[:, :1] - 1).abs().sum()      # "generator" loss, "discriminator" loss (reaches a, b, c too)
+            # expected: mean over ranks of the local gradients of both losses
+            lg, ld = losses()
+            eg = list(torch.autograd.grad(lg, used, retain_graph=True)); ed = list(torch.autograd.grad(ld, used))
+            for t in eg + ed:
+                dist.all_reduce(t); t /= world
+            # --- the TrainStep sequence
+            lg, ld = losses()
+            flags = torch.tensor([1.0 if rank == it % 2 else 0.0, 0.0])           # group 0 active on one rank only, group 1 on none
+            opt.mark_active(flags)
+            red.begin(opt); lg.backward(retain_graph=True); scale = red.finish()
+            od.attach_grads()
+            red.begin(od); ld.backward(); red.finish()
+            opt.attach_grads()
+            for p, a, b in zip(used, eg, ed):
+                k = pos[id(p)]
+                errs.append(float((opt.grad_views[k] * scale - a).abs().max()))
+                errs.append(float((od.grad_views[k] * scale - b).abs().max()))
+            assert list(opt.gate_flags) == [1.0, 0.0]                          # OR over the ranks, by the same all-reduce
+            assert model.unused.weight.grad is None
+            # accumulation (accum == 2): reduced micro-batch gradient joins the accumulator once; clip acts on the accumulator
+            acc.add_(opt._g_full, alpha=scale); opt.zero_grad(); od.zero_grad()
+            n = opt.numel
+            coef = torch.clamp(1.0 / (acc[:n].norm() + 1e-6), max=1.0); acc[:n].mul_(coef)
+            for r, a in zip(acc_ref, eg):
+                r.add_(a)
+            tn = torch.sqrt(sum((r ** 2).sum() for r in acc_ref)); c = torch.clamp(1.0 / (tn + 1e-6), max=1.0)
+            for r in acc_ref:
+                r.mul_(c)
+            for p, r in zip(used, acc_ref):
+                o = opt.offsets[pos[id(p)]]
+                errs.append(float((acc[o:o + p.numel()].view(p.shape) - r).abs().max()))
+            if it % 2 == 1:
+                acc.zero_()
+                for r in acc_ref:
+                    r.zero_()
+        q.put((rank, max(errs), opt.numel, len(opt.used)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0
+    return sorted(q.get(timeout=5) for _ in range(2))
+
+
+@pytest.mark.timeout(180)
+def test_two_optimizers_accumulation_world2():
+    for rank, err, numel, nused in _run(_worker_two_optimizers):
+        assert err < 1e-6, (rank, err)
+        assert nused == 6
+
+
 @pytest.mark.timeout(180)
 def test_bucketed_allreduce_world2():
     ctx = mp.get_context('spawn')
