@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--no-adv', action='store_true', help='lambda_adv_s = 0 (the shipped config.yaml)')
     ap.add_argument('--drop', action='store_true', help='missing-modality batches (BASELINE configs[3])')
     ap.add_argument('--recon-y', action='store_true', help="lambda_recon_y = 1: adds the 'U+SA' output decoder + segmentation loss (not the headline config)")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="compute dtype of the convolutions: f32 (headline, exact fp32 MFMA) or bf16 (BASELINE configs[2], stage 1: bf16 MFMA operands, "
+                         "fp32 accumulate, fp32 activations in HBM)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
@@ -189,7 +192,7 @@ def main():
     adv = not a.no_adv
     cfg = dict(mrdis.DEFAULT_CONFIG)
     cfg.update(contrast_list=['T1', 'T1c', 'T2', 'T2_FLAIR'][:M] if M <= 4 else [f'm{i}' for i in range(M)],
-               input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0 if adv else 0.0)
+               input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0 if adv else 0.0, compute_dtype=a.dtype)
     if a.recon_y:
         cfg.update(lambda_recon_y=1.0, out_num_ch=4)
     cfg = mrdis.derive_config(cfg, dev)
@@ -239,7 +242,7 @@ def main():
     # the same step on the direct-convolution kernels only (north_star describes a direct conv; the default policy runs
     # fused Winograd on the big 3x3 layers): reported beside the headline, never as `value`
     ms_direct = None
-    if not a.no_direct and mrdis.hip.get_option('wino') != 0:
+    if not a.no_direct and a.dtype == 'f32' and mrdis.hip.get_option('wino') != 0:
         prev = mrdis.hip.get_option('wino')
         mrdis.hip.set_option('wino', 0)
         nd = max(2, min(a.steps, 5))
@@ -261,7 +264,7 @@ def main():
             'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
             'value': round(value, 3), 'unit': 'slices/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if a.dtype == 'f32' else 'bf16 MFMA operands / f32 accumulate / f32 storage', 'data': 'synthetic',
             'config': {'workload': f'BraTS-shaped {M}-modality {a.slice}x{a.slice} fp32 slices '
                                    f'({"zero-padded with background to" if a.fit == "pad" else "centre-cropped to"} {H}x{W}), '
                                    f'batch {B}/GPU, full train step (fwd, recon_x+recon_x_mix+latent_z+sim_s+sim_z'

@@ -98,27 +98,45 @@ int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* 
  * nn.Conv2d of the discriminator model.py:2773-2789 ---------------------------
  * x : NHWC view (N,H,W,Ci) ld=ldx ; y : NHWC view (N,Ho,Wo,Co) ld=ldy
  * w_tck from mrdis_mix_experts_fwd ; bias (Co) or NULL.
- * kernel (kh,kw) in {1x1,3x3,4x4}; stride in {1,2}; zero padding `pad`.      */
-int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
+ * kernel (kh,kw) in {1x1,3x3,4x4}; stride in {1,2}; zero padding `pad`.
+ *
+ * dtype (BASELINE.json configs[2], SURVEY.md 8b "dtype"):
+ *   MRDIS_DT_F32       fp32 activations, fp32 MFMA (v_mfma_f32_32x32x2_f32 / Winograd) -- the parity path;
+ *   MRDIS_DT_F32_BF16M fp32 activations in HBM, bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, inputs rounded RNE on the
+ *                      way into LDS), fp32 accumulate / bias / epilogue.  Needs the bf16 copy of the filter with the
+ *                      REDUCTION axis contiguous (mrdis_cast_bf16 of the other layout): forward w_bf16_tkc = bf16
+ *                      [T][Co][Ci], data gradient w_bf16_tck = bf16 [T][Ci][Co].  Geometries the bf16 kernel does not
+ *                      cover (reduction axis not a multiple of 16, fewer than 16 output channels) and a NULL bf16 filter
+ *                      run the fp32 kernels: the result is then exact fp32;
+ *   MRDIS_DT_BF16      bf16 activations in HBM: not built, MRDIS_EUNSUPPORTED.                                       */
+#define MRDIS_DT_F32        0
+#define MRDIS_DT_F32_BF16M  1
+#define MRDIS_DT_BF16       2
+int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                      float* y, int ldy, int N, int H, int W, int Ci, int Co,
-                     int kh, int kw, int stride, int pad, int epilogue, void* stream);
+                     int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream);
 
 /* data gradient (autograd convolution_backward, input part).
  * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
-int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc,
+int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
                           float* dx, int lddx, int N, int H, int W, int Ci, int Co,
-                          int kh, int kw, int stride, int pad, void* stream);
+                          int kh, int kw, int stride, int pad, int dtype, void* stream);
+
+/* fp32 -> bf16, round to nearest even (the bf16 filter copies above); src 16-byte, dst 8-byte aligned. */
+int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.
  * dw_tck: [T][Ci][Co] ; dbias (Co) or NULL.                                   */
 size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
                                          int kh, int kw, int stride, int pad);
-/* accumulate_bias != 0: dbias += column sums of dy (instead of =), e.g. straight into the parameter's gradient */
+/* accumulate_bias != 0: dbias += column sums of dy (instead of =), e.g. straight into the parameter's gradient.
+ * dtype MRDIS_DT_F32_BF16M: x and dy are rounded to bf16 on their way into LDS and multiplied on bf16 MFMA with fp32
+ * accumulation (stride-1 "same" layers with Ci % 32 == 0; others run the fp32 kernels); dbias stays an fp32 sum.       */
 int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
                             float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                             int N, int H, int W, int Ci, int Co,
-                            int kh, int kw, int stride, int pad, int accumulate_bias, void* stream);
+                            int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream);
 
 /* ---- LeakyReLU backward (model.py:2227/2240, 2375-2394): dx = dy * (y>0 ? 1 : slope),
  * y being the activation OUTPUT (sign-preserving for slope > 0).              */

@@ -1,0 +1,573 @@
+// mrdis_bf16.hip -- the tap-table convolution (mrdis_conv.hip) on v_mfma_f32_32x32x16_bf16: bf16 MFMA operands, fp32
+// accumulation, fp32 bias / epilogue.  BASELINE.json configs[2] ("bf16"), stage 1: activations stay fp32 in HBM
+// (MRDIS_DT_F32_BF16M) and are rounded to bf16 (RNE) on their way into LDS; the filter arrives as a bf16 copy of the mixed
+// kernel with the reduction axis contiguous.  At 16x the fp32 MFMA rate the big layers become HBM-bound, so the kernel is
+// built around keeping loads in flight:
+//
+//   * PERSISTENT workgroups walk (position tile, channel chunk) items; the global loads of item i+1 (input tile chunk and
+//     filter chunk, register-staged) are issued before the MFMAs of item i start, and a filter that fits one chunk
+//     (Cin <= KC) is staged once per workgroup instead of once per tile;
+//   * LDS images: xs[pixel][KC + 8] and ws[tap][cout][KC + 8] bf16 -- a 16-byte ds_read_b128 per lane is one MFMA operand
+//     (8 consecutive reduction indices); the 16-byte row pad makes the 16 lanes of a read group land on distinct banks;
+//   * operands swapped as in the fp32 kernels (A = filter, B = pixels): D[cout][position], a lane owns one position and
+//     4-cout groups, i.e. 16-byte stores.
+//
+// Reference op: F.conv2d at src/model.py:2104 and its autograd data gradient.
+#include "mrdis_tapconv.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct BConvGeom {
+    int tiles;            // position tiles (tilesA * tilesB * tilesN)
+    int nchunks;          // Cin / KC
+    int tile_stride;      // workgroups walking one cout tile (gridDim.x / coTiles)
+};
+
+__device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
+    bf16x8 r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+}
+
+// KC channels per chunk; 4 waves as WAVES_C (cout) x 4/WAVES_C (positions); a wave owns WP x WC blocks of 32 positions x 32 couts
+template <int KC, int WAVES_C, int WP, int WC>
+__global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
+    constexpr int WAVES_P = 4 / WAVES_C;
+    constexpr int BM = 32 * WP * WAVES_P, BN = 32 * WC * WAVES_C;
+    constexpr int PITCH = KC + 8;                 // bf16 elements per LDS row
+    constexpr int QX = KC / 8;                    // 16-byte pieces per pixel row
+    constexpr int XR = 6, WR = 9;                 // register-staged pieces per thread (input, filter)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* ws = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* xs = ws + p.ntaps * BN * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
+    const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;
+    const int cot = blockIdx.x % p.coTiles, wg = blockIdx.x / p.coTiles;
+    const int co0 = cot * BN;
+    const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
+
+    // ---- per-lane constants: the pixel slot and (nb, ty, tx) of each of the lane's WP positions
+    int abase[WP], pos_nb[WP], pos_ty[WP], pos_tx[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int m = 32 * (wave_p * WP + i) + e;
+        int nb = 0, ty = 0, tx = 0;
+        if (m < npos) { nb = m / (p.TH * p.TW); const int rem = m - nb * p.TH * p.TW; ty = rem / p.TW; tx = rem - ty * p.TW; }
+        else nb = -1;
+        pos_nb[i] = nb; pos_ty[i] = ty; pos_tx[i] = tx;
+        abase[i] = (nb < 0) ? 0 : ((nb * p.TinH + ty * p.is) * p.TinW + tx * p.is) * PITCH + 8 * half;
+    }
+    // ---- staging descriptors (tile-invariant part): input pieces and filter pieces of this thread
+    int x_desc[XR];                                // (nb << 16) | (iy << 8) | ix of the piece's pixel, or -1
+    const int nx = npix_in * QX;
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 256;
+        x_desc[it] = -1;
+        if (idx < nx) {
+            const int pi = idx / QX;
+            const int nb = pi / tinHW; const int rem = pi - nb * tinHW;
+            const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            x_desc[it] = (nb << 16) | (iy << 8) | ix;
+        }
+    }
+    const int nw = p.ntaps * BN * QX;
+    int w_off[WR];                                 // element offset of the piece in the bf16 filter at chunk 0, or -1 (host: < 2^31)
+#pragma unroll
+    for (int it = 0; it < WR; ++it) {
+        const int idx = tid + it * 256;
+        w_off[it] = -1;
+        if (idx < nw) {
+            const int row = idx / QX, q = idx - row * QX;
+            const int t = row / BN, co = co0 + (row - t * BN);
+            if (co < p.Cout) w_off[it] = (p.widx[t] * p.Cout + co) * p.Cin + 8 * q;
+        }
+    }
+    const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.w_bf16);
+
+    float4 xr[XR][2];
+    bf16x8 wr[WR];
+    auto tile_origin = [&](int tile, int& n0, int& a0, int& b0) {
+        const int tb = tile % p.tilesB; tile /= p.tilesB;
+        const int ta = tile % p.tilesA;
+        n0 = (tile / p.tilesA) * p.NB; a0 = ta * p.TH; b0 = tb * p.TW;
+    };
+    auto load_item = [&](int tile, int chunk, bool want_w) {
+        int n0, a0, b0; tile_origin(tile, n0, a0, b0);
+        const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min, c0 = chunk * KC;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
+            if (x_desc[it] >= 0) {
+                const int n = n0 + (x_desc[it] >> 16), h = h_org + ((x_desc[it] >> 8) & 255), w_ = w_org + (x_desc[it] & 255);
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win) {
+                    const float* src = p.in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c0 + 8 * ((tid + it * 256) % QX);
+                    xr[it][0] = *reinterpret_cast<const float4*>(src);
+                    xr[it][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+        }
+        if (want_w) {
+#pragma unroll
+            for (int it = 0; it < WR; ++it) {
+                bf16x8 z; for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+                wr[it] = z;
+                if (w_off[it] >= 0) wr[it] = *reinterpret_cast<const bf16x8*>(wsrc + w_off[it] + c0);
+            }
+        }
+    };
+    auto store_item = [&](bool have_w) {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < nx) *reinterpret_cast<bf16x8*>(xs + (idx / QX) * PITCH + 8 * (idx % QX)) = cvt8(xr[it][0], xr[it][1]);
+        }
+        if (have_w) {
+#pragma unroll
+            for (int it = 0; it < WR; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < nw) *reinterpret_cast<bf16x8*>(ws + (idx / QX) * PITCH + 8 * (idx % QX)) = wr[it];
+            }
+        }
+    };
+
+    f32x16 acc[WC][WP];
+    const bool w_resident = g.nchunks == 1;       // the whole reduction fits one chunk: the filter is staged once
+    int tile = wg, chunk = 0;
+    if (tile >= g.tiles) return;
+    load_item(tile, 0, true);
+    bool first = true;
+    const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+    while (tile < g.tiles) {
+        __syncthreads();                           // everyone is done reading the previous item's LDS images
+        store_item(first || !w_resident);
+        __syncthreads();
+        // next item: its loads fly while this one is multiplied
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == g.nchunks) { nchunk = 0; ntile = tile + g.tile_stride; }
+        if (ntile < g.tiles) load_item(ntile, nchunk, !w_resident);
+        first = false;
+        if (chunk == 0) {
+#pragma unroll
+            for (int j = 0; j < WC; ++j)
+#pragma unroll
+                for (int i = 0; i < WP; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+        }
+        const __bf16* wbase = ws + (32 * (wave_c * WC) + e) * PITCH + 8 * half;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * PITCH;
+            const __bf16* wt = wbase + t * BN * PITCH;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                bf16x8 bf[WP], af[WC];
+#pragma unroll
+                for (int i = 0; i < WP; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(xs + abase[i] + toff + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < WC; ++j) af[j] = *reinterpret_cast<const bf16x8*>(wt + 32 * j * PITCH + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < WC; ++j)
+#pragma unroll
+                    for (int i = 0; i < WP; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[i], acc[j][i], 0, 0, 0);
+            }
+        }
+        if (chunk == g.nchunks - 1) {
+            // ---- epilogue: D[cout][position]; a lane owns one position per block and the couts 8g + 4*half .. +3 (g = 0..3)
+            int n0, a0, b0; tile_origin(tile, n0, a0, b0);
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                if (pos_nb[i] < 0) continue;
+                const int n = n0 + pos_nb[i], a = a0 + pos_ty[i], b = b0 + pos_tx[i];
+                if (n >= p.N || a >= p.A || b >= p.B) continue;
+                float* dst = p.out + ((long long)(n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0) * p.ldout;
+#pragma unroll
+                for (int j = 0; j < WC; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = co0 + 32 * (wave_c * WC + j) + 8 * q + 4 * half;
+                        if (co >= p.Cout) continue;
+                        float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+                        if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + co); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                        if (lrelu) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
+                        *reinterpret_cast<float4*>(dst + co) = v;
+                    }
+            }
+        }
+        tile = ntile; chunk = nchunk;
+    }
+}
+
+template <int KC, int WAVES_C, int WP, int WC>
+static int launch_bconv(const TapConvParams& p, const BConvGeom& g, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)bconv_kernel<KC, WAVES_C, WP, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC>), dim3(grid), dim3(256), lds, s, p, g);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+static int bconv_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
+        ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
+}
+
+// Eligibility: reduction axis a multiple of 16, 16-byte aligned views, cout a multiple of 4 (16-byte stores).
+int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
+    if (!p.w_bf16 || p.dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
+    if (p.Cin % 16 != 0 || p.Cout % 4 != 0 || p.Cout < 16 || (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (p.ldin % 4 != 0 || p.ldout % 4 != 0 || (((uintptr_t)p.in | (uintptr_t)p.out | (uintptr_t)p.w_bf16) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    // tile shape by cout width: (WAVES_C, WP, WC) -> BM x BN
+    struct Cfg { int waves_c, wp, wc; };
+    Cfg c;
+    if (p.Cout > 64) c = {2, 2, 2};               // 128 positions x 128 couts
+    else if (p.Cout > 32) c = {1, 2, 2};          // 256 positions x 64 couts
+    else c = {1, 2, 1};                           // 256 positions x 32 couts
+    int BM = 32 * c.wp * (4 / c.waves_c);
+    const int BN = 32 * c.wc * c.waves_c;
+    auto geom = [&](int bm) {
+        const TileChoice tc = choose_tile(p.N, p.A, p.B, bm);
+        p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
+        p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
+        p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
+        p.tilesA = mrdis_cdiv(p.A, p.TH); p.tilesB = mrdis_cdiv(p.B, p.TW); p.tilesN = mrdis_cdiv(p.N, p.NB);
+    };
+    geom(BM);
+    int KC = (p.Cin % 32 == 0) ? 32 : 16;
+    auto npix = [&]() { return (long long)p.NB * p.TinH * p.TinW; };
+    auto lds_bytes = [&](int kc) { return 2 * (size_t)(kc + 8) * ((size_t)p.ntaps * BN + (size_t)npix()); };
+    auto fits = [&](int kc) { return p.TinH < 256 && p.TinW < 256 && npix() * (kc / 8) <= 6 * 256 && (long long)p.ntaps * BN * (kc / 8) <= 9 * 256 && lds_bytes(kc) <= 80 * 1024; };
+    if (!fits(KC) && KC == 32) KC = 16;
+    if (!fits(KC) && c.wp == 2 && c.waves_c == 1) {        // stride-2 halos: fall back to 128-position tiles
+        c.wp = 1; BM = 128; geom(BM);
+        KC = (p.Cin % 32 == 0) ? 32 : 16;
+        if (!fits(KC) && KC == 32) KC = 16;
+    }
+    if (!fits(KC)) return MRDIS_EUNSUPPORTED;
+    if ((long long)p.N * p.Hin * p.Win * p.ldin >= 0x7fffffffLL * 2LL) return MRDIS_EUNSUPPORTED;
+    p.coTiles = mrdis_cdiv(p.Cout, BN);
+    BConvGeom g;
+    const long long tiles = (long long)p.tilesA * p.tilesB * p.tilesN;
+    if (tiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    g.tiles = (int)tiles; g.nchunks = p.Cin / KC;
+    const size_t lds = lds_bytes(KC);
+    int per_cu = (int)((150 * 1024) / (lds + 1024)); if (per_cu > 2) per_cu = 2; if (per_cu < 1) per_cu = 1;
+    long long per_cot = (long long)bconv_ncu() * per_cu / p.coTiles; if (per_cot < 1) per_cot = 1;
+    if (per_cot > tiles) per_cot = tiles;
+    g.tile_stride = (int)per_cot;
+    const int grid = (int)per_cot * p.coTiles;
+#define BC_CASE(kc, a, b_, d) if (KC == kc && c.waves_c == a && c.wp == b_ && c.wc == d) return launch_bconv<kc, a, b_, d>(p, g, grid, lds, s)
+    BC_CASE(32, 2, 2, 2); BC_CASE(16, 2, 2, 2);
+    BC_CASE(32, 1, 2, 2); BC_CASE(16, 1, 2, 2); BC_CASE(32, 1, 1, 2); BC_CASE(16, 1, 1, 2);
+    BC_CASE(32, 1, 2, 1); BC_CASE(16, 1, 2, 1); BC_CASE(32, 1, 1, 1); BC_CASE(16, 1, 1, 1);
+#undef BC_CASE
+    return MRDIS_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------ fp32 -> bf16 (round to nearest even), e.g. the mixed filters
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        bf16x4 r; r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(dst + i) = r;
+    } else {
+        for (long long k = i; k < n; ++k) dst[k] = (__bf16)src[k];
+    }
+}
+extern "C" int mrdis_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+    if (!src || !dst || n < 1 || (((uintptr_t)src & 15) != 0) || (((uintptr_t)dst & 7) != 0)) return MRDIS_EINVAL;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(dst), n);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// =====================================================================================================================
+// Weight gradient on bf16 MFMA: dw[t][ci][co] = sum over (n, a, b) of x[n, a + dh_t, b + dw_t, ci] * dy[n, a, b, co]
+// (stride 1; autograd convolution_backward, weight part, of F.conv2d at src/model.py:2104).
+//
+// The reduction axis is the POSITION, and both operands are stored channel-contiguous (NHWC), so the MFMA operands are
+// gathered with gfx950's transposing LDS read: the tiles sit in LDS as [pixel][32 channels] bf16 images (64-byte rows: the
+// four rows of one ds_read_b64_tr_b16 block cover all 64 banks once) and a lane receives 4 consecutive positions of one
+// channel per read -- two reads per 32x32x16 operand.  A workgroup (512 threads, 8 waves) owns CIW x COW channels and a
+// grid-stride share of the 128-position tiles; a wave keeps the 32 x 32 block of ALL taps (9 x 16 accumulators), so one dy
+// operand feeds 9 MFMAs.  Waves that share a channel block split the 8 position steps of a tile among themselves.
+// Global loads of the next tile (register-staged, fp32 -> bf16 on the way into LDS) fly while the current one is
+// multiplied; the bias gradient (column sums of dy) is accumulated in fp32 from the staging registers.  Every wave writes
+// its partial to its own slab [S][T][Ci][Co]; a fixed-order reduction kernel sums the slabs (bit-reproducible).
+struct BWgradParams {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, Ci, Co, ldx, lddy;
+    int ntaps, dh[9], dw[9];
+    int NB, TH, TW, lgTH, lgTW, TinH, TinW;         // TH, TW powers of two, NB * TH * TW = 128
+    int tilesA, tilesB, tilesN, tiles;
+    int nCiB, nCoB, splits;
+    int dh_min, dw_min;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int WCI, int WCO>
+__global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
+    constexpr int KS = 8 / (WCI * WCO);            // waves sharing a channel block split the position steps
+    constexpr int CIW = 32 * WCI, COW = 32 * WCO;
+    constexpr int XQ = CIW / 8, YQ = COW / 8;       // 16-byte pieces per pixel
+    constexpr int XR = (WCI == 2) ? 4 : 2, YR = (WCO == 2) ? 2 : 1;
+    constexpr int TP = 128;                         // positions per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* dys = reinterpret_cast<__bf16*>(smem_raw);                  // [WCO][128][32]
+    __bf16* xs = dys + WCO * TP * 32;                                    // [WCI][npix][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave % WCI, wco = (wave / WCI) % WCO, ks = wave / (WCI * WCO);
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int cob = bid % p.nCoB, cib = bid / p.nCoB;
+    const int ci0 = cib * CIW, co0 = cob * COW;
+    const int tinHW = p.TinH * p.TinW, npix = p.NB * tinHW;
+
+    // lane constants of the transposing reads: 16-lane group g, row q, 4-column piece pc
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int chan = 16 * (g & 1) + 4 * pc, kbase = 8 * (g >> 1) + q;
+
+    int x_desc[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 512;
+        x_desc[it] = -1;
+        if (idx < npix * XQ) {
+            const int pi = idx / XQ;
+            const int nb = pi / tinHW; const int rem = pi - nb * tinHW;
+            const int iy = rem / p.TinW, ix = rem - iy * p.TinW;
+            x_desc[it] = (nb << 16) | (iy << 8) | ix;
+        }
+    }
+    float4 xr[XR][2], yr[YR][2];
+    float bsum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
+    auto tile_origin = [&](int tile, int& n0, int& a0, int& b0) {
+        const int tb = tile % p.tilesB; tile /= p.tilesB;
+        const int ta = tile % p.tilesA;
+        n0 = (tile / p.tilesA) * p.NB; a0 = ta * p.TH; b0 = tb * p.TW;
+    };
+    auto load_tile = [&](int tile) {
+        int n0, a0, b0; tile_origin(tile, n0, a0, b0);
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
+            if (x_desc[it] >= 0) {
+                const int n = n0 + (x_desc[it] >> 16), h = a0 + p.dh_min + ((x_desc[it] >> 8) & 255), w_ = b0 + p.dw_min + (x_desc[it] & 255);
+                if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W) {
+                    const float* src = p.x + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + ci0 + 8 * ((tid + it * 512) % XQ);
+                    xr[it][0] = *reinterpret_cast<const float4*>(src);
+                    xr[it][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + it * 512;                 // < 128 * YQ by construction
+            const int m = idx / YQ, c = co0 + 8 * (idx % YQ);
+            const int tx = m & (p.TW - 1), ty = (m >> p.lgTW) & (p.TH - 1), nb = m >> (p.lgTW + p.lgTH);
+            const int n = n0 + nb, a = a0 + ty, b = b0 + tx;
+            yr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); yr[it][1] = yr[it][0];
+            if (n < p.N && a < p.H && b < p.W && c < p.Co) {
+                const float* src = p.dy + ((long long)(n * p.H + a) * p.W + b) * p.lddy + c;
+                yr[it][0] = *reinterpret_cast<const float4*>(src);
+                yr[it][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + it * 512;
+            if (idx < npix * XQ) {
+                const int pi = idx / XQ, qq = idx % XQ;
+                *reinterpret_cast<bf16x8*>(xs + ((qq >> 2) * npix + pi) * 32 + 8 * (qq & 3)) = cvt8(xr[it][0], xr[it][1]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + it * 512;
+            const int m = idx / YQ, qq = idx % YQ;
+            *reinterpret_cast<bf16x8*>(dys + ((qq >> 2) * TP + m) * 32 + 8 * (qq & 3)) = cvt8(yr[it][0], yr[it][1]);
+            bsum[0] += yr[it][0].x; bsum[1] += yr[it][0].y; bsum[2] += yr[it][0].z; bsum[3] += yr[it][0].w;
+            bsum[4] += yr[it][1].x; bsum[5] += yr[it][1].y; bsum[6] += yr[it][1].z; bsum[7] += yr[it][1].w;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const __bf16* xw = xs + wci * npix * 32 + chan;
+    const __bf16* yw = dys + wco * TP * 32 + chan;
+    int tile = split;
+    if (tile < p.tiles) load_tile(tile);
+    while (tile < p.tiles) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        const int ntile = tile + p.splits;
+        if (ntile < p.tiles) load_tile(ntile);
+        for (int kk = ks; kk < TP / 16; kk += KS) {
+            // the lane's two rows (positions) of this step: m0 = 16 kk + kbase and m0 + 4
+            const int m0 = 16 * kk + kbase, m1 = m0 + 4;
+            const int tx0 = m0 & (p.TW - 1), ty0 = (m0 >> p.lgTW) & (p.TH - 1), nb0 = m0 >> (p.lgTW + p.lgTH);
+            const int tx1 = m1 & (p.TW - 1), ty1 = (m1 >> p.lgTW) & (p.TH - 1), nb1 = m1 >> (p.lgTW + p.lgTH);
+            const int px0 = (nb0 * p.TinH + ty0) * p.TinW + tx0, px1 = (nb1 * p.TinH + ty1) * p.TinW + tx1;
+            union { bf16x8 v; s16x4 h[2]; } bq;
+            bq.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yw + m0 * 32));
+            bq.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yw + m1 * 32));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < p.ntaps) {
+                    const int off = (p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min);
+                    union { bf16x8 v; s16x4 h[2]; } aq;
+                    aq.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xw + (px0 + off) * 32));
+                    aq.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xw + (px1 + off) * 32));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq.v, bq.v, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        tile = ntile;
+    }
+    // ---- partial slabs: D[ci row][co col]; slab s = split * KS + ks, layout [S][T][Ci][Co]
+    const int half = lane >> 5, e = lane & 31;
+    const int s_idx = split * KS + ks;
+    const int co = co0 + 32 * wco + e;
+    if (co < p.Co) {
+        for (int t = 0; t < p.ntaps; ++t) {
+            float* dst = p.slab + (((long long)s_idx * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = 0.f;
+                switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
+                             case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
+                dst[(long long)row * p.Co] = v;
+            }
+        }
+    }
+    // ---- bias gradient: column sums of dy from the staging registers (fp32), workgroups of the first ci block only
+    if (p.bias_slab && cib == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);            // [512][8]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bsum[k];
+        __syncthreads();
+        if (tid < COW) {
+            const int qq = tid / 8, k = tid % 8;                    // channel tid = 8 qq + k; threads with tid % YQ == qq hold it
+            float sum = 0.f;
+            for (int th = qq; th < 512; th += YQ) sum += red[th * 8 + k];
+            if (co0 + tid < p.Co) p.bias_slab[(long long)split * p.Co + co0 + tid] = sum;
+        }
+    }
+}
+
+// out[i] = sum over s of slab[s][i] (fixed order); the bias row likewise
+__global__ void bwgrad_reduce_kernel(const float* __restrict__ slab, int S, long long n, float* __restrict__ out,
+                                     const float* __restrict__ bias_slab, int SB, int Co, float* __restrict__ dbias, int accumulate_bias) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slab[(long long)k * n + i];
+        out[i] = s;
+    } else if (bias_slab && i - n < Co) {
+        const int c = (int)(i - n);
+        float s = 0.f;
+        for (int k = 0; k < SB; ++k) s += bias_slab[(long long)k * Co + c];
+        dbias[c] = accumulate_bias ? dbias[c] + s : s;
+    }
+}
+
+struct BWgradPlan { BWgradParams p; int wci, wco, KS; size_t lds; long long slab_floats, bias_floats; };
+
+static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    if (stride != 1 || kh * kw > 9 || kh != kw || 2 * pad != kh - 1) return MRDIS_EUNSUPPORTED;    // "same" convolutions only (Ho = H)
+    if (Ci % 32 != 0 || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W < 4096) return MRDIS_EUNSUPPORTED;                                    // tiny maps: the fp32 kernels' slabs are cheaper
+    BWgradParams& p = pl.p;
+    p = BWgradParams{};
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
+    p.ntaps = kh * kw;
+    for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) { p.dh[r * kw + s_] = r - pad; p.dw[r * kw + s_] = s_ - pad; }
+    p.dh_min = -pad; p.dw_min = -pad;
+    // 128-position tile with power-of-two sides
+    int tw = 32; while (tw > 1 && tw / 2 >= W) tw >>= 1;
+    int th = 128 / tw; while (th > 1 && th / 2 >= H) th >>= 1;
+    int nb = 128 / (tw * th);
+    p.TW = tw; p.TH = th; p.NB = nb;
+    p.lgTW = 0; while ((1 << p.lgTW) < tw) ++p.lgTW;
+    p.lgTH = 0; while ((1 << p.lgTH) < th) ++p.lgTH;
+    p.TinH = th + kh - 1; p.TinW = tw + kw - 1;
+    if (p.TinH > 255 || p.TinW > 255 || nb > 255) return MRDIS_EUNSUPPORTED;
+    p.tilesA = mrdis_cdiv(H, th); p.tilesB = mrdis_cdiv(W, tw); p.tilesN = mrdis_cdiv(N, nb);
+    const long long tiles = (long long)p.tilesA * p.tilesB * p.tilesN;
+    if (tiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.tiles = (int)tiles;
+    pl.wci = (Ci % 64 == 0) ? 2 : 1;
+    pl.wco = (Co > 32) ? 2 : 1;
+    pl.KS = 8 / (pl.wci * pl.wco);
+    p.nCiB = Ci / (32 * pl.wci); p.nCoB = mrdis_cdiv(Co, 32 * pl.wco);
+    const long long npix = (long long)nb * p.TinH * p.TinW;
+    if (npix * (4 * pl.wci) > (long long)(pl.wci == 2 ? 4 : 2) * 512) return MRDIS_EUNSUPPORTED;
+    pl.lds = 2 * 32 * ((size_t)pl.wco * 128 + (size_t)pl.wci * npix);
+    if (pl.lds < 512 * 8 * 4) pl.lds = 512 * 8 * 4;
+    long long splits = mrdis_cdiv(bconv_ncu(), (long long)p.nCiB * p.nCoB);
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    p.splits = (int)splits;
+    pl.slab_floats = (long long)p.splits * pl.KS * p.ntaps * Ci * Co;
+    pl.bias_floats = (long long)p.splits * Co;
+    return MRDIS_OK;
+}
+
+size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    BWgradPlan pl;
+    if (plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
+    return sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
+}
+
+int mrdis_run_bwgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s) {
+    BWgradPlan pl;
+    int rc = plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
+    if (rc) return rc;
+    if (ldx % 4 != 0 || lddy % 4 != 0 || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256) return MRDIS_EWORKSPACE;
+    BWgradParams& p = pl.p;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
+    const int grid = p.splits * p.nCiB * p.nCoB;
+#define BW_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
+        static bool attr_set = false; \
+        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
+        hipLaunchKernelGGL((bwgrad_kernel<a, b_>), dim3(grid), dim3(512), pl.lds, s, p); }
+    BW_CASE(1, 1) else BW_CASE(1, 2) else BW_CASE(2, 1) else BW_CASE(2, 2)
+#undef BW_CASE
+    MRDIS_CHECK_LAUNCH();
+    const long long n = (long long)p.ntaps * Ci * Co;
+    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + Co + 255) / 256)), dim3(256), 0, s, p.slab, p.splits * pl.KS, n, dw_tck,
+                       p.bias_slab, p.splits, Co, dbias, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

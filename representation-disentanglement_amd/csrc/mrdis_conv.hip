@@ -26,28 +26,13 @@
 // workgroups and waves; partial 32x32 slabs are written once and summed in a
 // fixed order by a second kernel (bit-reproducible, no float atomics).
 #include "mrdis_common.h"
+#include "mrdis_tapconv.h"
 #include <stdlib.h>
 #include <type_traits>
 
-#define TC_BM 128
 // 256 B of zeros: the source of LDS-DMA lanes that fall outside the image / channel range
 __device__ float g_mrdis_zero_page[64];
 #define TC_TAB_INTS 320   // tapconv16: tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad (tapconv_kernel: 2*BM + 64)
-
-struct TapConvParams {
-    const float* in; const float* w; const float* bias; float* out;
-    int N, Hin, Win, Cin, ldin;
-    int Hout, Wout, Cout, ldout;
-    int A, B, os, oh0, ow0, is;
-    int ntaps;
-    int dh[MRDIS_MAX_TAPS], dw[MRDIS_MAX_TAPS], widx[MRDIS_MAX_TAPS];
-    int dh_min, dw_min;
-    int NB, TH, TW, TinH, TinW;
-    int tilesA, tilesB, tilesN, coTiles;
-    int epilogue;
-    int vec_in, vec_w;
-    int prefetch;                 // staging mode of tapconv_kernel: 0 generic | 1 hoisted descriptors + register prefetch
-};
 
 template <int KC, int BN, int MODE, int BM>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch; BM positions per workgroup
 __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
@@ -621,22 +606,6 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
 }
 
 // ------------------------------------------------------------------ host side
-struct TileChoice { int NB, TH, TW; };
-
-static TileChoice choose_tile(int N, int A, int B, int BMv = TC_BM) {
-    TileChoice best{1, 1, 1};
-    double best_u = -1.0;
-    for (int tw = 1; tw <= 32 && tw <= B; ++tw) {
-        int th = BMv / tw; if (th > A) th = A;
-        int nb = BMv / (tw * th); if (nb > N) nb = N; if (nb < 1) nb = 1;
-        const double u = ((double)B / ((double)mrdis_cdiv(B, tw) * tw)) * ((double)A / ((double)mrdis_cdiv(A, th) * th)) *
-                         ((double)N / ((double)mrdis_cdiv(N, nb) * nb)) * ((double)(tw * th * nb) / BMv);
-        // prefer wide rows (coalesced staging, conflict-free LDS reads) on ties
-        if (u > best_u + 1e-9 || (u > best_u - 1e-9 && tw > best.TW)) { best_u = u; best = {nb, th, tw}; }
-    }
-    return best;
-}
-
 template <int KC, int BN>
 static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM, hipStream_t s) {
     if (BM == 256) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 256>), dim3(nblk), dim3(256), lds, s, p);      // BM 256 only with MODE 1
@@ -661,6 +630,10 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
         if (p.dh[t] > dh_max) dh_max = p.dh[t];
         if (p.dw[t] < p.dw_min) p.dw_min = p.dw[t];
         if (p.dw[t] > dw_max) dw_max = p.dw[t];
+    }
+    if (p.dtype == MRDIS_DT_F32_BF16M && p.w_bf16) {          // bf16 MFMA operands (mrdis_bf16.hip) where the geometry allows
+        const int rc = mrdis_run_bconv(p, dh_max, dw_max, s);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     const TileChoice tc = choose_tile(p.N, p.A, p.B);
     p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
@@ -1071,16 +1044,22 @@ static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int
     return nblk >= (cg == 2 ? 256 : 512);
 }
 
-extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const float* bias,
+static bool bf16m_wanted(int dtype, const void* w_bf16, int Cred, int Cout) {
+    return dtype == MRDIS_DT_F32_BF16M && w_bf16 != nullptr && Cred % 16 == 0 && Cout % 4 == 0 && Cout >= 16;
+}
+
+extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                                 float* y, int ldy, int N, int H, int W, int Ci, int Co,
-                                int kh, int kw, int stride, int pad, int epilogue, void* stream) {
+                                int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream) {
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;       // MRDIS_DT_BF16 storage: not built
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
     if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
-    if (wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
+    const bool bf = bf16m_wanted(dtype, w_bf16_tkc, Ci, Co);
+    if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
         rc = mrdis_run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
@@ -1096,12 +1075,14 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
             p.dh[t] = r - pad; p.dw[t] = s_ - pad; p.widx[t] = t;
         }
     p.epilogue = epilogue;
+    p.w_bf16 = bf ? w_bf16_tkc : nullptr; p.dtype = dtype;
     return run_tapconv(p, (hipStream_t)stream);
 }
 
-extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc,
+extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
                                      float* dx, int lddx, int N, int H, int W, int Ci, int Co,
-                                     int kh, int kw, int stride, int pad, void* stream) {
+                                     int kh, int kw, int stride, int pad, int dtype, void* stream) {
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
@@ -1111,12 +1092,14 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
     base.N = N; base.Hin = Ho; base.Win = Wo; base.Cin = Co; base.ldin = lddy;
     base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
     base.is = 1; base.epilogue = 0;
+    const bool bf = bf16m_wanted(dtype, w_bf16_tck, Co, Ci);      // the data gradient reduces over Co and produces Ci channels
+    base.w_bf16 = bf ? w_bf16_tck : nullptr; base.dtype = dtype;
     if (stride == 1) {
         // dx of a Ci <- 4 layer (ana_dec.output): a 4 -> Ci convolution of dy with the taps reversed; [tap][Co=4][Ci] is
         // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
         if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
-        if (wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
+        if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
             rc = mrdis_run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
@@ -2118,11 +2101,17 @@ static bool wino_wgrad_wanted(int N, int H, int W, int Ci, int Co, int kh, int k
     return (long long)N * ((H + 3) / 4) * ((W + 7) / 8) >= 256;
 }
 
+// mrdis_bf16.hip: weight gradient on bf16 MFMA operands (stride-1 "same" convolutions, Ci % 32 == 0)
+size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);
+int mrdis_run_bwgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
+
 extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
                                                     int kh, int kw, int stride, int pad) {
     WgradPlan pl;
     if (plan_wgrad(pl, N, H, W, Ci, Ci, Co, kh, kw, stride, pad)) return 0;
     size_t need = wgrad_need(pl);
+    { const size_t nb = mrdis_bwgrad_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (nb > need) need = nb; }   // any dtype may be asked for
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1) {           // either kernel may run (MRDIS_WINO is read per call)
         const size_t nw = mrdis_wino_wgrad_workspace(N, H, W, Ci, Co);
         if (nw > need) need = nw;
@@ -2157,13 +2146,19 @@ static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
 extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
-                                       int kh, int kw, int stride, int pad, int accumulate_bias, void* stream) {
+                                       int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream) {
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
     WgradPlan pl;
     int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
     if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
+    if (dtype == MRDIS_DT_F32_BF16M) {
+        rc = mrdis_run_bwgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
+                              accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
         rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;

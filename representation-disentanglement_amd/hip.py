@@ -40,10 +40,11 @@ _SIGS = {
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
-    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
-    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
+    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
+    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
+    'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
-    'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 10 + [_P]),
+    'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 11 + [_P]),
     'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P]),
     'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
     'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _P]),
@@ -257,7 +258,21 @@ def conv_out_hw(H, W, kh, kw, stride, pad):
     return (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
 
 
-def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None):
+DT_F32, DT_F32_BF16M, DT_BF16 = 0, 1, 2          # include/mrdis.h MRDIS_DT_*
+
+
+def cast_bf16(t):
+    """fp32 tensor -> bf16 copy (round to nearest even) through the library's cast kernel."""
+    lib = load()
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    _chk(lib.mrdis_cast_bf16(_ptr(t), _ptr(out), t.numel(), _stream()), 'cast_bf16')
+    return out
+
+
+def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf16=None):
+    """w_bf16: bf16 [T][Co][Ci] copy of the filter (reduction axis contiguous) -> bf16 MFMA operands, fp32 accumulate
+    (MRDIS_DT_F32_BF16M) where the geometry allows; None -> exact fp32."""
     lib = load()
     x, ldx = nhwc(x)
     N, Ci, H, W = x.shape
@@ -268,12 +283,15 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None):
         out = empty_nhwc(N, Co, Ho, Wo, x.device)
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr(), 'conv2d_fwd: `out` must already be an NHWC view'
-    _chk(lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              1 if lrelu else 0, _stream()), 'conv2d_fwd')
+    if w_bf16 is not None:
+        assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
+    _chk(lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
+                              1 if lrelu else 0, DT_F32 if w_bf16 is None else DT_F32_BF16M, _stream()), 'conv2d_fwd')
     return out
 
 
-def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad):
+def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None):
+    """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co)."""
     lib = load()
     dy, lddy = nhwc(dy)
     N, Co, Ho, Wo = dy.shape
@@ -281,14 +299,16 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad):
     H, W = in_hw
     assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
     dx = empty_nhwc(N, Ci, H, W, dy.device)
-    _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad, _stream()),
-         'conv2d_bwd_data')
+    if w_bf16 is not None:
+        assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
+    _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad,
+                                   DT_F32 if w_bf16 is None else DT_F32_BF16M, _stream()), 'conv2d_bwd_data')
     return dx
 
 
-def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None):
+def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32):
     """-> (dw_tck, dbias).  bias_sink: a (Co,) buffer the bias gradient is ADDED to in the reduce launch
-    (then dbias is returned as None)."""
+    (then dbias is returned as None).  dtype DT_F32_BF16M: bf16 MFMA operands where the geometry allows."""
     lib = load()
     x, ldx = nhwc(x)
     dy, lddy = nhwc(dy)
@@ -302,7 +322,7 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
     ws = _ws(nb, x.device)
     sink = bias_sink if (need_bias and bias_sink is not None) else None
     _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
-                                     N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _stream()), 'conv2d_bwd_weight')
+                                     N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, int(dtype), _stream()), 'conv2d_bwd_weight')
     return dw, db
 
 

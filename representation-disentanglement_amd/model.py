@@ -93,7 +93,8 @@ class CondConv2d(nn.Module):
             if not ops.mix_cache_active():
                 # the seam as ONE dispatcher-visible op (mix + conv, torch.ops.mrdis.cond_conv2d): plain module use
                 return torch.ops.mrdis.cond_conv2d(inputs, inputs_type[:1], self.weight, self._routing_fn.fc.weight,
-                                                   self._routing_fn.fc.bias, self.bias, self.stride[0], self.padding[0], lrelu)
+                                                   self._routing_fn.fc.bias, self.bias, self.stride[0], self.padding[0], lrelu,
+                                                   ops.compute_dtype())
             # inside a training step the mixed kernels of all modality labels are cached and shared by every call
             w_tck, w_tkc = self.mixed_uniform(inputs_type)
             return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)

@@ -155,8 +155,38 @@ def set_grad_sink(enabled):
 
 
 # --------------------------------------------------------------------------- convolution
+# Compute dtype of the convolutions (BASELINE.json configs[2]): 'f32' = exact fp32 MFMA (the parity path), 'bf16' = bf16
+# MFMA operands with fp32 accumulation on fp32 activations (include/mrdis.h MRDIS_DT_F32_BF16M); config key `compute_dtype`.
+_COMPUTE_DTYPE = hip.DT_F32
+
+
+def set_compute_dtype(name):
+    global _COMPUTE_DTYPE
+    table = {'f32': hip.DT_F32, 'fp32': hip.DT_F32, 'float32': hip.DT_F32, 'bf16': hip.DT_F32_BF16M, 'bfloat16': hip.DT_F32_BF16M}
+    if name not in table:
+        raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {name!r}")
+    _COMPUTE_DTYPE = table[name]
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def bf16_filters(w_tck, w_tkc):
+    """bf16 copies of a mixed filter with the reduction axis contiguous: (forward = cast(w_tkc), data gradient = cast(w_tck));
+    memoised for the step next to the mixed kernels themselves."""
+    def make():
+        with torch.no_grad():
+            return (w_tck, hip.cast_bf16(w_tkc.detach()), hip.cast_bf16(w_tck.detach()))
+    hit = cached_mix(('bf16w', id(w_tck)), make)
+    return hit[1], hit[2]
+
+
 def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
     """-> torch.ops.mrdis.conv2d (registered at the bottom of this file: CUDA kernel, fake kernel, autograd formula)."""
+    if _COMPUTE_DTYPE == hip.DT_F32_BF16M:
+        wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
+        return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
     return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
 
 
@@ -356,14 +386,14 @@ def cached_mix(key, make):
 # (model.py:2108-2117) for a batch-constant type; `mrdis::conv2d` is the same convolution on an already mixed kernel
 # (what the model calls inside a training step, where one mix serves 8-16 calls).
 _lib = torch.library.Library('mrdis', 'DEF')
-_lib.define('conv2d(Tensor x, Tensor w_tck, Tensor w_tkc, Tensor? bias, int kh, int kw, int stride, int pad, bool lrelu) -> Tensor')
-_lib.define('conv2d_bwd_data(Tensor dy, Tensor w_tkc, int H, int W, int kh, int kw, int stride, int pad) -> Tensor')
-_lib.define('conv2d_bwd_weight(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, bool need_bias) -> (Tensor, Tensor)')
-_lib.define('conv2d_bwd_weight_sink(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, Tensor(a!) bias_grad) -> Tensor')
+_lib.define('conv2d(Tensor x, Tensor w_tck, Tensor w_tkc, Tensor? bias, int kh, int kw, int stride, int pad, bool lrelu, Tensor? wb_fwd=None, Tensor? wb_bwd=None) -> Tensor')
+_lib.define('conv2d_bwd_data(Tensor dy, Tensor w_tkc, int H, int W, int kh, int kw, int stride, int pad, Tensor? w_bf16=None) -> Tensor')
+_lib.define('conv2d_bwd_weight(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, bool need_bias, int dtype=0) -> (Tensor, Tensor)')
+_lib.define('conv2d_bwd_weight_sink(Tensor x, Tensor dy, int kh, int kw, int stride, int pad, Tensor(a!) bias_grad, int dtype=0) -> Tensor')
 _lib.define('lrelu_bwd(Tensor dy, Tensor y, float slope) -> Tensor')
 _lib.define('mix_experts_routed(Tensor W, Tensor fc_w, Tensor fc_b, Tensor type_row) -> (Tensor, Tensor, Tensor)')
 _lib.define('mix_experts_routed_bwd(Tensor dw_tck, Tensor W, Tensor r, Tensor type_row) -> (Tensor, Tensor, Tensor)')
-_lib.define('cond_conv2d(Tensor x, Tensor type_row, Tensor weight, Tensor fc_w, Tensor fc_b, Tensor? bias, int stride, int pad, bool lrelu) -> Tensor')
+_lib.define('cond_conv2d(Tensor x, Tensor type_row, Tensor weight, Tensor fc_w, Tensor fc_b, Tensor? bias, int stride, int pad, bool lrelu, int dtype=0) -> Tensor')
 
 
 def _nhwc_like(x, N, C, H, W):
@@ -375,21 +405,21 @@ def _out_hw(x, kh, kw, stride, pad):
 
 
 # ---- kernels (CUDA = the HIP device under PyTorch-ROCm)
-def _k_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
-    return hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu)
+def _k_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd=None, wb_bwd=None):
+    return hip.conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu, w_bf16=wb_fwd)
 
 
-def _k_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad):
-    return hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad)
+def _k_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad, w_bf16=None):
+    return hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad, w_bf16=w_bf16)
 
 
-def _k_bwd_weight(x, dy, kh, kw, stride, pad, need_bias):
-    dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=need_bias)
+def _k_bwd_weight(x, dy, kh, kw, stride, pad, need_bias, dtype=0):
+    dw, db = hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=need_bias, dtype=dtype)
     return dw, (db if db is not None else dw.new_zeros(dy.shape[1]))
 
 
-def _k_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad):
-    return hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=bias_grad)[0]
+def _k_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad, dtype=0):
+    return hip.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=bias_grad, dtype=dtype)[0]
 
 
 def _k_mix(W, fc_w, fc_b, type_row):
@@ -400,9 +430,10 @@ def _k_mix_bwd(dw_tck, W, r, type_row):
     return hip.mix_experts_routed_bwd(dw_tck, W, r, type_row, type_row.shape[-1])
 
 
-def _k_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu):
-    w_tck, _, _ = hip.mix_experts_routed_fwd(weight, fc_w, fc_b, type_row)
-    return hip.conv2d_fwd(x, w_tck, bias, weight.shape[3], weight.shape[4], stride, pad, lrelu)
+def _k_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu, dtype=0):
+    w_tck, w_tkc, _ = hip.mix_experts_routed_fwd(weight, fc_w, fc_b, type_row)
+    wb = hip.cast_bf16(w_tkc) if dtype == hip.DT_F32_BF16M else None
+    return hip.conv2d_fwd(x, w_tck, bias, weight.shape[3], weight.shape[4], stride, pad, lrelu, w_bf16=wb)
 
 
 for _name, _fn in (('conv2d', _k_conv2d), ('conv2d_bwd_data', _k_bwd_data), ('conv2d_bwd_weight', _k_bwd_weight),
@@ -413,23 +444,23 @@ for _name, _fn in (('conv2d', _k_conv2d), ('conv2d_bwd_data', _k_bwd_data), ('co
 
 # ---- fake kernels: shapes / strides only
 @torch.library.register_fake('mrdis::conv2d')
-def _f_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu):
+def _f_conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd=None, wb_bwd=None):
     Ho, Wo = _out_hw(x, kh, kw, stride, pad)
     return _nhwc_like(x, x.shape[0], w_tck.shape[2], Ho, Wo)
 
 
 @torch.library.register_fake('mrdis::conv2d_bwd_data')
-def _f_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad):
+def _f_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad, w_bf16=None):
     return _nhwc_like(dy, dy.shape[0], w_tkc.shape[2], H, W)
 
 
 @torch.library.register_fake('mrdis::conv2d_bwd_weight')
-def _f_bwd_weight(x, dy, kh, kw, stride, pad, need_bias):
+def _f_bwd_weight(x, dy, kh, kw, stride, pad, need_bias, dtype=0):
     return x.new_empty((kh * kw, x.shape[1], dy.shape[1])), x.new_empty((dy.shape[1],))
 
 
 @torch.library.register_fake('mrdis::conv2d_bwd_weight_sink')
-def _f_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad):
+def _f_bwd_weight_sink(x, dy, kh, kw, stride, pad, bias_grad, dtype=0):
     return x.new_empty((kh * kw, x.shape[1], dy.shape[1]))
 
 
@@ -450,36 +481,37 @@ def _f_mix_bwd(dw_tck, W, r, type_row):
 
 
 @torch.library.register_fake('mrdis::cond_conv2d')
-def _f_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu):
+def _f_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu, dtype=0):
     Ho, Wo = _out_hw(x, weight.shape[3], weight.shape[4], stride, pad)
     return _nhwc_like(x, x.shape[0], weight.shape[1], Ho, Wo)
 
 
 # ---- autograd formulas (backward = other mrdis ops, so it traces too)
 def _conv2d_setup(ctx, inputs, output):
-    x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu = inputs
+    x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd = inputs
     ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3])
     ctx.bias_param = bias                         # the Parameter object: its .grad may be an in-kernel gradient sink
-    ctx.save_for_backward(x, w_tkc, output if lrelu else None)
+    ctx.dtype = hip.DT_F32 if wb_fwd is None else hip.DT_F32_BF16M
+    ctx.save_for_backward(x, w_tkc, output if lrelu else None, wb_bwd)
 
 
 def _conv2d_backward(ctx, dy):
     kh, kw, stride, pad, lrelu, H, W = ctx.geom
-    x, w_tkc, y = ctx.saved_tensors
+    x, w_tkc, y, wb_bwd = ctx.saved_tensors
     if lrelu:
         dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
-    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
+    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad, wb_bwd) if ctx.needs_input_grad[0] else None
     dw = db = None
     has_bias = ctx.bias_param is not None
     if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
         sink = _grad_sink(ctx.bias_param) if has_bias else None
         if sink is not None:
-            dw = torch.ops.mrdis.conv2d_bwd_weight_sink(x, dy, kh, kw, stride, pad, sink)
+            dw = torch.ops.mrdis.conv2d_bwd_weight_sink(x, dy, kh, kw, stride, pad, sink, ctx.dtype)
         else:
-            dw, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, has_bias)
+            dw, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, has_bias, ctx.dtype)
             if not has_bias:
                 db = None
-    return dx, dw, None, db, None, None, None, None, None
+    return dx, dw, None, db, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd('mrdis::conv2d', _conv2d_backward, setup_context=_conv2d_setup)
@@ -500,8 +532,9 @@ torch.library.register_autograd('mrdis::mix_experts_routed', _mix_backward, setu
 
 
 def _cond_setup(ctx, inputs, output):
-    x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu = inputs
+    x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu, dtype = inputs
     ctx.geom = (stride, pad, lrelu)
+    ctx.dtype = dtype
     ctx.has_bias = bias is not None
     ctx.save_for_backward(x, type_row, weight, fc_w, fc_b, output if lrelu else None)
 
@@ -512,11 +545,13 @@ def _cond_backward(ctx, dy):
     kh, kw = weight.shape[3], weight.shape[4]
     if lrelu:
         dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
-    _, w_tkc, r = torch.ops.mrdis.mix_experts_routed(weight, fc_w, fc_b, type_row)          # re-mixed: nothing but x is kept alive
-    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, x.shape[2], x.shape[3], kh, kw, stride, pad) if ctx.needs_input_grad[0] else None
-    dw_tck, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, ctx.has_bias)
+    # the kernel is re-mixed here: nothing but x is kept alive between forward and backward
+    w_tck, w_tkc, r = torch.ops.mrdis.mix_experts_routed(weight, fc_w, fc_b, type_row)
+    wb = hip.cast_bf16(w_tck) if (ctx.dtype == hip.DT_F32_BF16M and w_tck.is_cuda and not isinstance(w_tck, torch._subclasses.FakeTensor)) else None
+    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, x.shape[2], x.shape[3], kh, kw, stride, pad, wb) if ctx.needs_input_grad[0] else None
+    dw_tck, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, ctx.has_bias, ctx.dtype)
     dW, dfcw, dfcb = torch.ops.mrdis.mix_experts_routed_bwd(dw_tck, weight, r, type_row)
-    return dx, None, dW, dfcw, dfcb, (db if ctx.has_bias else None), None, None, None
+    return dx, None, dW, dfcw, dfcb, (db if ctx.has_bias else None), None, None, None, None
 
 
 torch.library.register_autograd('mrdis::cond_conv2d', _cond_backward, setup_context=_cond_setup)

@@ -35,6 +35,7 @@ DEFAULT_CONFIG = {
     'ckpt_name': 'model_best.pth.tar', 'ckpt_timelabel': None,
     # keys added by this implementation (defaults reproduce the reference)
     'backend': 'hip', 'is_patch_gan': False,
+    'compute_dtype': 'f32',            # 'bf16': bf16 MFMA operands + fp32 accumulate on fp32 activations (BASELINE configs[2], stage 1)
 }
 
 
@@ -503,6 +504,7 @@ class TrainStep:
 
     def __init__(self, model, config, ddp_group=None, ddp_buckets=6):
         self.model, self.config = model, config
+        ops.set_compute_dtype(config.get('compute_dtype', 'f32'))
         self.accum = max(1, 16 // config['batch_size'])                                          # :282 (guarded for B > 16)
         used = model.trainable_parameters() if hasattr(model, 'trainable_parameters') else None
         self.optimizer = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=1e-5, used=used)   # :118

@@ -457,3 +457,43 @@ def test_optimizer_state_dict_round_trip_with_torch_adam(mrdis, golden_dir):
     for v in lay['monitor']:
         sched.step(v); lrs.append(step2.optimizer.lr)
     assert lrs == lay['lr_trajectory']
+
+
+@pytest.mark.parametrize('tag', ['b2m4', 'b2m2_adv'])
+def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag):
+    """BASELINE configs[2], stage 1 (`compute_dtype: bf16`): every eligible convolution on bf16 MFMA operands with fp32
+    accumulation, activations / norms / losses / optimizer in fp32.  Against the fp32 vectors of the real reference the
+    stated tolerances are: loss and loss parts 2e-2 relative, total gradient norm 5e-2, per-tensor gradient norms 0.15
+    (bf16 operands carry 8 significant bits; the 1e-3 bar of the fp32 path cannot hold)."""
+    meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
+    B, M, adv = meta['B'], meta['M'], meta['adv']
+    cfg = _cfg(mrdis, M, 160, 192, B, adv)
+    cfg['compute_dtype'] = 'bf16'
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    if adv:
+        reinit_discriminator(model.discrim_s)
+    inputs, mask, mask_img = make_inputs(B, M, 160, 192, seed=10, drop=meta['drop'])
+    step = mrdis.TrainStep(model, cfg)
+    try:
+        assert mrdis.ops.compute_dtype() == mrdis.hip.DT_F32_BF16M
+        torch.manual_seed(11); np.random.seed(11)
+        names = {id(p): n for n, p in model.named_parameters()}
+        with mrdis.ops.mix_cache():
+            loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+            loss.backward(retain_graph=adv)
+        assert abs(float(loss) - meta['loss']) <= 2e-2 * abs(meta['loss']), (float(loss), meta['loss'])
+        assert abs(float(loss) - meta['loss']) > 1e-7 * abs(meta['loss'])          # not the fp32 path
+        for k, v in meta['parts'].items():
+            assert abs(float(parts[k]) - v) <= 2e-2 * abs(v) + 1e-4, (k, float(parts[k]), v)
+        gn = {names[id(p)]: float(p.grad.double().norm()) for p in step.optimizer.used}
+        hot = {k: v for k, v in meta['grad_norms'].items() if not k.startswith('output_decoder')}
+        assert set(hot) == set(gn)
+        total = float(np.sqrt(sum(v * v for v in gn.values()))); ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
+        assert abs(total - ref_total) <= 5e-2 * ref_total, (total, ref_total)
+        bad = [k for k, v in hot.items() if abs(gn[k] - v) > 0.15 * v + 1e-3 * ref_total]
+        assert len(bad) <= 0.02 * len(hot), bad[:8]
+        step.optimizer.step(fused_clip=True)
+        assert torch.isfinite(step.optimizer.flat_p).all()
+    finally:
+        mrdis.ops.set_compute_dtype('f32')

@@ -530,3 +530,44 @@ def test_torch_ops_registered_with_fake_and_autograd(mrdis):
         fy = torch.ops.mrdis.cond_conv2d(fx, torch.empty((1, 1), device='cuda'), torch.empty((3, Co, Ci, 4, 4), device='cuda'),
                                          torch.empty((3, 1), device='cuda'), torch.empty((3,), device='cuda'), None, 2, 1, False)
         assert tuple(fy.shape) == (4, Co, 16, 10) and fy.is_contiguous(memory_format=torch.channels_last)
+
+
+BF16_CASES = [(2, 32, 64, 40, 56, 3, 1, 1), (3, 64, 32, 33, 21, 3, 1, 1), (20, 128, 256, 16, 16, 3, 1, 1), (4, 16, 48, 20, 24, 3, 1, 1),
+              (4, 32, 16, 64, 48, 3, 1, 1), (2, 32, 64, 32, 48, 4, 2, 1), (70, 128, 128, 8, 8, 3, 1, 1), (2, 64, 128, 24, 24, 3, 2, 1),
+              (5, 512, 128, 32, 32, 3, 1, 1), (6, 64, 64, 24, 40, 1, 1, 0), (3, 96, 40, 50, 30, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('case', BF16_CASES, ids=[str(c) for c in BF16_CASES])
+def test_conv_bf16_mfma(mrdis, case):
+    """MRDIS_DT_F32_BF16M (BASELINE configs[2], stage 1): bf16 MFMA operands, fp32 accumulation, fp32 activations in HBM.
+    The kernels must reproduce -- to fp32 rounding -- a torch fp32 convolution of the bf16-ROUNDED operands (that is exactly
+    what they multiply), forward / data gradient / weight gradient; against the unrounded fp32 result the error is the bf16
+    operand rounding: stated tolerance 1e-2 of the output's max magnitude (measured ~2.5e-3)."""
+    N, Ci, Co, H, W, k, s, p = case
+    hip = mrdis.hip
+    x = rnd((N, Ci, H, W), 1); w = rnd((Co, Ci, k, k), 2, 1.0 / np.sqrt(Ci * k * k)); b = rnd((Co,), 3, 0.1)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    want = F.conv2d(xb, wb, b, s, p)
+    got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), k, k, s, p, w_bf16=hip.cast_bf16(to_tkc(w).to(dev())))
+    close(got, want, rtol=2e-5, what='fwd vs bf16-rounded operands')
+    close(got, F.conv2d(x, w, b, s, p), rtol=1e-2, what='fwd vs fp32')
+    exact = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), k, k, s, p)
+    assert not torch.equal(exact, got)                                            # the bf16 kernel really ran
+    gy = rnd(tuple(want.shape), 4); gyb = gy.bfloat16().float()
+    dx = hip.conv2d_bwd_data(cl(gy), to_tkc(w).to(dev()), (H, W), k, k, s, p, w_bf16=hip.cast_bf16(to_tck(w).to(dev())))
+    if Co % 16 == 0 and Ci % 4 == 0 and Ci >= 16:                                 # the data gradient reduces over Co
+        close(dx, torch.nn.grad.conv2d_input(x.shape, wb, gyb, s, p), rtol=2e-5, what='dgrad vs bf16-rounded operands')
+    else:                                                                         # not a multiple of 16: the fp32 kernel ran, exact
+        close(dx, torch.nn.grad.conv2d_input(x.shape, w, gy, s, p), rtol=1e-4, what='dgrad (fp32 kernel)')
+    wz = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(xb, wz, None, s, p).backward(gyb)
+    dw, db = hip.conv2d_bwd_weight(cl(x), cl(gy), k, k, s, p, need_bias=True, dtype=hip.DT_F32_BF16M)
+    want_b = to_tck(wz.grad)
+    wz.grad = None; F.conv2d(x, wz, None, s, p).backward(gy)
+    want_f = to_tck(wz.grad)
+    err_b = float((dw.cpu() - want_b).abs().max() / want_b.abs().max()); err_f = float((dw.cpu() - want_f).abs().max() / want_f.abs().max())
+    if s == 1 and N * H * W >= 4096:                                              # the bf16 kernel's domain (stride-1 "same" layers on real maps)
+        assert err_b <= 4e-5, ('wgrad vs bf16-rounded operands', err_b)
+    else:                                                                         # stride 2 / tiny maps: the fp32 kernels run -> exact fp32
+        assert err_f <= 3e-4, ('wgrad (fp32 kernels)', err_f, err_b)
+    close(db, gy.sum((0, 2, 3)), rtol=2e-5, what='dbias (fp32 sum)')

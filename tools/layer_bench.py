@@ -40,7 +40,7 @@ def layers(B, H, W):
     for i, (ci, co, d) in enumerate(sp):
         hh, ww = H // d, W // d
         L.append((f'sp{i + 1}.si', 4, ci, 3, 1, 1, hh, ww, 16, 16))
-        L.append((f'sp{i + 1}.gamma/beta', ci, ci, 3, 1, 1, hh, ww, 32, 32))
+        L.append((f'sp{i + 1}.gamma+beta', ci, 2 * ci, 3, 1, 1, hh, ww, 16, 16))      # as the step runs them: ONE fused conv
         L.append((f'sp{i + 1}.out', ci, co, 3, 1, 1, hh, ww, 16, 16))
     L.append(('dec.out1x1', 16, 7, 1, 1, 0, H, W, 16, 16))
     return L
@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--hw', type=int, nargs=2, default=[256, 256])
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="bf16: bf16 MFMA operands + fp32 accumulate on fp32 activations")
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     B, (H, W) = a.batch, a.hw
@@ -77,9 +78,13 @@ def main():
         dy = torch.randn(B, co, ho, wo, device=dev).contiguous(memory_format=torch.channels_last)
         flop = 2.0 * k * k * ci * co * B * ho * wo
         byts = 4.0 * (B * ci * hi * wi + B * co * ho * wo)
-        tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p), a.iters)
-        td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p), a.iters)
-        tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p), a.iters)
+        bf = a.dtype == 'bf16'
+        wb_f = hip.cast_bf16(wk) if bf else None
+        wb_b = hip.cast_bf16(wt) if bf else None
+        dt = hip.DT_F32_BF16M if bf else hip.DT_F32
+        tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p, w_bf16=wb_f), a.iters)
+        td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p, w_bf16=wb_b), a.iters)
+        tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p, dtype=dt), a.iters)
         rows.append((name, ci, co, k, s, hi, wi, calls, flop, byts, tf, td, tw, dcalls))
         del x, dy
     tot = sum(r[10] * r[7] + r[11] * r[13] + r[12] * r[7] for r in rows)
