@@ -35,8 +35,7 @@ __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
 // KC channels per chunk; 4 waves as WAVES_C (cout) x 4/WAVES_C (positions); a wave owns WP x WC blocks of 32 positions x 32 couts
 template <int KC, int WAVES_C, int WP, int WC>
 __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
-    constexpr int WAVES_P = 4 / WAVES_C;
-    constexpr int BM = 32 * WP * WAVES_P, BN = 32 * WC * WAVES_C;
+    constexpr int BN = 32 * WC * WAVES_C;          // x 32 * WP * WAVES_P positions
     constexpr int PITCH = KC + 8;                 // bf16 elements per LDS row
     constexpr int QX = KC / 8;                    // 16-byte pieces per pixel row
     constexpr int XR = 6, WR = 9;                 // register-staged pieces per thread (input, filter)
@@ -45,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
     __bf16* xs = ws + p.ntaps * BN * PITCH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
-    const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;
+    const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;          // 4 / WAVES_C position groups
     const int cot = blockIdx.x % p.coTiles, wg = blockIdx.x / p.coTiles;
     const int co0 = cot * BN;
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
@@ -234,10 +233,11 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
     // tile shape by cout width: (WAVES_C, WP, WC) -> BM x BN
     struct Cfg { int waves_c, wp, wc; };
     Cfg c;
-    if (p.Cout > 64) c = {2, 2, 2};               // 128 positions x 128 couts
-    else if (p.Cout > 32) c = {1, 2, 2};          // 256 positions x 64 couts
+    // measured (tools/layer_bench.py --dtype bf16): 64-cout tiles with 32-channel chunks beat 128-cout tiles (which only fit
+    // 16-channel chunks in LDS) on every wide layer: sp4.gamma+beta 153 -> 123 us, ana.up_3 106 -> 83 us
+    if (p.Cout > 32) c = {1, 2, 2};               // 256 positions x 64 couts
     else c = {1, 2, 1};                           // 256 positions x 32 couts
-    int BM = 32 * c.wp * (4 / c.waves_c);
+    int BM = 32 * c.wp * (4 / c.waves_c);          // positions per workgroup
     const int BN = 32 * c.wc * c.waves_c;
     auto geom = [&](int bm) {
         const TileChoice tc = choose_tile(p.N, p.A, p.B, bm);
@@ -271,7 +271,6 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
     g.tile_stride = (int)per_cot;
     const int grid = (int)per_cot * p.coTiles;
 #define BC_CASE(kc, a, b_, d) if (KC == kc && c.waves_c == a && c.wp == b_ && c.wc == d) return launch_bconv<kc, a, b_, d>(p, g, grid, lds, s)
-    BC_CASE(32, 2, 2, 2); BC_CASE(16, 2, 2, 2);
     BC_CASE(32, 1, 2, 2); BC_CASE(16, 1, 2, 2); BC_CASE(32, 1, 1, 2); BC_CASE(16, 1, 1, 2);
     BC_CASE(32, 1, 2, 1); BC_CASE(16, 1, 2, 1); BC_CASE(32, 1, 1, 1); BC_CASE(16, 1, 1, 1);
 #undef BC_CASE
@@ -308,7 +307,8 @@ extern "C" int mrdis_cast_bf16(const float* src, void* dst, long long n, void* s
 // operand feeds 9 MFMAs.  Waves that share a channel block split the 8 position steps of a tile among themselves.
 // Global loads of the next tile (register-staged, fp32 -> bf16 on the way into LDS) fly while the current one is
 // multiplied; the bias gradient (column sums of dy) is accumulated in fp32 from the staging registers.  Every wave writes
-// its partial to its own slab [S][T][Ci][Co]; a fixed-order reduction kernel sums the slabs (bit-reproducible).
+// its partial; the waves of a channel block add theirs through LDS in a fixed order and the workgroup writes one slab
+// [split][T][Ci][Co]; a fixed-order reduction kernel sums the slabs (bit-reproducible).
 struct BWgradParams {
     const float* x; const float* dy; float* slab; float* bias_slab;
     int N, H, W, Ci, Co, ldx, lddy;
@@ -449,19 +449,31 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
         }
         tile = ntile;
     }
-    // ---- partial slabs: D[ci row][co col]; slab s = split * KS + ks, layout [S][T][Ci][Co]
+    // ---- the KS waves of a channel block add their partials through LDS (tap by tap, fixed order), then the ks = 0 wave
+    // writes the block: D[ci row][co col] -> slab [split][T][Ci][Co]
     const int half = lane >> 5, e = lane & 31;
-    const int s_idx = split * KS + ks;
     const int co = co0 + 32 * wco + e;
-    if (co < p.Co) {
-        for (int t = 0; t < p.ntaps; ++t) {
-            float* dst = p.slab + (((long long)s_idx * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+    float* red_acc = reinterpret_cast<float*>(smem_raw);            // [8 waves][16][64]
+    auto tap_acc = [&](int t, int r) -> float {
+        float v;
+        switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
+                     case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
+        return v;
+    };
+    for (int t = 0; t < p.ntaps; ++t) {
+        __syncthreads();
+        if (ks > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = tap_acc(t, r);
+        }
+        __syncthreads();
+        if (ks == 0 && co < p.Co) {
+            float* dst = p.slab + (((long long)split * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float v = tap_acc(t, r);
+                for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = 0.f;
-                switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
-                             case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
                 dst[(long long)row * p.Co] = v;
             }
         }
@@ -503,6 +515,9 @@ struct BWgradPlan { BWgradParams p; int wci, wco, KS; size_t lds; long long slab
 static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
     if (stride != 1 || kh * kw > 9 || kh != kw || 2 * pad != kh - 1) return MRDIS_EUNSUPPORTED;    // "same" convolutions only (Ho = H)
     if (Ci % 32 != 0 || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;
+    // measured (tools/layer_bench.py --dtype bf16, B = 32): with 32 or fewer couts a wave's 32 x 32 block leaves too few waves per
+    // channel block and the fp32 narrow-cout kernels win (sp6.out 593 vs 249 us, sp5.out 310 vs 198 us) unless Cin >= 128
+    if (Co <= 32 && Ci < 128) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W < 4096) return MRDIS_EUNSUPPORTED;                                    // tiny maps: the fp32 kernels' slabs are cheaper
     BWgradParams& p = pl.p;
     p = BWgradParams{};
@@ -530,12 +545,12 @@ static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int 
     const long long npix = (long long)nb * p.TinH * p.TinW;
     if (npix * (4 * pl.wci) > (long long)(pl.wci == 2 ? 4 : 2) * 512) return MRDIS_EUNSUPPORTED;
     pl.lds = 2 * 32 * ((size_t)pl.wco * 128 + (size_t)pl.wci * npix);
-    if (pl.lds < 512 * 8 * 4) pl.lds = 512 * 8 * 4;
+    if (pl.lds < 8 * 16 * 64 * 4) pl.lds = 8 * 16 * 64 * 4;          // the epilogue's wave-reduction buffer / bias scratch
     long long splits = mrdis_cdiv(bconv_ncu(), (long long)p.nCiB * p.nCoB);
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
-    pl.slab_floats = (long long)p.splits * pl.KS * p.ntaps * Ci * Co;
+    pl.slab_floats = (long long)p.splits * p.ntaps * Ci * Co;
     pl.bias_floats = (long long)p.splits * Co;
     return MRDIS_OK;
 }
@@ -566,7 +581,7 @@ int mrdis_run_bwgrad(const float* x, int ldx, const float* dy, int lddy, float* 
 #undef BW_CASE
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)p.ntaps * Ci * Co;
-    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + Co + 255) / 256)), dim3(256), 0, s, p.slab, p.splits * pl.KS, n, dw_tck,
+    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + Co + 255) / 256)), dim3(256), 0, s, p.slab, p.splits, n, dw_tck,
                        p.bias_slab, p.splits, Co, dbias, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -566,7 +566,7 @@ def test_conv_bf16_mfma(mrdis, case):
     wz.grad = None; F.conv2d(x, wz, None, s, p).backward(gy)
     want_f = to_tck(wz.grad)
     err_b = float((dw.cpu() - want_b).abs().max() / want_b.abs().max()); err_f = float((dw.cpu() - want_f).abs().max() / want_f.abs().max())
-    if s == 1 and N * H * W >= 4096:                                              # the bf16 kernel's domain (stride-1 "same" layers on real maps)
+    if s == 1 and N * H * W >= 4096 and Ci % 32 == 0 and (Co > 32 or Ci >= 128):  # the bf16 kernel's domain (stride-1 "same" layers on real maps)
         assert err_b <= 4e-5, ('wgrad vs bf16-rounded operands', err_b)
     else:                                                                         # stride 2 / tiny maps: the fp32 kernels run -> exact fp32
         assert err_f <= 3e-4, ('wgrad (fp32 kernels)', err_f, err_b)

@@ -6,7 +6,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py --no-direct --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bf16 -- python bench.py --dtype bf16 --no-cpu-baseline --no-roofline > $OUT/bench_bf16_profiled.json 2> $OUT/bench_bf16_profiled.err
+python tools/prof_summary.py stats $OUT/bf16_kernel_stats.csv $OUT/bf16_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 ($TAG)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ns -- python tools/northstar_conv.py 20 > $OUT/ns_stats.log 2>&1
 python tools/prof_summary.py stats $OUT/ns_kernel_stats.csv $OUT/ns_kernel_trace.csv $OUT/${TAG}_northstar_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python tools/northstar_conv.py 20 ($TAG): north-star conv only"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ns_fetch -- python tools/northstar_conv.py 10 > $OUT/ns_fetch.log 2>&1
