@@ -52,9 +52,9 @@ def parse():
     ap.add_argument('--no-adv', action='store_true', help='lambda_adv_s = 0 (the shipped config.yaml)')
     ap.add_argument('--drop', action='store_true', help='missing-modality batches (BASELINE configs[3])')
     ap.add_argument('--recon-y', action='store_true', help="lambda_recon_y = 1: adds the 'U+SA' output decoder + segmentation loss (not the headline config)")
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                    help="compute dtype of the convolutions: f32 (headline, exact fp32 MFMA) or bf16 (BASELINE configs[2], stage 1: bf16 MFMA operands, "
-                         "fp32 accumulate, fp32 activations in HBM)")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16m'],
+                    help="f32 (headline: exact fp32 MFMA, fp32 activations) | bf16 (BASELINE configs[2]: bf16 activations in HBM, bf16 MFMA operands, "
+                         "fp32 accumulate / statistics / master weights / optimizer) | bf16m (bf16 MFMA operands on fp32 activations)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
@@ -264,7 +264,8 @@ def main():
             'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
             'value': round(value, 3), 'unit': 'slices/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if a.dtype == 'f32' else 'bf16 MFMA operands / f32 accumulate / f32 storage', 'data': 'synthetic',
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 (bf16 activations + MFMA operands, f32 accumulate / statistics / master weights)',
+                      'bf16m': 'bf16 MFMA operands / f32 accumulate / f32 storage'}[a.dtype], 'data': 'synthetic',
             'config': {'workload': f'BraTS-shaped {M}-modality {a.slice}x{a.slice} fp32 slices '
                                    f'({"zero-padded with background to" if a.fit == "pad" else "centre-cropped to"} {H}x{W}), '
                                    f'batch {B}/GPU, full train step (fwd, recon_x+recon_x_mix+latent_z+sim_s+sim_z'

@@ -108,22 +108,31 @@ int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* 
  *                      [T][Co][Ci], data gradient w_bf16_tck = bf16 [T][Ci][Co].  Geometries the bf16 kernel does not
  *                      cover (reduction axis not a multiple of 16, fewer than 16 output channels) and a NULL bf16 filter
  *                      run the fp32 kernels: the result is then exact fp32;
- *   MRDIS_DT_BF16      bf16 activations in HBM: not built, MRDIS_EUNSUPPORTED.                                       */
+ *   MRDIS_DT_BF16      bf16 activations in HBM (x, y, dy, dx are bf16 views, ld in bf16 elements), bf16 MFMA operands, fp32
+ *                      accumulate; bias, filters' master copy, weight / bias gradients and all statistics stay fp32.
+ *                      Convolutions: the geometries of the bf16 kernels only (reduction axis % 16 == 0, at least 16 output
+ *                      channels, % 4) -- others return MRDIS_EUNSUPPORTED and the caller casts the view (mrdis_cast_view)
+ *                      around the fp32 kernel.  The norm / resize / activation entry points take either storage type
+ *                      through their own `dtype` argument (arithmetic is fp32 inside).                               */
 #define MRDIS_DT_F32        0
 #define MRDIS_DT_F32_BF16M  1
 #define MRDIS_DT_BF16       2
-int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
-                     float* y, int ldy, int N, int H, int W, int Ci, int Co,
+int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
+                     void* y, int ldy, int N, int H, int W, int Ci, int Co,
                      int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream);
 
 /* data gradient (autograd convolution_backward, input part).
  * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
-int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
-                          float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+int mrdis_conv2d_bwd_data(const void* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
+                          void* dx, int lddx, int N, int H, int W, int Ci, int Co,
                           int kh, int kw, int stride, int pad, int dtype, void* stream);
 
 /* fp32 -> bf16, round to nearest even (the bf16 filter copies above); src 16-byte, dst 8-byte aligned. */
 int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+/* NHWC view cast between the storage types (P rows of C channels, ld in ELEMENTS of the respective type): the boundary
+ * between bf16 activations and the fp32-only kernels.  One of src_dtype / dst_dtype is MRDIS_DT_BF16, the other fp32.  */
+int mrdis_cast_view(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst, int dst_dtype,
+                    long long P, int C, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.
@@ -133,55 +142,55 @@ size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
 /* accumulate_bias != 0: dbias += column sums of dy (instead of =), e.g. straight into the parameter's gradient.
  * dtype MRDIS_DT_F32_BF16M: x and dy are rounded to bf16 on their way into LDS and multiplied on bf16 MFMA with fp32
  * accumulation (stride-1 "same" layers with Ci % 32 == 0; others run the fp32 kernels); dbias stays an fp32 sum.       */
-int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
+int mrdis_conv2d_bwd_weight(const void* x, int ldx, const void* dy, int lddy,
                             float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                             int N, int H, int W, int Ci, int Co,
                             int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream);
 
 /* ---- LeakyReLU backward (model.py:2227/2240, 2375-2394): dx = dy * (y>0 ? 1 : slope),
  * y being the activation OUTPUT (sign-preserving for slope > 0).              */
-int mrdis_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
-                    long long P, int C, float slope, void* stream);
+int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
+                    long long P, int C, float slope, int dtype, void* stream);
 
 /* ---- BatchNorm2d, training mode: model.py:2132/2151, 2179/2191, 2776-2785 --
  * x view (P = N*H*W rows, C) ; writes y view, save_mean/save_rstd (C) and
  * updates running_mean/var (momentum 0.1, unbiased var) when non-NULL.
  * workspace: mrdis_norm_workspace(1, P, C) bytes.                             */
 size_t mrdis_norm_workspace(int groups, long long P, int C);
-int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma,
+int mrdis_bn_train_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma,
                        const float* beta, float* running_mean, float* running_var,
                        float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                       long long P, int C, float eps, float momentum, void* stream);
+                       long long P, int C, float eps, float momentum, int dtype, void* stream);
 /* inference mode (model.eval(), main_missing.py:338): y = (x - running_mean) * rsqrt(running_var + eps) * gamma + beta */
-int mrdis_bn_eval_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
-                      const float* running_mean, const float* running_var, long long P, int C, float eps, void* stream);
+int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, long long P, int C, float eps, int dtype, void* stream);
 /* acc_dgamma / acc_dbeta (both or neither): running parameter-gradient sums this call's dgamma / dbeta are
  * added to in the same launch (a module called several times per step needs no separate accumulation).   */
-int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
-                       const float* save_mean, const float* save_rstd, float* dx, int lddx,
+int mrdis_bn_train_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma,
+                       const float* save_mean, const float* save_rstd, void* dx, int lddx,
                        float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
-                       void* workspace, size_t workspace_bytes, long long P, int C, void* stream);
+                       void* workspace, size_t workspace_bytes, long long P, int C, int dtype, void* stream);
 
 /* ---- InstanceNorm2d(affine=False) fused with the SPADE modulation:
  * model.py:2431/2440 + 2446:  out = IN(z) * (1 + gamma) + beta ---------------
  * z, gamma, beta, out : (N, HW, C) views ; save_mean/save_rstd : (N*C).       */
-int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* gamma, int ldg,
-                             const float* beta, int ldb, float* out, int ldo,
+int mrdis_instnorm_spade_fwd(const void* z, int ldz, const void* gamma, int ldg,
+                             const void* beta, int ldb, void* out, int ldo,
                              float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                             int N, long long HW, int C, float eps, void* stream);
+                             int N, long long HW, int C, float eps, int dtype, void* stream);
 size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C);
-int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float* z, int ldz,
-                             const float* gamma, int ldg, const float* save_mean, const float* save_rstd,
-                             float* dz, int lddz, float* dgamma, int lddg, float* dbeta, int lddb,
+int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz,
+                             const void* gamma, int ldg, const float* save_mean, const float* save_rstd,
+                             void* dz, int lddz, void* dgamma, int lddg, void* dbeta, int lddb,
                              void* workspace, size_t workspace_bytes,
-                             int N, long long HW, int C, void* stream);
+                             int N, long long HW, int C, int dtype, void* stream);
 
 /* ---- bilinear resize: nn.Upsample at model.py:2175 (align_corners=True),
  * 2432 / 2501-2509 (align_corners=False, arbitrary output size) --------------*/
-int mrdis_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi,
-                       int Ho, int Wo, int C, int align_corners, void* stream);
-int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
-                       int Ho, int Wo, int C, int align_corners, void* stream);
+int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi,
+                       int Ho, int Wo, int C, int align_corners, int dtype, void* stream);
+int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi,
+                       int Ho, int Wo, int C, int align_corners, int dtype, void* stream);
 
 /* ---- softmax over [100*mask_img, s] with channel 0 dropped: model.py:3150-3153
  * s view (P, C) ; mask_img (P) ; out view (P, C).                             */

@@ -32,8 +32,32 @@ __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
     return r;
 }
 
-// KC channels per chunk; 4 waves as WAVES_C (cout) x 4/WAVES_C (positions); a wave owns WP x WC blocks of 32 positions x 32 couts
-template <int KC, int WAVES_C, int WP, int WC>
+// 8 consecutive channels of one pixel in flight between global memory and LDS: two float4 (fp32 storage, converted when
+// they are written to LDS) or one 16-byte bf16x8 (bf16 storage)
+template <typename TS> struct Piece8;
+template <> struct Piece8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ bf16x8 bf() const { return cvt8(a, b); }
+    __device__ __forceinline__ void add_to(float* s) const { s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w; }
+};
+template <> struct Piece8<__bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void zero() { for (int k = 0; k < 8; ++k) v[k] = (__bf16)0.f; }
+    __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ bf16x8 bf() const { return v; }
+    __device__ __forceinline__ void add_to(float* s) const { for (int k = 0; k < 8; ++k) s[k] += (float)v[k]; }
+};
+__device__ __forceinline__ void store4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(__bf16* p, const float4 v) {
+    bf16x4 r; r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// KC channels per chunk; 4 waves as WAVES_C (cout) x 4/WAVES_C (positions); a wave owns WP x WC blocks of 32 positions x 32 couts;
+// TS = storage type of the activations (float: MRDIS_DT_F32_BF16M, __bf16: MRDIS_DT_BF16)
+template <int KC, int WAVES_C, int WP, int WC, typename TS>
 __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
     constexpr int BN = 32 * WC * WAVES_C;          // x 32 * WP * WAVES_P positions
     constexpr int PITCH = KC + 8;                 // bf16 elements per LDS row
@@ -88,8 +112,10 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
     }
     const __bf16* wsrc = reinterpret_cast<const __bf16*>(p.w_bf16);
 
-    float4 xr[XR][2];
+    Piece8<TS> xr[XR];
     bf16x8 wr[WR];
+    const TS* in = reinterpret_cast<const TS*>(p.in);
+    TS* outp = reinterpret_cast<TS*>(p.out);
     auto tile_origin = [&](int tile, int& n0, int& a0, int& b0) {
         const int tb = tile % p.tilesB; tile /= p.tilesB;
         const int ta = tile % p.tilesA;
@@ -100,14 +126,11 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
         const int h_org = a0 * p.is + p.dh_min, w_org = b0 * p.is + p.dw_min, c0 = chunk * KC;
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
-            xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
+            xr[it].zero();
             if (x_desc[it] >= 0) {
                 const int n = n0 + (x_desc[it] >> 16), h = h_org + ((x_desc[it] >> 8) & 255), w_ = w_org + (x_desc[it] & 255);
-                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win) {
-                    const float* src = p.in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c0 + 8 * ((tid + it * 256) % QX);
-                    xr[it][0] = *reinterpret_cast<const float4*>(src);
-                    xr[it][1] = *reinterpret_cast<const float4*>(src + 4);
-                }
+                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                    xr[it].load(in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c0 + 8 * ((tid + it * 256) % QX));
             }
         }
         if (want_w) {
@@ -123,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             const int idx = tid + it * 256;
-            if (idx < nx) *reinterpret_cast<bf16x8*>(xs + (idx / QX) * PITCH + 8 * (idx % QX)) = cvt8(xr[it][0], xr[it][1]);
+            if (idx < nx) *reinterpret_cast<bf16x8*>(xs + (idx / QX) * PITCH + 8 * (idx % QX)) = xr[it].bf();
         }
         if (have_w) {
 #pragma unroll
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
                 if (pos_nb[i] < 0) continue;
                 const int n = n0 + pos_nb[i], a = a0 + pos_ty[i], b = b0 + pos_tx[i];
                 if (n >= p.N || a >= p.A || b >= p.B) continue;
-                float* dst = p.out + ((long long)(n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0) * p.ldout;
+                TS* dst = outp + ((long long)(n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0) * p.ldout;
 #pragma unroll
                 for (int j = 0; j < WC; ++j)
 #pragma unroll
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
                         float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
                         if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + co); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
                         if (lrelu) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
-                        *reinterpret_cast<float4*>(dst + co) = v;
+                        store4(dst + co, v);
                     }
             }
         }
@@ -202,17 +225,22 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
     }
 }
 
-template <int KC, int WAVES_C, int WP, int WC>
-static int launch_bconv(const TapConvParams& p, const BConvGeom& g, int grid, size_t lds, hipStream_t s) {
+template <int KC, int WAVES_C, int WP, int WC, typename TS>
+static int launch_bconv_t(const TapConvParams& p, const BConvGeom& g, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)bconv_kernel<KC, WAVES_C, WP, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)bconv_kernel<KC, WAVES_C, WP, WC, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC>), dim3(grid), dim3(256), lds, s, p, g);
+    hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC, TS>), dim3(grid), dim3(256), lds, s, p, g);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
+}
+template <int KC, int WAVES_C, int WP, int WC>
+static int launch_bconv(const TapConvParams& p, const BConvGeom& g, int grid, size_t lds, hipStream_t s) {
+    return p.dtype == MRDIS_DT_BF16 ? launch_bconv_t<KC, WAVES_C, WP, WC, __bf16>(p, g, grid, lds, s)
+                                    : launch_bconv_t<KC, WAVES_C, WP, WC, float>(p, g, grid, lds, s);
 }
 
 static int bconv_ncu() {
@@ -226,9 +254,12 @@ static int bconv_ncu() {
 
 // Eligibility: reduction axis a multiple of 16, 16-byte aligned views, cout a multiple of 4 (16-byte stores).
 int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
-    if (!p.w_bf16 || p.dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
+    if (!p.w_bf16 || (p.dtype != MRDIS_DT_F32_BF16M && p.dtype != MRDIS_DT_BF16)) return MRDIS_EUNSUPPORTED;
+    const bool st_bf16 = p.dtype == MRDIS_DT_BF16;
     if (p.Cin % 16 != 0 || p.Cout % 4 != 0 || p.Cout < 16 || (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
-    if (p.ldin % 4 != 0 || p.ldout % 4 != 0 || (((uintptr_t)p.in | (uintptr_t)p.out | (uintptr_t)p.w_bf16) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    // 16-byte input pieces (8 bf16 or 2 x 4 fp32), 4-channel output stores
+    if (p.ldin % (st_bf16 ? 8 : 4) != 0 || p.ldout % 4 != 0 || (((uintptr_t)p.in | (uintptr_t)p.w_bf16) & 15) != 0 ||
+        ((uintptr_t)p.out & (st_bf16 ? 7 : 15)) != 0) return MRDIS_EUNSUPPORTED;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return MRDIS_EUNSUPPORTED;
     // tile shape by cout width: (WAVES_C, WP, WC) -> BM x BN
     struct Cfg { int waves_c, wp, wc; };
@@ -310,7 +341,7 @@ extern "C" int mrdis_cast_bf16(const float* src, void* dst, long long n, void* s
 // its partial; the waves of a channel block add theirs through LDS in a fixed order and the workgroup writes one slab
 // [split][T][Ci][Co]; a fixed-order reduction kernel sums the slabs (bit-reproducible).
 struct BWgradParams {
-    const float* x; const float* dy; float* slab; float* bias_slab;
+    const void* x; const void* dy; float* slab; float* bias_slab;      // x, dy: fp32 or bf16 views (kernel template)
     int N, H, W, Ci, Co, ldx, lddy;
     int ntaps, dh[9], dw[9];
     int NB, TH, TW, lgTH, lgTW, TinH, TinW;         // TH, TW powers of two, NB * TH * TW = 128
@@ -321,7 +352,7 @@ struct BWgradParams {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int WCI, int WCO>
+template <int WCI, int WCO, typename TS>
 __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
     constexpr int KS = 8 / (WCI * WCO);            // waves sharing a channel block split the position steps
     constexpr int CIW = 32 * WCI, COW = 32 * WCO;
@@ -355,7 +386,9 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
             x_desc[it] = (nb << 16) | (iy << 8) | ix;
         }
     }
-    float4 xr[XR][2], yr[YR][2];
+    Piece8<TS> xr[XR], yr[YR];
+    const TS* xin = reinterpret_cast<const TS*>(p.x);
+    const TS* dyin = reinterpret_cast<const TS*>(p.dy);
     float bsum[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
@@ -368,14 +401,11 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
         int n0, a0, b0; tile_origin(tile, n0, a0, b0);
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
-            xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
+            xr[it].zero();
             if (x_desc[it] >= 0) {
                 const int n = n0 + (x_desc[it] >> 16), h = a0 + p.dh_min + ((x_desc[it] >> 8) & 255), w_ = b0 + p.dw_min + (x_desc[it] & 255);
-                if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W) {
-                    const float* src = p.x + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + ci0 + 8 * ((tid + it * 512) % XQ);
-                    xr[it][0] = *reinterpret_cast<const float4*>(src);
-                    xr[it][1] = *reinterpret_cast<const float4*>(src + 4);
-                }
+                if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                    xr[it].load(xin + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + ci0 + 8 * ((tid + it * 512) % XQ));
             }
         }
 #pragma unroll
@@ -384,12 +414,8 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
             const int m = idx / YQ, c = co0 + 8 * (idx % YQ);
             const int tx = m & (p.TW - 1), ty = (m >> p.lgTW) & (p.TH - 1), nb = m >> (p.lgTW + p.lgTH);
             const int n = n0 + nb, a = a0 + ty, b = b0 + tx;
-            yr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); yr[it][1] = yr[it][0];
-            if (n < p.N && a < p.H && b < p.W && c < p.Co) {
-                const float* src = p.dy + ((long long)(n * p.H + a) * p.W + b) * p.lddy + c;
-                yr[it][0] = *reinterpret_cast<const float4*>(src);
-                yr[it][1] = *reinterpret_cast<const float4*>(src + 4);
-            }
+            yr[it].zero();
+            if (n < p.N && a < p.H && b < p.W && c < p.Co) yr[it].load(dyin + ((long long)(n * p.H + a) * p.W + b) * p.lddy + c);
         }
     };
     auto store_tile = [&]() {
@@ -398,16 +424,15 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
             const int idx = tid + it * 512;
             if (idx < npix * XQ) {
                 const int pi = idx / XQ, qq = idx % XQ;
-                *reinterpret_cast<bf16x8*>(xs + ((qq >> 2) * npix + pi) * 32 + 8 * (qq & 3)) = cvt8(xr[it][0], xr[it][1]);
+                *reinterpret_cast<bf16x8*>(xs + ((qq >> 2) * npix + pi) * 32 + 8 * (qq & 3)) = xr[it].bf();
             }
         }
 #pragma unroll
         for (int it = 0; it < YR; ++it) {
             const int idx = tid + it * 512;
             const int m = idx / YQ, qq = idx % YQ;
-            *reinterpret_cast<bf16x8*>(dys + ((qq >> 2) * TP + m) * 32 + 8 * (qq & 3)) = cvt8(yr[it][0], yr[it][1]);
-            bsum[0] += yr[it][0].x; bsum[1] += yr[it][0].y; bsum[2] += yr[it][0].z; bsum[3] += yr[it][0].w;
-            bsum[4] += yr[it][1].x; bsum[5] += yr[it][1].y; bsum[6] += yr[it][1].z; bsum[7] += yr[it][1].w;
+            *reinterpret_cast<bf16x8*>(dys + ((qq >> 2) * TP + m) * 32 + 8 * (qq & 3)) = yr[it].bf();
+            yr[it].add_to(bsum);
         }
     };
 
@@ -561,23 +586,25 @@ size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int k
     return sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
 }
 
-int mrdis_run_bwgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s) {
+int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, hipStream_t s) {
+    const bool st_bf16 = dtype == MRDIS_DT_BF16;
     BWgradPlan pl;
     int rc = plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
-    if (ldx % 4 != 0 || lddy % 4 != 0 || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (ldx % (st_bf16 ? 8 : 4) != 0 || lddy % (st_bf16 ? 8 : 4) != 0 || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256) return MRDIS_EWORKSPACE;
     BWgradParams& p = pl.p;
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
     const int grid = p.splits * p.nCiB * p.nCoB;
-#define BW_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
+#define BW_CASE(a, b_, TS) if (pl.wci == a && pl.wco == b_) { \
         static bool attr_set = false; \
-        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
-        hipLaunchKernelGGL((bwgrad_kernel<a, b_>), dim3(grid), dim3(512), pl.lds, s, p); }
-    BW_CASE(1, 1) else BW_CASE(1, 2) else BW_CASE(2, 1) else BW_CASE(2, 2)
+        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
+        hipLaunchKernelGGL((bwgrad_kernel<a, b_, TS>), dim3(grid), dim3(512), pl.lds, s, p); }
+    if (st_bf16) { BW_CASE(1, 1, __bf16) else BW_CASE(1, 2, __bf16) else BW_CASE(2, 1, __bf16) else BW_CASE(2, 2, __bf16) }
+    else { BW_CASE(1, 1, float) else BW_CASE(1, 2, float) else BW_CASE(2, 1, float) else BW_CASE(2, 2, float) }
 #undef BW_CASE
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)p.ntaps * Ci * Co;

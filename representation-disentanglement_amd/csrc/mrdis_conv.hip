@@ -631,10 +631,11 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
         if (p.dw[t] < p.dw_min) p.dw_min = p.dw[t];
         if (p.dw[t] > dw_max) dw_max = p.dw[t];
     }
-    if (p.dtype == MRDIS_DT_F32_BF16M && p.w_bf16) {          // bf16 MFMA operands (mrdis_bf16.hip) where the geometry allows
+    if ((p.dtype == MRDIS_DT_F32_BF16M || p.dtype == MRDIS_DT_BF16) && p.w_bf16) {      // bf16 MFMA operands (mrdis_bf16.hip) where the geometry allows
         const int rc = mrdis_run_bconv(p, dh_max, dw_max, s);
-        if (rc != MRDIS_EUNSUPPORTED) return rc;
+        if (rc != MRDIS_EUNSUPPORTED || p.dtype == MRDIS_DT_BF16) return rc;         // bf16 views never reach the fp32 kernels
     }
+    if (p.dtype == MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
     const TileChoice tc = choose_tile(p.N, p.A, p.B);
     p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
     p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
@@ -1045,20 +1046,23 @@ static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int
 }
 
 static bool bf16m_wanted(int dtype, const void* w_bf16, int Cred, int Cout) {
-    return dtype == MRDIS_DT_F32_BF16M && w_bf16 != nullptr && Cred % 16 == 0 && Cout % 4 == 0 && Cout >= 16;
+    return (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) && w_bf16 != nullptr && Cred % 16 == 0 && Cout % 4 == 0 && Cout >= 16;
 }
 
-extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
-                                float* y, int ldy, int N, int H, int W, int Ci, int Co,
+extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
+                                void* y_, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;       // MRDIS_DT_BF16 storage: not built
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    const float* x = reinterpret_cast<const float*>(x_); float* y = reinterpret_cast<float*>(y_);   // bf16 views when dtype == MRDIS_DT_BF16
+    const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
-    if (c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
+    if (!st_bf16 && c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     const bool bf = bf16m_wanted(dtype, w_bf16_tkc, Ci, Co);
+    if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;                // bf16 views: only the bf16 kernels may touch them
     if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
         rc = mrdis_run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
@@ -1079,10 +1083,12 @@ extern "C" int mrdis_conv2d_fwd(const float* x, int ldx, const float* w_tck, con
     return run_tapconv(p, (hipStream_t)stream);
 }
 
-extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
-                                     float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_tkc, const void* w_bf16_tck,
+                                     void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
                                      int kh, int kw, int stride, int pad, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
+    const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
@@ -1093,11 +1099,12 @@ extern "C" int mrdis_conv2d_bwd_data(const float* dy, int lddy, const float* w_t
     base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
     base.is = 1; base.epilogue = 0;
     const bool bf = bf16m_wanted(dtype, w_bf16_tck, Co, Ci);      // the data gradient reduces over Co and produces Ci channels
+    if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;
     base.w_bf16 = bf ? w_bf16_tck : nullptr; base.dtype = dtype;
     if (stride == 1) {
         // dx of a Ci <- 4 layer (ana_dec.output): a 4 -> Ci convolution of dy with the taps reversed; [tap][Co=4][Ci] is
         // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
-        if (c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
+        if (!st_bf16 && c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
             rc = mrdis_run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
@@ -2103,8 +2110,8 @@ static bool wino_wgrad_wanted(int N, int H, int W, int Ci, int Co, int kh, int k
 
 // mrdis_bf16.hip: weight gradient on bf16 MFMA operands (stride-1 "same" convolutions, Ci % 32 == 0)
 size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);
-int mrdis_run_bwgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
+int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                     int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, hipStream_t s);
 
 extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci, int Co,
                                                     int kh, int kw, int stride, int pad) {
@@ -2143,21 +2150,22 @@ static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
     return MRDIS_OK;
 }
 
-extern "C" int mrdis_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy,
+extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_, int lddy,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
                                        int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    const float* x = reinterpret_cast<const float*>(x_); const float* dy = reinterpret_cast<const float*>(dy_);
     WgradPlan pl;
     int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
     if (rc) return rc;
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
     if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
-    if (dtype == MRDIS_DT_F32_BF16M) {
-        rc = mrdis_run_bwgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              accumulate_bias, (hipStream_t)stream);
-        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    if (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) {
+        rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
+                              accumulate_bias, dtype, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED || dtype == MRDIS_DT_BF16) return rc;          // bf16 views never reach the fp32 kernels
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
         rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);

@@ -9,11 +9,16 @@
 #include <string.h>
 
 // ------------------------------------------------------------------ small vector helper
+// Activations are stored as fp32 or bf16 (MRDIS_DT_BF16: BASELINE.json configs[2]); the arithmetic is fp32 either way:
+// a kernel is templated on the storage type T and converts on load / store (bf16 stores round to nearest even).
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 template <int V> struct Vec;
 template <> struct Vec<1> {
     float v[1];
     __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
     __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+    __device__ __forceinline__ void load(const __bf16* p) { v[0] = (float)p[0]; }
+    __device__ __forceinline__ void store(__bf16* p) const { p[0] = (__bf16)v[0]; }
 };
 template <> struct Vec<4> {
     float v[4];
@@ -21,9 +26,27 @@ template <> struct Vec<4> {
         const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ __forceinline__ void load(const __bf16* p) {
+        const bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p); v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    __device__ __forceinline__ void store(__bf16* p) const {
+        bf16x4_t t; t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4_t*>(p) = t;
+    }
 };
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
 
-static inline bool vec4_ok(const void* p, int ld, int C) { return (C % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)p & 15) == 0); }
+template <typename T>
+static inline bool vec4_ok(const T* p, int ld, int C) { return (C % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)p & (4 * sizeof(T) - 1)) == 0); }
+// dtype of the activation views of an entry point: fp32 (MRDIS_DT_F32 and MRDIS_DT_F32_BF16M store fp32) or bf16
+#define MRDIS_BY_DTYPE(dtype, CALL_F32, CALL_BF16) \
+    ((dtype) == MRDIS_DT_BF16 ? (CALL_BF16) : (((dtype) == MRDIS_DT_F32 || (dtype) == MRDIS_DT_F32_BF16M) ? (CALL_F32) : MRDIS_EUNSUPPORTED))
 static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 
 #define EW_LOOP(total) for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (total); idx += (long long)gridDim.x * blockDim.x)
@@ -45,9 +68,9 @@ extern "C" size_t mrdis_norm_workspace(int groups, long long P, int C) {
 // MODE 0: (sum x, sum x^2)            a = x
 // MODE 1: (sum dy, sum dy*xhat)       a = dy, b = x, stats (mean,rstd) per (group? no: per channel) -> BN bwd
 // MODE 2: (sum dzh, sum dzh*zhat)     a = dout, b = z, c = gamma ; dzh = dout*(1+gamma)  -> SPADE/IN bwd
-template <int MODE>
-__global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
-                                    const float* __restrict__ g, int ldg, const float* __restrict__ mean,
+template <int MODE, typename T>
+__global__ void stat_partial_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
+                                    const T* __restrict__ g, int ldg, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, int stat_per_group,
                                     long long P, int C, int rpb, float* __restrict__ part) {
     __shared__ float red[2][4][64];
@@ -68,9 +91,9 @@ __global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const 
             if (MODE != 0) { const int si = stat_per_group ? grp * C + c : c; mu = mean[si]; rs = rstd[si]; }
             for (long long r = r0 + threadIdx.y * rpx + sub; r < r1; r += 4 * rpx) {
                 const long long row = gbase + r;
-                if (MODE == 0) { const float x = a[row * lda + c]; s0 += x; s1 += x * x; }
-                else if (MODE == 1) { const float d = a[row * lda + c]; const float xh = (b[row * ldb + c] - mu) * rs; s0 += d; s1 += d * xh; }
-                else { const float d = a[row * lda + c] * (1.f + g[row * ldg + c]); const float zh = (b[row * ldb + c] - mu) * rs; s0 += d; s1 += d * zh; }
+                if (MODE == 0) { const float x = ld1(a + row * lda + c); s0 += x; s1 += x * x; }
+                else if (MODE == 1) { const float d = ld1(a + row * lda + c); const float xh = (ld1(b + row * ldb + c) - mu) * rs; s0 += d; s1 += d * xh; }
+                else { const float d = ld1(a + row * lda + c) * (1.f + ld1(g + row * ldg + c)); const float zh = (ld1(b + row * ldb + c) - mu) * rs; s0 += d; s1 += d * zh; }
             }
         }
         red[0][threadIdx.y][threadIdx.x] = s0; red[1][threadIdx.y][threadIdx.x] = s1;
@@ -90,9 +113,9 @@ __global__ void stat_partial_kernel(const float* __restrict__ a, int lda, const 
 // and walks rows with float4 loads, `rows_pp` = 256 / (C/4) rows per pass of the block, 4 rows in flight per
 // thread.  The scalar kernel keeps 4 bytes per lane in flight and reached 1.9 TB/s on the 268 MB maps; the
 // statistics passes are pure streaming reads.  Block reduction in LDS, fixed order.
-template <int MODE>
-__global__ __launch_bounds__(256) void stat_partial_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
-                                                               const float* __restrict__ g, int ldg, const float* __restrict__ mean,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void stat_partial_vec_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
+                                                               const T* __restrict__ g, int ldg, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int stat_per_group,
                                                                long long P, int C, int rpb, float* __restrict__ part) {
     __shared__ float red[256][9];                      // [thread][8 sums], padded
@@ -118,16 +141,16 @@ __global__ __launch_bounds__(256) void stat_partial_vec_kernel(const float* __re
             }
             auto one = [&](long long r) {
                 const long long row = gbase + r;
-                const float4 av = *reinterpret_cast<const float4*>(a + row * lda + c);
+                const float4 av = ld4(a + row * lda + c);
                 const float aa[4] = {av.x, av.y, av.z, av.w};
                 if (MODE == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { s0[k] += aa[k]; s1[k] += aa[k] * aa[k]; }
                 } else {
-                    const float4 bv = *reinterpret_cast<const float4*>(b + row * ldb + c);
+                    const float4 bv = ld4(b + row * ldb + c);
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
                     float gg[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == 2) { const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + c); gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w; }
+                    if (MODE == 2) { const float4 gv = ld4(g + row * ldg + c); gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w; }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float d = (MODE == 2) ? aa[k] * (1.f + gg[k]) : aa[k];
@@ -203,25 +226,25 @@ __global__ void stat_final_kernel(const float* __restrict__ part, int chunks, in
 
 static int stat_final_lanes(int chunks) { int y = 4; while (y < 16 && y * 8 < chunks) y <<= 1; return y; }
 
-template <int MODE>
-static int launch_stats(const float* a, int lda, const float* b, int ldb, const float* g, int ldg, const float* mean,
+template <int MODE, typename T>
+static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, int ldg, const float* mean,
                         const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s) {
     const StatPlan sp = stat_plan(groups, P);
     const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || vec4_ok(b, ldb, C)) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
                      ((C >> 2) >= 256 ? (C >> 2) % 256 == 0 : 256 % (C >> 2) == 0);
     if (vec)
-        hipLaunchKernelGGL((stat_partial_vec_kernel<MODE>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+        hipLaunchKernelGGL((stat_partial_vec_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                            stat_per_group, P, C, sp.rpb, part);
     else
-    hipLaunchKernelGGL((stat_partial_kernel<MODE>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+    hipLaunchKernelGGL((stat_partial_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                        stat_per_group, P, C, sp.rpb, part);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 // ------------------------------------------------------------------ BatchNorm (training)
-template <int V>
-__global__ void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+template <int V, typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
                                 long long P, int C) {
     const int Q = C / V;
@@ -237,7 +260,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int ldx, float* __r
     }
 }
 
-extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma,
+template <typename T>
+static int bn_train_fwd_impl(const T* x, int ldx, T* y, int ldy, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var,
                                   float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                                   long long P, int C, float eps, float momentum, void* stream) {
@@ -245,23 +269,23 @@ extern "C" int mrdis_bn_train_fwd(const float* x, int ldx, float* y, int ldy, co
     if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<0>(x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
+    int rc = launch_stats<0, T>(x, ldx, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
                        save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+        hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+        hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 // inference-mode BatchNorm (evaluate(), main_missing.py:338): per-channel affine from the running statistics
-template <int V>
-__global__ void bn_eval_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, const float* __restrict__ gamma,
+template <int V, typename T>
+__global__ void bn_eval_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ rmean, const float* __restrict__ rvar,
                                float eps, long long P, int C) {
     const int Q = C / V;
@@ -276,22 +300,23 @@ __global__ void bn_eval_kernel(const float* __restrict__ x, int ldx, float* __re
         o.store(y + r * ldy + c);
     }
 }
-extern "C" int mrdis_bn_eval_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+template <typename T>
+static int bn_eval_fwd_impl(const T* x, int ldx, T* y, int ldy, const float* gamma, const float* beta,
                                  const float* running_mean, const float* running_var, long long P, int C, float eps, void* stream) {
     if (!x || !y || !running_mean || !running_var || P < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bn_eval_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+        hipLaunchKernelGGL((bn_eval_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
     else
-        hipLaunchKernelGGL((bn_eval_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+        hipLaunchKernelGGL((bn_eval_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-template <int V>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+template <int V, typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ sdy, const float* __restrict__ sdyxh, float* __restrict__ dx, int lddx,
+                                    const float* __restrict__ sdy, const float* __restrict__ sdyxh, T* __restrict__ dx, int lddx,
                                     long long P, int C, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
     const int Q = C / V;
     const float invP = 1.f / (float)P;
@@ -310,8 +335,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, cons
     }
 }
 
-extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma,
-                                  const float* save_mean, const float* save_rstd, float* dx, int lddx,
+template <typename T>
+static int bn_train_bwd_impl(const T* dy, int lddy, const T* x, int ldx, const float* gamma,
+                                  const float* save_mean, const float* save_rstd, T* dx, int lddx,
                                   float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
                                   void* workspace, size_t workspace_bytes, long long P, int C, void* stream) {
     if (!dy || !x || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || P < 1 || C < 1) return MRDIS_EINVAL;
@@ -319,7 +345,7 @@ extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int
     if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<1>(dy, lddy, x, ldx, nullptr, 0, save_mean, save_rstd, 0, 1, P, C, part, s);
+    int rc = launch_stats<1, T>(dy, lddy, x, ldx, (const T*)nullptr, 0, save_mean, save_rstd, 0, 1, P, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     // dbeta = sum dy ; dgamma = sum dy * xhat
@@ -327,17 +353,17 @@ extern "C" int mrdis_bn_train_bwd(const float* dy, int lddy, const float* x, int
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 // ------------------------------------------------------------------ InstanceNorm + SPADE modulation
-template <int V>
-__global__ void spade_fwd_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg, const float* __restrict__ b, int ldb,
-                                 float* __restrict__ out, int ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
+template <int V, typename T>
+__global__ void spade_fwd_kernel(const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg, const T* __restrict__ b, int ldb,
+                                 T* __restrict__ out, int ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
                                  long long HW, long long rows, int C) {
     const int Q = C / V;
     EW_LOOP(rows * Q) {
@@ -353,15 +379,16 @@ __global__ void spade_fwd_kernel(const float* __restrict__ z, int ldz, const flo
     }
 }
 
-extern "C" int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* gamma, int ldg,
-                                        const float* beta, int ldb, float* out, int ldo,
+template <typename T>
+static int instnorm_spade_fwd_impl(const T* z, int ldz, const T* gamma, int ldg,
+                                        const T* beta, int ldb, T* out, int ldo,
                                         float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                                         int N, long long HW, int C, float eps, void* stream) {
     if (!z || !gamma || !beta || !out || !save_mean || !save_rstd || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
     if (workspace_bytes < mrdis_norm_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<0>(z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
+    int rc = launch_stats<0, T>(z, ldz, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
     hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
@@ -369,18 +396,18 @@ extern "C" int mrdis_instnorm_spade_fwd(const float* z, int ldz, const float* ga
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
     if (vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(beta, ldb, C) && vec4_ok(out, ldo, C))
-        hipLaunchKernelGGL((spade_fwd_kernel<4>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+        hipLaunchKernelGGL((spade_fwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
     else
-        hipLaunchKernelGGL((spade_fwd_kernel<1>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+        hipLaunchKernelGGL((spade_fwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-template <int V>
-__global__ void spade_bwd_kernel(const float* __restrict__ dout, int lddo, const float* __restrict__ z, int ldz, const float* __restrict__ g, int ldg,
+template <int V, typename T>
+__global__ void spade_bwd_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
                                  const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
-                                 const float* __restrict__ s1, float* __restrict__ dz, int lddz, float* __restrict__ dgm, int lddg,
-                                 float* __restrict__ dbt, int lddb, long long HW, long long rows, int C) {
+                                 const float* __restrict__ s1, T* __restrict__ dz, int lddz, T* __restrict__ dgm, int lddg,
+                                 T* __restrict__ dbt, int lddb, long long HW, long long rows, int C) {
     const int Q = C / V;
     const float inv = 1.f / (float)HW;
     EW_LOOP(rows * Q) {
@@ -401,9 +428,10 @@ __global__ void spade_bwd_kernel(const float* __restrict__ dout, int lddo, const
     }
 }
 
-extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float* z, int ldz,
-                                        const float* gamma, int ldg, const float* save_mean, const float* save_rstd,
-                                        float* dz, int lddz, float* dgamma, int lddg, float* dbeta, int lddb,
+template <typename T>
+static int instnorm_spade_bwd_impl(const T* dout, int lddo, const T* z, int ldz,
+                                        const T* gamma, int ldg, const float* save_mean, const float* save_rstd,
+                                        T* dz, int lddz, T* dgamma, int lddg, T* dbeta, int lddb,
                                         void* workspace, size_t workspace_bytes,
                                         int N, long long HW, int C, void* stream) {
     if (!dout || !z || !gamma || !save_mean || !save_rstd || !dz || !dgamma || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
@@ -415,7 +443,7 @@ extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float
     float* part = reinterpret_cast<float*>(workspace);
     float* s0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
     float* s1 = s0 + (size_t)N * C;
-    int rc = launch_stats<2>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
+    int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
     hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
@@ -424,9 +452,9 @@ extern "C" int mrdis_instnorm_spade_bwd(const float* dout, int lddo, const float
     const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dz, lddz, C) &&
                    vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
     if (v)
-        hipLaunchKernelGGL((spade_bwd_kernel<4>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+        hipLaunchKernelGGL((spade_bwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
     else
-        hipLaunchKernelGGL((spade_bwd_kernel<1>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+        hipLaunchKernelGGL((spade_bwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -435,8 +463,8 @@ extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C)
 }
 
 // ------------------------------------------------------------------ LeakyReLU backward
-template <int V>
-__global__ void lrelu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, float* __restrict__ dx, int lddx,
+template <int V, typename T>
+__global__ void lrelu_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy, T* __restrict__ dx, int lddx,
                                  long long P, int C, float slope) {
     const int Q = C / V;
     EW_LOOP(P * Q) {
@@ -447,14 +475,15 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dy, int lddy, const f
         o.store(dx + r * lddx + c);
     }
 }
-extern "C" int mrdis_lrelu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
+template <typename T>
+static int lrelu_bwd_impl(const T* dy, int lddy, const T* y, int ldy, T* dx, int lddx,
                                long long P, int C, float slope, void* stream) {
     if (!dy || !y || !dx || P < 1 || C < 1) return MRDIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (vec4_ok(dy, lddy, C) && vec4_ok(y, ldy, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((lrelu_bwd_kernel<4>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+        hipLaunchKernelGGL((lrelu_bwd_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
     else
-        hipLaunchKernelGGL((lrelu_bwd_kernel<1>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+        hipLaunchKernelGGL((lrelu_bwd_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -479,15 +508,15 @@ static inline float bil_scale(int isz, int osz, int align) {
 
 // grid (Ho, N): one output row per workgroup, so the row's vertical stencil is wave-uniform and a thread only
 // splits a 32-bit in-row index (the flat-index version spent its time in 64-bit divisions: 1.6 TB/s).
-template <int V>
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N, int Hi, int Wi, int Ho, int Wo,
+template <int V, typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int Hi, int Wi, int Ho, int Wo,
                                     int C, int align, float sh, float sw) {
     const int Q = C / V;
     const int ho = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;   // XCD-aware: neighbouring output rows read the same two input rows -> same L2
     const BilAxis ah = bil_axis(ho, sh, align, Hi);
-    const float* r0 = x + ((long long)n * Hi + ah.i0) * Wi * ldx;
-    const float* r1 = x + ((long long)n * Hi + ah.i1) * Wi * ldx;
-    float* yo = y + ((long long)n * Ho + ho) * Wo * ldy;
+    const T* r0 = x + ((long long)n * Hi + ah.i0) * Wi * ldx;
+    const T* r1 = x + ((long long)n * Hi + ah.i1) * Wi * ldx;
+    T* yo = y + ((long long)n * Ho + ho) * Wo * ldy;
     const int items = Wo * Q;
     // two items per trip: eight 16-byte loads in flight per thread (the tail item is clamped to the last one and not stored)
     for (int j = threadIdx.x; j < items; j += 2 * blockDim.x) {
@@ -529,15 +558,15 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int osz
 // pixel): for the x2 up-sampling of the decoders the 7x7 candidate window holds only 3x3 non-zero weights and the
 // old loop spent its time re-deriving them.
 #define BIL_MAXR 8
-template <int V>
-__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo,
+template <int V, typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo,
                                     int C, int align, float sh, float sw) {
     const int Q = C / V;
     const int hi = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;   // XCD-aware: neighbouring input rows gather from the same output rows
     int hlo, hhi;
     bil_range(hi, sh, align, Ho, &hlo, &hhi);
-    const float* base = dy + (long long)n * Ho * Wo * lddy;
-    float* dxo = dx + ((long long)n * Hi + hi) * Wi * lddx;
+    const T* base = dy + (long long)n * Ho * Wo * lddy;
+    T* dxo = dx + ((long long)n * Hi + hi) * Wi * lddx;
     const int items = Wi * Q;
     const bool small_h = hhi - hlo < BIL_MAXR;
     float whv[BIL_MAXR];
@@ -573,7 +602,7 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, floa
             for (int a = 0; a < BIL_MAXR; ++a) {
                 const float wh = whv[a];
                 if (wh == 0.f) continue;
-                const float* row = base + (long long)(hlo + a) * Wo * lddy + q * V;
+                const T* row = base + (long long)(hlo + a) * Wo * lddy + q * V;
 #pragma unroll
                 for (int b = 0; b < BIL_MAXR; ++b) {
                     const float ww = wwv[b];
@@ -608,8 +637,8 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int lddy, floa
 // each join, so the ~12 useful loads of a thread ran one after the other.  Here the first contributing row / column is
 // found by evaluating weights only (no memory), then NA x NB loads are issued unconditionally (coordinates clamped,
 // weights zero outside the support): same products, same summation order, all loads in flight.
-template <int V, int NA, int NB>
-__global__ void bilinear_bwd_tight_kernel(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N, int Hi, int Wi,
+template <int V, int NA, int NB, typename T>
+__global__ void bilinear_bwd_tight_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int N, int Hi, int Wi,
                                           int Ho, int Wo, int C, int align, float sh, float sw) {
     const int Q = C / V;
     const int hi = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;
@@ -625,8 +654,8 @@ __global__ void bilinear_bwd_tight_kernel(const float* __restrict__ dy, int lddy
         hrow[a] = ho <= Ho - 1 ? ho : Ho - 1;
         whv[a] = ho <= hhi ? wgt_h(ho) : 0.f;
     }
-    const float* base = dy + (long long)n * Ho * Wo * lddy;
-    float* dxo = dx + ((long long)n * Hi + hi) * Wi * lddx;
+    const T* base = dy + (long long)n * Ho * Wo * lddy;
+    T* dxo = dx + ((long long)n * Hi + hi) * Wi * lddx;
     const int items = Wi * Q;
     for (int j = threadIdx.x; j < items; j += blockDim.x) {
         const int wi = j / Q, q = j - wi * Q;
@@ -665,20 +694,22 @@ __global__ void bilinear_bwd_tight_kernel(const float* __restrict__ dy, int lddy
 
 static inline int bil_threads(long long items) { return items >= 256 ? 256 : (items > 64 ? 128 : 64); }
 
-extern "C" int mrdis_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi,
+template <typename T>
+static int bilinear_fwd_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, int Wi,
                                   int Ho, int Wo, int C, int align_corners, void* stream) {
     if (!x || !y || N < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
     if (N > 65535) return MRDIS_EUNSUPPORTED;
     const float sh = bil_scale(Hi, Ho, align_corners), sw = bil_scale(Wi, Wo, align_corners);
     hipStream_t s = (hipStream_t)stream;
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bilinear_fwd_kernel<4>), dim3(Ho, N), dim3(bil_threads((long long)Wo * (C / 4))), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_fwd_kernel<4, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * (C / 4))), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else
-        hipLaunchKernelGGL((bilinear_fwd_kernel<1>), dim3(Ho, N), dim3(bil_threads((long long)Wo * C)), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_fwd_kernel<1, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * C)), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
-extern "C" int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi,
+template <typename T>
+static int bilinear_bwd_impl(const T* dy, int lddy, T* dx, int lddx, int N, int Hi, int Wi,
                                   int Ho, int Wo, int C, int align_corners, void* stream) {
     if (!dy || !dx || N < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || C < 1 || lddy < C || lddx < C) return MRDIS_EINVAL;
     if (N > 65535) return MRDIS_EUNSUPPORTED;
@@ -689,18 +720,95 @@ extern "C" int mrdis_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx
     const bool big = (long long)N * Hi * Wi * C >= 6000000LL;          // measured: 108 vs 129 us at 16 M elements, a wash below 6 M
     const bool tight3 = big && sh >= 1.f && sw >= 1.f, tight5 = big && smin > 0.4975f && !mrdis_opt(MRDIS_OPT_BILGEN);
     if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight3 && !mrdis_opt(MRDIS_OPT_BILGEN))
-        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 3, 3>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 3, 3, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight5)
-        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 5, 5>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 5, 5, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_bwd_kernel<4, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else
-        hipLaunchKernelGGL((bilinear_bwd_kernel<1>), dim3(Hi, N), dim3(bil_threads((long long)Wi * C)), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        hipLaunchKernelGGL((bilinear_bwd_kernel<1, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * C)), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 // ------------------------------------------------------------------ softmax([scale*mask, s])[1:]
+
+// ---- C ABI: activation views are fp32 or bf16 by `dtype` (include/mrdis.h MRDIS_DT_*); statistics, parameters and their
+// gradients are always fp32
+typedef const __bf16* cbf; typedef __bf16* bf;
+extern "C" int mrdis_bn_train_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                  long long P, int C, float eps, float momentum, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        bn_train_fwd_impl((const float*)x, ldx, (float*)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, stream),
+        bn_train_fwd_impl((cbf)x, ldx, (bf)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, stream));
+}
+extern "C" int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, long long P, int C, float eps, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype, bn_eval_fwd_impl((const float*)x, ldx, (float*)y, ldy, gamma, beta, running_mean, running_var, P, C, eps, stream),
+                          bn_eval_fwd_impl((cbf)x, ldx, (bf)y, ldy, gamma, beta, running_mean, running_var, P, C, eps, stream));
+}
+extern "C" int mrdis_bn_train_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* save_mean,
+                                  const float* save_rstd, void* dx, int lddx, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
+                                  void* workspace, size_t workspace_bytes, long long P, int C, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        bn_train_bwd_impl((const float*)dy, lddy, (const float*)x, ldx, gamma, save_mean, save_rstd, (float*)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, stream),
+        bn_train_bwd_impl((cbf)dy, lddy, (cbf)x, ldx, gamma, save_mean, save_rstd, (bf)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, stream));
+}
+extern "C" int mrdis_instnorm_spade_fwd(const void* z, int ldz, const void* gamma, int ldg, const void* beta, int ldb, void* out, int ldo,
+                                        float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                        int N, long long HW, int C, float eps, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        instnorm_spade_fwd_impl((const float*)z, ldz, (const float*)gamma, ldg, (const float*)beta, ldb, (float*)out, ldo, save_mean, save_rstd, workspace, workspace_bytes, N, HW, C, eps, stream),
+        instnorm_spade_fwd_impl((cbf)z, ldz, (cbf)gamma, ldg, (cbf)beta, ldb, (bf)out, ldo, save_mean, save_rstd, workspace, workspace_bytes, N, HW, C, eps, stream));
+}
+extern "C" int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz, const void* gamma, int ldg, const float* save_mean,
+                                        const float* save_rstd, void* dz, int lddz, void* dgamma, int lddg, void* dbeta, int lddb,
+                                        void* workspace, size_t workspace_bytes, int N, long long HW, int C, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        instnorm_spade_bwd_impl((const float*)dout, lddo, (const float*)z, ldz, (const float*)gamma, ldg, save_mean, save_rstd, (float*)dz, lddz, (float*)dgamma, lddg, (float*)dbeta, lddb, workspace, workspace_bytes, N, HW, C, stream),
+        instnorm_spade_bwd_impl((cbf)dout, lddo, (cbf)z, ldz, (cbf)gamma, ldg, save_mean, save_rstd, (bf)dz, lddz, (bf)dgamma, lddg, (bf)dbeta, lddb, workspace, workspace_bytes, N, HW, C, stream));
+}
+extern "C" int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, long long P, int C, float slope, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype, lrelu_bwd_impl((const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, P, C, slope, stream),
+                          lrelu_bwd_impl((cbf)dy, lddy, (cbf)y, ldy, (bf)dx, lddx, P, C, slope, stream));
+}
+extern "C" int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype, bilinear_fwd_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream),
+                          bilinear_fwd_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream));
+}
+extern "C" int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype, bilinear_bwd_impl((const float*)dy, lddy, (float*)dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, stream),
+                          bilinear_bwd_impl((cbf)dy, lddy, (bf)dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, stream));
+}
+
+// NHWC view cast between the two storage types (src -> dst, P rows of C channels): the boundary between bf16 activations
+// and the fp32-only kernels (Cin = 4 / 7 first layers, heads with fewer than 16 output channels, losses)
+template <int V, typename TS, typename TD>
+__global__ void cast_view_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, long long P, int C) {
+    const int Q = C / V;
+    EW_LOOP(P * Q) {
+        const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        Vec<V> a; a.load(src + r * lds_ + c); a.store(dst + r * ldd + c);
+    }
+}
+template <typename TS, typename TD>
+static int cast_view_impl(const TS* src, int lds_, TD* dst, int ldd, long long P, int C, void* stream) {
+    if (!src || !dst || P < 1 || C < 1 || lds_ < C || ldd < C) return MRDIS_EINVAL;
+    if (vec4_ok(src, lds_, C) && vec4_ok(dst, ldd, C))
+        hipLaunchKernelGGL((cast_view_kernel<4, TS, TD>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, P, C);
+    else
+        hipLaunchKernelGGL((cast_view_kernel<1, TS, TD>), dim3(ew_blocks(P * C)), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, P, C);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+extern "C" int mrdis_cast_view(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst, int dst_dtype, long long P, int C, void* stream) {
+    const bool sb = src_dtype == MRDIS_DT_BF16, db = dst_dtype == MRDIS_DT_BF16;
+    if (sb && !db) return cast_view_impl((cbf)src, ld_src, (float*)dst, ld_dst, P, C, stream);
+    if (!sb && db) return cast_view_impl((const float*)src, ld_src, (bf)dst, ld_dst, P, C, stream);
+    return MRDIS_EINVAL;
+}
+
 #define SM_MAXC 8
 __global__ void softmax_md_fwd_kernel(const float* __restrict__ s, int lds_, const float* __restrict__ mask, float* __restrict__ out, int ldo,
                                       long long P, int C, float scale) {

@@ -43,18 +43,19 @@ _SIGS = {
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
+    'mrdis_cast_view': (_I, [_P, _I, _I, _P, _I, _I, _L, _I, _P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
     'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 11 + [_P]),
-    'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P]),
+    'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _I, _P]),
     'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
-    'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _P]),
-    'mrdis_bn_eval_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _F, _P]),
-    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _L, _I, _P]),
-    'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _P]),
+    'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _I, _P]),
+    'mrdis_bn_eval_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _P]),
+    'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
-    'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _P]),
-    'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 7 + [_P]),
-    'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 7 + [_P]),
+    'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
+    'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
+    'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_softmax_mask_drop_fwd': (_I, [_P, _I, _P, _P, _I, _L, _I, _F, _P]),
     'mrdis_softmax_mask_drop_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'mrdis_recon_err_workspace': (_Z, [_I, _L, _I]),
@@ -141,9 +142,9 @@ def _ws(nbytes, device):
 
 # ---------------------------------------------------------------- NHWC views
 def nhwc(t):
-    """(tensor, ld) for a logical (N,C,H,W) fp32 tensor whose memory is NHWC with pixel
-    stride ld (channels_last tensors and channel slices of them qualify as they are)."""
-    assert t.dim() == 4 and t.dtype == torch.float32, (t.shape, t.dtype)
+    """(tensor, ld) for a logical (N,C,H,W) fp32 or bf16 tensor whose memory is NHWC with pixel
+    stride ld in elements (channels_last tensors and channel slices of them qualify as they are)."""
+    assert t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16), (t.shape, t.dtype)
     N, C, H, W = t.shape
     s = t.stride()
     ld = s[3] if W > 1 else (s[2] if H > 1 else (s[0] if N > 1 else C))
@@ -157,8 +158,35 @@ def nhwc(t):
     return t, ld
 
 
-def empty_nhwc(N, C, H, W, device):
-    return torch.empty((N, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+def empty_nhwc(N, C, H, W, device, dtype=torch.float32):
+    return torch.empty((N, C, H, W), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def _dt(*tensors):
+    """MRDIS_DT_* storage code of a set of activation views (all fp32 or all bf16)."""
+    kinds = {t.dtype for t in tensors if t is not None}
+    if kinds == {torch.float32}:
+        return 0
+    if kinds == {torch.bfloat16}:
+        return 2
+    raise MrdisError(f'activation views must be all fp32 or all bf16, got {sorted(str(k) for k in kinds)}')
+
+
+def cast_view(x, dtype):
+    """NHWC view -> new NHWC tensor of the other storage type (fp32 <-> bf16, round to nearest even)."""
+    lib = load()
+    x, ldx = nhwc(x)
+    if x.dtype == dtype:
+        return x
+    N, C, H, W = x.shape
+    y = empty_nhwc(N, C, H, W, x.device, dtype)
+    _chk(lib.mrdis_cast_view(_ptr(x), ldx, _dt(x), _ptr(y), C, _dt(y), N * H * W, C, _stream()), 'cast_view')
+    return y
+
+
+def bconv_eligible(c_reduce, c_out):
+    """geometry the bf16 MFMA convolution kernels cover (csrc/mrdis_bf16.hip): reduction axis % 16, >= 16 outputs, % 4."""
+    return c_reduce % 16 == 0 and c_out % 4 == 0 and c_out >= 16
 
 
 # ---------------------------------------------------------------- expert mixing
@@ -280,13 +308,14 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     assert T == kh * kw and Ci2 == Ci, (w_tck.shape, x.shape, kh, kw)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, pad)
     if out is None:
-        out = empty_nhwc(N, Co, Ho, Wo, x.device)
+        out = empty_nhwc(N, Co, Ho, Wo, x.device, x.dtype)
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr(), 'conv2d_fwd: `out` must already be an NHWC view'
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
+    dt = DT_BF16 if _dt(x, y) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
     _chk(lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              1 if lrelu else 0, DT_F32 if w_bf16 is None else DT_F32_BF16M, _stream()), 'conv2d_fwd')
+                              1 if lrelu else 0, dt, _stream()), 'conv2d_fwd')
     return out
 
 
@@ -298,11 +327,15 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None):
     T, Co2, Ci = w_tkc.shape
     H, W = in_hw
     assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
-    dx = empty_nhwc(N, Ci, H, W, dy.device)
+    dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype)
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
-    _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad,
-                                   DT_F32 if w_bf16 is None else DT_F32_BF16M, _stream()), 'conv2d_bwd_data')
+    dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
+    rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad, dt, _stream())
+    if rc == -2 and dt == DT_BF16:
+        # a geometry outside the bf16 kernels (e.g. a reduction axis that is not a multiple of 16): fp32 kernel between two view casts
+        return cast_view(conv2d_bwd_data(cast_view(dy, torch.float32), w_tkc, in_hw, kh, kw, stride, pad), torch.bfloat16)
+    _chk(rc, 'conv2d_bwd_data')
     return dx
 
 
@@ -321,8 +354,15 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
         raise MrdisError('conv2d_bwd_weight: unsupported geometry')
     ws = _ws(nb, x.device)
     sink = bias_sink if (need_bias and bias_sink is not None) else None
+    if _dt(x, dy) == DT_BF16:
+        rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
+                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, DT_BF16, _stream())
+        if rc == -2:      # stride-2 / narrow layers: the fp32 weight-gradient kernels on fp32 copies of the two views
+            return conv2d_bwd_weight(cast_view(x, torch.float32), cast_view(dy, torch.float32), kh, kw, stride, pad, need_bias, bias_sink, DT_F32)
+        _chk(rc, 'conv2d_bwd_weight')
+        return dw, db
     _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
-                                     N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, int(dtype), _stream()), 'conv2d_bwd_weight')
+                                     N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, DT_BF16 if _dt(x, dy) == DT_BF16 else int(dtype), _stream()), 'conv2d_bwd_weight')
     return dw, db
 
 
@@ -330,8 +370,8 @@ def lrelu_bwd(dy, y, slope=0.2):
     lib = load()
     dy, lddy = nhwc(dy); y, ldy = nhwc(y)
     N, C, H, W = y.shape
-    dx = empty_nhwc(N, C, H, W, y.device)
-    _chk(lib.mrdis_lrelu_bwd(_ptr(dy), lddy, _ptr(y), ldy, _ptr(dx), C, N * H * W, C, slope, _stream()), 'lrelu_bwd')
+    dx = empty_nhwc(N, C, H, W, y.device, y.dtype)
+    _chk(lib.mrdis_lrelu_bwd(_ptr(dy), lddy, _ptr(y), ldy, _ptr(dx), C, N * H * W, C, slope, _dt(dy, y), _stream()), 'lrelu_bwd')
     return dx
 
 
@@ -342,7 +382,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=N
     N, C, H, W = x.shape
     P = N * H * W
     if out is None:
-        out = empty_nhwc(N, C, H, W, x.device)
+        out = empty_nhwc(N, C, H, W, x.device, x.dtype)
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr()
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -350,7 +390,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=N
     nb = lib.mrdis_norm_workspace(1, P, C)
     ws = _ws(nb, x.device)
     _chk(lib.mrdis_bn_train_fwd(_ptr(x), ldx, _ptr(y), ldy, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _stream()), 'bn_train_fwd')
+                                _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _dt(x, y), _stream()), 'bn_train_fwd')
     return out, mean, rstd
 
 
@@ -358,9 +398,9 @@ def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps):
     lib = load()
     x, ldx = nhwc(x)
     N, C, H, W = x.shape
-    y = empty_nhwc(N, C, H, W, x.device)
+    y = empty_nhwc(N, C, H, W, x.device, x.dtype)
     _chk(lib.mrdis_bn_eval_fwd(_ptr(x), ldx, _ptr(y), C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                               N * H * W, C, eps, _stream()), 'bn_eval_fwd')
+                               N * H * W, C, eps, _dt(x), _stream()), 'bn_eval_fwd')
     return y
 
 
@@ -370,14 +410,14 @@ def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None):
     dy, lddy = nhwc(dy); x, ldx = nhwc(x)
     N, C, H, W = x.shape
     P = N * H * W
-    dx = empty_nhwc(N, C, H, W, x.device)
+    dx = empty_nhwc(N, C, H, W, x.device, x.dtype)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = lib.mrdis_norm_workspace(1, P, C)
     ws = _ws(nb, x.device)
     ag, ab = sink if sink is not None else (None, None)
     _chk(lib.mrdis_bn_train_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), C, _ptr(dg), _ptr(db),
-                                _ptr(ag), _ptr(ab), _ptr(ws), nb, P, C, _stream()), 'bn_train_bwd')
+                                _ptr(ag), _ptr(ab), _ptr(ws), nb, P, C, _dt(dy, x), _stream()), 'bn_train_bwd')
     return dx, dg, db
 
 
@@ -385,13 +425,13 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
     lib = load()
     z, ldz = nhwc(z); gamma, ldg = nhwc(gamma); beta, ldb = nhwc(beta)
     N, C, H, W = z.shape
-    out = empty_nhwc(N, C, H, W, z.device)
+    out = empty_nhwc(N, C, H, W, z.device, z.dtype)
     mean = torch.empty(N * C, dtype=torch.float32, device=z.device)
     rstd = torch.empty(N * C, dtype=torch.float32, device=z.device)
     nb = lib.mrdis_norm_workspace(N, H * W, C)
     ws = _ws(nb, z.device)
     _chk(lib.mrdis_instnorm_spade_fwd(_ptr(z), ldz, _ptr(gamma), ldg, _ptr(beta), ldb, _ptr(out), C, _ptr(mean), _ptr(rstd),
-                                      _ptr(ws), nb, N, H * W, C, eps, _stream()), 'instnorm_spade_fwd')
+                                      _ptr(ws), nb, N, H * W, C, eps, _dt(z, gamma, beta), _stream()), 'instnorm_spade_fwd')
     return out, mean, rstd
 
 
@@ -402,18 +442,19 @@ def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False):
     lib = load()
     dout, lddo = nhwc(dout); z, ldz = nhwc(z); gamma, ldg = nhwc(gamma)
     N, C, H, W = z.shape
-    dz = empty_nhwc(N, C, H, W, z.device)
+    dz = empty_nhwc(N, C, H, W, z.device, z.dtype)
     nb = lib.mrdis_instnorm_spade_bwd_workspace(N, H * W, C)
     ws = _ws(nb, z.device)
+    dt = _dt(dout, z, gamma)
     if fused_gb:
-        dgb = empty_nhwc(N, 2 * C, H, W, z.device)
+        dgb = empty_nhwc(N, 2 * C, H, W, z.device, z.dtype)
         _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
-                                          dgb.data_ptr(), 2 * C, dgb.data_ptr() + 4 * C, 2 * C, _ptr(ws), nb, N, H * W, C, _stream()),
+                                          dgb.data_ptr(), 2 * C, dgb.data_ptr() + dgb.element_size() * C, 2 * C, _ptr(ws), nb, N, H * W, C, dt, _stream()),
              'instnorm_spade_bwd')
         return dz, dgb
-    dg = empty_nhwc(N, C, H, W, z.device)
+    dg = empty_nhwc(N, C, H, W, z.device, z.dtype)
     _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
-                                      _ptr(dg), C, None, 0, _ptr(ws), nb, N, H * W, C, _stream()), 'instnorm_spade_bwd')
+                                      _ptr(dg), C, None, 0, _ptr(ws), nb, N, H * W, C, dt, _stream()), 'instnorm_spade_bwd')
     return dz, dg
 
 
@@ -423,8 +464,8 @@ def bilinear_fwd(x, out_hw, align_corners):
     x, ldx = nhwc(x)
     N, C, Hi, Wi = x.shape
     Ho, Wo = out_hw
-    y = empty_nhwc(N, C, Ho, Wo, x.device)
-    _chk(lib.mrdis_bilinear_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _stream()), 'bilinear_fwd')
+    y = empty_nhwc(N, C, Ho, Wo, x.device, x.dtype)
+    _chk(lib.mrdis_bilinear_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _dt(x), _stream()), 'bilinear_fwd')
     return y
 
 
@@ -433,8 +474,8 @@ def bilinear_bwd(dy, in_hw, align_corners):
     dy, lddy = nhwc(dy)
     N, C, Ho, Wo = dy.shape
     Hi, Wi = in_hw
-    dx = empty_nhwc(N, C, Hi, Wi, dy.device)
-    _chk(lib.mrdis_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _stream()), 'bilinear_bwd')
+    dx = empty_nhwc(N, C, Hi, Wi, dy.device, dy.dtype)
+    _chk(lib.mrdis_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _dt(dy), _stream()), 'bilinear_bwd')
     return dx
 
 

@@ -90,11 +90,11 @@ class CondConv2d(nn.Module):
         kh, kw = self.kernel_size
         B = inputs.shape[0]
         if B == 1 or inputs_type.stride(0) == 0:
-            if not ops.mix_cache_active():
+            if not ops.mix_cache_active() and not ops.storage_bf16():
                 # the seam as ONE dispatcher-visible op (mix + conv, torch.ops.mrdis.cond_conv2d): plain module use
                 return torch.ops.mrdis.cond_conv2d(inputs, inputs_type[:1], self.weight, self._routing_fn.fc.weight,
                                                    self._routing_fn.fc.bias, self.bias, self.stride[0], self.padding[0], lrelu,
-                                                   ops.compute_dtype())
+                                                   ops.compute_dtype())        # 0 exact fp32 | 1 bf16 MFMA operands
             # inside a training step the mixed kernels of all modality labels are cached and shared by every call
             w_tck, w_tkc = self.mixed_uniform(inputs_type)
             return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
@@ -278,7 +278,7 @@ class ModalityEncoderNew(nn.Module):
             conv = getattr(self, f'conv{i + 1}')
             x = conv(x, inputs_type, lrelu=True) if self.is_cond else conv(x, lrelu=True)   # :2374-2383
         # `view(-1, 5*6*128)` flattens NCHW order (:2396): make that order physical (tiny tensor)
-        x = x.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1)
+        x = x.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1).float()     # bf16 storage: the Linears stay fp32
         x = self.fcs(x)
         return self.mean(x), self.log_var(x)
 
@@ -347,7 +347,7 @@ class SPADENewShared(nn.Module):
 
     def forward(self, si, zi, inputs_type=None):
         H, W = self.image_size
-        x = self.zi_scaler(zi).reshape(-1, self.z_num_ch, H // 32, W // 32)
+        x = ops.to_storage(self.zi_scaler(zi).reshape(-1, self.z_num_ch, H // 32, W // 32))     # opens the decoder's bf16 stretch
         x = self.sp1(si, x, inputs_type)
         x = self.sp2(si, _up2(x), inputs_type)
         x = self.sp3(si, _up2(x), inputs_type)
@@ -417,7 +417,7 @@ class Discriminator(nn.Module):
         if self.is_patch_gan:
             return self.fc(x)
         # nn.Flatten flattens NCHW order: make it physical before the Linear (tiny tensor)
-        return self.fc(x.contiguous(memory_format=torch.contiguous_format))
+        return self.fc(x.contiguous(memory_format=torch.contiguous_format).float())
 
 
 # =============================================================================
@@ -550,6 +550,8 @@ class MultimodalModel(nn.Module):
         # position (after the input decoders, before the discriminator, model.py:2955-2967) so seeds give the same init
         self.fuse_method = fuse_method
         if build_output_decoder:
+            if ops.storage_bf16():
+                raise NotImplementedError("compute_dtype 'bf16' (bf16 activations) covers the shipped loss set; the 'U+SA' output decoder runs in 'f32' / 'bf16m'")
             if target_model_name != 'U+SA' or fuse_method != 'mean':
                 raise NotImplementedError("output decoder: only target_model_name 'U+SA' with fuse_method 'mean' (config.yaml:64, 66)")
             self.output_decoder = GANShortGeneratorWithSpatialAttention(s_num_ch, out_num_ch, 64, target_output_act)

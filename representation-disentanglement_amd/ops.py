@@ -155,21 +155,52 @@ def set_grad_sink(enabled):
 
 
 # --------------------------------------------------------------------------- convolution
-# Compute dtype of the convolutions (BASELINE.json configs[2]): 'f32' = exact fp32 MFMA (the parity path), 'bf16' = bf16
-# MFMA operands with fp32 accumulation on fp32 activations (include/mrdis.h MRDIS_DT_F32_BF16M); config key `compute_dtype`.
+# Compute dtype (config key `compute_dtype`, BASELINE.json configs[2]):
+#   'f32'   exact fp32 MFMA, fp32 activations -- the parity path (MRDIS_DT_F32);
+#   'bf16m' bf16 MFMA operands + fp32 accumulate on fp32 activations (MRDIS_DT_F32_BF16M);
+#   'bf16'  bf16 activations in HBM + bf16 MFMA operands + fp32 accumulate (MRDIS_DT_BF16): every tensor with >= 16 channels is
+#           stored in bf16; master weights, biases, all statistics, the 4-channel anatomy maps, reconstructions, losses, the
+#           optimizer and every parameter gradient stay fp32.
 _COMPUTE_DTYPE = hip.DT_F32
 
 
 def set_compute_dtype(name):
     global _COMPUTE_DTYPE
-    table = {'f32': hip.DT_F32, 'fp32': hip.DT_F32, 'float32': hip.DT_F32, 'bf16': hip.DT_F32_BF16M, 'bfloat16': hip.DT_F32_BF16M}
+    table = {'f32': hip.DT_F32, 'fp32': hip.DT_F32, 'float32': hip.DT_F32, 'bf16m': hip.DT_F32_BF16M,
+             'bf16': hip.DT_BF16, 'bfloat16': hip.DT_BF16}
     if name not in table:
-        raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {name!r}")
+        raise ValueError(f"compute_dtype must be 'f32', 'bf16m' or 'bf16', got {name!r}")
     _COMPUTE_DTYPE = table[name]
 
 
 def compute_dtype():
     return _COMPUTE_DTYPE
+
+
+def storage_bf16():
+    return _COMPUTE_DTYPE == hip.DT_BF16
+
+
+class _CastView(Function):
+    """fp32 <-> bf16 copy of an NHWC view (mrdis_cast_view); the adjoint casts the gradient back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return hip.cast_view(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.cast_view(g, ctx.src), None
+
+
+def cast_view(x, dtype):
+    return x if x.dtype == dtype else _CastView.apply(x, dtype)
+
+
+def to_storage(x):
+    """an activation tensor in the storage type of the current compute dtype (bf16 for 'bf16', unchanged otherwise)."""
+    return cast_view(x, torch.bfloat16) if (storage_bf16() and x.dtype == torch.float32) else x
 
 
 def bf16_filters(w_tck, w_tkc):
@@ -183,11 +214,22 @@ def bf16_filters(w_tck, w_tkc):
 
 
 def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
-    """-> torch.ops.mrdis.conv2d (registered at the bottom of this file: CUDA kernel, fake kernel, autograd formula)."""
+    """-> torch.ops.mrdis.conv2d (registered at the bottom of this file: CUDA kernel, fake kernel, autograd formula).
+    With bf16 storage the bf16 kernels run bf16 -> bf16 where the geometry allows (reduction axis % 16, >= 16 outputs);
+    other layers (Cin = 4 / 7 first layers, heads with < 16 outputs) run the fp32 kernels between explicit view casts:
+    fp32 in -> bf16 out for the layers that open a bf16 stretch, bf16 in -> fp32 out for the heads."""
+    if _COMPUTE_DTYPE == hip.DT_F32:
+        return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
+    Ci, Co = w_tck.shape[1], w_tck.shape[2]
+    wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
     if _COMPUTE_DTYPE == hip.DT_F32_BF16M:
-        wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
         return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
-    return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
+    eligible = hip.bconv_eligible(Ci, Co)
+    if eligible:
+        y = torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+        return y
+    y = torch.ops.mrdis.conv2d(cast_view(x, torch.float32), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
+    return cast_view(y, torch.bfloat16) if Co >= 16 else y
 
 
 # --------------------------------------------------------------------------- norms
@@ -431,6 +473,8 @@ def _k_mix_bwd(dw_tck, W, r, type_row):
 
 
 def _k_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu, dtype=0):
+    if dtype not in (hip.DT_F32, hip.DT_F32_BF16M) or x.dtype != torch.float32:
+        raise hip.MrdisError('mrdis::cond_conv2d takes fp32 activations (dtype 0 or 1); bf16 storage goes through mrdis::conv2d')
     w_tck, w_tkc, _ = hip.mix_experts_routed_fwd(weight, fc_w, fc_b, type_row)
     wb = hip.cast_bf16(w_tkc) if dtype == hip.DT_F32_BF16M else None
     return hip.conv2d_fwd(x, w_tck, bias, weight.shape[3], weight.shape[4], stride, pad, lrelu, w_bf16=wb)

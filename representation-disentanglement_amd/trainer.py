@@ -35,7 +35,7 @@ DEFAULT_CONFIG = {
     'ckpt_name': 'model_best.pth.tar', 'ckpt_timelabel': None,
     # keys added by this implementation (defaults reproduce the reference)
     'backend': 'hip', 'is_patch_gan': False,
-    'compute_dtype': 'f32',            # 'bf16': bf16 MFMA operands + fp32 accumulate on fp32 activations (BASELINE configs[2], stage 1)
+    'compute_dtype': 'f32',            # BASELINE configs[2]: 'bf16' = bf16 activations + bf16 MFMA operands + fp32 accumulate; 'bf16m' = bf16 MFMA operands only
 }
 
 
@@ -62,6 +62,7 @@ def derive_config(config, device):
 
 def build_model(config):
     """main_missing.py:87-95."""
+    ops.set_compute_dtype(config.get('compute_dtype', 'f32'))
     return MultimodalModel(
         input_size=(config['input_height'], config['input_width']), modality_num=len(config['contrast_list']),
         in_num_ch=2 * config['block_size'] + 1, out_num_ch=config['out_num_ch'], s_num_ch=config['s_num_ch'],
