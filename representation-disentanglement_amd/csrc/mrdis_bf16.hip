@@ -537,12 +537,13 @@ __global__ void bwgrad_reduce_kernel(const float* __restrict__ slab, int S, long
 
 struct BWgradPlan { BWgradParams p; int wci, wco, KS; size_t lds; long long slab_floats, bias_floats; };
 
-static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dtype = MRDIS_DT_F32_BF16M) {
     if (stride != 1 || kh * kw > 9 || kh != kw || 2 * pad != kh - 1) return MRDIS_EUNSUPPORTED;    // "same" convolutions only (Ho = H)
     if (Ci % 32 != 0 || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;
     // measured (tools/layer_bench.py --dtype bf16, B = 32): with 32 or fewer couts a wave's 32 x 32 block leaves too few waves per
     // channel block and the fp32 narrow-cout kernels win (sp6.out 593 vs 249 us, sp5.out 310 vs 198 us) unless Cin >= 128
-    if (Co <= 32 && Ci < 128) return MRDIS_EUNSUPPORTED;
+    // (with bf16 activations the alternative is two full-size view casts in front of the fp32 kernel: stay here)
+    if (Co <= 32 && Ci < 128 && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W < 4096) return MRDIS_EUNSUPPORTED;                                    // tiny maps: the fp32 kernels' slabs are cheaper
     BWgradParams& p = pl.p;
     p = BWgradParams{};
@@ -582,7 +583,7 @@ static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int 
 
 size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
     BWgradPlan pl;
-    if (plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
+    if (plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad, MRDIS_DT_BF16)) return 0;          // the widest domain
     return sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
 }
 
@@ -590,7 +591,7 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
                      int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, hipStream_t s) {
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     BWgradPlan pl;
-    int rc = plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
+    int rc = plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad, dtype);
     if (rc) return rc;
     if (ldx % (st_bf16 ? 8 : 4) != 0 || lddy % (st_bf16 ? 8 : 4) != 0 || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256) return MRDIS_EWORKSPACE;
