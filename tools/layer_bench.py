@@ -62,7 +62,9 @@ def main():
     ap.add_argument('--hw', type=int, nargs=2, default=[256, 256])
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="bf16: bf16 MFMA operands + fp32 accumulate on fp32 activations")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16m'],
+                    help='bf16: bf16 activations + bf16 MFMA operands (fp32 kernels between view casts where the bf16 kernels do not apply: '
+                         'timed with the casts); bf16m: bf16 MFMA operands on fp32 activations')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     B, (H, W) = a.batch, a.hw
@@ -78,13 +80,39 @@ def main():
         dy = torch.randn(B, co, ho, wo, device=dev).contiguous(memory_format=torch.channels_last)
         flop = 2.0 * k * k * ci * co * B * ho * wo
         byts = 4.0 * (B * ci * hi * wi + B * co * ho * wo)
-        bf = a.dtype == 'bf16'
+        bf = a.dtype != 'f32'
         wb_f = hip.cast_bf16(wk) if bf else None
         wb_b = hip.cast_bf16(wt) if bf else None
         dt = hip.DT_F32_BF16M if bf else hip.DT_F32
-        tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p, w_bf16=wb_f), a.iters)
-        td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p, w_bf16=wb_b), a.iters)
-        tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p, dtype=dt), a.iters)
+        if a.dtype == 'bf16':
+            # storage mode as ops.conv2d runs it: bf16 views where the layer keeps >= 16 channels on that side, the bf16 kernels
+            # where they apply, otherwise a view cast + the fp32 kernel (+ a cast back)
+            B16 = torch.bfloat16
+            xs = x.to(B16) if ci >= 16 else x
+            dys = dy.to(B16) if co >= 16 else dy
+            byts = xs.element_size() * xs.numel() + dys.element_size() * dys.numel()
+
+            def f_fwd():
+                if hip.bconv_eligible(ci, co):
+                    return hip.conv2d_fwd(hip.cast_view(xs, B16), wt, bias, k, k, s, p, w_bf16=wb_f)
+                y = hip.conv2d_fwd(hip.cast_view(xs, torch.float32), wt, bias, k, k, s, p)
+                return hip.cast_view(y, B16) if co >= 16 else y
+
+            def f_dgrad():
+                if dys.dtype == B16 and xs.dtype == B16:
+                    return hip.conv2d_bwd_data(dys, wk, (hi, wi), k, k, s, p, w_bf16=wb_b)
+                g = hip.conv2d_bwd_data(hip.cast_view(dys, torch.float32), wk, (hi, wi), k, k, s, p)
+                return hip.cast_view(g, B16) if ci >= 16 else g
+
+            def f_wgrad():
+                if dys.dtype == B16 and xs.dtype == B16:
+                    return hip.conv2d_bwd_weight(xs, dys, k, k, s, p)
+                return hip.conv2d_bwd_weight(hip.cast_view(xs, torch.float32), hip.cast_view(dys, torch.float32), k, k, s, p)
+            tf, td, tw = timeit(f_fwd, a.iters), timeit(f_dgrad, a.iters), timeit(f_wgrad, a.iters)
+        else:
+            tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p, w_bf16=wb_f), a.iters)
+            td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p, w_bf16=wb_b), a.iters)
+            tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p, dtype=dt), a.iters)
         rows.append((name, ci, co, k, s, hi, wi, calls, flop, byts, tf, td, tw, dcalls))
         del x, dy
     tot = sum(r[10] * r[7] + r[11] * r[13] + r[12] * r[7] for r in rows)
