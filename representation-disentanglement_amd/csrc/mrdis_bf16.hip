@@ -281,14 +281,20 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
     int KC = (p.Cin % 32 == 0) ? 32 : 16;
     auto npix = [&]() { return (long long)p.NB * p.TinH * p.TinW; };
     auto lds_bytes = [&](int kc) { return 2 * (size_t)(kc + 8) * ((size_t)p.ntaps * BN + (size_t)npix()); };
-    auto fits = [&](int kc) { return p.TinH < 256 && p.TinW < 256 && npix() * (kc / 8) <= 6 * 256 && (long long)p.ntaps * BN * (kc / 8) <= 9 * 256 && lds_bytes(kc) <= 80 * 1024; };
-    if (!fits(KC) && KC == 32) KC = 16;
-    if (!fits(KC) && c.wp == 2 && c.waves_c == 1) {        // stride-2 halos: fall back to 128-position tiles
-        c.wp = 1; BM = 128; geom(BM);
+    // register-staged pieces per thread (6 input, 9 filter) and LDS: two workgroups per CU up to 80 KB each, one up to 120 KB
+    auto fits = [&](int kc, size_t cap) { return p.TinH < 256 && p.TinW < 256 && npix() * (kc / 8) <= 6 * 256 && (long long)p.ntaps * BN * (kc / 8) <= 9 * 256 && lds_bytes(kc) <= cap; };
+    auto pick = [&](size_t cap) {
         KC = (p.Cin % 32 == 0) ? 32 : 16;
-        if (!fits(KC) && KC == 32) KC = 16;
+        if (!fits(KC, cap) && KC == 32) KC = 16;
+        return fits(KC, cap);
+    };
+    bool ok = pick(80 * 1024);
+    if (!ok && c.wp == 2) {                                  // stride-2 halos, many-image tiles of tiny maps: 128-position tiles
+        c.wp = 1; BM = 128; geom(BM);
+        ok = pick(80 * 1024) || pick(120 * 1024);
     }
-    if (!fits(KC)) return MRDIS_EUNSUPPORTED;
+    if (!ok) ok = pick(120 * 1024);
+    if (!ok) return MRDIS_EUNSUPPORTED;
     if ((long long)p.N * p.Hin * p.Win * p.ldin >= 0x7fffffffLL * 2LL) return MRDIS_EUNSUPPORTED;
     p.coTiles = mrdis_cdiv(p.Cout, BN);
     BConvGeom g;

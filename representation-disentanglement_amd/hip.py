@@ -314,8 +314,14 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
     dt = DT_BF16 if _dt(x, y) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
-    _chk(lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              1 if lrelu else 0, dt, _stream()), 'conv2d_fwd')
+    rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
+                              1 if lrelu else 0, dt, _stream())
+    if rc == -2 and dt == DT_BF16:
+        # a tile geometry the bf16 kernel cannot stage (or a view it cannot address): the fp32 kernel between two view casts
+        y32 = conv2d_fwd(cast_view(x, torch.float32), w_tck, bias, kh, kw, stride, pad, lrelu)
+        lib.mrdis_cast_view(_ptr(y32), Co, DT_F32, _ptr(y), ldy, DT_BF16, N * Ho * Wo, Co, _stream())
+        return out
+    _chk(rc, 'conv2d_fwd')
     return out
 
 

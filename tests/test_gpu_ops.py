@@ -571,3 +571,78 @@ def test_conv_bf16_mfma(mrdis, case):
     else:                                                                         # stride 2 / tiny maps: the fp32 kernels run -> exact fp32
         assert err_f <= 3e-4, ('wgrad (fp32 kernels)', err_f, err_b)
     close(db, gy.sum((0, 2, 3)), rtol=2e-5, what='dbias (fp32 sum)')
+
+
+def test_conv_bf16_storage_random_shapes(mrdis):
+    """MRDIS_DT_BF16 (bf16 activation views in and out) over a seeded sweep of geometries inside the bf16 kernels' domain
+    (channels in multiples of 16, >= 16 outputs): no shape may be refused without a working fallback, and every result must
+    match torch fp32 on the bf16-rounded operands up to the rounding of the bf16 OUTPUT (2^-8 relative per element)."""
+    hip = mrdis.hip
+    g = np.random.RandomState(77)
+    B16 = torch.bfloat16
+    for case in range(30):
+        k = int(g.choice([1, 3, 3, 4])); stride = 1 if k == 1 else int(g.choice([1, 1, 2])); pad = 0 if k == 1 else 1
+        N = int(g.randint(1, 9)); Ci = 16 * int(g.randint(1, 9)); Co = int(g.choice([16, 20, 32, 48, 64, 96, 128, 256]))
+        H = int(g.randint(2, 40)); W = int(g.randint(2, 50))
+        if (H + 2 * pad - k) // stride + 1 <= 0 or (W + 2 * pad - k) // stride + 1 <= 0:
+            continue
+        x = rnd((N, Ci, H, W), 10 + case); w = rnd((Co, Ci, k, k), 100 + case, 1.0 / np.sqrt(Ci * k * k)); b = rnd((Co,), 200 + case, 0.1)
+        xb, wb = x.bfloat16().float(), w.bfloat16().float()
+        want = F.conv2d(xb, wb, b, stride, pad)
+        tag = f'case {case}: N{N} {Ci}->{Co} {H}x{W} k{k} s{stride}'
+        xd = cl(x).to(B16)
+        got = hip.conv2d_fwd(xd, to_tck(w).to(dev()), b.to(dev()), k, k, stride, pad, w_bf16=hip.cast_bf16(to_tkc(w).to(dev())))
+        assert got.dtype == B16
+        close(got, want, rtol=6e-3, what=tag + ' fwd')
+        gy = rnd(tuple(want.shape), 300 + case); gyb = gy.bfloat16().float()
+        dyd = cl(gy).to(B16)
+        dx = hip.conv2d_bwd_data(dyd, to_tkc(w).to(dev()), (H, W), k, k, stride, pad, w_bf16=hip.cast_bf16(to_tck(w).to(dev())))
+        assert dx.dtype == B16
+        close(dx, torch.nn.grad.conv2d_input(x.shape, wb, gyb, stride, pad), rtol=6e-3, what=tag + ' dgrad')
+        wz = torch.zeros(Co, Ci, k, k, requires_grad=True)
+        F.conv2d(xb, wz, None, stride, pad).backward(gyb)
+        dw, db = hip.conv2d_bwd_weight(xd, dyd, k, k, stride, pad, need_bias=True)
+        assert dw.dtype == torch.float32
+        close(dw, to_tck(wz.grad), rtol=3e-4, what=tag + ' wgrad')
+        close(db, gyb.sum((0, 2, 3)), rtol=3e-4, what=tag + ' dbias')
+
+
+@pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 16), (32, 3, 9, 7), (256, 2, 5, 6)])
+def test_norms_resize_bf16_storage(mrdis, C, N, H, W):
+    """BatchNorm (train / eval), InstanceNorm+SPADE, bilinear, LeakyReLU backward on bf16 views: fp32 arithmetic inside,
+    so results equal the fp32 formulas on the bf16-rounded inputs up to the rounding of the bf16 outputs; statistics fp32."""
+    hip = mrdis.hip
+    B16 = torch.bfloat16
+    rb = lambda t: t.bfloat16().float()
+    x = rb(rnd((N, C, H, W), 11) * 2 + 0.5).requires_grad_(True)
+    gm = rnd((C,), 12).requires_grad_(True); bt = rnd((C,), 13).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.batch_norm(x, rm, rv, gm, bt, True, 0.1, 1e-5)
+    gy = rb(rnd(tuple(y.shape), 14)); y.backward(gy)
+    rmd, rvd = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    xd = cl(x.detach()).to(B16)
+    yd, mean, rstd = hip.bn_train_fwd(xd, gm.detach().to(dev()), bt.detach().to(dev()), rmd, rvd, 1e-5, 0.1)
+    assert yd.dtype == B16 and mean.dtype == torch.float32
+    close(yd, y, rtol=6e-3); close(rmd, rm, rtol=1e-5); close(rvd, rv, rtol=1e-5)
+    dx, dg, db = hip.bn_train_bwd(cl(gy).to(B16), xd, gm.detach().to(dev()), mean, rstd)
+    close(dx, x.grad, rtol=8e-3); close(dg, gm.grad, rtol=3e-4); close(db, bt.grad, rtol=3e-4)
+    close(hip.bn_eval_fwd(xd, gm.detach().to(dev()), bt.detach().to(dev()), rmd, rvd, 1e-5),
+          F.batch_norm(x.detach(), rm, rv, gm.detach(), bt.detach(), False, 0.1, 1e-5), rtol=6e-3)
+    z = rb(rnd((N, C, H, W), 15) * 1.5 + 0.3).requires_grad_(True)
+    g = rb(rnd((N, C, H, W), 16)).requires_grad_(True); b = rb(rnd((N, C, H, W), 17)).requires_grad_(True)
+    out = F.instance_norm(z, eps=1e-5) * (1 + g) + b
+    go = rb(rnd(tuple(out.shape), 18)); out.backward(go)
+    od, m2, r2 = hip.instnorm_spade_fwd(cl(z.detach()).to(B16), cl(g.detach()).to(B16), cl(b.detach()).to(B16), 1e-5)
+    close(od, out, rtol=6e-3)
+    dz, dgm = hip.instnorm_spade_bwd(cl(go).to(B16), cl(z.detach()).to(B16), cl(g.detach()).to(B16), m2, r2)
+    close(dz, z.grad, rtol=8e-3); close(dgm, g.grad, rtol=6e-3)
+    xi = rb(rnd((N, C, H, W), 19)).requires_grad_(True)
+    for ac in (True, False):
+        yi = F.interpolate(xi, size=(2 * H, 2 * W), mode='bilinear', align_corners=ac)
+        gyi = rb(rnd(tuple(yi.shape), 20)); xi.grad = None; yi.backward(gyi)
+        close(hip.bilinear_fwd(cl(xi.detach()).to(B16), (2 * H, 2 * W), ac), yi, rtol=6e-3)
+        close(hip.bilinear_bwd(cl(gyi).to(B16), (H, W), ac), xi.grad, rtol=6e-3)
+    ya = F.leaky_relu(xi.detach(), 0.2)
+    close(hip.lrelu_bwd(cl(gy).to(B16), cl(rb(ya)).to(B16), 0.2), torch.where(ya > 0, gy, 0.2 * gy), rtol=6e-3)
+    t32 = cl(rnd((N, C, H, W), 21))
+    assert torch.equal(hip.cast_view(hip.cast_view(t32, B16), torch.float32), t32.bfloat16().float())

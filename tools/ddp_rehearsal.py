@@ -3,7 +3,8 @@ cuda:0 and the exchange runs over gloo (RCCL needs one device per rank).  Every 
 seeds, so the averaged gradients equal the single-process ones bit for bit ((g + g) / 2 == g in fp32) and, the kernels
 being bit-reproducible, the weights after k steps must be IDENTICAL to a single-process run and across ranks.  That
 pins the parts the CPU gloo test cannot reach: gradient sinks written inside backward kernels, hook-driven bucket
-launches racing the rest of the backward pass, the adversarial second backward, the first (arena-less) step.
+launches racing the rest of the backward pass, the adversarial second backward into the second optimizer's buffer, gradient
+accumulation (the reference's default schedule), gated decoders, and the bf16 mode.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_rehearsal.py
 """
@@ -18,9 +19,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mrdis  # noqa: E402
 
 
-def run(steps, B, M, H, W, dev):
+def run(steps, B, M, H, W, dev, batch_size=16, compute_dtype='f32'):
     cfg = dict(mrdis.DEFAULT_CONFIG)
-    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=16, lambda_adv_s=1.0)
+    cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=batch_size, lambda_adv_s=1.0,
+               compute_dtype=compute_dtype)
     cfg = mrdis.derive_config(cfg, dev)
     torch.manual_seed(10); np.random.seed(10)
     model = mrdis.build_model(cfg).train()
@@ -43,22 +45,27 @@ def main():
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     mrdis.hip.load()
-    steps, B, M, H, W = 3, 4, 3, 64, 96
-    ref, ref_losses, _ = run(steps, B, M, H, W, dev)                     # single process: no reducer
+    B, M, H, W = 4, 3, 64, 96
+    # (steps, config.batch_size, compute_dtype): accum = 1; the reference's default schedule (accum = 2, two optimizer steps); bf16 storage
+    cases = [(3, 16, 'f32'), (4, 8, 'f32'), (2, 16, 'bf16')]
+    refs = [run(st, B, M, H, W, dev, bs, cd)[:2] for st, bs, cd in cases]        # single process: no reducer
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    got, losses, step = run(steps, B, M, H, W, dev)
-    assert step.reducer is not None and step.reducer.world == world
-    same = bool(torch.equal(ref, got))
-    maxdiff = float((ref - got).abs().max())
-    sums = [None] * world
-    dist.all_gather_object(sums, (float(got.double().sum()), float(got.double().abs().sum())))
-    across = all(s == sums[0] for s in sums)
-    if rank == 0:
-        print(f'[ddp rehearsal] world {world}: weights after {steps} steps identical to single-process: {same} '
-              f'(max |diff| {maxdiff:.3e}); identical across ranks: {across}; losses {losses} vs {ref_losses}', flush=True)
+    ok = True
+    for (st, bs, cd), (ref, ref_losses) in zip(cases, refs):
+        got, losses, step = run(st, B, M, H, W, dev, bs, cd)
+        assert step.reducer is not None and step.reducer.world == world
+        same = bool(torch.equal(ref, got))
+        maxdiff = float((ref - got).abs().max())
+        sums = [None] * world
+        dist.all_gather_object(sums, (float(got.double().sum()), float(got.double().abs().sum())))
+        across = all(s == sums[0] for s in sums)
+        if rank == 0:
+            print(f'[ddp rehearsal] world {world}, batch_size {bs} (accum {step.accum}), compute_dtype {cd}: weights after {st} iterations identical '
+                  f'to single-process: {same} (max |diff| {maxdiff:.3e}); identical across ranks: {across}; losses {losses} vs {ref_losses}', flush=True)
+        ok = ok and same and across
     dist.barrier()
     dist.destroy_process_group()
-    if not (same and across):
+    if not ok:
         sys.exit(1)
 
 
