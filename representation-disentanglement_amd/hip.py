@@ -128,8 +128,16 @@ class option:
         set_option(self.name, self.prev)
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's CURRENT stream on this process's device (one process per GPU).  `torch.cuda.current_stream()`
+    costs ~9 us of Python per call (2,000 calls per step); the raw query is a C call."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def _ptr(t):

@@ -531,34 +531,46 @@ def _f_cond_conv2d(x, type_row, weight, fc_w, fc_b, bias, stride, pad, lrelu, dt
 
 
 # ---- autograd formulas (backward = other mrdis ops, so it traces too)
-def _conv2d_setup(ctx, inputs, output):
-    x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd = inputs
-    ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3])
-    ctx.bias_param = bias                         # the Parameter object: its .grad may be an in-kernel gradient sink
-    ctx.dtype = hip.DT_F32 if wb_fwd is None else hip.DT_F32_BF16M
-    ctx.save_for_backward(x, w_tkc, output if lrelu else None, wb_bwd)
+class _Conv2dFn(Function):
+    """autograd kernel of mrdis::conv2d, registered on the Autograd dispatch key.  (torch.library.register_autograd's generic
+    wrapper costs ~45 us of Python per call -- fill_defaults, keyset bookkeeping -- and the step makes 326 such calls; this
+    Function + one redispatch below the Autograd key is ~15 us.)"""
+
+    @staticmethod
+    def forward(ctx, x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd):
+        with torch._C._AutoDispatchBelowAutograd():
+            y = torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+        ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3])
+        ctx.bias_param = bias                         # the Parameter object: its .grad may be an in-kernel gradient sink
+        ctx.dtype = hip.DT_F32 if wb_fwd is None else hip.DT_F32_BF16M
+        ctx.save_for_backward(x, w_tkc, y if lrelu else None, wb_bwd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kh, kw, stride, pad, lrelu, H, W = ctx.geom
+        x, w_tkc, y, wb_bwd = ctx.saved_tensors
+        if lrelu:
+            dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
+        dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad, wb_bwd) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        has_bias = ctx.bias_param is not None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
+            sink = _grad_sink(ctx.bias_param) if has_bias else None
+            if sink is not None:
+                dw = torch.ops.mrdis.conv2d_bwd_weight_sink(x, dy, kh, kw, stride, pad, sink, ctx.dtype)
+            else:
+                dw, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, has_bias, ctx.dtype)
+                if not has_bias:
+                    db = None
+        return dx, dw, None, db, None, None, None, None, None, None, None
 
 
-def _conv2d_backward(ctx, dy):
-    kh, kw, stride, pad, lrelu, H, W = ctx.geom
-    x, w_tkc, y, wb_bwd = ctx.saved_tensors
-    if lrelu:
-        dy = torch.ops.mrdis.lrelu_bwd(dy, y, 0.2)
-    dx = torch.ops.mrdis.conv2d_bwd_data(dy, w_tkc, H, W, kh, kw, stride, pad, wb_bwd) if ctx.needs_input_grad[0] else None
-    dw = db = None
-    has_bias = ctx.bias_param is not None
-    if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[3]):
-        sink = _grad_sink(ctx.bias_param) if has_bias else None
-        if sink is not None:
-            dw = torch.ops.mrdis.conv2d_bwd_weight_sink(x, dy, kh, kw, stride, pad, sink, ctx.dtype)
-        else:
-            dw, db = torch.ops.mrdis.conv2d_bwd_weight(x, dy, kh, kw, stride, pad, has_bias, ctx.dtype)
-            if not has_bias:
-                db = None
-    return dx, dw, None, db, None, None, None, None, None, None, None
+def _conv2d_autograd(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd=None, wb_bwd=None):
+    return _Conv2dFn.apply(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
 
 
-torch.library.register_autograd('mrdis::conv2d', _conv2d_backward, setup_context=_conv2d_setup)
+_lib.impl('conv2d', _conv2d_autograd, 'Autograd')
 
 
 def _mix_setup(ctx, inputs, output):

@@ -12,15 +12,15 @@ import mrdis  # noqa: E402
 
 dev = torch.device('cuda:0')
 mrdis.hip.load()
-B, M, H, W = 32, 4, 256, 256
+B, M, H, W = (int(v) for v in os.environ.get('HOSTPROF_SHAPE', '32,4,256,256').split(','))      # a tiny shape shows the pure host cost
 cfg = dict(mrdis.DEFAULT_CONFIG)
-cfg.update(contrast_list=['T1', 'T1c', 'T2', 'T2_FLAIR'], input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0)
+cfg.update(contrast_list=['T1', 'T1c', 'T2', 'T2_FLAIR'], input_height=H, input_width=W, batch_size=max(B, 16), lambda_adv_s=1.0,
+           compute_dtype=os.environ.get('HOSTPROF_DTYPE', 'f32'))
 cfg = mrdis.derive_config(cfg, dev)
 torch.manual_seed(10); np.random.seed(10)
 model = mrdis.build_model(cfg).train()
 step = mrdis.TrainStep(model, cfg)
-x, mask, mask_img = mrdis.synthetic_batch(B, M, 240, 240, seed=10)
-x = mrdis.fit_to_model(x, (H, W), fill=-10.0)
+x, mask, mask_img = mrdis.synthetic_batch(B, M, H, W, seed=10)
 mask_img = (x[:, 0] == 0).float()
 xd = x.to(dev).contiguous(memory_format=torch.channels_last)
 maskd, mimgd = mask.to(dev), mask_img.to(dev)
@@ -34,4 +34,10 @@ for _ in range(3):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(35)
+import time
+t0 = time.perf_counter()
+for _ in range(5):
+    step(xd, maskd, mimgd, mask)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f'un-profiled: host enqueue {(t1 - t0) / 5 * 1e3:.1f} ms/step, with final sync {(t2 - t0) / 5 * 1e3:.1f} ms/step')
+st.sort_stats('tottime').print_stats(45)
