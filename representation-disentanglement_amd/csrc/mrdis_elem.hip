@@ -692,6 +692,85 @@ __global__ void bilinear_bwd_tight_kernel(const T* __restrict__ dy, int lddy, T*
     }
 }
 
+// ---- exact x2 up-sampling, align_corners = False (nn.Upsample(scale_factor=(2,2)) of the SPADE decoder, model.py:2551): the
+// source index rule gives out[2i] = 0.25 x[max(i-1,0)] + 0.75 x[i], out[2i+1] = 0.75 x[i] + 0.25 x[min(i+1,H-1)] on both axes
+// (same fp32 products and association as the generic kernel).  A thread owns one INPUT pixel (4 channels) and writes its 2x2
+// outputs from the 3x3 neighbourhood: 9 loads per 4 outputs instead of 16, no per-output index arithmetic.
+template <typename T>
+__global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int Hi, int Wi, int C) {
+    const int Q = C / 4;
+    const int i = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;
+    const int im = i > 0 ? i - 1 : 0, ip = i < Hi - 1 ? i + 1 : Hi - 1;
+    const T* rm = x + ((long long)n * Hi + im) * Wi * ldx;
+    const T* rc = x + ((long long)n * Hi + i) * Wi * ldx;
+    const T* rp = x + ((long long)n * Hi + ip) * Wi * ldx;
+    T* y0 = y + ((long long)n * 2 * Hi + 2 * i) * (2 * Wi) * ldy;
+    T* y1 = y0 + (long long)(2 * Wi) * ldy;
+    // row weights of the two output rows: (top, centre, bottom); at the borders the clamped neighbour IS the centre row
+    const float a_t = i > 0 ? 0.25f : 0.f, a_c0 = i > 0 ? 0.75f : 1.f;              // out[2i]   = a_t x[im] + a_c0 x[i]   (src clamped to 0 at i = 0)
+    const float a_b = 0.25f, a_c1 = 0.75f;                                          // out[2i+1] = a_c1 x[i] + a_b x[ip]   (ip = i at the last row)
+    const int items = Wi * Q;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int j = it / Q, q = it - j * Q;
+        const int jm = j > 0 ? j - 1 : 0, jp = j < Wi - 1 ? j + 1 : Wi - 1;
+        const float b_l = j > 0 ? 0.25f : 0.f, b_c0 = j > 0 ? 0.75f : 1.f, b_r = 0.25f, b_c1 = 0.75f;
+        Vec<4> tl, tc, tr, cl_, cc, cr, bl, bc, br, o;
+        tl.load(rm + (long long)jm * ldx + 4 * q); tc.load(rm + (long long)j * ldx + 4 * q); tr.load(rm + (long long)jp * ldx + 4 * q);
+        cl_.load(rc + (long long)jm * ldx + 4 * q); cc.load(rc + (long long)j * ldx + 4 * q); cr.load(rc + (long long)jp * ldx + 4 * q);
+        bl.load(rp + (long long)jm * ldx + 4 * q); bc.load(rp + (long long)j * ldx + 4 * q); br.load(rp + (long long)jp * ldx + 4 * q);
+        // generic form: l0h * (l0w * p00 + l1w * p01) + l1h * (l0w * p10 + l1w * p11), (p0x = upper row, px0 = left column)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.v[k] = a_t * (b_l * tl.v[k] + b_c0 * tc.v[k]) + a_c0 * (b_l * cl_.v[k] + b_c0 * cc.v[k]);
+        o.store(y0 + (long long)(2 * j) * ldy + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.v[k] = a_t * (b_c1 * tc.v[k] + b_r * tr.v[k]) + a_c0 * (b_c1 * cc.v[k] + b_r * cr.v[k]);
+        o.store(y0 + (long long)(2 * j + 1) * ldy + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.v[k] = a_c1 * (b_l * cl_.v[k] + b_c0 * cc.v[k]) + a_b * (b_l * bl.v[k] + b_c0 * bc.v[k]);
+        o.store(y1 + (long long)(2 * j) * ldy + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.v[k] = a_c1 * (b_c1 * cc.v[k] + b_r * cr.v[k]) + a_b * (b_c1 * bc.v[k] + b_r * br.v[k]);
+        o.store(y1 + (long long)(2 * j + 1) * ldy + 4 * q);
+    }
+}
+// adjoint: dx[i][j] = sum over the 4 x 4 output block rows 2i-1 .. 2i+2, columns 2j-1 .. 2j+2 with the separable weights
+// (0.25, 0.75, 0.75, 0.25); at a border the row / column that falls outside is replaced by the clamped one (whose forward weight
+// went to the border pixel).  16 loads per input pixel instead of the 25 of the generic tight kernel.
+template <typename T>
+__global__ void bilinear_up2_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int Hi, int Wi, int C) {
+    const int Q = C / 4;
+    const int i = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    int rr[4] = {2 * i - 1, 2 * i, 2 * i + 1, 2 * i + 2};
+    float wr[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (i == 0) { rr[0] = 0; }                         // out[0] = 1.0 x[0]: the missing 0.25 comes from row 0 itself
+    if (i == Hi - 1) { rr[3] = Ho - 1; }               // out[Ho-1] = 1.0 x[Hi-1]
+    const T* base = dy + (long long)n * Ho * Wo * lddy;
+    T* dxo = dx + ((long long)n * Hi + i) * Wi * lddx;
+    const int items = Wi * Q;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int j = it / Q, q = it - j * Q;
+        int cc[4] = {2 * j - 1, 2 * j, 2 * j + 1, 2 * j + 2};
+        if (j == 0) cc[0] = 0;
+        if (j == Wi - 1) cc[3] = Wo - 1;
+        Vec<4> d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[a][b].load(base + ((long long)rr[a] * Wo + cc[b]) * lddy + 4 * q);
+        Vec<4> acc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                s += wr[a] * ((0.25f * d[a][0].v[k] + 0.75f * d[a][1].v[k]) + (0.75f * d[a][2].v[k] + 0.25f * d[a][3].v[k]));
+            acc.v[k] = s;
+        }
+        acc.store(dxo + (long long)j * lddx + 4 * q);
+    }
+}
+
 static inline int bil_threads(long long items) { return items >= 256 ? 256 : (items > 64 ? 128 : 64); }
 
 template <typename T>
@@ -701,6 +780,11 @@ static int bilinear_fwd_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, 
     if (N > 65535) return MRDIS_EUNSUPPORTED;
     const float sh = bil_scale(Hi, Ho, align_corners), sw = bil_scale(Wi, Wo, align_corners);
     hipStream_t s = (hipStream_t)stream;
+    if (!align_corners && Ho == 2 * Hi && Wo == 2 * Wi && vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C) && !mrdis_opt(MRDIS_OPT_BILGEN)) {
+        hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, x, ldx, y, ldy, Hi, Wi, C);
+        MRDIS_CHECK_LAUNCH();
+        return MRDIS_OK;
+    }
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
         hipLaunchKernelGGL((bilinear_fwd_kernel<4, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * (C / 4))), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else
@@ -718,6 +802,11 @@ static int bilinear_bwd_impl(const T* dy, int lddy, T* dx, int lddx, int N, int 
     // support of an input pixel along one axis: < 2 / scale + 1 output pixels (scale = input step per output pixel)
     const float smin = sh < sw ? sh : sw;
     const bool big = (long long)N * Hi * Wi * C >= 6000000LL;          // measured: 108 vs 129 us at 16 M elements, a wash below 6 M
+    if (!align_corners && Ho == 2 * Hi && Wo == 2 * Wi && vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && !mrdis_opt(MRDIS_OPT_BILGEN)) {
+        hipLaunchKernelGGL((bilinear_up2_bwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, Hi, Wi, C);
+        MRDIS_CHECK_LAUNCH();
+        return MRDIS_OK;
+    }
     const bool tight3 = big && sh >= 1.f && sw >= 1.f, tight5 = big && smin > 0.4975f && !mrdis_opt(MRDIS_OPT_BILGEN);
     if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight3 && !mrdis_opt(MRDIS_OPT_BILGEN))
         hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 3, 3, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
