@@ -77,7 +77,7 @@ def _time_conv(hip, xs, w, b, ys, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def roofline_conv(mrdis, dev, iters=24):
+def roofline_conv(mrdis, dev, iters=24, extras=True):
     """The north-star 3x3 conv forward.  Its output is checked against torch fp32 on the host first.  Timed
     three ways: `achieved` = ROTATING buffers (4 x/y pairs, 1.06 GB > the 256 MiB Infinity Cache, so every launch reads and
     writes HBM), `single_buffer` = one x/y pair re-used (the 236 MB output partly lives in the Infinity Cache between
@@ -98,6 +98,8 @@ def roofline_conv(mrdis, dev, iters=24):
     err = float((ys[0].cpu() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-5, f'north-star conv output differs from torch fp32: rel {err:.2e}'
     us_rot = _time_conv(hip, xs, w, b, ys, iters)
+    if not extras:          # tools/northstar_conv.py under rocprofv3 --pmc: only launches of the north-star shape
+        return {'us_per_launch': round(us_rot, 2), 'achieved': round(NS_BYTES / (us_rot * 1e-6) / 1e9, 1)}
     us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
     del xs, ys
     n6 = NS['N'] * 256 * 256

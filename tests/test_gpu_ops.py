@@ -460,8 +460,9 @@ def test_error_codes(mrdis):
 
 
 @pytest.mark.parametrize('N,C,Ct,H,W', [(3, 7, 28, 20, 24), (2, 1, 1, 160, 192), (2, 7, 7, 9, 300)])
-def test_recon_metrics(mrdis, N, C, Ct, H, W):
-    """evaluate() metrics (util.py:935-978) on the device vs the host restatement; target is a channel
+def test_recon_metrics_vs_unpinned_host_restatement(mrdis, N, C, Ct, H, W):
+    """evaluate() metrics (util.py:935-978) on the device vs the host restatement of the skimage formulas -- which is NOT pinned by
+    the reference (scikit-image is absent from this image, see oracle/ref_model.py): device == restatement, nothing more; target is a channel
     slice of a wider NHWC tensor as in EvalStep."""
     from oracle import ref_model as R
     tfull = rnd((N, Ct, H, W), 31); tfull[:, :, :3] = -10.0
