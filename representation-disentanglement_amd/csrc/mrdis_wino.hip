@@ -52,7 +52,8 @@ struct WinoParams {
 // kernel with (kd, ci) as the reduction axis (a chunk whose plane lies outside the volume contributes zeros).
 template <int CG, int TG, bool D3 = false>
 __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_conv_kernel(const WinoParams p) {
-    constexpr int KC = 8, RS = KC + 1, NT = 64 * CG * TG;
+    constexpr int KC = 8, NT = 64 * CG * TG;
+    constexpr int RWP = 24;                           // row pitch of a raw channel plane (18 pixels used): see the V transform below
     constexpr int BN = 32 * CG, T = 16 * TG;
     constexpr int TS = T + 16, US = BN + 16;          // row pitches: the 4 k-rows of an MFMA operand land 16 banks apart
     constexpr int XR = NT == 512 ? 2 : 3;             // raw float4 items per thread (host: RH * RW * 2 <= XR * NT)
@@ -60,11 +61,12 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* U = smem;                                  // [16][KC][US]
     float* V = U + 16 * KC * US;                      // [16][KC][TS]
-    float* raw = V + 16 * KC * TS;                    // [RH * RW][RS]
+    float* raw = V + 16 * KC * TS;                    // [KC][RH][RWP]: one plane per channel of the chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
     const int cg = wave % CG, tg = wave / CG;
     const int RH = 2 * p.TBH + 2, RW = 2 * p.TBW + 2, npix = RH * RW;
+    const int PIXP = RH * RWP;                        // floats per raw channel plane
 
     int bid = mrdis_xcd_remap(blockIdx.x, gridDim.x);
     const int cot = bid % p.coTiles; bid /= p.coTiles;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
             const int pi = idx >> 1, q = idx & 1;
             const int ry = pi / RW, rx = pi - ry * RW;
             const int h = oy0 - 1 + ry, w_ = ox0 - 1 + rx;
-            xl[it] = pi * RS + 4 * q;
+            xl[it] = 4 * q * PIXP + ry * RWP + rx;       // channel 4q of the pixel; its three neighbours are PIXP apart
             if ((unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
                 xg[it] = ((n * p.H + h) * p.W + w_) * p.ldin + 4 * q;            // host: < 2^31 elements
         }
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
     auto store_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < XR; ++it)
-            if (xl[it] >= 0) { float* d = raw + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+            if (xl[it] >= 0) { float* d = raw + xl[it]; d[0] = xr[it].x; d[PIXP] = xr[it].y; d[2 * PIXP] = xr[it].z; d[3 * PIXP] = xr[it].w; }
 #ifndef WINO_ABL_NOU
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
@@ -165,12 +167,17 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
             const int tc = tid + rep * NT;
             const int tile = tc % T, ch = tc / T;
             const int ty = tile / p.TBW, tx = tile - ty * p.TBW;
-            const float* rp = raw + ((2 * ty) * RW + 2 * tx) * RS + ch;
+            // Raw block as channel planes with a 24-float row pitch, read as two 8-byte pairs per row.  The 32 lanes of a read
+            // group are the tiles (tx 0..7, ty 0..3) of one channel: 2 tx covers 16 consecutive banks and 2 ty * 24 = 48 ty steps
+            // the four rows to distinct quarters of the 64 banks -- conflict-free.  (The former [pixel][9] image read 16 single
+            // floats at 18 tx + 324 ty: 18 tx + 4 ty mod 32 collides up to 4-way; PMC: 1.17 conflict cycles per LDS instruction.)
+            const float* rp = raw + ch * PIXP + (2 * ty) * RWP + 2 * tx;
             float d[4][4], r[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = rp[(i * RW + j) * RS];
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(rp + i * RWP), hi = *reinterpret_cast<const float2*>(rp + i * RWP + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 r[0][j] = d[0][j] - d[2][j]; r[1][j] = d[1][j] + d[2][j];
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64 * CG * TG, (CG * TG == 8) ? 1 : 2) void wino_con
 template <int CG, int TG>
 static size_t wino_lds(int TBH, int TBW) {
     constexpr int KC = 8, BN = 32 * CG, T = 16 * TG;
-    return sizeof(float) * ((size_t)16 * KC * (BN + 16) + (size_t)16 * KC * (T + 16) + (size_t)(2 * TBH + 2) * (2 * TBW + 2) * (KC + 1));
+    return sizeof(float) * ((size_t)16 * KC * (BN + 16) + (size_t)16 * KC * (T + 16) + (size_t)KC * (2 * TBH + 2) * 24);      // raw: [KC][RH][24]
 }
 
 // returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers (caller falls back to the direct kernel)
