@@ -491,7 +491,13 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
         auto store_chunk = [&]() {
 #pragma unroll
             for (int it = 0; it < XR; ++it)
-                if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+                if (xl[it] >= 0) {
+                    float* d = xs + xl[it];
+                    // THIN4: pixel pitch 20 floats -> the quad is 16-byte aligned: one ds_write_b128 (four single stores at that
+                    // pitch collide up to 4-way: 20 pi + 4 q mod 32; PMC 1.5 conflict cycles per LDS instruction)
+                    if constexpr (THIN4) *reinterpret_cast<float4*>(d) = xr[it];
+                    else { d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+                }
 #pragma unroll
             for (int it = 0; it < WR; ++it)
                 if (wg[it] >= 0) *reinterpret_cast<float4*>(ws + wl[it]) = wr[it];
