@@ -129,10 +129,12 @@ int mrdis_conv2d_bwd_data(const void* dy, int lddy, const float* w_tkc, const vo
 
 /* fp32 -> bf16, round to nearest even (the bf16 filter copies above); src 16-byte, dst 8-byte aligned. */
 int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
-/* NHWC view cast between the storage types (P rows of C channels, ld in ELEMENTS of the respective type): the boundary
- * between bf16 activations and the fp32-only kernels.  One of src_dtype / dst_dtype is MRDIS_DT_BF16, the other fp32.  */
-int mrdis_cast_view(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst, int dst_dtype,
-                    long long P, int C, void* stream);
+/* NHWC view cast (P rows; ld in ELEMENTS of the respective type) between the storage types, optionally changing the channel
+ * count: the first min(C_src, C_dst) channels are copied, the rest of a wider destination is zero.  The boundary between bf16
+ * activations and the fp32-only tensors: e.g. the 4-channel anatomy map -> a 16-channel bf16 view the bf16 MFMA kernels accept,
+ * and a 16-channel bf16 head output -> its first 7 channels in fp32.  Any combination of MRDIS_DT_F32 / MRDIS_DT_BF16.          */
+int mrdis_cast_view(const void* src, int ld_src, int src_dtype, int C_src, void* dst, int ld_dst, int dst_dtype, int C_dst,
+                    long long P, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.

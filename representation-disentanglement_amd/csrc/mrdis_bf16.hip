@@ -358,7 +358,7 @@ struct BWgradParams {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int WCI, int WCO, typename TS>
+template <int WCI, int WCO, typename TS, bool HALF = false>      // HALF: Ci = 16, the upper half of the 32-channel image stays zero
 __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
     constexpr int KS = 8 / (WCI * WCO);            // waves sharing a channel block split the position steps
     constexpr int CIW = 32 * WCI, COW = 32 * WCO;
@@ -410,8 +410,9 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
             xr[it].zero();
             if (x_desc[it] >= 0) {
                 const int n = n0 + (x_desc[it] >> 16), h = a0 + p.dh_min + ((x_desc[it] >> 8) & 255), w_ = b0 + p.dw_min + (x_desc[it] & 255);
-                if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
-                    xr[it].load(xin + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + ci0 + 8 * ((tid + it * 512) % XQ));
+                const int cq = ci0 + 8 * ((tid + it * 512) % XQ);
+                if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W && (!HALF || cq < p.Ci))
+                    xr[it].load(xin + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + cq);
             }
         }
 #pragma unroll
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
                 float v = tap_acc(t, r);
                 for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                dst[(long long)row * p.Co] = v;
+                if (!HALF || ci0 + 32 * wci + row < p.Ci) dst[(long long)row * p.Co] = v;
             }
         }
     }
@@ -562,7 +563,7 @@ struct BWgradPlan { BWgradParams p; int wci, wco, KS; size_t lds; long long slab
 
 static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dtype = MRDIS_DT_F32_BF16M) {
     if (stride != 1 || kh * kw > 9 || kh != kw || 2 * pad != kh - 1) return MRDIS_EUNSUPPORTED;    // "same" convolutions only (Ho = H)
-    if (Ci % 32 != 0 || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;
+    if ((Ci % 32 != 0 && !(Ci == 16 && dtype == MRDIS_DT_BF16)) || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;   // Ci = 16: HALF instantiation
     // measured (tools/layer_bench.py --dtype bf16, B = 32): with 32 or fewer couts a wave's 32 x 32 block leaves too few waves per
     // channel block and the fp32 narrow-cout kernels win (sp6.out 593 vs 249 us, sp5.out 310 vs 198 us) unless Cin >= 128
     // (with bf16 activations the alternative is two full-size view casts in front of the fp32 kernel: stay here)
@@ -590,7 +591,7 @@ static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int 
     pl.wci = (Ci % 64 == 0) ? 2 : 1;
     pl.wco = (Co > 32) ? 2 : 1;
     pl.KS = 8 / (pl.wci * pl.wco);
-    p.nCiB = Ci / (32 * pl.wci); p.nCoB = mrdis_cdiv(Co, 32 * pl.wco);
+    p.nCiB = mrdis_cdiv(Ci, 32 * pl.wci); p.nCoB = mrdis_cdiv(Co, 32 * pl.wco);
     const long long npix = (long long)nb * p.TinH * p.TinW;
     if (npix * (4 * pl.wci) > (long long)(pl.wci == 2 ? 4 : 2) * 512) return MRDIS_EUNSUPPORTED;
     pl.lds = 2 * 32 * ((size_t)pl.wco * 128 + (size_t)pl.wci * npix);
@@ -623,13 +624,16 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
     const int grid = p.splits * p.nCiB * p.nCoB;
-#define BW_CASE(a, b_, TS) if (pl.wci == a && pl.wco == b_) { \
+#define BW_CASE_H(a, b_, TS, HF) if (pl.wci == a && pl.wco == b_) { \
         static bool attr_set = false; \
-        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
-        hipLaunchKernelGGL((bwgrad_kernel<a, b_, TS>), dim3(grid), dim3(512), pl.lds, s, p); }
-    if (st_bf16) { BW_CASE(1, 1, __bf16) else BW_CASE(1, 2, __bf16) else BW_CASE(2, 1, __bf16) else BW_CASE(2, 2, __bf16) }
+        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_, TS, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
+        hipLaunchKernelGGL((bwgrad_kernel<a, b_, TS, HF>), dim3(grid), dim3(512), pl.lds, s, p); }
+#define BW_CASE(a, b_, TS) BW_CASE_H(a, b_, TS, false)
+    if (Ci == 16) { BW_CASE_H(1, 1, __bf16, true) else BW_CASE_H(1, 2, __bf16, true) }
+    else if (st_bf16) { BW_CASE(1, 1, __bf16) else BW_CASE(1, 2, __bf16) else BW_CASE(2, 1, __bf16) else BW_CASE(2, 2, __bf16) }
     else { BW_CASE(1, 1, float) else BW_CASE(1, 2, float) else BW_CASE(2, 1, float) else BW_CASE(2, 2, float) }
 #undef BW_CASE
+#undef BW_CASE_H
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)p.ntaps * Ci * Co;
     hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, p.slab, p.splits, n, dw_tck,

@@ -871,31 +871,41 @@ extern "C" int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, 
                           bilinear_bwd_impl((cbf)dy, lddy, (bf)dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, stream));
 }
 
-// NHWC view cast between the two storage types (src -> dst, P rows of C channels): the boundary between bf16 activations
-// and the fp32-only kernels (Cin = 4 / 7 first layers, heads with fewer than 16 output channels, losses)
+// NHWC view cast between the two storage types (src -> dst, P rows), optionally changing the channel count: the first
+// min(C_src, C_dst) channels are copied, the rest of a wider destination is ZERO.  The boundary between bf16 activations and
+// the fp32-only tensors (4-channel anatomy maps, 7-channel inputs / reconstructions): a narrow fp32 view is padded to a 16-channel
+// bf16 one so that the bf16 MFMA kernels take the layer, and the padded result is sliced back.
 template <int V, typename TS, typename TD>
-__global__ void cast_view_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, long long P, int C) {
-    const int Q = C / V;
+__global__ void cast_view_kernel(const TS* __restrict__ src, int lds_, int Cs, TD* __restrict__ dst, int ldd, int Cd, long long P) {
+    const int Q = Cd / V;
     EW_LOOP(P * Q) {
         const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
-        Vec<V> a; a.load(src + r * lds_ + c); a.store(dst + r * ldd + c);
+        Vec<V> a;
+        if (c + V <= Cs) a.load(src + r * lds_ + c);
+        else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) a.v[k] = (c + k < Cs) ? ld1(src + r * lds_ + c + k) : 0.f;
+        }
+        a.store(dst + r * ldd + c);
     }
 }
 template <typename TS, typename TD>
-static int cast_view_impl(const TS* src, int lds_, TD* dst, int ldd, long long P, int C, void* stream) {
-    if (!src || !dst || P < 1 || C < 1 || lds_ < C || ldd < C) return MRDIS_EINVAL;
-    if (vec4_ok(src, lds_, C) && vec4_ok(dst, ldd, C))
-        hipLaunchKernelGGL((cast_view_kernel<4, TS, TD>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, P, C);
+static int cast_view_impl(const TS* src, int lds_, int Cs, TD* dst, int ldd, int Cd, long long P, void* stream) {
+    if (!src || !dst || P < 1 || Cs < 1 || Cd < 1 || lds_ < Cs || ldd < Cd) return MRDIS_EINVAL;
+    if (vec4_ok(dst, ldd, Cd) && (Cs >= Cd ? vec4_ok(src, lds_, Cd) : (lds_ % 4 == 0 && Cs % 4 == 0 && (((uintptr_t)src & (4 * sizeof(TS) - 1)) == 0))))
+        hipLaunchKernelGGL((cast_view_kernel<4, TS, TD>), dim3(ew_blocks(P * Cd / 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
     else
-        hipLaunchKernelGGL((cast_view_kernel<1, TS, TD>), dim3(ew_blocks(P * C)), dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, P, C);
+        hipLaunchKernelGGL((cast_view_kernel<1, TS, TD>), dim3(ew_blocks(P * Cd)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
-extern "C" int mrdis_cast_view(const void* src, int ld_src, int src_dtype, void* dst, int ld_dst, int dst_dtype, long long P, int C, void* stream) {
+extern "C" int mrdis_cast_view(const void* src, int ld_src, int src_dtype, int C_src, void* dst, int ld_dst, int dst_dtype, int C_dst,
+                               long long P, void* stream) {
     const bool sb = src_dtype == MRDIS_DT_BF16, db = dst_dtype == MRDIS_DT_BF16;
-    if (sb && !db) return cast_view_impl((cbf)src, ld_src, (float*)dst, ld_dst, P, C, stream);
-    if (!sb && db) return cast_view_impl((const float*)src, ld_src, (bf)dst, ld_dst, P, C, stream);
-    return MRDIS_EINVAL;
+    if (sb && !db) return cast_view_impl((cbf)src, ld_src, C_src, (float*)dst, ld_dst, C_dst, P, stream);
+    if (!sb && db) return cast_view_impl((const float*)src, ld_src, C_src, (bf)dst, ld_dst, C_dst, P, stream);
+    if (sb && db) return cast_view_impl((cbf)src, ld_src, C_src, (bf)dst, ld_dst, C_dst, P, stream);
+    return cast_view_impl((const float*)src, ld_src, C_src, (float*)dst, ld_dst, C_dst, P, stream);
 }
 
 #define SM_MAXC 8

@@ -43,7 +43,7 @@ _SIGS = {
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
-    'mrdis_cast_view': (_I, [_P, _I, _I, _P, _I, _I, _L, _I, _P]),
+    'mrdis_cast_view': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
     'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 11 + [_P]),
     'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _I, _P]),
@@ -180,15 +180,17 @@ def _dt(*tensors):
     raise MrdisError(f'activation views must be all fp32 or all bf16, got {sorted(str(k) for k in kinds)}')
 
 
-def cast_view(x, dtype):
-    """NHWC view -> new NHWC tensor of the other storage type (fp32 <-> bf16, round to nearest even)."""
+def cast_view(x, dtype, channels=None):
+    """NHWC view -> new NHWC tensor of storage type `dtype` (fp32 / bf16, round to nearest even) with `channels` channels
+    (default: unchanged): the first min(C, channels) are copied, a wider result is zero-padded."""
     lib = load()
     x, ldx = nhwc(x)
-    if x.dtype == dtype:
-        return x
     N, C, H, W = x.shape
-    y = empty_nhwc(N, C, H, W, x.device, dtype)
-    _chk(lib.mrdis_cast_view(_ptr(x), ldx, _dt(x), _ptr(y), C, _dt(y), N * H * W, C, _stream()), 'cast_view')
+    Cd = C if channels is None else int(channels)
+    if x.dtype == dtype and Cd == C:
+        return x
+    y = empty_nhwc(N, Cd, H, W, x.device, dtype)
+    _chk(lib.mrdis_cast_view(_ptr(x), ldx, _dt(x), C, _ptr(y), Cd, _dt(y), Cd, N * H * W, _stream()), 'cast_view')
     return y
 
 
@@ -327,7 +329,7 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     if rc == -2 and dt == DT_BF16:
         # a tile geometry the bf16 kernel cannot stage (or a view it cannot address): the fp32 kernel between two view casts
         y32 = conv2d_fwd(cast_view(x, torch.float32), w_tck, bias, kh, kw, stride, pad, lrelu)
-        lib.mrdis_cast_view(_ptr(y32), Co, DT_F32, _ptr(y), ldy, DT_BF16, N * Ho * Wo, Co, _stream())
+        lib.mrdis_cast_view(_ptr(y32), Co, DT_F32, Co, _ptr(y), ldy, DT_BF16, Co, N * Ho * Wo, _stream())
         return out
     _chk(rc, 'conv2d_fwd')
     return out

@@ -182,20 +182,22 @@ def storage_bf16():
 
 
 class _CastView(Function):
-    """fp32 <-> bf16 copy of an NHWC view (mrdis_cast_view); the adjoint casts the gradient back."""
+    """copy of an NHWC view in another storage type and / or channel count (mrdis_cast_view: first min(C, channels) channels, zero
+    padding beyond); the adjoint casts / slices / pads the gradient back."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
-        ctx.src = x.dtype
-        return hip.cast_view(x, dtype)
+    def forward(ctx, x, dtype, channels):
+        ctx.src = (x.dtype, x.shape[1])
+        return hip.cast_view(x, dtype, channels)
 
     @staticmethod
     def backward(ctx, g):
-        return hip.cast_view(g, ctx.src), None
+        return hip.cast_view(g, ctx.src[0], ctx.src[1]), None, None
 
 
-def cast_view(x, dtype):
-    return x if x.dtype == dtype else _CastView.apply(x, dtype)
+def cast_view(x, dtype, channels=None):
+    channels = x.shape[1] if channels is None else int(channels)
+    return x if (x.dtype == dtype and channels == x.shape[1]) else _CastView.apply(x, dtype, channels)
 
 
 def to_storage(x):
@@ -224,10 +226,22 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
     wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
     if _COMPUTE_DTYPE == hip.DT_F32_BF16M:
         return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
-    eligible = hip.bconv_eligible(Ci, Co)
-    if eligible:
-        y = torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
-        return y
+    if hip.bconv_eligible(Ci, Co):
+        return torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+    # Narrow side (the 4-channel anatomy maps into the SPADE `si_layers`, the 64 -> 4 and 16 -> 7 heads): pad the narrow channel
+    # count to 16 with zeros -- the view cast writes the zero channels, the filter gets zero rows / columns -- and the bf16 MFMA
+    # kernels take the layer in all three directions (the matrix pipe has 16x the fp32 rate: the padding is free, the layer is
+    # HBM-bound); a padded output is sliced back to fp32.  Stride-1 layers only: the bf16 weight-gradient kernel has no stride 2.
+    Ci_p, Co_p = max(Ci, 16), max(Co, 16)
+    if stride == 1 and Ci_p % 16 == 0 and hip.bconv_eligible(Ci_p, Co_p):
+        def padded():
+            import torch.nn.functional as F
+            return (w_tck, F.pad(w_tck, (0, Co_p - Co, 0, Ci_p - Ci)), F.pad(w_tkc.detach(), (0, Ci_p - Ci, 0, Co_p - Co)),
+                    None if bias is None else F.pad(bias, (0, Co_p - Co)))
+        _, wp_tck, wp_tkc, bias_p = cached_mix(('pad16', id(w_tck), None if bias is None else id(bias)), padded)
+        wpb_fwd, wpb_bwd = bf16_filters(wp_tck, wp_tkc)
+        y = torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16, Ci_p), wp_tck, wp_tkc, bias_p, kh, kw, stride, pad, lrelu, wpb_fwd, wpb_bwd)
+        return y if Co_p == Co else cast_view(y, torch.float32, Co)
     y = torch.ops.mrdis.conv2d(cast_view(x, torch.float32), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
     return cast_view(y, torch.bfloat16) if Co >= 16 else y
 
