@@ -1041,6 +1041,17 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
 // MRDIS_WINO: 0 never | 1 (default) measured policy | 2 wherever the kernel applies.  Policy (tools/layer_bench.py, B = 32
 // layer zoo): Winograd wins for Cout >= 32 and Cin >= 16 once the grid fills the chip (>= 256 workgroups): 1.13x on
 // 32 -> 32, 1.3-1.5x on the 64..512-channel layers; a 16-cout layer wastes half of its 32-wide cout tile (slower).
+// software-pipelined variant for Cout > 32 (mrdis_wino2.hip); option wino_pipe = 0 keeps the phase-by-phase kernel everywhere
+int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
+static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s) {
+    if (Co > 32 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {
+        const int rc = mrdis_run_wino2(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
+    return mrdis_run_wino(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s);
+}
 static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
     const int mode = (int)mrdis_opt(MRDIS_OPT_WINO);          // MRDIS_WINO at load; mrdis_set_option("wino", v) afterwards
     if (mode == 0 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
@@ -1070,7 +1081,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
     const bool bf = bf16m_wanted(dtype, w_bf16_tkc, Ci, Co);
     if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;                // bf16 views: only the bf16 kernels may touch them
     if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
-        rc = mrdis_run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     TapConvParams p{};
@@ -1113,7 +1124,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
         if (!st_bf16 && c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
-            rc = mrdis_run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
+            rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
         TapConvParams p = base;
