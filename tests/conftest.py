@@ -36,3 +36,4 @@ def _restore_library_options():
     if m is not None and getattr(m.hip, '_lib', None) is not None:
         m.hip.set_option('wino', int(os.environ.get('MRDIS_WINO', '1')))
         m.hip.set_option('nt_mb', int(os.environ.get('MRDIS_NT_MB', '128')))
+        m.hip.set_option('wino_pipe', int(os.environ.get('MRDIS_WINO_PIPE', '1')))

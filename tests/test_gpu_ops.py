@@ -139,6 +139,43 @@ def test_conv_winograd_forced(mrdis, case):
     close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
 
 
+PIPE_CASES = [
+    (8, 64, 128, 96, 80),     # 480 blocks on <= 256 persistent workgroups: every workgroup walks several blocks, both cout tiles
+    (3, 36, 72, 50, 18),      # channel tail in the last chunk, cout tail in the second 64-wide tile, partial tile blocks
+    (2, 8, 40, 23, 37),       # one chunk per block: the pipeline turns over at every iteration
+    (1, 256, 64, 33, 47),     # 32 chunks per block, odd extents
+    (5, 128, 256, 16, 16),    # 4 cout tiles, one tile block per image
+]
+
+
+@pytest.mark.parametrize('case', PIPE_CASES, ids=[str(c) for c in PIPE_CASES])
+def test_winograd_pipelined_kernel(mrdis, case):
+    """mrdis_wino2.hip (option wino_pipe = 1, the default for Cout > 32) against torch and against the phase-by-phase
+    kernel it replaces (wino_pipe = 0): forward with bias + LeakyReLU, data gradient (flipped taps, no bias), and a
+    channel-slice input view whose last pixel ends exactly at the buffer descriptor's record count."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    x = rnd((N, Ci, H, W), 1).requires_grad_(True)
+    w = rnd((Co, Ci, 3, 3), 2, 0.2).requires_grad_(True)
+    b = rnd((Co,), 3, 0.1)
+    y = F.conv2d(x, w, b, 1, 1)
+    gy = rnd(tuple(y.shape), 4)
+    y.backward(gy)
+    w_tck, w_tkc = to_tck(w.detach()).to(dev()), to_tkc(w.detach()).to(dev())
+    hip.set_option('wino', 2)
+    out = {}
+    for pipe in (0, 1):
+        hip.set_option('wino_pipe', pipe)
+        out[pipe] = (hip.conv2d_fwd(cl(x.detach()), w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True),
+                     hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), 3, 3, 1, 1))
+    close(out[1][0], F.leaky_relu(y, 0.2), rtol=1e-4, what='pipelined fwd')
+    close(out[1][1], x.grad, rtol=1e-4, what='pipelined dgrad')
+    close(out[1][0], out[0][0], rtol=2e-6, what='pipelined vs phase kernel, fwd')          # same arithmetic, same order
+    close(out[1][1], out[0][1], rtol=2e-6, what='pipelined vs phase kernel, dgrad')
+    wide = cl(torch.cat([rnd((N, 8, H, W), 9), x.detach()], 1))          # channel slice: ld = Ci + 8, view ends at the allocation's end
+    close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
+
+
 @pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 32, 16, 240, 232), (1, 16, 8, 321, 333), (3, 48, 12, 200, 180)])
 def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
     """mrdis_wgrad16.hip: weight / bias gradient of 3x3 s1 layers with 8..16 couts on large maps (sp6.out), 16-channel input

@@ -19,6 +19,18 @@ def stats(stats_csv, trace_csv, out, title):
     for r in rows[:30]:
         lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
                      f"{float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+    fam = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        name = r['Name']
+        name = name.split('<')[0].split('(')[0].replace('void ', '').strip()
+        if name.startswith('_Z'):                      # mangled template instantiation: keep the identifier only
+            import re
+            m = re.match(r'_Z(\d+)', name)
+            name = name[2 + len(m.group(1)):2 + len(m.group(1)) + int(m.group(1))] if m else name
+        fam[name][0] += int(r['Calls']); fam[name][1] += float(r['TotalDurationNs'])
+    lines += ['', '## every kernel family (template arguments folded), by total time', '', '| kernel | calls | total ms | % |', '|---|---|---|---|']
+    for k, a in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f'| `{k[:70]}` | {a[0]} | {a[1] / 1e6:.3f} | {100 * a[1] / tot:.2f} |')
     agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for r in csv.DictReader(open(trace_csv)):
         name = r['Kernel_Name'].split('(')[0][:60]

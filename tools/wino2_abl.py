@@ -18,7 +18,7 @@ for (B, ci, co, H, W) in [(32, 128, 256, 64, 64), (32, 32, 64, 256, 256)]:
     bias = torch.randn(co, device=dev)
     out = []
     for abl, name in ((-1, 'full'), (3, 'noUV'), (8, 'noFiltLoads'), (32, 'noRawLoads'), (40, 'noGlobal'),
-                      (43, 'MFMA+opreads only'),  (-1, 'full again')):
+                      (43, 'MFMA+opreads only'), (256, 'no stores'),  (-1, 'full again')):
         hip.set_option('debug_mode', abl)
         out.append(f'{name} {timeit(lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1)):.1f}')
     hip.set_option('debug_mode', -1)
