@@ -21,6 +21,7 @@
 // The data gradient of such a layer is the same convolution with the taps reversed and [tap][Co][Ci] filters.
 // Results differ from the direct kernel by fp32 rounding of the transforms (~1e-6 relative; parity bar 1e-3).
 #include "mrdis_common.h"
+#include "mrdis_wino.h"
 #include <stdlib.h>
 
 struct WinoParams {
@@ -359,14 +360,6 @@ int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias,
 // B = Z_xi[4 tiles x 16 co]; a wave owns 16 ci x 32 co for all 16 xi (128 accumulators), so G^T dU G is lane-local
 // and a workgroup writes nine [ci][co] planes (not sixteen) into its split-K slab; a fixed-order sum over the slabs
 // finishes dw_tck (bit-reproducible).  The bias gradient (column sums of dy) rides along in the Z pass.
-struct WinoWgradParams {
-    const float* x; const float* dy; float* slab; float* bias_slab;
-    int N, H, W, Ci, ldx, Co, lddy;
-    int nby, nbx, nblocks;        // tile blocks (2 x 4 tiles) per image row / column, total
-    int nCiB, nCoB, splits;
-    int D, kd;                    // hybrid 3-D form: N counts planes (samples x D); x is read from plane + kd - 1 of the same sample
-};
-
 // D3: slice kd of a 3x3x3 filter gradient = the 2-D gradient between dy plane d and x plane d + kd - 1 (three launches)
 template <int WCI, int WCO, bool D3 = false>       // waves along ci (16 each) x waves along co (32 each)
 __global__ __launch_bounds__(64 * WCI * WCO, (WCI * WCO == 8) ? 1 : 2) void wino_wgrad_kernel(const WinoWgradParams p) {
@@ -651,7 +644,13 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
         attr_set = true;
     }
     const int nblk = p.splits * p.nCiB * p.nCoB;
-    if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p);
+    int rc2 = MRDIS_EUNSUPPORTED;
+    if (pl.wci == 4 && pl.wco == 2 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {         // software-pipelined form (mrdis_wino2.hip)
+        rc2 = mrdis_launch_wino_wgrad2(p, s);
+        if (rc2 != MRDIS_OK && rc2 != MRDIS_EUNSUPPORTED) return rc2;
+    }
+    if (rc2 == MRDIS_OK) {}
+    else if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p);
     else if (pl.wci == 4) hipLaunchKernelGGL((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p);
     else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p);
     MRDIS_CHECK_LAUNCH();

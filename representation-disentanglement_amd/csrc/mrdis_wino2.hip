@@ -38,6 +38,10 @@ constexpr int BIASBUF = 1024;                          // the bias vector, stage
 constexpr size_t WINO2_LDS = sizeof(float) * (4 * UVBUF + 2 * RAWBUF + BIASBUF);
 template <int V_> struct IC { static constexpr int value = V_; };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// An LDS pointer the compiler may not fold constants into: accesses at ptr[k * XI] then use the instruction's 16-bit offset
+// field; left alone, hipcc builds one address register per 2 KB plane beyond the first 64 KB (27 spilled registers in wgrad2).
+// (The laundering is done on the element INDEX: a laundered pointer would lose its LDS address space and turn into flat loads.)
+__device__ __forceinline__ int w2_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
 constexpr unsigned W2_OOB = 0xfffffff0u;               // byte offset past every record count: the buffer load returns zeros
 }  // namespace
 
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     // ---- transform pieces (called whole in the prologue, one piece per MFMA step in the loop)
     float d[4][4], r[4][4], t_[4][3];
     auto v_row = [&](const float* Rr, int i) {
-        const float2 lo = *reinterpret_cast<const float2*>(Rr + v_src + i * RWP), hi = *reinterpret_cast<const float2*>(Rr + v_src + i * RWP + 2);
+        const float2 lo = *reinterpret_cast<const float2*>(Rr + i * RWP), hi = *reinterpret_cast<const float2*>(Rr + i * RWP + 2);
         d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
     };
     auto v_col = [&](int j) {                         // B^T d: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
         r[2][j] = d[2][j] - d[1][j]; r[3][j] = d[1][j] - d[3][j];
     };
     auto v_out = [&](float* Vn, int a) {
-        float* vp = Vn + 4 * a * XI + t_dst;
+        float* vp = Vn + 4 * a * XI;                  // Vn / Un include this thread's t_dst, Rr its v_src
         vp[0] = r[a][0] - r[a][2]; vp[XI] = r[a][1] + r[a][2]; vp[2 * XI] = r[a][2] - r[a][1]; vp[3 * XI] = r[a][1] - r[a][3];
     };
     auto u_col = [&]() {                              // G g: G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
         }
     };
     auto u_out = [&](float* Un, int a) {
-        float* up = Un + 4 * a * XI + t_dst;
+        float* up = Un + 4 * a * XI;
         up[0] = t_[a][0]; up[XI] = 0.5f * (t_[a][0] + t_[a][1] + t_[a][2]);
         up[2 * XI] = 0.5f * (t_[a][0] - t_[a][1] + t_[a][2]); up[3 * XI] = t_[a][2];
     };
@@ -188,15 +192,15 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     raw_store(IC<0>{}, Rb);
     u_col();
 #pragma unroll
-    for (int a = 0; a < 4; ++a) u_out(Ub, a);
+    for (int a = 0; a < 4; ++a) u_out(Ub + t_dst, a);
     filt_next(); load_filt();                         // filter(1), as if issued in step 11 of an iteration -1
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v_row(Rb, i);
+    for (int i = 0; i < 4; ++i) v_row(Rb + v_src, i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v_col(j);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) v_out(Vb, a);
+    for (int a = 0; a < 4; ++a) v_out(Vb + t_dst, a);
     raw_store(IC<1>{}, Rb + RAWBUF);
     load_raw(IC<1>{});
     __syncthreads();
@@ -205,9 +209,10 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     // one iteration; P = its parity = the U / V / raw buffers and the register set it LOADS into
     auto iteration = [&](auto P_) {
         constexpr int P = decltype(P_)::value;
-        const float* Uc = Ub + P * UVBUF; const float* Vc = Vb + P * UVBUF;
-        float* Un = Ub + (P ^ 1) * UVBUF; float* Vn = Vb + (P ^ 1) * UVBUF;
-        const float* Rr = Rb + (P ^ 1) * RAWBUF;      // raw block of chunk i + 1
+        const float* Ua0 = smem + w2_opaque(P * UVBUF + a0_off); const float* Ua1 = smem + w2_opaque(P * UVBUF + a1_off);
+        const float* Vbv = smem + w2_opaque((2 + P) * UVBUF + b_off);
+        float* Un = smem + w2_opaque((P ^ 1) * UVBUF + t_dst); float* Vn = smem + w2_opaque((2 + (P ^ 1)) * UVBUF + t_dst);
+        const float* Rr = smem + w2_opaque(4 * UVBUF + (P ^ 1) * RAWBUF + v_src);      // raw block of chunk i + 1
         float* Rw = Rb + P * RAWBUF;                  // raw block of chunk i + 2 goes where chunk i's was
         // Global loads go out ONE OR TWO PER STEP: a burst of 11 vector-memory instructions per wave fills the CU's memory
         // queue, the in-order waves stall on their loads and the matrix pipe idles behind them (measured: 65 us of a 375 us
@@ -218,16 +223,16 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
         float2 a0[3], a1[3], bv[3];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
-            a0[s_] = *reinterpret_cast<const float2*>(Uc + s_ * XI + a0_off);
-            a1[s_] = *reinterpret_cast<const float2*>(Uc + s_ * XI + a1_off);
-            bv[s_] = *reinterpret_cast<const float2*>(Vc + s_ * XI + b_off);
+            a0[s_] = *reinterpret_cast<const float2*>(Ua0 + s_ * XI);
+            a1[s_] = *reinterpret_cast<const float2*>(Ua1 + s_ * XI);
+            bv[s_] = *reinterpret_cast<const float2*>(Vbv + s_ * XI);
         }
 #pragma unroll
         for (int s_ = 0; s_ < 16; ++s_) {
             if (s_ + 2 < 16 && !(ABL & 16)) {
-                a0[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Uc + (s_ + 2) * XI + a0_off);
-                a1[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Uc + (s_ + 2) * XI + a1_off);
-                bv[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Vc + (s_ + 2) * XI + b_off);
+                a0[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Ua0 + (s_ + 2) * XI);
+                a1[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Ua1 + (s_ + 2) * XI);
+                bv[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Vbv + (s_ + 2) * XI);
             }
             // the slice of the next chunk's transforms that rides in this step's MFMA shadows
             if (s_ == 2) load_raw1(IC<P>{}, 0);
@@ -334,6 +339,251 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
 #undef W2A
 #endif
     hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// =========================================================================== pipelined Winograd weight gradient
+// wino_wgrad_kernel<4, 2> (mrdis_wino.hip) with the same pipeline: a workgroup owns a 64 x 64 block of (ci, co) and every
+// `splits`-th block of 2 x 4 tiles; iteration i multiplies V(i) [16 points][8 tiles][64 ci] by Z(i) [16][8][64 co] (64 MFMAs per
+// wave, reduction axis = tile) while the same waves build V(i+1) = B^T d B from the raw x block of iteration i+1 (LDS) and
+// Z(i+1) = A dY A^T from the four dy values loaded one iteration earlier, store the raw block of iteration i+2 and issue the
+// loads of iterations i+3 (x) and i+2 (dy), one per MFMA step.  V / Z planes use the rotation layout of wino2_kernel (the tile
+// index is the MFMA k axis); the raw block is [pixel][64 ci] with 8 floats of skew per block row, so the transform's reads
+// (lanes = 16 ci x 2 tile rows) and the 16-byte staging writes are conflict-free.  2 x 32 + 2 x 32 + 2 x 15.2 KB = 158.4 KB of LDS.
+#include "mrdis_wino.h"
+
+namespace {
+constexpr int G_RH = 6, G_RW = 10, G_NPX = G_RH * G_RW;
+constexpr int G_RAW = G_NPX * 64 + G_RH * 8;            // floats of one raw x block
+constexpr size_t WGRAD2_LDS = sizeof(float) * (4 * UVBUF + 2 * G_RAW);
+__device__ __forceinline__ int g_raw_off(int ry, int rx) { return (ry * G_RW + rx) * 64 + ry * 8; }
+}  // namespace
+
+__global__ __launch_bounds__(512, 1) void wino_wgrad2_kernel(const WinoWgradParams p, const int s_n, const int s_by, const int s_bx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Vb = smem;                           // [2][16][XI]
+    float* const Zb = smem + 2 * UVBUF;               // [2][16][XI]
+    float* const Rb = smem + 4 * UVBUF;               // [2][G_RAW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int wi = wave & 3, wo = wave >> 2;
+    int b_ = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // the (cib, cob) workgroups of a split read the same x / dy tiles: same XCD, same L2
+    const int cob = b_ % p.nCoB; b_ /= p.nCoB;
+    const int cib = b_ % p.nCiB;
+    const int split = b_ / p.nCiB;
+    const int ci0 = cib * 64, co0 = cob * 64;
+
+    // transform role: tile = 4 ks + kq_t (tile row ks, tile column kq_t of the 2 x 4 block), channel m of the 64 (ci for V, co for Z)
+    const int ks_t = lane & 1, m_t = 32 * (wave >> 2) + (lane >> 1), kq_t = wave & 3;
+    const int t_dst = kq_t * 128 + ((2 * m_t + ks_t + 32 * kq_t) & 127);
+    const int v_src = g_raw_off(2 * ks_t, 2 * kq_t) + m_t;
+    // MFMA role: A = V (rows ci = 16 wi + l16), B = Z (columns co = 32 wo + 16 b + l16), k = tile
+    const int a_off = kq * 128 + ((2 * (16 * wi + l16) + 32 * kq) & 127);
+    const int b0_off = kq * 128 + ((2 * (32 * wo + l16) + 32 * kq) & 127);
+    const int b1_off = kq * 128 + ((2 * (32 * wo + 16 + l16) + 32 * kq) & 127);
+    // staging role: two (pixel, 4-channel group) items of the 6 x 10 raw block (960 items)
+    int s_l[2], s_rc[2];                              // LDS offset (or -1), (row << 8) | column in the raw block
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NT, pi = idx >> 4, ry = pi / G_RW, rx = pi - ry * G_RW;
+        s_rc[it] = (ry << 8) | rx;
+        s_l[it] = (idx < G_NPX * 16) ? g_raw_off(ry, rx) + 4 * (idx & 15) : -1;
+    }
+    const int q4 = 4 * (tid & 15);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)(4LL * ((long long)(p.N * p.H) * p.W - 1) * p.ldx + 4LL * p.Ci), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)(4LL * ((long long)(p.N * p.H) * p.W - 1) * p.lddy + 4LL * p.Co), 0x00020000);
+
+    // block cursors: (n, by, bx) advance by `splits` blocks per iteration = (s_n, s_by, s_bx) with carries (wave-uniform, scalar)
+    struct Cur { int n, by, bx; };
+    auto advance = [&](Cur& c) {
+        c.bx += s_bx; if (c.bx >= p.nbx) { c.bx -= p.nbx; ++c.by; }
+        c.by += s_by; if (c.by >= p.nby) { c.by -= p.nby; ++c.n; }
+        c.n += s_n;
+    };
+    Cur rcur, dcur;
+    { int t = split; rcur.bx = t % p.nbx; t /= p.nbx; rcur.by = t % p.nby; rcur.n = t / p.nby; dcur = rcur; }
+
+    // Offsets are computed in the step that issues the load (short live ranges: the kernel sits at the 256-register limit)
+    float4 xr[2][2];
+    auto load_raw1 = [&](auto S_, int it) {           // item `it` of the raw block of the cursor's block; the cursor advances after item 1
+        constexpr int S = decltype(S_)::value;
+        const int h = 4 * rcur.by - 1 + (s_rc[it] >> 8), w_ = 8 * rcur.bx - 1 + (s_rc[it] & 255);
+        const bool ok = s_l[it] >= 0 && rcur.n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+        const unsigned o = ok ? 4u * (unsigned)(((rcur.n * p.H + h) * p.W + w_) * p.ldx + ci0 + q4) : W2_OOB;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)o, 0, 0);
+        xr[S][it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        if (it == 1) advance(rcur);
+    };
+    auto load_raw = [&](auto S_) { load_raw1(S_, 0); load_raw1(S_, 1); };
+    auto raw_store = [&](auto S_, float* Rw) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            if (s_l[it] >= 0) *reinterpret_cast<float4*>(Rw + s_l[it]) = xr[S][it];
+    };
+
+    float dr[4];
+    auto load_dy1 = [&](int e) {                      // dy(row a, column b) of this thread's tile in the cursor's block; advances after the fourth
+        const int a = e >> 1, b = e & 1;
+        const int oy = 4 * dcur.by + 2 * ks_t + a, ox = 8 * dcur.bx + 2 * kq_t + b;
+        const bool ok = dcur.n < p.N && oy < p.H && ox < p.W;
+        const unsigned o = ok ? 4u * (unsigned)(((dcur.n * p.H + oy) * p.W + ox) * p.lddy + co0 + m_t) : W2_OOB;
+        dr[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dy, (int)o, 0, 0));
+        if (e == 3) advance(dcur);
+    };
+
+    float d[4][4], r[4][4], tz[4][2], bsum = 0.f;
+    auto v_row = [&](const float* Rr, int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = Rr[g_raw_off(i, j)];      // Rr includes this thread's v_src
+    };
+    auto v_col = [&](int j) {
+        r[0][j] = d[0][j] - d[2][j]; r[1][j] = d[1][j] + d[2][j];
+        r[2][j] = d[2][j] - d[1][j]; r[3][j] = d[1][j] - d[3][j];
+    };
+    auto v_out = [&](float* Vn, int a) {             // Vn / Zn include this thread's t_dst
+        float* vp = Vn + 4 * a * XI;
+        vp[0] = r[a][0] - r[a][2]; vp[XI] = r[a][1] + r[a][2]; vp[2 * XI] = r[a][2] - r[a][1]; vp[3 * XI] = r[a][1] - r[a][3];
+    };
+    auto z_col = [&]() {                              // A dY: A = [1 0; 1 1; 1 -1; 0 -1]; the bias gradient (sum of dy) rides along
+        const float d00 = dr[0], d01 = dr[1], d10 = dr[2], d11 = dr[3];
+        bsum += (d00 + d01) + (d10 + d11);
+        tz[0][0] = d00; tz[0][1] = d01; tz[1][0] = d00 + d10; tz[1][1] = d01 + d11;
+        tz[2][0] = d00 - d10; tz[2][1] = d01 - d11; tz[3][0] = -d10; tz[3][1] = -d11;
+    };
+    auto z_out = [&](float* Zn, int i) {
+        float* zp = Zn + 4 * i * XI;
+        zp[0] = tz[i][0]; zp[XI] = tz[i][0] + tz[i][1]; zp[2 * XI] = tz[i][0] - tz[i][1]; zp[3 * XI] = -tz[i][1];
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // ---- prologue: V(0), Z(0), raw(1) in LDS, raw(2) in register set 1, dy(1) in `dr`; cursors at raw(3), dy(2)
+    load_raw(IC<0>{});
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_dy1(e);
+    load_raw(IC<1>{});
+    raw_store(IC<0>{}, Rb);
+    z_col();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) z_out(Zb + t_dst, a);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_dy1(e);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_row(Rb + v_src, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_col(j);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v_out(Vb + t_dst, a);
+    raw_store(IC<1>{}, Rb + G_RAW);
+    load_raw(IC<1>{});
+    __syncthreads();
+
+    const int niter = (p.nblocks - split + p.splits - 1) / p.splits;
+    auto iteration = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const float* Va = smem + w2_opaque(P * UVBUF + a_off);
+        const float* Zb0 = smem + w2_opaque((2 + P) * UVBUF + b0_off); const float* Zb1 = smem + w2_opaque((2 + P) * UVBUF + b1_off);
+        float* Vn = smem + w2_opaque((P ^ 1) * UVBUF + t_dst); float* Zn = smem + w2_opaque((2 + (P ^ 1)) * UVBUF + t_dst);
+        const float* Rr = smem + w2_opaque(4 * UVBUF + (P ^ 1) * G_RAW + v_src);     // raw block of iteration i + 1
+        float* Rw = Rb + P * G_RAW;                   // raw block of iteration i + 2
+        // raw(i + 3) is loaded in steps 1 and 5, dy(i + 2) in steps 11-14, once Z(i + 1) has left `dr`
+        float2 av[3], b0[3], b1[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            av[s_] = *reinterpret_cast<const float2*>(Va + s_ * XI);
+            b0[s_] = *reinterpret_cast<const float2*>(Zb0 + s_ * XI);
+            b1[s_] = *reinterpret_cast<const float2*>(Zb1 + s_ * XI);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            if (s_ + 2 < 16) {
+                av[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Va + (s_ + 2) * XI);
+                b0[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Zb0 + (s_ + 2) * XI);
+                b1[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Zb1 + (s_ + 2) * XI);
+            }
+            if (s_ == 1) load_raw1(IC<P>{}, 0);
+            if (s_ == 5) load_raw1(IC<P>{}, 1);
+            if (s_ < 4) v_row(Rr, s_);
+            else if (s_ == 4) { v_col(0); v_col(1); }
+            else if (s_ == 5) { v_col(2); v_col(3); }
+            else if (s_ < 10) v_out(Vn, s_ - 6);
+            else if (s_ == 10) z_col();
+            else if (s_ < 15) { load_dy1(s_ - 11); z_out(Zn, s_ - 11); }
+            else raw_store(IC<P ^ 1>{}, Rw);
+            const int c_ = s_ % 3;
+            acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].x, b0[c_].x, acc[s_][0], 0, 0, 0);
+            acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].x, b1[c_].x, acc[s_][1], 0, 0, 0);
+            acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, b0[c_].y, acc[s_][0], 0, 0, 0);
+            acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, b1[c_].y, acc[s_][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int i = 0; i < niter; i += 2) {
+        iteration(IC<0>{});
+        if (i + 1 < niter) iteration(IC<1>{});
+    }
+
+    // ---- epilogue: dg = G^T dU G per lane; D rows (4 kq + r) = ci, col l16 = co
+    float* out = p.slab + (long long)split * 9 * p.Ci * p.Co;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int co = co0 + 32 * wo + 16 * b + l16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = ci0 + 16 * wi + 4 * kq + q;
+            float t_[3][4];                           // rows: G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u0 = acc[j][b][q], u1 = acc[4 + j][b][q], u2 = acc[8 + j][b][q], u3 = acc[12 + j][b][q];
+                t_[0][j] = u0 + 0.5f * (u1 + u2); t_[1][j] = 0.5f * (u1 - u2); t_[2][j] = 0.5f * (u1 + u2) + u3;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float g0 = t_[a][0] + 0.5f * (t_[a][1] + t_[a][2]);
+                const float g1 = 0.5f * (t_[a][1] - t_[a][2]);
+                const float g2 = 0.5f * (t_[a][1] + t_[a][2]) + t_[a][3];
+                out[((long long)(3 * a + 0) * p.Ci + ci) * p.Co + co] = g0;
+                out[((long long)(3 * a + 1) * p.Ci + ci) * p.Co + co] = g1;
+                out[((long long)(3 * a + 2) * p.Ci + ci) * p.Co + co] = g2;
+            }
+        }
+    }
+    if (p.bias_slab != nullptr && cib == 0) {
+        // the eight threads (ks, kq_t) that hold channel m of this workgroup's 64 couts meet in LDS, fixed order
+        float* red = smem;
+        red[tid] = bsum;                              // every wave is past its last MFMA read of this region: the loop ends with a barrier
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) t += red[(4 * (tid >> 5) + k) * 64 + 2 * (tid & 31) + e];
+            p.bias_slab[(long long)split * p.Co + co0 + tid] = t;
+        }
+    }
+}
+
+int mrdis_launch_wino_wgrad2(const WinoWgradParams& p, hipStream_t s) {
+    if (p.D != 0 || p.Ci % 64 != 0 || p.Co % 64 != 0 || p.ldx % 4 != 0 || (((uintptr_t)p.x) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)p.N * p.H * p.W * p.ldx >= 0x3fffffffLL || (long long)p.N * p.H * p.W * p.lddy >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wino_wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGRAD2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        attr_set = true;
+    }
+    int t = p.splits;
+    const int s_bx = t % p.nbx; t /= p.nbx;
+    const int s_by = t % p.nby;
+    const int s_n = t / p.nby;
+    hipLaunchKernelGGL(wino_wgrad2_kernel, dim3(p.splits * p.nCiB * p.nCoB), dim3(NT), WGRAD2_LDS, s, p, s_n, s_by, s_bx);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
