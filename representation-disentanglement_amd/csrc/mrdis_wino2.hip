@@ -251,6 +251,14 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
                 acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c_].y, bv[c_].y, acc[s_][0], 0, 0, 0);
                 acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c_].y, bv[c_].y, acc[s_][1], 0, 0, 0);
             } else { acc[s_][0][0] += a0[c_].x * bv[c_].x + a0[c_].y * bv[c_].y; acc[s_][1][0] += a1[c_].x * bv[c_].y; }
+            // interleave the step's fillers with its MFMAs (left alone hipcc issues one MFMA, all fillers, then three MFMAs back to back)
+#pragma unroll
+            for (int g_ = 0; g_ < 4; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // then at most one vector-memory read,
+                __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);      // two LDS operations
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // and three VALU instructions in its shadow
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -521,6 +529,13 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad2_kernel(const WinoWgradPara
             acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].x, b1[c_].x, acc[s_][1], 0, 0, 0);
             acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, b0[c_].y, acc[s_][0], 0, 0, 0);
             acc[s_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, b1[c_].y, acc[s_][1], 0, 0, 0);
+#pragma unroll
+            for (int g_ = 0; g_ < 4; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();

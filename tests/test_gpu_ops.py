@@ -176,6 +176,31 @@ def test_winograd_pipelined_kernel(mrdis, case):
     close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
 
 
+@pytest.mark.parametrize('case', [(2, 64, 64, 23, 37), (3, 128, 64, 50, 18), (4, 128, 128, 32, 32), (9, 64, 192, 40, 72), (1, 64, 64, 2, 3)],
+                         ids=str)
+def test_winograd_pipelined_wgrad(mrdis, case):
+    """wino_wgrad2_kernel (mrdis_wino2.hip; 64 x 64 (ci, co) blocks, option wino_pipe = 1) against torch and against the
+    phase-by-phase kernel: weight and bias gradient, odd extents (partial 2 x 4 tile blocks), more tile blocks than splits
+    (every workgroup walks several), a map smaller than one tile block."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    x = rnd((N, Ci, H, W), 1); gy = rnd((N, Co, H, W), 2)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    b = torch.zeros(Co, requires_grad=True)
+    F.conv2d(x, w, b, 1, 1).backward(gy)
+    hip.set_option('wino', 2)
+    out = {}
+    for pipe in (0, 1):
+        hip.set_option('wino_pipe', pipe)
+        out[pipe] = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+    close(out[1][0], to_tck(w.grad), rtol=2e-4, what='pipelined wgrad')
+    close(out[1][1], b.grad, rtol=2e-4, what='pipelined dbias')
+    close(out[1][0], out[0][0], rtol=1e-5, what='pipelined vs phase kernel')
+    sink = torch.ones(Co, device=dev())
+    hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True, bias_sink=sink)
+    close(sink - 1, b.grad, rtol=2e-4, what='dbias accumulated into a sink')
+
+
 @pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 32, 16, 240, 232), (1, 16, 8, 321, 333), (3, 48, 12, 200, 180)])
 def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
     """mrdis_wgrad16.hip: weight / bias gradient of 3x3 s1 layers with 8..16 couts on large maps (sp6.out), 16-channel input
