@@ -1059,6 +1059,9 @@ static bool wino_wanted(int N, int H, int W, int Ci, int Co, int kh, int kw, int
     if (Ci < 16 || Co < 32) return false;
     const int cg = Co > 32 ? 2 : 1;
     const long long nblk = (long long)N * mrdis_cdiv((H + 1) / 2, 8) * mrdis_cdiv((W + 1) / 2, 8) * mrdis_cdiv(Co, 32 * cg);
+    // measured (tools/layer_bench.py, B = 32, pipelined kernel): 16x16 maps with 128 blocks still win (ana.up_4 105 -> 92 us, sp2.gamma+beta
+    // 58 -> 50 us); 8x8 maps fill a quarter of a 16x16-output block and lose (sp1: 36 -> 47 us), 64 blocks lose (66 -> 87 us)
+    if (cg == 2 && nblk >= 128 && H >= 16 && W >= 16) return true;
     return nblk >= (cg == 2 ? 256 : 512);
 }
 
@@ -2120,8 +2123,8 @@ static bool wino_wgrad_wanted(int N, int H, int W, int Ci, int Co, int kh, int k
     if (mrdis_wino_wgrad_workspace(N, H, W, Ci, Co) == 0) return false;
     if (mode == 2) return true;
     // measured (tools/layer_bench.py, B = 32): 1.3-1.7x on every 64 x 64 and 32 x 64 blocked layer down to 16x16 maps; the
-    // 64 x 32 blocking (Cout = 32) amortises the input transform over too few couts unless Cin >= 128
-    if (Co % 64 != 0 && Ci < 128) return false;
+    // 64 x 32 blocking (Cout = 32) amortises the input transform over too few couts unless Cin >= 64 (sp5.out 64 -> 32: 195 -> 138 us)
+    if (Co % 64 != 0 && Ci < 64) return false;
     return (long long)N * ((H + 3) / 4) * ((W + 7) / 8) >= 256;
 }
 
