@@ -49,6 +49,9 @@ int mrdis_version(void);
  *   "wino"  (MRDIS_WINO, default 1): 0 = direct convolution kernels only, 1 = fused Winograd F(2x2,3x3) where it measured
  *           faster (csrc/mrdis_conv.hip wino_wanted), 2 = Winograd wherever the kernel applies (tests);
  *   "nt_mb" (MRDIS_NT_MB, default 128): Winograd outputs of at least this many MB are written with non-temporal stores;
+ *   "wino_pipe" (MRDIS_WINO_PIPE, default 1): 1 = the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip: forward / data
+ *           gradient for Cout > 32, weight gradient for Ci, Co multiples of 64), 0 = the phase-by-phase kernels everywhere
+ *           (same arithmetic; results agree to 1e-5);
  *   "debug_*": kernel-selection overrides used by tools/ (see csrc/mrdis_elem.hip OPT_DEFS).
  * set: 0 or MRDIS_EINVAL (unknown name); get: the value, or MRDIS_EINVAL for an unknown name.  Not synchronised with launches
  * in flight on other threads. */

@@ -57,7 +57,8 @@ __device__ __forceinline__ void store4(__bf16* p, const float4 v) {
 
 // KC channels per chunk; 4 waves as WAVES_C (cout) x 4/WAVES_C (positions); a wave owns WP x WC blocks of 32 positions x 32 couts;
 // TS = storage type of the activations (float: MRDIS_DT_F32_BF16M, __bf16: MRDIS_DT_BF16)
-template <int KC, int WAVES_C, int WP, int WC, typename TS>
+// ABL (timing-only builds, -DBCONV_ABLATIONS; results wrong): 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 no operand reads, 16 no epilogue stores
+template <int KC, int WAVES_C, int WP, int WC, typename TS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
     constexpr int BN = 32 * WC * WAVES_C;          // x 32 * WP * WAVES_P positions
     constexpr int PITCH = KC + 8;                 // bf16 elements per LDS row
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
             xr[it].zero();
             if (x_desc[it] >= 0) {
                 const int n = n0 + (x_desc[it] >> 16), h = h_org + ((x_desc[it] >> 8) & 255), w_ = w_org + (x_desc[it] & 255);
-                if (n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
+                if (!(ABL & 2) && n < p.N && (unsigned)h < (unsigned)p.Hin && (unsigned)w_ < (unsigned)p.Win)
                     xr[it].load(in + ((long long)(n * p.Hin + h) * p.Win + w_) * p.ldin + c0 + 8 * ((tid + it * 256) % QX));
             }
         }
@@ -138,21 +139,22 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
             for (int it = 0; it < WR; ++it) {
                 bf16x8 z; for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
                 wr[it] = z;
-                if (w_off[it] >= 0) wr[it] = *reinterpret_cast<const bf16x8*>(wsrc + w_off[it] + c0);
+                if (!(ABL & 2) && w_off[it] >= 0) wr[it] = *reinterpret_cast<const bf16x8*>(wsrc + w_off[it] + c0);
             }
         }
     };
+    bool first_store = true;
     auto store_item = [&](bool have_w) {
 #pragma unroll
         for (int it = 0; it < XR; ++it) {
             const int idx = tid + it * 256;
-            if (idx < nx) *reinterpret_cast<bf16x8*>(xs + (idx / QX) * PITCH + 8 * (idx % QX)) = xr[it].bf();
+            if (idx < nx && !((ABL & 4) && !first_store)) *reinterpret_cast<bf16x8*>(xs + (idx / QX) * PITCH + 8 * (idx % QX)) = xr[it].bf();
         }
         if (have_w) {
 #pragma unroll
             for (int it = 0; it < WR; ++it) {
                 const int idx = tid + it * 256;
-                if (idx < nw) *reinterpret_cast<bf16x8*>(ws + (idx / QX) * PITCH + 8 * (idx % QX)) = wr[it];
+                if (idx < nw && !((ABL & 4) && !first_store)) *reinterpret_cast<bf16x8*>(ws + (idx / QX) * PITCH + 8 * (idx % QX)) = wr[it];
             }
         }
     };
@@ -189,16 +191,19 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
             for (int ks = 0; ks < KC / 16; ++ks) {
                 bf16x8 bf[WP], af[WC];
 #pragma unroll
-                for (int i = 0; i < WP; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(xs + abase[i] + toff + 16 * ks);
+                for (int i = 0; i < WP; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(xs + abase[i] + ((ABL & 8) ? 0 : toff + 16 * ks));
 #pragma unroll
-                for (int j = 0; j < WC; ++j) af[j] = *reinterpret_cast<const bf16x8*>(wt + 32 * j * PITCH + 16 * ks);
+                for (int j = 0; j < WC; ++j) af[j] = *reinterpret_cast<const bf16x8*>(((ABL & 8) ? wbase : wt + 16 * ks) + 32 * j * PITCH);
 #pragma unroll
                 for (int j = 0; j < WC; ++j)
 #pragma unroll
-                    for (int i = 0; i < WP; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[i], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < WP; ++i) {
+                        if (ABL & 1) acc[j][i][0] += (float)af[j][0] * (float)bf[i][0];
+                        else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], bf[i], acc[j][i], 0, 0, 0);
+                    }
             }
         }
+        first_store = false;
         if (chunk == g.nchunks - 1) {
             // ---- epilogue: D[cout][position]; a lane owns one position per block and the couts 8g + 4*half .. +3 (g = 0..3)
             int n0, a0, b0; tile_origin(tile, n0, a0, b0);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
                         float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
                         if (p.bias) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + co); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
                         if (lrelu) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
-                        store4(dst + co, v);
+                        if (!(ABL & 16) || v.x == 1.2345f) store4(dst + co, v);
                     }
             }
         }
@@ -233,6 +238,15 @@ static int launch_bconv_t(const TapConvParams& p, const BConvGeom& g, int grid, 
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
+#ifdef BCONV_ABLATIONS
+    if (KC == 32 && WP == 2 && WC == 2) {
+        const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
+#define BA(a) if (abl == a) { hipFuncSetAttribute((const void*)bconv_kernel<KC, WAVES_C, WP, WC, TS, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+        hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC, TS, a>), dim3(grid), dim3(256), lds, s, p, g); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        BA(1) BA(2) BA(4) BA(8) BA(16) BA(6) BA(14) BA(15) BA(30)
+#undef BA
+    }
+#endif
     hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC, TS>), dim3(grid), dim3(256), lds, s, p, g);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -252,10 +266,16 @@ static int bconv_ncu() {
     return ncu;
 }
 
+int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s);      // mrdis_bf16p.hip
+
 // Eligibility: reduction axis a multiple of 16, 16-byte aligned views, cout a multiple of 4 (16-byte stores).
 int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
     if (!p.w_bf16 || (p.dtype != MRDIS_DT_F32_BF16M && p.dtype != MRDIS_DT_BF16)) return MRDIS_EUNSUPPORTED;
     const bool st_bf16 = p.dtype == MRDIS_DT_BF16;
+    if (st_bf16 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {               // 3x3 s1 layers on bf16 activations: the pipelined kernel (mrdis_bf16p.hip)
+        const int rc3 = mrdis_run_bconv3(p, s);
+        if (rc3 != MRDIS_EUNSUPPORTED) return rc3;
+    }
     if (p.Cin % 16 != 0 || p.Cout % 4 != 0 || p.Cout < 16 || (long long)MRDIS_MAX_TAPS * p.Cin * p.Cout >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     // 16-byte input pieces (8 bf16 or 2 x 4 fp32), 4-channel output stores
     if (p.ldin % (st_bf16 ? 8 : 4) != 0 || p.ldout % 4 != 0 || (((uintptr_t)p.in | (uintptr_t)p.w_bf16) & 15) != 0 ||

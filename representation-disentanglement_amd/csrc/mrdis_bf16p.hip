@@ -1,0 +1,272 @@
+// mrdis_bf16p.hip -- software-pipelined bf16 convolution for the 3x3 / stride 1 / pad 1 layers with bf16 activations
+// (MRDIS_DT_BF16), Cin a multiple of 32, maps at least 32 wide: the layers that are most of `compute_dtype: bf16`.
+//
+// bconv_kernel (mrdis_bf16.hip) runs an item (256 positions x 64 couts x 32 channels x 9 taps) as: barrier | registers -> LDS |
+// barrier | issue next item's loads | 72 MFMAs.  Timing-only builds of it on 128 -> 256 at 64x64, B = 32 (tools/bconv_abl.py):
+// 115 us = ~28 us of MFMAs + operand reads, ~35 us waiting on the global loads (fifteen 16-byte loads per thread issued in one
+// burst), ~10 us of LDS stores, ~40 us of loop skeleton (address arithmetic of the staging, barriers, epilogue) -- back to back, although
+// two workgroups share a CU.  Here the pipeline of wino2_kernel (mrdis_wino2.hip) carries the same arithmetic:
+//
+//   * ONE persistent workgroup of 8 waves per CU walks (tile, cout tile) units and their 32-channel chunks; a wave owns one row of
+//     32 positions of the 8 x 32 tile x all 32 WC couts (v_mfma_f32_32x32x16_bf16, A = filter, B = pixels: D[cout][position]);
+//   * the LDS images xs[pixel][32 + 8] and ws[tap][cout][32 + 8] (bf16) are double-buffered and there is ONE barrier per item:
+//     while item i is multiplied, item i+1 goes from registers to LDS and the loads of item i+2 are issued, one 16-byte load or
+//     store per (tap, k-step) of the MFMA sequence;
+//   * every global load is a buffer load whose offset lies beyond the record count where there is nothing to read (zero padding,
+//     ragged tiles, cout tails): no branch, counted vmcnt waits; staging offsets are item-invariant per thread plus two scalars;
+//   * the bias sits in LDS; the epilogue converts to bf16 and writes 8 bytes per lane and 4-cout group.
+//
+// Results are bit-identical to bconv_kernel's (same products, same accumulation order).
+#include "mrdis_tapconv.h"
+
+typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bp_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int P_KC = 32, P_PITCH = P_KC + 8, P_TH = 8, P_TW = 32, P_TINH = P_TH + 2, P_TINW = P_TW + 2, P_NPIX = P_TINH * P_TINW;
+constexpr int P_XS = P_NPIX * P_PITCH;                 // bf16 elements of one x image
+constexpr int P_BIAS = 1024;
+constexpr unsigned P_OOB = 0xfffffff0u;
+template <int V_> struct PIC { static constexpr int value = V_; };
+__device__ __forceinline__ int p_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
+}  // namespace
+
+struct BConv3Params {
+    const void* in; const void* w; const float* bias; void* out;       // bf16 activations, bf16 filter [tap][Cout][Cin], fp32 bias
+    int N, H, W, Cin, ldin, Cout, ldout;
+    int tilesA, tilesB, coTiles, units;               // units = N * tilesA * tilesB * coTiles
+    int nchunks, lrelu;
+    int dh[9], dw[9], widx[9];
+    unsigned in_bytes, w_bytes;
+};
+
+// ABL (timing-only, -DBCONV3_ABLATIONS): 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 operand reads at one address, 16 no output stores
+template <int WC, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
+    constexpr int BN = 32 * WC, NT = 512;
+    constexpr int WS = 9 * BN * P_PITCH;              // bf16 elements of one filter image
+    constexpr int XR = (P_NPIX * 4 + NT - 1) / NT;    // 16-byte x pieces per thread (3)
+    constexpr int WR = (9 * BN * 4 + NT - 1) / NT;    // 16-byte filter pieces per thread (5 | 3)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem_raw);      // [2][WS] filter images, then [2][P_XS] x images, then the bias (fp32)
+    float* const Bs = reinterpret_cast<float*>(lds + 2 * WS + 2 * P_XS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
+    // MFMA role: positions (ty = wave, tx = e) of the 8 x 32 tile, k-group `half`
+    const int b_base = (wave * P_TINW + e) * P_PITCH + 8 * half;          // + tap offset + 16 ks, in the x image
+    const int a_base = e * P_PITCH + 8 * half;                            // + (tap * BN + 32 j) * PITCH + 16 ks, in the filter image
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = ((p.dh[t] + 1) * P_TINW + (p.dw[t] + 1)) * P_PITCH;
+
+    // staging roles (item-invariant): LDS element offset of each piece and its global offset relative to the item's origin
+    int x_lds[XR]; unsigned x_rel[XR]; int x_yx[XR];   // x_yx = (iy << 8) | ix, or -1
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * NT, pi = idx >> 2, q = idx & 3;
+        const int iy = pi / P_TINW, ix = pi - iy * P_TINW;
+        x_yx[it] = (idx < P_NPIX * 4) ? ((iy << 8) | ix) : -1;
+        x_lds[it] = pi * P_PITCH + 8 * q;
+        x_rel[it] = 2u * (unsigned)((iy * p.W + ix) * p.ldin + 8 * q);
+    }
+    int w_lds[WR]; unsigned w_rel[WR]; int w_co[WR];   // w_co: cout within the tile, or -1
+#pragma unroll
+    for (int it = 0; it < WR; ++it) {
+        const int idx = tid + it * NT, row = idx >> 2, q = idx & 3;
+        const int t = row / BN, co = row - t * BN;
+        w_co[it] = (idx < 9 * BN * 4) ? co : -1;
+        w_lds[it] = row * P_PITCH + 8 * q;
+        w_rel[it] = 2u * (unsigned)((p.widx[t < 9 ? t : 0] * p.Cout + co) * p.Cin + 8 * q);
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    for (int c = tid; c < P_BIAS; c += NT) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+
+    const int grid = gridDim.x;
+    const int u0 = mrdis_xcd_remap(blockIdx.x, grid);
+    const int nmine = (p.units - u0 + grid - 1) / grid;           // host: grid <= units
+    const int total = nmine * p.nchunks;
+    auto decode = [&](int j, int& n, int& a0, int& b0, int& co0) {
+        int u = u0 + j * grid;
+        const int cot = u % p.coTiles; u /= p.coTiles;
+        const int tb = u % p.tilesB; u /= p.tilesB;
+        const int ta = u % p.tilesA;
+        n = u / p.tilesA; a0 = ta * P_TH; b0 = tb * P_TW; co0 = cot * BN;
+    };
+
+    // ---- load cursor: unit lj, chunk lc; per-unit scalars recomputed when the unit changes
+    int lj = 0, lc = 0;
+    int l_h0 = 0, l_w0 = 0, l_co0 = 0; unsigned l_xorg = 0; bool l_live = false;
+    auto load_unit = [&]() {
+        l_live = lj < nmine;
+        if (l_live) {
+            int n, a0, b0, co0; decode(lj, n, a0, b0, co0);
+            l_h0 = a0 - 1; l_w0 = b0 - 1; l_co0 = co0;
+            l_xorg = 2u * (unsigned)(((n * p.H + l_h0) * p.W + l_w0) * p.ldin);        // wraps for halo origins; added mod 2^32 below
+        }
+    };
+    bp_u32x4 xr[2][XR], wr[2][WR];
+    unsigned xo[XR], wo[WR];                           // byte offsets of the NEXT item's pieces
+    auto next_offsets = [&]() {
+        const unsigned c0b = 2u * (unsigned)(lc * P_KC);
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int h = l_h0 + (x_yx[it] >> 8), w_ = l_w0 + (x_yx[it] & 255);
+            const bool ok = l_live && x_yx[it] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            xo[it] = ok ? l_xorg + x_rel[it] + c0b : P_OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < WR; ++it) {
+            const bool ok = l_live && w_co[it] >= 0 && l_co0 + w_co[it] < p.Cout;
+            wo[it] = ok ? w_rel[it] + 2u * (unsigned)(l_co0 * p.Cin) + c0b : P_OOB;
+        }
+        if (++lc == p.nchunks) { lc = 0; ++lj; load_unit(); }
+    };
+    auto load_x = [&](auto S_, int it) { constexpr int S = decltype(S_)::value; if (ABL & 2) xr[S][it] = bp_u32x4{0u, 0u, 0u, 0u}; else xr[S][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)xo[it], 0, 0); };
+    auto load_w = [&](auto S_, int it) { constexpr int S = decltype(S_)::value; if (ABL & 2) wr[S][it] = bp_u32x4{0u, 0u, 0u, 0u}; else wr[S][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wo[it], 0, 0); };
+    auto store_x = [&](auto S_, __bf16* xs, int it) {
+        constexpr int S = decltype(S_)::value;
+        if (x_yx[it] >= 0 && !(ABL & 4)) *reinterpret_cast<bp_u32x4*>(xs + x_lds[it]) = xr[S][it];
+    };
+    auto store_w = [&](auto S_, __bf16* ws, int it) {
+        constexpr int S = decltype(S_)::value;
+        if (w_co[it] >= 0 && !(ABL & 4)) *reinterpret_cast<bp_u32x4*>(ws + w_lds[it]) = wr[S][it];
+    };
+
+    f32x16 acc[WC];
+#pragma unroll
+    for (int j = 0; j < WC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- prologue: item 0 in LDS buffer 0, item 1 in register set 1, cursor at item 2
+    load_unit();
+    next_offsets();
+#pragma unroll
+    for (int it = 0; it < XR; ++it) load_x(PIC<0>{}, it);
+#pragma unroll
+    for (int it = 0; it < WR; ++it) load_w(PIC<0>{}, it);
+    next_offsets();
+#pragma unroll
+    for (int it = 0; it < XR; ++it) load_x(PIC<1>{}, it);
+#pragma unroll
+    for (int it = 0; it < WR; ++it) load_w(PIC<1>{}, it);
+#pragma unroll
+    for (int it = 0; it < XR; ++it) store_x(PIC<0>{}, lds + 2 * WS, it);
+#pragma unroll
+    for (int it = 0; it < WR; ++it) store_w(PIC<0>{}, lds, it);
+    __syncthreads();
+
+    int mj = 0, mc = 0;
+    auto iteration = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const __bf16* wa = lds + p_opaque(P * WS + a_base);
+        const __bf16* xb = lds + p_opaque(2 * WS + P * P_XS + b_base);
+        __bf16* wn = lds + (P ^ 1) * WS;              // item i + 1 goes here (from register set P ^ 1)
+        __bf16* xn = lds + 2 * WS + (P ^ 1) * P_XS;
+        next_offsets();                               // item i + 2: loaded into register set P in the first XR + WR steps
+        bp_bf16x8 af[2][WC], bf[2];
+#pragma unroll
+        for (int j = 0; j < WC; ++j) af[0][j] = *reinterpret_cast<const bp_bf16x8*>(wa + 32 * j * P_PITCH);
+        bf[0] = *reinterpret_cast<const bp_bf16x8*>(xb + toff[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            const int t = s_ >> 1, ks = s_ & 1, c_ = s_ & 1;
+            if (s_ + 1 < 18 && !(ABL & 8)) {
+                const int t1 = (s_ + 1) >> 1, ks1 = (s_ + 1) & 1;
+#pragma unroll
+                for (int j = 0; j < WC; ++j) af[c_ ^ 1][j] = *reinterpret_cast<const bp_bf16x8*>(wa + (t1 * BN + 32 * j) * P_PITCH + 16 * ks1);
+                bf[c_ ^ 1] = *reinterpret_cast<const bp_bf16x8*>(xb + toff[t1] + 16 * ks1);
+            }
+            // staging slice of this step: loads of item i + 2 first, then the LDS stores of item i + 1
+            if (s_ < XR) load_x(PIC<P>{}, s_);
+            else if (s_ < XR + WR) load_w(PIC<P>{}, s_ - XR);
+            else if (s_ < 2 * XR + WR) store_x(PIC<P ^ 1>{}, xn, s_ - XR - WR);
+            else if (s_ < 2 * XR + 2 * WR) store_w(PIC<P ^ 1>{}, wn, s_ - 2 * XR - WR);
+            (void)t; (void)ks;
+#pragma unroll
+            for (int j = 0; j < WC; ++j) { if (ABL & 1) acc[j][0] += (float)af[(ABL & 8) ? 0 : c_][j][0] * (float)bf[(ABL & 8) ? 0 : c_][0]; else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ABL & 8) ? 0 : c_][j], bf[(ABL & 8) ? 0 : c_], acc[j], 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+
+        if (++mc == p.nchunks) {
+            // ---- epilogue of unit mj: D[cout][position]; a lane owns position (wave, e) and the couts 8 g + 4 half .. + 3 (g = 0..3) of each block
+            int n, a0, b0, co0; decode(mj, n, a0, b0, co0);
+            mc = 0; ++mj;
+            const int a = a0 + wave, b = b0 + e;
+            const bool pos_ok = a < p.H && b < p.W;
+            __bf16* dst = reinterpret_cast<__bf16*>(p.out) + ((long long)(n * p.H + a) * p.W + b) * p.ldout;
+#pragma unroll
+            for (int j = 0; j < WC; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + 32 * j + 8 * q + 4 * half;
+                    const float4 bb = *reinterpret_cast<const float4*>(Bs + (co < P_BIAS - 3 ? co : 0));
+                    float v[4] = {acc[j][4 * q] + bb.x, acc[j][4 * q + 1] + bb.y, acc[j][4 * q + 2] + bb.z, acc[j][4 * q + 3] + bb.w};
+                    if (p.lrelu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+                    }
+                    bp_bf16x4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                    if (pos_ok && co < p.Cout && (!(ABL & 16) || v[0] == 1.2345f)) *reinterpret_cast<bp_bf16x4*>(dst + co) = o;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            }
+        }
+    };
+    for (int i = 0; i < total; i += 2) {
+        iteration(PIC<0>{});
+        if (i + 1 < total) iteration(PIC<1>{});
+    }
+}
+
+// MRDIS_EUNSUPPORTED: the caller (mrdis_run_bconv) takes bconv_kernel
+int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s) {
+    if (t.dtype != MRDIS_DT_BF16 || !t.w_bf16 || t.ntaps != 9 || t.is != 1 || t.os != 1 || t.oh0 != 0 || t.ow0 != 0) return MRDIS_EUNSUPPORTED;
+    if (t.A != t.Hin || t.B != t.Win || t.Hout != t.Hin || t.Wout != t.Win) return MRDIS_EUNSUPPORTED;
+    if (t.Cin % 32 != 0 || t.Cout % 4 != 0 || t.Cout < 16 || t.Cout > P_BIAS || t.Win < 32 || t.ldin % 8 != 0 || t.ldout % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if ((((uintptr_t)t.in | (uintptr_t)t.w_bf16) & 15) != 0 || ((uintptr_t)t.out & 7) != 0) return MRDIS_EUNSUPPORTED;
+    BConv3Params p{};
+    int wt = 0;
+    for (int k = 0; k < 9; ++k) {
+        if (t.dh[k] < -1 || t.dh[k] > 1 || t.dw[k] < -1 || t.dw[k] > 1) return MRDIS_EUNSUPPORTED;
+        p.dh[k] = t.dh[k]; p.dw[k] = t.dw[k]; p.widx[k] = t.widx[k];
+        if (t.widx[k] + 1 > wt) wt = t.widx[k] + 1;
+    }
+    const long long in_b = 2LL * (((long long)t.N * t.Hin * t.Win - 1) * t.ldin + t.Cin), w_b = 2LL * wt * t.Cin * t.Cout;
+    if (in_b >= 0xffffffe0LL || w_b >= 0xffffffe0LL) return MRDIS_EUNSUPPORTED;
+    p.in = t.in; p.w = t.w_bf16; p.bias = t.bias; p.out = t.out;
+    p.N = t.N; p.H = t.Hin; p.W = t.Win; p.Cin = t.Cin; p.ldin = t.ldin; p.Cout = t.Cout; p.ldout = t.ldout;
+    p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
+    const int WC = t.Cout > 32 ? 2 : 1, BN = 32 * WC;
+    p.tilesA = mrdis_cdiv(t.Hin, P_TH); p.tilesB = mrdis_cdiv(t.Win, P_TW); p.coTiles = mrdis_cdiv(t.Cout, BN);
+    const long long units = (long long)t.N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = t.Cin / P_KC; p.lrelu = (t.epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)bconv3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = units < n_cu ? (int)units : n_cu;
+    const size_t lds = 2 * (size_t)(2 * 9 * BN * P_PITCH + 2 * P_XS) + sizeof(float) * P_BIAS;
+#ifdef BCONV3_ABLATIONS
+    if (WC == 2) {
+        const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
+#define BA(a) if (abl == a) { (void)hipFuncSetAttribute((const void*)bconv3_kernel<2, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((bconv3_kernel<2, a>), dim3(grid), dim3(512), lds, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        BA(1) BA(2) BA(4) BA(8) BA(16) BA(6) BA(14) BA(15) BA(30)
+#undef BA
+    }
+#endif
+    if (WC == 2) hipLaunchKernelGGL(bconv3_kernel<2>, dim3(grid), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(bconv3_kernel<1>, dim3(grid), dim3(512), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

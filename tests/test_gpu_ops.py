@@ -139,6 +139,31 @@ def test_conv_winograd_forced(mrdis, case):
     close(hip.conv2d_fwd(wide[:, 8:], w_tck, None, 3, 3, 1, 1), y - b.view(1, -1, 1, 1), rtol=1e-4, what='strided view')
 
 
+@pytest.mark.parametrize('case', [(2, 32, 64, 23, 37), (3, 64, 40, 50, 33), (1, 96, 16, 9, 70), (6, 128, 256, 64, 64), (2, 64, 32, 40, 96)], ids=str)
+def test_bf16_pipelined_conv_bit_identical(mrdis, case):
+    """bconv3_kernel (mrdis_bf16p.hip: 3x3 s1 on bf16 activations, Cin % 32 == 0, maps >= 32 wide; option wino_pipe = 1) computes the
+    same products in the same order as bconv_kernel (wino_pipe = 0): forward (+ bias, LeakyReLU) and data gradient must be
+    bit-identical, ragged tiles, cout tails and several units per workgroup included; and both agree with torch on bf16-rounded operands."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    B16 = torch.bfloat16
+    x = rnd((N, Ci, H, W), 1); w = rnd((Co, Ci, 3, 3), 2, 0.2); b = rnd((Co,), 3, 0.1); gy = rnd((N, Co, H, W), 4)
+    xb, gyb = cl(x).to(B16), cl(gy).to(B16)
+    w_tck, w_tkc = to_tck(w).to(dev()), to_tkc(w).to(dev())
+    wb_f, wb_b = hip.cast_bf16(w_tkc), hip.cast_bf16(w_tck)
+    out = {}
+    for pipe in (0, 1):
+        hip.set_option('wino_pipe', pipe)
+        y = hip.conv2d_fwd(xb, w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f)
+        g = hip.conv2d_bwd_data(gyb, w_tkc, (H, W), 3, 3, 1, 1, w_bf16=wb_b) if Co % 32 == 0 else None
+        out[pipe] = (y, g)
+    assert out[1][0].dtype == B16 and torch.equal(out[0][0], out[1][0])
+    if out[1][1] is not None:
+        assert torch.equal(out[0][1], out[1][1])
+    ref = F.leaky_relu(F.conv2d(x.to(B16).float(), w.to(B16).float(), b, 1, 1), 0.2)
+    close(out[1][0].float(), ref, rtol=1.5e-2, what='bf16 pipelined fwd vs torch on bf16-rounded operands')
+
+
 PIPE_CASES = [
     (8, 64, 128, 96, 80),     # 480 blocks on <= 256 persistent workgroups: every workgroup walks several blocks, both cout tiles
     (3, 36, 72, 50, 18),      # channel tail in the last chunk, cout tail in the second 64-wide tile, partial tile blocks
