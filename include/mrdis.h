@@ -91,6 +91,8 @@ int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W, const floa
  * means "type m received no gradient".  r_out (M, E).  dW, dfc_w, dfc_b are the sums over the types.     */
 int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const float* fc_b, const float* types, int emb, int M,
                                        float* r_out, float* const* w_tck, float* const* w_tkc,
+                                       void* const* w_bf16_tck, void* const* w_bf16_tkc,   /* both NULL, or M bf16 buffers each: bf16 copies of
+                                                                                              the two layouts (what mrdis_cast_bf16 would give) */
                                        int E, int Co, int Ci, int T, void* stream);
 size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int Co, int Ci, int T);
 int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,

@@ -2341,7 +2341,7 @@ __global__ void mix_routed_bwd_final_kernel(const float* __restrict__ part, int 
 // (model.py:3138: inputs_type = (1+i) * ones); mixing them in one forward and one backward launch pair cuts the
 // launches 4x and removes the gradient accumulation adds autograd would issue for W / fc.weight / fc.bias.
 #define MIX_MAX_TYPES 8
-struct MixPtrs { float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; };
+struct MixPtrs { float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* btck[MIX_MAX_TYPES]; __bf16* btkc[MIX_MAX_TYPES]; };   // b*: optional bf16 copies
 struct MixCPtrs { const float* p[MIX_MAX_TYPES]; };
 __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
                                             const float* __restrict__ types, int emb, float* __restrict__ r_out, MixPtrs out,
@@ -2350,6 +2350,8 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
     const float* t = types + m * emb;
     float* __restrict__ w_tck = out.tck[m];
     float* __restrict__ w_tkc = out.tkc[m];
+    __bf16* __restrict__ b_tck = out.btck[m];
+    __bf16* __restrict__ b_tkc = out.btkc[m];
     const long long total = (long long)Co * Ci * T;
     float rr[8];
 #pragma unroll
@@ -2367,6 +2369,10 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
         for (int e = 0; e < E; ++e) s_ += rr[e] * W[(long long)e * total + i];      // same order as the single-type kernel
         w_tck[((long long)tt * Ci + ci) * Co + co] = s_;
         w_tkc[((long long)tt * Co + co) * Ci + ci] = s_;
+        if (b_tck != nullptr) {                              // the bf16 MFMA operands of compute_dtype bf16 (round to nearest even, as mrdis_cast_bf16)
+            b_tck[((long long)tt * Ci + ci) * Co + co] = (__bf16)s_;
+            b_tkc[((long long)tt * Co + co) * Ci + ci] = (__bf16)s_;
+        }
     }
 }
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
@@ -2504,11 +2510,20 @@ extern "C" int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W,
 
 extern "C" int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const float* fc_b, const float* types, int emb, int M,
                                                   float* r_out, float* const* w_tck, float* const* w_tkc,
+                                                  void* const* w_bf16_tck, void* const* w_bf16_tkc,
                                                   int E, int Co, int Ci, int T, void* stream) {
     if (!W || !fc_w || !fc_b || !types || !r_out || !w_tck || !w_tkc || E < 1 || E > 8 || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES)
         return MRDIS_EINVAL;
     MixPtrs out{};
-    for (int m = 0; m < M; ++m) { if (!w_tck[m] || !w_tkc[m]) return MRDIS_EINVAL; out.tck[m] = w_tck[m]; out.tkc[m] = w_tkc[m]; }
+    if ((w_bf16_tck == nullptr) != (w_bf16_tkc == nullptr)) return MRDIS_EINVAL;
+    for (int m = 0; m < M; ++m) {
+        if (!w_tck[m] || !w_tkc[m]) return MRDIS_EINVAL;
+        out.tck[m] = w_tck[m]; out.tkc[m] = w_tkc[m];
+        if (w_bf16_tck != nullptr) {
+            if (!w_bf16_tck[m] || !w_bf16_tkc[m]) return MRDIS_EINVAL;
+            out.btck[m] = reinterpret_cast<__bf16*>(w_bf16_tck[m]); out.btkc[m] = reinterpret_cast<__bf16*>(w_bf16_tkc[m]);
+        }
+    }
     const long long total = (long long)Co * Ci * T;
     hipLaunchKernelGGL(mix_routed_multi_fwd_kernel, dim3(mix_blocks(total), M), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, types, emb,
                        r_out, out, E, Co, Ci, T);

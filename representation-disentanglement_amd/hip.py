@@ -37,7 +37,7 @@ _SIGS = {
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
-    'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
@@ -256,8 +256,8 @@ def mix_experts_routed_bwd(dw_tck, W, r, t_row, emb):
     return dW, dfcw, dfcb
 
 
-def mix_experts_routed_multi_fwd(W, fcw, fcb, types):
-    """all M type rows at once: -> ([w_tck_m], [w_tkc_m], r (M,E))."""
+def mix_experts_routed_multi_fwd(W, fcw, fcb, types, want_bf16=False):
+    """all M type rows at once: -> ([w_tck_m], [w_tkc_m], r (M,E)); want_bf16: + ([bf16(w_tck_m)], [bf16(w_tkc_m)]) from the same launch."""
     lib = load()
     E, Co, Ci, kh, kw = W.shape
     T = kh * kw
@@ -267,8 +267,15 @@ def mix_experts_routed_multi_fwd(W, fcw, fcb, types):
     tkc = [torch.empty((T, Co, Ci), dtype=torch.float32, device=W.device) for _ in range(M)]
     r = torch.empty((M, E), dtype=torch.float32, device=W.device)
     a = (_c.c_void_p * M)(*[t.data_ptr() for t in tck]); b = (_c.c_void_p * M)(*[t.data_ptr() for t in tkc])
-    _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, E, Co, Ci, T, _stream()),
+    ba = bb = None
+    if want_bf16:
+        btck = [torch.empty((T, Ci, Co), dtype=torch.bfloat16, device=W.device) for _ in range(M)]
+        btkc = [torch.empty((T, Co, Ci), dtype=torch.bfloat16, device=W.device) for _ in range(M)]
+        ba = (_c.c_void_p * M)(*[t.data_ptr() for t in btck]); bb = (_c.c_void_p * M)(*[t.data_ptr() for t in btkc])
+    _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, ba, bb, E, Co, Ci, T, _stream()),
          'mix_experts_routed_multi_fwd')
+    if want_bf16:
+        return tck, tkc, r, btck, btkc
     return tck, tkc, r
 
 

@@ -62,7 +62,14 @@ class _MixExpertsRoutedAll(Function):
 
     @staticmethod
     def forward(ctx, W, fcw, fcb, types):
-        tck, tkc, r = hip.mix_experts_routed_multi_fwd(W, fcw, fcb, types)
+        if _COMPUTE_DTYPE != hip.DT_F32:
+            # bf16 modes: the mixing launch also writes the bf16 MFMA operands (one launch instead of two casts per filter)
+            tck, tkc, r, btck, btkc = hip.mix_experts_routed_multi_fwd(W, fcw, fcb, types, want_bf16=True)
+            if _MIX_CACHE is not None:
+                for a, ba, bb in zip(tck, btck, btkc):
+                    _MIX_CACHE[('bf16w', id(a))] = (a, bb, ba)       # what bf16_filters would make: (w_tck, bf16(w_tkc), bf16(w_tck))
+        else:
+            tck, tkc, r = hip.mix_experts_routed_multi_fwd(W, fcw, fcb, types)
         ctx.save_for_backward(W, r, types)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*tkc)
@@ -207,7 +214,8 @@ def to_storage(x):
 
 def bf16_filters(w_tck, w_tkc):
     """bf16 copies of a mixed filter with the reduction axis contiguous: (forward = cast(w_tkc), data gradient = cast(w_tck));
-    memoised for the step next to the mixed kernels themselves."""
+    memoised for the step next to the mixed kernels themselves (the multi-label mixing launch files its own bf16 outputs under
+    the same key, so filters that come straight from it are never cast)."""
     def make():
         with torch.no_grad():
             return (w_tck, hip.cast_bf16(w_tkc.detach()), hip.cast_bf16(w_tck.detach()))
