@@ -97,6 +97,7 @@ int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const 
 size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int Co, int Ci, int T);
 int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
                                        int emb, int M, float* dW, float* dfc_w, float* dfc_b,
+                                       int accumulate,      /* 1: the three results are ADDED to dW / dfc_w / dfc_b (gradient sinks) */
                                        void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream);
 
 /* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and
@@ -140,6 +141,10 @@ int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream)
  * and a 16-channel bf16 head output -> its first 7 channels in fp32.  Any combination of MRDIS_DT_F32 / MRDIS_DT_BF16.          */
 int mrdis_cast_view(const void* src, int ld_src, int src_dtype, int C_src, void* dst, int ld_dst, int dst_dtype, int C_dst,
                     long long P, void* stream);
+
+/* Word-wise copy src -> dst by a kernel (nbytes % 4 == 0, 4-byte aligned).  src may be pinned host memory: the way small
+ * host -> device transfers inside a step avoid the copy engine's host round trip (the reference's CPU-drawn eps, model.py:3159-3162). */
+int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.

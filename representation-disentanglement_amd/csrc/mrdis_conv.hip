@@ -2378,7 +2378,7 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
 // dW[e] = sum_m r[m][e] dw_m (types in order m = 0..M-1; a type without gradient contributes nothing).
 __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
-                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T) {
+                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate) {
     __shared__ double red[8][4];
     const int m = blockIdx.y;
     const long long total = (long long)Co * Ci * T;
@@ -2412,7 +2412,7 @@ __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, c
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (e < E) dW[(long long)e * total + i] = acc[e];
+                if (e < E) { float* d_ = dW + (long long)e * total + i; *d_ = accumulate ? *d_ + acc[e] : acc[e]; }      // accumulate: dW is a gradient sink
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2428,7 +2428,7 @@ __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, c
 }
 // one block of 64 threads: thread (m, e) sums its partials, dz = dr r (1 - r); then e-threads sum over types
 __global__ void mix_multi_bwd_final_kernel(const float* __restrict__ part, int nblk, int M, int E, const float* __restrict__ r,
-                                           const float* __restrict__ types, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb) {
+                                           const float* __restrict__ types, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb, int accumulate) {
     __shared__ float dz[MIX_MAX_TYPES][8];
     const int m = threadIdx.x >> 3, e = threadIdx.x & 7;
     if (m < M && e < E) {
@@ -2441,11 +2441,11 @@ __global__ void mix_multi_bwd_final_kernel(const float* __restrict__ part, int n
     if (m == 0 && e < E) {
         float sb = 0.f;
         for (int mm = 0; mm < M; ++mm) sb += dz[mm][e];
-        dfcb[e] = sb;
+        dfcb[e] = accumulate ? dfcb[e] + sb : sb;
         for (int k = 0; k < emb; ++k) {
             float sw = 0.f;
             for (int mm = 0; mm < M; ++mm) sw += dz[mm][e] * types[mm * emb + k];
-            dfcw[e * emb + k] = sw;
+            dfcw[e * emb + k] = accumulate ? dfcw[e * emb + k] + sw : sw;
         }
     }
 }
@@ -2537,7 +2537,7 @@ extern "C" size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int
 }
 
 extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
-                                                  int emb, int M, float* dW, float* dfc_w, float* dfc_b,
+                                                  int emb, int M, float* dW, float* dfc_w, float* dfc_b, int accumulate,
                                                   void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream) {
     if (!dw_tck || !W || !r || !types || !dW || !dfc_w || !dfc_b || !workspace || E < 1 || E > 8 || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES)
         return MRDIS_EINVAL;
@@ -2547,10 +2547,10 @@ extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, co
     MixCPtrs dw{};
     for (int m = 0; m < M; ++m) dw.p[m] = dw_tck[m];
     hipLaunchKernelGGL(mix_multi_bwd_kernel, dim3(nb, M), dim3(256), 0, (hipStream_t)stream, dw, W, r, dW,
-                       reinterpret_cast<float*>(workspace), M, E, Co, Ci, T);
+                       reinterpret_cast<float*>(workspace), M, E, Co, Ci, T, accumulate ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(mix_multi_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float*>(workspace), nb, M, E, r, types, emb, dfc_w, dfc_b);
+                       reinterpret_cast<const float*>(workspace), nb, M, E, r, types, emb, dfc_w, dfc_b, accumulate ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -1361,6 +1361,24 @@ extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float
     return MRDIS_OK;
 }
 
+// ------------------------------------------------------------------ small host -> device transfers without the copy engine
+// src may be PINNED HOST memory (mapped into the device's address space): the kernel reads it across the link.  A stream-ordered
+// hipMemcpyAsync of a few KB between two kernels costs the GPU ~0.5 ms of idle time (the runtime waits for the preceding kernel on
+// the host side before it programs the copy: 10 such copies per training step = 5.5 ms of a 191 ms step); a kernel is just the next
+// packet in the queue.
+__global__ void copy_bytes_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long long nwords) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+extern "C" int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, void* stream) {
+    if (!src || !dst || nbytes < 1 || (nbytes & 3) != 0 || (((uintptr_t)src | (uintptr_t)dst) & 3) != 0) return MRDIS_EINVAL;
+    const long long nw = nbytes / 4;
+    long long nb = (nw + 255) / 256; if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(src),
+                       reinterpret_cast<unsigned*>(dst), nw);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // ------------------------------------------------------------------ misc
 // ---------------------------------------------------------------------------------------------- process-wide switches
 namespace {

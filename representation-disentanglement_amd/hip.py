@@ -37,9 +37,10 @@ _SIGS = {
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
-    'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
@@ -180,6 +181,48 @@ def _dt(*tensors):
     raise MrdisError(f'activation views must be all fp32 or all bf16, got {sorted(str(k) for k in kinds)}')
 
 
+class _Mailbox:
+    """Small host -> device transfers by a KERNEL that reads pinned host memory (mrdis_copy_bytes) instead of hipMemcpyAsync:
+    a ring of pinned slots; a slot is rewritten only after the event recorded behind its last copy kernel has completed."""
+    SLOT = 1 << 16          # bytes per slot = the largest tensor that goes through the mailbox
+    NSLOT = 64
+
+    def __init__(self):
+        self.buf = torch.empty(self.SLOT * self.NSLOT, dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.NSLOT
+        self.next = 0
+
+    def send(self, t_cpu, device):
+        nbytes = t_cpu.numel() * t_cpu.element_size()
+        k = self.next
+        self.next = (k + 1) % self.NSLOT
+        ev = self.events[k]
+        if ev is not None:
+            ev.synchronize()                           # 64 transfers ago: long done unless the host is a whole ring ahead of the GPU
+        slot = self.buf[k * self.SLOT:k * self.SLOT + nbytes]
+        slot.copy_(t_cpu.contiguous().view(-1).view(torch.uint8))
+        out = torch.empty(t_cpu.shape, dtype=t_cpu.dtype, device=device)
+        _chk(load().mrdis_copy_bytes(slot.data_ptr(), _ptr(out), nbytes, _stream()), 'copy_bytes')
+        if ev is None:
+            ev = self.events[k] = torch.cuda.Event()
+        ev.record()
+        return out
+
+
+_mailbox = None
+
+
+def to_device_small(t_cpu, device):
+    """CPU tensor (<= 64 KB, element size 4 or 8) -> new device tensor, stream-ordered, without the copy engine; None if it does not qualify."""
+    global _mailbox
+    nbytes = t_cpu.numel() * t_cpu.element_size()
+    if nbytes == 0 or nbytes > _Mailbox.SLOT or nbytes % 4 != 0 or t_cpu.dtype in (torch.bool,):
+        return None
+    if _mailbox is None:
+        _mailbox = _Mailbox()
+    return _mailbox.send(t_cpu, device)
+
+
 def cast_view(x, dtype, channels=None):
     """NHWC view -> new NHWC tensor of storage type `dtype` (fp32 / bf16, round to nearest even) with `channels` channels
     (default: unchanged): the first min(C, channels) are copied, a wider result is zero-padded."""
@@ -279,8 +322,9 @@ def mix_experts_routed_multi_fwd(W, fcw, fcb, types, want_bf16=False):
     return tck, tkc, r
 
 
-def mix_experts_routed_multi_bwd(dw_list, W, r, types):
-    """dw_list: M tensors (T,Ci,Co) or None -> (dW, dfcw, dfcb) summed over the types."""
+def mix_experts_routed_multi_bwd(dw_list, W, r, types, sinks=None):
+    """dw_list: M tensors (T,Ci,Co) or None -> (dW, dfcw, dfcb) summed over the types.  sinks = (gW, gfcw, gfcb): contiguous fp32
+    gradient buffers the three results are ADDED to in-kernel (returned as they are)."""
     lib = load()
     E, Co, Ci, kh, kw = W.shape
     T = kh * kw
@@ -288,13 +332,16 @@ def mix_experts_routed_multi_bwd(dw_list, W, r, types):
     M, emb = types.shape
     dw_list = [None if g is None else g.contiguous() for g in dw_list]
     a = (_c.c_void_p * M)(*[None if g is None else g.data_ptr() for g in dw_list])
-    dW = torch.empty_like(W)
-    dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
-    dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
+    if sinks is not None:
+        dW, dfcw, dfcb = sinks
+    else:
+        dW = torch.empty_like(W)
+        dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
+        dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
     nb = lib.mrdis_mix_experts_routed_multi_bwd_workspace(M, E, Co, Ci, T)
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_routed_multi_bwd(a, _ptr(W), _ptr(r), _ptr(types), emb, M, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
-                                                _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
+                                                1 if sinks is not None else 0, _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
     return dW, dfcw, dfcb
 
 

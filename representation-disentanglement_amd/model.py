@@ -69,6 +69,10 @@ class CondConv2d(nn.Module):
         if bias:
             nn.init.constant_(self.bias, 0)
             self.bias._mrdis_sink = True           # gradient accumulated in-kernel (ops._grad_sink)
+        # expert weights and routing parameters: the multi-label mixing backward adds into their gradient buffers in-kernel
+        self.weight._mrdis_sink = True
+        self._routing_fn.fc.weight._mrdis_sink = True
+        self._routing_fn.fc.bias._mrdis_sink = True
 
     def _mixed(self, t_row):
         """t_row: (1, embeddings) -> (w_tck, w_tkc) for that type."""

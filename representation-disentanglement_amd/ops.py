@@ -71,6 +71,7 @@ class _MixExpertsRoutedAll(Function):
         else:
             tck, tkc, r = hip.mix_experts_routed_multi_fwd(W, fcw, fcb, types)
         ctx.save_for_backward(W, r, types)
+        ctx.params = (W, fcw, fcb)                    # the Parameter objects: their .grad may be in-kernel gradient sinks
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*tkc)
         out = []
@@ -81,6 +82,12 @@ class _MixExpertsRoutedAll(Function):
     @staticmethod
     def backward(ctx, *grads):
         W, r, types = ctx.saved_tensors
+        sinks = tuple(_grad_sink(q) for q in ctx.params)
+        if all(g is not None for g in sinks) and sinks[0].shape == W.shape:
+            # the three gradients are added to the optimizer's persistent buffers inside the two launches: no result tensors,
+            # no AccumulateGrad add_ per parameter (3 x ~90 modules per step at the host-bound tail of the backward pass)
+            hip.mix_experts_routed_multi_bwd(list(grads[0::2]), W, r, types, sinks=sinks)
+            return None, None, None, None
         dW, dfcw, dfcb = hip.mix_experts_routed_multi_bwd(list(grads[0::2]), W, r, types)
         return dW, dfcw, dfcb, None
 
@@ -426,12 +433,21 @@ def mix_cache_active():
 
 
 def to_device(t_cpu, device):
-    """Host tensor -> device without stalling the host: a pageable source makes the copy wait for everything already
-    queued on the stream (62 ms per step were spent in three such copies); staged through the pinned-memory cache the
-    copy is stream-ordered and the call returns at once."""
+    """Host tensor -> device without stalling the host OR the GPU.  A pageable source makes the copy wait for everything already
+    queued on the stream (62 ms per step were spent in three such copies); a pinned source is stream-ordered, but the runtime still
+    waits on the host for the preceding kernel before it programs the copy engine: ~0.5 ms of GPU idle time per transfer, ten
+    transfers per step (the CPU-drawn eps of `sample`, loss weights, index lists).  Small tensors therefore go through a ring of
+    pinned slots that a copy KERNEL reads (hip.to_device_small); anything else through the pinned-memory cache."""
     if torch.device(device).type != 'cuda':
         return t_cpu.to(device)
+    if _MAILBOX:
+        out = hip.to_device_small(t_cpu, device)
+        if out is not None:
+            return out
     return t_cpu.pin_memory().to(device, non_blocking=True)
+
+
+_MAILBOX = _os.environ.get('MRDIS_MAILBOX', '1') != '0'
 
 
 def cached_mix(key, make):

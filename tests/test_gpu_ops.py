@@ -164,6 +164,29 @@ def test_bf16_pipelined_conv_bit_identical(mrdis, case):
     close(out[1][0].float(), ref, rtol=1.5e-2, what='bf16 pipelined fwd vs torch on bf16-rounded operands')
 
 
+def test_to_device_mailbox_ring(mrdis):
+    """ops.to_device for small tensors: pinned ring slot + copy kernel (no copy engine).  More transfers than ring slots, mixed dtypes
+    and sizes, all checked only at the end (the GPU consumes the slots while the host keeps refilling them)."""
+    ops = mrdis.ops
+    g = torch.Generator().manual_seed(5)
+    sent, got = [], []
+    filler = torch.zeros(1 << 22, device=dev())
+    for k in range(3 * mrdis.hip._Mailbox.NSLOT + 7):
+        if k % 3 == 0:
+            t = torch.randn(32, 16, generator=g)
+        elif k % 3 == 1:
+            t = torch.randint(0, 1 << 40, (2, 1 + k % 5), generator=g, dtype=torch.long)
+        else:
+            t = torch.randn(1 + (k * 37) % 4000, generator=g)
+        filler.add_(1.0)                               # keeps the GPU behind the host
+        sent.append(t); got.append(ops.to_device(t, dev()))
+    torch.cuda.synchronize()
+    for a, b in zip(sent, got):
+        assert b.device.type == 'cuda' and b.dtype == a.dtype and torch.equal(a, b.cpu())
+    big = torch.randn(1 << 16)                         # 256 KB: beyond a slot -> pinned-cache path
+    assert torch.equal(ops.to_device(big, dev()).cpu(), big)
+
+
 PIPE_CASES = [
     (8, 64, 128, 96, 80),     # 480 blocks on <= 256 persistent workgroups: every workgroup walks several blocks, both cout tiles
     (3, 36, 72, 50, 18),      # channel tail in the last chunk, cout tail in the second 64-wide tile, partial tile blocks
