@@ -546,6 +546,226 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bwgrad2_kernel: bwgrad_kernel for bf16 activations with the pipeline of bconv3_kernel / wino_wgrad2_kernel.  bwgrad_kernel stages a
+// 128-position tile as barrier | registers -> LDS | barrier | next tile's loads | MFMAs; its matrix pipe is 14-16 % busy and the
+// big layers run at 2-4x their HBM floor.  Here the two LDS images are double-buffered with ONE barrier per tile: while tile i is
+// multiplied, tile i+1 goes from registers to LDS and the loads of tile i+2 are issued, one per MFMA; loads are buffer loads with
+// out-of-range offsets for padding / ragged tiles (no branches: counted vmcnt); the lane constants of the transposing reads and the
+// staging offsets are tile-invariant.  Same products, same order per workgroup: results identical to bwgrad_kernel's.
+typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
+template <int V_> struct BwIC { static constexpr int value = V_; };
+constexpr unsigned BW_OOB = 0xfffffff0u;
+__device__ __forceinline__ int bw_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
+
+template <int WCI, int WCO>
+__global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, const unsigned x_bytes, const unsigned dy_bytes) {
+    constexpr int KS = 8 / (WCI * WCO), NSTEP = 8 / KS;
+    constexpr int CIW = 32 * WCI, COW = 32 * WCO;
+    constexpr int XQ = CIW / 8, YQ = COW / 8;
+    constexpr int XR = (WCI == 2) ? 4 : 2, YR = (WCO == 2) ? 2 : 1, NL = XR + YR, NM = NSTEP * 9;
+    constexpr int TP = 128, DYS = WCO * TP * 32;
+    static_assert(2 * NL <= NM, "one staging operation per MFMA slot");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem_raw);      // [2][DYS] dy images, then [2][XS] x images
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave % WCI, wco = (wave / WCI) % WCO, ks = wave / (WCI * WCO);
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int cob = bid % p.nCoB, cib = bid / p.nCoB;
+    const int ci0 = cib * CIW, co0 = cob * COW;
+    const int tinHW = p.TinH * p.TinW, npix = p.NB * tinHW;
+    const int XS = WCI * npix * 32;
+
+    // lane constants of the transposing reads: 16-lane group g, row q, 4-column piece pc; the lane's two positions of each step
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int chan = 16 * (g & 1) + 4 * pc, kbase = 8 * (g >> 1) + q;
+    int xa0[NSTEP], xa1[NSTEP], ya0[NSTEP];            // element offsets in the x image (tap 0 corner) and the dy image
+#pragma unroll
+    for (int s_ = 0; s_ < NSTEP; ++s_) {
+        const int m0 = 16 * (ks + s_ * KS) + kbase, m1 = m0 + 4;
+        const int tx0 = m0 & (p.TW - 1), ty0 = (m0 >> p.lgTW) & (p.TH - 1), nb0 = m0 >> (p.lgTW + p.lgTH);
+        const int tx1 = m1 & (p.TW - 1), ty1 = (m1 >> p.lgTW) & (p.TH - 1), nb1 = m1 >> (p.lgTW + p.lgTH);
+        xa0[s_] = (wci * npix + (nb0 * p.TinH + ty0) * p.TinW + tx0) * 32 + chan;
+        xa1[s_] = (wci * npix + (nb1 * p.TinH + ty1) * p.TinW + tx1) * 32 + chan;
+        ya0[s_] = (wco * TP + m0) * 32 + chan;          // m1 = m0 + 4: + 128 elements
+    }
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = t < p.ntaps ? ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * 32 : 0;
+
+    // staging roles (tile-invariant)
+    int x_lds[XR], x_yx[XR]; unsigned x_rel[XR];      // x_yx = (nb << 16) | (iy << 8) | ix, or -1
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + it * 512, pi = idx / XQ, qq = idx - pi * XQ;
+        const int nb = pi / tinHW, rem = pi - nb * tinHW, iy = rem / p.TinW, ix = rem - iy * p.TinW;
+        const bool on = idx < npix * XQ && ci0 + 8 * qq < p.Ci;
+        x_yx[it] = on ? ((nb << 16) | (iy << 8) | ix) : -1;
+        x_lds[it] = ((qq >> 2) * npix + pi) * 32 + 8 * (qq & 3);
+        x_rel[it] = 2u * (unsigned)(((nb * p.H + iy) * p.W + ix) * p.ldx + ci0 + 8 * qq);
+    }
+    int y_lds[YR], y_pos[YR]; unsigned y_rel[YR];     // y_pos = (nb << 16) | (ty << 8) | tx, or -1
+#pragma unroll
+    for (int it = 0; it < YR; ++it) {
+        const int idx = tid + it * 512, m = idx / YQ, qq = idx - m * YQ;      // < 128 * YQ by construction
+        const int tx = m & (p.TW - 1), ty = (m >> p.lgTW) & (p.TH - 1), nb = m >> (p.lgTW + p.lgTH);
+        y_pos[it] = (co0 + 8 * qq < p.Co) ? ((nb << 16) | (ty << 8) | tx) : -1;
+        y_lds[it] = ((qq >> 2) * TP + m) * 32 + 8 * (qq & 3);
+        y_rel[it] = 2u * (unsigned)(((nb * p.H + ty) * p.W + tx) * p.lddy + co0 + 8 * qq);
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, dy_bytes, 0x00020000);
+
+    bw_u32x4 xr[2][XR], yr[2][YR];
+    unsigned xo[XR], yo[YR];
+    int ltile = split;                                 // load cursor
+    auto next_offsets = [&]() {
+        const bool live = ltile < p.tiles;
+        int t_ = live ? ltile : 0;
+        const int tb = t_ % p.tilesB; t_ /= p.tilesB;
+        const int ta = t_ % p.tilesA;
+        const int n0 = (t_ / p.tilesA) * p.NB, a0 = ta * p.TH, b0 = tb * p.TW;
+        const int h0 = a0 + p.dh_min, w0 = b0 + p.dw_min;
+        const unsigned xorg = 2u * (unsigned)(((n0 * p.H + h0) * p.W + w0) * p.ldx);     // may wrap for halo origins: added mod 2^32
+        const unsigned yorg = 2u * (unsigned)(((n0 * p.H + a0) * p.W + b0) * p.lddy);
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int n = n0 + (x_yx[it] >> 16), h = h0 + ((x_yx[it] >> 8) & 255), w_ = w0 + (x_yx[it] & 255);
+            const bool ok = live && x_yx[it] >= 0 && n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            xo[it] = ok ? xorg + x_rel[it] : BW_OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int n = n0 + (y_pos[it] >> 16), a = a0 + ((y_pos[it] >> 8) & 255), b = b0 + (y_pos[it] & 255);
+            const bool ok = live && y_pos[it] >= 0 && n < p.N && a < p.H && b < p.W;
+            yo[it] = ok ? yorg + y_rel[it] : BW_OOB;
+        }
+        ltile += p.splits;
+    };
+    auto load1 = [&](auto S_, int k) {                  // staging operation k of NL: x pieces first, then dy pieces
+        constexpr int S = decltype(S_)::value;
+        if (k < XR) xr[S][k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xo[k], 0, 0);
+        else yr[S][k - XR] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)yo[k - XR], 0, 0);
+    };
+    float bsum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
+    auto store1 = [&](auto S_, __bf16* dys, __bf16* xs, int k) {
+        constexpr int S = decltype(S_)::value;
+        if (k < XR) {
+            if (tid + k * 512 < npix * XQ) *reinterpret_cast<bw_u32x4*>(xs + x_lds[k]) = xr[S][k];
+        } else {
+            *reinterpret_cast<bw_u32x4*>(dys + y_lds[k - XR]) = yr[S][k - XR];
+            union { bw_u32x4 u; bf16x8 v; } c; c.u = yr[S][k - XR];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += (float)c.v[j];
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- prologue: tile 0 in LDS buffer 0, tile 1 in register set 1, cursor at tile 2
+    next_offsets();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load1(BwIC<0>{}, k);
+    next_offsets();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load1(BwIC<1>{}, k);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) store1(BwIC<0>{}, lds, lds + 2 * DYS, k);
+    __syncthreads();
+
+    const int ntile = (p.tiles - split + p.splits - 1) / p.splits;
+    auto iteration = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const __bf16* yb = lds + bw_opaque(P * DYS);
+        const __bf16* xb = lds + bw_opaque(2 * DYS + P * XS);
+        __bf16* dyn = lds + (P ^ 1) * DYS;
+        __bf16* xn = lds + 2 * DYS + (P ^ 1) * XS;
+        next_offsets();                               // tile i + 2 -> register set P, one load per MFMA slot
+        // operands one slot ahead of the MFMA that uses them (two register sets; the sched_barriers keep hipcc from sinking the
+        // reads back next to their use: left alone it emits read, read, wait, MFMA and every MFMA eats a full LDS round trip)
+        union Op { bf16x8 v; s16x4 h[2]; };
+        Op aq[2], bq[2];
+        auto read_a = [&](Op& o, int s_, int t) {
+            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xb + xa0[s_] + toff[t]));
+            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xb + xa1[s_] + toff[t]));
+        };
+        auto read_b = [&](Op& o, int s_) {
+            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yb + ya0[s_]));
+            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yb + ya0[s_] + 128));
+        };
+        read_b(bq[0], 0); read_a(aq[0], 0, 0);
+#pragma unroll
+        for (int slot = 0; slot < NM; ++slot) {
+            const int s_ = slot / 9, t = slot - 9 * s_;
+            if (slot + 1 < NM) {
+                const int s1 = (slot + 1) / 9, t1 = (slot + 1) - 9 * s1;
+                read_a(aq[(slot + 1) & 1], s1, t1);
+                if (t1 == 0) read_b(bq[s1 & 1], s1);
+            }
+            if (slot < NL) load1(BwIC<P>{}, slot);
+            if (slot >= NM - NL) store1(BwIC<P ^ 1>{}, dyn, xn, slot - (NM - NL));
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < p.ntaps) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[slot & 1].v, bq[s_ & 1].v, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int i = 0; i < ntile; i += 2) {
+        iteration(BwIC<0>{});
+        if (i + 1 < ntile) iteration(BwIC<1>{});
+    }
+
+    // ---- the KS waves of a channel block add their partials through LDS (tap by tap, fixed order), then the ks = 0 wave
+    // writes the block: D[ci row][co col] -> slab [split][T][Ci][Co]   (as bwgrad_kernel)
+    const int half = lane >> 5, e = lane & 31;
+    const int co = co0 + 32 * wco + e;
+    float* red_acc = reinterpret_cast<float*>(smem_raw);            // [8 waves][16][64]
+    auto tap_acc = [&](int t, int r) -> float {
+        float v;
+        switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
+                     case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
+        return v;
+    };
+    for (int t = 0; t < p.ntaps; ++t) {
+        __syncthreads();
+        if (ks > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = tap_acc(t, r);
+        }
+        __syncthreads();
+        if (ks == 0 && co < p.Co) {
+            float* dst = p.slab + (((long long)split * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = tap_acc(t, r);
+                for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[(long long)row * p.Co] = v;
+            }
+        }
+    }
+    if (p.bias_slab && cib == 0) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);            // [512][8]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bsum[k];
+        __syncthreads();
+        if (tid < COW) {
+            const int qq = tid / 8, k = tid % 8;                    // channel tid = 8 qq + k; threads with tid % YQ == qq hold it
+            float sum = 0.f;
+            for (int th = qq; th < 512; th += YQ) sum += red[th * 8 + k];
+            if (co0 + tid < p.Co) p.bias_slab[(long long)split * p.Co + co0 + tid] = sum;
+        }
+    }
+}
+
 // out[i] = sum over s of slab[s][i]; the bias row likewise.  A block owns 64 consecutive outputs; its sixteen waves take the slabs
 // s = w, w + 16, ... (each wave reads 256 contiguous bytes per slab) and meet in LDS: fixed order, bit-reproducible.  (One thread
 // per output walking all S slabs serially was latency-bound: 60 us for the 18,432 outputs x 256 slabs of sp6.gamma+beta.)
@@ -649,7 +869,21 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
         if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_, TS, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
         hipLaunchKernelGGL((bwgrad_kernel<a, b_, TS, HF>), dim3(grid), dim3(512), pl.lds, s, p); }
 #define BW_CASE(a, b_, TS) BW_CASE_H(a, b_, TS, false)
-    if (Ci == 16) { BW_CASE_H(1, 1, __bf16, true) else BW_CASE_H(1, 2, __bf16, true) }
+    bool done2 = false;
+    if (st_bf16 && Ci % 32 == 0 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {              // pipelined form (bwgrad2_kernel); needs both images twice in LDS
+        const long long xb = 2LL * (((long long)N * H * W - 1) * ldx + Ci), yb = 2LL * (((long long)N * H * W - 1) * lddy + Co);
+        const size_t lds2 = 2 * (size_t)pl.lds;
+        if (xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds2 <= 150 * 1024 && p.tiles >= 2 * p.splits) {
+#define BW2_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
+            static bool attr2 = false; \
+            if (!attr2) { if (hipFuncSetAttribute((const void*)bwgrad2_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr2 = true; } \
+            hipLaunchKernelGGL((bwgrad2_kernel<a, b_>), dim3(grid), dim3(512), lds2 < 32768 ? 32768 : lds2, s, p, (unsigned)xb, (unsigned)yb); done2 = true; }
+            BW2_CASE(1, 1) else BW2_CASE(1, 2) else BW2_CASE(2, 1) else BW2_CASE(2, 2)
+#undef BW2_CASE
+        }
+    }
+    if (done2) {}
+    else if (Ci == 16) { BW_CASE_H(1, 1, __bf16, true) else BW_CASE_H(1, 2, __bf16, true) }
     else if (st_bf16) { BW_CASE(1, 1, __bf16) else BW_CASE(1, 2, __bf16) else BW_CASE(2, 1, __bf16) else BW_CASE(2, 2, __bf16) }
     else { BW_CASE(1, 1, float) else BW_CASE(1, 2, float) else BW_CASE(2, 1, float) else BW_CASE(2, 2, float) }
 #undef BW_CASE
