@@ -145,8 +145,31 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_WS = {}          # (device, raw stream) -> grow-only scratch buffer
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    """Scratch memory of one call.  Every kernel that uses it runs on the current stream, so consecutive calls can share ONE buffer per
+    (device, stream): stream order keeps them apart, and no caller keeps workspace contents beyond its own launches.  (A fresh
+    torch.empty per call was ~1,000 allocator round trips per training step.)"""
+    n = max(int(nbytes), 16)
+    key = (device, _stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < n:
+        size = max(n, 1 << 20) if buf is None else max(n, 2 * buf.numel())
+        buf = _WS[key] = torch.empty(size, dtype=torch.uint8, device=device)
+    return buf
+
+
+_WS_BYTES = {}    # (entry point, geometry) -> workspace bytes: the queries are pure functions of their arguments
+
+
+def _ws_bytes(fn, *args):
+    key = (fn.__name__, args)
+    v = _WS_BYTES.get(key)
+    if v is None:
+        v = _WS_BYTES[key] = fn(*args)
+    return v
 
 
 # ---------------------------------------------------------------- NHWC views
@@ -262,7 +285,7 @@ def mix_experts_bwd(dw_tck, W, r):
     W = W.contiguous(); r = r.contiguous(); dw_tck = dw_tck.contiguous()
     dW = torch.empty_like(W)
     dr = torch.zeros(E, dtype=torch.float32, device=W.device)
-    nb = lib.mrdis_mix_experts_bwd_workspace(E, Co, Ci, T)
+    nb = _ws_bytes(lib.mrdis_mix_experts_bwd_workspace, E, Co, Ci, T)
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(dW), _ptr(dr), _ptr(ws), nb, E, Co, Ci, T, _stream()),
          'mix_experts_bwd')
@@ -292,7 +315,7 @@ def mix_experts_routed_bwd(dw_tck, W, r, t_row, emb):
     dW = torch.empty_like(W)
     dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
     dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
-    nb = lib.mrdis_mix_experts_bwd_workspace(E, Co, Ci, T)
+    nb = _ws_bytes(lib.mrdis_mix_experts_bwd_workspace, E, Co, Ci, T)
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_routed_bwd(_ptr(dw_tck), _ptr(W), _ptr(r), _ptr(t_row), emb, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
                                           _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_bwd')
@@ -338,7 +361,7 @@ def mix_experts_routed_multi_bwd(dw_list, W, r, types, sinks=None):
         dW = torch.empty_like(W)
         dfcw = torch.empty((E, emb), dtype=torch.float32, device=W.device)
         dfcb = torch.empty(E, dtype=torch.float32, device=W.device)
-    nb = lib.mrdis_mix_experts_routed_multi_bwd_workspace(M, E, Co, Ci, T)
+    nb = _ws_bytes(lib.mrdis_mix_experts_routed_multi_bwd_workspace, M, E, Co, Ci, T)
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_routed_multi_bwd(a, _ptr(W), _ptr(r), _ptr(types), emb, M, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
                                                 1 if sinks is not None else 0, _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
@@ -419,7 +442,7 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
     Co = dy.shape[1]
     dw = torch.empty((kh * kw, Ci, Co), dtype=torch.float32, device=x.device)
     db = torch.empty(Co, dtype=torch.float32, device=x.device) if (need_bias and bias_sink is None) else None
-    nb = lib.mrdis_conv2d_bwd_weight_workspace(N, H, W, Ci, Co, kh, kw, stride, pad)
+    nb = _ws_bytes(lib.mrdis_conv2d_bwd_weight_workspace, N, H, W, Ci, Co, kh, kw, stride, pad)
     if nb == 0:
         raise MrdisError('conv2d_bwd_weight: unsupported geometry')
     ws = _ws(nb, x.device)
@@ -457,7 +480,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=N
     assert y.data_ptr() == out.data_ptr()
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    nb = lib.mrdis_norm_workspace(1, P, C)
+    nb = _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
     ws = _ws(nb, x.device)
     _chk(lib.mrdis_bn_train_fwd(_ptr(x), ldx, _ptr(y), ldy, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                 _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _dt(x, y), _stream()), 'bn_train_fwd')
@@ -483,7 +506,7 @@ def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None):
     dx = empty_nhwc(N, C, H, W, x.device, x.dtype)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
-    nb = lib.mrdis_norm_workspace(1, P, C)
+    nb = _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
     ws = _ws(nb, x.device)
     ag, ab = sink if sink is not None else (None, None)
     _chk(lib.mrdis_bn_train_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), C, _ptr(dg), _ptr(db),
@@ -498,7 +521,7 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
     out = empty_nhwc(N, C, H, W, z.device, z.dtype)
     mean = torch.empty(N * C, dtype=torch.float32, device=z.device)
     rstd = torch.empty(N * C, dtype=torch.float32, device=z.device)
-    nb = lib.mrdis_norm_workspace(N, H * W, C)
+    nb = _ws_bytes(lib.mrdis_norm_workspace, N, H * W, C)
     ws = _ws(nb, z.device)
     _chk(lib.mrdis_instnorm_spade_fwd(_ptr(z), ldz, _ptr(gamma), ldg, _ptr(beta), ldb, _ptr(out), C, _ptr(mean), _ptr(rstd),
                                       _ptr(ws), nb, N, H * W, C, eps, _dt(z, gamma, beta), _stream()), 'instnorm_spade_fwd')
@@ -513,7 +536,7 @@ def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False):
     dout, lddo = nhwc(dout); z, ldz = nhwc(z); gamma, ldg = nhwc(gamma)
     N, C, H, W = z.shape
     dz = empty_nhwc(N, C, H, W, z.device, z.dtype)
-    nb = lib.mrdis_instnorm_spade_bwd_workspace(N, H * W, C)
+    nb = _ws_bytes(lib.mrdis_instnorm_spade_bwd_workspace, N, H * W, C)
     ws = _ws(nb, z.device)
     dt = _dt(dout, z, gamma)
     if fused_gb:
@@ -573,7 +596,7 @@ def recon_err_fwd(gt, x, p):
     gt, ldgt = nhwc(gt); x, ldx = nhwc(x)
     N, C, H, W = x.shape
     out = torch.empty(N, dtype=torch.float32, device=x.device)
-    nb = lib.mrdis_recon_err_workspace(N, H * W, C)
+    nb = _ws_bytes(lib.mrdis_recon_err_workspace, N, H * W, C)
     ws = _ws(nb, x.device)
     _chk(lib.mrdis_recon_err_fwd(_ptr(gt), ldgt, _ptr(x), ldx, _ptr(out), _ptr(ws), nb, N, H * W, C, p, _stream()), 'recon_err_fwd')
     return out
@@ -585,7 +608,7 @@ def recon_metrics(target, pred):
     target, ldt = nhwc(target); pred, ldp = nhwc(pred)
     N, _, H, W = pred.shape
     out = torch.empty(N, 3, dtype=torch.float32, device=pred.device)
-    nb = lib.mrdis_recon_metrics_workspace(N, H)
+    nb = _ws_bytes(lib.mrdis_recon_metrics_workspace, N, H)
     ws = _ws(nb, pred.device)
     _chk(lib.mrdis_recon_metrics(_ptr(target), ldt, _ptr(pred), ldp, _ptr(out), _ptr(ws), nb, N, H, W, _stream()), 'recon_metrics')
     return out
@@ -639,7 +662,7 @@ def maxpool_bwd(dy, arg, in_shape, k):
 # ---------------------------------------------------------------- optimizer arena
 def sumsq_finite(g, out):
     lib = load()
-    nb = lib.mrdis_sumsq_workspace()
+    nb = _ws_bytes(lib.mrdis_sumsq_workspace)
     ws = _ws(nb, g.device)
     _chk(lib.mrdis_sumsq_finite(_ptr(g), g.numel(), _ptr(out), _ptr(ws), nb, _stream()), 'sumsq_finite')
 
