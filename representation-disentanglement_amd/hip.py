@@ -176,7 +176,9 @@ def _ws_bytes(fn, *args):
 def nhwc(t):
     """(tensor, ld) for a logical (N,C,H,W) fp32 or bf16 tensor whose memory is NHWC with pixel
     stride ld in elements (channels_last tensors and channel slices of them qualify as they are)."""
-    assert t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16), (t.shape, t.dtype)
+    assert t.dim() == 4 and (t.dtype is torch.float32 or t.dtype is torch.bfloat16), (t.shape, t.dtype)
+    if t.is_contiguous(memory_format=torch.channels_last) and t.shape[1] > 1 and t.shape[3] > 1:
+        return t, t.shape[1]                         # the common case: a dense channels_last tensor
     N, C, H, W = t.shape
     s = t.stride()
     ld = s[3] if W > 1 else (s[2] if H > 1 else (s[0] if N > 1 else C))
@@ -196,12 +198,20 @@ def empty_nhwc(N, C, H, W, device, dtype=torch.float32):
 
 def _dt(*tensors):
     """MRDIS_DT_* storage code of a set of activation views (all fp32 or all bf16)."""
-    kinds = {t.dtype for t in tensors if t is not None}
-    if kinds == {torch.float32}:
+    kind = None
+    for t in tensors:
+        if t is None:
+            continue
+        d = t.dtype
+        if kind is None:
+            kind = d
+        elif d is not kind:
+            raise MrdisError(f'activation views must be all fp32 or all bf16, got {kind} and {d}')
+    if kind is torch.float32:
         return 0
-    if kinds == {torch.bfloat16}:
+    if kind is torch.bfloat16:
         return 2
-    raise MrdisError(f'activation views must be all fp32 or all bf16, got {sorted(str(k) for k in kinds)}')
+    raise MrdisError(f'activation views must be fp32 or bf16, got {kind}')
 
 
 class _Mailbox:
