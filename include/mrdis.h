@@ -93,11 +93,15 @@ int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const 
                                        float* r_out, float* const* w_tck, float* const* w_tkc,
                                        void* const* w_bf16_tck, void* const* w_bf16_tkc,   /* both NULL, or M bf16 buffers each: bf16 copies of
                                                                                               the two layouts (what mrdis_cast_bf16 would give) */
+                                       int ld_tck, long long tap_tkc,   /* 0 = dense.  Otherwise the row pitch of the [T][Ci][.] outputs and the tap
+                                                                           pitch of the [T][.][Ci] outputs: the pointers address a column / row block of a
+                                                                           wider filter (the halves of a fused gamma | beta filter, model.py:2443-2444) */
                                        int E, int Co, int Ci, int T, void* stream);
 size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int Co, int Ci, int T);
 int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
                                        int emb, int M, float* dW, float* dfc_w, float* dfc_b,
                                        int accumulate,      /* 1: the three results are ADDED to dW / dfc_w / dfc_b (gradient sinks) */
+                                       int ld_dw,           /* 0 = dense; otherwise the row pitch of the dw_tck tensors (a column block of a wider gradient) */
                                        void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream);
 
 /* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and

@@ -2345,7 +2345,9 @@ struct MixPtrs { float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* b
 struct MixCPtrs { const float* p[MIX_MAX_TYPES]; };
 __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
                                             const float* __restrict__ types, int emb, float* __restrict__ r_out, MixPtrs out,
-                                            int E, int Co, int Ci, int T) {
+                                            int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc) {
+    // ld_tck: row pitch of the [T][Ci][.] outputs, tap_tkc: tap pitch of the [T][.][Ci] outputs -- Co and Co * Ci for a filter of its
+    // own, 2 Co and 2 Co * Ci when the pointers address one half of a fused gamma | beta filter
     const int m = blockIdx.y;
     const float* t = types + m * emb;
     float* __restrict__ w_tck = out.tck[m];
@@ -2367,18 +2369,19 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
         float s_ = 0.f;
         for (int e = 0; e < E; ++e) s_ += rr[e] * W[(long long)e * total + i];      // same order as the single-type kernel
-        w_tck[((long long)tt * Ci + ci) * Co + co] = s_;
-        w_tkc[((long long)tt * Co + co) * Ci + ci] = s_;
+        const long long o_tck = ((long long)tt * Ci + ci) * ld_tck + co, o_tkc = (long long)tt * tap_tkc + (long long)co * Ci + ci;
+        w_tck[o_tck] = s_;
+        w_tkc[o_tkc] = s_;
         if (b_tck != nullptr) {                              // the bf16 MFMA operands of compute_dtype bf16 (round to nearest even, as mrdis_cast_bf16)
-            b_tck[((long long)tt * Ci + ci) * Co + co] = (__bf16)s_;
-            b_tkc[((long long)tt * Co + co) * Ci + ci] = (__bf16)s_;
+            b_tck[o_tck] = (__bf16)s_;
+            b_tkc[o_tkc] = (__bf16)s_;
         }
     }
 }
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
 // dW[e] = sum_m r[m][e] dw_m (types in order m = 0..M-1; a type without gradient contributes nothing).
 __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
-                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate) {
+                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw) {
     __shared__ double red[8][4];
     const int m = blockIdx.y;
     const long long total = (long long)Co * Ci * T;
@@ -2391,7 +2394,7 @@ __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, c
         const int t = (int)(i % T);
         const long long q = i / T;
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
-        const long long idx = ((long long)t * Ci + ci) * Co + co;
+        const long long idx = ((long long)t * Ci + ci) * ld_dw + co;          // ld_dw: row pitch of the gradient tensors (Co, or 2 Co for a fused half)
         if (g_m != nullptr) {
             const float g = g_m[idx];
 #pragma unroll
@@ -2510,7 +2513,7 @@ extern "C" int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W,
 
 extern "C" int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* fc_w, const float* fc_b, const float* types, int emb, int M,
                                                   float* r_out, float* const* w_tck, float* const* w_tkc,
-                                                  void* const* w_bf16_tck, void* const* w_bf16_tkc,
+                                                  void* const* w_bf16_tck, void* const* w_bf16_tkc, int ld_tck, long long tap_tkc,
                                                   int E, int Co, int Ci, int T, void* stream) {
     if (!W || !fc_w || !fc_b || !types || !r_out || !w_tck || !w_tkc || E < 1 || E > 8 || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES)
         return MRDIS_EINVAL;
@@ -2525,8 +2528,11 @@ extern "C" int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* f
         }
     }
     const long long total = (long long)Co * Ci * T;
+    if (ld_tck <= 0) ld_tck = Co;
+    if (tap_tkc <= 0) tap_tkc = (long long)Co * Ci;
+    if (ld_tck < Co || tap_tkc < (long long)Co * Ci) return MRDIS_EINVAL;
     hipLaunchKernelGGL(mix_routed_multi_fwd_kernel, dim3(mix_blocks(total), M), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, types, emb,
-                       r_out, out, E, Co, Ci, T);
+                       r_out, out, E, Co, Ci, T, ld_tck, tap_tkc);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -2537,7 +2543,7 @@ extern "C" size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int
 }
 
 extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
-                                                  int emb, int M, float* dW, float* dfc_w, float* dfc_b, int accumulate,
+                                                  int emb, int M, float* dW, float* dfc_w, float* dfc_b, int accumulate, int ld_dw,
                                                   void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream) {
     if (!dw_tck || !W || !r || !types || !dW || !dfc_w || !dfc_b || !workspace || E < 1 || E > 8 || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES)
         return MRDIS_EINVAL;
@@ -2547,7 +2553,7 @@ extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, co
     MixCPtrs dw{};
     for (int m = 0; m < M; ++m) dw.p[m] = dw_tck[m];
     hipLaunchKernelGGL(mix_multi_bwd_kernel, dim3(nb, M), dim3(256), 0, (hipStream_t)stream, dw, W, r, dW,
-                       reinterpret_cast<float*>(workspace), M, E, Co, Ci, T, accumulate ? 1 : 0);
+                       reinterpret_cast<float*>(workspace), M, E, Co, Ci, T, accumulate ? 1 : 0, ld_dw > 0 ? ld_dw : Co);
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(mix_multi_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, M, E, r, types, emb, dfc_w, dfc_b, accumulate ? 1 : 0);

@@ -38,9 +38,9 @@ _SIGS = {
     'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
-    'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
-    'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
@@ -332,39 +332,51 @@ def mix_experts_routed_bwd(dw_tck, W, r, t_row, emb):
     return dW, dfcw, dfcb
 
 
-def mix_experts_routed_multi_fwd(W, fcw, fcb, types, want_bf16=False):
-    """all M type rows at once: -> ([w_tck_m], [w_tkc_m], r (M,E)); want_bf16: + ([bf16(w_tck_m)], [bf16(w_tkc_m)]) from the same launch."""
+def mix_experts_routed_multi_fwd(W, fcw, fcb, types, want_bf16=False, into=None):
+    """all M type rows at once: -> ([w_tck_m], [w_tkc_m], r (M,E)); want_bf16: + ([bf16(w_tck_m)], [bf16(w_tkc_m)]) from the same launch.
+    into = (tck, tkc, btck, btkc, col0, co_total): write into column block [col0, col0 + Co) of existing WIDER filters (lists of M tensors
+    (T, Ci, co_total) / (T, co_total, Ci); btck / btkc None or the bf16 twins) -- the halves of a fused gamma | beta filter; -> r only."""
     lib = load()
     E, Co, Ci, kh, kw = W.shape
     T = kh * kw
     W = W.contiguous(); fcw = fcw.contiguous(); fcb = fcb.contiguous(); types = types.contiguous()
     M, emb = types.shape
+    r = torch.empty((M, E), dtype=torch.float32, device=W.device)
+    if into is not None:
+        tck, tkc, btck, btkc, col0, cot = into
+        a = (_c.c_void_p * M)(*[t.data_ptr() + 4 * col0 for t in tck]); b = (_c.c_void_p * M)(*[t.data_ptr() + 4 * col0 * Ci for t in tkc])
+        ba = bb = None
+        if btck is not None:
+            ba = (_c.c_void_p * M)(*[t.data_ptr() + 2 * col0 for t in btck]); bb = (_c.c_void_p * M)(*[t.data_ptr() + 2 * col0 * Ci for t in btkc])
+        _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, ba, bb, cot, cot * Ci,
+                                                    E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_fwd')
+        return r
     tck = [torch.empty((T, Ci, Co), dtype=torch.float32, device=W.device) for _ in range(M)]
     tkc = [torch.empty((T, Co, Ci), dtype=torch.float32, device=W.device) for _ in range(M)]
-    r = torch.empty((M, E), dtype=torch.float32, device=W.device)
     a = (_c.c_void_p * M)(*[t.data_ptr() for t in tck]); b = (_c.c_void_p * M)(*[t.data_ptr() for t in tkc])
     ba = bb = None
     if want_bf16:
         btck = [torch.empty((T, Ci, Co), dtype=torch.bfloat16, device=W.device) for _ in range(M)]
         btkc = [torch.empty((T, Co, Ci), dtype=torch.bfloat16, device=W.device) for _ in range(M)]
         ba = (_c.c_void_p * M)(*[t.data_ptr() for t in btck]); bb = (_c.c_void_p * M)(*[t.data_ptr() for t in btkc])
-    _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, ba, bb, E, Co, Ci, T, _stream()),
+    _chk(lib.mrdis_mix_experts_routed_multi_fwd(_ptr(W), _ptr(fcw), _ptr(fcb), _ptr(types), emb, M, _ptr(r), a, b, ba, bb, 0, 0, E, Co, Ci, T, _stream()),
          'mix_experts_routed_multi_fwd')
     if want_bf16:
         return tck, tkc, r, btck, btkc
     return tck, tkc, r
 
 
-def mix_experts_routed_multi_bwd(dw_list, W, r, types, sinks=None):
+def mix_experts_routed_multi_bwd(dw_list, W, r, types, sinks=None, col0=0, ld=0):
     """dw_list: M tensors (T,Ci,Co) or None -> (dW, dfcw, dfcb) summed over the types.  sinks = (gW, gfcw, gfcb): contiguous fp32
-    gradient buffers the three results are ADDED to in-kernel (returned as they are)."""
+    gradient buffers the three results are ADDED to in-kernel (returned as they are).  col0 / ld: the gradients are the column block
+    [col0, col0 + Co) of contiguous (T, Ci, ld) tensors (one half of a fused gamma | beta filter gradient)."""
     lib = load()
     E, Co, Ci, kh, kw = W.shape
     T = kh * kw
     W = W.contiguous(); types = types.contiguous()
     M, emb = types.shape
     dw_list = [None if g is None else g.contiguous() for g in dw_list]
-    a = (_c.c_void_p * M)(*[None if g is None else g.data_ptr() for g in dw_list])
+    a = (_c.c_void_p * M)(*[None if g is None else g.data_ptr() + 4 * col0 for g in dw_list])
     if sinks is not None:
         dW, dfcw, dfcb = sinks
     else:
@@ -374,7 +386,7 @@ def mix_experts_routed_multi_bwd(dw_list, W, r, types, sinks=None):
     nb = _ws_bytes(lib.mrdis_mix_experts_routed_multi_bwd_workspace, M, E, Co, Ci, T)
     ws = _ws(nb, W.device)
     _chk(lib.mrdis_mix_experts_routed_multi_bwd(a, _ptr(W), _ptr(r), _ptr(types), emb, M, _ptr(dW), _ptr(dfcw), _ptr(dfcb),
-                                                1 if sinks is not None else 0, _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
+                                                1 if sinks is not None else 0, ld, _ptr(ws), nb, E, Co, Ci, T, _stream()), 'mix_experts_routed_multi_bwd')
     return dW, dfcw, dfcb
 
 

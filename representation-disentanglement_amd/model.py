@@ -322,7 +322,16 @@ class SPADEBlockNew(nn.Module):
                 b_tck, b_tkc = self.beta.mixed_uniform(inputs_type)
                 return (torch.cat([g_tck, b_tck], 2), torch.cat([g_tkc, b_tkc], 1),
                         torch.cat([self.gamma.bias, self.beta.bias]))
-            w_tck, w_tkc, bias = ops.step_cache(key, fused)
+            hit = ops.lookup_type_row(inputs_type) if ops.mix_cache_active() else None
+            if hit is not None and self.gamma.weight.shape == self.beta.weight.shape:
+                # one of the model's modality labels: gamma and beta are mixed for ALL labels straight into the fused filters
+                table, row = hit
+                allw = ops.cached_mix((id(self), 'gb_all', table.data_ptr(), table._version),
+                                      lambda: ops.mix_pair_fused_all(self.gamma, self.beta, table))
+                bias = ops.cached_mix((id(self), 'gb_bias'), lambda: torch.cat([self.gamma.bias, self.beta.bias]))
+                w_tck, w_tkc = allw[2 * row], allw[2 * row + 1]
+            else:
+                w_tck, w_tkc, bias = ops.step_cache(key, fused)
             gb = ops.conv2d(si_out, w_tck, w_tkc, bias, kh, kw, 1, self.gamma.padding[0])
             mix = ops.instnorm_spade_gb(zi, gb, self.zi_layers.eps)       # :2440 + :2446
         else:

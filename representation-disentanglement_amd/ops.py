@@ -96,6 +96,60 @@ def mix_experts_routed_all(W, fcw, fcb, types):
     return _MixExpertsRoutedAll.apply(W, fcw, fcb, types)
 
 
+class _MixPairFusedAll(Function):
+    """The gamma and beta experts of a SPADE block (model.py:2443-2444), mixed for every modality label of the step straight into ONE
+    fused filter per label -- [T][Ci][2C] and [T][2C][Ci], gamma in the first C couts, beta in the second -- by two launches
+    (the op-by-op construction was two mixes + three concatenations per label forward and two strided copies per label backward).
+    Returns (w_tck_0, w_tkc_0, ..., w_tck_{M-1}, w_tkc_{M-1}); the backward reads each half of the fused gradients in place."""
+
+    @staticmethod
+    def forward(ctx, Wg, fwg, fbg, Wb, fwb, fbb, types):
+        E, C, Ci, kh, kw = Wg.shape
+        T, M = kh * kw, types.shape[0]
+        dev_ = Wg.device
+        tck = [torch.empty((T, Ci, 2 * C), dtype=torch.float32, device=dev_) for _ in range(M)]
+        tkc = [torch.empty((T, 2 * C, Ci), dtype=torch.float32, device=dev_) for _ in range(M)]
+        btck = btkc = None
+        if _COMPUTE_DTYPE != hip.DT_F32:
+            btck = [torch.empty((T, Ci, 2 * C), dtype=torch.bfloat16, device=dev_) for _ in range(M)]
+            btkc = [torch.empty((T, 2 * C, Ci), dtype=torch.bfloat16, device=dev_) for _ in range(M)]
+        rg = hip.mix_experts_routed_multi_fwd(Wg, fwg, fbg, types, into=(tck, tkc, btck, btkc, 0, 2 * C))
+        rb = hip.mix_experts_routed_multi_fwd(Wb, fwb, fbb, types, into=(tck, tkc, btck, btkc, C, 2 * C))
+        if btck is not None and _MIX_CACHE is not None:
+            for a, ba, bb in zip(tck, btck, btkc):
+                _MIX_CACHE[('bf16w', id(a))] = (a, bb, ba)
+        ctx.save_for_backward(Wg, rg, Wb, rb, types)
+        ctx.params = (Wg, fwg, fbg, Wb, fwb, fbb)
+        ctx.C = C
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*tkc)
+        out = []
+        for a, b in zip(tck, tkc):
+            out += [a, b]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        Wg, rg, Wb, rb, types = ctx.saved_tensors
+        C = ctx.C
+        g = list(grads[0::2])
+        res = []
+        for W, r, prm, col0 in ((Wg, rg, ctx.params[0:3], 0), (Wb, rb, ctx.params[3:6], C)):
+            sinks = tuple(_grad_sink(q) for q in prm)
+            if all(x is not None for x in sinks) and sinks[0].shape == W.shape:
+                hip.mix_experts_routed_multi_bwd(g, W, r, types, sinks=sinks, col0=col0, ld=2 * C)
+                res += [None, None, None]
+            else:
+                res += list(hip.mix_experts_routed_multi_bwd(g, W, r, types, col0=col0, ld=2 * C))
+        return tuple(res) + (None,)
+
+
+def mix_pair_fused_all(gamma, beta, types):
+    """gamma / beta: CondConv2d modules with equal geometry -> the tuple of _MixPairFusedAll."""
+    return _MixPairFusedAll.apply(gamma.weight, gamma._routing_fn.fc.weight, gamma._routing_fn.fc.bias,
+                                  beta.weight, beta._routing_fn.fc.weight, beta._routing_fn.fc.bias, types)
+
+
 # registry of the per-model type tables: storage pointer -> (M, emb) tensor whose rows are the modality labels
 _TYPE_TABLES = {}
 
