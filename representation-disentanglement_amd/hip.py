@@ -434,15 +434,19 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     return out
 
 
-def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None):
-    """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co)."""
+def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None):
+    """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co).  out: a dense NHWC (N, Ci, H, W) view to write into."""
     lib = load()
     dy, lddy = nhwc(dy)
     N, Co, Ho, Wo = dy.shape
     T, Co2, Ci = w_tkc.shape
     H, W = in_hw
     assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
-    dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype)
+    if out is None:
+        dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype)
+    else:
+        dx, ldo = nhwc(out)
+        assert dx.data_ptr() == out.data_ptr() and ldo == Ci and tuple(out.shape) == (N, Ci, H, W) and out.dtype == dy.dtype
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)

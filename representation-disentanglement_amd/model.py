@@ -340,6 +340,33 @@ class SPADEBlockNew(nn.Module):
             mix = ops.instnorm_spade(zi, gamma, beta, self.zi_layers.eps)
         return self.out(mix, *t)
 
+    def _fused_gb(self, inputs_type):
+        """((w_tck, w_tkc), bias) of the fused gamma | beta convolution for one modality label (see forward)."""
+        hit = ops.lookup_type_row(inputs_type) if ops.mix_cache_active() else None
+        if hit is not None and self.gamma.weight.shape == self.beta.weight.shape:
+            table, row = hit
+            allw = ops.cached_mix((id(self), 'gb_all', table.data_ptr(), table._version),
+                                  lambda: ops.mix_pair_fused_all(self.gamma, self.beta, table))
+            bias = ops.cached_mix((id(self), 'gb_bias'), lambda: torch.cat([self.gamma.bias, self.beta.bias]))
+            return (allw[2 * row], allw[2 * row + 1]), bias
+        g_tck, g_tkc = self.gamma.mixed_uniform(inputs_type)
+        b_tck, b_tkc = self.beta.mixed_uniform(inputs_type)
+        return (torch.cat([g_tck, b_tck], 2), torch.cat([g_tkc, b_tkc], 1)), torch.cat([self.gamma.bias, self.beta.bias])
+
+    def forward_grouped(self, si, z_cat, types):
+        """The block for G modality labels at once: z_cat holds G sample blocks of B (block g belongs to types[g]), `si` the B anatomy
+        maps every block reads.  One launch per normalisation kernel, one op per convolution layer (ops.conv2d_grouped)."""
+        size = self.input_size
+        src = si
+        si = ops.step_cache(('bil', id(src), size), lambda: (src, ops.bilinear(src, size, False)))[1]
+        kh, kw = self.gamma.kernel_size
+        pad = self.gamma.padding[0]
+        si_out = ops.conv2d_grouped(si, [self.si_layers.mixed_uniform(t) for t in types], self.si_layers.bias, kh, kw, pad, share_x=True)
+        fused = [self._fused_gb(t) for t in types]
+        gb = ops.conv2d_grouped(si_out, [f[0] for f in fused], fused[0][1], kh, kw, pad)
+        mix = ops.instnorm_spade_gb(z_cat, gb, self.zi_layers.eps)
+        return ops.conv2d_grouped(mix, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, pad)
+
 
 def _up2(x):
     """nn.Upsample(scale_factor=(2,2), mode='bilinear')  (model.py:2551)."""
@@ -392,6 +419,21 @@ class SPADENewNotShared(nn.Module):
         x = self.sp6(si, _up2(x), inputs_type)
         x = self.out(x, inputs_type) if self.is_cond else self.out(x)
         return self.out_act(x)
+
+    def forward_grouped(self, si, z_cat, types):
+        """forward for G modality labels on batch-concatenated inputs (see SPADEBlockNew.forward_grouped)."""
+        x = self.sp4.forward_grouped(si, z_cat, types)
+        x = self.sp5.forward_grouped(si, _up2(x), types)
+        x = self.sp6.forward_grouped(si, _up2(x), types)
+        kh, kw = self.out.kernel_size
+        x = ops.conv2d_grouped(x, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, self.out.padding[0])
+        return self.out_act(x)
+
+    def grouped_ok(self):
+        blocks = (self.sp4, self.sp5, self.sp6)
+        return (self.is_cond and all(b.si_layers.stride == (1, 1) and b.gamma.kernel_size == b.out.kernel_size == b.si_layers.kernel_size
+                                     and b.gamma.weight.shape == b.beta.weight.shape for b in blocks)
+                and self.out.stride == (1, 1))
 
 
 # =============================================================================
@@ -674,10 +716,36 @@ class MultimodalModel(nn.Module):
             return (list(si_list), list(zi_list), mids)       # inputs kept alive with the cache entry
         return ops.step_cache(key, make)[2]
 
+    def _notshared_all(self, si_list, zi_list):
+        """Every (decoder i, label j) reconstruction of the step, or None when the grouped path does not apply.  Decoder i serves
+        (s_i, z_j) for all M labels j (model.py:3200-3203, 3219-3224): run as ONE batch-concatenated call per decoder, sample block j
+        with the kernels mixed for label j (SPADENewNotShared.forward_grouped) -- the normalisation / resize kernels and the Python
+        op dispatches of the four calls collapse into one."""
+        decs = [self.input_decoder_list[i] for i in range(self.modality_num)]
+        if not (ops.grouped_applies() and all(hasattr(d, 'grouped_ok') and d.grouped_ok() for d in decs)):
+            return None
+        key = ('nsall', id(si_list[0]), id(zi_list[0]))
+
+        def make():
+            M, B = self.modality_num, si_list[0].shape[0]
+            mids = self._shared_mids(si_list, zi_list)
+            types = [self._type(j, B) for j in range(M)]
+            outs = {}
+            for i in range(M):
+                z_cat = torch.cat([mids[(i, j)] for j in range(M)], 0)
+                y = self.input_decoder_list[i].forward_grouped(si_list[i], z_cat, types)
+                for j, part in enumerate(ops.split_batch(y, M)):
+                    outs[(i, j)] = part
+            return (list(si_list), list(zi_list), outs)
+        return ops.step_cache(key, make)[2]
+
     # ---- model.py:3187-3203
     def reconstruct_input_si_zi(self, si_list, zi_list):
         out = []
         B = si_list[0].shape[0]
+        allo = self._notshared_all(si_list, zi_list)
+        if allo is not None:
+            return [allo[(i, i)] for i in range(self.modality_num)]
         mids = self._shared_mids(si_list, zi_list)
         for i in range(self.modality_num):
             out.append(self.input_decoder_list[i](si_list[i], mids[(i, i)], self._type(i, B)))
@@ -687,6 +755,9 @@ class MultimodalModel(nn.Module):
     def reconstruct_input_si_zj(self, si_list, zi_list):
         out = []
         B = si_list[0].shape[0]
+        allo = self._notshared_all(si_list, zi_list)
+        if allo is not None:
+            return [allo[(i, j)] for i in range(self.modality_num) for j in range(self.modality_num) if i != j]
         mids = self._shared_mids(si_list, zi_list)
         for i in range(self.modality_num):
             for j in range(self.modality_num):

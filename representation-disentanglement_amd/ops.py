@@ -315,6 +315,83 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
     return cast_view(y, torch.bfloat16) if Co >= 16 else y
 
 
+# --------------------------------------------------------------------------- grouped convolution (one autograd node, G filter sets)
+# The M modality types of a not-shared decoder (model.py:3187-3224) share the layer geometry and differ in the mixed filters only.  Run
+# batch-concatenated (G * B samples, sample block g uses filter set g) every normalisation / resize / activation kernel of the
+# decoder is ONE launch instead of G, and the G convolutions of a layer are one Python op (G calls of the C entry on batch slices):
+# a quarter of the op dispatches, autograd nodes and allocations of the per-type form.  Same kernels per sample block, same results.
+_GROUPED = _os.environ.get('MRDIS_GROUPED', '1') != '0'
+
+
+def set_grouped(enabled):
+    global _GROUPED
+    _GROUPED = bool(enabled)
+
+
+def grouped_applies():
+    """fp32 and bf16m compute dtypes inside a training step (the bf16 STORAGE mode keeps the per-type path: its narrow layers are
+    padded per call)."""
+    return _GROUPED and _MIX_CACHE is not None and _COMPUTE_DTYPE != hip.DT_BF16 and torch.is_grad_enabled()
+
+
+class _GroupedConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, *filt):
+        bm = _COMPUTE_DTYPE == hip.DT_F32_BF16M
+        B = x.shape[0] if share_x else x.shape[0] // G
+        H, W = x.shape[2], x.shape[3]
+        Co = filt[0].shape[2]
+        y = hip.empty_nhwc(G * B, Co, H, W, x.device, x.dtype)
+        wbs = []
+        for g in range(G):
+            tck, tkc = filt[2 * g], filt[2 * g + 1]
+            wb = bf16_filters(tck, tkc) if bm else (None, None)
+            wbs.append(wb[1])
+            hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bias, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb[0])
+        ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32)
+        ctx.wbs = wbs
+        ctx.bias_param = bias
+        ctx.save_for_backward(x, y if lrelu else None, *[filt[2 * g + 1] for g in range(G)])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        G, B, share_x, kh, kw, pad, lrelu, dt = ctx.meta
+        x, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        tkcs = ctx.saved_tensors[2:]
+        bias = ctx.bias_param
+        if lrelu:
+            dy = hip.lrelu_bwd(dy, y, 0.2)
+        Ci, H, W = x.shape[1], x.shape[2], x.shape[3]
+        need_x = ctx.needs_input_grad[0]
+        dxb = hip.empty_nhwc(G * B, Ci, H, W, x.device, dy.dtype) if need_x else None
+        sink = _grad_sink(bias) if bias is not None else None
+        dws, db_total = [], None
+        for g in range(G):
+            dyg = dy[g * B:(g + 1) * B]
+            xg = x if share_x else x[g * B:(g + 1) * B]
+            if need_x:
+                hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, 1, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
+            dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
+            dws += [dw, None]
+            if db is not None:
+                db_total = db if db_total is None else db_total + db
+        dx = None
+        if need_x:
+            # a shared input collects the gradients of all G uses: one reduction over the group axis
+            dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci).sum(0).permute(0, 3, 1, 2) if share_x else dxb
+        return (dx, db_total, None, None, None, None, None, None) + tuple(dws)
+
+
+def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False):
+    """x: (G * B, Ci, H, W) sample blocks (or (B, Ci, H, W) read by every group when share_x); filters: G pairs (w_tck, w_tkc);
+    stride 1.  -> (G * B, Co, H, W): block g = conv(x_g, filters[g]) + bias."""
+    flat = []
+    for a, b in filters:
+        flat += [a, b]
+    return _GroupedConvFn.apply(x, bias, len(filters), bool(share_x), kh, kw, pad, bool(lrelu), *flat)
+
+
 # --------------------------------------------------------------------------- norms
 class _BatchNormTrain(Function):
     """nn.BatchNorm2d in training mode (model.py:2151, 2191, 2776-2785)."""

@@ -254,6 +254,38 @@ def test_train_step_vs_oracle_other_sizes(mrdis, B, M, H, W, drop, adv):
             assert p.grad is None, n
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16m'])
+def test_grouped_decoder_matches_per_type_calls(mrdis, mode):
+    """The not-shared decoders run batch-concatenated over the modality labels (SPADENewNotShared.forward_grouped, ops.conv2d_grouped)
+    launch the same kernels per sample block as the 16 per-type calls: loss, reconstructions and parameter gradients agree to rounding
+    of the gradient sums (the order in which the four labels' contributions meet changes)."""
+    B, M, H, W = 2, 4, 64, 96
+    cfg = _cfg(mrdis, M, H, W, B, adv=True)
+    cfg['compute_dtype'] = mode
+    res = {}
+    try:
+        for on in (False, True):
+            mrdis.ops.set_grouped(on)
+            torch.manual_seed(10); np.random.seed(10)
+            model = mrdis.build_model(cfg).train()
+            inputs, mask, mask_img = make_inputs(B, M, H, W, seed=10, drop=True)
+            torch.manual_seed(11); np.random.seed(11)
+            with mrdis.ops.mix_cache():
+                loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+                loss.backward()
+            res[on] = (loss.detach().clone(), [t.detach().clone() for t in aux['xi_fake_list'] + aux['xi_fake_mix_list']],
+                       {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        mrdis.ops.set_grouped(True)
+        mrdis.ops.set_compute_dtype('f32')
+    assert torch.equal(res[False][0], res[True][0]), (float(res[False][0]), float(res[True][0]))        # the forward pass is the same arithmetic
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+    assert res[False][2].keys() == res[True][2].keys()
+    for n in res[False][2]:
+        close(res[True][2][n], res[False][2][n].cpu(), 2e-5, n)
+
+
 def test_train_step_winograd_vs_direct_kernels(mrdis):
     """The whole step with every eligible 3x3 layer forced through the Winograd kernels (MRDIS_WINO=2: forward, data and
     weight gradients) against the same step on the direct kernels (MRDIS_WINO=0): loss, loss parts and every parameter
