@@ -329,57 +329,99 @@ def set_grouped(enabled):
 
 
 def grouped_applies():
-    """fp32 and bf16m compute dtypes inside a training step (the bf16 STORAGE mode keeps the per-type path: its narrow layers are
-    padded per call)."""
-    return _GROUPED and _MIX_CACHE is not None and _COMPUTE_DTYPE != hip.DT_BF16 and torch.is_grad_enabled()
+    """inside a training step (mixed-kernel cache open, autograd on), every compute dtype."""
+    return _GROUPED and _MIX_CACHE is not None and torch.is_grad_enabled()
+
+
+def _pad16_filters(w_tck, w_tkc, bias, Ci_p, Co_p):
+    """zero-padded copies of a narrow filter (+ bias) for the bf16 MFMA kernels and their bf16 layouts, memoised for the step:
+    -> (wp_tck, wp_tkc, bias_p, bf16 forward operand, bf16 data-gradient operand).  Detached: the grouped Function slices the
+    padded weight gradient back itself."""
+    import torch.nn.functional as F
+    Ci, Co = w_tck.shape[1], w_tck.shape[2]
+
+    def make():
+        with torch.no_grad():
+            wp_tck = F.pad(w_tck.detach(), (0, Co_p - Co, 0, Ci_p - Ci))
+            wp_tkc = F.pad(w_tkc.detach(), (0, Ci_p - Ci, 0, Co_p - Co))
+            bp = None if bias is None else F.pad(bias.detach(), (0, Co_p - Co))
+            return (w_tck, wp_tck, wp_tkc, bp, hip.cast_bf16(wp_tkc), hip.cast_bf16(wp_tck))
+    return cached_mix(('pad16g', id(w_tck), None if bias is None else id(bias)), make)[1:]
 
 
 class _GroupedConvFn(Function):
+    """G convolutions with the same geometry on the G sample blocks of a batch-concatenated tensor (or on one shared input).  In the
+    bf16 storage mode it applies the policy of ops.conv2d per group: bf16 kernels on bf16 views, a narrow channel side (the 4-channel
+    anatomy maps in, the 7-channel reconstruction out) zero-padded to 16."""
+
     @staticmethod
     def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, *filt):
-        bm = _COMPUTE_DTYPE == hip.DT_F32_BF16M
+        bm = _COMPUTE_DTYPE != hip.DT_F32
+        st = _COMPUTE_DTYPE == hip.DT_BF16
         B = x.shape[0] if share_x else x.shape[0] // G
         H, W = x.shape[2], x.shape[3]
-        Co = filt[0].shape[2]
-        y = hip.empty_nhwc(G * B, Co, H, W, x.device, x.dtype)
-        wbs = []
+        Ci, Co = filt[0].shape[1], filt[0].shape[2]
+        Ci_p, Co_p = (max(Ci, 16), max(Co, 16)) if st else (Ci, Co)
+        padded = (Ci_p, Co_p) != (Ci, Co)
+        xin = x
+        if st and (x.dtype != torch.bfloat16 or Ci_p != Ci):
+            xin = hip.cast_view(x, torch.bfloat16, Ci_p)           # fp32 -> bf16 view cast, zero channels up to 16
+        y = hip.empty_nhwc(G * B, Co_p, H, W, x.device, xin.dtype)
+        use_tkc, wbs = [], []
         for g in range(G):
             tck, tkc = filt[2 * g], filt[2 * g + 1]
-            wb = bf16_filters(tck, tkc) if bm else (None, None)
-            wbs.append(wb[1])
-            hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bias, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb[0])
-        ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32)
+            bg = bias
+            if padded:
+                tck, tkc, bg, wb_f, wb_b = _pad16_filters(tck, tkc, bias, Ci_p, Co_p)
+            else:
+                wb_f, wb_b = bf16_filters(tck, tkc) if bm else (None, None)
+            use_tkc.append(tkc); wbs.append(wb_b)
+            hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
+        ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype)
         ctx.wbs = wbs
         ctx.bias_param = bias
-        ctx.save_for_backward(x, y if lrelu else None, *[filt[2 * g + 1] for g in range(G)])
-        return y
+        ctx.save_for_backward(xin, y if lrelu else None, *use_tkc)
+        return y if Co_p == Co else hip.cast_view(y, torch.float32, Co)       # a padded head leaves as fp32 (the losses read it)
 
     @staticmethod
     def backward(ctx, dy):
-        G, B, share_x, kh, kw, pad, lrelu, dt = ctx.meta
-        x, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        G, B, share_x, kh, kw, pad, lrelu, dt, Ci, Co, Ci_p, Co_p, x_dtype = ctx.meta
+        xin, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         tkcs = ctx.saved_tensors[2:]
         bias = ctx.bias_param
+        if Co_p != Co:
+            dy = hip.cast_view(dy, torch.bfloat16, Co_p)
+        elif dy.dtype != xin.dtype:
+            dy = hip.cast_view(dy, xin.dtype)
         if lrelu:
             dy = hip.lrelu_bwd(dy, y, 0.2)
-        Ci, H, W = x.shape[1], x.shape[2], x.shape[3]
+        H, W = xin.shape[2], xin.shape[3]
         need_x = ctx.needs_input_grad[0]
-        dxb = hip.empty_nhwc(G * B, Ci, H, W, x.device, dy.dtype) if need_x else None
-        sink = _grad_sink(bias) if bias is not None else None
+        dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, dy.dtype) if need_x else None
+        sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None
         dws, db_total = [], None
         for g in range(G):
             dyg = dy[g * B:(g + 1) * B]
-            xg = x if share_x else x[g * B:(g + 1) * B]
+            xg = xin if share_x else xin[g * B:(g + 1) * B]
             if need_x:
                 hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, 1, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
             dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
+            if (Ci_p, Co_p) != (Ci, Co):
+                dw = dw[:, :Ci, :Co].contiguous()
             dws += [dw, None]
             if db is not None:
                 db_total = db if db_total is None else db_total + db
+        if db_total is not None and Co_p != Co:
+            db_total = db_total[:Co]
+            s_ = _grad_sink(bias)
+            if s_ is not None:
+                s_.add_(db_total); db_total = None
         dx = None
         if need_x:
             # a shared input collects the gradients of all G uses: one reduction over the group axis
-            dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci).sum(0).permute(0, 3, 1, 2) if share_x else dxb
+            dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci_p).sum(0).permute(0, 3, 1, 2) if share_x else dxb
+            if dx.dtype != x_dtype or Ci_p != Ci:
+                dx = hip.cast_view(dx, x_dtype, Ci)
         return (dx, db_total, None, None, None, None, None, None) + tuple(dws)
 
 

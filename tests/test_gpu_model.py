@@ -254,7 +254,7 @@ def test_train_step_vs_oracle_other_sizes(mrdis, B, M, H, W, drop, adv):
             assert p.grad is None, n
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16m'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16m', 'bf16'])
 def test_grouped_decoder_matches_per_type_calls(mrdis, mode):
     """The not-shared decoders run batch-concatenated over the modality labels (SPADENewNotShared.forward_grouped, ops.conv2d_grouped)
     launch the same kernels per sample block as the 16 per-type calls: loss, reconstructions and parameter gradients agree to rounding
@@ -283,7 +283,13 @@ def test_grouped_decoder_matches_per_type_calls(mrdis, mode):
         assert torch.equal(a, b)
     assert res[False][2].keys() == res[True][2].keys()
     for n in res[False][2]:
-        close(res[True][2][n], res[False][2][n].cpu(), 2e-5, n)
+        a, b = res[True][2][n], res[False][2][n]
+        if mode != 'bf16':
+            close(a, b.cpu(), 2e-5, n)
+        elif a.dim() >= 2:
+            # bf16 storage: the gradient sums of the shared anatomy maps round in bf16 in a different order; compare in the Frobenius
+            # norm (biases in front of a BatchNorm have an analytically zero gradient: pure rounding noise, skipped)
+            assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
 
 
 def test_train_step_winograd_vs_direct_kernels(mrdis):
