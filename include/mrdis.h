@@ -150,6 +150,17 @@ int mrdis_cast_view(const void* src, int ld_src, int src_dtype, int C_src, void*
  * host -> device transfers inside a step avoid the copy engine's host round trip (the reference's CPU-drawn eps, model.py:3159-3162). */
 int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, void* stream);
 
+/* A SPADE block's  InstanceNorm(z) * (1 + gamma(s)) + beta(s)  (model.py:2440-2446) with the gamma | beta convolution and the modulation in
+ * ONE launch: x = the si_layers output (N, H, W, Ci), w_tck = the fused [9][Ci][2 C] filter (gamma couts first), bias (2 C), z (N, H, W, C)
+ * and its instance statistics (mrdis_instnorm_stats).  Writes mix and gamma (the backward, mrdis_instnorm_spade_bwd, needs gamma).
+ * fp32.  MRDIS_EUNSUPPORTED where the pipelined Winograd kernel is not the kernel of choice: run mrdis_conv2d_fwd +
+ * mrdis_instnorm_spade_fwd instead. */
+int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                         int N, long long HW, int C, float eps, int dtype, void* stream);
+int mrdis_conv2d_fwd_spade(const float* x, int ldx, const float* w_tck, const float* bias, const float* z, int ldz,
+                           const float* mean, const float* rstd, float* mix, int ldmix, float* gamma, int ldg,
+                           int N, int H, int W, int Ci, int C, void* stream);
+
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.
  * dw_tck: [T][Ci][Co] ; dbias (Co) or NULL.                                   */

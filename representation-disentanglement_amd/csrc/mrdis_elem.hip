@@ -851,6 +851,24 @@ extern "C" int mrdis_instnorm_spade_fwd(const void* z, int ldz, const void* gamm
         instnorm_spade_fwd_impl((const float*)z, ldz, (const float*)gamma, ldg, (const float*)beta, ldb, (float*)out, ldo, save_mean, save_rstd, workspace, workspace_bytes, N, HW, C, eps, stream),
         instnorm_spade_fwd_impl((cbf)z, ldz, (cbf)gamma, ldg, (cbf)beta, ldb, (bf)out, ldo, save_mean, save_rstd, workspace, workspace_bytes, N, HW, C, eps, stream));
 }
+// Instance statistics only (mean, 1 / sqrt(var + eps) per (sample, channel)): the first half of mrdis_instnorm_spade_fwd, for callers that
+// apply the modulation elsewhere (the SPADE epilogue of the Winograd kernel, mrdis_conv2d_fwd_spade).
+extern "C" int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                                    int N, long long HW, int C, float eps, int dtype, void* stream) {
+    if (!z || !save_mean || !save_rstd || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_norm_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    int rc;
+    if (dtype == MRDIS_DT_BF16) rc = launch_stats<0, __bf16>((const __bf16*)z, ldz, (const __bf16*)nullptr, 0, (const __bf16*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
+    else rc = launch_stats<0, float>((const float*)z, ldz, (const float*)nullptr, 0, (const float*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(N, HW);
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+                       save_mean, save_rstd, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
 extern "C" int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz, const void* gamma, int ldg, const float* save_mean,
                                         const float* save_rstd, void* dz, int lddz, void* dgamma, int lddg, void* dbeta, int lddb,
                                         void* workspace, size_t workspace_bytes, int N, long long HW, int C, int dtype, void* stream) {

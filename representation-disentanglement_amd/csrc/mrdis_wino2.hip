@@ -28,6 +28,11 @@ struct Wino2Params {
     int flip, lrelu, nt_out;
     int nby, nbx, coTiles, nblk;      // 8x8-tile blocks per image, 64-cout tiles, blocks in total
     unsigned in_bytes, w_bytes;       // record counts of the buffer descriptors
+    // SPADE epilogue (wino2_kernel<.., true>): the filter is the fused gamma | beta filter of a SPADE block (Cout = 2 C); a workgroup owns
+    // 32 channels and their 32 gamma + 32 beta couts, a lane gets gamma and beta of the same 4 channels, and the epilogue writes
+    // out = (z - mean) * rstd * (1 + gamma) + beta and gamma itself (model.py:2440-2446) -- the 2C-channel tensor never exists
+    const float* z; const float* mean; const float* rstd; float* gamma_out;
+    int ldz, ldg, C;
 };
 
 namespace {
@@ -46,7 +51,7 @@ constexpr unsigned W2_OOB = 0xfffffff0u;               // byte offset past every
 }  // namespace
 
 // ABL: timing-only ablations (results wrong): 1 no V transform, 2 no U transform, 4 no MFMAs, 8 no filter loads, 32 no raw loads, 16 no operand reads
-template <int ABL>
+template <int ABL, bool SPADE = false>
 __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ub = smem;                           // [2][16][XI]
@@ -135,7 +140,13 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     int fj = 0, fc = 0, f_co = 0; bool f_on = false;
     auto filt_block = [&]() {
         f_on = false;
-        if (fj < nmine) { int n, oy0, ox0, co0; decode(fj, n, oy0, ox0, co0); f_co = co0 + idx_t; f_on = f_co < p.Cout; }
+        if (fj < nmine) {
+            int n, oy0, ox0, co0; decode(fj, n, oy0, ox0, co0);
+            if (SPADE) {      // 16-cout blocks of the workgroup: gamma[c0..+15], beta[c0..+15], gamma[c0+16..+31], beta[c0+16..+31]
+                const int ch = co0 / 2 + 16 * (idx_t >> 5) + (idx_t & 15);
+                f_co = ((idx_t >> 4) & 1 ? p.C : 0) + ch; f_on = ch < p.C;
+            } else { f_co = co0 + idx_t; f_on = f_co < p.Cout; }
+        }
     };
     const unsigned tstride4 = 4u * (unsigned)(p.Cin * p.Cout);
     float gr[9];
@@ -269,6 +280,50 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
             mc = 0; ++mj;
             const int tile = 16 * tg + l16;
             const int oy = oy0 + 2 * (tile >> 3), ox = ox0 + 2 * (tile & 7);
+            if (SPADE) {
+                // lane: channels ch .. ch + 3; accumulator block 0 = their gamma, block 1 = their beta
+                const int ch = co0 / 2 + 16 * cg + 4 * kq;
+                const bool ch_ok = ch < p.C;
+                // the loads first: their latency hides under the output transform
+                f32x4 zv[2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const bool ok = ch_ok && oy + dy < p.H && ox + dx < p.W;
+                        zv[dy][dx] = ok ? *reinterpret_cast<const f32x4*>(p.z + ((long long)(n * p.H + oy + dy) * p.W + ox + dx) * p.ldz + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                const f32x4 mu = ch_ok ? *reinterpret_cast<const f32x4*>(p.mean + (long long)n * p.C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 rs = ch_ok ? *reinterpret_cast<const f32x4*>(p.rstd + (long long)n * p.C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 y[2][2][2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 t0[4], t1[4];
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) {
+                        t0[i2] = acc[4 * i2][b] + acc[4 * i2 + 1][b] + acc[4 * i2 + 2][b];
+                        t1[i2] = acc[4 * i2 + 1][b] - acc[4 * i2 + 2][b] - acc[4 * i2 + 3][b];
+                    }
+                    y[b][0][0] = t0[0] + t0[1] + t0[2]; y[b][0][1] = t1[0] + t1[1] + t1[2];
+                    y[b][1][0] = t0[1] - t0[2] - t0[3]; y[b][1][1] = t1[1] - t1[2] - t1[3];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) acc[x][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const f32x4 bg = *reinterpret_cast<const f32x4*>(Bs + (ch_ok ? ch : 0));
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + (ch_ok ? p.C + ch : 0));
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        if (!(ch_ok && oy + dy < p.H && ox + dx < p.W)) continue;
+                        const f32x4 g = y[0][dy][dx] + bg, bt = y[1][dy][dx] + bb;
+                        const f32x4 o = (zv[dy][dx] - mu) * rs * (g + 1.f) + bt;
+                        const long long pix = (long long)(n * p.H + oy + dy) * p.W + ox + dx;
+                        *reinterpret_cast<f32x4*>(p.out + pix * p.ldout + ch) = o;
+                        *reinterpret_cast<f32x4*>(p.gamma_out + pix * p.ldg + ch) = g;
+                    }
+                return;
+            }
             const bool full = oy0 + 16 <= p.H && ox0 + 16 <= p.W && co0 + 64 <= p.Cout;        // block-uniform: no per-store tests
             const f32x4 slope = p.lrelu ? f32x4{0.2f, 0.2f, 0.2f, 0.2f} : f32x4{1.f, 1.f, 1.f, 1.f};
             float* const o00 = p.out + ((long long)(n * p.H + oy) * p.W + ox) * p.ldout + co0 + 32 * cg + 4 * kq;
@@ -347,6 +402,37 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
 #undef W2A
 #endif
     hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// SPADE-fused form: x = si_out (N, H, W, Ci), w = fused gamma | beta filter [9][Ci][2 C], bias (2 C); z (N, H, W, C) with its instance
+// statistics; writes mix = (z - mean) rstd (1 + gamma) + beta and gamma.  MRDIS_EUNSUPPORTED: the caller runs the two-step path.
+int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
+                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s) {
+    const int Co = 2 * C;
+    if (C < 16 || C % 16 != 0 || Co > BIASBUF || Ci % 4 != 0 || ldx % 4 != 0 || ldz % 4 != 0 || ldmix % 4 != 0 || ldg % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)z) | ((uintptr_t)mix) | ((uintptr_t)gamma) | ((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W * ldx >= 0x3fffffffLL || 9LL * Ci * Co >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
+    Wino2Params p{};
+    p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci); p.w_bytes = (unsigned)(36LL * Ci * Co);
+    p.in = x; p.w = w; p.bias = bias; p.out = mix;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldmix;
+    p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    p.nby = mrdis_cdiv((H + 1) / 2, 8); p.nbx = mrdis_cdiv((W + 1) / 2, 8);
+    p.coTiles = mrdis_cdiv(C, 32);
+    const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.nblk = (int)nblk;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)wino2_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    hipLaunchKernelGGL((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

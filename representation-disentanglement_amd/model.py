@@ -332,8 +332,12 @@ class SPADEBlockNew(nn.Module):
                 w_tck, w_tkc = allw[2 * row], allw[2 * row + 1]
             else:
                 w_tck, w_tkc, bias = ops.step_cache(key, fused)
-            gb = ops.conv2d(si_out, w_tck, w_tkc, bias, kh, kw, 1, self.gamma.padding[0])
-            mix = ops.instnorm_spade_gb(zi, gb, self.zi_layers.eps)       # :2440 + :2446
+            if ((kh, kw) == (3, 3) and self.gamma.padding[0] == 1 and type(si_out) is torch.Tensor and si_out.is_cuda
+                    and ops.mix_cache_active() and torch.is_grad_enabled()):
+                mix = ops.gb_spade(si_out, zi, [(w_tck, w_tkc)], bias, self.zi_layers.eps)            # :2440 + :2446, one node
+            else:
+                gb = ops.conv2d(si_out, w_tck, w_tkc, bias, kh, kw, 1, self.gamma.padding[0])
+                mix = ops.instnorm_spade_gb(zi, gb, self.zi_layers.eps)       # :2440 + :2446
         else:
             gamma = self.gamma(si_out, *t)
             beta = self.beta(si_out, *t)
@@ -363,8 +367,7 @@ class SPADEBlockNew(nn.Module):
         pad = self.gamma.padding[0]
         si_out = ops.conv2d_grouped(si, [self.si_layers.mixed_uniform(t) for t in types], self.si_layers.bias, kh, kw, pad, share_x=True)
         fused = [self._fused_gb(t) for t in types]
-        gb = ops.conv2d_grouped(si_out, [f[0] for f in fused], fused[0][1], kh, kw, pad)
-        mix = ops.instnorm_spade_gb(z_cat, gb, self.zi_layers.eps)
+        mix = ops.gb_spade(si_out, z_cat, [f[0] for f in fused], fused[0][1], self.zi_layers.eps)     # :2440-2446, one node
         return ops.conv2d_grouped(mix, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, pad)
 
 

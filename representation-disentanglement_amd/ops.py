@@ -425,6 +425,88 @@ class _GroupedConvFn(Function):
         return (dx, db_total, None, None, None, None, None, None) + tuple(dws)
 
 
+class _GbSpadeFn(Function):
+    """gamma | beta convolution + InstanceNorm modulation of a SPADE block (model.py:2440-2446) for G sample blocks with G fused filters,
+    as one autograd node.  fp32: the convolution's epilogue applies the modulation (hip.gb_spade_fwd: the 2C-channel gamma | beta tensor
+    is never written or re-read -- 0.8 GB less HBM traffic per full-resolution block call); elsewhere conv + instnorm_spade kernels.
+    The backward is that of the two-step form (it needs gamma, which the fused kernel stores)."""
+
+    @staticmethod
+    def forward(ctx, si_out, z, bias, G, eps, *filt):
+        bm = _COMPUTE_DTYPE == hip.DT_F32_BF16M
+        B = z.shape[0] // G
+        C, H, W = z.shape[1], z.shape[2], z.shape[3]
+        mix = gamma = mean = rstd = None
+        wbs = [None] * G
+        if _COMPUTE_DTYPE == hip.DT_F32 and _GB_SPADE and si_out.dtype == torch.float32 and z.dtype == torch.float32:
+            mix = hip.empty_nhwc(G * B, C, H, W, z.device); gamma = hip.empty_nhwc(G * B, C, H, W, z.device)
+            mean = torch.empty(G * B * C, dtype=torch.float32, device=z.device); rstd = torch.empty_like(mean)
+            for g in range(G):
+                sl = slice(g * B, (g + 1) * B)
+                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps,
+                                      out=(mix[sl], gamma[sl], mean[g * B * C:(g + 1) * B * C], rstd[g * B * C:(g + 1) * B * C]))
+                if ok is None:
+                    assert g == 0                    # the decision depends on the geometry only
+                    mix = None
+                    break
+        if mix is None:
+            zs = z
+            if _COMPUTE_DTYPE == hip.DT_BF16 and z.dtype == torch.float32:
+                zs = hip.cast_view(z, torch.bfloat16)
+            gb = hip.empty_nhwc(G * B, 2 * C, H, W, z.device, si_out.dtype)
+            for g in range(G):
+                wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE != hip.DT_F32 else (None, None)
+                wbs[g] = wb[1]
+                hip.conv2d_fwd(si_out[g * B:(g + 1) * B], filt[2 * g], bias, 3, 3, 1, 1, out=gb[g * B:(g + 1) * B], w_bf16=wb[0])
+            mix, mean, rstd = hip.instnorm_spade_fwd(zs, gb[:, :C], gb[:, C:], eps)
+            gamma = gb[:, :C]
+            ctx.z_cast = zs is not z
+            z = zs
+        else:
+            ctx.z_cast = False
+        ctx.meta = (G, B, hip.DT_F32_BF16M if _COMPUTE_DTYPE != hip.DT_F32 else hip.DT_F32)
+        ctx.wbs = wbs
+        ctx.save_for_backward(si_out, z, gamma, mean, rstd, *[filt[2 * g + 1] for g in range(G)])
+        return mix
+
+    @staticmethod
+    def backward(ctx, dmix):
+        G, B, dt = ctx.meta
+        si_out, z, gamma, mean, rstd = ctx.saved_tensors[:5]
+        tkcs = ctx.saved_tensors[5:]
+        H, W = z.shape[2], z.shape[3]
+        dz, dgb = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True)
+        if ctx.z_cast:
+            dz = hip.cast_view(dz, torch.float32)
+        need_x = ctx.needs_input_grad[0]
+        dx = hip.empty_nhwc(G * B, si_out.shape[1], H, W, z.device, si_out.dtype) if need_x else None
+        dws, db_total = [], None
+        for g in range(G):
+            sl = slice(g * B, (g + 1) * B)
+            if need_x:
+                hip.conv2d_bwd_data(dgb[sl], tkcs[g], (H, W), 3, 3, 1, 1, w_bf16=ctx.wbs[g], out=dx[sl])
+            dw, db = hip.conv2d_bwd_weight(si_out[sl], dgb[sl], 3, 3, 1, 1, need_bias=True, dtype=dt)
+            dws += [dw, None]
+            db_total = db if db_total is None else db_total + db
+        return (dx, dz, db_total, None, None) + tuple(dws)
+
+
+_GB_SPADE = _os.environ.get('MRDIS_GB_SPADE', '1') != '0'
+
+
+def set_gb_spade(enabled):
+    global _GB_SPADE
+    _GB_SPADE = bool(enabled)
+
+
+def gb_spade(si_out, z, filters, bias, eps):
+    """si_out, z: G sample blocks; filters: G fused gamma | beta pairs (w_tck [9][C][2C], w_tkc); bias (2C).  -> mix (see _GbSpadeFn)."""
+    flat = []
+    for a, b in filters:
+        flat += [a, b]
+    return _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, *flat)
+
+
 def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False):
     """x: (G * B, Ci, H, W) sample blocks (or (B, Ci, H, W) read by every group when share_x); filters: G pairs (w_tck, w_tkc);
     stride 1.  -> (G * B, Co, H, W): block g = conv(x_g, filters[g]) + bias."""

@@ -292,6 +292,32 @@ def test_grouped_decoder_matches_per_type_calls(mrdis, mode):
             assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
 
 
+def test_gb_spade_fusion_matches_two_step_path(mrdis):
+    """A full step with the fused gamma | beta + modulation epilogue on and off (ops.set_gb_spade): same loss and gradients to fp32
+    rounding (the fused kernel adds the bias and applies the modulation in registers, the two-step path round-trips through memory:
+    identical arithmetic per element, so in practice bit-identical)."""
+    B, M, H, W = 2, 4, 64, 96
+    cfg = _cfg(mrdis, M, H, W, B, adv=True)
+    res = {}
+    try:
+        for on in (False, True):
+            mrdis.ops.set_gb_spade(on)
+            torch.manual_seed(10); np.random.seed(10)
+            model = mrdis.build_model(cfg).train()
+            inputs, mask, mask_img = make_inputs(B, M, H, W, seed=10, drop=True)
+            torch.manual_seed(11); np.random.seed(11)
+            with mrdis.ops.mix_cache():
+                loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+                loss.backward()
+            res[on] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        mrdis.ops.set_gb_spade(True)
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-6 * abs(float(res[False][0]))
+    for n in res[False][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
+
+
 def test_train_step_winograd_vs_direct_kernels(mrdis):
     """The whole step with every eligible 3x3 layer forced through the Winograd kernels (MRDIS_WINO=2: forward, data and
     weight gradients) against the same step on the direct kernels (MRDIS_WINO=0): loss, loss parts and every parameter

@@ -187,6 +187,33 @@ def test_to_device_mailbox_ring(mrdis):
     assert torch.equal(ops.to_device(big, dev()).cpu(), big)
 
 
+@pytest.mark.parametrize('case', [(8, 32, 32, 64, 96), (3, 64, 64, 50, 72), (5, 128, 128, 33, 47), (2, 32, 48, 64, 80), (2, 16, 128, 8, 8)], ids=str)
+def test_gb_spade_fused_epilogue(mrdis, case):
+    """mrdis_conv2d_fwd_spade (the gamma | beta convolution with the InstanceNorm modulation in the Winograd kernel's epilogue) against the
+    two-step form (convolution, then instnorm_spade): mix and gamma, ragged tile blocks, a channel count that is not a multiple of 32
+    (48: half-filled last workgroup), and a geometry the fused kernel declines (-> None)."""
+    N, Ci, C, H, W = case
+    hip = mrdis.hip
+    x = cl(rnd((N, Ci, H, W), 1)); z = cl(rnd((N, C, H, W), 2))
+    w = rnd((2 * C, Ci, 3, 3), 3, 0.2); b = rnd((2 * C,), 4, 0.1).to(dev())
+    w_tck = to_tck(w).to(dev())
+    gb = hip.conv2d_fwd(x, w_tck, b, 3, 3, 1, 1)
+    mix_ref, mean_ref, rstd_ref = hip.instnorm_spade_fwd(z, gb[:, :C], gb[:, C:], 1e-5)
+    if H < 16:
+        assert hip.gb_spade_fwd(x, w_tck, b, z, 1e-5) is None          # too few tile blocks for the Winograd policy: the caller falls back
+        return
+    hip.set_option('wino', 2)                           # Winograd wherever the kernel applies (the size policy is tested at scale)
+    res = hip.gb_spade_fwd(x, w_tck, b, z, 1e-5)
+    assert res is not None
+    mix, gamma, mean, rstd = res
+    close(gamma, gb[:, :C].cpu(), rtol=2e-5, what='gamma')
+    close(mix, mix_ref.cpu(), rtol=2e-5, what='mix')
+    close(mean, mean_ref.cpu(), rtol=1e-6, what='mean'); close(rstd, rstd_ref.cpu(), rtol=1e-6, what='rstd')
+    zr = z.float().cpu().permute(0, 2, 3, 1); gr = F.conv2d(x.cpu(), w, b.cpu(), 1, 1)
+    ref = F.instance_norm(z.cpu(), eps=1e-5) * (1 + gr[:, :C]) + gr[:, C:]
+    close(mix, ref, rtol=1e-4, what='mix vs torch')
+
+
 PIPE_CASES = [
     (8, 64, 128, 96, 80),     # 480 blocks on <= 256 persistent workgroups: every workgroup walks several blocks, both cout tiles
     (3, 36, 72, 50, 18),      # channel tail in the last chunk, cout tail in the second 64-wide tile, partial tile blocks
