@@ -153,13 +153,13 @@ int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, void* stream)
 /* A SPADE block's  InstanceNorm(z) * (1 + gamma(s)) + beta(s)  (model.py:2440-2446) with the gamma | beta convolution and the modulation in
  * ONE launch: x = the si_layers output (N, H, W, Ci), w_tck = the fused [9][Ci][2 C] filter (gamma couts first), bias (2 C), z (N, H, W, C)
  * and its instance statistics (mrdis_instnorm_stats).  Writes mix and gamma (the backward, mrdis_instnorm_spade_bwd, needs gamma).
- * fp32.  MRDIS_EUNSUPPORTED where the pipelined Winograd kernel is not the kernel of choice: run mrdis_conv2d_fwd +
- * mrdis_instnorm_spade_fwd instead. */
+ * dtype MRDIS_DT_F32 (x, z, mix, gamma fp32; w_tck) or MRDIS_DT_BF16 (bf16 views; w_bf16_tkc = the bf16 [9][2 C][Ci] filter).
+ * MRDIS_EUNSUPPORTED where the pipelined kernels are not the kernels of choice: run mrdis_conv2d_fwd + mrdis_instnorm_spade_fwd instead. */
 int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                          int N, long long HW, int C, float eps, int dtype, void* stream);
-int mrdis_conv2d_fwd_spade(const float* x, int ldx, const float* w_tck, const float* bias, const float* z, int ldz,
-                           const float* mean, const float* rstd, float* mix, int ldmix, float* gamma, int ldg,
-                           int N, int H, int W, int Ci, int C, void* stream);
+int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
+                           const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
+                           int N, int H, int W, int Ci, int C, int dtype, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.

@@ -39,11 +39,17 @@ struct BConv3Params {
     int nchunks, lrelu;
     int dh[9], dw[9], widx[9];
     unsigned in_bytes, w_bytes;
+    // SPADE epilogue (bconv3_kernel<2, ., true>): the filter is a fused gamma | beta filter (Cout = 2 C); a workgroup owns 32 channels and their
+    // 32 gamma + 32 beta couts (accumulator block 0 / 1 of a lane: gamma / beta of the same channels); the epilogue writes
+    // (z - mean) * rstd * (1 + gamma) + beta and gamma (model.py:2440-2446)
+    const void* z; const float* mean; const float* rstd; void* gamma_out;
+    int ldz, ldg, C;
 };
 
 // ABL (timing-only, -DBCONV3_ABLATIONS): 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 operand reads at one address, 16 no output stores
-template <int WC, int ABL = 0>
+template <int WC, int ABL = 0, bool SPADE = false>
 __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
+    static_assert(!SPADE || WC == 2, "SPADE: 32 gamma + 32 beta couts per workgroup");
     constexpr int BN = 32 * WC, NT = 512;
     constexpr int WS = 9 * BN * P_PITCH;              // bf16 elements of one filter image
     constexpr int XR = (P_NPIX * 4 + NT - 1) / NT;    // 16-byte x pieces per thread (3)
@@ -77,7 +83,9 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
         const int t = row / BN, co = row - t * BN;
         w_co[it] = (idx < 9 * BN * 4) ? co : -1;
         w_lds[it] = row * P_PITCH + 8 * q;
-        w_rel[it] = 2u * (unsigned)((p.widx[t < 9 ? t : 0] * p.Cout + co) * p.Cin + 8 * q);
+        // SPADE: local couts 0..31 are the gamma couts of the workgroup's 32 channels, 32..63 their beta couts (C further on in the filter)
+        const int co_g = SPADE ? ((co >> 5) ? p.C : 0) + (co & 31) : co;
+        w_rel[it] = 2u * (unsigned)((p.widx[t < 9 ? t : 0] * p.Cout + co_g) * p.Cin + 8 * q);
     }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
@@ -118,8 +126,8 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
         }
 #pragma unroll
         for (int it = 0; it < WR; ++it) {
-            const bool ok = l_live && w_co[it] >= 0 && l_co0 + w_co[it] < p.Cout;
-            wo[it] = ok ? w_rel[it] + 2u * (unsigned)(l_co0 * p.Cin) + c0b : P_OOB;
+            const bool ok = l_live && w_co[it] >= 0 && (SPADE ? l_co0 / 2 + (w_co[it] & 31) < p.C : l_co0 + w_co[it] < p.Cout);
+            wo[it] = ok ? w_rel[it] + 2u * (unsigned)((SPADE ? l_co0 / 2 : l_co0) * p.Cin) + c0b : P_OOB;
         }
         if (++lc == p.nchunks) { lc = 0; ++lj; load_unit(); }
     };
@@ -197,6 +205,45 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
             mc = 0; ++mj;
             const int a = a0 + wave, b = b0 + e;
             const bool pos_ok = a < p.H && b < p.W;
+            if (SPADE) {
+                const int c0 = co0 / 2;                          // the workgroup's first channel
+                const long long pix = (long long)(n * p.H + a) * p.W + b;
+                const __bf16* zp = reinterpret_cast<const __bf16*>(p.z) + pix * p.ldz;
+                bp_bf16x4 zq[4]; float4 mu[4], rs[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                  // loads first
+                    const int ch = c0 + 8 * q + 4 * half;
+                    const bool ok = pos_ok && ch < p.C;
+                    zq[q] = ok ? *reinterpret_cast<const bp_bf16x4*>(zp + ch) : bp_bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    mu[q] = ch < p.C ? *reinterpret_cast<const float4*>(p.mean + (long long)n * p.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rs[q] = ch < p.C ? *reinterpret_cast<const float4*>(p.rstd + (long long)n * p.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                __bf16* mixp = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout;
+                __bf16* gamp = reinterpret_cast<__bf16*>(p.gamma_out) + pix * p.ldg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = c0 + 8 * q + 4 * half;
+                    const float4 bg = *reinterpret_cast<const float4*>(Bs + (ch < p.C ? ch : 0));
+                    const float4 bb = *reinterpret_cast<const float4*>(Bs + (ch < p.C ? p.C + ch : 0));
+                    const float g[4] = {acc[0][4 * q] + bg.x, acc[0][4 * q + 1] + bg.y, acc[0][4 * q + 2] + bg.z, acc[0][4 * q + 3] + bg.w};
+                    const float bt[4] = {acc[WC - 1][4 * q] + bb.x, acc[WC - 1][4 * q + 1] + bb.y, acc[WC - 1][4 * q + 2] + bb.z, acc[WC - 1][4 * q + 3] + bb.w};
+                    const float m_[4] = {mu[q].x, mu[q].y, mu[q].z, mu[q].w}, r_[4] = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
+                    bp_bf16x4 o, og;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // gamma and beta reach the modulation kernel of the two-step path as bf16: round them the same way
+                        const float gr = (float)(__bf16)g[k], br = (float)(__bf16)bt[k];
+                        og[k] = (__bf16)g[k];
+                        o[k] = (__bf16)(((float)zq[q][k] - m_[k]) * r_[k] * (1.f + gr) + br);
+                    }
+                    if (pos_ok && ch < p.C) { *reinterpret_cast<bp_bf16x4*>(mixp + ch) = o; *reinterpret_cast<bp_bf16x4*>(gamp + ch) = og; }
+                }
+#pragma unroll
+                for (int j = 0; j < WC; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                return;
+            }
             __bf16* dst = reinterpret_cast<__bf16*>(p.out) + ((long long)(n * p.H + a) * p.W + b) * p.ldout;
 #pragma unroll
             for (int j = 0; j < WC; ++j) {
@@ -267,6 +314,39 @@ int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s) {
 #endif
     if (WC == 2) hipLaunchKernelGGL(bconv3_kernel<2>, dim3(grid), dim3(512), lds, s, p);
     else hipLaunchKernelGGL(bconv3_kernel<1>, dim3(grid), dim3(512), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// SPADE-fused form on bf16 activations (see BConv3Params): x = si_out (N, H, W, Ci) bf16, w = bf16 fused gamma | beta filter [9][2C][Ci],
+// bias (2 C) fp32, z (N, H, W, C) bf16 with its instance statistics; writes mix and gamma (bf16).  MRDIS_EUNSUPPORTED: two-step path.
+int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
+                           void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s) {
+    if (!mrdis_opt(MRDIS_OPT_WINO_PIPE) || Ci % 32 != 0 || C % 4 != 0 || C < 16 || 2 * C > P_BIAS || W < 32) return MRDIS_EUNSUPPORTED;
+    if (ldx % 8 != 0 || ldz % 4 != 0 || ldmix % 4 != 0 || ldg % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)w_bf16) | ((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) != 0 || ((((uintptr_t)z) | ((uintptr_t)mix) | ((uintptr_t)gamma)) & 7) != 0) return MRDIS_EUNSUPPORTED;
+    BConv3Params p{};
+    for (int k = 0; k < 9; ++k) { p.dh[k] = k / 3 - 1; p.dw[k] = k % 3 - 1; p.widx[k] = k; }
+    const long long in_b = 2LL * (((long long)N * H * W - 1) * ldx + Ci), w_b = 2LL * 9 * Ci * 2 * C;
+    if (in_b >= 0xffffffe0LL || w_b >= 0xffffffe0LL) return MRDIS_EUNSUPPORTED;
+    p.in = x; p.w = w_bf16; p.bias = bias; p.out = mix;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
+    p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
+    p.tilesA = mrdis_cdiv(H, P_TH); p.tilesB = mrdis_cdiv(W, P_TW); p.coTiles = mrdis_cdiv(C, 32);
+    const long long units = (long long)N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = Ci / P_KC; p.lrelu = 0;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)bconv3_kernel<2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = units < n_cu ? (int)units : n_cu;
+    const size_t lds = 2 * (size_t)(2 * 9 * 64 * P_PITCH + 2 * P_XS) + sizeof(float) * P_BIAS;
+    hipLaunchKernelGGL((bconv3_kernel<2, 0, true>), dim3(grid), dim3(512), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

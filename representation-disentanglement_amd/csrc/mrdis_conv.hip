@@ -1069,17 +1069,26 @@ static bool bf16m_wanted(int dtype, const void* w_bf16, int Cred, int Cout) {
     return (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) && w_bf16 != nullptr && Cred % 16 == 0 && Cout % 4 == 0 && Cout >= 16;
 }
 
-// SPADE block, fused: gamma | beta convolution + InstanceNorm modulation in one launch (mrdis_wino2.hip, SPADE epilogue).  Only where the
-// pipelined Winograd kernel is the kernel of choice for the 2C-cout layer; MRDIS_EUNSUPPORTED otherwise (the caller then runs
-// mrdis_conv2d_fwd + mrdis_instnorm_spade_fwd).  fp32 only.
+// SPADE block, fused: gamma | beta convolution + InstanceNorm modulation in one launch.  fp32 (MRDIS_DT_F32): the SPADE epilogue of the
+// pipelined Winograd kernel (mrdis_wino2.hip), only where that kernel is the kernel of choice for the 2C-cout layer; bf16 activations
+// (MRDIS_DT_BF16): the SPADE epilogue of the pipelined bf16 kernel (mrdis_bf16p.hip).  MRDIS_EUNSUPPORTED otherwise (the caller then runs
+// mrdis_conv2d_fwd + mrdis_instnorm_spade_fwd).
 int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
                           float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
-extern "C" int mrdis_conv2d_fwd_spade(const float* x, int ldx, const float* w_tck, const float* bias, const float* z, int ldz,
-                                      const float* mean, const float* rstd, float* mix, int ldmix, float* gamma, int ldg,
-                                      int N, int H, int W, int Ci, int C, void* stream) {
-    if (!x || !w_tck || !bias || !z || !mean || !rstd || !mix || !gamma || N < 1 || H < 1 || W < 1 || Ci < 1 || C < 1) return MRDIS_EINVAL;
+int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
+                           void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
+extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
+                                      const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
+                                      int N, int H, int W, int Ci, int C, int dtype, void* stream) {
+    if (!x || !bias || !z || !mean || !rstd || !mix || !gamma || N < 1 || H < 1 || W < 1 || Ci < 1 || C < 1) return MRDIS_EINVAL;
+    if (dtype == MRDIS_DT_BF16) {
+        if (!w_bf16_tkc) return MRDIS_EINVAL;
+        return mrdis_run_bconv3_spade(x, ldx, w_bf16_tkc, bias, z, ldz, mean, rstd, mix, ldmix, gamma, ldg, N, H, W, Ci, C, (hipStream_t)stream);
+    }
+    if (dtype != MRDIS_DT_F32 || !w_tck) return dtype == MRDIS_DT_F32 ? MRDIS_EINVAL : MRDIS_EUNSUPPORTED;
     if (!mrdis_opt(MRDIS_OPT_WINO_PIPE) || !wino_wanted(N, H, W, Ci, 2 * C, 3, 3, 1, 1)) return MRDIS_EUNSUPPORTED;
-    return mrdis_run_wino2_spade(x, ldx, w_tck, bias, z, ldz, mean, rstd, mix, ldmix, gamma, ldg, N, H, W, Ci, C, (hipStream_t)stream);
+    return mrdis_run_wino2_spade((const float*)x, ldx, w_tck, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
+                                 (hipStream_t)stream);
 }
 
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,

@@ -39,7 +39,7 @@ _SIGS = {
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
     'mrdis_instnorm_stats': (_I, [_P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
-    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _I, _I, _P]),
@@ -556,31 +556,33 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
     return out, mean, rstd
 
 
-def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None):
+def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None):
     """fused gamma | beta convolution + InstanceNorm modulation (mrdis_conv2d_fwd_spade): -> (mix, gamma, mean, rstd), or None where the
-    fused kernel does not apply (the caller then runs conv2d_fwd + instnorm_spade_fwd).  out = (mix, gamma, mean, rstd) dense views to fill."""
+    fused kernel does not apply (the caller then runs conv2d_fwd + instnorm_spade_fwd).  fp32 views, or bf16 views with w_bf16 = the bf16
+    [9][2C][Ci] filter.  out = (mix, gamma, mean, rstd) dense views to fill."""
     lib = load()
-    if si_out.dtype is not torch.float32 or z.dtype is not torch.float32:
+    if si_out.dtype is not z.dtype or (z.dtype is torch.bfloat16 and w_bf16 is None):
         return None
     x, ldx = nhwc(si_out); z, ldz = nhwc(z)
     N, C, H, W = z.shape
     Ci = x.shape[1]
     if tuple(w_tck.shape) != (9, Ci, 2 * C) or x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
         return None
+    dt = _dt(x, z)
     if out is None:
         mean = torch.empty(N * C, dtype=torch.float32, device=z.device)
         rstd = torch.empty(N * C, dtype=torch.float32, device=z.device)
-        mix = empty_nhwc(N, C, H, W, z.device)
-        gamma = empty_nhwc(N, C, H, W, z.device)
+        mix = empty_nhwc(N, C, H, W, z.device, z.dtype)
+        gamma = empty_nhwc(N, C, H, W, z.device, z.dtype)
     else:
         mix, gamma, mean, rstd = out
     nb = _ws_bytes(lib.mrdis_norm_workspace, N, H * W, C)
     ws = _ws(nb, z.device)
     st = _stream()
     # the statistics first (stream order); if the fused kernel then declines, they are simply recomputed by the two-step path
-    _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, 0, st), 'instnorm_stats')
-    rc = lib.mrdis_conv2d_fwd_spade(_ptr(x), ldx, _ptr(w_tck), _ptr(bias), _ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(mix), C, _ptr(gamma), C,
-                                    N, H, W, Ci, C, st)
+    _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, dt, st), 'instnorm_stats')
+    rc = lib.mrdis_conv2d_fwd_spade(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(mix), C, _ptr(gamma), C,
+                                    N, H, W, Ci, C, dt, st)
     if rc == -2:
         return None
     _chk(rc, 'conv2d_fwd_spade')

@@ -438,12 +438,16 @@ class _GbSpadeFn(Function):
         C, H, W = z.shape[1], z.shape[2], z.shape[3]
         mix = gamma = mean = rstd = None
         wbs = [None] * G
-        if _COMPUTE_DTYPE == hip.DT_F32 and _GB_SPADE and si_out.dtype == torch.float32 and z.dtype == torch.float32:
-            mix = hip.empty_nhwc(G * B, C, H, W, z.device); gamma = hip.empty_nhwc(G * B, C, H, W, z.device)
+        fusable = (_COMPUTE_DTYPE == hip.DT_F32 and si_out.dtype == torch.float32 and z.dtype == torch.float32) or \
+                  (_COMPUTE_DTYPE == hip.DT_BF16 and si_out.dtype == torch.bfloat16 and z.dtype == torch.bfloat16)
+        if _GB_SPADE and fusable:
+            mix = hip.empty_nhwc(G * B, C, H, W, z.device, z.dtype); gamma = hip.empty_nhwc(G * B, C, H, W, z.device, z.dtype)
             mean = torch.empty(G * B * C, dtype=torch.float32, device=z.device); rstd = torch.empty_like(mean)
             for g in range(G):
                 sl = slice(g * B, (g + 1) * B)
-                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps,
+                wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE == hip.DT_BF16 else (None, None)
+                wbs[g] = wb[1]
+                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps, w_bf16=wb[0],
                                       out=(mix[sl], gamma[sl], mean[g * B * C:(g + 1) * B * C], rstd[g * B * C:(g + 1) * B * C]))
                 if ok is None:
                     assert g == 0                    # the decision depends on the geometry only

@@ -214,6 +214,36 @@ def test_gb_spade_fused_epilogue(mrdis, case):
     close(mix, ref, rtol=1e-4, what='mix vs torch')
 
 
+@pytest.mark.parametrize('case', [(8, 32, 32, 64, 96), (3, 64, 64, 50, 72), (5, 128, 128, 33, 47), (2, 32, 48, 64, 80), (2, 32, 128, 8, 8)], ids=str)
+def test_gb_spade_fused_epilogue_bf16(mrdis, case):
+    """the bf16 form of mrdis_conv2d_fwd_spade (SPADE epilogue of the pipelined bf16 kernel) against the two-step bf16 path
+    (bf16 convolution -> bf16 gamma | beta, then instnorm_spade): the same accumulation order and the same roundings, so mix and
+    gamma must be bit-identical; a map narrower than the kernel's 32-pixel tile is declined (-> None)."""
+    N, Ci, C, H, W = case
+    hip = mrdis.hip
+    x = cl(rnd((N, Ci, H, W), 1)).to(torch.bfloat16); z = cl(rnd((N, C, H, W), 2)).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last); z = z.contiguous(memory_format=torch.channels_last)
+    w = rnd((2 * C, Ci, 3, 3), 3, 0.2); b = rnd((2 * C,), 4, 0.1).to(dev())
+    w_tck = to_tck(w).to(dev()); wb = hip.cast_bf16(to_tkc(w).to(dev()))
+    gb = hip.conv2d_fwd(x, w_tck, b, 3, 3, 1, 1, w_bf16=wb)
+    assert gb.dtype == torch.bfloat16
+    mix_ref, mean_ref, rstd_ref = hip.instnorm_spade_fwd(z, gb[:, :C], gb[:, C:], 1e-5)
+    res = hip.gb_spade_fwd(x, w_tck, b, z, 1e-5, w_bf16=wb)
+    if W < 32:
+        assert res is None
+        return
+    assert res is not None
+    mix, gamma, mean, rstd = res
+    assert mix.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16
+    assert torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+    assert torch.equal(gamma, gb[:, :C]), 'gamma differs from the two-step path'
+    assert torch.equal(mix, mix_ref), 'mix differs from the two-step path'
+    gr = F.conv2d(x.float().cpu(), w, b.cpu(), 1, 1)
+    ref = F.instance_norm(z.float().cpu(), eps=1e-5) * (1 + gr[:, :C]) + gr[:, C:]
+    err = (mix.float().cpu() - ref).norm() / ref.norm()
+    assert err < 1e-2, err
+
+
 PIPE_CASES = [
     (8, 64, 128, 96, 80),     # 480 blocks on <= 256 persistent workgroups: every workgroup walks several blocks, both cout tiles
     (3, 36, 72, 50, 18),      # channel tail in the last chunk, cout tail in the second 64-wide tile, partial tile blocks
