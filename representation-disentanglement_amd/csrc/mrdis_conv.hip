@@ -2133,6 +2133,9 @@ static size_t wgrad_need(const WgradPlan& pl) {
 }
 
 size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
+size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);     // mrdis_wgrad_s2.hip: Cin <= 7 stride-2 first layers
+int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
 int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
                       size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 size_t mrdis_wino_wgrad_workspace(int N, int H, int W, int Ci, int Co);
@@ -2167,6 +2170,7 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
         const size_t n16 = mrdis_wgrad16_workspace(N, H, W, Ci, Co);
         if (n16 > need) need = n16;
     }
+    { const size_t n2 = mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (n2 > need) need = n2; }
     return need;
 }
 
@@ -2211,6 +2215,11 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
         rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
+    if (stride == 2 && Ci <= 7) {
+        rc = mrdis_run_wgrad_s2(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, accumulate_bias,
+                                (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (wino_wgrad_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {

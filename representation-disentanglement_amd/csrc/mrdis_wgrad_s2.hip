@@ -1,0 +1,294 @@
+// mrdis_wgrad_s2.hip -- weight (+ bias) gradient of the stride-2 first layers: Cin <= 7 image channels, 3x3 or 4x4 taps, pad 1,
+// Cout = 16 / 32 (ana_enc.down_1 7 -> 32 k4 and mod_enc.conv1 7 -> 16 k3 at full resolution, model.py:2150 / :2374; the input is a
+// 7-channel slice of the 28-channel batch tensor, so ldx = 28 and the base is not 16-byte aligned).
+//
+// The layer is HBM-bound (59 MB of x + 34-67 MB of dy per call, 1-4 GFLOP); the generic split-K kernel (wgrad_kernel<1>) spends
+// 190 us per call on scalar staging.  Here the GEMM is dW[m = (tap, ci)][co] = sum_pixels xpatch[m][pixel] * dy[pixel][co]:
+//   v_mfma_f32_16x16x4_f32, A = 16 (tap, ci) rows x 4 output pixels, B = 4 pixels x 16 couts, all (tap, ci) tiles of a wave live in
+//   registers (k4: 7 x 2 tiles = 56 accumulators), so one dy read feeds 7 MFMAs and one x read 2.
+//   A workgroup walks output rows (n, oy) with a grid stride; the k input rows of an output row sit in LDS as the memory image
+//   [row][pixel + 1][ci] (one zero pixel each side), so A(m, pixel) is ONE ds_read at  row(m) * pitch + (tx(m) * Ci + ci(m)) + 2 Ci * ox:
+//   consecutive m are consecutive words, the pitch continues that sequence across tap rows (pitch = k * Ci mod 64), the four pixel
+//   groups of a wave sit 2 Ci = 14 banks apart: conflict-free up to the two rows shared by neighbouring groups.
+//   dy rows are staged [pixel][48 | 16] (48: the four pixel groups land 16 banks apart).
+//   The next output row's x / dy are in flight in registers while the MFMAs of the current one run.
+// In-block wave reduction through LDS, fixed-order slab reduction: deterministic.
+#include "mrdis_common.h"
+
+struct WgradS2Params {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, Ci, ldx, Co, lddy, Hout, Wout;
+    int rowp;                 // LDS pitch of an x row, floats
+    int segs, R, splits;      // workgroups per image, output rows per workgroup, workgroups in total
+    int M;                    // taps * Ci rows of the gradient
+    unsigned x_bytes, dy_bytes;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+namespace {
+constexpr unsigned S2_OOB = 0xfffffff0u;
+constexpr int S2_XJ = 7;      // x items per thread and input row: W * Ci <= 1792
+template <int V_> struct IC { static constexpr int value = V_; };
+}
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void wgrad_s2_kernel(const WgradS2Params p) {
+    constexpr int MT = (KS * KS * 7 + 15) / 16;       // 7 (k4) / 4 (k3) tiles of 16 (tap, ci) rows
+    constexpr int DYP = NT == 2 ? 48 : 16;
+    constexpr int YJ = NT == 2 ? 4 : 2;               // dy float4 items per thread and row: Wout * Co / 4 <= 256 * YJ
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                 // [4][rowp]: two pairs of input rows
+    float* dys = smem + 4 * p.rowp;                   // [Wout][DYP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int Ci = p.Ci, Co = NT * 16;
+    const int n = split / p.segs, oy0 = (split - n * p.segs) * p.R, oy1 = min(oy0 + p.R, p.Hout);      // a workgroup = R consecutive output rows of one image
+
+    // A-operand offsets: row m = mt * 16 + l16 = (ty * KS + tx) * Ci + ci
+    // (LDS row of tap row ty at an even output row: ty; at an odd one the two pairs have swapped places: ty ^ 2)
+    int aoff[MT], aflip[MT]; bool aok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l16;
+        aok[mt] = m < p.M;
+        const int tap = aok[mt] ? m / Ci : 0, ci = aok[mt] ? m - tap * Ci : 0;
+        const int ty = tap / KS;
+        aoff[mt] = ty * p.rowp + (tap % KS) * Ci + ci + 2 * Ci * kq;
+        aflip[mt] = ((ty ^ 2) - ty) * p.rowp;
+    }
+    const int boff = kq * DYP + l16;
+
+    // staging roles
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    unsigned xg[S2_XJ]; int xl[S2_XJ];
+#pragma unroll
+    for (int j = 0; j < S2_XJ; ++j) {
+        const int idx = tid + 256 * j;
+        xg[j] = S2_OOB; xl[j] = -1;
+        if (idx < p.W * Ci) { const int pix = idx / Ci, c = idx - pix * Ci; xg[j] = 4u * (unsigned)(pix * p.ldx + c); xl[j] = (pix + 1) * Ci + c; }
+    }
+    const int cq = Co >> 2;
+    unsigned yg[YJ]; int yl[YJ];
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+        const int idx = tid + 256 * j;
+        yg[j] = S2_OOB; yl[j] = -1;
+        if (idx < p.Wout * cq) { const int pix = idx / cq, q = idx - pix * cq; yg[j] = 4u * (unsigned)(pix * p.lddy + 4 * q); yl[j] = pix * DYP + 4 * q; }
+    }
+    // the zero pixels either side of every x row (and the pitch padding) are written once
+    for (int i = tid; i < 4 * p.rowp; i += 256) xs[i] = 0.f;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+    // input rows travel in pairs: pair j = rows (2 j - 1, 2 j) lives in LDS rows 2 (j & 1) + (0 | 1); output row oy reads pairs oy and oy + 1
+    // (rows 2 oy - 1 .. 2 oy + 2; 3x3 taps leave the last one unread), so stepping to oy + 1 replaces pair oy by pair oy + 2:
+    // two new rows per output row instead of KS.  Rows outside the image come back as zeros (offset out of range).
+    // Two register sets: what output row oy + 1 needs (pair oy + 2, dy row oy + 1) and what oy + 2 needs are both in flight while oy is
+    // computed -- one output row of MFMAs is shorter than the memory latency.
+    float xr[2][2][S2_XJ];
+    u32x4 yr[2][YJ];
+    auto load_set = [&](auto S_, int j, int oy) {     // pair j and dy row oy; nothing to fetch -> offsets out of range -> zeros, no branch
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int iy = 2 * j - 1 + h;
+            const bool ok = j <= oy1 && (unsigned)iy < (unsigned)p.H;
+            const unsigned base = 4u * (unsigned)((n * p.H + iy) * p.W * p.ldx);           // host: the tensor is < 2^31 bytes
+#pragma unroll
+            for (int jj = 0; jj < S2_XJ; ++jj)
+                xr[S][h][jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)((ok && xl[jj] >= 0) ? base + xg[jj] : S2_OOB), 0, 0));
+        }
+        const bool on = oy >= 0 && oy < oy1;
+        const unsigned ybase = 4u * (unsigned)((n * p.Hout + oy) * p.Wout * p.lddy);
+#pragma unroll
+        for (int j2 = 0; j2 < YJ; ++j2) yr[S][j2] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && yl[j2] >= 0) ? ybase + yg[j2] : S2_OOB), 0, 0);
+    };
+    auto store_set = [&](auto S_, int j, bool with_dy) {
+        constexpr int S = decltype(S_)::value;
+        float* d = xs + 2 * (j & 1) * p.rowp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < S2_XJ; ++jj)
+                if (xl[jj] >= 0) d[h * p.rowp + xl[jj]] = xr[S][h][jj];
+        if (with_dy) {
+#pragma unroll
+            for (int j2 = 0; j2 < YJ; ++j2)
+                if (yl[j2] >= 0) *reinterpret_cast<u32x4*>(dys + yl[j2]) = yr[S][j2];
+        }
+    };
+    const int nsteps = p.Wout >> 4;                   // host: Wout % 16 == 0; a wave takes every fourth group of 4 pixels
+    auto compute = [&](int oy) {
+        int ao[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ao[mt] = aoff[mt] + ((oy & 1) ? aflip[mt] : 0);
+        // operands of pixel group i + 1 are read while the MFMAs of group i run (the last group re-reads itself: no branch)
+        float bvn[NT], avn[MT];
+        auto read_ops = [&](int i) {
+            const int ox0 = 4 * (wave + 4 * i);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bvn[nt] = dys[ox0 * DYP + boff + 16 * nt];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) avn[mt] = xs[ao[mt] + 2 * Ci * ox0];
+        };
+        read_ops(0);
+        for (int i = 0; i < nsteps; ++i) {
+            float bv[NT], av[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bv[nt] = bvn[nt]; bsum[nt] += bv[nt]; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aok[mt] ? avn[mt] : 0.f;
+            read_ops(i + 1 < nsteps ? i + 1 : i);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    auto step = [&](auto S_, int oy) {                // set S holds (pair oy + 2, dy row oy + 1)
+        compute(oy);
+        __syncthreads();
+        store_set(S_, oy + 2, true);
+        load_set(S_, oy + 4, oy + 3);
+        __syncthreads();
+    };
+
+    load_set(IC<0>{}, oy0, -1);
+    load_set(IC<1>{}, oy0 + 1, oy0);
+    __syncthreads();                                  // the zero fill
+    store_set(IC<0>{}, oy0, false);
+    store_set(IC<1>{}, oy0 + 1, true);
+    load_set(IC<0>{}, oy0 + 2, oy0 + 1);
+    load_set(IC<1>{}, oy0 + 3, oy0 + 2);
+    __syncthreads();
+    for (int oy = oy0; oy < oy1; oy += 2) {           // an odd row count runs one more row on an all-zero dy row
+        step(IC<0>{}, oy);
+        step(IC<1>{}, oy + 1);
+    }
+
+    // cross-wave reduction, one (tap, ci) tile at a time: red[wave][nt][16 rows][16 couts]
+    float* red = smem;
+    float* out = p.slab + (long long)split * p.M * Co;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NT + nt) * 256 + (4 * kq + r) * 16 + l16] = acc[mt][nt][r];
+        __syncthreads();
+        for (int e = tid; e < NT * 256; e += 256) {
+            const int nt = e >> 8, rr = (e >> 4) & 15, cc = e & 15, m = mt * 16 + rr;
+            const float v = (red[e] + red[NT * 256 + e]) + (red[2 * NT * 256 + e] + red[3 * NT * 256 + e]);
+            if (m < p.M) out[m * Co + nt * 16 + cc] = v;
+        }
+        __syncthreads();
+    }
+    if (p.bias_slab != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float b = bsum[nt];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (kq == 0) red[(wave * NT + nt) * 16 + l16] = b;
+        }
+        __syncthreads();
+        if (tid < Co) {
+            const int nt = tid >> 4, cc = tid & 15;
+            p.bias_slab[(long long)split * Co + tid] = (red[nt * 16 + cc] + red[(NT + nt) * 16 + cc]) + (red[(2 * NT + nt) * 16 + cc] + red[(3 * NT + nt) * 16 + cc]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void wgrad_s2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int total, int Co, int nslab,
+                                                               const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
+    // 32 outputs x 32 slab lanes per block; a lane walks its slabs four at a time (independent loads in flight), fixed order throughout
+    __shared__ float red[32][33];
+    const int nout = total + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 32 + threadIdx.x, y = threadIdx.y;
+    const float* src = nullptr; long long stride = 0;
+    if (i < total) { src = slab + i; stride = total; }
+    else if (i < nout) { src = bslab + (i - total); stride = Co; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (src != nullptr) {
+        int k = y;
+        for (; k + 96 < nslab; k += 128) {
+            s0 += src[(long long)k * stride]; s1 += src[(long long)(k + 32) * stride];
+            s2 += src[(long long)(k + 64) * stride]; s3 += src[(long long)(k + 96) * stride];
+        }
+        for (; k < nslab; k += 32) s0 += src[(long long)k * stride];
+    }
+    red[y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0 && i < nout) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+        if (i < total) dw[i] = t;
+        else { const int co = i - total; dbias[co] = accumulate_bias ? dbias[co] + t : t; }
+    }
+}
+
+static bool plan_wgrad_s2(WgradS2Params& p, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    if (stride != 2 || pad != 1 || kh != kw || (kh != 3 && kh != 4)) return false;
+    if (Ci < 1 || Ci > 7 || (Co != 16 && Co != 32)) return false;
+    if ((H & 1) || W % 32 != 0 || W * Ci > 256 * S2_XJ) return false;        // Wout % 16 == 0; a row's items fit the staging registers
+    if ((long long)N * H * W < 100000 || mrdis_opt(MRDIS_OPT_NOW16)) return false;     // small maps: the generic kernel's slabs are cheaper
+    p = WgradS2Params{};
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.Hout = H / 2; p.Wout = W / 2;
+    p.M = kh * kw * Ci;
+    // x-row pitch: >= (W + 2) pixels, and = kw * Ci mod 64 so that the (tap, ci) sequence runs on across tap rows bank-wise
+    int rowp = (W + 2) * Ci;
+    while ((rowp & 63) != ((kw * Ci) & 63)) ++rowp;
+    p.rowp = rowp;
+    // ~512 workgroups (2 per CU), each a run of consecutive output rows of one image (consecutive rows share an input-row pair)
+    int segs = mrdis_cdiv(512, N);
+    if (segs > p.Hout) segs = p.Hout;
+    p.R = mrdis_cdiv(p.Hout, segs);
+    p.segs = mrdis_cdiv(p.Hout, p.R);
+    p.splits = N * p.segs;
+    return true;
+}
+
+size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    WgradS2Params p;
+    if (!plan_wgrad_s2(p, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
+    return sizeof(float) * ((size_t)p.splits * p.M * Co + (size_t)p.splits * Co) + 256;
+}
+
+// returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers
+int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
+                       size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                       int accumulate_bias, hipStream_t s) {
+    WgradS2Params p;
+    if (!plan_wgrad_s2(p, N, H, W, Ci, Co, kh, kw, stride, pad)) return MRDIS_EUNSUPPORTED;
+    if (lddy % 4 != 0 || (((uintptr_t)dy) & 15) != 0 || (((uintptr_t)x) & 3) != 0) return MRDIS_EUNSUPPORTED;
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci), yb = 4LL * (((long long)N * p.Hout * p.Wout - 1) * lddy + Co);
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad)) return MRDIS_EUNSUPPORTED;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy; p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + (size_t)p.splits * p.M * Co : nullptr;
+    const int NT = Co / 16, DYP = NT == 2 ? 48 : 16;
+    size_t lds = sizeof(float) * ((size_t)4 * p.rowp + (size_t)p.Wout * DYP);
+    const size_t red = sizeof(float) * (size_t)(4 * NT * 256);
+    if (lds < red) lds = red;
+    if (lds > 64 * 1024) return MRDIS_EUNSUPPORTED;
+    if (kh == 4 && NT == 2) hipLaunchKernelGGL((wgrad_s2_kernel<4, 2>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (kh == 4) hipLaunchKernelGGL((wgrad_s2_kernel<4, 1>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (NT == 2) hipLaunchKernelGGL((wgrad_s2_kernel<3, 2>), dim3(p.splits), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_s2_kernel<3, 1>), dim3(p.splits), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    const int total = p.M * Co;
+    const int nout = total + (dbias ? Co : 0);
+    hipLaunchKernelGGL(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, p.slab, dw_tck, total, Co, p.splits,
+                       p.bias_slab, dbias, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

@@ -386,6 +386,43 @@ def test_wgrad_dma_pipeline(mrdis, N, Ci, Co, H, W, k, st, wino):
     close(dw, to_tck(w.grad), rtol=3e-4, what='wgrad dma'); close(db, b.grad, rtol=3e-4, what='dbias dma')
 
 
+S2_CASES = [
+    (8, 7, 32, 128, 128, 4, 1),     # ana_enc.down_1 geometry, modality 1 of a 28-channel batch tensor: ldx = 28, base 28 bytes into a pixel
+    (8, 7, 16, 128, 128, 3, 3),     # mod_enc.conv1 geometry, modality 3
+    (5, 7, 32, 66, 160, 3, 0),      # odd row count per workgroup, 3x3 with 32 couts
+    (4, 5, 16, 96, 256, 4, 2),      # Cin = 5: several all-zero (tap, ci) rows in the last tiles; the widest row the kernel stages
+    (16, 3, 32, 64, 96, 4, 0),      # Cin = 3
+]
+
+
+@pytest.mark.parametrize('case', S2_CASES, ids=str)
+def test_wgrad_stride2_first_layers(mrdis, case):
+    """mrdis_wgrad_s2.hip (Cin <= 7, stride 2, 3x3 / 4x4 taps, 16 / 32 couts) on a channel-slice view of a wider NHWC batch tensor
+    (the step hands the first layers `inputs[:, 7 i : 7 i + 7]`), against torch; bias gradient both fresh and added into a sink;
+    option now16 = 1 (the generic split-K kernel) must agree."""
+    N, Ci, Co, H, W, k, mod = case
+    hip = mrdis.hip
+    full = rnd((N, 4 * Ci, H, W), 70)
+    x = full[:, mod * Ci:(mod + 1) * Ci]
+    w = rnd((Co, Ci, k, k), 71, 0.1).requires_grad_(True); b = rnd((Co,), 72, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, 2, 1)
+    gy = rnd(tuple(y.shape), 73); y.backward(gy)
+    xv = cl(full)[:, mod * Ci:(mod + 1) * Ci]
+    assert hip.nhwc(xv)[1] == 4 * Ci
+    dw, db = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True)
+    close(dw, to_tck(w.grad), rtol=3e-4, what='wgrad s2'); close(db, b.grad, rtol=3e-4, what='dbias s2')
+    sink = torch.full((Co,), 2.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True, bias_sink=sink)
+    assert none is None and torch.equal(dw2, dw)
+    close(sink, b.grad + 2.0, rtol=3e-4, what='dbias sink')
+    hip.set_option('debug_now16', 1)
+    try:
+        dw3, db3 = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True)
+    finally:
+        hip.set_option('debug_now16', 0)
+    close(dw3, dw.cpu(), rtol=3e-4, what='generic vs s2'); close(db3, db.cpu(), rtol=3e-4, what='generic vs s2 bias')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
