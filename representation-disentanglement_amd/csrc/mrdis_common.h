@@ -43,3 +43,7 @@ __device__ __forceinline__ double mrdis_wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+
+// mrdis_wgrad_s2.hip: dw[i] = sum_k slab[k * total + i], dbias[co] (+)= sum_k bslab[k * Co + co], fixed order
+int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
+                             hipStream_t s);

@@ -1091,6 +1091,10 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
                                  (hipStream_t)stream);
 }
 
+// mrdis_pointwise.hip: the 1x1 decoder head (16 -> <= 8 channels) as streaming kernels
+int mrdis_run_pw_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co, int lrelu, hipStream_t s);
+int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, long long npix, int Ci, int Co, hipStream_t s);
+
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                                 void* y_, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream) {
@@ -1101,6 +1105,10 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
+    if (!st_bf16 && kh == 1 && kw == 1 && stride == 1 && pad == 0) {
+        rc = mrdis_run_pw_fwd(x, ldx, w_tck, bias, y, ldy, (long long)N * H * W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     if (!st_bf16 && c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     const bool bf = bf16m_wanted(dtype, w_bf16_tkc, Ci, Co);
@@ -1135,6 +1143,10 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!dy || !w_tkc || !dx || lddy < Co || lddx < Ci) return MRDIS_EINVAL;
+    if (!st_bf16 && kh == 1 && kw == 1 && stride == 1 && pad == 0) {
+        rc = mrdis_run_pw_dgrad(dy, lddy, w_tkc, dx, lddx, (long long)N * H * W, Ci, Co, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     TapConvParams base{};
     base.in = dy; base.w = w_tkc; base.bias = nullptr; base.out = dx;
     base.N = N; base.Hin = Ho; base.Win = Wo; base.Cin = Co; base.ldin = lddy;
@@ -2134,6 +2146,9 @@ static size_t wgrad_need(const WgradPlan& pl) {
 
 size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
 size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);     // mrdis_wgrad_s2.hip: Cin <= 7 stride-2 first layers
+size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co);                    // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
+int mrdis_run_pw_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       long long npix, int Ci, int Co, int accumulate_bias, hipStream_t s);
 int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
 int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
@@ -2171,6 +2186,7 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
         if (n16 > need) need = n16;
     }
     { const size_t n2 = mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (n2 > need) need = n2; }
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) { const size_t n1 = mrdis_pw_wgrad_workspace((long long)N * H * W, Ci, Co); if (n1 > need) need = n1; }
     return need;
 }
 
@@ -2215,6 +2231,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
         rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {
+        rc = mrdis_run_pw_wgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (stride == 2 && Ci <= 7) {

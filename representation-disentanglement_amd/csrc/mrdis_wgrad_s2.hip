@@ -235,6 +235,15 @@ __global__ __launch_bounds__(1024) void wgrad_s2_reduce_kernel(const float* __re
     }
 }
 
+// dw[i] = sum_k slab[k][i] (i < total), dbias[co] (+)= sum_k bslab[k][co]: the fixed-order slab reduction shared with mrdis_pointwise.hip
+int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
+                             hipStream_t s) {
+    const int nout = total + (dbias ? Co : 0);
+    hipLaunchKernelGGL(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 static bool plan_wgrad_s2(WgradS2Params& p, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
     if (stride != 2 || pad != 1 || kh != kw || (kh != 3 && kh != 4)) return false;
     if (Ci < 1 || Ci > 7 || (Co != 16 && Co != 32)) return false;
@@ -286,9 +295,5 @@ int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float
     else hipLaunchKernelGGL((wgrad_s2_kernel<3, 1>), dim3(p.splits), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     const int total = p.M * Co;
-    const int nout = total + (dbias ? Co : 0);
-    hipLaunchKernelGGL(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, p.slab, dw_tck, total, Co, p.splits,
-                       p.bias_slab, dbias, accumulate_bias);
-    MRDIS_CHECK_LAUNCH();
-    return MRDIS_OK;
+    return mrdis_launch_slab_reduce(p.slab, dw_tck, total, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
 }

@@ -423,6 +423,38 @@ def test_wgrad_stride2_first_layers(mrdis, case):
     close(dw3, dw.cpu(), rtol=3e-4, what='generic vs s2'); close(db3, db.cpu(), rtol=3e-4, what='generic vs s2 bias')
 
 
+@pytest.mark.parametrize('case', [(8, 7, 128, 96), (3, 8, 100, 75), (5, 4, 64, 80), (2, 1, 96, 96), (32, 7, 64, 64)], ids=str)
+def test_pointwise_head_kernels(mrdis, case):
+    """mrdis_pointwise.hip (the 1x1 16 -> <= 8 channel decoder head as streaming kernels): forward with bias (+ LeakyReLU), data gradient
+    and weight / bias gradient against torch, with the 16-channel side a channel slice of a wider tensor (ld = 32) and a pixel count
+    that is not a multiple of the grid stride; option debug_now16 = 1 (the generic tile kernels) must agree."""
+    N, Co, H, W = case
+    hip = mrdis.hip
+    wide = rnd((N, 32, H, W), 80)
+    x = wide[:, 16:].clone().requires_grad_(True)
+    w = rnd((Co, 16, 1, 1), 81, 0.3).requires_grad_(True); b = rnd((Co,), 82, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b)
+    gy = rnd(tuple(y.shape), 83); y.backward(gy)
+    xv = cl(wide)[:, 16:]
+    w_tck, w_tkc = to_tck(w.detach()).to(dev()), to_tkc(w.detach()).to(dev())
+    got = {}
+    for now16 in (0, 1):
+        hip.set_option('debug_now16', now16)
+        try:
+            yy = hip.conv2d_fwd(xv, w_tck, b.detach().to(dev()), 1, 1, 1, 0)
+            yl = hip.conv2d_fwd(xv, w_tck, b.detach().to(dev()), 1, 1, 1, 0, lrelu=True)
+            dx = hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), 1, 1, 1, 0)
+            dw, db = hip.conv2d_bwd_weight(xv, cl(gy), 1, 1, 1, 0, need_bias=True)
+        finally:
+            hip.set_option('debug_now16', 0)
+        close(yy, y.detach(), rtol=2e-5, what=f'pw fwd now16={now16}'); close(yl, F.leaky_relu(y.detach(), 0.2), rtol=2e-5, what='pw fwd lrelu')
+        close(dx, x.grad, rtol=2e-5, what=f'pw dgrad now16={now16}')
+        close(dw, to_tck(w.grad), rtol=3e-4, what=f'pw wgrad now16={now16}'); close(db, b.grad, rtol=3e-4, what='pw dbias')
+        got[now16] = (yy.cpu(), dx.cpu(), dw.cpu())
+    for a, c in zip(got[0], got[1]):
+        close(a, c, rtol=3e-4, what='streaming vs tile kernels')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
