@@ -455,6 +455,34 @@ def test_pointwise_head_kernels(mrdis, case):
         close(a, c, rtol=3e-4, what='streaming vs tile kernels')
 
 
+@pytest.mark.parametrize('case', [(4, 32, 128, 160), (3, 16, 150, 150), (2, 32, 203, 171), (9, 32, 96, 96)], ids=str)
+def test_conv3x3_16_couts_register_filter(mrdis, case):
+    """mrdis_c16.hip (3x3 s1 p1, 16 output channels, 16 / 32 input channels: sp6.out): filter in registers, persistent 8 x 32 tiles.
+    Against torch with bias (+ LeakyReLU), ragged tiles in both directions, input and output both channel slices of wider tensors;
+    option debug_now16 = 1 (tapconv16_kernel) must agree."""
+    N, Ci, H, W = case
+    hip = mrdis.hip
+    wide = rnd((N, Ci + 8, H, W), 84)
+    x = wide[:, 4:4 + Ci]
+    w = rnd((16, Ci, 3, 3), 85, 0.15); b = rnd((16,), 86, 0.1)
+    want = F.conv2d(x, w, b, 1, 1)
+    xv = cl(wide)[:, 4:4 + Ci]
+    w_tck, bd = to_tck(w).to(dev()), b.to(dev())
+    got = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+    close(got, want, rtol=2e-5, what='c16 fwd')
+    out = hip.empty_nhwc(N, 32, H, W, dev())
+    out.fill_(7.0)
+    hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1, lrelu=True, out=out[:, 16:])
+    close(out[:, 16:], F.leaky_relu(want, 0.2), rtol=2e-5, what='c16 fwd lrelu into a slice')
+    assert bool((out[:, :16] == 7.0).all()), 'wrote outside its 16 channels'
+    hip.set_option('debug_now16', 1)
+    try:
+        ref = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+    finally:
+        hip.set_option('debug_now16', 0)
+    close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs c16')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
