@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const C16Params p) 
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[g][j] = p.w[((g / HALVES) * CI + 16 * (g % HALVES) + 4 * kq + j) * 16 + l16];
-    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bv = p.bias ? make_float4(p.bias[4 * kq], p.bias[4 * kq + 1], p.bias[4 * kq + 2], p.bias[4 * kq + 3])      // (a parameter view: 4-byte aligned)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
 
     // staging roles: item = (pixel of the 10 x 34 block, float4 piece)
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const C16Params p) 
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
                   int lrelu, hipStream_t s) {
     if (Co != 16 || (Ci != 16 && Ci != 32) || ldx % 4 != 0 || ldy % 4 != 0) return MRDIS_EUNSUPPORTED;
-    if (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w_tck)) & 15) != 0 || (bias && (((uintptr_t)bias) & 15) != 0)) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W < 65536 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;          // small maps: launch-bound either way
     const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci);
     if (xb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
