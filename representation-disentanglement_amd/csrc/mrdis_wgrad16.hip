@@ -19,20 +19,26 @@ struct Wgrad16Params {
 #define W16_RW (W16_TW + 2)
 #define W16_NPX ((W16_TH + 2) * W16_RW)
 
+template <int NS>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
-    constexpr int S = 17, XR = (W16_NPX * 4 + 255) / 256;          // 180 pixels x 4 float4 = 720 items
+    // NS = 16-channel slices of x handled by one workgroup (2 for Ci = 32: dy is staged and read once for both)
+    constexpr int S = NS == 1 ? 16 : 48, QX = 4 * NS;           // pixel pitch = 16 mod 64: the four positions of a k-step land 16 banks apart
+    constexpr int XR = (W16_NPX * QX + 255) / 256;          // 180 pixels x QX float4
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dys = smem;                                  // [128][16]
     float* xs = smem + 2048;                            // [pixel][17]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
     const int lb = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int cic = lb % p.nCi, split = lb / p.nCi;
-    const int c_lo = cic * 16;
+    const int ncol = p.nCi / NS;                       // workgroup columns
+    const int cic = lb % ncol, split = lb / ncol;
+    const int c_lo = cic * 16 * NS;
 
     int loff[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) loff[t] = ((t / 3) * W16_RW + (t % 3)) * S + l16;
-    const bool ci_ok = (c_lo + l16) < p.Ci;
+    bool ci_ok[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) ci_ok[sl] = (c_lo + 16 * sl + l16) < p.Ci;
     int tin[8];
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -44,9 +50,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
     for (int it = 0; it < XR; ++it) {
         const int idx = tid + it * 256;
         xl[it] = -1; xc[it] = 0;
-        if (idx < W16_NPX * 4) { const int pi = idx >> 2, q = idx & 3; xl[it] = pi * S + 4 * q; xc[it] = ((pi / W16_RW) << 10) | (pi % W16_RW); }
+        if (idx < W16_NPX * QX) { const int pi = idx / QX, q = idx % QX; xl[it] = pi * S + 4 * q; xc[it] = ((pi / W16_RW) << 10) | (pi % W16_RW); }
     }
-    const int qx = c_lo + (tid & 3) * 4;
+    const int qx = c_lo + (tid % QX) * 4;             // 256 % QX == 0: a thread's items share their channel quad
     const bool qx_ok = qx < p.Ci;
     int yc[2];
 #pragma unroll
@@ -54,9 +60,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
     const int qy = (tid & 3) * 4;
     const bool qy_ok = qy < p.Co;
 
-    f32x4 acc[9];
+    f32x4 acc[NS][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[sl][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     float4 xr[XR], yr[2];
     auto load_box = [&](int box) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
     auto store_box = [&]() {
 #pragma unroll
         for (int it = 0; it < XR; ++it)
-            if (xl[it] >= 0) { float* d = xs + xl[it]; d[0] = xr[it].x; d[1] = xr[it].y; d[2] = xr[it].z; d[3] = xr[it].w; }
+            if (xl[it] >= 0) *reinterpret_cast<float4*>(xs + xl[it]) = xr[it];
 #pragma unroll
         for (int it = 0; it < 2; ++it) *reinterpret_cast<float4*>(dys + 4 * (tid + it * 256)) = yr[it];
     };
@@ -101,25 +109,31 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
             const float bv = dys[(wave * 32 + g * 4 + kq) * 16 + l16];
             bsum += bv;
             const float* xa = xs + tin[g];
-            float av[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) av[t] = ci_ok ? xa[loff[t]] : 0.f;
+            for (int sl = 0; sl < NS; ++sl) {
+                float av[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[t], 0, 0, 0);
+                for (int t = 0; t < 9; ++t) av[t] = ci_ok[sl] ? xa[loff[t] + 16 * sl] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[sl][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[sl][t], 0, 0, 0);
+            }
         }
         if (nxt < p.numTiles) { __syncthreads(); store_box(); __syncthreads(); }
     }
     // cross-wave reduction through LDS (fixed order), then slab[split][cic][tap][16 ci][16 co]
     float* red = smem;                                  // [4 waves][9][256] = 9216 floats (host sizes the LDS for it)
-    float* out = p.slab + ((long long)lb * 9) * 256;
-    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int sl = 0; sl < NS; ++sl) {
+        float* out = p.slab + (((long long)split * p.nCi + cic * NS + sl) * 9) * 256;
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 9 + t) * 256 + (4 * kq + r) * 16 + l16] = acc[t][r];
-    __syncthreads();
-    for (int i = tid; i < 9 * 256; i += 256)
-        out[i] = (red[i] + red[9 * 256 + i]) + (red[2 * 9 * 256 + i] + red[3 * 9 * 256 + i]);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 9 + t) * 256 + (4 * kq + r) * 16 + l16] = acc[sl][t][r];
+        __syncthreads();
+        for (int i = tid; i < 9 * 256; i += 256)
+            out[i] = (red[i] + red[9 * 256 + i]) + (red[2 * 9 * 256 + i] + red[3 * 9 * 256 + i]);
+    }
     if (p.bias_slab != nullptr && cic == 0) {
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
@@ -192,8 +206,10 @@ int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float*
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + (size_t)p.splits * p.nCi * 9 * 256 : nullptr;
-    const size_t lds = sizeof(float) * (size_t)(4 * 9 * 256);           // reduction buffer (36 KB) >= dys + x box (20 KB)
-    hipLaunchKernelGGL(wgrad16_kernel, dim3(p.splits * p.nCi), dim3(256), lds, s, p);
+    const size_t lds = sizeof(float) * (size_t)(4 * 9 * 256);           // reduction buffer (36 KB) >= dys + x box (19.5 KB)
+    // (two slices per workgroup -- dy staged once, wgrad16_kernel<2> -- measured slower: 338 vs 289 us on 32 -> 16 at 256x256, B = 32;
+    //  the kernel lives on workgroup-level overlap of its staging and MFMA phases, and half as many workgroups overlap less)
+    hipLaunchKernelGGL(wgrad16_kernel<1>, dim3(p.splits * p.nCi), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     const long long nout = 9LL * Ci * Co + (dbias ? Co : 0);
     int SL = 1;
