@@ -1093,6 +1093,9 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
 
 // mrdis_pointwise.hip: the 1x1 decoder head (16 -> <= 8 channels) as streaming kernels
 int mrdis_run_pw_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co, int lrelu, hipStream_t s);
+// mrdis_wgrad_s2.hip: forward of the stride-2 first layers (Cin <= 7)
+int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                          int kh, int kw, int stride, int pad, int lrelu, hipStream_t s);
 // mrdis_c16.hip: 3x3 s1 p1 with 16 output channels, filter in registers
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu, hipStream_t s);
 int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, long long npix, int Ci, int Co, hipStream_t s);
@@ -1115,6 +1118,10 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
         return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream);
     const bool bf = bf16m_wanted(dtype, w_bf16_tkc, Ci, Co);
     if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;                // bf16 views: only the bf16 kernels may touch them
+    if (!st_bf16 && stride == 2 && Ci <= 7) {
+        rc = mrdis_run_conv_s2_fwd(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, kh, kw, stride, pad, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     if (!bf && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 16) {
         rc = mrdis_run_c16(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;

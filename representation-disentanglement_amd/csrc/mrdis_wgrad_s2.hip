@@ -235,6 +235,128 @@ __global__ __launch_bounds__(1024) void wgrad_s2_reduce_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- forward
+// The same layers forward: y[pixel][co] = bias[co] + sum_m xpatch[m][pixel] w[m][co], m = (tap, ci).  Same staging (rolling input-row
+// pairs, two register sets in flight); the filter is the A operand and lives in registers (k4, 32 couts: 28 k-steps x 2 = 56 VGPRs),
+// the pixel operand B[k = m][pixel] is one ds_read per (k-step, 16-pixel tile) at  row(m) * pitch + (2 ox + tx(m)) * Ci + ci(m).
+// D[cout][pixel]: lane = pixel, registers = 4 consecutive couts -> 16-byte stores.
+struct ConvS2Params {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, H, W, Ci, ldx, Co, ldy, Hout, Wout, lrelu;
+    int rowp, segs, R, M;
+    unsigned x_bytes;
+};
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void conv_s2_fwd_kernel(const ConvS2Params p) {
+    constexpr int KSTEPS = (KS * KS * 7 + 3) / 4;     // 28 (k4) / 16 (k3) k-steps of 4 (tap, ci) rows
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                 // [4][rowp]: two pairs of input rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int Ci = p.Ci;
+    const int n = split / p.segs, oy0 = (split - n * p.segs) * p.R, oy1 = min(oy0 + p.R, p.Hout);
+
+    // A = filter: a[s][nt] = w[m = 4 s + kq][16 nt + l16]; B offsets of row m at an even output row, and which rows swap at an odd one
+    float a[KSTEPS][NT];
+    int moff[KSTEPS];
+    unsigned hi = 0;                                  // bit s: tap row >= 2 (its LDS row moves down by two at odd output rows, the others up)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const int m = 4 * s + kq;
+        const bool ok = m < p.M;
+        const int tap = ok ? m / Ci : 0, ci = ok ? m - tap * Ci : 0, ty = tap / KS;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[s][nt] = ok ? p.w[m * p.Co + 16 * nt + l16] : 0.f;
+        moff[s] = ty * p.rowp + (tap % KS) * Ci + ci + 2 * Ci * l16;
+        if (ty >= 2) hi |= 1u << s;
+    }
+    float4 bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        bv[nt] = p.bias ? make_float4(p.bias[16 * nt + 4 * kq], p.bias[16 * nt + 4 * kq + 1], p.bias[16 * nt + 4 * kq + 2], p.bias[16 * nt + 4 * kq + 3])
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    unsigned xg[S2_XJ]; int xl[S2_XJ];
+#pragma unroll
+    for (int j = 0; j < S2_XJ; ++j) {
+        const int idx = tid + 256 * j;
+        xg[j] = S2_OOB; xl[j] = -1;
+        if (idx < p.W * Ci) { const int pix = idx / Ci, c = idx - pix * Ci; xg[j] = 4u * (unsigned)(pix * p.ldx + c); xl[j] = (pix + 1) * Ci + c; }
+    }
+    for (int i = tid; i < 4 * p.rowp; i += 256) xs[i] = 0.f;
+
+    float xr[2][2][S2_XJ];
+    auto load_set = [&](auto S_, int j) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int iy = 2 * j - 1 + h;
+            const bool ok = j <= oy1 && (unsigned)iy < (unsigned)p.H;
+            const unsigned base = 4u * (unsigned)((n * p.H + iy) * p.W * p.ldx);
+#pragma unroll
+            for (int jj = 0; jj < S2_XJ; ++jj)
+                xr[S][h][jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)((ok && xl[jj] >= 0) ? base + xg[jj] : S2_OOB), 0, 0));
+        }
+    };
+    auto store_set = [&](auto S_, int j) {
+        constexpr int S = decltype(S_)::value;
+        float* d = xs + 2 * (j & 1) * p.rowp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < S2_XJ; ++jj)
+                if (xl[jj] >= 0) d[h * p.rowp + xl[jj]] = xr[S][h][jj];
+    };
+    const int ntile = p.Wout >> 4;                    // host: Wout % 16 == 0; wave w takes tiles w, w + 4, ...
+    auto compute = [&](int oy) {
+        if (oy >= oy1) return;                        // (wave-uniform; an odd row count runs the staging of one more row)
+        const int flip = (oy & 1) ? 2 * p.rowp : 0;
+        for (int t = wave; t < ntile; t += 4) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xt = xs + 32 * Ci * t;
+            float bn = xt[moff[0] + ((hi & 1u) ? -flip : flip)];
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const float b = bn;
+                if (s + 1 < KSTEPS) bn = xt[moff[s + 1] + (((hi >> (s + 1)) & 1u) ? -flip : flip)];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][nt], b, acc[nt], 0, 0, 0);
+            }
+            const int ox = 16 * t + l16;
+            float* dst = p.y + ((long long)(n * p.Hout + oy) * p.Wout + ox) * p.ldy + 4 * kq;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float4 o = make_float4(acc[nt][0] + bv[nt].x, acc[nt][1] + bv[nt].y, acc[nt][2] + bv[nt].z, acc[nt][3] + bv[nt].w);
+                if (p.lrelu) { o.x = o.x > 0.f ? o.x : 0.2f * o.x; o.y = o.y > 0.f ? o.y : 0.2f * o.y; o.z = o.z > 0.f ? o.z : 0.2f * o.z; o.w = o.w > 0.f ? o.w : 0.2f * o.w; }
+                *reinterpret_cast<float4*>(dst + 16 * nt) = o;
+            }
+        }
+    };
+    auto step = [&](auto S_, int oy) {                // set S holds pair oy + 2
+        compute(oy);
+        __syncthreads();
+        store_set(S_, oy + 2);
+        load_set(S_, oy + 4);
+        __syncthreads();
+    };
+    load_set(IC<0>{}, oy0);
+    load_set(IC<1>{}, oy0 + 1);
+    __syncthreads();                                  // the zero fill
+    store_set(IC<0>{}, oy0);
+    store_set(IC<1>{}, oy0 + 1);
+    load_set(IC<0>{}, oy0 + 2);
+    load_set(IC<1>{}, oy0 + 3);
+    __syncthreads();
+    for (int oy = oy0; oy < oy1; oy += 2) {
+        step(IC<0>{}, oy);
+        step(IC<1>{}, oy + 1);
+    }
+}
+
 // dw[i] = sum_k slab[k][i] (i < total), dbias[co] (+)= sum_k bslab[k][co]: the fixed-order slab reduction shared with mrdis_pointwise.hip
 int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
                              hipStream_t s) {
@@ -296,4 +418,25 @@ int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float
     MRDIS_CHECK_LAUNCH();
     const int total = p.M * Co;
     return mrdis_launch_slab_reduce(p.slab, dw_tck, total, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
+}
+
+// forward of the same layers; MRDIS_EUNSUPPORTED outside what the kernel covers
+int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                          int kh, int kw, int stride, int pad, int lrelu, hipStream_t s) {
+    WgradS2Params q;
+    if (!plan_wgrad_s2(q, N, H, W, Ci, Co, kh, kw, stride, pad)) return MRDIS_EUNSUPPORTED;
+    if (ldy % 4 != 0 || (((uintptr_t)y) & 15) != 0 || (((uintptr_t)x) & 3) != 0) return MRDIS_EUNSUPPORTED;
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci);
+    if (xb >= 0x7fffffffLL || (long long)N * q.Hout * q.Wout * ldy >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    ConvS2Params p{};
+    p.x = x; p.w = w_tck; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.Co = Co; p.ldy = ldy;
+    p.Hout = q.Hout; p.Wout = q.Wout; p.lrelu = lrelu; p.rowp = q.rowp; p.segs = q.segs; p.R = q.R; p.M = q.M; p.x_bytes = (unsigned)xb;
+    const size_t lds = sizeof(float) * (size_t)4 * p.rowp;
+    const int NT = Co / 16;
+    if (kh == 4 && NT == 2) hipLaunchKernelGGL((conv_s2_fwd_kernel<4, 2>), dim3(q.splits), dim3(256), lds, s, p);
+    else if (kh == 4) hipLaunchKernelGGL((conv_s2_fwd_kernel<4, 1>), dim3(q.splits), dim3(256), lds, s, p);
+    else if (NT == 2) hipLaunchKernelGGL((conv_s2_fwd_kernel<3, 2>), dim3(q.splits), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_s2_fwd_kernel<3, 1>), dim3(q.splits), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
 }

@@ -424,6 +424,8 @@ class GradAllReduce:
 
 
 # --------------------------------------------------------------------------- one training iteration
+_PLANAR_INPUTS = os.environ.get('MRDIS_PLANAR_INPUTS', '1') != '0'
+
 LOSS_KEYS = ('recon_y', 'recon_y_fused', 'recon_x', 'recon_x_mix', 'kl', 'latent_z', 'sim_s', 'sim_z',
              'adv_s', 'adv_s_d', 'all')
 
@@ -434,6 +436,13 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
     M = len(config['contrast_list'])
     c = 2 * config['block_size'] + 1
     inputs_list = [inputs[:, i * c:(i + 1) * c] for i in range(M)]                               # :166-168 (views)
+    if _PLANAR_INPUTS and M > 1 and inputs.is_cuda and inputs.is_contiguous(memory_format=torch.channels_last):
+        # one pass that turns the (B, H, W, M c) batch into M dense (B, H, W, c) blocks: a c-channel slice of the interleaved tensor
+        # touches every cache line of it, so each of the ~60 reads of a modality per step (first layers, their weight gradients,
+        # the reconstruction losses) would fetch all M c channels from HBM
+        B, _, H, W = inputs.shape
+        planar = inputs.permute(0, 2, 3, 1).reshape(B, H, W, M, c).permute(3, 0, 1, 2, 4).contiguous()
+        inputs_list = [planar[i].permute(0, 3, 1, 2) for i in range(M)]
     p = config['p']
     dev = inputs.device
     zero = torch.zeros((), device=dev)

@@ -415,12 +415,22 @@ def test_wgrad_stride2_first_layers(mrdis, case):
     dw2, none = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True, bias_sink=sink)
     assert none is None and torch.equal(dw2, dw)
     close(sink, b.grad + 2.0, rtol=3e-4, what='dbias sink')
+    # forward of the same layers (conv_s2_fwd_kernel): bias, LeakyReLU, output into a channel slice
+    w_tck, bd = to_tck(w.detach()).to(dev()), b.detach().to(dev())
+    yy = hip.conv2d_fwd(xv, w_tck, bd, k, k, 2, 1)
+    close(yy, y.detach(), rtol=2e-5, what='fwd s2')
+    out = hip.empty_nhwc(N, Co + 16, H // 2, W // 2, dev()); out.fill_(3.0)
+    hip.conv2d_fwd(xv, w_tck, bd, k, k, 2, 1, lrelu=True, out=out[:, 16:])
+    close(out[:, 16:], F.leaky_relu(y.detach(), 0.2), rtol=2e-5, what='fwd s2 lrelu into a slice')
+    assert bool((out[:, :16] == 3.0).all())
     hip.set_option('debug_now16', 1)
     try:
         dw3, db3 = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True)
+        y3 = hip.conv2d_fwd(xv, w_tck, bd, k, k, 2, 1)
     finally:
         hip.set_option('debug_now16', 0)
     close(dw3, dw.cpu(), rtol=3e-4, what='generic vs s2'); close(db3, db.cpu(), rtol=3e-4, what='generic vs s2 bias')
+    close(y3, yy.cpu(), rtol=2e-5, what='generic vs s2 forward')
 
 
 @pytest.mark.parametrize('case', [(8, 7, 128, 96), (3, 8, 100, 75), (5, 4, 64, 80), (2, 1, 96, 96), (32, 7, 64, 64)], ids=str)

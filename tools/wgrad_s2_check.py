@@ -20,6 +20,10 @@ for (co, k, x) in [(32, 4, full[:, 7:14]), (16, 3, full[:, 7:14]), (32, 4, dense
     for now16 in (0, 1, 0):
         hip.set_option('debug_now16', now16)
         out.append(f'now16={now16}: {timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, 2, 1, need_bias=True)):.1f} us')
+    w_tck = torch.randn(k * k, 7, co, device=dev) * 0.1; bias = torch.randn(co, device=dev)
+    for now16 in (0, 1):
+        hip.set_option('debug_now16', now16)
+        out.append(f'fwd now16={now16}: {timeit(lambda: hip.conv2d_fwd(x, w_tck, bias, k, k, 2, 1)):.1f} us')
     hip.set_option('debug_now16', 0)
     mb = (32 * 256 * 256 * 7 + 32 * 128 * 128 * co) * 4 / 1e6
     print(f'7 -> {co} k{k} s2 256x256 B=32 ldx={hip.nhwc(x)[1]} ({mb:.0f} MB algorithmic): ' + ' | '.join(out), flush=True)
