@@ -1,0 +1,133 @@
+// mrdis_co4.hip -- 3x3 / stride 1 / pad 1 convolution with FOUR output channels and 32 / 64 input channels, fp32:
+// ana_dec.output (64 -> 4 at full resolution, model.py:2260) and the data gradients of the SPADE `si_layers` (C -> 4, model.py:2436).
+// A 16-wide MFMA tile over 4 couts is 75 % padding and the packed-FMA kernel that ran these layers (tapconv16_kernel<., THIN4>) is
+// LDS-issue bound at 2.4 TB/s.  Here the product is split into a GEMM that needs no window and a gather that needs no multiplies:
+//     Z[tap][q][co] = sum_ci x[q][ci] w[tap][ci][co]        36 = 9 taps x 4 couts rows per INPUT pixel q: three 16-row MFMA tiles (75 % used),
+//     y[p][co]      = bias[co] + sum_tap Z[tap][p + off(tap)][co]
+// * the pixel operand of the GEMM is the unshifted input: it goes from global memory straight into MFMA registers (one 16-byte load per
+//   16 channels and lane), no LDS staging, no halo; the filter (A operand, rows ordered co-major inside a tile) stays in registers;
+// * D[row][pixel] leaves every lane (pixel, kq = co) with the values of 4 taps of its cout: nine conflict-free ds_write_b32 per tile put
+//   Z[tap][pixel][co] into LDS (36 KB per 256-pixel row);
+// * a workgroup streams down the rows of one image: after the Z of input row r is in LDS, thread p adds the three taps of each tap row
+//   (fixed order) -- tap row 0 starts output row r + 1, tap row 1 continues output row r, tap row 2 completes output row r - 1, which is
+//   stored; the two running rows live in the thread's registers.  Two barriers per row; next row's pixel operands are in flight in the
+//   registers of the tile that was just multiplied.
+#include "mrdis_common.h"
+
+struct Co4Params {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, H, W, Ci, ldx, ldy, flip, lrelu;
+    int R, segs;              // output rows per workgroup, workgroups per image
+    unsigned x_bytes;
+};
+
+namespace {
+constexpr unsigned CO4_OOB = 0xfffffff0u;
+typedef unsigned co4_u32x4 __attribute__((ext_vector_type(4)));
+}
+
+// HALVES = Ci / 16 (2 | 4), TPW = 16-pixel tiles per wave and row = W / 64 (1 | 2 | 4)
+template <int HALVES, int TPW>
+__global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) {
+    constexpr int CI = 16 * HALVES, KS = CI / 4;
+    extern __shared__ __attribute__((aligned(16))) float zs[];      // [9][W + 2][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int W = p.W, WP = W + 2;
+    const int b = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = b / p.segs, r0 = (b - n * p.segs) * p.R, r1 = min(r0 + p.R, p.H);
+
+    // A = filter rows: row i = 16 rt + l16 <-> cout l16 >> 2, tap 4 rt + (l16 & 3); k-step 4 h + j <-> channel 16 h + 4 kq + j
+    float a[KS][3];
+    {
+        const int co = l16 >> 2, tl = l16 & 3;
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) {
+            const int tap = 4 * rt + tl;
+            const int tf = p.flip ? 8 - tap : tap;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                a[ks][rt] = tap < 9 ? p.w[(tf * CI + 16 * (ks >> 2) + 4 * kq + (ks & 3)) * 4 + co] : 0.f;
+        }
+    }
+    for (int i = tid; i < 9 * WP * 4; i += 256) zs[i] = 0.f;       // the halo columns stay zero
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    co4_u32x4 xr[TPW][HALVES];
+    auto load_tile = [&](int t, int r) {              // tile t of the wave (pixels 16 (wave + 4 t) ..) of input row r; outside -> zeros
+        const int px = 16 * (wave + 4 * t) + l16;
+        const bool ok = (unsigned)r < (unsigned)p.H && r >= r0 - 1 && r <= r1;
+        const unsigned base = 4u * (unsigned)(((n * p.H + r) * W + px) * p.ldx + 4 * kq);
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) xr[t][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? base + 64u * h : CO4_OOB), 0, 0);
+    };
+    const float4 bias4 = p.bias ? make_float4(p.bias[0], p.bias[1], p.bias[2], p.bias[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 runA = make_float4(0.f, 0.f, 0.f, 0.f), runB = runA;   // output rows r + 1 and r so far, column tid
+    auto tap_row = [&](int ty, int pcol) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zs + ((3 * ty + 0) * WP + pcol + 0) * 4);
+        const float4 z1 = *reinterpret_cast<const float4*>(zs + ((3 * ty + 1) * WP + pcol + 1) * 4);
+        const float4 z2 = *reinterpret_cast<const float4*>(zs + ((3 * ty + 2) * WP + pcol + 2) * 4);
+        return make_float4((z0.x + z1.x) + z2.x, (z0.y + z1.y) + z2.y, (z0.z + z1.z) + z2.z, (z0.w + z1.w) + z2.w);
+    };
+
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) load_tile(t, r0 - 1);
+    __syncthreads();
+    for (int r = r0 - 1; r <= r1; ++r) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                const float xv[4] = {__uint_as_float(xr[t][h].x), __uint_as_float(xr[t][h].y), __uint_as_float(xr[t][h].z), __uint_as_float(xr[t][h].w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * h + j][rt], xv[j], acc[rt], 0, 0, 0);
+            }
+            load_tile(t, r + 1);                      // the registers just multiplied take the next row's pixels
+            // Z[tap = 4 rt + reg][pixel][co = kq]: lanes (pixel, co) are 64 consecutive words
+            float* zd = zs + (16 * (wave + 4 * t) + l16 + 1) * 4 + kq;
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * rt + q < 9) zd[(4 * rt + q) * WP * 4] = acc[rt][q];
+        }
+        __syncthreads();
+        if (tid < W) {
+            // taps (ty, tx) of input row r feed output row r - ty + 1 at column q - tx + 1: column p reads q = p + tx - 1 (+ 1 halo)
+            const float4 g0 = tap_row(0, tid), g1 = tap_row(1, tid), g2 = tap_row(2, tid);
+            float4 o = make_float4((runB.x + g2.x) + bias4.x, (runB.y + g2.y) + bias4.y, (runB.z + g2.z) + bias4.z, (runB.w + g2.w) + bias4.w);
+            if (p.lrelu) { o.x = o.x > 0.f ? o.x : 0.2f * o.x; o.y = o.y > 0.f ? o.y : 0.2f * o.y; o.z = o.z > 0.f ? o.z : 0.2f * o.z; o.w = o.w > 0.f ? o.w : 0.2f * o.w; }
+            if (r - 1 >= r0) *reinterpret_cast<float4*>(p.y + ((long long)(n * p.H + r - 1) * W + tid) * p.ldy) = o;
+            runB = make_float4(runA.x + g1.x, runA.y + g1.y, runA.z + g1.z, runA.w + g1.w);
+            runA = g0;
+        }
+        __syncthreads();
+    }
+}
+
+// returns MRDIS_EUNSUPPORTED outside what the kernel covers
+int mrdis_run_co4(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                  int flip, int lrelu, hipStream_t s) {
+    if (Co != 4 || (Ci != 32 && Ci != 64) || (W != 64 && W != 128 && W != 256) || ldx % 4 != 0 || ldy % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W < 65536) return MRDIS_EUNSUPPORTED;
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci);
+    if (xb >= 0x7fffffffLL || (long long)N * H * W * ldy >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    Co4Params p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.ldy = ldy; p.flip = flip; p.lrelu = lrelu;
+    p.x_bytes = (unsigned)xb;
+    int segs = mrdis_cdiv(512, N);                     // ~512 workgroups, each a run of consecutive rows of one image
+    if (segs > H / 4) segs = H / 4 > 0 ? H / 4 : 1;
+    p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
+    const size_t lds = sizeof(float) * (size_t)9 * (W + 2) * 4;
+    const dim3 grid(N * p.segs), block(256);
+#define CO4_LAUNCH(HV, TP) hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP>), grid, block, lds, s, p)
+    const int tpw = W / 64;
+    if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4); else if (tpw == 2) CO4_LAUNCH(4, 2); else CO4_LAUNCH(4, 1); }
+    else { if (tpw == 4) CO4_LAUNCH(2, 4); else if (tpw == 2) CO4_LAUNCH(2, 2); else CO4_LAUNCH(2, 1); }
+#undef CO4_LAUNCH
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

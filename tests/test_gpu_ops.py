@@ -493,6 +493,38 @@ def test_conv3x3_16_couts_register_filter(mrdis, case):
     close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs c16')
 
 
+@pytest.mark.parametrize('case', [(2, 64, 256, 256), (3, 32, 70, 256), (5, 64, 128, 128), (9, 32, 100, 128), (17, 64, 64, 64), (20, 32, 61, 64)], ids=str)
+def test_conv3x3_4_couts_gemm_gather(mrdis, case):
+    """mrdis_co4.hip (3x3 s1 p1, 4 output channels, 32 / 64 input channels: ana_dec.output forward, the si_layers data gradients):
+    window-free MFMA GEMM Z[tap][pixel][co] + fixed-order tap gather while streaming down the rows.  Forward with bias (+ LeakyReLU)
+    and the data gradient of a 4 -> C layer against torch; row counts that do not divide into the workgroups' row runs; the input a
+    channel slice of a wider tensor; option debug_now16 = 1 (the packed-FMA tile kernel) must agree."""
+    N, C, H, W = case
+    hip = mrdis.hip
+    wide = rnd((N, C + 16, H, W), 87)
+    x = wide[:, 8:8 + C]
+    w = rnd((4, C, 3, 3), 88, 0.15); b = rnd((4,), 89, 0.1)
+    want = F.conv2d(x, w, b, 1, 1)
+    xv = cl(wide)[:, 8:8 + C]
+    w_tck, bd = to_tck(w).to(dev()), b.to(dev())
+    got = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+    close(got, want, rtol=2e-5, what='co4 fwd')
+    gotl = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1, lrelu=True)
+    close(gotl, F.leaky_relu(want, 0.2), rtol=2e-5, what='co4 fwd lrelu')
+    # data gradient of a 4 -> C layer: dx (N, 4, H, W) from dy = the C-channel tensor
+    w2 = rnd((C, 4, 3, 3), 90, 0.15)
+    want_dx = torch.nn.grad.conv2d_input((N, 4, H, W), w2, x.contiguous(), 1, 1)
+    dx = hip.conv2d_bwd_data(xv, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
+    close(dx, want_dx, rtol=2e-5, what='co4 dgrad')
+    hip.set_option('debug_now16', 1)
+    try:
+        ref = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+        ref_dx = hip.conv2d_bwd_data(xv, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
+    finally:
+        hip.set_option('debug_now16', 0)
+    close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs co4'); close(ref_dx, dx.cpu(), rtol=2e-5, what='tile kernel vs co4 dgrad')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
