@@ -2418,17 +2418,15 @@ __global__ void mix_routed_bwd_final_kernel(const float* __restrict__ part, int 
 #define MIX_MAX_TYPES 8
 struct MixPtrs { float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* btck[MIX_MAX_TYPES]; __bf16* btkc[MIX_MAX_TYPES]; };   // b*: optional bf16 copies
 struct MixCPtrs { const float* p[MIX_MAX_TYPES]; };
-__global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
-                                            const float* __restrict__ types, int emb, float* __restrict__ r_out, MixPtrs out,
-                                            int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc) {
+// (bx, gx): block index and block count of this filter's share of the grid -- blockIdx.x / gridDim.x for the one-layer launch, the
+// job's block range for the all-layers launch (mix_jobs_fwd_kernel)
+__device__ __forceinline__ void mix_fwd_body(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                             const float* __restrict__ types, int emb, float* __restrict__ r_out,
+                                             float* __restrict__ w_tck, float* __restrict__ w_tkc, __bf16* __restrict__ b_tck, __bf16* __restrict__ b_tkc,
+                                             int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc, int m, int bx, int gx) {
     // ld_tck: row pitch of the [T][Ci][.] outputs, tap_tkc: tap pitch of the [T][.][Ci] outputs -- Co and Co * Ci for a filter of its
     // own, 2 Co and 2 Co * Ci when the pointers address one half of a fused gamma | beta filter
-    const int m = blockIdx.y;
     const float* t = types + m * emb;
-    float* __restrict__ w_tck = out.tck[m];
-    float* __restrict__ w_tkc = out.tkc[m];
-    __bf16* __restrict__ b_tck = out.btck[m];
-    __bf16* __restrict__ b_tkc = out.btkc[m];
     const long long total = (long long)Co * Ci * T;
     float rr[8];
 #pragma unroll
@@ -2437,8 +2435,8 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
         if (e < E) { z = fcb[e]; for (int k = 0; k < emb; ++k) z += fcw[e * emb + k] * t[k]; }
         rr[e] = e < E ? 1.f / (1.f + expf(-z)) : 0.f;
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < E) r_out[m * E + threadIdx.x] = rr[threadIdx.x];
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (bx == 0 && (int)threadIdx.x < E) r_out[m * E + threadIdx.x] = rr[threadIdx.x];
+    for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
         const int tt = (int)(i % T);
         const long long q = i / T;
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
@@ -2453,19 +2451,26 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
         }
     }
 }
+__global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                            const float* __restrict__ types, int emb, float* __restrict__ r_out, MixPtrs out,
+                                            int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc) {
+    const int m = blockIdx.y;
+    mix_fwd_body(W, fcw, fcb, types, emb, r_out, out.tck[m], out.tkc[m], out.btck[m], out.btkc[m], E, Co, Ci, T, ld_tck, tap_tkc, m,
+                 (int)blockIdx.x, (int)gridDim.x);
+}
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
 // dW[e] = sum_m r[m][e] dw_m (types in order m = 0..M-1; a type without gradient contributes nothing).
-__global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
-                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw) {
+__device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __restrict__ W, const float* __restrict__ r,
+                                             float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw,
+                                             int m, int bx, int gx) {
     __shared__ double red[8][4];
-    const int m = blockIdx.y;
     const long long total = (long long)Co * Ci * T;
     const float* __restrict__ g_m = dw.p[m];
     double dr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) dr[e] = 0.0;
     if (g_m != nullptr || m == 0)
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
         const int t = (int)(i % T);
         const long long q = i / T;
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
@@ -2501,12 +2506,16 @@ __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, c
     }
     __syncthreads();
     if (threadIdx.x < 8 && (int)threadIdx.x < E)
-        part[((long long)m * gridDim.x + blockIdx.x) * 8 + threadIdx.x] =
+        part[((long long)m * gx + bx) * 8 + threadIdx.x] =
             (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
+__global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
+                                     float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw) {
+    mix_bwd_body(dw, W, r, dW, part, M, E, Co, Ci, T, accumulate, ld_dw, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
 // one block of 64 threads: thread (m, e) sums its partials, dz = dr r (1 - r); then e-threads sum over types
-__global__ void mix_multi_bwd_final_kernel(const float* __restrict__ part, int nblk, int M, int E, const float* __restrict__ r,
-                                           const float* __restrict__ types, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb, int accumulate) {
+__device__ __forceinline__ void mix_bwd_final_body(const float* __restrict__ part, int nblk, int M, int E, const float* __restrict__ r,
+                                                   const float* __restrict__ types, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb, int accumulate) {
     __shared__ float dz[MIX_MAX_TYPES][8];
     const int m = threadIdx.x >> 3, e = threadIdx.x & 7;
     if (m < M && e < E) {
@@ -2526,6 +2535,48 @@ __global__ void mix_multi_bwd_final_kernel(const float* __restrict__ part, int n
             dfcw[e * emb + k] = accumulate ? dfcw[e * emb + k] + sw : sw;
         }
     }
+}
+
+__global__ void mix_multi_bwd_final_kernel(const float* __restrict__ part, int nblk, int M, int E, const float* __restrict__ r,
+                                           const float* __restrict__ types, int emb, float* __restrict__ dfcw, float* __restrict__ dfcb, int accumulate) {
+    mix_bwd_final_body(part, nblk, M, E, r, types, emb, dfcw, dfcb, accumulate);
+}
+
+// ---- every CondConv2d layer of the model in ONE launch (forward) / one launch pair (backward).  A step mixes ~90 filters and takes
+// their gradients apart again: 90 + 2 x 90 launches of 10-20 us each, 4 % of the bf16 step.  A job = one layer (or one half of a fused
+// gamma | beta pair); the table lives in device memory, the grid is the concatenation of the jobs' block ranges.  Same bodies, same
+// block-to-element mapping, same summation order as the per-layer launches: bit-identical results.
+struct MixJob {
+    const float* W; const float* fcw; const float* fcb; float* r;                  // r: [M][E], written forward, read backward
+    float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* btck[MIX_MAX_TYPES]; __bf16* btkc[MIX_MAX_TYPES];
+    float* dW; float* dfcw; float* dfcb; float* part;                              // gradient sinks, partial-sum workspace [M][nblk][8]
+    long long tap_tkc;
+    int E, Co, Ci, T, ld_tck, ld_dw, block0, nblk, accumulate, pad_;
+};
+__device__ __forceinline__ const MixJob* mix_find_job(const MixJob* __restrict__ jobs, int njobs, int bx) {
+    int lo = 0, hi = njobs - 1;                       // last job with block0 <= bx
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= bx) lo = mid; else hi = mid - 1; }
+    return jobs + lo;
+}
+__global__ void mix_jobs_fwd_kernel(const MixJob* __restrict__ jobs, int njobs, const float* __restrict__ types, int emb) {
+    const MixJob* j = mix_find_job(jobs, njobs, (int)blockIdx.x);
+    const int m = blockIdx.y;
+    mix_fwd_body(j->W, j->fcw, j->fcb, types, emb, j->r, j->tck[m], j->tkc[m], j->btck[m], j->btkc[m], j->E, j->Co, j->Ci, j->T, j->ld_tck,
+                 j->tap_tkc, m, (int)blockIdx.x - j->block0, j->nblk);
+}
+// dw: [njobs][MIX_MAX_TYPES] gradient pointers of this step (null: that label's filter got no gradient)
+__global__ void mix_jobs_bwd_kernel(const MixJob* __restrict__ jobs, int njobs, const float* const* __restrict__ dw, int M) {
+    const MixJob* j = mix_find_job(jobs, njobs, (int)blockIdx.x);
+    MixCPtrs g;
+    const float* const* gp = dw + (long long)(j - jobs) * MIX_MAX_TYPES;
+#pragma unroll
+    for (int mm = 0; mm < MIX_MAX_TYPES; ++mm) g.p[mm] = mm < M ? gp[mm] : nullptr;
+    mix_bwd_body(g, j->W, j->r, j->dW, j->part, M, j->E, j->Co, j->Ci, j->T, j->accumulate, j->ld_dw, (int)blockIdx.y,
+                 (int)blockIdx.x - j->block0, j->nblk);
+}
+__global__ void mix_jobs_bwd_final_kernel(const MixJob* __restrict__ jobs, const float* __restrict__ types, int emb, int M) {
+    const MixJob* j = jobs + blockIdx.x;
+    mix_bwd_final_body(j->part, j->nblk, M, j->E, j->r, types, emb, j->dfcw, j->dfcb, j->accumulate);
 }
 
 static int mix_blocks(long long total) { int b = mrdis_cdiv(total, 256); return b > 128 ? 128 : (b < 1 ? 1 : b); }
@@ -2632,6 +2683,26 @@ extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, co
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL(mix_multi_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, M, E, r, types, emb, dfc_w, dfc_b, accumulate ? 1 : 0);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" size_t mrdis_mix_job_bytes(void) { return sizeof(MixJob); }
+extern "C" int mrdis_mix_job_blocks(int Co, int Ci, int T) { return mix_blocks((long long)Co * Ci * T); }
+
+extern "C" int mrdis_mix_jobs_fwd(const void* jobs, int njobs, int total_blocks, const float* types, int emb, int M, void* stream) {
+    if (!jobs || !types || njobs < 1 || total_blocks < njobs || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES) return MRDIS_EINVAL;
+    hipLaunchKernelGGL(mix_jobs_fwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs, types, emb);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+extern "C" int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void* dw_table, const float* types, int emb, int M, void* stream) {
+    if (!jobs || !dw_table || !types || njobs < 1 || total_blocks < njobs || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES) return MRDIS_EINVAL;
+    hipLaunchKernelGGL(mix_jobs_bwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs,
+                       reinterpret_cast<const float* const*>(dw_table), M);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mix_jobs_bwd_final_kernel, dim3(njobs), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), types, emb, M);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

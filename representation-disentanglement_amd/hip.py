@@ -43,6 +43,10 @@ _SIGS = {
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _I, _I, _P]),
+    'mrdis_mix_job_bytes': (_Z, []),
+    'mrdis_mix_job_blocks': (_I, [_I, _I, _I]),
+    'mrdis_mix_jobs_fwd': (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    'mrdis_mix_jobs_bwd': (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
     'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
     'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
@@ -256,6 +260,41 @@ def to_device_small(t_cpu, device):
     if _mailbox is None:
         _mailbox = _Mailbox()
     return _mailbox.send(t_cpu, device)
+
+
+class MixJob(_c.Structure):
+    """csrc/mrdis_conv.hip `MixJob`: one CondConv2d layer (or one half of a fused gamma | beta pair) of the all-layers mixing launches."""
+    _fields_ = [('W', _c.c_void_p), ('fcw', _c.c_void_p), ('fcb', _c.c_void_p), ('r', _c.c_void_p),
+                ('tck', _c.c_void_p * 8), ('tkc', _c.c_void_p * 8), ('btck', _c.c_void_p * 8), ('btkc', _c.c_void_p * 8),
+                ('dW', _c.c_void_p), ('dfcw', _c.c_void_p), ('dfcb', _c.c_void_p), ('part', _c.c_void_p),
+                ('tap_tkc', _c.c_longlong),
+                ('E', _c.c_int), ('Co', _c.c_int), ('Ci', _c.c_int), ('T', _c.c_int), ('ld_tck', _c.c_int), ('ld_dw', _c.c_int),
+                ('block0', _c.c_int), ('nblk', _c.c_int), ('accumulate', _c.c_int), ('pad_', _c.c_int)]
+
+
+def mix_job_table(jobs, device):
+    """list of MixJob -> device tensor holding the table (checked against the library's struct size)."""
+    lib = load()
+    nb = _c.sizeof(MixJob)
+    if nb != lib.mrdis_mix_job_bytes():
+        raise MrdisError(f'MixJob layout mismatch: binding {nb} bytes, library {lib.mrdis_mix_job_bytes()}')
+    arr = (MixJob * len(jobs))(*jobs)
+    host = torch.frombuffer(bytearray(_c.string_at(_c.addressof(arr), nb * len(jobs))), dtype=torch.uint8)
+    return host.to(device)
+
+
+def mix_job_blocks(Co, Ci, T):
+    return int(load().mrdis_mix_job_blocks(Co, Ci, T))
+
+
+def mix_jobs_fwd(table, njobs, total_blocks, types):
+    M, emb = types.shape
+    _chk(load().mrdis_mix_jobs_fwd(_ptr(table), njobs, total_blocks, _ptr(types), emb, M, _stream()), 'mix_jobs_fwd')
+
+
+def mix_jobs_bwd(table, njobs, total_blocks, dw_table, types):
+    M, emb = types.shape
+    _chk(load().mrdis_mix_jobs_bwd(_ptr(table), njobs, total_blocks, _ptr(dw_table), _ptr(types), emb, M, _stream()), 'mix_jobs_bwd')
 
 
 def cast_view(x, dtype, channels=None):

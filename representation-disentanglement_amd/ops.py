@@ -5,6 +5,7 @@ libmrdis_hip.so (include/mrdis.h); there is no arithmetic here.  Tensors stay
 logically NCHW (reference interface) and physically NHWC (channels_last).
 """
 import contextlib
+import os as _os
 
 import torch
 from torch.autograd import Function
@@ -150,6 +151,201 @@ def mix_pair_fused_all(gamma, beta, types):
                                   beta.weight, beta._routing_fn.fc.weight, beta._routing_fn.fc.bias, types)
 
 
+# --------------------------------------------------------------------------- all layers of a model mixed in one launch
+class MixPlan:
+    """The static part of the all-layers mixing launches of one model (mrdis_mix_jobs_fwd / _bwd): which CondConv2d layers (`singles`)
+    and fused gamma | beta pairs (`pairs`: (block, gamma, beta)) there are, persistent output buffers -- a step's mixed filters are
+    dead once its backward has run, so every step writes the same storage and the job table is built once -- the routing values,
+    the partial-sum workspace and the job table in device memory.  None if a parameter has no in-kernel gradient sink."""
+
+    def __init__(self, singles, pairs, M, want_bf16, device):
+        self.singles, self.pairs, self.M, self.want_bf16 = singles, pairs, M, want_bf16
+        self.params = []
+        self.probe = singles[0].weight if singles else (pairs[0][1].weight if pairs else None)
+        shapes = []                                    # per entry: (T, Ci, Cw) with Cw = Co or 2 C
+        specs = []                                     # per job: (entry index, conv module, col0, ld)
+        for m in singles:
+            E, Co, Ci, kh, kw = m.weight.shape
+            shapes.append((kh * kw, Ci, Co)); specs.append((len(shapes) - 1, m, 0, Co))
+        for blk, g, b in pairs:
+            E, C, Ci, kh, kw = g.weight.shape
+            shapes.append((kh * kw, Ci, 2 * C))
+            specs.append((len(shapes) - 1, g, 0, 2 * C)); specs.append((len(shapes) - 1, b, C, 2 * C))
+        self.shapes = shapes
+        sizes = [t * ci * cw for (t, ci, cw) in shapes]
+        self.sizes = sizes
+        tot = sum(sizes)
+        # [entry][label] blocks: tck then tkc
+        self.flat = torch.empty(2 * M * tot, dtype=torch.float32, device=device)
+        self.flat16 = torch.empty(2 * M * tot, dtype=torch.bfloat16, device=device) if want_bf16 else None
+        offs, o = [], 0
+        for sz in sizes:
+            offs.append(o); o += 2 * M * sz
+        self.offs = offs
+        jobs, blocks = [], 0
+        self.ok = True
+        rbuf = torch.zeros(len(specs) * M * 8, dtype=torch.float32, device=device)
+        parts = []
+        for k, (ei, m, col0, ld) in enumerate(specs):
+            E, Co, Ci, kh, kw = m.weight.shape
+            T = kh * kw
+            W, fw, fb = m.weight, m._routing_fn.fc.weight, m._routing_fn.fc.bias
+            sinks = [_grad_sink(q) for q in (W, fw, fb)]
+            if any(q is None for q in sinks) or sinks[0].shape != W.shape or E > 8 or M > 8:
+                self.ok = False
+                return
+            self.params += [W, fw, fb]
+            nblk = hip.mix_job_blocks(Co, Ci, T)
+            part = torch.empty(8 * nblk * M, dtype=torch.float32, device=device)
+            parts.append(part)
+            j = hip.MixJob()
+            j.W, j.fcw, j.fcb = W.data_ptr(), fw.data_ptr(), fb.data_ptr()
+            j.r = rbuf.data_ptr() + 4 * k * M * 8
+            sz = sizes[ei]
+            for mm in range(M):
+                base = offs[ei] + 2 * mm * sz
+                j.tck[mm] = self.flat.data_ptr() + 4 * (base + col0)
+                j.tkc[mm] = self.flat.data_ptr() + 4 * (base + sz + col0 * Ci)
+                if want_bf16:
+                    j.btck[mm] = self.flat16.data_ptr() + 2 * (base + col0)
+                    j.btkc[mm] = self.flat16.data_ptr() + 2 * (base + sz + col0 * Ci)
+            j.dW, j.dfcw, j.dfcb = (q.data_ptr() for q in sinks)
+            j.part = part.data_ptr()
+            j.tap_tkc = ld * Ci
+            j.E, j.Co, j.Ci, j.T, j.ld_tck, j.ld_dw = E, Co, Ci, T, ld, ld
+            j.block0, j.nblk, j.accumulate = blocks, nblk, 1
+            blocks += nblk
+            jobs.append(j)
+        self.specs, self.njobs, self.blocks = specs, len(jobs), blocks
+        self.keep = (rbuf, parts)
+        self.jobs, self.device = jobs, device
+        self.table = hip.mix_job_table(jobs, device)
+        self.tables = {self.probe.grad.data_ptr(): self.table}       # by gradient arena: the d-step re-points every .grad (trainer.py)
+
+    def table_for_current_sinks(self):
+        """the job table whose gradient sinks are the parameters' CURRENT .grad buffers (TrainStep attaches another optimizer's arena for
+        the discriminator-loss backward); built once per arena"""
+        g = self.probe.grad
+        key = g.data_ptr() if g is not None else None
+        tab = self.tables.get(key)
+        if tab is None:
+            for j, (ei, m, col0, ld) in zip(self.jobs, self.specs):
+                sinks = [_grad_sink(q) for q in (m.weight, m._routing_fn.fc.weight, m._routing_fn.fc.bias)]
+                if any(q is None for q in sinks):
+                    raise RuntimeError('all-layers mixing backward: a parameter lost its gradient buffer between forward and backward')
+                j.dW, j.dfcw, j.dfcb = (q.data_ptr() for q in sinks)
+            tab = self.tables[key] = hip.mix_job_table(self.jobs, self.device)
+        return tab
+
+    def still_valid(self):
+        """the expert weights are views of the optimizer's arena: re-check (cheaply) that they have not moved"""
+        return all(j.W == m.weight.data_ptr() for j, (ei, m, col0, ld) in zip(self.jobs[:4], self.specs[:4])) and self.probe.grad is not None
+
+    def views(self):
+        """fresh tensor objects over the persistent buffers: per entry a tuple (tck_0, tkc_0, ..., tck_{M-1}, tkc_{M-1}) [+ bf16 pairs]"""
+        out, out16 = [], []
+        M = self.M
+        for ei, (T, Ci, Cw) in enumerate(self.shapes):
+            sz = self.sizes[ei]
+            blk = self.flat[self.offs[ei]:self.offs[ei] + 2 * M * sz].view(M, 2, sz)
+            ent = []
+            for mm in range(M):
+                ent += [blk[mm, 0].view(T, Ci, Cw), blk[mm, 1].view(T, Cw, Ci)]
+            out.append(ent)
+            if self.flat16 is not None:
+                b16 = self.flat16[self.offs[ei]:self.offs[ei] + 2 * M * sz].view(M, 2, sz)
+                out16.append([(b16[mm, 0].view(T, Ci, Cw), b16[mm, 1].view(T, Cw, Ci)) for mm in range(M)])
+        return out, out16
+
+
+class _MixAllLayers(Function):
+    """Every CondConv2d layer of the model mixed for all modality labels of the step by ONE launch; the backward takes the gradients
+    of all mixed filters apart again (dW, dfc.weight, dfc.bias added to the optimizer's buffers in-kernel) by one launch pair.
+    Same arithmetic in the same order as _MixExpertsRoutedAll / _MixPairFusedAll per layer."""
+
+    @staticmethod
+    def forward(ctx, holder, types, *params):
+        plan = holder[0]
+        hip.mix_jobs_fwd(plan.table, plan.njobs, plan.blocks, types)
+        ents, ents16 = plan.views()
+        holder.append((ents, ents16))
+        ctx.plan = plan
+        ctx.save_for_backward(types)
+        ctx.set_materialize_grads(False)
+        flat = []
+        for ent in ents:
+            flat += ent
+        ctx.mark_non_differentiable(*flat[1::2])
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        types, = ctx.saved_tensors
+        M = plan.M
+        ptrs = torch.zeros(plan.njobs, 8, dtype=torch.int64)
+        keep = []
+        acc = ptrs.numpy()
+        for k, (ei, m, col0, ld) in enumerate(plan.specs):
+            for mm in range(M):
+                g = grads[2 * (ei * M + mm)]
+                if g is None:
+                    continue
+                if not g.is_contiguous():
+                    g = g.contiguous(); keep.append(g)
+                acc[k, mm] = g.data_ptr() + 4 * col0
+        dev_tab = to_device(ptrs, types.device)
+        hip.mix_jobs_bwd(plan.table_for_current_sinks(), plan.njobs, plan.blocks, dev_tab, types)
+        return (None, None) + (None,) * (len(plan.params))
+
+
+_PREMIX = _os.environ.get('MRDIS_PREMIX', '1') != '0'
+
+
+def premix_all(model, table):
+    """Fill the step's mixed-filter cache for every CondConv2d layer of `model` with one launch (see MixPlan); no-op outside a
+    training step, without gradient sinks, or when disabled (MRDIS_PREMIX=0).  The modules find their filters under the same cache
+    keys their own lazy mixing would have used."""
+    if not _PREMIX or _MIX_CACHE is None or not torch.is_grad_enabled() or not table.is_cuda:
+        return False
+    want16 = _COMPUTE_DTYPE != hip.DT_F32
+    key = (table.shape[0], want16, table.device)
+    plans = model.__dict__.setdefault('_mrdis_mix_plans', {})
+    plan = plans.get(key)
+    if plan is not None and not plan.ok and plan.probe is not None and _grad_sink(plan.probe) is not None:
+        plan = None                                   # built before the optimizer gave the parameters their gradient buffers
+    if plan is None or (plan.ok and not plan.still_valid()):
+        singles, pairs, fused_ids = [], [], set()
+        from . import model as _model
+        for blk in model.modules():
+            if isinstance(blk, _model.SPADEBlockNew) and blk.is_cond and blk.gamma.weight.shape == blk.beta.weight.shape:
+                pairs.append((blk, blk.gamma, blk.beta)); fused_ids.update((id(blk.gamma), id(blk.beta)))
+        for m in model.modules():
+            if isinstance(m, _model.CondConv2d) and id(m) not in fused_ids:
+                singles.append(m)
+        plan = plans[key] = MixPlan(singles, pairs, table.shape[0], want16, table.device)
+    if not plan.ok:
+        return False
+    holder = [plan]
+    outs = _MixAllLayers.apply(holder, table, *plan.params)
+    ents, ents16 = holder[1]
+    M = plan.M
+    tkey = (table.data_ptr(), table._version)
+    pos = 0
+    for ei in range(len(plan.shapes)):
+        allw = outs[pos:pos + 2 * M]; pos += 2 * M
+        if ei < len(plan.singles):
+            _MIX_CACHE[(id(plan.singles[ei]), 'all') + tkey] = allw
+        else:
+            _MIX_CACHE[(id(plan.pairs[ei - len(plan.singles)][0]), 'gb_all') + tkey] = allw
+        if ents16:
+            for mm in range(M):
+                a = allw[2 * mm]
+                btck, btkc = ents16[ei][mm]
+                _MIX_CACHE[('bf16w', id(a))] = (a, btkc, btck)
+    return True
+
+
 # registry of the per-model type tables: storage pointer -> (M, emb) tensor whose rows are the modality labels
 _TYPE_TABLES = {}
 
@@ -204,7 +400,6 @@ def split_batch(x, parts):
 # optimizer owns a persistent gradient buffer for the parameter (`p.grad` is a view of the arena, zeroed
 # per step), the backward kernels add their contribution to it directly and hand autograd `None`.
 # Parameters opt in with `p._mrdis_sink = True` (set by the modules of model.py).
-import os as _os
 _GRAD_SINK = _os.environ.get('MRDIS_GRAD_SINK', '1') != '0'
 
 

@@ -446,6 +446,7 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
     p = config['p']
     dev = inputs.device
     zero = torch.zeros((), device=dev)
+    ops.premix_all(model, model._type_table)          # every CondConv2d layer's experts mixed for all modality labels: one launch
     si_list = model.compute_anatomy_encoding(inputs_list, mask_img)                              # :175
     zi_list, mu_list, lv_list = model.compute_modality_encoding(inputs_list, si_list, phase=phase)     # :176 / :400
     xi_fake_list = model.reconstruct_input_si_zi(si_list, zi_list)                               # :177

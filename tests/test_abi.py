@@ -65,3 +65,12 @@ def test_product_never_imports_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert 'oracle' not in src.replace('# oracle', ''), fn
+
+
+def test_mix_job_struct_matches_library():
+    """the ctypes mirror of csrc `MixJob` (hip.MixJob) has the library's size; job block counts are positive (host-only calls)"""
+    import ctypes
+    import mrdis
+    lib = mrdis.hip.load()
+    assert ctypes.sizeof(mrdis.hip.MixJob) == lib.mrdis_mix_job_bytes() == 368
+    assert 1 <= lib.mrdis_mix_job_blocks(32, 16, 9) <= 128

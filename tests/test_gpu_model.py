@@ -292,6 +292,42 @@ def test_grouped_decoder_matches_per_type_calls(mrdis, mode):
             assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-9, (n, float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
+    """ops.premix_all (every CondConv2d layer's experts mixed for all modality labels by ONE launch, their gradients taken apart by one
+    launch pair: mrdis_mix_jobs_fwd / _bwd over a job table in device memory) against the per-layer launches on three full training
+    steps with the adversarial loss on -- its discriminator-loss backward runs with every .grad re-pointed into another optimizer's
+    arena, so the backward has to pick the job table of the current sinks.  Same kernel bodies, same block-to-element mapping, same
+    summation order: losses and every parameter after the three Adam steps are bit-identical."""
+    B, M, H, W = 2, 4, 64, 64
+    res = {}
+    try:
+        for on in (True, False):
+            mrdis.ops._PREMIX = on
+            cfg = _cfg(mrdis, M, H, W, B, adv=True)
+            cfg['compute_dtype'] = mode
+            torch.manual_seed(10); np.random.seed(10)
+            model = mrdis.build_model(cfg).train()
+            step = mrdis.TrainStep(model, cfg)
+            inputs, mask, mask_img = make_inputs(B, M, H, W, seed=10)
+            losses = []
+            for it in range(3):
+                torch.manual_seed(100 + it)
+                loss, parts, aux = step(cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+                losses.append(loss.detach().clone())
+            if on:
+                plans = model.__dict__.get('_mrdis_mix_plans')
+                assert plans and all(p.ok for p in plans.values()), 'the all-layers launch did not run'
+                assert all(len(p.tables) == 2 for p in plans.values()), 'expected one job table per gradient arena (generator / discriminator step)'
+            res[on] = (losses, torch.cat([p.detach().flatten().float() for p in model.parameters()]))
+    finally:
+        mrdis.ops._PREMIX = True
+        mrdis.ops.set_compute_dtype('f32')
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b), (float(a), float(b))
+    assert torch.equal(res[True][1], res[False][1])
+
+
 def test_gb_spade_fusion_matches_two_step_path(mrdis):
     """A full step with the fused gamma | beta + modulation epilogue on and off (ops.set_gb_spade): same loss and gradients to fp32
     rounding (the fused kernel adds the bias and applies the modulation in registers, the two-step path round-trips through memory:
