@@ -242,19 +242,20 @@ class MixPlan:
         return all(j.W == m.weight.data_ptr() for j, (ei, m, col0, ld) in zip(self.jobs[:4], self.specs[:4])) and self.probe.grad is not None
 
     def views(self):
-        """fresh tensor objects over the persistent buffers: per entry a tuple (tck_0, tkc_0, ..., tck_{M-1}, tkc_{M-1}) [+ bf16 pairs]"""
+        """fresh tensor objects over the persistent buffers: per entry a list [tck_0, tkc_0, ..., tck_{M-1}, tkc_{M-1}] (+ bf16 pairs)"""
         out, out16 = [], []
-        M = self.M
+        M, flat, flat16 = self.M, self.flat, self.flat16
         for ei, (T, Ci, Cw) in enumerate(self.shapes):
-            sz = self.sizes[ei]
-            blk = self.flat[self.offs[ei]:self.offs[ei] + 2 * M * sz].view(M, 2, sz)
+            sz, o = self.sizes[ei], self.offs[ei]
+            s_tck, s_tkc = (Ci * Cw, Cw, 1), (Cw * Ci, Ci, 1)
             ent = []
             for mm in range(M):
-                ent += [blk[mm, 0].view(T, Ci, Cw), blk[mm, 1].view(T, Cw, Ci)]
+                ent.append(flat.as_strided((T, Ci, Cw), s_tck, o + 2 * mm * sz))
+                ent.append(flat.as_strided((T, Cw, Ci), s_tkc, o + 2 * mm * sz + sz))
             out.append(ent)
-            if self.flat16 is not None:
-                b16 = self.flat16[self.offs[ei]:self.offs[ei] + 2 * M * sz].view(M, 2, sz)
-                out16.append([(b16[mm, 0].view(T, Ci, Cw), b16[mm, 1].view(T, Cw, Ci)) for mm in range(M)])
+            if flat16 is not None:
+                out16.append([(flat16.as_strided((T, Ci, Cw), s_tck, o + 2 * mm * sz), flat16.as_strided((T, Cw, Ci), s_tkc, o + 2 * mm * sz + sz))
+                              for mm in range(M)])
         return out, out16
 
 
