@@ -141,12 +141,13 @@ class BatchNorm2d(nn.BatchNorm2d):
             self.weight._mrdis_sink = True         # gradients accumulated in-kernel (ops._grad_sink)
             self.bias._mrdis_sink = True
 
-    def forward(self, x):
+    def forward(self, x, into=None):
+        """into = (buf, c0): training mode writes the result into channels [c0, c0 + C) of `buf` and returns that view"""
         if self.training:
             if self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                        self.eps, self.momentum)
+                                        self.eps, self.momentum, into)
         if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
             return ops.hip.bn_eval_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)   # evaluate()
         # eval-mode BatchNorm under autograd (fine-tuning with frozen statistics) is not on the path: plain torch
@@ -174,9 +175,17 @@ class Conv_BN_Act_New(nn.Module):
             self.bn = BatchNorm2d(out_num_ch)
         self.act = nn.ELU(inplace=True) if activation == 'elu' else nn.Sequential()
 
-    def forward(self, x, inputs_type=None):
+    def forward(self, x, inputs_type=None, skip=False):
+        """skip: this output is also the skip half of the decoder's concatenation (model.py:2192) -- BatchNorm writes it straight into
+        the first C channels of a 2C-channel buffer that the decoder level completes (ops.cat_join): no concatenation copy"""
         x = self.conv(x, inputs_type) if self.is_cond else self.conv(x)
         if self.is_bn:
+            if (skip and self.training and x.is_cuda and ops.cat_elision() and isinstance(self.act, nn.Sequential) and len(self.act) == 0):
+                N, C, H, W = x.shape
+                buf = ops.hip.empty_nhwc(N, 2 * C, H, W, x.device, x.dtype)
+                x = self.bn(x, into=(buf, 0))
+                x._mrdis_catbuf = buf
+                return x
             x = self.bn(x)
         return self.act(x)
 
@@ -201,6 +210,13 @@ class Act_Deconv_BN_Concat_New(nn.Module):
         x_up = self.conv(x_up, inputs_type) if self.is_cond else self.conv(x_up)
         if self.is_last:
             return x_up
+        if self.is_bn and self.training and x_up.is_cuda and ops.cat_elision() and x_down.dtype == x_up.dtype and isinstance(self.act, nn.Sequential) \
+                and x_down.shape[0] == x_up.shape[0] and x_down.shape[2:] == x_up.shape[2:]:
+            Cd, Cu = x_down.shape[1], x_up.shape[1]
+            buf = getattr(x_down, '_mrdis_catbuf', None)
+            if buf is not None and buf.shape[1] == Cd + Cu and buf.dtype == x_up.dtype:
+                x_up = self.bn(x_up, into=(buf, Cd))
+                return ops.cat_join(x_down, x_up, buf)
         if self.is_bn:
             x_up = self.bn(x_up)
         return torch.cat([x_down, x_up], 1)
@@ -222,9 +238,9 @@ class AnatomyEncoderEncNew(nn.Module):
 
     def forward(self, x, inputs_type=None):
         d1 = self.down_1(x, inputs_type, lrelu=True) if self.is_cond else self.down_1(x, lrelu=True)
-        d2 = self.down_2(d1, inputs_type)
-        d3 = self.down_3(d2, inputs_type)
-        d4 = self.down_4(d3, inputs_type)
+        d2 = self.down_2(d1, inputs_type, skip=True)
+        d3 = self.down_3(d2, inputs_type, skip=True)
+        d4 = self.down_4(d3, inputs_type, skip=True)
         d5 = self.down_5(d4, inputs_type)
         return [d1, d2, d3, d4, d5]
 

@@ -721,8 +721,13 @@ class _BatchNormTrain(Function):
     """nn.BatchNorm2d in training mode (model.py:2151, 2191, 2776-2785)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum):
-        y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, into=None):
+        # into = (buf, c0): the result is written into channels [c0, c0 + C) of the NHWC tensor `buf` (one half of a skip-connection
+        # concatenation, model.py:2192) and returned as that view
+        out = None
+        if into is not None:
+            out = into[0][:, into[1]:into[1] + x.shape[1]]
+        y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=out)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
         return y
@@ -733,13 +738,44 @@ class _BatchNormTrain(Function):
         sg, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
         if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
             dx, _, _ = hip.bn_train_bwd(dy, x, gamma, mean, rstd, sink=(sg, sb))
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         dx, dg, db = hip.bn_train_bwd(dy, x, gamma, mean, rstd)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
-    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum)
+def batch_norm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, into=None):
+    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum, into)
+
+
+class _CatJoin(Function):
+    """torch.cat([a, b], 1) of a U-Net skip connection (model.py:2192) without the copy: both halves were WRITTEN into `buf` by their
+    producers (BatchNorm with `into`); the result is `buf`, the adjoint hands each producer its channel slice of the gradient.
+    A half that lives elsewhere (the first encoder level has no BatchNorm) is copied in."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        Ca = a.shape[1]
+        ctx.Ca = Ca
+        if a.data_ptr() != buf.data_ptr():
+            buf[:, :Ca].copy_(a)
+        if b.data_ptr() != buf[:, Ca:].data_ptr():
+            buf[:, Ca:].copy_(b)
+        return buf[:, :]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.Ca], g[:, ctx.Ca:], None
+
+
+def cat_join(a, b, buf):
+    return _CatJoin.apply(a, b, buf)
+
+
+_CAT_ELISION = _os.environ.get('MRDIS_CAT_ELISION', '1') != '0'
+
+
+def cat_elision():
+    return _CAT_ELISION and torch.is_grad_enabled()
 
 
 class _InstNormSpade(Function):
