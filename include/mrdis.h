@@ -101,7 +101,9 @@ size_t mrdis_mix_experts_routed_multi_bwd_workspace(int M, int E, int Co, int Ci
 int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* W, const float* r, const float* types,
                                        int emb, int M, float* dW, float* dfc_w, float* dfc_b,
                                        int accumulate,      /* 1: the three results are ADDED to dW / dfc_w / dfc_b (gradient sinks) */
-                                       int ld_dw,           /* 0 = dense;
+                                       int ld_dw,           /* 0 = dense; otherwise the row pitch of the dw_tck tensors (a column block of a wider gradient) */
+                                       void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream);
+
 
 /* Every CondConv2d layer of the model in one launch (forward) and one launch pair (backward): the per-layer launches above over a
  * table of jobs in device memory.  A job = one layer, or one half of a fused gamma | beta filter pair; its fields (pointers to the
@@ -113,8 +115,7 @@ int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, const float* 
 size_t mrdis_mix_job_bytes(void);
 int mrdis_mix_job_blocks(int Co, int Ci, int T);
 int mrdis_mix_jobs_fwd(const void* jobs, int njobs, int total_blocks, const float* types, int emb, int M, void* stream);
-int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void* dw_table, const float* types, int emb, int M, void* stream); otherwise the row pitch of the dw_tck tensors (a column block of a wider gradient) */
-                                       void* workspace, size_t workspace_bytes, int E, int Co, int Ci, int T, void* stream);
+int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void* dw_table, const float* types, int emb, int M, void* stream);
 
 /* ---- convolution: F.conv2d at model.py:2104 (CondConv2d._conv_forward) and
  * nn.Conv2d of the discriminator model.py:2773-2789 ---------------------------

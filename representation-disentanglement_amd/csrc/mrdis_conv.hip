@@ -2170,6 +2170,9 @@ static size_t wgrad_need(const WgradPlan& pl) {
 
 size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
 size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);     // mrdis_wgrad_s2.hip: Cin <= 7 stride-2 first layers
+size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co);              // mrdis_wgrad_s2.hip: the 4 -> C si_layers
+int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co);                    // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
 int mrdis_run_pw_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        long long npix, int Ci, int Co, int accumulate_bias, hipStream_t s);
@@ -2208,6 +2211,8 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
         if (nw > need) need = nw;
         const size_t n16 = mrdis_wgrad16_workspace(N, H, W, Ci, Co);
         if (n16 > need) need = n16;
+        const size_t n4 = mrdis_wgrad_c4_workspace(N, H, W, Ci, Co);
+        if (n4 > need) need = n4;
     }
     { const size_t n2 = mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (n2 > need) need = n2; }
     if (kh == 1 && kw == 1 && stride == 1 && pad == 0) { const size_t n1 = mrdis_pw_wgrad_workspace((long long)N * H * W, Ci, Co); if (n1 > need) need = n1; }
@@ -2252,6 +2257,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
         rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
                               accumulate_bias, dtype, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED || dtype == MRDIS_DT_BF16) return rc;          // bf16 views never reach the fp32 kernels
+    }
+    if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4) {
+        rc = mrdis_run_wgrad_c4(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {
         rc = mrdis_run_wgrad16(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);

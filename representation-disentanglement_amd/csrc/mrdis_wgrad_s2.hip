@@ -357,6 +357,163 @@ __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(const ConvS2Params p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- 4 -> C, stride 1
+// Weight (+ bias) gradient of the SPADE `si_layers` (4 -> 32 / 64 / 128, 3x3 s1 p1, model.py:2436; 48 calls per step on the 256^2 ..
+// 64^2 maps): the same GEMM  dW[m = (tap, ci)][co] = sum_pixels xpatch[m][pixel] dy[pixel][co]  with 36 rows (three 16-row tiles) and
+// NT = C / 16 cout tiles.  An output row needs input rows oy - 1 .. oy + 1: a four-slot ring in LDS (row iy lives in slot (iy + 1) & 3,
+// memory image [pixel + 1][4 ch], one new row per output row), dy rows [pixel][C + 16]; two register sets in flight.
+struct WgradC4Params {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, ldx, Co, lddy;
+    int rowp, segs, R, splits;
+    unsigned x_bytes, dy_bytes;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
+    constexpr int MT = 3, DYP = 16 * NT + 16, CO = 16 * NT;
+    constexpr int YI = 8;                             // dy float4 items per thread and row: W * C / 1024 <= 8 (host)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                 // [4][rowp]
+    float* dys = smem + 4 * p.rowp;                   // [W][DYP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = split / p.segs, oy0 = (split - n * p.segs) * p.R, oy1 = min(oy0 + p.R, p.H);
+    const int W = p.W, WQ = W >> 6;                   // host: W % 64 == 0, W <= 256
+
+    int acol[MT], aty[MT]; bool aok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l16;
+        aok[mt] = m < 36;
+        const int tap = aok[mt] ? m >> 2 : 0, ci = m & 3;
+        aty[mt] = tap / 3;
+        acol[mt] = (tap % 3) * 4 + ci + 4 * kq;
+    }
+    const int boff = kq * DYP + l16;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    for (int i = tid; i < 4 * p.rowp; i += 256) xs[i] = 0.f;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+    // staging: x row = W float4 (thread tid < W takes pixel tid); dy row = W * C / 4 float4: item = (pixel, quad), 4 NT quads per pixel
+    u32x4 xr[2], yr[2][YI];
+    auto load_set = [&](auto S_, int iy, int oy) {    // input row iy and dy row oy; nothing to fetch -> offsets out of range -> zeros
+        constexpr int S = decltype(S_)::value;
+        const bool xok = tid < W && iy <= oy1 && (unsigned)iy < (unsigned)p.H;
+        xr[S] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xok ? 4u * (unsigned)(((n * p.H + iy) * W + tid) * p.ldx) : S2_OOB), 0, 0);
+        const bool on = oy >= 0 && oy < oy1;
+        const unsigned ybase = 4u * (unsigned)((n * p.H + oy) * W * p.lddy);
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            const int idx = tid + 256 * j;            // valid while < W * 4 NT = 256 WQ NT
+            const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
+            yr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && j < WQ * NT) ? ybase + 4u * (unsigned)(pix * p.lddy + 4 * q) : S2_OOB), 0, 0);
+        }
+    };
+    auto store_set = [&](auto S_, int iy, bool with_dy) {
+        constexpr int S = decltype(S_)::value;
+        if (tid < W) *reinterpret_cast<u32x4*>(xs + ((iy + 1) & 3) * p.rowp + (tid + 1) * 4) = xr[S];
+        if (with_dy) {
+#pragma unroll
+            for (int j = 0; j < YI; ++j) {
+                const int idx = tid + 256 * j;
+                const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
+                if (j < WQ * NT) *reinterpret_cast<u32x4*>(dys + pix * DYP + 4 * q) = yr[S][j];
+            }
+        }
+    };
+    const int nsteps = W >> 4;                        // a wave takes every fourth group of 4 pixels
+    auto compute = [&](int oy) {
+        int ao[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ao[mt] = ((oy + aty[mt]) & 3) * p.rowp + acol[mt];     // input row oy - 1 + ty -> slot (oy + ty) & 3
+        float bvn[NT], avn[MT];
+        auto read_ops = [&](int i) {
+            const int ox0 = 4 * (wave + 4 * i);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bvn[nt] = dys[ox0 * DYP + boff + 16 * nt];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) avn[mt] = xs[ao[mt] + 4 * ox0];
+        };
+        read_ops(0);
+        for (int i = 0; i < nsteps; ++i) {
+            float bv[NT], av[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bv[nt] = bvn[nt]; bsum[nt] += bv[nt]; }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aok[mt] ? avn[mt] : 0.f;
+            read_ops(i + 1 < nsteps ? i + 1 : i);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    auto step = [&](auto S_, int oy) {                // set S holds (input row oy + 2, dy row oy + 1)
+        compute(oy);
+        __syncthreads();
+        store_set(S_, oy + 2, true);
+        load_set(S_, oy + 4, oy + 3);
+        __syncthreads();
+    };
+    // prologue: rows oy0 - 1, oy0, oy0 + 1 and dy row oy0 in LDS; sets hold (oy0 + 2, dy oy0 + 1) and (oy0 + 3, dy oy0 + 2)
+    load_set(IC<0>{}, oy0 - 1, -1);
+    load_set(IC<1>{}, oy0, oy0);
+    __syncthreads();                                  // the zero fill
+    store_set(IC<0>{}, oy0 - 1, false);
+    store_set(IC<1>{}, oy0, true);
+    load_set(IC<0>{}, oy0 + 1, -1);
+    __syncthreads();
+    store_set(IC<0>{}, oy0 + 1, false);
+    load_set(IC<0>{}, oy0 + 2, oy0 + 1);
+    load_set(IC<1>{}, oy0 + 3, oy0 + 2);
+    __syncthreads();
+    for (int oy = oy0; oy < oy1; oy += 2) {           // an odd row count runs one more row on an all-zero dy row
+        step(IC<0>{}, oy);
+        step(IC<1>{}, oy + 1);
+    }
+
+    float* red = smem;
+    float* out = p.slab + (long long)split * 36 * CO;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NT + nt) * 256 + (4 * kq + r) * 16 + l16] = acc[mt][nt][r];
+        __syncthreads();
+        for (int e = tid; e < NT * 256; e += 256) {
+            const int nt = e >> 8, rr = (e >> 4) & 15, cc = e & 15, m = mt * 16 + rr;
+            const float v = (red[e] + red[NT * 256 + e]) + (red[2 * NT * 256 + e] + red[3 * NT * 256 + e]);
+            if (m < 36) out[m * CO + nt * 16 + cc] = v;
+        }
+        __syncthreads();
+    }
+    if (p.bias_slab != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float b = bsum[nt];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (kq == 0) red[(wave * NT + nt) * 16 + l16] = b;
+        }
+        __syncthreads();
+        if (tid < CO) {
+            const int nt = tid >> 4, cc = tid & 15;
+            p.bias_slab[(long long)split * CO + tid] = (red[nt * 16 + cc] + red[(NT + nt) * 16 + cc]) + (red[(2 * NT + nt) * 16 + cc] + red[(3 * NT + nt) * 16 + cc]);
+        }
+    }
+}
+
 // dw[i] = sum_k slab[k][i] (i < total), dbias[co] (+)= sum_k bslab[k][co]: the fixed-order slab reduction shared with mrdis_pointwise.hip
 int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
                              hipStream_t s) {
@@ -439,4 +596,57 @@ int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const flo
     else hipLaunchKernelGGL((conv_s2_fwd_kernel<3, 1>), dim3(q.splits), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
+}
+
+static bool plan_wgrad_c4(WgradC4Params& p, int N, int H, int W, int Ci, int Co) {
+    if (Ci != 4 || (Co != 32 && Co != 64 && Co != 128) || (W != 64 && W != 128 && W != 256)) return false;
+    if ((long long)W * Co > 256 * 32 || (long long)N * H * W < 100000 || mrdis_opt(MRDIS_OPT_NOW16)) return false;    // a dy row fits the staging registers
+    p = WgradC4Params{};
+    p.N = N; p.H = H; p.W = W; p.Co = Co;
+    int rowp = (W + 2) * 4;
+    while ((rowp & 63) != 12) ++rowp;                  // the (tap, ci) sequence of a tap row (12 words) runs on into the next ring slot bank-wise
+    p.rowp = rowp;
+    int segs = mrdis_cdiv(512, N);
+    if (segs > H / 2) segs = H / 2 > 0 ? H / 2 : 1;
+    p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
+    p.splits = N * p.segs;
+    return true;
+}
+
+size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co) {
+    WgradC4Params p;
+    if (!plan_wgrad_c4(p, N, H, W, Ci, Co)) return 0;
+    return sizeof(float) * ((size_t)p.splits * 36 * Co + (size_t)p.splits * Co) + 256;
+}
+
+// weight gradient of a 4 -> C 3x3 s1 p1 layer; MRDIS_EUNSUPPORTED outside what the kernel covers
+int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+    WgradC4Params p;
+    if (!plan_wgrad_c4(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    if (ldx % 4 != 0 || lddy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + 4), yb = 4LL * (((long long)N * H * W - 1) * lddy + Co);
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wgrad_c4_workspace(N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy; p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + (size_t)p.splits * 36 * Co : nullptr;
+    const int NT = Co / 16;
+    size_t lds = sizeof(float) * ((size_t)4 * p.rowp + (size_t)W * (Co + 16));
+    const size_t red = sizeof(float) * (size_t)(4 * NT * 256);
+    if (lds < red) lds = red;
+    if (lds > 72 * 1024) return MRDIS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {          // > 64 KB of dynamic LDS needs the opt-in (4 -> 32 at W = 256: 65.7 KB)
+        if (hipFuncSetAttribute((const void*)wgrad_c4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+            return MRDIS_EUNSUPPORTED;
+        attr_set = true;
+    }
+    if (NT == 2) hipLaunchKernelGGL((wgrad_c4_kernel<2>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (NT == 4) hipLaunchKernelGGL((wgrad_c4_kernel<4>), dim3(p.splits), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((wgrad_c4_kernel<8>), dim3(p.splits), dim3(256), lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
 }

@@ -525,6 +525,31 @@ def test_conv3x3_4_couts_gemm_gather(mrdis, case):
     close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs co4'); close(ref_dx, dx.cpu(), rtol=2e-5, what='tile kernel vs co4 dgrad')
 
 
+@pytest.mark.parametrize('case', [(3, 32, 150, 256), (5, 64, 100, 128), (9, 128, 64, 64), (2, 32, 256, 256), (30, 128, 63, 64)], ids=str)
+def test_wgrad_si_layers_4_to_c(mrdis, case):
+    """wgrad_c4_kernel (mrdis_wgrad_s2.hip): weight + bias gradient of the 4 -> 32 / 64 / 128 `si_layers` (3x3 s1 p1) through a
+    four-slot ring of input rows, against torch; row counts that do not divide into the workgroups' runs; bias added into a sink;
+    option debug_now16 = 1 (the packed-FMA split-K kernel) must agree."""
+    N, Co, H, W = case
+    hip = mrdis.hip
+    x = rnd((N, 4, H, W), 91)
+    w = rnd((Co, 4, 3, 3), 92, 0.1).requires_grad_(True); b = rnd((Co,), 93, 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, 1)
+    gy = rnd(tuple(y.shape), 94); y.backward(gy)
+    dw, db = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+    close(dw, to_tck(w.grad), rtol=3e-4, what='wgrad c4'); close(db, b.grad, rtol=3e-4, what='dbias c4')
+    sink = torch.full((Co,), -1.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True, bias_sink=sink)
+    assert none is None and torch.equal(dw2, dw)
+    close(sink, b.grad - 1.0, rtol=3e-4, what='dbias sink')
+    hip.set_option('debug_now16', 1)
+    try:
+        dw3, db3 = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+    finally:
+        hip.set_option('debug_now16', 0)
+    close(dw3, dw.cpu(), rtol=3e-4, what='split-K vs c4'); close(db3, db.cpu(), rtol=3e-4, what='split-K vs c4 bias')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
