@@ -484,17 +484,21 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
     H, W = in_hw
     assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
     if out is None:
-        dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype)
+        dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype); ldo = Ci
     else:
-        dx, ldo = nhwc(out)
-        assert dx.data_ptr() == out.data_ptr() and ldo == Ci and tuple(out.shape) == (N, Ci, H, W) and out.dtype == dy.dtype
+        dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
+        assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W) and out.dtype == dy.dtype
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
-    rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), Ci, N, H, W, Ci, Co, kh, kw, stride, pad, dt, _stream())
+    rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, dt, _stream())
     if rc == -2 and dt == DT_BF16:
         # a geometry outside the bf16 kernels (e.g. a reduction axis that is not a multiple of 16): fp32 kernel between two view casts
-        return cast_view(conv2d_bwd_data(cast_view(dy, torch.float32), w_tkc, in_hw, kh, kw, stride, pad), torch.bfloat16)
+        res = cast_view(conv2d_bwd_data(cast_view(dy, torch.float32), w_tkc, in_hw, kh, kw, stride, pad), torch.bfloat16)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
     _chk(rc, 'conv2d_bwd_data')
     return dx
 
@@ -628,6 +632,19 @@ def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None):
     return mix, gamma, mean, rstd
 
 
+def gb_slot(t):
+    """the (N, 2C, H, W) NHWC buffer whose channels [C, 2C) are exactly the NCHW-shaped tensor `t`, or None"""
+    base = t._base
+    if base is None or base.dim() != 4 or t.dim() != 4:
+        return None
+    N, C, H, W = t.shape
+    if tuple(base.shape) != (N, 2 * C, H, W) or base.dtype != t.dtype or not base.is_contiguous(memory_format=torch.channels_last):
+        return None
+    if t.stride() != (H * W * 2 * C, 1, W * 2 * C, 2 * C) or t.storage_offset() != base.storage_offset() + C:
+        return None
+    return base
+
+
 def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False):
     """returns (dz, dgamma); dbeta == dout and is not materialised.
     fused_gb=True: returns (dz, dgb) with dgb (N,2C,H,W) = [dgamma | dout] in one buffer (the gradient of
@@ -640,6 +657,13 @@ def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False):
     ws = _ws(nb, z.device)
     dt = _dt(dout, z, gamma)
     if fused_gb:
+        base = gb_slot(dout)
+        if base is not None:
+            # dout already IS channels [C, 2C) of a 2C-channel buffer (its producer wrote it there, ops._GroupedConvFn): only dgamma is
+            # written, into the first half -- one pass over the tensor less
+            _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
+                                              base.data_ptr(), 2 * C, None, 0, _ptr(ws), nb, N, H * W, C, dt, _stream()), 'instnorm_spade_bwd')
+            return dz, base
         dgb = empty_nhwc(N, 2 * C, H, W, z.device, z.dtype)
         _chk(lib.mrdis_instnorm_spade_bwd(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dz), C,
                                           dgb.data_ptr(), 2 * C, dgb.data_ptr() + dgb.element_size() * C, 2 * C, _ptr(ws), nb, N, H * W, C, dt, _stream()),

@@ -574,6 +574,7 @@ class _GroupedConvFn(Function):
             use_tkc.append(tkc); wbs.append(wb_b)
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype)
+        ctx.dx_in_gb = bool(getattr(x, '_mrdis_want_dgb', False)) and _GB_INPLACE
         ctx.wbs = wbs
         ctx.bias_param = bias
         ctx.save_for_backward(xin, y if lrelu else None, *use_tkc)
@@ -593,7 +594,14 @@ class _GroupedConvFn(Function):
             dy = hip.lrelu_bwd(dy, y, 0.2)
         H, W = xin.shape[2], xin.shape[3]
         need_x = ctx.needs_input_grad[0]
-        dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, dy.dtype) if need_x else None
+        dxb = None
+        if need_x:
+            if ctx.dx_in_gb and not share_x and Ci_p == Ci and dy.dtype == x_dtype:
+                # the input is the modulated map of a fused SPADE node (ops._GbSpadeFn): its gradient is also the beta half of that node's
+                # [dgamma | dbeta] buffer -- write it there, the node then fills in the other half (hip.gb_slot)
+                dxb = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, dy.dtype)[:, Ci:]
+            else:
+                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, dy.dtype)
         sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None
         dws, db_total = [], None
         for g in range(G):
@@ -692,6 +700,7 @@ class _GbSpadeFn(Function):
 
 
 _GB_SPADE = _os.environ.get('MRDIS_GB_SPADE', '1') != '0'
+_GB_INPLACE = _os.environ.get('MRDIS_GB_INPLACE', '1') != '0'      # d(mix) written straight into the beta half of [dgamma | dbeta]
 
 
 def set_gb_spade(enabled):
@@ -704,7 +713,9 @@ def gb_spade(si_out, z, filters, bias, eps):
     flat = []
     for a, b in filters:
         flat += [a, b]
-    return _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, *flat)
+    mix = _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, *flat)
+    mix._mrdis_want_dgb = True                       # a grouped convolution that reads `mix` writes d(mix) into the node's [dgamma | dbeta] buffer
+    return mix
 
 
 def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False):

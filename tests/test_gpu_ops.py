@@ -550,6 +550,27 @@ def test_wgrad_si_layers_4_to_c(mrdis, case):
     close(dw3, dw.cpu(), rtol=3e-4, what='split-K vs c4'); close(db3, db.cpu(), rtol=3e-4, what='split-K vs c4 bias')
 
 
+def test_spade_bwd_beta_half_in_place(mrdis):
+    """instnorm_spade_bwd(fused_gb=True) when the incoming gradient already is channels [C, 2C) of a 2C-channel NHWC buffer (the
+    producing data-gradient kernel wrote it there, ops._GroupedConvFn): only dgamma is written, the buffer is returned as [dgamma | dbeta];
+    same dz and same buffer contents as the copying path; the data gradient itself lands in the slice (conv2d_bwd_data out = slice)."""
+    hip = mrdis.hip
+    N, C, H, W = 3, 32, 40, 56
+    z = cl(rnd((N, C, H, W), 95)); gamma = cl(rnd((N, C, H, W), 96, 0.3))
+    dy = cl(rnd((N, 16, H, W), 97)); w2 = rnd((16, C, 3, 3), 98, 0.1)
+    mean = z.mean(dim=(2, 3)).reshape(-1).contiguous(); rstd = (1.0 / (z.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt()).reshape(-1).contiguous()
+    buf = hip.empty_nhwc(N, 2 * C, H, W, dev()); buf.fill_(9.0)
+    dmix_view = buf[:, C:]
+    assert hip.gb_slot(dmix_view) is buf and hip.gb_slot(buf[:, :C]) is None
+    hip.conv2d_bwd_data(dy, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1, out=dmix_view)
+    dmix = hip.conv2d_bwd_data(dy, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
+    assert torch.equal(dmix_view, dmix) and bool((buf[:, :C] == 9.0).all())
+    dz_ref, dgb_ref = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True)
+    dz, dgb = hip.instnorm_spade_bwd(dmix_view, z, gamma, mean, rstd, fused_gb=True)
+    assert dgb is buf
+    assert torch.equal(dz, dz_ref) and torch.equal(dgb, dgb_ref)
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
