@@ -115,7 +115,7 @@ def roofline_conv(mrdis, dev, iters=24, extras=True):
         try:
             rec = json.load(open(pmc))
             traffic = rec.get('hbm_bytes_per_launch')
-            traffic_src = f"profiles/northstar_conv_pmc.json ({rec.get('tag', 'r01j')}, commit {rec.get('commit', 'n/a')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run"
+            traffic_src = f"profiles/northstar_conv_pmc.json ({rec.get('tag', 'untagged')}, commit {rec.get('commit', 'n/a')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run"
         except Exception:
             traffic = None
     gbs = lambda nbytes, us: round(nbytes / (us * 1e-6) / 1e9, 1)
