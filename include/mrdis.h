@@ -52,7 +52,11 @@ int mrdis_version(void);
  *   "wino_pipe" (MRDIS_WINO_PIPE, default 1): 1 = the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip: forward / data
  *           gradient for Cout > 32, weight gradient for Ci, Co multiples of 64), 0 = the phase-by-phase kernels everywhere
  *           (same arithmetic; results agree to 1e-5);
- *   "debug_*": kernel-selection overrides used by tools/ (see csrc/mrdis_elem.hip OPT_DEFS).
+ *   "debug_now16" (MRDIS_DEBUG_NOW16, default 0): 1 = the dedicated narrow-layer kernels off -- Cout <= 16 weight gradient
+ *           (mrdis_wgrad16.hip), stride-2 first layers and 4 -> C weight gradient (mrdis_wgrad_s2.hip), 1x1 head (mrdis_pointwise.hip),
+ *           16-cout and 4-cout 3x3 layers (mrdis_c16.hip, mrdis_co4.hip): the generic tile kernels run those layers (tests and
+ *           tools/ use it for A/B; results agree to fp32 rounding);
+ *   other "debug_*": kernel-selection overrides used by tools/ (see csrc/mrdis_elem.hip OPT_DEFS).
  * set: 0 or MRDIS_EINVAL (unknown name); get: the value, or MRDIS_EINVAL for an unknown name.  Not synchronised with launches
  * in flight on other threads. */
 int mrdis_set_option(const char* name, long long value);
