@@ -2432,7 +2432,8 @@ struct MixCPtrs { const float* p[MIX_MAX_TYPES]; };
 __device__ __forceinline__ void mix_fwd_body(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
                                              const float* __restrict__ types, int emb, float* __restrict__ r_out,
                                              float* __restrict__ w_tck, float* __restrict__ w_tkc, __bf16* __restrict__ b_tck, __bf16* __restrict__ b_tkc,
-                                             int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc, int m, int bx, int gx) {
+                                             int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc, int m, int bx, int gx, int cip) {
+    // cip: channel pitch of the outputs (Ci, or more when the filter is written into a zero-padded [T][cip][.] / [T][.][cip] buffer)
     // ld_tck: row pitch of the [T][Ci][.] outputs, tap_tkc: tap pitch of the [T][.][Ci] outputs -- Co and Co * Ci for a filter of its
     // own, 2 Co and 2 Co * Ci when the pointers address one half of a fused gamma | beta filter
     const float* t = types + m * emb;
@@ -2451,7 +2452,7 @@ __device__ __forceinline__ void mix_fwd_body(const float* __restrict__ W, const 
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
         float s_ = 0.f;
         for (int e = 0; e < E; ++e) s_ += rr[e] * W[(long long)e * total + i];      // same order as the single-type kernel
-        const long long o_tck = ((long long)tt * Ci + ci) * ld_tck + co, o_tkc = (long long)tt * tap_tkc + (long long)co * Ci + ci;
+        const long long o_tck = ((long long)tt * cip + ci) * ld_tck + co, o_tkc = (long long)tt * tap_tkc + (long long)co * cip + ci;
         w_tck[o_tck] = s_;
         w_tkc[o_tkc] = s_;
         if (b_tck != nullptr) {                              // the bf16 MFMA operands of compute_dtype bf16 (round to nearest even, as mrdis_cast_bf16)
@@ -2465,13 +2466,13 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
                                             int E, int Co, int Ci, int T, int ld_tck, long long tap_tkc) {
     const int m = blockIdx.y;
     mix_fwd_body(W, fcw, fcb, types, emb, r_out, out.tck[m], out.tkc[m], out.btck[m], out.btkc[m], E, Co, Ci, T, ld_tck, tap_tkc, m,
-                 (int)blockIdx.x, (int)gridDim.x);
+                 (int)blockIdx.x, (int)gridDim.x, Ci);
 }
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
 // dW[e] = sum_m r[m][e] dw_m (types in order m = 0..M-1; a type without gradient contributes nothing).
 __device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __restrict__ W, const float* __restrict__ r,
                                              float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw,
-                                             int m, int bx, int gx) {
+                                             int m, int bx, int gx, int cip) {
     __shared__ double red[8][4];
     const long long total = (long long)Co * Ci * T;
     const float* __restrict__ g_m = dw.p[m];
@@ -2483,7 +2484,7 @@ __device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __
         const int t = (int)(i % T);
         const long long q = i / T;
         const int ci = (int)(q % Ci), co = (int)(q / Ci);
-        const long long idx = ((long long)t * Ci + ci) * ld_dw + co;          // ld_dw: row pitch of the gradient tensors (Co, or 2 Co for a fused half)
+        const long long idx = ((long long)t * cip + ci) * ld_dw + co;         // ld_dw: row pitch of the gradient tensors (Co, or 2 Co for a fused half); cip: their channel pitch
         if (g_m != nullptr) {
             const float g = g_m[idx];
 #pragma unroll
@@ -2520,7 +2521,7 @@ __device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __
 }
 __global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
                                      float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw) {
-    mix_bwd_body(dw, W, r, dW, part, M, E, Co, Ci, T, accumulate, ld_dw, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    mix_bwd_body(dw, W, r, dW, part, M, E, Co, Ci, T, accumulate, ld_dw, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, Ci);
 }
 // one block of 64 threads: thread (m, e) sums its partials, dz = dr r (1 - r); then e-threads sum over types
 __device__ __forceinline__ void mix_bwd_final_body(const float* __restrict__ part, int nblk, int M, int E, const float* __restrict__ r,
@@ -2560,7 +2561,7 @@ struct MixJob {
     float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* btck[MIX_MAX_TYPES]; __bf16* btkc[MIX_MAX_TYPES];
     float* dW; float* dfcw; float* dfcb; float* part;                              // gradient sinks, partial-sum workspace [M][nblk][8]
     long long tap_tkc;
-    int E, Co, Ci, T, ld_tck, ld_dw, block0, nblk, accumulate, pad_;
+    int E, Co, Ci, T, ld_tck, ld_dw, block0, nblk, accumulate, ci_pitch;          // ci_pitch >= Ci: channel pitch of outputs and gradients
 };
 __device__ __forceinline__ const MixJob* mix_find_job(const MixJob* __restrict__ jobs, int njobs, int bx) {
     int lo = 0, hi = njobs - 1;                       // last job with block0 <= bx
@@ -2571,7 +2572,7 @@ __global__ void mix_jobs_fwd_kernel(const MixJob* __restrict__ jobs, int njobs, 
     const MixJob* j = mix_find_job(jobs, njobs, (int)blockIdx.x);
     const int m = blockIdx.y;
     mix_fwd_body(j->W, j->fcw, j->fcb, types, emb, j->r, j->tck[m], j->tkc[m], j->btck[m], j->btkc[m], j->E, j->Co, j->Ci, j->T, j->ld_tck,
-                 j->tap_tkc, m, (int)blockIdx.x - j->block0, j->nblk);
+                 j->tap_tkc, m, (int)blockIdx.x - j->block0, j->nblk, j->ci_pitch);
 }
 // dw: [njobs][MIX_MAX_TYPES] gradient pointers of this step (null: that label's filter got no gradient)
 __global__ void mix_jobs_bwd_kernel(const MixJob* __restrict__ jobs, int njobs, const float* const* __restrict__ dw, int M) {
@@ -2581,7 +2582,7 @@ __global__ void mix_jobs_bwd_kernel(const MixJob* __restrict__ jobs, int njobs, 
 #pragma unroll
     for (int mm = 0; mm < MIX_MAX_TYPES; ++mm) g.p[mm] = mm < M ? gp[mm] : nullptr;
     mix_bwd_body(g, j->W, j->r, j->dW, j->part, M, j->E, j->Co, j->Ci, j->T, j->accumulate, j->ld_dw, (int)blockIdx.y,
-                 (int)blockIdx.x - j->block0, j->nblk);
+                 (int)blockIdx.x - j->block0, j->nblk, j->ci_pitch);
 }
 __global__ void mix_jobs_bwd_final_kernel(const MixJob* __restrict__ jobs, const float* __restrict__ types, int emb, int M) {
     const MixJob* j = jobs + blockIdx.x;

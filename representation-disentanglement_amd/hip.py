@@ -269,7 +269,7 @@ class MixJob(_c.Structure):
                 ('dW', _c.c_void_p), ('dfcw', _c.c_void_p), ('dfcb', _c.c_void_p), ('part', _c.c_void_p),
                 ('tap_tkc', _c.c_longlong),
                 ('E', _c.c_int), ('Co', _c.c_int), ('Ci', _c.c_int), ('T', _c.c_int), ('ld_tck', _c.c_int), ('ld_dw', _c.c_int),
-                ('block0', _c.c_int), ('nblk', _c.c_int), ('accumulate', _c.c_int), ('pad_', _c.c_int)]
+                ('block0', _c.c_int), ('nblk', _c.c_int), ('accumulate', _c.c_int), ('ci_pitch', _c.c_int)]
 
 
 def mix_job_table(jobs, device):

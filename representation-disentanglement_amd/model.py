@@ -101,7 +101,7 @@ class CondConv2d(nn.Module):
                                                    ops.compute_dtype())        # 0 exact fp32 | 1 bf16 MFMA operands
             # inside a training step the mixed kernels of all modality labels are cached and shared by every call
             w_tck, w_tkc = self.mixed_uniform(inputs_type)
-            return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu)
+            return ops.conv2d(inputs, w_tck, w_tkc, self.bias, kh, kw, self.stride[0], self.padding[0], lrelu, co=self.out_channels)
         outs = []                                    # per-sample path, model.py:2114-2117
         for i in range(B):
             w_tck, w_tkc = self._mixed(inputs_type[i:i + 1])
@@ -381,10 +381,11 @@ class SPADEBlockNew(nn.Module):
         si = ops.step_cache(('bil', id(src), size), lambda: (src, ops.bilinear(src, size, False)))[1]
         kh, kw = self.gamma.kernel_size
         pad = self.gamma.padding[0]
-        si_out = ops.conv2d_grouped(si, [self.si_layers.mixed_uniform(t) for t in types], self.si_layers.bias, kh, kw, pad, share_x=True)
+        si_out = ops.conv2d_grouped(si, [self.si_layers.mixed_uniform(t) for t in types], self.si_layers.bias, kh, kw, pad, share_x=True,
+                                    co=self.si_layers.out_channels)
         fused = [self._fused_gb(t) for t in types]
         mix = ops.gb_spade(si_out, z_cat, [f[0] for f in fused], fused[0][1], self.zi_layers.eps)     # :2440-2446, one node
-        return ops.conv2d_grouped(mix, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, pad)
+        return ops.conv2d_grouped(mix, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, pad, co=self.out.out_channels)
 
 
 def _up2(x):
@@ -445,7 +446,7 @@ class SPADENewNotShared(nn.Module):
         x = self.sp5.forward_grouped(si, _up2(x), types)
         x = self.sp6.forward_grouped(si, _up2(x), types)
         kh, kw = self.out.kernel_size
-        x = ops.conv2d_grouped(x, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, self.out.padding[0])
+        x = ops.conv2d_grouped(x, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, self.out.padding[0], co=self.out.out_channels)
         return self.out_act(x)
 
     def grouped_ok(self):

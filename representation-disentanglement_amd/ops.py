@@ -158,15 +158,22 @@ class MixPlan:
     dead once its backward has run, so every step writes the same storage and the job table is built once -- the routing values,
     the partial-sum workspace and the job table in device memory.  None if a parameter has no in-kernel gradient sink."""
 
-    def __init__(self, singles, pairs, M, want_bf16, device):
+    def __init__(self, singles, pairs, M, want_bf16, device, pad16=False):
         self.singles, self.pairs, self.M, self.want_bf16 = singles, pairs, M, want_bf16
         self.params = []
         self.probe = singles[0].weight if singles else (pairs[0][1].weight if pairs else None)
         shapes = []                                    # per entry: (T, Ci, Cw) with Cw = Co or 2 C
         specs = []                                     # per job: (entry index, conv module, col0, ld)
+        self.padded = {}                               # id(module) -> (Ci, Co) true channel counts of a layer whose filters are zero-padded
         for m in singles:
             E, Co, Ci, kh, kw = m.weight.shape
-            shapes.append((kh * kw, Ci, Co)); specs.append((len(shapes) - 1, m, 0, Co))
+            Ci_p, Co_p = Ci, Co
+            if pad16 and m.stride[0] == 1 and (Ci < 16 or Co < 16) and hip.bconv_eligible(max(Ci, 16), max(Co, 16)):
+                # bf16 storage: the narrow side of the 4 -> C si_layers and of the 64 -> 4 / 16 -> 7 heads is zero-padded to 16 so that the
+                # bf16 MFMA kernels take the layer (ops.conv2d); the mixing launch writes the filter straight into the padded layout
+                Ci_p, Co_p = max(Ci, 16), max(Co, 16)
+                self.padded[id(m)] = (Ci, Co)
+            shapes.append((kh * kw, Ci_p, Co_p)); specs.append((len(shapes) - 1, m, 0, Co_p))
         for blk, g, b in pairs:
             E, C, Ci, kh, kw = g.weight.shape
             shapes.append((kh * kw, Ci, 2 * C))
@@ -176,8 +183,8 @@ class MixPlan:
         self.sizes = sizes
         tot = sum(sizes)
         # [entry][label] blocks: tck then tkc
-        self.flat = torch.empty(2 * M * tot, dtype=torch.float32, device=device)
-        self.flat16 = torch.empty(2 * M * tot, dtype=torch.bfloat16, device=device) if want_bf16 else None
+        self.flat = torch.zeros(2 * M * tot, dtype=torch.float32, device=device)         # zero once: the padding of padded filters is never written
+        self.flat16 = torch.zeros(2 * M * tot, dtype=torch.bfloat16, device=device) if want_bf16 else None
         offs, o = [], 0
         for sz in sizes:
             offs.append(o); o += 2 * M * sz
@@ -211,9 +218,10 @@ class MixPlan:
                     j.btkc[mm] = self.flat16.data_ptr() + 2 * (base + sz + col0 * Ci)
             j.dW, j.dfcw, j.dfcb = (q.data_ptr() for q in sinks)
             j.part = part.data_ptr()
-            j.tap_tkc = ld * Ci
+            cip = self.shapes[ei][1]                   # channel pitch of this entry's tensors (Ci, or 16 for a padded narrow layer)
+            j.tap_tkc = ld * cip
             j.E, j.Co, j.Ci, j.T, j.ld_tck, j.ld_dw = E, Co, Ci, T, ld, ld
-            j.block0, j.nblk, j.accumulate = blocks, nblk, 1
+            j.block0, j.nblk, j.accumulate, j.ci_pitch = blocks, nblk, 1, cip
             blocks += nblk
             jobs.append(j)
         self.specs, self.njobs, self.blocks = specs, len(jobs), blocks
@@ -310,7 +318,7 @@ def premix_all(model, table):
     if not _PREMIX or _MIX_CACHE is None or not torch.is_grad_enabled() or not table.is_cuda:
         return False
     want16 = _COMPUTE_DTYPE != hip.DT_F32
-    key = (table.shape[0], want16, table.device)
+    key = (table.shape[0], _COMPUTE_DTYPE, table.device)
     plans = model.__dict__.setdefault('_mrdis_mix_plans', {})
     plan = plans.get(key)
     if plan is not None and not plan.ok and plan.probe is not None and _grad_sink(plan.probe) is not None:
@@ -324,7 +332,7 @@ def premix_all(model, table):
         for m in model.modules():
             if isinstance(m, _model.CondConv2d) and id(m) not in fused_ids:
                 singles.append(m)
-        plan = plans[key] = MixPlan(singles, pairs, table.shape[0], want16, table.device)
+        plan = plans[key] = MixPlan(singles, pairs, table.shape[0], want16, table.device, pad16=_COMPUTE_DTYPE == hip.DT_BF16)
     if not plan.ok:
         return False
     holder = [plan]
@@ -480,7 +488,12 @@ def bf16_filters(w_tck, w_tkc):
     return hit[1], hit[2]
 
 
-def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
+def _pad_bias16(bias, Co_p):
+    import torch.nn.functional as F
+    return cached_mix(('padb', id(bias), Co_p), lambda: (bias, F.pad(bias, (0, Co_p - bias.shape[0]))))[1]
+
+
+def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
     """-> torch.ops.mrdis.conv2d (registered at the bottom of this file: CUDA kernel, fake kernel, autograd formula).
     With bf16 storage the bf16 kernels run bf16 -> bf16 where the geometry allows (reduction axis % 16, >= 16 outputs);
     other layers (Cin = 4 / 7 first layers, heads with < 16 outputs) run the fp32 kernels between explicit view casts:
@@ -492,7 +505,12 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False):
     if _COMPUTE_DTYPE == hip.DT_F32_BF16M:
         return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
     if hip.bconv_eligible(Ci, Co):
-        return torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+        # (a filter that the all-layers mixing launch wrote zero-padded to 16 channels -- MixPlan.padded -- meets a narrower input / bias /
+        #  true output width `co` here: the view cast pads the input, the bias is padded once per step, the output is sliced back to fp32)
+        if bias is not None and bias.shape[0] < Co:
+            bias = _pad_bias16(bias, Co)
+        y = torch.ops.mrdis.conv2d(cast_view(x, torch.bfloat16, Ci), w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+        return y if (co is None or co == Co) else cast_view(y, torch.float32, co)
     # Narrow side (the 4-channel anatomy maps into the SPADE `si_layers`, the 64 -> 4 and 16 -> 7 heads): pad the narrow channel
     # count to 16 with zeros -- the view cast writes the zero channels, the filter gets zero rows / columns -- and the bf16 MFMA
     # kernels take the layer in all three directions (the matrix pipe has 16x the fp32 rate: the padding is free, the layer is
@@ -551,14 +569,15 @@ class _GroupedConvFn(Function):
     anatomy maps in, the 7-channel reconstruction out) zero-padded to 16."""
 
     @staticmethod
-    def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, *filt):
+    def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, co, *filt):
         bm = _COMPUTE_DTYPE != hip.DT_F32
         st = _COMPUTE_DTYPE == hip.DT_BF16
         B = x.shape[0] if share_x else x.shape[0] // G
         H, W = x.shape[2], x.shape[3]
-        Ci, Co = filt[0].shape[1], filt[0].shape[2]
-        Ci_p, Co_p = (max(Ci, 16), max(Co, 16)) if st else (Ci, Co)
-        padded = (Ci_p, Co_p) != (Ci, Co)
+        Cif, Cof = filt[0].shape[1], filt[0].shape[2]           # the filters' channel counts: already zero-padded to 16 when they come from
+        Ci, Co = x.shape[1], (int(co) if co else Cof)           # the all-layers mixing launch (MixPlan.padded); Ci, Co: the layer's own
+        Ci_p, Co_p = (max(Cif, 16), max(Cof, 16)) if st else (Cif, Cof)
+        padded = (Ci_p, Co_p) != (Cif, Cof)                     # the filters still need padding here
         xin = x
         if st and (x.dtype != torch.bfloat16 or Ci_p != Ci):
             xin = hip.cast_view(x, torch.bfloat16, Ci_p)           # fp32 -> bf16 view cast, zero channels up to 16
@@ -571,9 +590,11 @@ class _GroupedConvFn(Function):
                 tck, tkc, bg, wb_f, wb_b = _pad16_filters(tck, tkc, bias, Ci_p, Co_p)
             else:
                 wb_f, wb_b = bf16_filters(tck, tkc) if bm else (None, None)
+                if bias is not None and bias.shape[0] < Co_p:
+                    bg = _pad_bias16(bias.detach(), Co_p)
             use_tkc.append(tkc); wbs.append(wb_b)
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
-        ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype)
+        ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
         ctx.dx_in_gb = bool(getattr(x, '_mrdis_want_dgb', False)) and _GB_INPLACE
         ctx.wbs = wbs
         ctx.bias_param = bias
@@ -582,7 +603,7 @@ class _GroupedConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        G, B, share_x, kh, kw, pad, lrelu, dt, Ci, Co, Ci_p, Co_p, x_dtype = ctx.meta
+        G, B, share_x, kh, kw, pad, lrelu, dt, Ci, Co, Ci_p, Co_p, x_dtype, padded, Cif, Cof = ctx.meta
         xin, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         tkcs = ctx.saved_tensors[2:]
         bias = ctx.bias_param
@@ -610,8 +631,8 @@ class _GroupedConvFn(Function):
             if need_x:
                 hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, 1, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
             dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
-            if (Ci_p, Co_p) != (Ci, Co):
-                dw = dw[:, :Ci, :Co].contiguous()
+            if padded:
+                dw = dw[:, :Cif, :Cof].contiguous()
             dws += [dw, None]
             if db is not None:
                 db_total = db if db_total is None else db_total + db
@@ -626,7 +647,7 @@ class _GroupedConvFn(Function):
             dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci_p).sum(0).permute(0, 3, 1, 2) if share_x else dxb
             if dx.dtype != x_dtype or Ci_p != Ci:
                 dx = hip.cast_view(dx, x_dtype, Ci)
-        return (dx, db_total, None, None, None, None, None, None) + tuple(dws)
+        return (dx, db_total, None, None, None, None, None, None, None) + tuple(dws)
 
 
 class _GbSpadeFn(Function):
@@ -718,13 +739,13 @@ def gb_spade(si_out, z, filters, bias, eps):
     return mix
 
 
-def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False):
+def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False, co=None):
     """x: (G * B, Ci, H, W) sample blocks (or (B, Ci, H, W) read by every group when share_x); filters: G pairs (w_tck, w_tkc);
     stride 1.  -> (G * B, Co, H, W): block g = conv(x_g, filters[g]) + bias."""
     flat = []
     for a, b in filters:
         flat += [a, b]
-    return _GroupedConvFn.apply(x, bias, len(filters), bool(share_x), kh, kw, pad, bool(lrelu), *flat)
+    return _GroupedConvFn.apply(x, bias, len(filters), bool(share_x), kh, kw, pad, bool(lrelu), co, *flat)
 
 
 # --------------------------------------------------------------------------- norms

@@ -32,7 +32,10 @@ with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     for _ in range(N):
         step(xd, maskd, mimgd, mask)
 torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::')]
+VIEWS = {'aten::as_strided', 'aten::slice', 'aten::select', 'aten::view', 'aten::empty', 'aten::t', 'aten::transpose', 'aten::narrow', 'aten::reshape',
+         'aten::empty_like', 'aten::empty_strided', 'aten::permute', 'aten::expand', 'aten::unsqueeze', 'aten::squeeze', 'aten::detach', 'aten::alias',
+         'aten::contiguous', 'aten::to', 'aten::resize_', 'aten::linear', 'aten::zeros', 'aten::ones', 'aten::pad', 'aten::clone'}
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::') and e.key not in VIEWS]
 rows.sort(key=lambda e: -e.count)
 print(f'{"op":34s} {"calls/step":>10s} {"self cpu us/step":>16s}  input shapes')
 for e in rows[:70]:
