@@ -488,9 +488,10 @@ def bf16_filters(w_tck, w_tkc):
     return hit[1], hit[2]
 
 
-def _pad_bias16(bias, Co_p):
+def _pad_bias16(bias, Co_p, detach=False):
+    """bias zero-padded to Co_p entries, once per step and bias (autograd-connected unless `detach`)"""
     import torch.nn.functional as F
-    return cached_mix(('padb', id(bias), Co_p), lambda: (bias, F.pad(bias, (0, Co_p - bias.shape[0]))))[1]
+    return cached_mix(('padb', id(bias), Co_p, detach), lambda: (bias, F.pad(bias.detach() if detach else bias, (0, Co_p - bias.shape[0]))))[1]
 
 
 def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
@@ -591,7 +592,7 @@ class _GroupedConvFn(Function):
             else:
                 wb_f, wb_b = bf16_filters(tck, tkc) if bm else (None, None)
                 if bias is not None and bias.shape[0] < Co_p:
-                    bg = _pad_bias16(bias.detach(), Co_p)
+                    bg = _pad_bias16(bias, Co_p, detach=True)
             use_tkc.append(tkc); wbs.append(wb_b)
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
