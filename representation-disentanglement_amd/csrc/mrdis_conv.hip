@@ -1096,6 +1096,8 @@ int mrdis_run_pw_fwd(const float* x, int ldx, const float* w_tck, const float* b
 // mrdis_wgrad_s2.hip: forward of the stride-2 first layers (Cin <= 7)
 int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
                           int kh, int kw, int stride, int pad, int lrelu, hipStream_t s);
+int mrdis_run_dgrad_s2(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+                       int kh, int kw, int stride, int pad, hipStream_t s);
 // mrdis_co4.hip: 3x3 s1 p1 with 4 output channels: window-free GEMM + tap gather
 int mrdis_run_co4(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
 // mrdis_c16.hip: 3x3 s1 p1 with 16 output channels, filter in registers
@@ -1174,6 +1176,10 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
     const bool bf = bf16m_wanted(dtype, w_bf16_tck, Co, Ci);      // the data gradient reduces over Co and produces Ci channels
     if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;
     base.w_bf16 = bf ? w_bf16_tck : nullptr; base.dtype = dtype;
+    if (!st_bf16 && stride == 2 && Ci <= 7) {
+        rc = mrdis_run_dgrad_s2(dy, lddy, w_tkc, dx, lddx, N, H, W, Ci, Co, kh, kw, stride, pad, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     if (!st_bf16 && stride == 1 && kh == 3 && kw == 3 && pad == 1 && Ci == 4) {
         // dx of a 4 -> Co layer (the SPADE si_layers): a Co -> 4 convolution of dy with the taps reversed; [tap][Co][4] is the filter layout
         rc = mrdis_run_co4(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);

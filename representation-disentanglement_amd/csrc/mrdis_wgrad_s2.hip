@@ -514,6 +514,111 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- data gradient
+// dx of the same stride-2 layers (the second encoder pass back-propagates into the generated images): a window-free GEMM per dy pixel q,
+//     Z[m = (tap, ci)][q] = sum_co w[tap][co][ci] dy[q][co]            (112 = 7 tiles | 63 rows, K = Co: no padding waste),
+// and a gather  dx[2 q + tap - 1][ci] += Z[(tap, ci)][q]:  every dx pixel takes the 2 x 2 taps of its parity class.  As in mrdis_co4.hip
+// the dy operand goes from global memory straight into MFMA registers, the filter stays in registers, Z of one dy row goes to LDS
+// ([q + 1][M + pad], conflict-free 16-byte writes) and thread ix adds its taps in fixed order while the workgroup streams down the dy
+// rows of one image: dy row r completes dx rows 2 r - 1 (tap rows 2 of r - 1 and 0 of r) and 2 r (tap rows 3 of r - 1 and 1 of r).
+struct DgradS2Params {
+    const float* dy; const float* w; float* dx;
+    int N, H, W, Ci, lddx, Co, lddy, Hout, Wout;
+    int R, segs, M, MP;
+    unsigned dy_bytes;
+};
+
+template <int KS, int HALVES>
+__global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgradS2Params p) {
+    constexpr int MT = (KS * KS * 7 + 15) / 16, KSTEPS = 4 * HALVES, CO = 16 * HALVES;
+    extern __shared__ __attribute__((aligned(16))) float zs[];      // [Wout + 2][MP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int Ci = p.Ci, MP = p.MP;
+    const int b = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = b / p.segs, r0 = (b - n * p.segs) * p.R, r1 = min(r0 + p.R, p.Hout);
+    // A = filter: a[ks][mt] = w[tap][co = 16 h + 4 kq + j][ci], row m = 16 mt + l16 = tap * Ci + ci, ks = 4 h + j
+    float a[KSTEPS][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l16;
+        const bool ok = m < p.M;
+        const int tap = ok ? m / Ci : 0, ci = ok ? m - tap * Ci : 0;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) a[ks][mt] = ok ? p.w[(tap * CO + 16 * (ks >> 2) + 4 * kq + (ks & 3)) * Ci + ci] : 0.f;
+    }
+    for (int i = tid; i < (p.Wout + 2) * MP; i += 256) zs[i] = 0.f;    // rows q = -1 and q = Wout stay zero
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const int tpw = p.Wout >> 6;                      // 16-pixel tiles per wave and row (host: Wout % 64 == 0, <= 2)
+    u32x4 yr[2][HALVES];
+    auto load_tile = [&](int t, int r) {
+        const int q = 16 * (wave + 4 * t) + l16;
+        const bool ok = t < tpw && (unsigned)r < (unsigned)p.Hout && r >= r0 - 1 && r <= r1;
+        const unsigned base = 4u * (unsigned)(((n * p.Hout + r) * p.Wout + q) * p.lddy + 4 * kq);
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) yr[t][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)(ok ? base + 64u * h : S2_OOB), 0, 0);
+    };
+    // thread ix = tid: its column's taps.  ix even (2 b): tx = 1 -> q = b, tx = 3 -> q = b - 1;  ix odd (2 b + 1): tx = 0 -> q = b + 1, tx = 2 -> q = b
+    const int ix = tid, bcol = ix >> 1;
+    const int txa = (ix & 1) ? 0 : 1, qa = (ix & 1) ? bcol + 1 : bcol;          // first tap column and its dy pixel
+    const int txb = txa + 2, qb = (ix & 1) ? bcol : bcol - 1;                    // second (absent for 3x3 taps when tx = 3)
+    const bool has_b = txb < KS;
+    float runE[7], runO[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { runE[c] = 0.f; runO[c] = 0.f; }
+    auto tap_row = [&](int ty, float (&g)[7]) {       // sum over this column's taps of tap row ty, fixed order
+        const float* za = zs + (qa + 1) * MP + (ty * KS + txa) * Ci;
+        const float* zb = zs + (qb + 1) * MP + (ty * KS + txb) * Ci;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) g[c] = c < Ci ? za[c] + (has_b ? zb[c] : 0.f) : 0.f;
+    };
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) load_tile(t, r0 - 1);
+    __syncthreads();
+    for (int r = r0 - 1; r <= r1; ++r) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < tpw) {
+                f32x4 acc[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < HALVES; ++h) {
+                    const float yv[4] = {__uint_as_float(yr[t][h].x), __uint_as_float(yr[t][h].y), __uint_as_float(yr[t][h].z), __uint_as_float(yr[t][h].w)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * h + j][mt], yv[j], acc[mt], 0, 0, 0);
+                }
+                float* zd = zs + (16 * (wave + 4 * t) + l16 + 1) * MP + 4 * kq;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(zd + 16 * mt) = acc[mt];
+            }
+            load_tile(t, r + 1);
+        }
+        __syncthreads();
+        if (ix < p.W) {
+            float g0[7], g1[7], g2[7], g3[7];
+            tap_row(0, g0); tap_row(1, g1); tap_row(2, g2);
+            if (KS == 4) tap_row(3, g3);
+            // dx row 2 r - 1 = tap row 2 of dy row r - 1 (runO) + tap row 0 of dy row r;  dx row 2 r = tap row 3 of r - 1 (runE) + tap row 1 of r
+            if (r - 1 >= r0 && r - 1 < r1) {
+                float* d = p.dx + ((long long)(n * p.H + 2 * r - 1) * p.W + ix) * p.lddx;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) if (c < Ci) d[c] = runO[c] + g0[c];
+            }
+            if (r >= r0 && r < r1) {
+                float* d = p.dx + ((long long)(n * p.H + 2 * r) * p.W + ix) * p.lddx;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) if (c < Ci) d[c] = runE[c] + g1[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) { runO[c] = g2[c]; runE[c] = KS == 4 ? g3[c] : 0.f; }
+        }
+        __syncthreads();
+    }
+}
+
 // dw[i] = sum_k slab[k][i] (i < total), dbias[co] (+)= sum_k bslab[k][co]: the fixed-order slab reduction shared with mrdis_pointwise.hip
 int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
                              hipStream_t s) {
@@ -649,4 +754,41 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float
     else hipLaunchKernelGGL((wgrad_c4_kernel<8>), dim3(p.splits), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
+}
+
+// data gradient of the same layers (dy (N, H/2, W/2, Co) -> dx (N, H, W, Ci)); MRDIS_EUNSUPPORTED outside what the kernel covers
+int mrdis_run_dgrad_s2(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, int N, int H, int W, int Ci, int Co,
+                       int kh, int kw, int stride, int pad, hipStream_t s) {
+    if (stride != 2 || pad != 1 || kh != kw || (kh != 3 && kh != 4) || Ci < 1 || Ci > 7 || (Co != 16 && Co != 32)) return MRDIS_EUNSUPPORTED;
+    if ((H & 1) || (W != 128 && W != 256) || lddy % 4 != 0 || (((uintptr_t)dy) & 15) != 0 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W < 100000) return MRDIS_EUNSUPPORTED;
+    DgradS2Params p{};
+    p.dy = dy; p.w = w_tkc; p.dx = dx; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.lddx = lddx; p.Co = Co; p.lddy = lddy;
+    p.Hout = H / 2; p.Wout = W / 2; p.M = kh * kw * Ci;
+    const int mrows = ((p.M + 15) / 16) * 16;
+    p.MP = mrows + 4;                                  // (MP / 4 odd: the 16 pixels of a tile write to 16 distinct 4-bank groups)
+    const long long yb = 4LL * (((long long)N * p.Hout * p.Wout - 1) * lddy + Co);
+    if (yb >= 0x7fffffffLL || (long long)N * H * W * lddx >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.dy_bytes = (unsigned)yb;
+    int segs = mrdis_cdiv(512, N);
+    if (segs > p.Hout / 2) segs = p.Hout / 2 > 0 ? p.Hout / 2 : 1;
+    p.R = mrdis_cdiv(p.Hout, segs); p.segs = mrdis_cdiv(p.Hout, p.R);
+    const size_t lds = sizeof(float) * (size_t)(p.Wout + 2) * p.MP;
+    if (lds > 72 * 1024) return MRDIS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)dgrad_s2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)dgrad_s2_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)dgrad_s2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)dgrad_s2_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+            return MRDIS_EUNSUPPORTED;
+        attr_set = true;
+    }
+    const dim3 grid(N * p.segs), block(256);
+    if (kh == 4 && Co == 32) hipLaunchKernelGGL((dgrad_s2_kernel<4, 2>), grid, block, lds, s, p);
+    else if (kh == 4) hipLaunchKernelGGL((dgrad_s2_kernel<4, 1>), grid, block, lds, s, p);
+    else if (Co == 32) hipLaunchKernelGGL((dgrad_s2_kernel<3, 2>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((dgrad_s2_kernel<3, 1>), grid, block, lds, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
 }

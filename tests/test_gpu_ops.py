@@ -423,14 +423,20 @@ def test_wgrad_stride2_first_layers(mrdis, case):
     hip.conv2d_fwd(xv, w_tck, bd, k, k, 2, 1, lrelu=True, out=out[:, 16:])
     close(out[:, 16:], F.leaky_relu(y.detach(), 0.2), rtol=2e-5, what='fwd s2 lrelu into a slice')
     assert bool((out[:, :16] == 3.0).all())
+    # data gradient of the same layers (dgrad_s2_kernel: window-free GEMM + parity gather), into a dense tensor and into a channel slice
+    want_dx = torch.nn.grad.conv2d_input((N, Ci, H, W), w.detach(), gy, 2, 1)
+    w_tkc = to_tkc(w.detach()).to(dev())
+    dx = hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), k, k, 2, 1)
+    close(dx, want_dx, rtol=2e-5, what='dgrad s2')
     hip.set_option('debug_now16', 1)
     try:
         dw3, db3 = hip.conv2d_bwd_weight(xv, cl(gy), k, k, 2, 1, need_bias=True)
         y3 = hip.conv2d_fwd(xv, w_tck, bd, k, k, 2, 1)
+        dx3 = hip.conv2d_bwd_data(cl(gy), w_tkc, (H, W), k, k, 2, 1)
     finally:
         hip.set_option('debug_now16', 0)
     close(dw3, dw.cpu(), rtol=3e-4, what='generic vs s2'); close(db3, db.cpu(), rtol=3e-4, what='generic vs s2 bias')
-    close(y3, yy.cpu(), rtol=2e-5, what='generic vs s2 forward')
+    close(y3, yy.cpu(), rtol=2e-5, what='generic vs s2 forward'); close(dx3, dx.cpu(), rtol=2e-5, what='generic vs s2 dgrad')
 
 
 @pytest.mark.parametrize('case', [(8, 7, 128, 96), (3, 8, 100, 75), (5, 4, 64, 80), (2, 1, 96, 96), (32, 7, 64, 64)], ids=str)

@@ -24,6 +24,10 @@ for (co, k, x) in [(32, 4, full[:, 7:14]), (16, 3, full[:, 7:14]), (32, 4, dense
     for now16 in (0, 1):
         hip.set_option('debug_now16', now16)
         out.append(f'fwd now16={now16}: {timeit(lambda: hip.conv2d_fwd(x, w_tck, bias, k, k, 2, 1)):.1f} us')
+    w_tkc = torch.randn(k * k, co, 7, device=dev) * 0.1
+    for now16 in (0, 1):
+        hip.set_option('debug_now16', now16)
+        out.append(f'dgrad now16={now16}: {timeit(lambda: hip.conv2d_bwd_data(dy, w_tkc, (256, 256), k, k, 2, 1)):.1f} us')
     hip.set_option('debug_now16', 0)
     mb = (32 * 256 * 256 * 7 + 32 * 128 * 128 * co) * 4 / 1e6
     print(f'7 -> {co} k{k} s2 256x256 B=32 ldx={hip.nhwc(x)[1]} ({mb:.0f} MB algorithmic): ' + ' | '.join(out), flush=True)
