@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgradS2Params p)
                 }
                 float* zd = zs + (16 * (wave + 4 * t) + l16 + 1) * MP + 4 * kq;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(zd + 16 * mt) = acc[mt];
+                for (int mt = 0; mt < MT; ++mt)
+                    if (16 * mt < p.M) *reinterpret_cast<f32x4*>(zd + 16 * mt) = acc[mt];      // (row tiles beyond taps * Ci do not exist in the MP-float pixel row)
             }
             load_tile(t, r + 1);
         }

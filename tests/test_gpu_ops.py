@@ -392,6 +392,8 @@ S2_CASES = [
     (5, 7, 32, 66, 160, 3, 0),      # odd row count per workgroup, 3x3 with 32 couts
     (4, 5, 16, 96, 256, 4, 2),      # Cin = 5: several all-zero (tap, ci) rows in the last tiles; the widest row the kernel stages
     (16, 3, 32, 64, 96, 4, 0),      # Cin = 3
+    (12, 4, 16, 64, 256, 4, 1),     # the discriminator's first layer (4 -> 16, 4x4): 64 gradient rows = 4 of the 7 row tiles, 8 output rows per workgroup
+    (6, 3, 16, 128, 128, 3, 0),     # Cin = 3, 3x3: 27 rows = 2 tiles
 ]
 
 

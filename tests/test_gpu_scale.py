@@ -112,6 +112,20 @@ def test_layer_zoo_at_bench_scale(mrdis, case):
     for what, a, c, tol in (('fwd', y, y0, 1e-4), ('dgrad', dx, dx0, 1e-4), ('wgrad', dw, dw0, 2e-4), ('dbias', db, db0, 2e-4)):
         err = float((a - c).abs().max()) / float(c.abs().max())
         assert err <= tol, (what + ' default policy vs direct', name, err)
+    # the narrow layers (<= 16 channels on one side, stride-2 first layers, 1x1 head) have dedicated kernels (mrdis_c16 / co4 / pointwise /
+    # wgrad_s2 / wgrad16): the generic tile kernels (option debug_now16 = 1) on the full tensors
+    if min(Ci, Co) <= 16:
+        hip.set_option('debug_now16', 1)
+        try:
+            y1 = hip.conv2d_fwd(xd, w_tck, bd, k, k, s, p)
+            dx1 = hip.conv2d_bwd_data(dyd, w_tkc, (H, W), k, k, s, p)
+            dw1, db1 = hip.conv2d_bwd_weight(xd, dyd, k, k, s, p, need_bias=True)
+        finally:
+            hip.set_option('debug_now16', 0)
+        for what, a, c, tol in (('fwd', y, y1, 1e-4), ('dgrad', dx, dx1, 1e-4), ('wgrad', dw, dw1, 2e-4), ('dbias', db, db1, 2e-4)):
+            err = float((a - c).abs().max()) / float(c.abs().max())
+            assert err <= tol, (what + ' dedicated narrow kernel vs tile kernel', name, err)
+        del y1, dx1, dw1, db1
     # the fused LeakyReLU epilogue at this size
     yl = hip.conv2d_fwd(xd, w_tck, bd, k, k, s, p, lrelu=True)
     assert torch.equal(yl, F.leaky_relu(y, 0.2)) or rel(yl, F.leaky_relu(y, 0.2)) <= 1e-6, ('lrelu', name)
@@ -149,12 +163,13 @@ def test_north_star_conv_output(mrdis):
 
 def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
     """One B=32, M=4, 256x256 training step (the headline workload, adversarial loss on) under the default policy vs
-    the direct kernels only: loss, every loss part, every parameter gradient, and the weights after Adam."""
+    (a) the direct kernels only (wino = 0) and (b) the generic tile kernels on the narrow layers (debug_now16 = 1: the dedicated
+    c16 / co4 / pointwise / stride-2 / wgrad16 kernels off): loss, every loss part, every parameter gradient, and the weights after Adam."""
     m = mrdis
     H = W = HW
     res = {}
-    for mode in (1, 0):
-        m.hip.set_option('wino', mode)
+    for mode in ((1, 0), (0, 0), (1, 1)):                # (wino, debug_now16): default policy | direct kernels only | narrow-layer kernels off
+        m.hip.set_option('wino', mode[0]); m.hip.set_option('debug_now16', mode[1])
         cfg = dict(m.DEFAULT_CONFIG); cfg.update(input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0, is_patch_gan=True)
         cfg = m.derive_config(cfg, DEV)
         torch.manual_seed(10); np.random.seed(10)
@@ -175,24 +190,26 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
                      {n: p.detach().clone() for n, p in model.named_parameters()})
         del model, step
         torch.cuda.empty_cache()
-    (l1, p1, g1, w1), (l0, p0, g0, w0) = res[1], res[0]
-    assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
-    for k_ in p0:
-        assert abs(p1[k_] - p0[k_]) <= 2e-4 * abs(p0[k_]) + 1e-7, (k_, p1[k_], p0[k_])
-    assert set(g0) == set(g1) and len(g0) > 200
-    assert any(not torch.equal(g0[n][0], g1[n][0]) for n in g0), 'the default policy did not change any kernel'
-    for pass_ in (0, 1):
-        names = [n for n in g0 if len(g0[n]) > pass_]
-        tot = float(torch.sqrt(sum((g0[n][pass_].double() ** 2).sum() for n in names)))
-        for n in names:
-            a, c = g0[n][pass_], g1[n][pass_]
-            err = float((a - c).double().norm())
-            assert err <= 2e-3 * float(a.double().norm()) + 2e-5 * tot, (pass_, n, err, float(a.norm()))
-    # an Adam step moves a weight by at most ~lr = 2e-4 (the sign of a noise-level gradient, e.g. of a conv bias in front of
-    # BatchNorm, may flip): bound the worst case
-    # and require the bulk to agree
-    for n in w0:
-        d = (w0[n] - w1[n]).abs()
-        assert float(d.max()) <= 8.4e-4, n          # two Adam steps (generator + discriminator optimizer), each <= ~lr per element
-    num = sum(float((w0[n] - w1[n]).abs().sum()) for n in w0); den = sum(w0[n].numel() for n in w0)
-    assert num / den <= 2e-6, num / den
+    m.hip.set_option('wino', 1); m.hip.set_option('debug_now16', 0)
+    for other in ((0, 0), (1, 1)):
+        (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0)], res[other]
+        assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
+        for k_ in p0:
+            assert abs(p1[k_] - p0[k_]) <= 2e-4 * abs(p0[k_]) + 1e-7, (k_, p1[k_], p0[k_])
+        assert set(g0) == set(g1) and len(g0) > 200
+        assert any(not torch.equal(g0[n][0], g1[n][0]) for n in g0), 'the default policy did not change any kernel'
+        for pass_ in (0, 1):
+            names = [n for n in g0 if len(g0[n]) > pass_]
+            tot = float(torch.sqrt(sum((g0[n][pass_].double() ** 2).sum() for n in names)))
+            for n in names:
+                a, c = g0[n][pass_], g1[n][pass_]
+                err = float((a - c).double().norm())
+                assert err <= 2e-3 * float(a.double().norm()) + 2e-5 * tot, (pass_, n, err, float(a.norm()))
+        # an Adam step moves a weight by at most ~lr = 2e-4 (the sign of a noise-level gradient, e.g. of a conv bias in front of
+        # BatchNorm, may flip): bound the worst case
+        # and require the bulk to agree
+        for n in w0:
+            d = (w0[n] - w1[n]).abs()
+            assert float(d.max()) <= 8.4e-4, n          # two Adam steps (generator + discriminator optimizer), each <= ~lr per element
+        num = sum(float((w0[n] - w1[n]).abs().sum()) for n in w0); den = sum(w0[n].numel() for n in w0)
+        assert num / den <= 2e-6, num / den
