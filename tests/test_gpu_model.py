@@ -328,6 +328,36 @@ def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
     assert torch.equal(res[True][1], res[False][1])
 
 
+@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace'])
+def test_layout_switches_do_not_change_the_step(mrdis, switch):
+    """MRDIS_PLANAR_INPUTS (modality-planar copy of the input batch), MRDIS_CAT_ELISION (skip concatenation written in place) and
+    MRDIS_GB_INPLACE (d(mix) written into the beta half of [dgamma | dbeta]) only change where tensors live: one step with the switch
+    off and on gives the same loss and the same parameter gradients (same kernels' arithmetic on other strides)."""
+    B, M, H, W = 2, 4, 64, 128
+    cfg = _cfg(mrdis, M, H, W, B, adv=True)
+    holder = {'planar_inputs': (mrdis.trainer, '_PLANAR_INPUTS'), 'cat_elision': (mrdis.ops, '_CAT_ELISION'), 'gb_inplace': (mrdis.ops, '_GB_INPLACE')}[switch]
+    res = {}
+    try:
+        for on in (False, True):
+            setattr(holder[0], holder[1], on)
+            torch.manual_seed(10); np.random.seed(10)
+            model = mrdis.build_model(cfg).train()
+            inputs, mask, mask_img = make_inputs(B, M, H, W, seed=10)
+            torch.manual_seed(11); np.random.seed(11)
+            with mrdis.ops.mix_cache():
+                loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+                loss.backward()
+            res[on] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        setattr(holder[0], holder[1], True)
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-6 * abs(float(res[False][0]))
+    assert res[True][1].keys() == res[False][1].keys()
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[False][1].values())))
+    for n, g0 in res[False][1].items():
+        err = float((res[True][1][n] - g0).double().norm())
+        assert err <= 1e-5 * float(g0.double().norm()) + 1e-7 * tot, (n, err, float(g0.norm()))
+
+
 def test_gb_spade_fusion_matches_two_step_path(mrdis):
     """A full step with the fused gamma | beta + modulation epilogue on and off (ops.set_gb_spade): same loss and gradients to fp32
     rounding (the fused kernel adds the bias and applies the modulation in registers, the two-step path round-trips through memory:
