@@ -34,8 +34,10 @@
 __device__ float g_mrdis_zero_page[64];
 #define TC_TAB_INTS 320   // tapconv16: tab_in[128] tab_out[128] tap_xoff[16] tap_widx[16] + pad (tapconv_kernel: 2*BM + 64)
 
+// (bx, gx): workgroup index and count of THIS launch slice -- blockIdx.x / gridDim.x for a plain launch, the class's own range when the
+// four parity classes of a stride-2 data gradient share one launch (tapconv_pack_kernel)
 template <int KC, int BN, int MODE, int BM>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch; BM positions per workgroup
-__global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
+__device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int bx, const int gx) {
     constexpr int S = KC + 1;
     constexpr int WAVES_N = (BN == 32) ? 1 : 2;
     constexpr int WAVES_M = 4 / WAVES_N;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
-    int bid = mrdis_xcd_remap(blockIdx.x, gridDim.x);
+    int bid = mrdis_xcd_remap(bx, gx);
     const int cot = bid % p.coTiles;
     int tile = bid / p.coTiles;
     const int tb = tile % p.tilesB; tile /= p.tilesB;
@@ -342,6 +344,21 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
     }
 }
 
+template <int KC, int BN, int MODE, int BM>
+__global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
+    tapconv_body<KC, BN, MODE, BM>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// The four output-parity classes of a stride-2 data gradient (each its own tap set and output grid, disjoint output pixels) in ONE
+// launch: blockIdx.y = class.  On the small maps of the encoders a class alone fills a quarter of the chip (128 workgroups at
+// 256 -> 256 on 16x16) and the four launches ran back to back.
+struct TapConvPack { TapConvParams c[4]; int nblk[4]; };
+template <int KC, int BN, int MODE, int BM>
+__global__ __launch_bounds__(256) void tapconv_pack_kernel(const TapConvPack pk) {
+    const int y = blockIdx.y;
+    if ((int)blockIdx.x >= pk.nblk[y]) return;
+    tapconv_body<KC, BN, MODE, BM>(pk.c[y], (int)blockIdx.x, pk.nblk[y]);
+}
+
 // ---------------------------------------------------------------- narrow-output variant (Cout <= 16)
 // Layers with 4 / 7 / 16 output channels (ana_dec.output, the data gradients of every `si_layers`,
 // sp6.out, the 1x1 decoder head, first-layer data gradients) waste 2-8x of a 32-wide cout tile.  This
@@ -621,12 +638,28 @@ static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM
     return MRDIS_OK;
 }
 
+// a planned (not yet launched) tapconv_kernel launch: run_tapconv fills it instead of launching when asked to
+struct TapLaunch { TapConvParams p; int KC, BN, BM, nblk; size_t lds; bool set; };
+template <int KC, int BN>
+static int launch_tapconv_pack_t(const TapLaunch (&L)[4], hipStream_t s) {
+    TapConvPack pk;
+    int gx = 0; size_t lds = 0;
+    for (int k = 0; k < 4; ++k) { pk.c[k] = L[k].p; pk.nblk[k] = L[k].nblk; if (L[k].nblk > gx) gx = L[k].nblk; if (L[k].lds > lds) lds = L[k].lds; }
+    const int BM = L[0].BM, pf = L[0].p.prefetch;
+    if (BM == 256) hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 1, 256>), dim3(gx, 4), dim3(256), lds, s, pk);
+    else if (pf == 1) hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 1, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
+    else hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 0, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 static size_t tapconv_lds(const TapConvParams& p, int KC, int BN, int BM = TC_BM) {
     return sizeof(float) * ((size_t)(2 * BM + 64) + (size_t)p.ntaps * KC * BN + (size_t)p.NB * p.TinH * p.TinW * (KC + 1));
 }
 
 // fills tiling fields and launches.  `p` must have geometry + taps set.
-static int run_tapconv(TapConvParams p, hipStream_t s) {
+static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullptr) {
+    if (defer) defer->set = false;
     if (p.ntaps < 1 || p.ntaps > MRDIS_MAX_TAPS) return MRDIS_EUNSUPPORTED;
     if (p.A <= 0 || p.B <= 0 || p.N <= 0) return MRDIS_OK;   // empty launch
     int dh_max = p.dh[0], dw_max = p.dw[0];
@@ -727,6 +760,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s) {
             if (q.NB * q.TH * q.TW == 256 && npix2 * (KC / 4) <= 6 * 256 && lds2 <= LDS_MAX) { p = q; nblk = nblk2; lds = lds2; BM = 256; }
         }
     }
+    if (defer) { defer->p = p; defer->KC = KC; defer->BN = BN; defer->BM = BM; defer->nblk = (int)nblk; defer->lds = lds; defer->set = true; return MRDIS_OK; }
 #define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, BM, s)
     TC_CASE(4, 32); TC_CASE(4, 64);
     TC_CASE(8, 32); TC_CASE(8, 64);
@@ -1205,6 +1239,8 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
         return run_tapconv(p, (hipStream_t)stream);
     }
     // stride 2: dx[hi] gathers dy[(hi + pad - r)/2] for the taps r with (hi + pad - r) even.
+    TapLaunch L[4];
+    const bool pack = !mrdis_opt(MRDIS_OPT_NOW16);           // (debug_now16 = 1: the four classes as four launches, as before)
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             TapConvParams p = base;
@@ -1221,9 +1257,30 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
                 }
             }
             if (p.ntaps == 0) return MRDIS_EUNSUPPORTED;   // would need a zero fill; not on the path
-            rc = run_tapconv(p, (hipStream_t)stream);
+            rc = run_tapconv(p, (hipStream_t)stream, pack ? &L[2 * ph + pw] : nullptr);
             if (rc) return rc;
         }
+    if (pack) {
+        // classes that were planned for tapconv_kernel (not launched yet): one launch if they agree on the instantiation, else one each
+        bool all = true;
+        for (int k = 0; k < 4; ++k) all = all && L[k].set;
+        bool same = all;
+        for (int k = 1; k < 4 && same; ++k)
+            same = L[k].KC == L[0].KC && L[k].BN == L[0].BN && L[k].BM == L[0].BM && L[k].p.prefetch == L[0].p.prefetch;
+        if (same) {
+#define TCP_CASE(kc, bn) if (L[0].KC == kc && L[0].BN == bn) return launch_tapconv_pack_t<kc, bn>(L, (hipStream_t)stream)
+            TCP_CASE(4, 32); TCP_CASE(4, 64); TCP_CASE(8, 32); TCP_CASE(8, 64); TCP_CASE(16, 32); TCP_CASE(16, 64);
+#undef TCP_CASE
+            return MRDIS_EUNSUPPORTED;
+        }
+        for (int k = 0; k < 4; ++k) {
+            if (!L[k].set) continue;
+#define TC1_CASE(kc, bn) if (L[k].KC == kc && L[k].BN == bn) rc = launch_tapconv_t<kc, bn>(L[k].p, L[k].lds, L[k].nblk, L[k].BM, (hipStream_t)stream)
+            TC1_CASE(4, 32); TC1_CASE(4, 64); TC1_CASE(8, 32); TC1_CASE(8, 64); TC1_CASE(16, 32); TC1_CASE(16, 64);
+#undef TC1_CASE
+            if (rc) return rc;
+        }
+    }
     return MRDIS_OK;
 }
 
