@@ -675,7 +675,14 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
         if (rc != MRDIS_EUNSUPPORTED || p.dtype == MRDIS_DT_BF16) return rc;         // bf16 views never reach the fp32 kernels
     }
     if (p.dtype == MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
-    const TileChoice tc = choose_tile(p.N, p.A, p.B);
+    TileChoice tc = choose_tile(p.N, p.A, p.B);
+    // small maps with many channels (the 16x16 / 8x8 levels of the encoders: 2048 output positions, K = 16 taps x 256 channels): 128-position
+    // tiles give 16 x (Cout / 32) workgroups, a fraction of the chip, each with a long serial K loop.  Half-filled tiles (64 positions of
+    // the 128 a workgroup can hold) double the workgroup count; the matrix pipe is far from busy there, the extra MFMA work is free
+    if (p.Cout > 16 && (long long)mrdis_cdiv(p.A, tc.TH) * mrdis_cdiv(p.B, tc.TW) * mrdis_cdiv(p.N, tc.NB) * mrdis_cdiv(p.Cout, 32) < 200 &&
+        (long long)p.N * p.A * p.B >= 256 && p.Cin >= 64 && p.os == 1 && !mrdis_opt(MRDIS_OPT_NOW16))      // (os == 2: the parity classes of a stride-2
+                                                                                                    // data gradient already share one launch)
+        tc = choose_tile(p.N, p.A, p.B, 64);
     p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
     p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
     p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
