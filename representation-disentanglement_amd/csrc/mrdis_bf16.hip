@@ -19,11 +19,6 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-struct BConvGeom {
-    int tiles;            // position tiles (tilesA * tilesB * tilesN)
-    int nchunks;          // Cin / KC
-    int tile_stride;      // workgroups walking one cout tile (gridDim.x / coTiles)
-};
 
 __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
     bf16x8 r;
@@ -59,7 +54,7 @@ __device__ __forceinline__ void store4(__bf16* p, const float4 v) {
 // TS = storage type of the activations (float: MRDIS_DT_F32_BF16M, __bf16: MRDIS_DT_BF16)
 // ABL (timing-only builds, -DBCONV_ABLATIONS; results wrong): 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 no operand reads, 16 no epilogue stores
 template <int KC, int WAVES_C, int WP, int WC, typename TS, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
+__device__ __forceinline__ void bconv_body(const TapConvParams& p, const BConvGeom& g, const int bx) {
     constexpr int BN = 32 * WC * WAVES_C;          // x 32 * WP * WAVES_P positions
     constexpr int PITCH = KC + 8;                 // bf16 elements per LDS row
     constexpr int QX = KC / 8;                    // 16-byte pieces per pixel row
@@ -70,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
     const int wave_c = wave % WAVES_C, wave_p = wave / WAVES_C;          // 4 / WAVES_C position groups
-    const int cot = blockIdx.x % p.coTiles, wg = blockIdx.x / p.coTiles;
+    const int cot = bx % p.coTiles, wg = bx / p.coTiles;
     const int co0 = cot * BN;
     const int tinHW = p.TinH * p.TinW, npix_in = p.NB * tinHW, npos = p.NB * p.TH * p.TW;
 
@@ -230,6 +225,34 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, co
     }
 }
 
+template <int KC, int WAVES_C, int WP, int WC, typename TS, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void bconv_kernel(const TapConvParams p, const BConvGeom g) {
+    bconv_body<KC, WAVES_C, WP, WC, TS, ABL>(p, g, (int)blockIdx.x);
+}
+// the four output-parity classes of a stride-2 data gradient in one launch (blockIdx.y = class), as tapconv_pack_kernel
+struct BConvPack { TapConvParams c[4]; BConvGeom g[4]; int grid[4]; };
+template <int KC, int WAVES_C, int WP, int WC, typename TS>
+__global__ __launch_bounds__(256, 2) void bconv_pack_kernel(const BConvPack pk) {
+    const int y = blockIdx.y;
+    if ((int)blockIdx.x >= pk.grid[y]) return;
+    bconv_body<KC, WAVES_C, WP, WC, TS, 0>(pk.c[y], pk.g[y], (int)blockIdx.x);
+}
+template <int KC, int WAVES_C, int WP, int WC, typename TS>
+static int launch_bconv_pack_t(const BConvLaunch (&L)[4], hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)bconv_pack_kernel<KC, WAVES_C, WP, WC, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return MRDIS_ELAUNCH;
+        attr_set = true;
+    }
+    BConvPack pk;
+    int gx = 0; size_t lds = 0;
+    for (int k = 0; k < 4; ++k) { pk.c[k] = L[k].p; pk.g[k] = L[k].g; pk.grid[k] = L[k].grid; if (L[k].grid > gx) gx = L[k].grid; if (L[k].lds > lds) lds = L[k].lds; }
+    hipLaunchKernelGGL((bconv_pack_kernel<KC, WAVES_C, WP, WC, TS>), dim3(gx, 4), dim3(256), lds, s, pk);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 template <int KC, int WAVES_C, int WP, int WC, typename TS>
 static int launch_bconv_t(const TapConvParams& p, const BConvGeom& g, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -269,7 +292,8 @@ static int bconv_ncu() {
 int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s);      // mrdis_bf16p.hip
 
 // Eligibility: reduction axis a multiple of 16, 16-byte aligned views, cout a multiple of 4 (16-byte stores).
-int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
+int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BConvLaunch* defer) {
+    if (defer) defer->set = false;
     if (!p.w_bf16 || (p.dtype != MRDIS_DT_F32_BF16M && p.dtype != MRDIS_DT_BF16)) return MRDIS_EUNSUPPORTED;
     const bool st_bf16 = p.dtype == MRDIS_DT_BF16;
     if (st_bf16 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {               // 3x3 s1 layers on bf16 activations: the pipelined kernel (mrdis_bf16p.hip)
@@ -327,6 +351,7 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s) {
     if (per_cot > tiles) per_cot = tiles;
     g.tile_stride = (int)per_cot;
     const int grid = (int)per_cot * p.coTiles;
+    if (defer) { defer->p = p; defer->g = g; defer->KC = KC; defer->waves_c = c.waves_c; defer->wp = c.wp; defer->wc = c.wc; defer->grid = grid; defer->lds = lds; defer->set = true; return MRDIS_OK; }
 #define BC_CASE(kc, a, b_, d) if (KC == kc && c.waves_c == a && c.wp == b_ && c.wc == d) return launch_bconv<kc, a, b_, d>(p, g, grid, lds, s)
     BC_CASE(32, 1, 2, 2); BC_CASE(16, 1, 2, 2); BC_CASE(32, 1, 1, 2); BC_CASE(16, 1, 1, 2);
     BC_CASE(32, 1, 2, 1); BC_CASE(16, 1, 2, 1); BC_CASE(32, 1, 1, 1); BC_CASE(16, 1, 1, 1);
@@ -893,5 +918,31 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, p.slab, p.splits, n, dw_tck,
                        p.bias_slab, p.splits, Co, dbias, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// launch what mrdis_run_bconv planned for the four parity classes: one launch when they share the instantiation, else one each
+int mrdis_launch_bconv_planned(const BConvLaunch (&L)[4], hipStream_t s) {
+    bool same = true;
+    for (int k = 0; k < 4; ++k) same = same && L[k].set;
+    for (int k = 1; k < 4 && same; ++k)
+        same = L[k].KC == L[0].KC && L[k].waves_c == L[0].waves_c && L[k].wp == L[0].wp && L[k].wc == L[0].wc && L[k].p.dtype == L[0].p.dtype;
+    if (same) {
+#define BP_CASE(kc, a, b_, d) if (L[0].KC == kc && L[0].waves_c == a && L[0].wp == b_ && L[0].wc == d) \
+        return L[0].p.dtype == MRDIS_DT_BF16 ? launch_bconv_pack_t<kc, a, b_, d, __bf16>(L, s) : launch_bconv_pack_t<kc, a, b_, d, float>(L, s)
+        BP_CASE(32, 1, 2, 2); BP_CASE(16, 1, 2, 2); BP_CASE(32, 1, 1, 2); BP_CASE(16, 1, 1, 2);
+        BP_CASE(32, 1, 2, 1); BP_CASE(16, 1, 2, 1); BP_CASE(32, 1, 1, 1); BP_CASE(16, 1, 1, 1);
+#undef BP_CASE
+        return MRDIS_EUNSUPPORTED;
+    }
+    for (int k = 0; k < 4; ++k) {
+        if (!L[k].set) continue;
+        int rc = MRDIS_EUNSUPPORTED;
+#define B1_CASE(kc, a, b_, d) if (L[k].KC == kc && L[k].waves_c == a && L[k].wp == b_ && L[k].wc == d) rc = launch_bconv<kc, a, b_, d>(L[k].p, L[k].g, L[k].grid, L[k].lds, s)
+        B1_CASE(32, 1, 2, 2); B1_CASE(16, 1, 2, 2); B1_CASE(32, 1, 1, 2); B1_CASE(16, 1, 1, 2);
+        B1_CASE(32, 1, 2, 1); B1_CASE(16, 1, 2, 1); B1_CASE(32, 1, 1, 1); B1_CASE(16, 1, 1, 1);
+#undef B1_CASE
+        if (rc) return rc;
+    }
     return MRDIS_OK;
 }

@@ -639,7 +639,7 @@ static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM
 }
 
 // a planned (not yet launched) tapconv_kernel launch: run_tapconv fills it instead of launching when asked to
-struct TapLaunch { TapConvParams p; int KC, BN, BM, nblk; size_t lds; bool set; };
+struct TapLaunch { TapConvParams p; int KC, BN, BM, nblk; size_t lds; bool set; BConvLaunch b; };
 template <int KC, int BN>
 static int launch_tapconv_pack_t(const TapLaunch (&L)[4], hipStream_t s) {
     TapConvPack pk;
@@ -659,7 +659,7 @@ static size_t tapconv_lds(const TapConvParams& p, int KC, int BN, int BM = TC_BM
 
 // fills tiling fields and launches.  `p` must have geometry + taps set.
 static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullptr) {
-    if (defer) defer->set = false;
+    if (defer) { defer->set = false; defer->b.set = false; }
     if (p.ntaps < 1 || p.ntaps > MRDIS_MAX_TAPS) return MRDIS_EUNSUPPORTED;
     if (p.A <= 0 || p.B <= 0 || p.N <= 0) return MRDIS_OK;   // empty launch
     int dh_max = p.dh[0], dw_max = p.dw[0];
@@ -671,7 +671,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
         if (p.dw[t] > dw_max) dw_max = p.dw[t];
     }
     if ((p.dtype == MRDIS_DT_F32_BF16M || p.dtype == MRDIS_DT_BF16) && p.w_bf16) {      // bf16 MFMA operands (mrdis_bf16.hip) where the geometry allows
-        const int rc = mrdis_run_bconv(p, dh_max, dw_max, s);
+        const int rc = mrdis_run_bconv(p, dh_max, dw_max, s, defer ? &defer->b : nullptr);
         if (rc != MRDIS_EUNSUPPORTED || p.dtype == MRDIS_DT_BF16) return rc;         // bf16 views never reach the fp32 kernels
     }
     if (p.dtype == MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
@@ -1268,6 +1268,16 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
             if (rc) return rc;
         }
     if (pack) {
+        {   // classes planned for the bf16 kernel
+            bool any = false;
+            for (int k = 0; k < 4; ++k) any = any || L[k].b.set;
+            if (any) {
+                BConvLaunch LB[4];
+                for (int k = 0; k < 4; ++k) LB[k] = L[k].b;
+                rc = mrdis_launch_bconv_planned(LB, (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        }
         // classes that were planned for tapconv_kernel (not launched yet): one launch if they agree on the instantiation, else one each
         bool all = true;
         for (int k = 0; k < 4; ++k) all = all && L[k].set;

@@ -21,6 +21,15 @@ struct TapConvParams {
 };
 
 
+// bf16 kernels (mrdis_bf16.hip): geometry of a launch, and a planned-but-not-launched launch (the four parity classes of a stride-2
+// data gradient are planned one by one and launched together)
+struct BConvGeom {
+    int tiles;            // position tiles (tilesA * tilesB * tilesN)
+    int nchunks;          // Cin / KC
+    int tile_stride;      // workgroups walking one cout tile (gridDim.x / coTiles)
+};
+struct BConvLaunch { TapConvParams p; BConvGeom g; int KC, waves_c, wp, wc, grid; size_t lds; bool set; };
+
 struct TileChoice { int NB, TH, TW; };
 
 static inline TileChoice choose_tile(int N, int A, int B, int BMv = TC_BM) {
@@ -39,4 +48,5 @@ static inline TileChoice choose_tile(int N, int A, int B, int BMv = TC_BM) {
 
 
 // mrdis_bf16.hip: the same tap-table launch on v_mfma_f32_32x32x16_bf16; MRDIS_EUNSUPPORTED = not eligible (caller falls back)
-int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s);
+int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BConvLaunch* defer = nullptr);
+int mrdis_launch_bconv_planned(const BConvLaunch (&L)[4], hipStream_t s);
