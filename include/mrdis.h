@@ -56,6 +56,8 @@ int mrdis_version(void);
  *           (mrdis_wgrad16.hip), stride-2 first layers and 4 -> C weight gradient (mrdis_wgrad_s2.hip), 1x1 head (mrdis_pointwise.hip),
  *           16-cout and 4-cout 3x3 layers (mrdis_c16.hip, mrdis_co4.hip): the generic tile kernels run those layers (tests and
  *           tools/ use it for A/B; results agree to fp32 rounding);
+ *   "debug_nopack" (MRDIS_DEBUG_NOPACK, default 0): 1 = the four output-parity classes of a stride-2 data gradient as four launches
+ *           instead of one (bit-identical results; A/B switch);
  *   other "debug_*": kernel-selection overrides used by tools/ (see csrc/mrdis_elem.hip OPT_DEFS).
  * set: 0 or MRDIS_EINVAL (unknown name); get: the value, or MRDIS_EINVAL for an unknown name.  Not synchronised with launches
  * in flight on other threads. */

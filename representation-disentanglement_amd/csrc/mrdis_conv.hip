@@ -1247,7 +1247,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
     }
     // stride 2: dx[hi] gathers dy[(hi + pad - r)/2] for the taps r with (hi + pad - r) even.
     TapLaunch L[4];
-    const bool pack = !mrdis_opt(MRDIS_OPT_NOW16);           // (debug_now16 = 1: the four classes as four launches, as before)
+    const bool pack = !mrdis_opt(MRDIS_OPT_NOW16) && !mrdis_opt(MRDIS_OPT_NOPACK);      // (debug_now16 / debug_nopack = 1: four launches, as before)
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             TapConvParams p = base;

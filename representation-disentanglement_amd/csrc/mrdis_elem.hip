@@ -1408,6 +1408,7 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
     {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
     {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},
+    {"debug_nopack", "MRDIS_DEBUG_NOPACK", 1, 0},   // 1: the four parity classes of a stride-2 data gradient as four launches
     {"debug_mode", "MRDIS_DEBUG_MODE", 0, -1}, {"debug_bn", "MRDIS_DEBUG_BN", 0, -1}, {"debug_kc", "MRDIS_DEBUG_KC", 0, -1},
     {"debug_bm", "MRDIS_DEBUG_BM", 0, -1}, {"debug_c4_tw", "MRDIS_DEBUG_C4_TW", 0, -1}, {"debug_wgsplit", "MRDIS_DEBUG_WGSPLIT", 0, -1},
     {"debug_bn3", "MRDIS_DEBUG_BN3", 0, -1}, {"debug_kc3", "MRDIS_DEBUG_KC3", 0, -1},

@@ -579,6 +579,37 @@ def test_spade_bwd_beta_half_in_place(mrdis):
     assert torch.equal(dz, dz_ref) and torch.equal(dgb, dgb_ref)
 
 
+@pytest.mark.parametrize('case', [(32, 256, 256, 16, 16, 4), (8, 64, 128, 64, 64, 4), (6, 128, 128, 16, 16, 3), (5, 32, 64, 37, 29, 3), (3, 16, 32, 128, 128, 3)], ids=str)
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_stride2_dgrad_parity_classes_in_one_launch(mrdis, case, mode):
+    """The data gradient of a stride-2 layer runs as four output-parity classes; they share ONE launch (tapconv_pack_kernel /
+    bconv_pack_kernel, blockIdx.y = class).  Against the four-launch form (option debug_nopack = 1): bit-identical (same kernel body,
+    same per-class block mapping), odd extents (classes of different sizes) and 3x3 taps (1 / 2 / 2 / 4 taps per class) included;
+    fp32 also against torch."""
+    N, Ci, Co, H, W, k = case
+    hip = mrdis.hip
+    w = rnd((Co, Ci, k, k), 101, 0.05)
+    Ho, Wo = hip.conv_out_hw(H, W, k, k, 2, 1)
+    gy = rnd((N, Co, Ho, Wo), 102)
+    w_tkc = to_tkc(w).to(dev())
+    if mode == 'bf16':
+        dy = cl(gy).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = hip.cast_bf16(to_tck(w).to(dev()))
+        kw_ = dict(w_bf16=wb)
+    else:
+        dy, kw_ = cl(gy), {}
+    dx = hip.conv2d_bwd_data(dy, w_tkc, (H, W), k, k, 2, 1, **kw_)
+    hip.set_option('debug_nopack', 1)
+    try:
+        dx4 = hip.conv2d_bwd_data(dy, w_tkc, (H, W), k, k, 2, 1, **kw_)
+    finally:
+        hip.set_option('debug_nopack', 0)
+    assert torch.equal(dx, dx4), 'one launch vs four launches'
+    if mode == 'f32':
+        want = torch.nn.grad.conv2d_input((N, Ci, H, W), w, gy, 2, 1)
+        close(dx, want, rtol=3e-5, what='stride-2 dgrad')
+
+
 def test_conv_large_grid_256_position_tiles(mrdis):
     """a 32-cout layer with >= 4096 workgroups takes the 256-position tile variant of tapconv_kernel (forward
     and data gradient), ragged in both image dimensions.  wino=0: under the default policy this grid would go to the
