@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import ref_data as RD
-from oracle.gen_golden import DATA_CFG, data_lists
+from fixtures import DATA_CFG, data_lists
 
 
 def _volumes():

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_model as R                                   # noqa: E402
-from oracle.gen_golden import make_inputs, make_seg_targets, reinit_discriminator, seeded   # noqa: E402
+from fixtures import make_inputs, make_seg_targets, reinit_discriminator, seeded   # noqa: E402
 
 
 @pytest.fixture(scope='module')

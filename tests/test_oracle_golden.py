@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_model as R
-from oracle.gen_golden import make_inputs, make_seg_targets, reinit_discriminator, seeded
+from fixtures import make_inputs, make_seg_targets, reinit_discriminator, seeded
 
 TOL = dict(rtol=2e-5, atol=2e-6)
 
