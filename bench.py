@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # dense f32-input MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
 # north-star conv x(32,4,240,240) -> y(32,32,240,240), W(32,4,3,3), fp32
 NS = dict(N=32, Ci=4, Co=32, H=240, W=240, k=3)
 NS_BYTES = 4 * (NS['N'] * NS['Ci'] * NS['H'] * NS['W'] + NS['N'] * NS['Co'] * NS['H'] * NS['W'] + NS['Co'] * NS['Ci'] * 9 + NS['Co'])
@@ -130,6 +131,58 @@ def roofline_conv(mrdis, dev, iters=24, extras=True):
             'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us_rot * 1e-6) / 1e12, 2)}
 
 
+def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
+    """The three kernel families that dominate the step -- the fused gamma | beta convolutions of the full-, half- and
+    quarter-resolution SPADE blocks (reference model.py:2443-2444; 16 calls each per step, forward + data gradient + weight
+    gradient = ~40 % of the step) -- timed live with HIP events at the shapes of the timed step and priced against the MFMA peak
+    of the arithmetic type.  fp32: Winograd F(2x2,3x3) executes 4/9 of the direct multiplies, so `frac` = direct-equivalent
+    FLOPs x 4/9 / time / 157.3 TF (the kernels' own MFMA work against the matrix pipe); bf16: direct FLOPs / time / bf16 peak,
+    and the HBM fraction of the layer's algorithmic bytes beside it (these layers are HBM-bound in bf16)."""
+    hip = mrdis.hip
+    bf = dtype != 'f32'
+    out = []
+    for name, ci, d in (('sp6.gamma+beta', 32, 1), ('sp5.gamma+beta', 64, 2), ('sp4.gamma+beta', 128, 4)):
+        co, h, w = 2 * ci, H // d, W // d
+        el = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        x = torch.randn(B, ci, h, w, device=dev).to(el).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, co, h, w, device=dev).to(el).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(9, ci, co, device=dev) * 0.05
+        wk = wt.permute(0, 2, 1).contiguous()
+        bias = torch.zeros(co, device=dev)
+        wb_f = hip.cast_bf16(wk) if bf else None
+        wb_b = hip.cast_bf16(wt) if bf else None
+        dt = hip.DT_F32_BF16M if bf else hip.DT_F32
+        fns = {'fwd': lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb_f),
+               'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b),
+               'wgrad': lambda: hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, dtype=dt)}
+        flop = 2.0 * 9 * ci * co * B * h * w
+        nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
+        row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
+               'algorithmic_bytes': nbytes}
+        for k_, fn in fns.items():
+            fn(); fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            if bf:
+                row[k_] = {'us': round(us, 1), 'tflops': round(flop / us / 1e6, 1), 'frac_mfma': round(flop / us / 1e6 / MFMA_BF16_PEAK_TF, 3),
+                           'gbs': round(nbytes / us / 1e3, 0), 'frac_hbm': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3)}
+            else:
+                row[k_] = {'us': round(us, 1), 'direct_equiv_tflops': round(flop / us / 1e6, 1),
+                           'frac_mfma': round(flop * 4 / 9 / us / 1e6 / MFMA_F32_PEAK_TF, 3)}
+        out.append(row)
+        del x, dy
+    return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
+            'pricing': 'fp32: direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) / time / 157.3 TF' if not bf else
+                       'bf16: algorithmic bytes (x + dy in bf16) / time / 8 TB/s; direct FLOPs / time / 2500 TF beside it',
+            'timing': f'{iters} launches per entry point after 2 warm-ups, HIP events on the launch stream, shapes of the timed step',
+            'layers': out}
+
+
 def cpu_baseline(M, H, W, adv):
     """The CPU restatement of the reference step (oracle, kind 'port'), bounded sample."""
     from oracle import ref_model as R
@@ -183,6 +236,12 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     if world > 1:
+        # one host serves all ranks: give each rank its share of the cores (torch's default is every core per process,
+        # which makes N ranks fight over the same cores while they enqueue ~3,000 launches per step)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        torch.set_num_threads(max(1, min(8, ncpu // max(1, local_world))))
+    if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     import mrdis
     mrdis.hip.load()
@@ -224,6 +283,9 @@ def main():
         step(xd, maskd, mimgd, mask, targets=tgt)
         torch.cuda.synchronize()
         log(f'warm-up step {i} done, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
+    if step.reducer is not None:
+        step.reducer.exposed_ms()                 # reset the exchange diagnostics (warm-up steps)
+        step.reducer.timing = True
     sync()
     t0 = time.perf_counter()
     host_ms = 0.0
@@ -231,13 +293,34 @@ def main():
         h0 = time.perf_counter()
         loss, parts, _ = step(xd, maskd, mimgd, mask, targets=tgt)
         host_ms += (time.perf_counter() - h0) * 1e3
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0           # this rank's own time for the K steps (before the closing barrier)
     sync()
     dt = time.perf_counter() - t0
     host_ms /= a.steps
+    ddp = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # what the exchange cost: per rank [own ms/step, host enqueue ms/step, compute-stream wait for the all-reduce ms/step]
+        step.reducer.timing = False
+        ex = step.reducer.exposed_ms()
+        mine = torch.tensor([dt_local / a.steps * 1e3, host_ms, ex['exposed_ms'] / a.steps], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        ddp = {'per_rank_ms_per_step': [round(float(v), 2) for v in allr[:, 0]],
+               'rank_ms_per_step_min': round(float(allr[:, 0].min()), 2), 'rank_ms_per_step_max': round(float(allr[:, 0].max()), 2),
+               'host_enqueue_ms_per_step_per_rank': [round(float(v), 1) for v in allr[:, 1]],
+               'allreduce_wait_ms_per_step_per_rank': [round(float(v), 3) for v in allr[:, 2]],
+               'allreduce_wait_ms': round(float(allr[:, 2].max()), 3),
+               'allreduce_wait_note': 'HIP events on the compute stream around the waits in GradAllReduce.finish(): time the compute stream '
+                                      'idles for the gradient exchange per step (max over ranks); includes waiting for the slowest rank to arrive',
+               'bytes_reduced_per_step': int(ex['bytes_reduced'] // max(1, a.steps)), 'buckets': ex['buckets'],
+               'buckets_launched_during_backward_per_step': round(ex['early_buckets'] / max(1, a.steps), 2),
+               'finish_calls_per_step': round(ex['finish_calls'] / max(1, a.steps), 2),
+               'host_threads_per_rank': torch.get_num_threads()}
     ms = dt / a.steps * 1e3
     value = B * world / (dt / a.steps)
     host_losses = step.losses_to_host(parts)
@@ -275,21 +358,33 @@ def main():
                        'global_batch': B * world, 'per_gpu_batch': B, 'modalities': M, 'input_hw': [H, W],
                        'parallelism': f'dp{world}', 'missing_modality': bool(a.drop),
                        'output_decoder': bool(a.recon_y),
-                       'conv_algorithms': 'fp32 throughout; direct MFMA kernels + fused Winograd F(2x2,3x3) for the big 3x3 stride-1 layers '
-                                          f'(option wino = {mrdis.hip.get_option("wino")}; 0 = direct only)'},
+                       'conv_algorithms': {
+                           'f32': 'fp32 throughout; direct MFMA kernels + fused Winograd F(2x2,3x3) for the big 3x3 stride-1 layers '
+                                  f'(option wino = {mrdis.hip.get_option("wino")}; 0 = direct only)',
+                           'bf16': 'bf16 activations in HBM, direct convolutions on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); fp32 kernels '
+                                   'on the 4- / 7-channel boundary layers; fp32 statistics, losses, master weights, optimizer',
+                           'bf16m': 'fp32 activations, bf16 MFMA operands (fp32 accumulate) in the direct convolution kernels'}[a.dtype]},
             'loss': round(host_losses['all'], 5),
-            'step_tflops_f32': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
-            'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)',
-            'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
+            'step_tflops': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
+            'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time' + (
+                ' (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)' if a.dtype == 'f32' else ''),
+            'mfma_peak_tflops': MFMA_F32_PEAK_TF if a.dtype == 'f32' else MFMA_BF16_PEAK_TF,
+            'mfma_peak_dtype': 'f32' if a.dtype == 'f32' else 'bf16',
             'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),
-            'step_tflops_f32_direct_only': None if ms_direct is None else round(
+            'step_tflops_direct_only': None if ms_direct is None else round(
                 FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
         }
         log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
         out['host_enqueue_ms_per_step'] = round(host_ms, 1)
+        if ddp is not None:
+            out['ddp'] = ddp
+            out['allreduce_wait_ms'] = ddp['allreduce_wait_ms']
+            out['bytes_reduced'] = ddp['bytes_reduced_per_step']
         if not a.no_roofline:
             out['roofline'] = roofline_conv(mrdis, dev)
             log(f'roofline: {out["roofline"]}')
+            out['roofline_step'] = roofline_step(mrdis, dev, B, H, W, a.dtype)
+            log(f'roofline_step: {out["roofline_step"]}')
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(M, H, W, adv)
         print(json.dumps(out), flush=True)

@@ -295,12 +295,16 @@ int mrdis_sumsq_finite(const float* g, long long n, float* out, void* workspace,
  * as non-finite; a skipped step does not advance the bias correction.
  * gates (n_gates <= 32): HOST arrays gate_ranges[2k], [2k+1] = index range [lo, hi) of the arena, gate_flag_index[k] = entry
  * of the DEVICE array gate_flags that gates it: a range whose flag is 0 is left untouched (torch's Adam skips parameters
- * whose grad is None: a decoder whose modality is absent from the whole batch).                                      */
+ * whose grad is None: a decoder whose modality is absent from the whole batch).
+ * gate_steps (DEVICE float[3 * n_flags], zero-initialised, or NULL; needs step_state): per-flag step counters.  torch's Adam
+ * keeps `step` per parameter and does not advance it while the gradient is None, so the ranges of flag k are bias-corrected
+ * with [k] = the number of applied steps in which flag k was set (incremented by this call); [n_flags ..) is scratch
+ * for the (1 - beta1^t, sqrt(1 - beta2^t)) pairs.  NULL: gated ranges use the arena-wide counter.                  */
 int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                             long long n, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int step_count, float* step_state, const float* norm_finite,
                             float max_norm, float grad_scale, const long long* gate_ranges, const int* gate_flag_index,
-                            int n_gates, const float* gate_flags, void* stream);
+                            int n_gates, const float* gate_flags, float* gate_steps, int n_flags, void* stream);
 
 /* ==== 3-D path: the Conv3d / GroupNorm / Upsample layers of BasicBlock, UNet3D, VAEBranch and
  * NVNet3D (src/model.py:1856-2060).  Tensors are NDHWC fp32 views (torch.channels_last_3d); 1x1x1 convolutions go

@@ -1316,15 +1316,30 @@ extern "C" int mrdis_sumsq_finite(const float* g, long long n, float* out, void*
 #define ADAM_MAX_GATES 32
 struct AdamGates { int n; long long lo[ADAM_MAX_GATES], hi[ADAM_MAX_GATES]; int flag[ADAM_MAX_GATES]; };
 
-// step_state[0] = optimizer steps applied so far, [1] = steps skipped because a gradient was non-finite
-__global__ void adam_advance_kernel(float* __restrict__ step_state, const float* __restrict__ norm_finite) {
+// step_state[0] = optimizer steps applied so far, [1] = steps skipped because a gradient was non-finite.
+// gate_steps (float[3 * n_flags] or NULL): [k] = steps applied to gate group k -- torch.optim.Adam keeps `step` PER PARAMETER and does
+// not advance it while the parameter's gradient is None, so a decoder whose modality was absent for some batches is bias-corrected
+// with ITS count, not the arena's; [n_flags + 2k], [n_flags + 2k + 1] = that group's (1 - b1^t, sqrt(1 - b2^t)), written here so that
+// the element kernel loads two floats instead of evaluating powf per element.
+__global__ void adam_advance_kernel(float* __restrict__ step_state, const float* __restrict__ norm_finite,
+                                    float* __restrict__ gate_steps, const float* __restrict__ gate_flags, int n_flags, float b1, float b2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (norm_finite && norm_finite[1] > 0.f) step_state[1] += 1.f; else step_state[0] += 1.f;
+    const bool skipped = norm_finite && norm_finite[1] > 0.f;
+    if (skipped) step_state[1] += 1.f; else step_state[0] += 1.f;
+    if (gate_steps && gate_flags) {
+        for (int k = 0; k < n_flags; ++k) {
+            float t = gate_steps[k];
+            if (!skipped && gate_flags[k] != 0.f) { t += 1.f; gate_steps[k] = t; }
+            gate_steps[n_flags + 2 * k] = 1.f - powf(b1, t);
+            gate_steps[n_flags + 2 * k + 1] = sqrtf(1.f - powf(b2, t));
+        }
+    }
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sbc2,
                             const float* __restrict__ norm_finite, float max_norm, float gscale,
-                            const float* __restrict__ step_state, const float* __restrict__ gate_flags, AdamGates gates) {
+                            const float* __restrict__ step_state, const float* __restrict__ gate_flags, AdamGates gates,
+                            const float* __restrict__ gate_steps, int n_flags) {
     float coef = gscale;
     if (norm_finite) {
         if (norm_finite[1] > 0.f) return;                       // non-finite gradient: skip the step (main_missing.py:273-278)
@@ -1338,12 +1353,20 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float t = step_state[0];
         bc1 = 1.f - powf(b1, t); sbc2 = sqrtf(1.f - powf(b2, t));
     }
-    const float step = lr / bc1;
+    const float step0 = lr / bc1, sbc20 = sbc2;
     EW_LOOP(n) {
+        float step = step0;
+        sbc2 = sbc20;
         if (gate_flags) {
             bool off = false;
-            for (int k = 0; k < gates.n; ++k) off |= (idx >= gates.lo[k] && idx < gates.hi[k] && gate_flags[gates.flag[k]] == 0.f);
+            int gk = -1;
+            for (int k = 0; k < gates.n; ++k)
+                if (idx >= gates.lo[k] && idx < gates.hi[k]) { gk = gates.flag[k]; off |= gate_flags[gk] == 0.f; }
             if (off) continue;
+            if (gk >= 0 && gate_steps) {                            // this range's own step count (torch: per-parameter `step`)
+                step = lr / gate_steps[n_flags + 2 * gk];
+                sbc2 = gate_steps[n_flags + 2 * gk + 1];
+            }
         }
         const float pv = p[idx];
         const float gv = g[idx] * coef + wd * pv;
@@ -1358,15 +1381,19 @@ extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float
                                        long long n, float lr, float beta1, float beta2, float eps,
                                        float weight_decay, int step_count, float* step_state, const float* norm_finite,
                                        float max_norm, float grad_scale, const long long* gate_ranges, const int* gate_flag_index,
-                                       int n_gates, const float* gate_flags, void* stream) {
+                                       int n_gates, const float* gate_flags, float* gate_steps, int n_flags, void* stream) {
     if (!p || !g || !m || !v || !vmax || n < 1 || (!step_state && step_count < 1)) return MRDIS_EINVAL;
     if (n_gates < 0 || n_gates > ADAM_MAX_GATES || (n_gates > 0 && (!gate_ranges || !gate_flag_index || !gate_flags))) return MRDIS_EINVAL;
+    if (gate_steps && (n_gates == 0 || !step_state || n_flags < 1 || n_flags > ADAM_MAX_GATES)) return MRDIS_EINVAL;
+    for (int k = 0; k < n_gates; ++k)
+        if (gate_flag_index[k] < 0 || (gate_steps && gate_flag_index[k] >= n_flags)) return MRDIS_EINVAL;
     AdamGates gates{};
     gates.n = n_gates;
     for (int k = 0; k < n_gates; ++k) { gates.lo[k] = gate_ranges[2 * k]; gates.hi[k] = gate_ranges[2 * k + 1]; gates.flag[k] = gate_flag_index[k]; }
     float bc1 = 1.f, sbc2 = 1.f;
     if (step_state) {
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, norm_finite);
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, norm_finite,
+                           gate_steps, n_gates > 0 ? gate_flags : (const float*)nullptr, n_flags, beta1, beta2);
         MRDIS_CHECK_LAUNCH();
     } else {
         bc1 = 1.f - powf(beta1, (float)step_count);
@@ -1374,7 +1401,7 @@ extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float
     }
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, sbc2, norm_finite, max_norm, grad_scale, (const float*)step_state,
-                       n_gates > 0 ? gate_flags : (const float*)nullptr, gates);
+                       n_gates > 0 ? gate_flags : (const float*)nullptr, gates, (const float*)gate_steps, n_flags);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

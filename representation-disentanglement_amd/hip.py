@@ -75,7 +75,7 @@ _SIGS = {
     'mrdis_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mrdis_sumsq_workspace': (_Z, []),
     'mrdis_sumsq_finite': (_I, [_P, _L, _P, _P, _Z, _P]),
-    'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P]),
+    'mrdis_adam_amsgrad_step': (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P, _I, _P]),
     'mrdis_conv3d_fwd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv3d_bwd_data': (_I, [_P, _I, _P, _P, _I] + [_I] * 9 + [_P]),
     'mrdis_conv3d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -792,9 +792,10 @@ def sumsq_finite(g, out):
 
 
 def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, norm_finite, max_norm, grad_scale=1.0,
-                      step_state=None, gates=None):
+                      step_state=None, gates=None, gate_steps=None):
     """step: 1-based host count, ignored when `step_state` (device float[2]: applied, skipped) is given.
-    gates: (ranges [(lo, hi), ...], flag_index [...], flags device tensor) or None."""
+    gates: (ranges [(lo, hi), ...], flag_index [...], flags device tensor) or None.
+    gate_steps: device float[3 * n_flags] per-flag step counters (+ scratch), see include/mrdis.h."""
     lib = load()
     if gates is not None and len(gates[0]):
         ranges, fidx, flags = gates
@@ -804,8 +805,13 @@ def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, ste
         fl = flags.data_ptr()
     else:
         n_g, ra, fa, fl = 0, None, None, None
+    n_flags = 0
+    if n_g and gate_steps is not None:
+        n_flags = gate_steps.numel() // 3
+    else:
+        gate_steps = None
     _chk(lib.mrdis_adam_amsgrad_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                                     int(step), _ptr(step_state), _ptr(norm_finite), max_norm, grad_scale, ra, fa, n_g, fl, _stream()),
+                                     int(step), _ptr(step_state), _ptr(norm_finite), max_norm, grad_scale, ra, fa, n_g, fl, _ptr(gate_steps), n_flags, _stream()),
          'adam_amsgrad_step')
 
 

@@ -657,6 +657,36 @@ class MultimodalModel(nn.Module):
             out.append(p)
         return out
 
+    # ---- expert mixing in groups (ops.premix_all) and the order in which their gradients complete
+    def mix_groups(self):
+        """[(name, [root modules])]: the CondConv2d layers under each entry are mixed by one launch right before the entry's first
+        use in a step and their gradients are taken apart by one backward node per entry."""
+        M = self.modality_num
+        g = [('enc', list(self.anatomy_encoder_enc_list) + [self.anatomy_encoder_dec] + list(self.modality_encoder_list)),
+             ('dec_shared', [self.input_decoder_list[-1]])]
+        g += [(f'dec{i}', [self.input_decoder_list[i]]) for i in range(M)]
+        return g
+
+    def premix(self, name):
+        """mix the experts of group `name` for all modality labels (no-op outside a training step / when already done this step)."""
+        roots = self.__dict__.get('_mix_roots')
+        if roots is None:
+            roots = self.__dict__['_mix_roots'] = dict(self.mix_groups())
+        return ops.premix_all(self, self._type_table, name, roots[name])
+
+    def completion_groups(self):
+        """parameter lists in the order in which a step's backward pass completes their gradients: the modality decoders in reverse
+        call order (each is done when its last SPADE block has back-propagated), then the shared decoder, then everything that the
+        FIRST encoder pass uses (encoders, discriminator: complete only at the very end).  The optimizer lays the gradient arena out
+        in this order and the data-parallel reducer cuts its buckets at the group boundaries, so a bucket can leave as soon as
+        its group's backward node has run."""
+        M = self.modality_num
+        groups = [list(self.input_decoder_list[i].parameters()) for i in reversed(range(M))]
+        groups.append(list(self.input_decoder_list[-1].parameters()))
+        seen = {id(p) for g in groups for p in g}
+        groups.append([p for p in self.parameters() if id(p) not in seen])
+        return groups
+
     def gated_parameter_groups(self):
         """group i = the parameters of input decoder i (SPADENewNotShared): they get a gradient only from batches in which
         modality i is present (every loss term through decoder i is masked by mask[:, i], model.py:3319-3341, 3388);
@@ -727,6 +757,7 @@ class MultimodalModel(nn.Module):
 
         def make():
             M, B = self.modality_num, si_list[0].shape[0]
+            self.premix('dec_shared')
             s_cat = torch.cat(list(si_list), 0)
             mids = {}
             for j in range(M):
@@ -752,6 +783,7 @@ class MultimodalModel(nn.Module):
             types = [self._type(j, B) for j in range(M)]
             outs = {}
             for i in range(M):
+                self.premix(f'dec{i}')
                 z_cat = torch.cat([mids[(i, j)] for j in range(M)], 0)
                 y = self.input_decoder_list[i].forward_grouped(si_list[i], z_cat, types)
                 for j, part in enumerate(ops.split_batch(y, M)):
@@ -768,6 +800,7 @@ class MultimodalModel(nn.Module):
             return [allo[(i, i)] for i in range(self.modality_num)]
         mids = self._shared_mids(si_list, zi_list)
         for i in range(self.modality_num):
+            self.premix(f'dec{i}')
             out.append(self.input_decoder_list[i](si_list[i], mids[(i, i)], self._type(i, B)))
         return out
 
@@ -780,6 +813,7 @@ class MultimodalModel(nn.Module):
             return [allo[(i, j)] for i in range(self.modality_num) for j in range(self.modality_num) if i != j]
         mids = self._shared_mids(si_list, zi_list)
         for i in range(self.modality_num):
+            self.premix(f'dec{i}')
             for j in range(self.modality_num):
                 if i == j:
                     continue

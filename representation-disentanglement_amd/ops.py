@@ -158,8 +158,9 @@ class MixPlan:
     dead once its backward has run, so every step writes the same storage and the job table is built once -- the routing values,
     the partial-sum workspace and the job table in device memory.  None if a parameter has no in-kernel gradient sink."""
 
-    def __init__(self, singles, pairs, M, want_bf16, device, pad16=False):
+    def __init__(self, singles, pairs, M, want_bf16, device, pad16=False, group=None):
         self.singles, self.pairs, self.M, self.want_bf16 = singles, pairs, M, want_bf16
+        self.group = group
         self.params = []
         self.probe = singles[0].weight if singles else (pairs[0][1].weight if pairs else None)
         shapes = []                                    # per entry: (T, Ci, Cw) with Cw = Co or 2 C
@@ -229,6 +230,10 @@ class MixPlan:
         self.jobs, self.device = jobs, device
         self.table = hip.mix_job_table(jobs, device)
         self.tables = {self.probe.grad.data_ptr(): self.table}       # by gradient arena: the d-step re-points every .grad (trainer.py)
+        # every parameter whose gradient is complete once this plan's backward has been enqueued: expert weights and routing
+        # parameters (written by that launch) and the layers' biases (written by the weight-gradient launches that produced its inputs)
+        mods = list(singles) + [m for _, g, b in pairs for m in (g, b)]
+        self.ready_params = list(self.params) + [m.bias for m in mods if m.bias is not None]
 
     def table_for_current_sinks(self):
         """the job table whose gradient sinks are the parameters' CURRENT .grad buffers (TrainStep attaches another optimizer's arena for
@@ -305,34 +310,60 @@ class _MixAllLayers(Function):
                 acc[k, mm] = g.data_ptr() + 4 * col0
         dev_tab = to_device(ptrs, types.device)
         hip.mix_jobs_bwd(plan.table_for_current_sinks(), plan.njobs, plan.blocks, dev_tab, types)
+        if _GROUP_READY is not None:
+            _GROUP_READY(plan.ready_params)            # in-kernel sinks fire no autograd hook: the exchange of this group's buckets starts here
         return (None, None) + (None,) * (len(plan.params))
 
 
 _PREMIX = _os.environ.get('MRDIS_PREMIX', '1') != '0'
 
 
-def premix_all(model, table):
-    """Fill the step's mixed-filter cache for every CondConv2d layer of `model` with one launch (see MixPlan); no-op outside a
-    training step, without gradient sinks, or when disabled (MRDIS_PREMIX=0).  The modules find their filters under the same cache
-    keys their own lazy mixing would have used."""
+_GROUP_READY = None
+
+
+def set_group_ready_hook(fn):
+    """fn(list of parameters) is called from the backward of each all-layers mixing node, right after its launches: the gradients of
+    those parameters (in-kernel sinks, which fire no post-accumulate hook) are complete in stream order.  trainer.GradAllReduce
+    starts the all-reduce of the buckets they fill from here.  None removes the hook."""
+    global _GROUP_READY
+    _GROUP_READY = fn
+
+
+def premix_all(model, table, group=None, roots=None):
+    """Fill the step's mixed-filter cache for every CondConv2d layer under `roots` (default: the whole model) with one launch
+    (see MixPlan); no-op outside a training step, without gradient sinks, or when disabled (MRDIS_PREMIX=0).  The modules find
+    their filters under the same cache keys their own lazy mixing would have used.
+    `group` names the plan: the model mixes its layers in GROUPS (encoders | shared decoder | one per modality decoder,
+    MultimodalModel.mix_groups), each right before its first use, so that each group's backward node sits in the autograd graph
+    behind the group's own layers and runs as soon as their filter gradients exist -- not at the very end of the backward pass:
+    the data-parallel exchange of a group's gradients then overlaps the backward of everything that was computed before it."""
     if not _PREMIX or _MIX_CACHE is None or not torch.is_grad_enabled() or not table.is_cuda:
         return False
+    if _MIX_CACHE.get(('premixed', id(model), group)):
+        return True
     want16 = _COMPUTE_DTYPE != hip.DT_F32
-    key = (table.shape[0], _COMPUTE_DTYPE, table.device)
+    key = (table.shape[0], _COMPUTE_DTYPE, table.device, group)
     plans = model.__dict__.setdefault('_mrdis_mix_plans', {})
     plan = plans.get(key)
     if plan is not None and not plan.ok and plan.probe is not None and _grad_sink(plan.probe) is not None:
         plan = None                                   # built before the optimizer gave the parameters their gradient buffers
     if plan is None or (plan.ok and not plan.still_valid()):
-        singles, pairs, fused_ids = [], [], set()
+        singles, pairs, fused_ids, seen = [], [], set(), set()
         from . import model as _model
-        for blk in model.modules():
-            if isinstance(blk, _model.SPADEBlockNew) and blk.is_cond and blk.gamma.weight.shape == blk.beta.weight.shape:
-                pairs.append((blk, blk.gamma, blk.beta)); fused_ids.update((id(blk.gamma), id(blk.beta)))
-        for m in model.modules():
-            if isinstance(m, _model.CondConv2d) and id(m) not in fused_ids:
-                singles.append(m)
-        plan = plans[key] = MixPlan(singles, pairs, table.shape[0], want16, table.device, pad16=_COMPUTE_DTYPE == hip.DT_BF16)
+        roots_ = [model] if roots is None else list(roots)
+        for root in roots_:
+            for blk in root.modules():
+                if isinstance(blk, _model.SPADEBlockNew) and blk.is_cond and blk.gamma.weight.shape == blk.beta.weight.shape and id(blk) not in seen:
+                    seen.add(id(blk))
+                    pairs.append((blk, blk.gamma, blk.beta)); fused_ids.update((id(blk.gamma), id(blk.beta)))
+        for root in roots_:
+            for m in root.modules():
+                if isinstance(m, _model.CondConv2d) and id(m) not in fused_ids and id(m) not in seen:
+                    seen.add(id(m))
+                    singles.append(m)
+        if not singles and not pairs:
+            return False
+        plan = plans[key] = MixPlan(singles, pairs, table.shape[0], want16, table.device, pad16=_COMPUTE_DTYPE == hip.DT_BF16, group=group)
     if not plan.ok:
         return False
     holder = [plan]
@@ -352,6 +383,7 @@ def premix_all(model, table):
                 a = allw[2 * mm]
                 btck, btkc = ents16[ei][mm]
                 _MIX_CACHE[('bf16w', id(a))] = (a, btkc, btck)
+    _MIX_CACHE[('premixed', id(model), group)] = True
     return True
 
 

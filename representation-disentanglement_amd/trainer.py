@@ -131,11 +131,15 @@ class ArenaAdam(torch.optim.Optimizer):
     * gates: groups of parameters that receive no gradient when their modality is absent from the whole batch
       (`set_gates`); the per-group activity flags ride at the tail of the gradient buffer (so a data-parallel sum
       all-reduce ORs them across ranks) and the Adam kernel leaves a gated-off range untouched, as torch's Adam does
-      for `grad is None`.
+      for `grad is None`.  torch keeps `step` per parameter and does not advance it for a skipped parameter: each gate
+      group has its own device step counter (`gate_steps`), used for the bias correction of its ranges and exported /
+      imported as the per-parameter `step` of the checkpoint.
     """
 
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, max_norm=1.0, used=None,
-                 share_weights_of=None):
+                 share_weights_of=None, order=None):
+        """order: parameter lists in the order their gradients complete during backward (MultimodalModel.completion_groups);
+        the arena is laid out in that order and `group_edges` holds the boundaries (GradAllReduce cuts its buckets there)."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=True, maximize=False, foreach=None,
                         capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
         super().__init__(list(params), defaults)
@@ -146,7 +150,10 @@ class ArenaAdam(torch.optim.Optimizer):
         self.used = None
         self.norm_finite = self.step_state = None
         self.gate_ranges, self.gate_flag_index, self.gate_flags, self.n_flags = [], [], None, 0
+        self.gate_steps, self.gate_of = None, {}
         self._share = share_weights_of
+        self._order = order
+        self.group_edges = None
         if share_weights_of is not None:
             self._build(share_weights_of.used)
         elif used is not None:
@@ -177,14 +184,22 @@ class ArenaAdam(torch.optim.Optimizer):
             if not used:
                 raise RuntimeError('ArenaAdam.step() before any backward()')
         used = [p for p in used if p.requires_grad]
-        # parameters whose gradient the backward kernels add to in place (ops._grad_sink) never pass through autograd's
-        # accumulation, so their post-accumulate hooks do not fire: keep them together at the end of the arena, i.e. in
-        # the last all-reduce bucket (GradAllReduce.finish() reduces it after backward; the others keep overlapping)
-        used.sort(key=lambda p: 1 if getattr(p, '_mrdis_sink', False) else 0)
+        rank_of = {}
+        if self._order is not None:
+            # completion order of the backward pass: group k's gradients are complete before group k + 1's, so the arena is
+            # laid out group by group and a bucket of the data-parallel exchange never waits for a later group
+            for k, grp in enumerate(self._order):
+                for p in grp:
+                    rank_of.setdefault(id(p), k)
+        # within a group (or without an order): parameters whose gradient the backward kernels add to in place (ops._grad_sink)
+        # fire no post-accumulate hook; keep them behind the hook-driven ones (stable sort: constructor order otherwise)
+        ngrp = len(self._order) if self._order is not None else 0
+        used.sort(key=lambda p: (rank_of.get(id(p), ngrp), 1 if getattr(p, '_mrdis_sink', False) else 0))
         dev = used[0].device
         share = self._share
         if share is not None:                   # second optimizer over the same weights (optimizer_d_s, main_missing.py:121-122)
             self.offsets, self.numel, self.flat_p = share.offsets, share.numel, share.flat_p
+            self.group_edges = share.group_edges
             n = self.numel
         else:
             # 16-byte align every tensor inside the arena (vectorised kernels read params in place)
@@ -192,6 +207,14 @@ class ArenaAdam(torch.optim.Optimizer):
             for p in used:
                 offs.append(n); n += (p.numel() + 3) // 4 * 4
             self.offsets, self.numel = offs, n
+            if self._order is not None:
+                edges, prev = [0], rank_of.get(id(used[0]), ngrp)
+                for p, o in zip(used, offs):
+                    r = rank_of.get(id(p), ngrp)
+                    if r != prev:
+                        edges.append(o); prev = r
+                edges.append(n)
+                self.group_edges = edges
             self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self._g_full = torch.zeros(n + self.TAIL, dtype=torch.float32, device=dev)
         self.flat_g = self._g_full[:n]
@@ -239,6 +262,9 @@ class ArenaAdam(torch.optim.Optimizer):
             raise NotImplementedError('more gated segments than the Adam kernel takes (32)')
         self.gate_ranges, self.gate_flag_index, self.n_flags = ranges, fidx, len(groups)
         self.gate_flags = self._g_full[self.numel:self.numel + self.n_flags]
+        # [k] = steps applied to group k; the rest is the kernel's scratch for the bias-correction pairs (include/mrdis.h)
+        self.gate_steps = torch.zeros(3 * self.n_flags, dtype=torch.float32, device=self._g_full.device) if ranges else None
+        self.gate_of = {id(p): k for k, group in enumerate(groups) for p in group if id(p) in off}
 
     def mark_active(self, flags):
         """flags: (n_groups,) device tensor, > 0 where the group receives a gradient from this (micro-)batch."""
@@ -285,7 +311,8 @@ class ArenaAdam(torch.optim.Optimizer):
             nf = self.norm_finite
         hip.adam_amsgrad_step(self.flat_p, g, self.m, self.v, self.vmax, self.lr, self.betas[0], self.betas[1],
                               self.eps, self.wd, self.step_count, nf, self.max_norm if fused_clip else 0.0, grad_scale,
-                              step_state=self.step_state, gates=self._gates() if use_gates else None)
+                              step_state=self.step_state, gates=self._gates() if use_gates else None,
+                              gate_steps=self.gate_steps if use_gates else None)
 
     def zero_grad(self, set_to_none=True):
         if self.used is None:
@@ -305,53 +332,91 @@ class ArenaAdam(torch.optim.Optimizer):
         state = {}
         if self.used is not None:
             applied = float(self.step_state[0].item())
+            gsteps = self.gate_steps[:self.n_flags].tolist() if self.gate_steps is not None else []
             if applied > 0:
                 idx = {id(p): i for i, p in enumerate(self.params)}
                 for p, o in zip(self.used, self.offsets):
                     k = p.numel()
-                    state[idx[id(p)]] = {'step': torch.tensor(applied, dtype=torch.float32),
+                    gk = self.gate_of.get(id(p))
+                    steps = applied if gk is None else gsteps[gk]
+                    if steps <= 0:              # a gated parameter that never received a gradient: torch has no state entry for it
+                        continue
+                    state[idx[id(p)]] = {'step': torch.tensor(steps, dtype=torch.float32),
                                          'exp_avg': self.m[o:o + k].view(p.shape).clone(),
                                          'exp_avg_sq': self.v[o:o + k].view(p.shape).clone(),
                                          'max_exp_avg_sq': self.vmax[o:o + k].view(p.shape).clone()}
         return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, state_dict):
-        """accepts what torch.optim.Adam(model.parameters(), amsgrad=True).state_dict() / our own state_dict() wrote."""
+        """accepts what torch.optim.Adam(model.parameters(), amsgrad=True).state_dict() / our own state_dict() wrote.
+        The payload is validated in full BEFORE the arena is touched: a bad checkpoint raises and leaves moments, step
+        counters and hyper-parameters as they were."""
         groups = state_dict['param_groups']
         if len(groups) != 1 or len(groups[0]['params']) != len(self.params):
             raise ValueError('optimizer state_dict does not match: expected one param group over model.parameters()')
-        for k, v in groups[0].items():
-            if k != 'params':
-                self.param_groups[0][k] = v
         if self.used is None:
             if state_dict['state']:
                 raise RuntimeError('load_state_dict() needs a built arena (construct with used=...)')
+            for k, v in groups[0].items():
+                if k != 'params':
+                    self.param_groups[0][k] = v
             return
         off = {id(p): (o, p.numel()) for p, o in zip(self.used, self.offsets)}
-        applied = 0.0
+        plan = []                                # (offset, numel, entry, gate group or None)
+        applied, gsteps = 0.0, [0.0] * self.n_flags
+        for i, st in state_dict['state'].items():
+            if not 0 <= int(i) < len(self.params):
+                raise ValueError(f'optimizer state for parameter #{i}: index out of range')
+            p = self.params[int(i)]
+            if id(p) not in off:
+                raise ValueError(f'optimizer state for parameter #{i}, which is outside the arena')
+            o, k = off[id(p)]
+            for key in ('step', 'exp_avg', 'exp_avg_sq'):
+                if key not in st:
+                    raise ValueError(f'optimizer state for parameter #{i} lacks {key!r}')
+            for key in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+                if key in st and st[key].numel() != k:
+                    raise ValueError(f'optimizer state for parameter #{i}: {key} has {st[key].numel()} elements, the parameter {k}')
+            gk = self.gate_of.get(id(p))
+            s = float(st['step'])
+            if gk is None:
+                applied = max(applied, s)
+            else:
+                gsteps[gk] = max(gsteps[gk], s)
+            plan.append((o, k, st))
+        # commit
+        for k, v in groups[0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
         self.m.zero_(); self.v.zero_(); self.vmax.zero_()
         with torch.no_grad():
-            for i, st in state_dict['state'].items():
-                p = self.params[int(i)]
-                if id(p) not in off:
-                    raise ValueError(f'optimizer state for parameter #{i}, which is outside the arena')
-                o, k = off[id(p)]
+            for o, k, st in plan:
                 self.m[o:o + k].copy_(st['exp_avg'].reshape(-1)); self.v[o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
                 if 'max_exp_avg_sq' in st:
                     self.vmax[o:o + k].copy_(st['max_exp_avg_sq'].reshape(-1))
-                applied = max(applied, float(st['step']))
+        applied = max([applied] + gsteps)        # the arena-wide counter is at least every group's (a group steps only when the arena does)
         self.step_state.zero_(); self.step_state[0] = applied
+        if self.gate_steps is not None:
+            self.gate_steps.zero_()
+            self.gate_steps[:self.n_flags] = torch.tensor(gsteps, dtype=torch.float32)
         self.step_count = int(applied)
 
 
 # --------------------------------------------------------------------------- data-parallel exchange
 class GradAllReduce:
     """Sum-all-reduce of a gradient arena over the data-parallel group (RCCL over xGMI on the GPU box, gloo in the CPU
-    tests); the 1/world scale is folded into the optimizer step.  The arena is cut into `buckets` contiguous slices; a
-    slice is reduced asynchronously as soon as autograd has produced every gradient in it (post-accumulate hooks), so
-    the exchange overlaps the rest of the backward pass; the slice that holds the in-kernel gradient sinks and the
-    gate flags goes last, from finish().  BatchNorm statistics stay per replica (the reference has no SyncBN).
-    One reducer serves every optimizer that shares the arena layout: begin(optimizer) names the buffer to reduce."""
+    tests); the 1/world scale is folded into the optimizer step.  The arena is cut into contiguous buckets -- at the
+    boundaries of the optimizer's completion groups when it has them (ArenaAdam(order=...): modality decoders, shared
+    decoder, encoders), else into `buckets` equal slices -- and a bucket is reduced asynchronously as soon as every gradient
+    in it is complete: autograd-accumulated gradients report through post-accumulate hooks, in-kernel gradient sinks
+    (which fire no hook) through mark_ready(), called from the backward node of their mixing group (ops.set_group_ready_hook).
+    What is still pending after backward (the group of the first encoder pass, the gate flags) goes from finish().
+    BatchNorm statistics stay per replica (the reference has no SyncBN).  One reducer serves every optimizer that shares
+    the arena layout: begin(optimizer) names the buffer to reduce.
+
+    Diagnostics (`timing = True`): per finish(), a pair of events on the compute stream around the waits -- the time the
+    compute stream idles for the exchange (`exposed_ms`) -- the number of buckets that had left before finish()
+    (`early_buckets`) and the bytes reduced."""
 
     def __init__(self, optim, group=None, buckets=6):
         self.optim, self.group, self.nbuckets = optim, group, buckets
@@ -360,12 +425,25 @@ class GradAllReduce:
         self.handles = []
         self.hooks = []
         self.armed = False
+        self.timing = False
+        self.events, self.early_buckets, self.bytes_reduced, self.calls = [], 0, 0, 0
 
     def _setup(self):
         o = self.optim
         n = o.numel
-        edges = [int(round(n * k / self.nbuckets / 4)) * 4 for k in range(self.nbuckets + 1)]
-        edges[-1] = n
+        if getattr(o, 'group_edges', None):
+            edges = list(o.group_edges)
+            big = max(n // 3, 1)                 # a group beyond a third of the arena is cut in two (the encoders' group)
+            out = [edges[0]]
+            for a, b in zip(edges[:-1], edges[1:]):
+                if b - a > big:
+                    out.append((a + (b - a) // 2) // 4 * 4)
+                out.append(b)
+            edges = sorted(set(out))
+            self.nbuckets = len(edges) - 1
+        else:
+            edges = [int(round(n * k / self.nbuckets / 4)) * 4 for k in range(self.nbuckets + 1)]
+            edges[-1] = n
         self.edges = edges
         self.bucket_of, self.pending0 = {}, [0] * self.nbuckets
         for p, off in zip(o.used, o.offsets):
@@ -377,15 +455,28 @@ class GradAllReduce:
             self.bucket_of[id(p)] = (b, last)
             self.hooks.append(p.register_post_accumulate_grad_hook(self._hook))
         self.pending = list(self.pending0)
+        self.done = set()
 
     def _hook(self, p):
         if not self.armed:
             return
-        b, last = self.bucket_of[id(p)]
+        key = id(p)
+        if key in self.done:                     # reported twice (hook and mark_ready): counted once
+            return
+        self.done.add(key)
+        b, last = self.bucket_of[key]
         for bb in range(b, last + 1):
             self.pending[bb] -= 1
             if self.pending[bb] == 0:
                 self._launch(bb)
+
+    def mark_ready(self, params):
+        """the gradients of `params` are complete in stream order (in-kernel sinks: no hook will fire for them)."""
+        if not self.armed or not self.hooks:
+            return
+        for p in params:
+            if id(p) in self.bucket_of:
+                self._hook(p)
 
     def _launch(self, b):
         if self.world == 1 or self.launched[b]:
@@ -393,6 +484,9 @@ class GradAllReduce:
         self.launched[b] = True
         t = self.target
         hi = self.edges[b + 1] if b + 1 < self.nbuckets else t._g_full.numel()      # last bucket: + the gate flags
+        if self.armed:
+            self.early_buckets += 1
+        self.bytes_reduced += 4 * (hi - self.edges[b])
         self.handles.append(dist.all_reduce(t._g_full[self.edges[b]:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin(self, target=None):
@@ -403,24 +497,46 @@ class GradAllReduce:
         if self.hooks:
             self.pending = list(self.pending0)
             self.launched = [False] * self.nbuckets
+            self.done = set()
         self.handles = []
         self.armed = True
+        ops.set_group_ready_hook(self.mark_ready)
 
     def finish(self):
         """call after backward(); returns the scale (1/world) the optimizer must apply."""
         self.armed = False
+        ops.set_group_ready_hook(None)
         if self.world == 1:
             return 1.0
+        self.calls += 1
         if not self.hooks:                       # arena built lazily, first step: reduce per tensor
             for p in self.optim.params:
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            for b in range(self.nbuckets):       # buckets whose hooks never completed (sinks, unused grads this step)
+            for b in range(self.nbuckets):       # buckets whose gradients were not all reported (first-pass group, unused grads this step)
                 self._launch(b)
+            ev = None
+            if self.timing and self.optim.flat_p.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self.handles:
                 h.wait()
+            if ev is not None:
+                ev[1].record()
+                self.events.append(ev)
         return 1.0 / self.world
+
+    def exposed_ms(self):
+        """total time (ms) the compute stream waited for the exchange over the finish() calls since the last reset
+        (synchronises; call outside the timed region), then resets the diagnostics."""
+        if self.events:
+            torch.cuda.synchronize()
+        tot = sum(a.elapsed_time(b) for a, b in self.events)
+        out = dict(exposed_ms=tot, finish_calls=self.calls, early_buckets=self.early_buckets, bytes_reduced=self.bytes_reduced,
+                   buckets=self.nbuckets)
+        self.events, self.early_buckets, self.bytes_reduced, self.calls = [], 0, 0, 0
+        return out
 
 
 # --------------------------------------------------------------------------- one training iteration
@@ -446,7 +562,12 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
     p = config['p']
     dev = inputs.device
     zero = torch.zeros((), device=dev)
-    ops.premix_all(model, model._type_table)          # every CondConv2d layer's experts mixed for all modality labels: one launch
+    # the encoders' experts mixed for all modality labels by one launch; the decoder groups follow right before their first use
+    # (MultimodalModel.premix: one backward node per group, so a group's gradients complete -- and its all-reduce starts -- mid-backward)
+    if hasattr(model, 'premix'):
+        model.premix('enc')
+    else:
+        ops.premix_all(model, model._type_table)
     si_list = model.compute_anatomy_encoding(inputs_list, mask_img)                              # :175
     zi_list, mu_list, lv_list = model.compute_modality_encoding(inputs_list, si_list, phase=phase)     # :176 / :400
     xi_fake_list = model.reconstruct_input_si_zi(si_list, zi_list)                               # :177
@@ -518,7 +639,8 @@ class TrainStep:
         ops.set_compute_dtype(config.get('compute_dtype', 'f32'))
         self.accum = max(1, 16 // config['batch_size'])                                          # :282 (guarded for B > 16)
         used = model.trainable_parameters() if hasattr(model, 'trainable_parameters') else None
-        self.optimizer = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=1e-5, used=used)   # :118
+        order = model.completion_groups() if hasattr(model, 'completion_groups') else None
+        self.optimizer = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=1e-5, used=used, order=order)   # :118
         if used is not None and hasattr(model, 'gated_parameter_groups'):
             self.optimizer.set_gates(model.gated_parameter_groups())
         self.optimizer_d_s = None

@@ -131,6 +131,74 @@ def _worker_two_optimizers(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _SinkLinearFn(torch.autograd.Function):
+    """y = x W^T + b whose parameter gradients are ADDED to p.grad inside backward and never handed to autograd -- the CPU twin of
+    the in-kernel gradient sinks of the HIP path (ops._grad_sink): no post-accumulate hook fires for W and b."""
+
+    @staticmethod
+    def forward(ctx, x, lin):
+        ctx.lin = lin
+        ctx.save_for_backward(x)
+        return x @ lin.weight.detach().t() + lin.bias.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        lin = ctx.lin
+        lin.weight.grad.add_(dy.t() @ x); lin.bias.grad.add_(dy.sum(0))
+        return dy @ lin.weight.detach(), None
+
+
+def _worker_sinks(rank, world, port, q):
+    """Parameters whose gradients are in-kernel sinks: no hook fires, their buckets leave when the group's backward node reports
+    them (GradAllReduce.mark_ready, called by ops._MixAllLayers.backward on the GPU path) -- here from a tensor hook that runs
+    mid-backward -- or from finish().  Arena laid out in completion order (ArenaAdam(order=...)), buckets cut at group edges."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mrdis
+        torch.manual_seed(0)
+        model = Tiny()
+        sink = [model.b.weight, model.b.bias, model.c.weight, model.c.bias]
+        for p in sink:
+            p._mrdis_sink = True
+        used = [p for n, p in model.named_parameters() if 'unused' not in n]
+        order = [[model.c.weight, model.c.bias], [model.b.weight, model.b.bias], [model.a.weight, model.a.bias]]
+        opt = mrdis.ArenaAdam(model.parameters(), lr=1e-3, used=used, order=order)
+        assert [id(p) for p in opt.used] == [id(p) for g in order for p in g]          # completion order = arena order
+        assert opt.group_edges == [0, opt.offsets[2], opt.offsets[4], opt.numel]
+        red = mrdis.GradAllReduce(opt)
+        errs, early = [], []
+        for it in range(3):
+            g = torch.Generator().manual_seed(100 * it + rank)
+            x = torch.randn(4, 7, generator=g)
+            ref = Tiny(); ref.load_state_dict(model.state_dict())
+            expect = list(torch.autograd.grad(ref(x).pow(2).sum(), [p for n, p in ref.named_parameters() if 'unused' not in n]))
+            for t in expect:
+                dist.all_reduce(t); t /= world
+            expect = {n: t for (n, _), t in zip([(n, p) for n, p in ref.named_parameters() if 'unused' not in n], expect)}
+            opt.zero_grad()
+            h = torch.tanh(model.a(x))
+            if it < 2:
+                # what the mixing group's backward node does: by the time dL/dh exists, b's and c's sink gradients are complete
+                h.register_hook(lambda g_, r=red: r.mark_ready(sink))
+            y = _SinkLinearFn.apply(torch.tanh(_SinkLinearFn.apply(h, model.b)), model.c) + \
+                _SinkLinearFn.apply(torch.tanh(_SinkLinearFn.apply(-h, model.b)), model.c)
+            red.begin()
+            before = red.early_buckets
+            y.pow(2).sum().backward()
+            scale = red.finish()
+            early.append(red.early_buckets - before)
+            for n, p in model.named_parameters():
+                if 'unused' not in n:
+                    errs.append(float((p.grad * scale - expect[n]).abs().max()))
+        # iterations 0, 1: the c and b buckets left from mark_ready, a's from its own hooks; iteration 2 (nobody reports the
+        # sinks): only a's bucket leaves early, the two sink buckets go from finish()
+        q.put((rank, max(errs), early, red.nbuckets))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(worker):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -149,6 +217,14 @@ def test_two_optimizers_accumulation_world2():
     for rank, err, numel, nused in _run(_worker_two_optimizers):
         assert err < 1e-6, (rank, err)
         assert nused == 6
+
+
+@pytest.mark.timeout(180)
+def test_sink_parameters_leave_from_mark_ready_or_finish_world2():
+    for rank, err, early, nb in _run(_worker_sinks):
+        assert err < 1e-6, (rank, err)
+        # groups c | b | a at 20 | 76 | 108 floats: the two beyond a third of the arena are cut in two -> 5 buckets
+        assert nb == 5 and early == [5, 5, 2], (early, nb)
 
 
 @pytest.mark.timeout(180)

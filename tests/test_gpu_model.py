@@ -318,7 +318,10 @@ def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
             if on:
                 plans = model.__dict__.get('_mrdis_mix_plans')
                 assert plans and all(p.ok for p in plans.values()), 'the all-layers launch did not run'
-                assert all(len(p.tables) == 2 for p in plans.values()), 'expected one job table per gradient arena (generator / discriminator step)'
+                # one plan per mixing group (encoders | shared decoder | one per modality decoder); the discriminator-loss backward only
+                # reaches the encoders, whose plan therefore holds one job table per gradient arena (generator / discriminator step)
+                assert sorted(k[3] for k in plans) == sorted(['enc', 'dec_shared'] + [f'dec{i}' for i in range(M)])
+                assert all(len(p.tables) == (2 if k[3] == 'enc' else 1) for k, p in plans.items())
             res[on] = (losses, torch.cat([p.detach().flatten().float() for p in model.parameters()]))
     finally:
         mrdis.ops._PREMIX = True
@@ -540,6 +543,70 @@ def test_absent_modality_leaves_its_decoder_untouched(mrdis):
     assert list(m4.active_decoders(mh)) == [1.0, 1.0, 1.0, 1.0]
 
 
+def test_gated_adam_keeps_a_step_count_per_group_like_torch(mrdis):
+    """torch.optim.Adam keeps `step` PER PARAMETER and does not advance it while the parameter's gradient is None
+    (main_missing.py:118, :283 with a modality absent from the batch, util.py:538-542).  ArenaAdam's gated ranges carry their own
+    device step counter: ten steps with the two gate groups present on different steps, against torch.optim.Adam(amsgrad) with
+    grad = None for an absent group -- weights after every step, the per-parameter `step` of the checkpoint, and the round trip
+    of torch's state (per-parameter steps differ) through load_state_dict."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37, 5), (64,), (3, 8, 9), (130,)]                       # a: always; b, c: group 0; d: group 1
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in shapes]
+    ours = mk()
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    for p in ours:
+        p.grad = torch.zeros_like(p)
+    opt = mrdis.ArenaAdam(ours, lr=2e-3, weight_decay=1e-5, used=ours)
+    opt.set_gates([[ours[1], ours[2]], [ours[3]]])
+    ref = torch.optim.Adam(theirs, lr=2e-3, weight_decay=1e-5, amsgrad=True)
+    pattern = [(1, 1), (0, 1), (0, 1), (1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (1, 1), (0, 1)]
+    member = [None, 0, 0, 1]
+    for it, flags in enumerate(pattern):
+        grads = [torch.randn(*s, generator=g).to(DEV) * (0.5 + it) for s in shapes]     # norms above and below the clip threshold
+        if it == 3:
+            grads = [x * 1e-3 for x in grads]
+        opt.zero_grad()
+        for p, q, gr, mem in zip(ours, theirs, grads, member):
+            on = mem is None or flags[mem]
+            if on:
+                p.grad.copy_(gr)
+            q.grad = gr.clone() if on else None
+        opt.mark_active(torch.tensor(flags, dtype=torch.float32, device=DEV))
+        torch.nn.utils.clip_grad_norm_(theirs, 1.0)
+        ref.step()
+        opt.step(fused_clip=True, use_gates=True)
+        for k, (p, q) in enumerate(zip(ours, theirs)):
+            err = float((p - q).abs().max())
+            assert err <= 2e-6 * max(1.0, float(q.abs().max())), (it, k, err)
+    want_steps = [10, 4, 4, 8]
+    sd = opt.state_dict()
+    assert [float(sd['state'][i]['step']) for i in range(4)] == want_steps
+    assert [float(ref.state_dict()['state'][i]['step']) for i in range(4)] == want_steps
+    # torch's state (per-parameter steps) -> a fresh arena -> one more step on both: still the same weights
+    ours2 = [torch.nn.Parameter(q.detach().clone()) for q in theirs]
+    for p in ours2:
+        p.grad = torch.zeros_like(p)
+    opt2 = mrdis.ArenaAdam(ours2, lr=2e-3, weight_decay=1e-5, used=ours2)
+    opt2.set_gates([[ours2[1], ours2[2]], [ours2[3]]])
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.gate_steps[:2].tolist() == [4.0, 8.0] and float(opt2.step_state[0]) == 10.0
+    grads = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+    for p, q, gr in zip(ours2, theirs, grads):
+        p.grad.copy_(gr); q.grad = gr.clone()
+    opt2.mark_active(torch.ones(2, device=DEV))
+    torch.nn.utils.clip_grad_norm_(theirs, 1.0); ref.step()
+    opt2.step(fused_clip=True, use_gates=True)
+    for k, (p, q) in enumerate(zip(ours2, theirs)):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), k
+    # a bad payload leaves the arena as it was (validated before anything is written)
+    bad = ref.state_dict()
+    bad['state'][2]['exp_avg'] = torch.zeros(7)
+    m_before, s_before = opt2.m.clone(), opt2.step_state.clone()
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+    assert torch.equal(m_before, opt2.m) and torch.equal(s_before, opt2.step_state)
+
+
 def test_optimizer_state_dict_round_trip_with_torch_adam(mrdis, golden_dir):
     """ArenaAdam.state_dict() has torch.optim.Adam's layout (keys pinned by tests/golden/ckpt_layout_m2.json from the real
     reference run) and loads into torch.optim.Adam; torch.optim.Adam's state loads back into the arena; a step after the
@@ -589,6 +656,11 @@ def test_optimizer_state_dict_round_trip_with_torch_adam(mrdis, golden_dir):
     assert lrs == lay['lr_trajectory']
 
 
+# bf16 against the fp32 vectors of the real reference: no more than 5x what the six cases measure (DESIGN.md section 4.1 lists the
+# measured values; the reference has no bf16 path, so these are stated tolerances of this configuration, not parity pins)
+BF16_TOL = dict(loss=2e-2, parts=2e-2, gnorm=5e-2, per_tensor_p98=0.15)
+
+
 @pytest.mark.parametrize('mode', ['bf16', 'bf16m'])
 @pytest.mark.parametrize('tag', ['b2m4', 'b2m2_adv', 'b2m4_drop'])
 def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
@@ -617,17 +689,26 @@ def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
             loss.backward(retain_graph=adv)
         if mode == 'bf16':      # the decoder trunk really is stored in bf16; what leaves it is fp32
             assert aux['xi_fake_list'][0].dtype == torch.float32 and aux['si_list'][0].dtype == torch.float32
-        assert abs(float(loss) - meta['loss']) <= 2e-2 * abs(meta['loss']), (float(loss), meta['loss'])
-        assert abs(float(loss) - meta['loss']) > 1e-7 * abs(meta['loss'])          # not the fp32 path
-        for k, v in meta['parts'].items():
-            assert abs(float(parts[k]) - v) <= 2e-2 * abs(v) + 1e-4, (k, float(parts[k]), v)
         gn = {names[id(p)]: float(p.grad.double().norm()) for p in step.optimizer.used}
         hot = {k: v for k, v in meta['grad_norms'].items() if not k.startswith('output_decoder')}
         assert set(hot) == set(gn)
         total = float(np.sqrt(sum(v * v for v in gn.values()))); ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
-        assert abs(total - ref_total) <= 5e-2 * ref_total, (total, ref_total)
-        bad = [k for k, v in hot.items() if abs(gn[k] - v) > 0.15 * v + 1e-3 * ref_total]
-        assert len(bad) <= 0.02 * len(hot), bad[:8]
+        pt = sorted(abs(gn[k] - v) / (v + 1e-3 * ref_total) for k, v in hot.items())
+        rec = dict(tag=tag, mode=mode, loss_rel=abs(float(loss) - meta['loss']) / abs(meta['loss']),
+                   parts_rel={k: abs(float(parts[k]) - v) / (abs(v) + 1e-4) for k, v in meta['parts'].items()},
+                   gnorm_rel=abs(total - ref_total) / ref_total, per_tensor_p98=pt[int(0.98 * (len(pt) - 1))], per_tensor_max=pt[-1])
+        try:
+            os.makedirs('gpurun_out', exist_ok=True)
+            with open('gpurun_out/bf16_golden_measured.jsonl', 'a') as f:
+                f.write(json.dumps(rec) + '\n')
+        except OSError:
+            pass
+        assert rec['loss_rel'] <= BF16_TOL['loss'], rec
+        assert abs(float(loss) - meta['loss']) > 1e-7 * abs(meta['loss'])          # not the fp32 path
+        for k, v in rec['parts_rel'].items():
+            assert v <= BF16_TOL['parts'], (k, rec)
+        assert rec['gnorm_rel'] <= BF16_TOL['gnorm'], rec
+        assert rec['per_tensor_p98'] <= BF16_TOL['per_tensor_p98'], rec
         step.optimizer.step(fused_clip=True)
         assert torch.isfinite(step.optimizer.flat_p).all()
     finally:

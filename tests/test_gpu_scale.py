@@ -213,3 +213,147 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
             assert float(d.max()) <= 8.4e-4, n          # two Adam steps (generator + discriminator optimizer), each <= ~lr per element
         num = sum(float((w0[n] - w1[n]).abs().sum()) for n in w0); den = sum(w0[n].numel() for n in w0)
         assert num / den <= 2e-6, num / den
+
+
+def _bf16_path(Ci, Co, s):
+    """which kernels ops.conv2d runs a layer on under compute_dtype 'bf16': 'bf16' = the bf16 MFMA kernels on bf16 views (a 4- / 7-channel
+    side of a stride-1 layer zero-padded to 16), 'f32' = the fp32 kernels between view casts (the stride-2 first layers)"""
+    if Ci % 16 == 0 and Co % 4 == 0 and Co >= 16:
+        return 'bf16'
+    return 'bf16' if s == 1 else 'f32'
+
+
+def _run_bf16_layer(m, xd, w, b, dyd, k, s, p, Co, prepadded=False):
+    """the layer as the bf16 step runs it: ops.conv2d (policy + view casts + autograd) inside a mixed-kernel cache scope.
+    prepadded: the filter arrives zero-padded to 16 channels, as the all-layers mixing launch writes the narrow ones (MixPlan.padded)."""
+    ops = m.ops
+    Ci = w.shape[1]
+    w_tck = to_tck(w)
+    if prepadded:
+        w_tck = F.pad(w_tck, (0, max(Co, 16) - Co, 0, max(Ci, 16) - Ci))
+    w_tck = w_tck.to(DEV).requires_grad_(True)
+    w_tkc = w_tck.detach().permute(0, 2, 1).contiguous()
+    bias = b.to(DEV).requires_grad_(True)
+    x = xd.detach().requires_grad_(True)
+    with ops.mix_cache():
+        y = ops.conv2d(x, w_tck, w_tkc, bias, k, k, s, p, co=Co)
+        y.backward(dyd.to(y.dtype))
+    dw = w_tck.grad[:, :Ci, :Co] if prepadded else w_tck.grad
+    return y.detach(), x.grad, dw, bias.grad[:Co]
+
+
+@pytest.mark.parametrize('case', ZOO, ids=[c[0] for c in ZOO])
+def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
+    """BASELINE configs[2] at the benchmarked scale: every convolution of the step at B = 32 / 256x256 as `compute_dtype: bf16` runs it
+    (ops.conv2d: bf16 MFMA kernels on bf16 views -- persistent bconv3 / bwgrad2 workgroups walking hundreds of items, the packed
+    stride-2 data gradient, narrow sides zero-padded to 16 -- or the fp32 kernels between view casts on the stride-2 first layers):
+      * forward / data gradient on sampled images and the weight / bias gradient (cotangent zero outside them) against torch fp32
+        on the operands the kernels actually multiply (bf16-rounded where the bf16 kernels run), up to the rounding of a bf16 result;
+      * option wino_pipe 0 vs 1 (bconv3 / bwgrad2 vs bconv / bwgrad) and debug_nopack 0 vs 1 (packed parity classes): bit-identical
+        on the full tensors;
+      * a filter that arrives pre-padded to 16 channels (the mixing launch's layout) against the explicit pad of ops.conv2d: bit-identical.
+    Reference geometry as in test_layer_zoo_at_bench_scale."""
+    name, N, Ci, Co, k, s, p, H, W = case
+    m, hip = mrdis, mrdis.hip
+    B16 = torch.bfloat16
+    path = _bf16_path(Ci, Co, s)
+    S = sorted({0, N // 2 + 1, N - 1})
+    w = rnd((Co, Ci, k, k), 2, 0.5 / np.sqrt(Ci * k * k)); b = rnd((Co,), 3, 0.1)
+    Ho, Wo = hip.conv_out_hw(H, W, k, k, s, p)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    xd = torch.randn((N, Ci, H, W), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    dyd = torch.randn((N, Co, Ho, Wo), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+    if Ci >= 16:
+        xd = xd.to(B16)                                   # stored in bf16 by its producer
+    if Co >= 16:
+        dyd = dyd.to(B16)
+    m.ops.set_compute_dtype('bf16')
+    try:
+        y, dx, dw, db = _run_bf16_layer(m, xd, w, b, dyd, k, s, p, Co)
+        assert y.dtype == (B16 if Co >= 16 else torch.float32) and dx.dtype == xd.dtype and dw.dtype == torch.float32
+        # torch fp32 on what the kernels multiply
+        r16 = lambda t_: t_.float().bfloat16().float()
+        xs = xd[S].float().cpu(); dy_s = dyd[S].float().cpu(); wr = w
+        if path == 'bf16':
+            xs, dy_s, wr = r16(xs), r16(dy_s), r16(w)
+        xs = xs.contiguous().requires_grad_(True); ws = wr.clone().requires_grad_(True)
+        ys = F.conv2d(xs, ws, b, s, p)
+        ys.backward(dy_s)
+        assert rel(y[S], ys) <= 4e-3, ('fwd vs torch', name, rel(y[S], ys))                       # a bf16 result: 2^-9 relative per element
+        assert rel(dx[S], xs.grad) <= 4e-3, ('dgrad vs torch', name, rel(dx[S], xs.grad))
+        dys = torch.zeros_like(dyd); dys[S] = dyd[S]
+        _, _, dw_s, db_s = _run_bf16_layer(m, xd, w, b, dys, k, s, p, Co)
+        assert rel(dw_s, to_tck(ws.grad)) <= 4e-4, ('wgrad vs torch', name, rel(dw_s, to_tck(ws.grad)))   # fp32 accumulation of bf16 products
+        assert rel(db_s, dy_s.sum((0, 2, 3))) <= 4e-4, ('dbias vs torch', name)
+        del dys, dw_s, db_s
+        # pipelined vs plain bf16 kernels, packed vs four-launch stride-2 data gradient: same arithmetic in the same order
+        for opt, val in (('wino_pipe', 0), ('debug_nopack', 1)):
+            with hip.option(opt, val):
+                y1, dx1, dw1, db1 = _run_bf16_layer(m, xd, w, b, dyd, k, s, p, Co)
+            for what, a, c in (('fwd', y, y1), ('dgrad', dx, dx1), ('wgrad', dw, dw1), ('dbias', db, db1)):
+                assert torch.equal(a, c), (f'{what}: option {opt} = {val} changed the result', name, rel(a, c))
+            del y1, dx1, dw1, db1
+        if path == 'bf16' and min(Ci, Co) < 16:
+            y2, dx2, dw2, db2 = _run_bf16_layer(m, xd, w, b, dyd, k, s, p, Co, prepadded=True)
+            for what, a, c in (('fwd', y, y2), ('dgrad', dx, dx2), ('wgrad', dw, dw2), ('dbias', db, db2)):
+                assert torch.equal(a, c), (f'{what}: pre-padded filter vs explicit pad', name, rel(a, c))
+    finally:
+        m.ops.set_compute_dtype('f32')
+
+
+def _one_step(m, mode, B_=B, H=HW, W=HW, opts=()):
+    """loss, loss parts, every parameter gradient (both backward passes) and the weights after Adam of ONE headline step"""
+    for o, v in opts:
+        m.hip.set_option(o, v)
+    try:
+        cfg = dict(m.DEFAULT_CONFIG); cfg.update(input_height=H, input_width=W, batch_size=B_, lambda_adv_s=1.0, is_patch_gan=True, compute_dtype=mode)
+        cfg = m.derive_config(cfg, DEV)
+        torch.manual_seed(10); np.random.seed(10)
+        model = m.build_model(cfg).train()
+        x, mask, mask_img = m.synthetic_batch(B_, 4, 240, 240, seed=10)
+        x = m.fit_to_model(x, (H, W), fill=-10.0); mask_img = (x[:, 0] == 0).float()
+        step = m.TrainStep(model, cfg)
+        torch.manual_seed(11); np.random.seed(11)
+        loss, parts, _ = step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+        names = {id(p): n for n, p in model.named_parameters()}
+        # the arena exists from the constructor: after the step the gradient buffers are zeroed, so read what the clip saw instead
+        gnorm = float(step.last_grad_norm_sq[0].sqrt())
+        out = (float(loss), {k_: float(v) for k_, v in parts.items()}, gnorm, step.optimizer.flat_p.detach().clone(),
+               [names[id(p)] for p in step.optimizer.used], list(step.optimizer.offsets))
+        del model, step
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        for o, v in opts:
+            m.hip.set_option(o, {'wino_pipe': 1, 'debug_nopack': 0, 'wino': 1}[o])
+        m.ops.set_compute_dtype('f32')
+
+
+def test_full_step_at_bench_scale_bf16(mrdis):
+    """One B = 32, M = 4, 256x256 training step (adversarial loss on) under `compute_dtype: bf16` -- the BASELINE configs[2] workload
+    per GPU: (a) the pipelined / packed kernels (default) vs the plain ones (wino_pipe = 0, debug_nopack = 1): identical arithmetic, so
+    loss, gradient norm and the weights after Adam agree to fp32 rounding; (b) against the fp32 step on the same batch and weights: the
+    difference is the bf16 rounding of activations and MFMA operands -- tolerances = 5x what was measured when the test was written
+    (DESIGN.md section 4.1 records the values)."""
+    m = mrdis
+    l_b, p_b, g_b, w_b, names, offs = _one_step(m, 'bf16')
+    l_p, p_p, g_p, w_p, _, _ = _one_step(m, 'bf16', opts=(('wino_pipe', 0), ('debug_nopack', 1)))
+    assert np.isfinite(l_b) and abs(l_b - l_p) <= 1e-6 * abs(l_p), (l_b, l_p)
+    assert abs(g_b - g_p) <= 1e-5 * g_p, (g_b, g_p)
+    assert float((w_b - w_p).abs().max()) <= 4.2e-4 and float((w_b - w_p).abs().mean()) <= 1e-7
+    l_f, p_f, g_f, w_f, names_f, _ = _one_step(m, 'f32')
+    assert names == names_f
+    rec = dict(loss_bf16=l_b, loss_f32=l_f, loss_rel=abs(l_b - l_f) / abs(l_f), gnorm_bf16=g_b, gnorm_f32=g_f, gnorm_rel=abs(g_b - g_f) / g_f,
+               parts_rel={k_: abs(p_b[k_] - p_f[k_]) / (abs(p_f[k_]) + 1e-12) for k_ in p_f if abs(p_f[k_]) > 0},
+               w_mean_abs_diff=float((w_b - w_f).abs().mean()))
+    try:
+        import json, os
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/bf16_scale_measured.json', 'w') as f:
+            json.dump(rec, f)
+    except OSError:
+        pass
+    assert rec['loss_rel'] <= 2e-3, rec
+    assert rec['gnorm_rel'] <= 5e-2, rec
+    for k_, v in rec['parts_rel'].items():
+        assert v <= (2e-2 if k_ in ('sim_s', 'sim_z', 'latent_z', 'adv_s', 'adv_s_d') else 2e-3), (k_, rec)
