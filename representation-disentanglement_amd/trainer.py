@@ -194,9 +194,12 @@ class ArenaAdam(torch.optim.Optimizer):
         # within a group (or without an order): parameters whose gradient the backward kernels add to in place (ops._grad_sink)
         # fire no post-accumulate hook; keep them behind the hook-driven ones (stable sort: constructor order otherwise)
         ngrp = len(self._order) if self._order is not None else 0
-        used.sort(key=lambda p: (rank_of.get(id(p), ngrp), 1 if getattr(p, '_mrdis_sink', False) else 0))
-        dev = used[0].device
         share = self._share
+        if share is not None:
+            used = list(share.used)             # the layout IS the other optimizer's: same tensors at the same offsets
+        else:
+            used.sort(key=lambda p: (rank_of.get(id(p), ngrp), 1 if getattr(p, '_mrdis_sink', False) else 0))
+        dev = used[0].device
         if share is not None:                   # second optimizer over the same weights (optimizer_d_s, main_missing.py:121-122)
             self.offsets, self.numel, self.flat_p = share.offsets, share.numel, share.flat_p
             self.group_edges = share.group_edges

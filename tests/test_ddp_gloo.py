@@ -167,6 +167,9 @@ def _worker_sinks(rank, world, port, q):
         opt = mrdis.ArenaAdam(model.parameters(), lr=1e-3, used=used, order=order)
         assert [id(p) for p in opt.used] == [id(p) for g in order for p in g]          # completion order = arena order
         assert opt.group_edges == [0, opt.offsets[2], opt.offsets[4], opt.numel]
+        od = mrdis.ArenaAdam(model.parameters(), lr=1e-3, weight_decay=0.0, share_weights_of=opt)     # optimizer_d_s: the same layout, its own gradients
+        assert [id(p) for p in od.used] == [id(p) for p in opt.used] and od.offsets == opt.offsets and od.group_edges == opt.group_edges
+        assert all(gv.shape == p.shape for gv, p in zip(od.grad_views, od.used))
         red = mrdis.GradAllReduce(opt)
         errs, early = [], []
         for it in range(3):

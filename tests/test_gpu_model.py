@@ -578,7 +578,7 @@ def test_gated_adam_keeps_a_step_count_per_group_like_torch(mrdis):
         for k, (p, q) in enumerate(zip(ours, theirs)):
             err = float((p - q).abs().max())
             assert err <= 2e-6 * max(1.0, float(q.abs().max())), (it, k, err)
-    want_steps = [10, 4, 4, 8]
+    want_steps = [len(pattern)] + [sum(f[0] for f in pattern)] * 2 + [sum(f[1] for f in pattern)]          # [10, 5, 5, 7]
     sd = opt.state_dict()
     assert [float(sd['state'][i]['step']) for i in range(4)] == want_steps
     assert [float(ref.state_dict()['state'][i]['step']) for i in range(4)] == want_steps
@@ -589,7 +589,7 @@ def test_gated_adam_keeps_a_step_count_per_group_like_torch(mrdis):
     opt2 = mrdis.ArenaAdam(ours2, lr=2e-3, weight_decay=1e-5, used=ours2)
     opt2.set_gates([[ours2[1], ours2[2]], [ours2[3]]])
     opt2.load_state_dict(ref.state_dict())
-    assert opt2.gate_steps[:2].tolist() == [4.0, 8.0] and float(opt2.step_state[0]) == 10.0
+    assert opt2.gate_steps[:2].tolist() == [5.0, 7.0] and float(opt2.step_state[0]) == 10.0
     grads = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
     for p, q, gr in zip(ours2, theirs, grads):
         p.grad.copy_(gr); q.grad = gr.clone()
@@ -658,7 +658,10 @@ def test_optimizer_state_dict_round_trip_with_torch_adam(mrdis, golden_dir):
 
 # bf16 against the fp32 vectors of the real reference: no more than 5x what the six cases measure (DESIGN.md section 4.1 lists the
 # measured values; the reference has no bf16 path, so these are stated tolerances of this configuration, not parity pins)
-BF16_TOL = dict(loss=2e-2, parts=2e-2, gnorm=5e-2, per_tensor_p98=0.15)
+# measured (round 3, six cases, worst): loss 2.7e-4, recon parts 5.1e-6, sim_z 1.1e-5, sim_s 1.3e-3, latent_z 1.4e-3, adv 6.5e-3,
+# total gradient norm 2.3e-2, per-tensor gradient norm 0.061 at the 98th percentile (0.11 worst)
+BF16_TOL = dict(loss=1e-3, gnorm=5e-2, per_tensor_p98=0.15,
+                parts=dict(recon_x=2.5e-5, recon_x_mix=2.5e-5, sim_z=5e-5, sim_s=6e-3, latent_z=7e-3, adv_s=2e-2, adv_s_d=3e-2))
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16m'])
@@ -667,9 +670,10 @@ def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
     """BASELINE configs[2] (`compute_dtype: bf16`): bf16 activations in HBM (every tensor with >= 16 channels), bf16 MFMA
     operands, fp32 accumulation; master weights, biases, norm statistics, the 4-channel anatomy maps, reconstructions,
     losses, gradients of parameters and the optimizer in fp32.  `bf16m` is the intermediate mode (bf16 MFMA operands on fp32
-    activations).  Against the fp32 vectors of the real reference the stated tolerances are: loss and loss parts 2e-2
-    relative, total gradient norm 5e-2, per-tensor gradient norms 0.15 for 98 % of the tensors (bf16 carries 8 significant
-    bits; the 1e-3 bar of the fp32 path cannot hold)."""
+    activations).  Against the fp32 vectors of the real reference the stated tolerances (BF16_TOL above: at most 5x what the six
+    cases measure) are: loss 1e-3 relative, reconstruction losses 2.5e-5, similarity / latent / adversarial parts 5e-5 .. 3e-2, total
+    gradient norm 5e-2, per-tensor gradient norms 0.15 for 98 % of the tensors (bf16 carries 8 significant bits: a gradient does
+    not meet the 1e-3 bar of the fp32 path, the loss does)."""
     meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
     B, M, adv = meta['B'], meta['M'], meta['adv']
     cfg = _cfg(mrdis, M, 160, 192, B, adv)
@@ -706,7 +710,7 @@ def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
         assert rec['loss_rel'] <= BF16_TOL['loss'], rec
         assert abs(float(loss) - meta['loss']) > 1e-7 * abs(meta['loss'])          # not the fp32 path
         for k, v in rec['parts_rel'].items():
-            assert v <= BF16_TOL['parts'], (k, rec)
+            assert v <= BF16_TOL['parts'][k], (k, rec)
         assert rec['gnorm_rel'] <= BF16_TOL['gnorm'], rec
         assert rec['per_tensor_p98'] <= BF16_TOL['per_tensor_p98'], rec
         step.optimizer.step(fused_clip=True)

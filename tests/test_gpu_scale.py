@@ -353,7 +353,10 @@ def test_full_step_at_bench_scale_bf16(mrdis):
             json.dump(rec, f)
     except OSError:
         pass
-    assert rec['loss_rel'] <= 2e-3, rec
-    assert rec['gnorm_rel'] <= 5e-2, rec
+    # measured when written (round 3): loss 6.9e-5, gradient norm 1.6e-3, recon_x / recon_x_mix 9e-7, sim_z 7e-8, latent_z 8.6e-4,
+    # sim_s 1.4e-3, adv_s / adv_s_d 6.6e-5
+    assert rec['loss_rel'] <= 3.5e-4, rec
+    assert rec['gnorm_rel'] <= 8e-3, rec
+    tol = dict(recon_x=5e-6, recon_x_mix=5e-6, sim_z=5e-6, latent_z=4.5e-3, sim_s=7e-3, adv_s=3.5e-4, adv_s_d=3.5e-4, all=3.5e-4)
     for k_, v in rec['parts_rel'].items():
-        assert v <= (2e-2 if k_ in ('sim_s', 'sim_z', 'latent_z', 'adv_s', 'adv_s_d') else 2e-3), (k_, rec)
+        assert v <= tol[k_], (k_, rec)

@@ -59,7 +59,11 @@ def main():
         sums = [None] * world
         dist.all_gather_object(sums, (float(got.double().sum()), float(got.double().abs().sum())))
         across = all(s == sums[0] for s in sums)
+        ex = step.reducer.exposed_ms()
         if rank == 0:
+            print(f'[ddp rehearsal]   exchange: {ex["buckets"]} buckets cut at the completion-group edges, {ex["early_buckets"]} of '
+                  f'{ex["buckets"] * ex["finish_calls"]} bucket launches left DURING backward (mark_ready / hooks), {ex["finish_calls"]} backward passes, '
+                  f'{ex["bytes_reduced"] / 1e6:.1f} MB reduced', flush=True)
             print(f'[ddp rehearsal] world {world}, batch_size {bs} (accum {step.accum}), compute_dtype {cd}: weights after {st} iterations identical '
                   f'to single-process: {same} (max |diff| {maxdiff:.3e}); identical across ranks: {across}; losses {losses} vs {ref_losses}', flush=True)
         ok = ok and same and across
