@@ -146,6 +146,13 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
 #define MRDIS_DT_F32        0
 #define MRDIS_DT_F32_BF16M  1
 #define MRDIS_DT_BF16       2
+/* mixed storage at the two ends of a bf16 stretch (`compute_dtype: bf16` keeps tensors with < 16 channels in fp32): named after the
+ * LAYER's input x (= dx) and output y (= dy), the same code goes to its forward, data-gradient and weight-gradient entry points.
+ *   MRDIS_DT_XBF16_YF32  x / dx bf16 views, y / dy fp32: the 1x1 decoder head 16 -> <= 8 (forward, data gradient, weight gradient)
+ *   MRDIS_DT_XF32_YBF16  x fp32, y bf16: forward of the 3x3 4 -> C si_layers; w_tck is then the [9][16][Co] layout (rows >= 4 zero)
+ *                        that the mixing launch writes for narrow layers under bf16 storage.  MRDIS_EUNSUPPORTED elsewhere.        */
+#define MRDIS_DT_XBF16_YF32 3
+#define MRDIS_DT_XF32_YBF16 4
 int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                      void* y, int ldy, int N, int H, int W, int Ci, int Co,
                      int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream);

@@ -827,12 +827,18 @@ struct C4Params {
     long long ntiles;
     int lrelu;
     int flip;                    // taps in reverse order: the stride-1 data gradient of a C -> 4 layer is this same convolution
+    int wrows;                   // channel rows per tap of the filter in memory: 4, or 16 for the zero-padded [9][16][Co] layout the mixing
+                                 // launch writes under bf16 storage (rows 4..15 are zero and never read)
 };
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define C4_OOB 0x40000000u       // any offset >= this is outside every descriptor this kernel builds
 
-template <int NS, bool LRELU, bool FULL>   // FULL: the strips tile the image exactly (no per-store position checks)
+// OBF16: the output is a bf16 view (MRDIS_DT_XF32_YBF16: the si_layers under `compute_dtype: bf16` read the fp32 anatomy map and open a
+// bf16 stretch).  A lane owns ONE cout, so a bf16 store of its own would be 2 bytes; adjacent lanes exchange one value per register pair
+// (DPP quad_perm 1,0,3,2) and each stores a packed cout PAIR: even lanes (m, m+1) of position r, odd lanes (m-1, m) of position r + 1 --
+// half the store instructions of the fp32 form, every one of them 4 bytes per lane.
+template <int NS, bool LRELU, bool FULL, bool OBF16 = false>   // FULL: the strips tile the image exactly (no per-store position checks)
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
     const unsigned ty = m / p.TW, tx = m - ty * p.TW;
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
             for (int ns = 0; ns < NS; ++ns) {
                 const int co = (cot * NS + ns) * 32 + m;
                 const int coc = co < p.Co ? co : p.Co - 1;
-                const float v = p.w[((p.flip ? 8 - t : t) * 4 + 2 * half + j) * p.Co + coc];
+                const float v = p.w[((p.flip ? 8 - t : t) * p.wrows + 2 * half + j) * p.Co + coc];
                 b[t][j][ns] = co < p.Co ? v : 0.f;
             }
     // bias in the accumulator layout (every register of a lane belongs to cout m).  Passing it once through
@@ -880,9 +886,10 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     };
     // geometry in bytes (host guarantees: image bytes < C4_OOB, every 24-bit multiply operand < 2^24)
     const unsigned pix = 4u * p.ldx, rowbytes = pix * (unsigned)p.W, imgbytes = rowbytes * (unsigned)p.H;
-    const unsigned opix = 4u * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
+    const unsigned opix = (OBF16 ? 2u : 4u) * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
     const unsigned lane_off = 8u * half;
-    const unsigned st_lane = 4u * m + 128u * NS * cot;             // cout m of this y-slice
+    const unsigned st_lane = OBF16 ? 2u * (m & ~1u) + 64u * NS * cot      // the cout pair this lane stores
+                                   : 4u * m + 128u * NS * cot;             // cout m of this y-slice
     const unsigned uH = p.H, uW = p.W;
     // timing-only builds (-DC4_ABL_NOLOAD / _NOSTORE / _NOMFMA): a zero-record descriptor drops the traffic
     // while the instruction stream and the waits stay
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const unsigned yrec = oimgbytes;
 #endif
     auto x_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * (imgbytes / 4)), 0, xrec, 0x00020000); };
-    auto y_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (size_t)n * (oimgbytes / 4)), 0, yrec, 0x00020000); };
+    auto y_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + (size_t)n * oimgbytes), 0, yrec, 0x00020000); };
     // 9 tap byte offsets of a strip: 3 row bases x 3 column offsets, each either valid or C4_OOB.
     auto strip_offsets = [&](int th, int tw, unsigned (&voff)[9]) {
         const unsigned h = (unsigned)(th * p.TH) + ty, w_ = (unsigned)(tw * p.TW) + tx;
@@ -929,6 +936,34 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) lane_ok_off[ns] = ((cot * NS + ns) * 32 + m < p.Co) ? 0u : C4_OOB;
     auto store_group = [&](const f32x16 (&acc)[NS], __amdgpu_buffer_rsrc_t rs, unsigned so, int th, int tw, int g) {
+        if (OBF16) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bool odd = (m & 1) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                const int r0 = 4 * g + k, r1 = r0 + 1;                                  // P(r1) = P(r0) + 1: the next position of the strip row
+                const int P0 = (r0 & 3) + 8 * (r0 >> 2), P1 = P0 + 1;
+                const int pty0 = P0 / p.TW, ptx0 = P0 - pty0 * p.TW, pty1 = P1 / p.TW, ptx1 = P1 - pty1 * p.TW;
+                const unsigned soff = odd ? ((unsigned)pty1 * uW + (unsigned)ptx1) * opix : ((unsigned)pty0 * uW + (unsigned)ptx0) * opix;
+                unsigned vo = so;
+                if (!FULL) {
+                    const unsigned h = (unsigned)(th * p.TH + (odd ? pty1 : pty0)), w_ = (unsigned)(tw * p.TW + (odd ? ptx1 : ptx0)) + 4u * half;
+                    vo = ((int)(h < uH) & (int)(w_ < uW)) ? so : C4_OOB;
+                }
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    float a0 = acc[ns][r0], a1 = acc[ns][r1];
+                    if (LRELU) { a0 = fmaxf(a0, 0.2f * a0); a1 = fmaxf(a1, 0.2f * a1); }
+                    const float send = odd ? a0 : a1;                                  // what the neighbour's store needs from this lane
+                    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
+                    bf16x2_t pk;
+                    pk[0] = (__bf16)(odd ? recv : a0);                                 // the lower cout of the pair
+                    pk[1] = (__bf16)(odd ? a1 : recv);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs, (int)(((vo == C4_OOB ? C4_OOB : vo + soff) | lane_ok_off[ns]) + 64u * ns), 0, C4_STORE_NT);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = 4 * g + k;
@@ -1022,17 +1057,17 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     }
 }
 
-static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int obytes = 4) {
     if (!(Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16)) return false;
     // 32-bit offsets against per-image buffer descriptors, 24-bit multiplies
-    const long long xin = 4LL * ldx * W * H, yout = 4LL * ldy * W * H;
-    return xin < 0x40000000LL && yout < 0x40000000LL && 4LL * ldx * W < (1 << 24) && (long long)H * W < (1 << 24) && 4LL * ldy < (1 << 24);
+    const long long xin = 4LL * ldx * W * H, yout = (long long)obytes * ldy * W * H;
+    return xin < 0x40000000LL && yout < 0x40000000LL && 4LL * ldx * W < (1 << 24) && (long long)H * W < (1 << 24) && (long long)obytes * ldy < (1 << 24);
 }
 
 static int run_c4conv(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                      int N, int H, int W, int Co, int epilogue, hipStream_t s, int flip = 0) {
+                      int N, int H, int W, int Co, int epilogue, hipStream_t s, int flip = 0, int wrows = 4, bool obf16 = false) {
     C4Params p{};
-    p.flip = flip;
+    p.flip = flip; p.wrows = wrows;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.ldx = ldx; p.Co = Co; p.ldy = ldy;
     p.lrelu = (epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
     // strip shape: 32x1 unless a 16x2 strip wastes fewer positions
@@ -1064,6 +1099,10 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
 #define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
+    if (obf16) {       // (the data gradient never takes this form: flip = 0, no LeakyReLU in front of a SPADE block's si_layers either, but keep the switch)
+        if (NS == 2) { if (fast) hipLaunchKernelGGL((c4conv_kernel<2, false, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<2, false, false, true>), grid, dim3(256), 0, s, p); }
+        else { if (fast) hipLaunchKernelGGL((c4conv_kernel<1, false, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }
+    } else
     if (NS == 2) {
         if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
         else { if (fast) C4_LAUNCH(2, false, true); else C4_LAUNCH(2, false, false); }
@@ -1133,7 +1172,7 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
 }
 
 // mrdis_pointwise.hip: the 1x1 decoder head (16 -> <= 8 channels) as streaming kernels
-int mrdis_run_pw_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co, int lrelu, hipStream_t s);
+int mrdis_run_pw_fwd(const void* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co, int lrelu, int x16_bf16, hipStream_t s);
 // mrdis_wgrad_s2.hip: forward of the stride-2 first layers (Cin <= 7)
 int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
                           int kh, int kw, int stride, int pad, int lrelu, hipStream_t s);
@@ -1143,20 +1182,29 @@ int mrdis_run_dgrad_s2(const float* dy, int lddy, const float* w_tkc, float* dx,
 int mrdis_run_co4(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
 // mrdis_c16.hip: 3x3 s1 p1 with 16 output channels, filter in registers
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu, hipStream_t s);
-int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, long long npix, int Ci, int Co, hipStream_t s);
+int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, int lddx, long long npix, int Ci, int Co, int x16_bf16, hipStream_t s);
 
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                                 void* y_, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    if (dtype < MRDIS_DT_F32 || dtype > MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); float* y = reinterpret_cast<float*>(y_);   // bf16 views when dtype == MRDIS_DT_BF16
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
+    if (dtype == MRDIS_DT_XBF16_YF32) {       // mixed storage, bf16 in / fp32 out: the 1x1 decoder head (16 -> <= 8)
+        if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
+        return mrdis_run_pw_fwd(x_, ldx, w_tck, bias, y, ldy, (long long)N * H * W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, 1, (hipStream_t)stream);
+    }
+    if (dtype == MRDIS_DT_XF32_YBF16) {       // mixed storage, fp32 in / bf16 out: the 4 -> C si_layers; w_tck is [9][16][Co] (rows >= 4 zero)
+        if (!c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad, 2) || Co % 2 != 0 || ldy % 2 != 0 || (((uintptr_t)y_) & 3) != 0 ||
+            (epilogue & MRDIS_EPI_LRELU) || mrdis_opt(MRDIS_OPT_NOC4)) return MRDIS_EUNSUPPORTED;
+        return run_c4conv(x, ldx, w_tck, bias, y, ldy, N, H, W, Co, epilogue, (hipStream_t)stream, 0, 16, true);
+    }
     if (!st_bf16 && kh == 1 && kw == 1 && stride == 1 && pad == 0) {
-        rc = mrdis_run_pw_fwd(x, ldx, w_tck, bias, y, ldy, (long long)N * H * W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        rc = mrdis_run_pw_fwd(x, ldx, w_tck, bias, y, ldy, (long long)N * H * W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (!st_bf16 && c4_eligible(x, ldx, ldy, N, H, W, Ci, Co, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
@@ -1198,15 +1246,19 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
 extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_tkc, const void* w_bf16_tck,
                                      void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
                                      int kh, int kw, int stride, int pad, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32) return MRDIS_EUNSUPPORTED;
     const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!dy || !w_tkc || !dx || lddy < Co || lddx < Ci) return MRDIS_EINVAL;
+    if (dtype == MRDIS_DT_XBF16_YF32) {       // the 1x1 head under bf16 storage: dy fp32 (<= 8 channels) -> dx bf16 (16 channels)
+        if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
+        return mrdis_run_pw_dgrad(dy, lddy, w_tkc, dx_, lddx, (long long)N * H * W, Ci, Co, 1, (hipStream_t)stream);
+    }
     if (!st_bf16 && kh == 1 && kw == 1 && stride == 1 && pad == 0) {
-        rc = mrdis_run_pw_dgrad(dy, lddy, w_tkc, dx, lddx, (long long)N * H * W, Ci, Co, (hipStream_t)stream);
+        rc = mrdis_run_pw_dgrad(dy, lddy, w_tkc, dx, lddx, (long long)N * H * W, Ci, Co, 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     TapConvParams base{};
@@ -2253,9 +2305,9 @@ size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int
 size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co);              // mrdis_wgrad_s2.hip: the 4 -> C si_layers
 int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
-size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co);                    // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
-int mrdis_run_pw_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       long long npix, int Ci, int Co, int accumulate_bias, hipStream_t s);
+size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co, int x16_bf16);      // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
+int mrdis_run_pw_wgrad(const void* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       long long npix, int Ci, int Co, int accumulate_bias, int x16_bf16, hipStream_t s);
 int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
 int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
@@ -2295,7 +2347,7 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
         if (n4 > need) need = n4;
     }
     { const size_t n2 = mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (n2 > need) need = n2; }
-    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) { const size_t n1 = mrdis_pw_wgrad_workspace((long long)N * H * W, Ci, Co); if (n1 > need) need = n1; }
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) { const size_t n1 = mrdis_pw_wgrad_workspace((long long)N * H * W, Ci, Co, 1); if (n1 > need) need = n1; }
     return need;
 }
 
@@ -2325,7 +2377,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
                                        int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); const float* dy = reinterpret_cast<const float*>(dy_);
     WgradPlan pl;
     int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
@@ -2333,6 +2385,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     if (!x || !dy || !dw_tck || !workspace || ldx < Ci || lddy < Co) return MRDIS_EINVAL;
     if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
+    if (dtype == MRDIS_DT_XBF16_YF32) {       // the 1x1 head under bf16 storage: x bf16 (16 channels), dy fp32 (<= 8 channels)
+        if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
+        return mrdis_run_pw_wgrad(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
+    }
     if (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) {
         rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
                               accumulate_bias, dtype, (hipStream_t)stream);
@@ -2347,7 +2403,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (kh == 1 && kw == 1 && stride == 1 && pad == 0) {
-        rc = mrdis_run_pw_wgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        rc = mrdis_run_pw_wgrad(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (stride == 2 && Ci <= 7) {

@@ -7,10 +7,25 @@
 //   dgrad     the quad's lanes read the pixel's 7 dy values (same addresses: one request), each produces its float4 of dx
 //   wgrad     28 + 7 running sums per lane over a grid-stride pixel set, lanes of equal q are added at the end (wave shuffles, LDS across
 //             waves), one slab row per workgroup, fixed-order slab reduction (mrdis_launch_slab_reduce): deterministic
+// The 16-channel side is templated on its storage type T16 (float | __bf16): under `compute_dtype: bf16` the decoder trunk is stored in
+// bf16 while the 7-channel reconstruction stays fp32 (MRDIS_DT_XBF16_YF32) -- the head then reads / writes bf16 directly (8 bytes per lane)
+// instead of running as a 16 -> 16 bf16 MFMA layer between a zero-padding cast and a slicing cast (70 / 88 / 114 us vs 35 / 33 / 37 us at B = 32).
 #include "mrdis_common.h"
 
 namespace {
 constexpr int PW_CI = 16, PW_MAXCO = 8;
+
+typedef __bf16 pw_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 pw_ld4(const __bf16* p) {
+    const pw_bf16x4 t = *reinterpret_cast<const pw_bf16x4*>(p);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+__device__ __forceinline__ void pw_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void pw_st4(__bf16* p, float4 v) {
+    pw_bf16x4 t; t[0] = (__bf16)v.x; t[1] = (__bf16)v.y; t[2] = (__bf16)v.z; t[3] = (__bf16)v.w;      // round to nearest even
+    *reinterpret_cast<pw_bf16x4*>(p) = t;
+}
 
 __device__ __forceinline__ float pw_quad_sum(float v) {
     // v + quad_perm(1,0,3,2)(v), then + quad_perm(2,3,0,1): every lane of the quad ends with the sum of the four
@@ -22,8 +37,8 @@ __device__ __forceinline__ float pw_quad_sum(float v) {
 }  // namespace
 
 // y[pix][co] = bias[co] + sum_ci x[pix][ci] w[ci][co]   (w_tck = [1][16][Co])
-template <int CO>
-__global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+template <int CO, typename T16>
+__global__ __launch_bounds__(256) void pw_fwd_kernel(const T16* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ y, int ldy, long long npix, int lrelu) {
     const int q = threadIdx.x & 3;
     float wq[4][CO], b0 = 0.f, b1 = 0.f;
@@ -38,7 +53,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long it = it0 + u * gsz;
-            xv[u] = it < nitems ? *reinterpret_cast<const float4*>(x + (it >> 2) * ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[u] = it < nitems ? pw_ld4(x + (it >> 2) * ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -60,9 +75,9 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const float* __restrict__ x
 }
 
 // dx[pix][ci] = sum_co dy[pix][co] w[co][ci]   (w_tkc = [1][Co][16])
-template <int CO>
+template <int CO, typename T16>
 __global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, int lddx, long long npix) {
+                                                       T16* __restrict__ dx, int lddx, long long npix) {
     const int q = threadIdx.x & 3;
     float wq[CO][4];
 #pragma unroll
@@ -85,14 +100,14 @@ __global__ __launch_bounds__(256) void pw_dgrad_kernel(const float* __restrict__
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < CO; ++c) { o.x += g[u][c] * wq[c][0]; o.y += g[u][c] * wq[c][1]; o.z += g[u][c] * wq[c][2]; o.w += g[u][c] * wq[c][3]; }
-            if (it < nitems) *reinterpret_cast<float4*>(dx + (it >> 2) * lddx + 4 * q) = o;
+            if (it < nitems) pw_st4(dx + (it >> 2) * lddx + 4 * q, o);
         }
     }
 }
 
 // slab[block][ci][co] = sum over the block's pixels of x[pix][ci] dy[pix][co];  bias_slab[block][co] = sum dy[pix][co]
-template <int CO>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+template <int CO, typename T16>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const T16* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                        float* __restrict__ slab, float* __restrict__ bias_slab, long long npix) {
     __shared__ float red[4][4][4 * CO + CO];          // [wave][q][4 channels x CO | CO column sums]
     const int tid = threadIdx.x, q = tid & 3, lane = tid & 63, wave = tid >> 6;
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
         for (int u = 0; u < 2; ++u) {
             const long long it = it0 + u * gsz;
             const bool ok = it < nitems;
-            xv[u] = ok ? *reinterpret_cast<const float4*>(x + (it >> 2) * ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[u] = ok ? pw_ld4(x + (it >> 2) * ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float* s = dy + (it >> 2) * lddy;
 #pragma unroll
             for (int c = 0; c < CO; ++c) g[u][c] = ok ? s[c] : 0.f;
@@ -148,49 +163,55 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float* __restrict__
     }
 }
 
-static bool pw_ok(int Ci, int Co, int ld16, const void* p16, long long npix) {
-    return Ci == PW_CI && Co >= 1 && Co <= PW_MAXCO && ld16 % 4 == 0 && (((uintptr_t)p16) & 15) == 0 && npix >= 4096 && !mrdis_opt(MRDIS_OPT_NOW16);
+// x16_bf16: the 16-channel side is a bf16 view (ld in bf16 elements).  For fp32 views the kernels are a measured policy (large maps only, option
+// debug_now16 = 1 turns them off); for the mixed-storage head they are the only kernels, so every size qualifies.
+static bool pw_ok(int Ci, int Co, int ld16, const void* p16, long long npix, bool x16_bf16) {
+    if (!(Ci == PW_CI && Co >= 1 && Co <= PW_MAXCO && ld16 % 4 == 0 && (((uintptr_t)p16) & (x16_bf16 ? 7 : 15)) == 0)) return false;
+    return x16_bf16 ? npix >= 1 : (npix >= 4096 && !mrdis_opt(MRDIS_OPT_NOW16));
 }
 static int pw_grid(long long nitems, int per_thread) {
     long long g = (nitems + 256LL * per_thread - 1) / (256LL * per_thread);
     if (g > 4096) g = 4096;
     return (int)(g < 1 ? 1 : g);
 }
-#define PW_BY_CO(K, ...) switch (Co) { case 1: K<1> __VA_ARGS__; break; case 2: K<2> __VA_ARGS__; break; case 3: K<3> __VA_ARGS__; break; \
-    case 4: K<4> __VA_ARGS__; break; case 5: K<5> __VA_ARGS__; break; case 6: K<6> __VA_ARGS__; break; case 7: K<7> __VA_ARGS__; break; default: K<8> __VA_ARGS__; break; }
+#define PW_BY_CO(K, T, ...) switch (Co) { case 1: K<1, T> __VA_ARGS__; break; case 2: K<2, T> __VA_ARGS__; break; case 3: K<3, T> __VA_ARGS__; break; \
+    case 4: K<4, T> __VA_ARGS__; break; case 5: K<5, T> __VA_ARGS__; break; case 6: K<6, T> __VA_ARGS__; break; case 7: K<7, T> __VA_ARGS__; break; default: K<8, T> __VA_ARGS__; break; }
 
-// each returns MRDIS_EUNSUPPORTED outside what it covers (16 channels on the wide side, <= 8 on the narrow one, fp32)
-int mrdis_run_pw_fwd(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co,
-                     int lrelu, hipStream_t s) {
-    if (!pw_ok(Ci, Co, ldx, x, npix)) return MRDIS_EUNSUPPORTED;
+// each returns MRDIS_EUNSUPPORTED outside what it covers (16 channels on the wide side -- fp32 or bf16 views --, <= 8 fp32 channels on the narrow one)
+int mrdis_run_pw_fwd(const void* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, long long npix, int Ci, int Co,
+                     int lrelu, int x16_bf16, hipStream_t s) {
+    if (!pw_ok(Ci, Co, ldx, x, npix, x16_bf16 != 0)) return MRDIS_EUNSUPPORTED;
     const int grid = pw_grid(npix * 4, 4);
-    PW_BY_CO(pw_fwd_kernel, <<<dim3(grid), dim3(256), 0, s>>>(x, ldx, w_tck, bias, y, ldy, npix, lrelu))
+    if (x16_bf16) { PW_BY_CO(pw_fwd_kernel, __bf16, <<<dim3(grid), dim3(256), 0, s>>>((const __bf16*)x, ldx, w_tck, bias, y, ldy, npix, lrelu)) }
+    else { PW_BY_CO(pw_fwd_kernel, float, <<<dim3(grid), dim3(256), 0, s>>>((const float*)x, ldx, w_tck, bias, y, ldy, npix, lrelu)) }
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, long long npix, int Ci, int Co, hipStream_t s) {
-    if (!pw_ok(Ci, Co, lddx, dx, npix)) return MRDIS_EUNSUPPORTED;
+int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, int lddx, long long npix, int Ci, int Co, int x16_bf16, hipStream_t s) {
+    if (!pw_ok(Ci, Co, lddx, dx, npix, x16_bf16 != 0)) return MRDIS_EUNSUPPORTED;
     const int grid = pw_grid(npix * 4, 2);
-    PW_BY_CO(pw_dgrad_kernel, <<<dim3(grid), dim3(256), 0, s>>>(dy, lddy, w_tkc, dx, lddx, npix))
+    if (x16_bf16) { PW_BY_CO(pw_dgrad_kernel, __bf16, <<<dim3(grid), dim3(256), 0, s>>>(dy, lddy, w_tkc, (__bf16*)dx, lddx, npix)) }
+    else { PW_BY_CO(pw_dgrad_kernel, float, <<<dim3(grid), dim3(256), 0, s>>>(dy, lddy, w_tkc, (float*)dx, lddx, npix)) }
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co) {
-    if (Ci != PW_CI || Co < 1 || Co > PW_MAXCO || npix < 4096) return 0;
+size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co, int x16_bf16) {
+    if (Ci != PW_CI || Co < 1 || Co > PW_MAXCO || (!x16_bf16 && npix < 4096) || npix < 1) return 0;
     return sizeof(float) * (size_t)512 * (PW_CI * Co + Co) + 256;
 }
 
-int mrdis_run_pw_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       long long npix, int Ci, int Co, int accumulate_bias, hipStream_t s) {
-    if (!pw_ok(Ci, Co, ldx, x, npix)) return MRDIS_EUNSUPPORTED;
-    if (workspace_bytes + 256 < mrdis_pw_wgrad_workspace(npix, Ci, Co)) return MRDIS_EUNSUPPORTED;
+int mrdis_run_pw_wgrad(const void* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       long long npix, int Ci, int Co, int accumulate_bias, int x16_bf16, hipStream_t s) {
+    if (!pw_ok(Ci, Co, ldx, x, npix, x16_bf16 != 0)) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_pw_wgrad_workspace(npix, Ci, Co, x16_bf16)) return MRDIS_EUNSUPPORTED;
     int grid = pw_grid(npix * 4, 16);
     if (grid > 512) grid = 512;
     float* slab = reinterpret_cast<float*>(workspace);
     float* bslab = dbias ? slab + (size_t)grid * PW_CI * Co : nullptr;
-    PW_BY_CO(pw_wgrad_kernel, <<<dim3(grid), dim3(256), 0, s>>>(x, ldx, dy, lddy, slab, bslab, npix))
+    if (x16_bf16) { PW_BY_CO(pw_wgrad_kernel, __bf16, <<<dim3(grid), dim3(256), 0, s>>>((const __bf16*)x, ldx, dy, lddy, slab, bslab, npix)) }
+    else { PW_BY_CO(pw_wgrad_kernel, float, <<<dim3(grid), dim3(256), 0, s>>>((const float*)x, ldx, dy, lddy, slab, bslab, npix)) }
     MRDIS_CHECK_LAUNCH();
     return mrdis_launch_slab_reduce(slab, dw_tck, PW_CI * Co, Co, grid, bslab, dbias, accumulate_bias, s);
 }

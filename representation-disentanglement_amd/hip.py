@@ -437,6 +437,18 @@ def conv_out_hw(H, W, kh, kw, stride, pad):
 
 
 DT_F32, DT_F32_BF16M, DT_BF16 = 0, 1, 2          # include/mrdis.h MRDIS_DT_*
+DT_XBF16_YF32, DT_XF32_YBF16 = 3, 4              # mixed storage at the ends of a bf16 stretch (layer input x / output y)
+
+
+def _dt_xy(x, y):
+    """storage code of a layer whose input-side view is x (or dx) and output-side view y (or dy)"""
+    if x.dtype is y.dtype:
+        return _dt(x)
+    if x.dtype is torch.bfloat16 and y.dtype is torch.float32:
+        return DT_XBF16_YF32
+    if x.dtype is torch.float32 and y.dtype is torch.bfloat16:
+        return DT_XF32_YBF16
+    raise MrdisError(f'activation views must be fp32 or bf16, got {x.dtype} and {y.dtype}')
 
 
 def cast_bf16(t):
@@ -448,22 +460,33 @@ def cast_bf16(t):
     return out
 
 
-def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf16=None):
+def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf16=None, out_dtype=None, may_decline=False):
     """w_bf16: bf16 [T][Co][Ci] copy of the filter (reduction axis contiguous) -> bf16 MFMA operands, fp32 accumulate
-    (MRDIS_DT_F32_BF16M) where the geometry allows; None -> exact fp32."""
+    (MRDIS_DT_F32_BF16M) where the geometry allows; None -> exact fp32.
+    Mixed storage (out / out_dtype differ from x.dtype): the 1x1 head reads bf16 and writes fp32 (MRDIS_DT_XBF16_YF32); the 3x3
+    4 -> C si_layers read the fp32 anatomy map and write bf16 (MRDIS_DT_XF32_YBF16, w_tck in the 16-row layout of the mixing launch).
+    may_decline: return None instead of raising when the library has no kernel for a mixed-storage geometry."""
     lib = load()
     x, ldx = nhwc(x)
     N, Ci, H, W = x.shape
     T, Ci2, Co = w_tck.shape
-    assert T == kh * kw and Ci2 == Ci, (w_tck.shape, x.shape, kh, kw)
     Ho, Wo = conv_out_hw(H, W, kh, kw, stride, pad)
     if out is None:
-        out = empty_nhwc(N, Co, Ho, Wo, x.device, x.dtype)
+        out = empty_nhwc(N, Co, Ho, Wo, x.device, out_dtype or x.dtype)
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr(), 'conv2d_fwd: `out` must already be an NHWC view'
+    mixed = _dt_xy(x, y)
+    assert T == kh * kw and (Ci2 == Ci or (mixed == DT_XF32_YBF16 and Ci2 == max(Ci, 16))), (w_tck.shape, x.shape, kh, kw)
+    if mixed in (DT_XBF16_YF32, DT_XF32_YBF16):
+        rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), None, _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
+                                  1 if lrelu else 0, mixed, _stream())
+        if rc == -2 and may_decline:
+            return None
+        _chk(rc, 'conv2d_fwd (mixed storage)')
+        return out
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
-    dt = DT_BF16 if _dt(x, y) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
+    dt = DT_BF16 if mixed == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
     rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
                               1 if lrelu else 0, dt, _stream())
     if rc == -2 and dt == DT_BF16:
@@ -487,7 +510,11 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
         dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype); ldo = Ci
     else:
         dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
-        assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W) and out.dtype == dy.dtype
+        assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W)
+        if out.dtype != dy.dtype:    # the 1x1 head under bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32)
+            _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), _stream()),
+                 'conv2d_bwd_data (mixed storage)')
+            return dx
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
@@ -518,6 +545,10 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
         raise MrdisError('conv2d_bwd_weight: unsupported geometry')
     ws = _ws(nb, x.device)
     sink = bias_sink if (need_bias and bias_sink is not None) else None
+    if x.dtype is not dy.dtype:      # the 1x1 head under bf16 storage: x bf16, dy fp32 (MRDIS_DT_XBF16_YF32)
+        _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
+                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _dt_xy(x, dy), _stream()), 'conv2d_bwd_weight (mixed storage)')
+        return dw, db
     if _dt(x, dy) == DT_BF16:
         rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
                                          N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, DT_BF16, _stream())

@@ -152,6 +152,12 @@ def mix_pair_fused_all(gamma, beta, types):
 
 
 # --------------------------------------------------------------------------- all layers of a model mixed in one launch
+def native_head(kh, kw, Ci, Co):
+    """the 1x1 decoder head (16 -> <= 8, model.py:2605): under bf16 storage it runs on the mixed-storage streaming kernels of
+    csrc/mrdis_pointwise.hip (bf16 in, fp32 out: MRDIS_DT_XBF16_YF32) with its filter as it is -- no zero-padding to a 16 -> 16 layer"""
+    return kh == 1 and kw == 1 and Ci == 16 and 1 <= Co <= 8
+
+
 class MixPlan:
     """The static part of the all-layers mixing launches of one model (mrdis_mix_jobs_fwd / _bwd): which CondConv2d layers (`singles`)
     and fused gamma | beta pairs (`pairs`: (block, gamma, beta)) there are, persistent output buffers -- a step's mixed filters are
@@ -169,7 +175,7 @@ class MixPlan:
         for m in singles:
             E, Co, Ci, kh, kw = m.weight.shape
             Ci_p, Co_p = Ci, Co
-            if pad16 and m.stride[0] == 1 and (Ci < 16 or Co < 16) and hip.bconv_eligible(max(Ci, 16), max(Co, 16)):
+            if pad16 and m.stride[0] == 1 and (Ci < 16 or Co < 16) and hip.bconv_eligible(max(Ci, 16), max(Co, 16)) and not native_head(kh, kw, Ci, Co):
                 # bf16 storage: the narrow side of the 4 -> C si_layers and of the 64 -> 4 / 16 -> 7 heads is zero-padded to 16 so that the
                 # bf16 MFMA kernels take the layer (ops.conv2d); the mixing launch writes the filter straight into the padded layout
                 Ci_p, Co_p = max(Ci, 16), max(Co, 16)
@@ -537,6 +543,12 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
     wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
     if _COMPUTE_DTYPE == hip.DT_F32_BF16M:
         return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
+    if native_head(kh, kw, Ci, Co) and stride == 1 and pad == 0 and x.shape[1] == 16 and type(x) is torch.Tensor:
+        return conv2d_grouped(cast_view(x, torch.bfloat16), [(w_tck, w_tkc)], bias, kh, kw, pad, lrelu)      # bf16 in, fp32 out
+    if (kh, kw, stride, pad) == (3, 3, 1, 1) and Ci in (4, 16) and Co >= 16 and x.shape[1] == 4 and x.dtype == torch.float32 and not lrelu and type(x) is torch.Tensor:
+        # the 4 -> C si_layers (filter as it is, or in the 16-row layout of the mixing launch): the route of the grouped decoders
+        # (forward on the Cin = 4 kernel: fp32 map in, bf16 out; backward on the zero-padded bf16 MFMA kernels)
+        return conv2d_grouped(x, [(w_tck, w_tkc)], bias, kh, kw, pad, co=co)
     if hip.bconv_eligible(Ci, Co):
         # (a filter that the all-layers mixing launch wrote zero-padded to 16 channels -- MixPlan.padded -- meets a narrower input / bias /
         #  true output width `co` here: the view cast pads the input, the bias is padded once per step, the output is sliced back to fp32)
@@ -609,16 +621,24 @@ class _GroupedConvFn(Function):
         H, W = x.shape[2], x.shape[3]
         Cif, Cof = filt[0].shape[1], filt[0].shape[2]           # the filters' channel counts: already zero-padded to 16 when they come from
         Ci, Co = x.shape[1], (int(co) if co else Cof)           # the all-layers mixing launch (MixPlan.padded); Ci, Co: the layer's own
-        Ci_p, Co_p = (max(Cif, 16), max(Cof, 16)) if st else (Cif, Cof)
+        head = st and native_head(kh, kw, Cif, Cof) and pad == 0 and Ci == 16        # bf16 in, fp32 out on the streaming 1x1 kernels
+        Ci_p, Co_p = (max(Cif, 16), max(Cof, 16)) if (st and not head) else (Cif, Cof)
         padded = (Ci_p, Co_p) != (Cif, Cof)                     # the filters still need padding here
+        # the 3x3 4 -> C si_layers with the filter in the 16-row layout of the mixing launch: the Cin = 4 kernel reads the fp32 anatomy
+        # map and writes bf16 (MRDIS_DT_XF32_YBF16) -- the zero-padded bf16 copy of x is only made for the weight gradient
+        si4 = st and x.dtype == torch.float32 and Ci == 4 and Ci_p == 16 and (kh, kw, pad) == (3, 3, 1) and Co_p == Cof and not lrelu
         xin = x
         if st and (x.dtype != torch.bfloat16 or Ci_p != Ci):
             xin = hip.cast_view(x, torch.bfloat16, Ci_p)           # fp32 -> bf16 view cast, zero channels up to 16
-        y = hip.empty_nhwc(G * B, Co_p, H, W, x.device, xin.dtype)
+        y = hip.empty_nhwc(G * B, Co_p, H, W, x.device, torch.float32 if head else xin.dtype)
         use_tkc, wbs = [], []
         for g in range(G):
             tck, tkc = filt[2 * g], filt[2 * g + 1]
             bg = bias
+            if head:
+                use_tkc.append(tkc); wbs.append(None)
+                hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B])
+                continue
             if padded:
                 tck, tkc, bg, wb_f, wb_b = _pad16_filters(tck, tkc, bias, Ci_p, Co_p)
             else:
@@ -626,8 +646,11 @@ class _GroupedConvFn(Function):
                 if bias is not None and bias.shape[0] < Co_p:
                     bg = _pad_bias16(bias, Co_p, detach=True)
             use_tkc.append(tkc); wbs.append(wb_b)
+            if si4 and hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, out=y[g * B:(g + 1) * B], may_decline=True) is not None:
+                continue
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
+        ctx.head = head
         ctx.dx_in_gb = bool(getattr(x, '_mrdis_want_dgb', False)) and _GB_INPLACE
         ctx.wbs = wbs
         ctx.bias_param = bias
@@ -640,7 +663,9 @@ class _GroupedConvFn(Function):
         xin, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         tkcs = ctx.saved_tensors[2:]
         bias = ctx.bias_param
-        if Co_p != Co:
+        if ctx.head:
+            dy = hip.cast_view(dy, torch.float32)                 # fp32 reconstruction gradient in, bf16 trunk gradient out
+        elif Co_p != Co:
             dy = hip.cast_view(dy, torch.bfloat16, Co_p)
         elif dy.dtype != xin.dtype:
             dy = hip.cast_view(dy, xin.dtype)
@@ -650,12 +675,12 @@ class _GroupedConvFn(Function):
         need_x = ctx.needs_input_grad[0]
         dxb = None
         if need_x:
-            if ctx.dx_in_gb and not share_x and Ci_p == Ci and dy.dtype == x_dtype:
+            if ctx.dx_in_gb and not share_x and Ci_p == Ci and xin.dtype == x_dtype:
                 # the input is the modulated map of a fused SPADE node (ops._GbSpadeFn): its gradient is also the beta half of that node's
                 # [dgamma | dbeta] buffer -- write it there, the node then fills in the other half (hip.gb_slot)
-                dxb = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, dy.dtype)[:, Ci:]
+                dxb = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, xin.dtype)[:, Ci:]
             else:
-                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, dy.dtype)
+                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, xin.dtype)
         sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None
         dws, db_total = [], None
         for g in range(G):

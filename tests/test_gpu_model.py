@@ -118,6 +118,11 @@ def _cfg(mrdis, M, H, W, B, adv=False):
     return mrdis.derive_config(cfg, DEV)
 
 
+# per-tensor gradient norms vs the reference: |ours - ref| <= a (ref + 4e-3 total).  The floor term is for tensors whose gradient is
+# rounding noise next to the step's total (conv biases in front of a norm layer: analytically zero), the relative term for the rest.
+PER_TENSOR_A = 5e-3
+
+
 @pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
 def test_train_step_golden(mrdis, golden_dir, tag):
     """One full training step at the reference's own size vs vectors from the real reference."""
@@ -152,8 +157,15 @@ def test_train_step_golden(mrdis, golden_dir, tag):
     total = float(np.sqrt(sum(v * v for v in gn.values())))
     ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
     assert abs(total - ref_total) <= 1e-3 * ref_total, (total, ref_total)
+    worst = max((abs(gn[k] - v) / (v + 4e-3 * ref_total), k) for k, v in hot.items())
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/f32_golden_measured.jsonl', 'a') as f:
+            f.write(json.dumps(dict(tag=tag, worst_per_tensor=worst[0], tensor=worst[1], total_rel=abs(total - ref_total) / ref_total)) + '\n')
+    except OSError:
+        pass
     for k, v in hot.items():
-        assert abs(gn[k] - v) <= 5e-3 * v + 2e-5 * ref_total, (k, gn[k], v)
+        assert abs(gn[k] - v) <= PER_TENSOR_A * (v + 4e-3 * ref_total), (k, gn[k], v)
     # clip + Adam on the arena vs the reference's weights after optimizer.step()
     step.optimizer.step(fused_clip=True)
     for k, v in meta['wsum_after'].items():

@@ -215,9 +215,12 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
         assert num / den <= 2e-6, num / den
 
 
-def _bf16_path(Ci, Co, s):
+def _bf16_path(Ci, Co, s, k=3):
     """which kernels ops.conv2d runs a layer on under compute_dtype 'bf16': 'bf16' = the bf16 MFMA kernels on bf16 views (a 4- / 7-channel
-    side of a stride-1 layer zero-padded to 16), 'f32' = the fp32 kernels between view casts (the stride-2 first layers)"""
+    side of a stride-1 layer zero-padded to 16), 'f32' = the fp32 kernels between view casts (the stride-2 first layers), 'head' = the
+    1x1 decoder head on the mixed-storage streaming kernels (bf16 in, fp32 weights and out)"""
+    if k == 1 and Ci == 16 and Co <= 8:
+        return 'head'
     if Ci % 16 == 0 and Co % 4 == 0 and Co >= 16:
         return 'bf16'
     return 'bf16' if s == 1 else 'f32'
@@ -256,7 +259,7 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
     name, N, Ci, Co, k, s, p, H, W = case
     m, hip = mrdis, mrdis.hip
     B16 = torch.bfloat16
-    path = _bf16_path(Ci, Co, s)
+    path = _bf16_path(Ci, Co, s, k)
     S = sorted({0, N // 2 + 1, N - 1})
     w = rnd((Co, Ci, k, k), 2, 0.5 / np.sqrt(Ci * k * k)); b = rnd((Co,), 3, 0.1)
     Ho, Wo = hip.conv_out_hw(H, W, k, k, s, p)
@@ -279,7 +282,11 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
         xs = xs.contiguous().requires_grad_(True); ws = wr.clone().requires_grad_(True)
         ys = F.conv2d(xs, ws, b, s, p)
         ys.backward(dy_s)
-        assert rel(y[S], ys) <= 4e-3, ('fwd vs torch', name, rel(y[S], ys))                       # a bf16 result: 2^-9 relative per element
+        if Ci == 4 and path == 'bf16':
+            # the si_layers' forward runs on the Cin = 4 kernel (fp32 map and filter in, bf16 out); only their backward multiplies bf16-rounded operands
+            assert rel(y[S], F.conv2d(xd[S].float().cpu(), w, b, s, p)) <= 4e-3, ('fwd (Cin = 4 kernel) vs torch', name)
+        else:
+            assert rel(y[S], ys) <= 4e-3, ('fwd vs torch', name, rel(y[S], ys))                   # a bf16 result: 2^-9 relative per element
         assert rel(dx[S], xs.grad) <= 4e-3, ('dgrad vs torch', name, rel(dx[S], xs.grad))
         dys = torch.zeros_like(dyd); dys[S] = dyd[S]
         _, _, dw_s, db_s = _run_bf16_layer(m, xd, w, b, dys, k, s, p, Co)
@@ -329,6 +336,82 @@ def _one_step(m, mode, B_=B, H=HW, W=HW, opts=()):
         m.ops.set_compute_dtype('f32')
 
 
+def test_bf16_boundary_kernels_at_bench_scale(mrdis):
+    """The two ends of the decoders' bf16 stretch as the grouped decoders run them at B = 32 / 256x256 (ops.conv2d_grouped, two groups):
+    the 4 -> 32 si_layers with the filter in the 16-row layout of the mixing launch -- forward on the Cin = 4 kernel reading the fp32
+    anatomy map and writing bf16 (MRDIS_DT_XF32_YBF16), backward on the padded bf16 kernels -- and the 1x1 head 16 -> 7 on the
+    mixed-storage streaming kernels (MRDIS_DT_XBF16_YF32: bf16 trunk in, fp32 reconstruction out, all three directions).  Against torch
+    fp32 on the operands each kernel multiplies, and the si forward against the padded bf16 MFMA path (option debug_noc4)."""
+    m, hip, ops = mrdis, mrdis.hip, mrdis.ops
+    B16 = torch.bfloat16
+    N, H = B, HW
+    S = [0, N - 1]
+    r16 = lambda t_: t_.float().bfloat16().float()
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    ops.set_compute_dtype('bf16')
+    try:
+        # ---- si_layers: one shared fp32 input, two filter sets
+        x = torch.randn((N, 4, H, H), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+        ws = [rnd((32, 4, 3, 3), 20 + g, 0.2) for g in range(2)]; b = rnd((32,), 23, 0.1)
+        dy = torch.randn((2 * N, 32, H, H), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last).to(B16)
+
+        def run_si():
+            xs = x.detach().requires_grad_(True)
+            tcks = [F.pad(to_tck(w), (0, 0, 0, 12)).to(DEV).requires_grad_(True) for w in ws]          # [9][16][32], rows 4.. zero
+            bias = b.to(DEV).requires_grad_(True)
+            with ops.mix_cache():
+                y = ops.conv2d_grouped(xs, [(t_, t_.detach().permute(0, 2, 1).contiguous()) for t_ in tcks], bias, 3, 3, 1, share_x=True, co=32)
+                y.backward(dy)
+            return y.detach(), xs.grad, [t_.grad[:, :4] for t_ in tcks], bias.grad
+        y, dx, dws, db = run_si()
+        assert y.dtype == B16 and dx.dtype == torch.float32
+        with hip.option('debug_noc4', 1):
+            y_p, dx_p, dws_p, db_p = run_si()
+        assert not torch.equal(y, y_p), 'the Cin = 4 kernel did not run'
+        assert torch.equal(dx, dx_p) and all(torch.equal(a, c) for a, c in zip(dws, dws_p))       # the backward is the same padded path
+        for g in range(2):
+            want = F.conv2d(x[S].cpu(), ws[g], b, 1, 1)                       # fp32 operands, bf16 result
+            assert rel(y[[g * N + s_ for s_ in S]], want) <= 4e-3, ('si fwd vs torch', g)
+            assert rel(y_p[[g * N + s_ for s_ in S]], F.conv2d(r16(x[S].cpu()), r16(ws[g]), b, 1, 1)) <= 4e-3
+        xr = r16(x[S].cpu()).requires_grad_(True)
+        wr = [r16(w).requires_grad_(True) for w in ws]
+        tot = sum((F.conv2d(xr, wr[g], None, 1, 1) * dy[[g * N + s_ for s_ in S]].float().cpu()).sum() for g in range(2))
+        tot.backward()
+        assert rel(dx[S], xr.grad) <= 1e-2, 'si dgrad vs torch'             # two bf16 group gradients, added in bf16: three roundings
+        del y, y_p, dx, dx_p, dy
+        # ---- 1x1 head: bf16 trunk in, fp32 out
+        xh = torch.randn((2 * N, 16, H, H), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last).to(B16)
+        wh = [rnd((7, 16, 1, 1), 30 + g, 0.25) for g in range(2)]; bh = rnd((7,), 33, 0.1)
+        dyh = torch.randn((2 * N, 7, H, H), device=DEV, generator=gen).contiguous(memory_format=torch.channels_last)
+        dyz = torch.zeros_like(dyh)
+        idx = [g * N + s_ for g in range(2) for s_ in S]
+        dyz[idx] = dyh[idx]
+
+        def run_head(dy_):
+            xs = xh.detach().requires_grad_(True)
+            tcks = [to_tck(w).to(DEV).requires_grad_(True) for w in wh]
+            bias = bh.to(DEV).requires_grad_(True)
+            with ops.mix_cache():
+                y = ops.conv2d_grouped(xs, [(t_, t_.detach().permute(0, 2, 1).contiguous()) for t_ in tcks], bias, 1, 1, 0, co=7)
+                y.backward(dy_)
+            return y.detach(), xs.grad, [t_.grad for t_ in tcks], bias.grad
+        yh, dxh, _, _ = run_head(dyh)
+        assert yh.dtype == torch.float32 and dxh.dtype == B16
+        _, _, dwz, dbz = run_head(dyz)
+        xs_c = xh[idx].float().cpu().requires_grad_(True)
+        wc = [w.clone().requires_grad_(True) for w in wh]
+        outs = [F.conv2d(xs_c[2 * g:2 * g + 2], wc[g], bh) for g in range(2)]
+        for g in range(2):
+            assert rel(yh[idx[2 * g:2 * g + 2]], outs[g]) <= 2e-5, ('head fwd vs torch', g)       # fp32 arithmetic on the stored bf16 values
+        sum((o * dyh[idx[2 * g:2 * g + 2]].cpu()).sum() for g, o in enumerate(outs)).backward()
+        assert rel(dxh[idx], xs_c.grad) <= 4e-3, 'head dgrad vs torch (bf16 result)'
+        for g in range(2):
+            assert rel(dwz[g], to_tck(wc[g].grad)) <= 2e-5, ('head wgrad vs torch', g)
+        assert rel(dbz, dyz.sum((0, 2, 3)).cpu()) <= 2e-5
+    finally:
+        ops.set_compute_dtype('f32')
+
+
 def test_full_step_at_bench_scale_bf16(mrdis):
     """One B = 32, M = 4, 256x256 training step (adversarial loss on) under `compute_dtype: bf16` -- the BASELINE configs[2] workload
     per GPU: (a) the pipelined / packed kernels (default) vs the plain ones (wino_pipe = 0, debug_nopack = 1): identical arithmetic, so
@@ -339,7 +422,7 @@ def test_full_step_at_bench_scale_bf16(mrdis):
     l_b, p_b, g_b, w_b, names, offs = _one_step(m, 'bf16')
     l_p, p_p, g_p, w_p, _, _ = _one_step(m, 'bf16', opts=(('wino_pipe', 0), ('debug_nopack', 1)))
     assert np.isfinite(l_b) and abs(l_b - l_p) <= 1e-6 * abs(l_p), (l_b, l_p)
-    assert abs(g_b - g_p) <= 1e-5 * g_p, (g_b, g_p)
+    assert abs(g_b - g_p) <= 1e-4 * g_p, (g_b, g_p)           # (measured 1.1e-5: wino_pipe = 0 also takes the SPADE modulation out of the convolution's epilogue)
     assert float((w_b - w_p).abs().max()) <= 4.2e-4 and float((w_b - w_p).abs().mean()) <= 1e-7
     l_f, p_f, g_f, w_f, names_f, _ = _one_step(m, 'f32')
     assert names == names_f
