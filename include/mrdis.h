@@ -226,7 +226,8 @@ int mrdis_bn_train_bwd(const void* dy, int lddy, const void* x, int ldx, const f
 
 /* ---- InstanceNorm2d(affine=False) fused with the SPADE modulation:
  * model.py:2431/2440 + 2446:  out = IN(z) * (1 + gamma) + beta ---------------
- * z, gamma, beta, out : (N, HW, C) views ; save_mean/save_rstd : (N*C).       */
+ * z, gamma, beta, out : (N, HW, C) views ; save_mean/save_rstd : (N*C), written -- or, with workspace = NULL, READ: the
+ * statistics of z are then taken from them (mrdis_bilinear_up2_stats_fwd computed them when z was produced).            */
 int mrdis_instnorm_spade_fwd(const void* z, int ldz, const void* gamma, int ldg,
                              const void* beta, int ldb, void* out, int ldo,
                              float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
@@ -242,6 +243,16 @@ int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz,
  * 2432 / 2501-2509 (align_corners=False, arbitrary output size) --------------*/
 int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi,
                        int Ho, int Wo, int C, int align_corners, int dtype, void* stream);
+/* nn.Upsample(scale_factor=(2,2), bilinear) between two SPADE blocks (model.py:2551-2573, 2622-2627) together with the InstanceNorm
+ * statistics of its result (model.py:2440): y (N, 2 Hi, 2 Wi, C) as mrdis_bilinear_fwd(align_corners = 0) writes it, save_mean /
+ * save_rstd (N*C) as mrdis_instnorm_stats would compute them from y -- taken from the values while they are stored, so the 4x tensor
+ * is not read back for a statistics pass.  C % 4 == 0, 16-byte aligned views; MRDIS_EUNSUPPORTED otherwise.  The consumer passes the
+ * statistics on: mrdis_conv2d_fwd_spade takes them as arguments, mrdis_instnorm_spade_fwd with workspace = NULL uses the ones in
+ * save_mean / save_rstd instead of computing them.                                                                                */
+size_t mrdis_bilinear_up2_stats_workspace(int N, int Hi, int C);
+int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C,
+                                 float* save_mean, float* save_rstd, float eps, void* workspace, size_t workspace_bytes,
+                                 int dtype, void* stream);
 int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi,
                        int Ho, int Wo, int C, int align_corners, int dtype, void* stream);
 

@@ -384,16 +384,18 @@ static int instnorm_spade_fwd_impl(const T* z, int ldz, const T* gamma, int ldg,
                                         const T* beta, int ldb, T* out, int ldo,
                                         float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
                                         int N, long long HW, int C, float eps, void* stream) {
-    if (!z || !gamma || !beta || !out || !save_mean || !save_rstd || !workspace || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
-    if (workspace_bytes < mrdis_norm_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
+    if (!z || !gamma || !beta || !out || !save_mean || !save_rstd || N < 1 || HW < 1 || C < 1) return MRDIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<0, T>(z, ldz, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
-    if (rc) return rc;
-    const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
-                       save_mean, save_rstd, nullptr, nullptr);
-    MRDIS_CHECK_LAUNCH();
+    if (workspace != nullptr) {        // workspace == NULL: save_mean / save_rstd already hold the statistics of z (e.g. from mrdis_bilinear_up2_stats_fwd)
+        if (workspace_bytes < mrdis_norm_workspace(N, HW, C)) return MRDIS_EWORKSPACE;
+        float* part = reinterpret_cast<float*>(workspace);
+        int rc = launch_stats<0, T>(z, ldz, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
+        if (rc) return rc;
+        const StatPlan sp = stat_plan(N, HW);
+        hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+                           save_mean, save_rstd, nullptr, nullptr);
+        MRDIS_CHECK_LAUNCH();
+    }
     const long long rows = (long long)N * HW;
     if (vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(beta, ldb, C) && vec4_ok(out, ldo, C))
         hipLaunchKernelGGL((spade_fwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
@@ -696,8 +698,14 @@ __global__ void bilinear_bwd_tight_kernel(const T* __restrict__ dy, int lddy, T*
 // source index rule gives out[2i] = 0.25 x[max(i-1,0)] + 0.75 x[i], out[2i+1] = 0.75 x[i] + 0.25 x[min(i+1,H-1)] on both axes
 // (same fp32 products and association as the generic kernel).  A thread owns one INPUT pixel (4 channels) and writes its 2x2
 // outputs from the 3x3 neighbourhood: 9 loads per 4 outputs instead of 16, no per-output index arithmetic.
-template <typename T>
-__global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int Hi, int Wi, int C) {
+// STATS: the kernel also leaves the per-(image, channel) sums of the values it STORES (sum, sum of squares; one partial per input row in
+// the `part` layout of stat_final_kernel, chunk = input row): the consumer of the up-sampled map is a SPADE block's InstanceNorm
+// (model.py:2440), whose statistics pass would otherwise read the 4x tensor back from HBM.  Needs blockDim.x % (C / 4) == 0 (a thread
+// keeps its channel group); block reduction in LDS in a fixed order.
+template <typename T, bool STATS = false>
+__global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int Hi, int Wi, int C, float* __restrict__ part = nullptr) {
+    __shared__ float red_[STATS ? 256 * 9 : 1];
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     const int Q = C / 4;
     const int i = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x), n = blockIdx.y;
     const int im = i > 0 ? i - 1 : 0, ip = i < Hi - 1 ? i + 1 : Hi - 1;
@@ -719,18 +727,40 @@ __global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __r
         cl_.load(rc + (long long)jm * ldx + 4 * q); cc.load(rc + (long long)j * ldx + 4 * q); cr.load(rc + (long long)jp * ldx + 4 * q);
         bl.load(rp + (long long)jm * ldx + 4 * q); bc.load(rp + (long long)j * ldx + 4 * q); br.load(rp + (long long)jp * ldx + 4 * q);
         // generic form: l0h * (l0w * p00 + l1w * p01) + l1h * (l0w * p10 + l1w * p11), (p0x = upper row, px0 = left column)
+        auto tally = [&](const Vec<4>& v_) {
+            if (STATS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float r_ = (float)(T)v_.v[k]; s0[k] += r_; s1[k] += r_ * r_; }      // the value as stored
+            }
+        };
 #pragma unroll
         for (int k = 0; k < 4; ++k) o.v[k] = a_t * (b_l * tl.v[k] + b_c0 * tc.v[k]) + a_c0 * (b_l * cl_.v[k] + b_c0 * cc.v[k]);
-        o.store(y0 + (long long)(2 * j) * ldy + 4 * q);
+        o.store(y0 + (long long)(2 * j) * ldy + 4 * q); tally(o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o.v[k] = a_t * (b_c1 * tc.v[k] + b_r * tr.v[k]) + a_c0 * (b_c1 * cc.v[k] + b_r * cr.v[k]);
-        o.store(y0 + (long long)(2 * j + 1) * ldy + 4 * q);
+        o.store(y0 + (long long)(2 * j + 1) * ldy + 4 * q); tally(o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o.v[k] = a_c1 * (b_l * cl_.v[k] + b_c0 * cc.v[k]) + a_b * (b_l * bl.v[k] + b_c0 * bc.v[k]);
-        o.store(y1 + (long long)(2 * j) * ldy + 4 * q);
+        o.store(y1 + (long long)(2 * j) * ldy + 4 * q); tally(o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o.v[k] = a_c1 * (b_c1 * cc.v[k] + b_r * cr.v[k]) + a_b * (b_c1 * bc.v[k] + b_r * br.v[k]);
-        o.store(y1 + (long long)(2 * j + 1) * ldy + 4 * q);
+        o.store(y1 + (long long)(2 * j + 1) * ldy + 4 * q); tally(o);
+    }
+    if (STATS) {
+        // every thread's items share one channel group q = threadIdx.x % Q; the blockDim.x / Q threads of a group are added in thread order
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red_[tid * 9 + k] = s0[k]; red_[tid * 9 + 4 + k] = s1[k]; }
+        __syncthreads();
+        if (tid < Q) {
+            float t_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int u = tid; u < (int)blockDim.x; u += Q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t_[k] += red_[u * 9 + k];
+            float* dst = part + ((long long)(n * Hi + i) * 2) * C;          // group = image n, chunk = input row i
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst[4 * tid + k] = t_[k]; dst[C + 4 * tid + k] = t_[4 + k]; }
+        }
     }
 }
 // adjoint: dx[i][j] = sum over the 4 x 4 output block rows 2i-1 .. 2i+2, columns 2j-1 .. 2j+2 with the separable weights
@@ -820,6 +850,27 @@ static int bilinear_bwd_impl(const T* dy, int lddy, T* dx, int lddx, int N, int 
     return MRDIS_OK;
 }
 
+// nn.Upsample(scale_factor=(2,2), bilinear, align_corners=False) + the instance statistics of its result in one pass (see the STATS form
+// of bilinear_up2_fwd_kernel): y as mrdis_bilinear_fwd writes it, save_mean / save_rstd as mrdis_instnorm_stats would compute them from y
+// (same fp64 combine of fp32 partial sums; the partial sums are taken in another order).
+extern "C" size_t mrdis_bilinear_up2_stats_workspace(int N, int Hi, int C) { return sizeof(float) * 2 * (size_t)N * Hi * C + 64; }
+template <typename T>
+static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, int Wi, int C, float* save_mean, float* save_rstd, float eps,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !y || !save_mean || !save_rstd || !workspace || N < 1 || Hi < 1 || Wi < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
+    if (workspace_bytes < mrdis_bilinear_up2_stats_workspace(N, Hi, C)) return MRDIS_EWORKSPACE;
+    const int threads = bil_threads((long long)Wi * (C / 4));
+    if (N > 65535 || C % 4 != 0 || !vec4_ok(x, ldx, C) || !vec4_ok(y, ldy, C) || threads % (C / 4) != 0) return MRDIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, true>), dim3(Hi, N), dim3(threads), 0, s, x, ldx, y, ldy, Hi, Wi, C, part);
+    MRDIS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(Hi)), 0, s, part, Hi, C, N, 4LL * Hi * Wi, eps, 0.f,
+                       save_mean, save_rstd, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // ------------------------------------------------------------------ softmax([scale*mask, s])[1:]
 
 // ---- C ABI: activation views are fp32 or bf16 by `dtype` (include/mrdis.h MRDIS_DT_*); statistics, parameters and their
@@ -883,6 +934,12 @@ extern "C" int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy,
 extern "C" int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype, bilinear_fwd_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream),
                           bilinear_fwd_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream));
+}
+extern "C" int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C, float* save_mean, float* save_rstd, float eps,
+                                            void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        bilinear_up2_stats_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, C, save_mean, save_rstd, eps, workspace, workspace_bytes, stream),
+        bilinear_up2_stats_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, C, save_mean, save_rstd, eps, workspace, workspace_bytes, stream));
 }
 extern "C" int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype, bilinear_bwd_impl((const float*)dy, lddy, (float*)dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, stream),

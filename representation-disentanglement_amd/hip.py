@@ -63,6 +63,8 @@ _SIGS = {
     'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
     'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
+    'mrdis_bilinear_up2_stats_workspace': (_Z, [_I, _I, _I]),
+    'mrdis_bilinear_up2_stats_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _Z, _I, _P]),
     'mrdis_softmax_mask_drop_fwd': (_I, [_P, _I, _P, _P, _I, _L, _I, _F, _P]),
     'mrdis_softmax_mask_drop_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'mrdis_recon_err_workspace': (_Z, [_I, _L, _I]),
@@ -616,11 +618,18 @@ def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None):
     return dx, dg, db
 
 
-def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
+def instnorm_spade_fwd(z, gamma, beta, eps=1e-5, stats=None):
+    """stats = (mean, rstd) of z already computed (bilinear_up2_stats): the statistics pass is skipped"""
     lib = load()
     z, ldz = nhwc(z); gamma, ldg = nhwc(gamma); beta, ldb = nhwc(beta)
     N, C, H, W = z.shape
     out = empty_nhwc(N, C, H, W, z.device, z.dtype)
+    if stats is not None:
+        mean, rstd = stats
+        assert mean.numel() == N * C and rstd.numel() == N * C and mean.is_contiguous() and rstd.is_contiguous()
+        _chk(lib.mrdis_instnorm_spade_fwd(_ptr(z), ldz, _ptr(gamma), ldg, _ptr(beta), ldb, _ptr(out), C, _ptr(mean), _ptr(rstd),
+                                          None, 0, N, H * W, C, eps, _dt(z, gamma, beta), _stream()), 'instnorm_spade_fwd')
+        return out, mean, rstd
     mean = torch.empty(N * C, dtype=torch.float32, device=z.device)
     rstd = torch.empty(N * C, dtype=torch.float32, device=z.device)
     nb = _ws_bytes(lib.mrdis_norm_workspace, N, H * W, C)
@@ -630,7 +639,7 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5):
     return out, mean, rstd
 
 
-def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None):
+def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_ready=False):
     """fused gamma | beta convolution + InstanceNorm modulation (mrdis_conv2d_fwd_spade): -> (mix, gamma, mean, rstd), or None where the
     fused kernel does not apply (the caller then runs conv2d_fwd + instnorm_spade_fwd).  fp32 views, or bf16 views with w_bf16 = the bf16
     [9][2C][Ci] filter.  out = (mix, gamma, mean, rstd) dense views to fill."""
@@ -654,7 +663,9 @@ def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None):
     ws = _ws(nb, z.device)
     st = _stream()
     # the statistics first (stream order); if the fused kernel then declines, they are simply recomputed by the two-step path
-    _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, dt, st), 'instnorm_stats')
+    # (stats_ready: `out`'s mean / rstd already hold them -- the x2 resize that produced z took them on the way, bilinear_up2_stats)
+    if not stats_ready:
+        _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, dt, st), 'instnorm_stats')
     rc = lib.mrdis_conv2d_fwd_spade(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(mix), C, _ptr(gamma), C,
                                     N, H, W, Ci, C, dt, st)
     if rc == -2:
@@ -715,6 +726,25 @@ def bilinear_fwd(x, out_hw, align_corners):
     y = empty_nhwc(N, C, Ho, Wo, x.device, x.dtype)
     _chk(lib.mrdis_bilinear_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _dt(x), _stream()), 'bilinear_fwd')
     return y
+
+
+def bilinear_up2_stats(x, eps):
+    """x2 bilinear (align_corners=False) + instance statistics of the result: -> (y, mean, rstd), or None where the fused kernel does not apply"""
+    lib = load()
+    x, ldx = nhwc(x)
+    N, C, Hi, Wi = x.shape
+    if C % 4 != 0:
+        return None
+    y = empty_nhwc(N, C, 2 * Hi, 2 * Wi, x.device, x.dtype)
+    mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    nb = _ws_bytes(lib.mrdis_bilinear_up2_stats_workspace, N, Hi, C)
+    ws = _ws(nb, x.device)
+    rc = lib.mrdis_bilinear_up2_stats_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, C, _ptr(mean), _ptr(rstd), eps, _ptr(ws), nb, _dt(x), _stream())
+    if rc == -2:
+        return None
+    _chk(rc, 'bilinear_up2_stats_fwd')
+    return y, mean, rstd
 
 
 def bilinear_bwd(dy, in_hw, align_corners):

@@ -388,9 +388,10 @@ class SPADEBlockNew(nn.Module):
         return ops.conv2d_grouped(mix, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, pad, co=self.out.out_channels)
 
 
-def _up2(x):
-    """nn.Upsample(scale_factor=(2,2), mode='bilinear')  (model.py:2551)."""
-    return ops.bilinear(x, (2 * x.shape[2], 2 * x.shape[3]), False)
+def _up2(x, norm=None):
+    """nn.Upsample(scale_factor=(2,2), mode='bilinear')  (model.py:2551).  norm: the InstanceNorm2d of the SPADE block that reads the
+    result -- its statistics are then taken while the result is written (ops.bilinear_up2) instead of in a pass of their own."""
+    return ops.bilinear_up2(x, None if norm is None else norm.eps)
 
 
 class SPADENewShared(nn.Module):
@@ -409,9 +410,9 @@ class SPADENewShared(nn.Module):
         H, W = self.image_size
         x = ops.to_storage(self.zi_scaler(zi).reshape(-1, self.z_num_ch, H // 32, W // 32))     # opens the decoder's bf16 stretch
         x = self.sp1(si, x, inputs_type)
-        x = self.sp2(si, _up2(x), inputs_type)
-        x = self.sp3(si, _up2(x), inputs_type)
-        return _up2(x)
+        x = self.sp2(si, _up2(x, self.sp2.zi_layers), inputs_type)
+        x = self.sp3(si, _up2(x, self.sp3.zi_layers), inputs_type)
+        return _up2(x, self.sp3.zi_layers)             # read by sp4 of a SPADENewNotShared (same InstanceNorm2d defaults)
 
 
 class SPADENewNotShared(nn.Module):
@@ -435,16 +436,16 @@ class SPADENewNotShared(nn.Module):
 
     def forward(self, si, zi_sp4_input, inputs_type=None):
         x = self.sp4(si, zi_sp4_input, inputs_type)
-        x = self.sp5(si, _up2(x), inputs_type)
-        x = self.sp6(si, _up2(x), inputs_type)
+        x = self.sp5(si, _up2(x, self.sp5.zi_layers), inputs_type)
+        x = self.sp6(si, _up2(x, self.sp6.zi_layers), inputs_type)
         x = self.out(x, inputs_type) if self.is_cond else self.out(x)
         return self.out_act(x)
 
     def forward_grouped(self, si, z_cat, types):
         """forward for G modality labels on batch-concatenated inputs (see SPADEBlockNew.forward_grouped)."""
         x = self.sp4.forward_grouped(si, z_cat, types)
-        x = self.sp5.forward_grouped(si, _up2(x), types)
-        x = self.sp6.forward_grouped(si, _up2(x), types)
+        x = self.sp5.forward_grouped(si, _up2(x, self.sp5.zi_layers), types)
+        x = self.sp6.forward_grouped(si, _up2(x, self.sp6.zi_layers), types)
         kh, kw = self.out.kernel_size
         x = ops.conv2d_grouped(x, [self.out.mixed_uniform(t) for t in types], self.out.bias, kh, kw, self.out.padding[0], co=self.out.out_channels)
         return self.out_act(x)
@@ -762,7 +763,11 @@ class MultimodalModel(nn.Module):
             mids = {}
             for j in range(M):
                 mid = self.input_decoder_list[-1](s_cat, zi_list[j].repeat(M, 1), self._type(j, M * B))
+                st = getattr(mid, '_mrdis_in_stats', None)                # instance statistics taken by the last x2 resize (ops.bilinear_up2)
                 for i, part in enumerate(ops.split_batch(mid, M)):        # one-pass adjoint instead of M zero-fills + adds
+                    if st is not None:
+                        n = st[0].numel() // M
+                        part._mrdis_in_stats = (st[0][i * n:(i + 1) * n], st[1][i * n:(i + 1) * n], st[2])
                     mids[(i, j)] = part
             return (list(si_list), list(zi_list), mids)       # inputs kept alive with the cache entry
         return ops.step_cache(key, make)[2]
@@ -785,6 +790,9 @@ class MultimodalModel(nn.Module):
             for i in range(M):
                 self.premix(f'dec{i}')
                 z_cat = torch.cat([mids[(i, j)] for j in range(M)], 0)
+                sts = [getattr(mids[(i, j)], '_mrdis_in_stats', None) for j in range(M)]
+                if all(s_ is not None and s_[2] == sts[0][2] for s_ in sts):
+                    z_cat._mrdis_in_stats = (torch.cat([s_[0] for s_ in sts]), torch.cat([s_[1] for s_ in sts]), sts[0][2])
                 y = self.input_decoder_list[i].forward_grouped(si_list[i], z_cat, types)
                 for j, part in enumerate(ops.split_batch(y, M)):
                     outs[(i, j)] = part

@@ -715,7 +715,8 @@ class _GbSpadeFn(Function):
     The backward is that of the two-step form (it needs gamma, which the fused kernel stores)."""
 
     @staticmethod
-    def forward(ctx, si_out, z, bias, G, eps, *filt):
+    def forward(ctx, si_out, z, bias, G, eps, smean, srstd, *filt):
+        # smean / srstd: the instance statistics of z when its producer already took them (ops.bilinear_up2), else None
         bm = _COMPUTE_DTYPE == hip.DT_F32_BF16M
         B = z.shape[0] // G
         C, H, W = z.shape[1], z.shape[2], z.shape[3]
@@ -725,12 +726,15 @@ class _GbSpadeFn(Function):
                   (_COMPUTE_DTYPE == hip.DT_BF16 and si_out.dtype == torch.bfloat16 and z.dtype == torch.bfloat16)
         if _GB_SPADE and fusable:
             mix = hip.empty_nhwc(G * B, C, H, W, z.device, z.dtype); gamma = hip.empty_nhwc(G * B, C, H, W, z.device, z.dtype)
-            mean = torch.empty(G * B * C, dtype=torch.float32, device=z.device); rstd = torch.empty_like(mean)
+            if smean is not None:
+                mean, rstd = smean, srstd
+            else:
+                mean = torch.empty(G * B * C, dtype=torch.float32, device=z.device); rstd = torch.empty_like(mean)
             for g in range(G):
                 sl = slice(g * B, (g + 1) * B)
                 wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE == hip.DT_BF16 else (None, None)
                 wbs[g] = wb[1]
-                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps, w_bf16=wb[0],
+                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps, w_bf16=wb[0], stats_ready=smean is not None,
                                       out=(mix[sl], gamma[sl], mean[g * B * C:(g + 1) * B * C], rstd[g * B * C:(g + 1) * B * C]))
                 if ok is None:
                     assert g == 0                    # the decision depends on the geometry only
@@ -745,7 +749,7 @@ class _GbSpadeFn(Function):
                 wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE != hip.DT_F32 else (None, None)
                 wbs[g] = wb[1]
                 hip.conv2d_fwd(si_out[g * B:(g + 1) * B], filt[2 * g], bias, 3, 3, 1, 1, out=gb[g * B:(g + 1) * B], w_bf16=wb[0])
-            mix, mean, rstd = hip.instnorm_spade_fwd(zs, gb[:, :C], gb[:, C:], eps)
+            mix, mean, rstd = hip.instnorm_spade_fwd(zs, gb[:, :C], gb[:, C:], eps, stats=(smean, srstd) if (smean is not None and zs is z) else None)
             gamma = gb[:, :C]
             ctx.z_cast = zs is not z
             z = zs
@@ -775,7 +779,7 @@ class _GbSpadeFn(Function):
             dw, db = hip.conv2d_bwd_weight(si_out[sl], dgb[sl], 3, 3, 1, 1, need_bias=True, dtype=dt)
             dws += [dw, None]
             db_total = db if db_total is None else db_total + db
-        return (dx, dz, db_total, None, None) + tuple(dws)
+        return (dx, dz, db_total, None, None, None, None) + tuple(dws)
 
 
 _GB_SPADE = _os.environ.get('MRDIS_GB_SPADE', '1') != '0'
@@ -792,7 +796,8 @@ def gb_spade(si_out, z, filters, bias, eps):
     flat = []
     for a, b in filters:
         flat += [a, b]
-    mix = _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, *flat)
+    smean, srstd = in_stats_of(z, eps)
+    mix = _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, smean, srstd, *flat)
     mix._mrdis_want_dgb = True                       # a grouped convolution that reads `mix` writes d(mix) into the node's [dgamma | dbeta] buffer
     return mix
 
@@ -927,6 +932,56 @@ class _Bilinear(Function):
 def bilinear(x, out_hw, align_corners):
     """nn.Upsample(mode='bilinear'): model.py:2175 (align_corners=True), 2432/2501 (False)."""
     return _Bilinear.apply(x, tuple(out_hw), bool(align_corners))
+
+
+class _BilinearUp2Stats(Function):
+    """nn.Upsample(scale_factor=(2,2), bilinear) in front of a SPADE block (model.py:2551-2573, 2622-2627) that also leaves the
+    InstanceNorm statistics (:2440) of its result: mrdis_bilinear_up2_stats_fwd takes the sums from the values while it stores them,
+    so the block's statistics pass over the 4x tensor disappears.  (mean, rstd) are auxiliary outputs: the SPADE node treats the
+    dependence of the statistics on z analytically in its own backward, as before."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.geom = (x.shape[2], x.shape[3])
+        res = hip.bilinear_up2_stats(x, eps)
+        if res is None:
+            y = hip.bilinear_fwd(x, (2 * x.shape[2], 2 * x.shape[3]), False)
+            mean = rstd = torch.empty(0, dtype=torch.float32, device=x.device)
+        else:
+            y, mean, rstd = res
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
+
+    @staticmethod
+    def backward(ctx, dy, _gm, _gr):
+        return hip.bilinear_bwd(dy, ctx.geom, False), None
+
+
+_UP2_STATS = _os.environ.get('MRDIS_UP2_STATS', '1') != '0'
+
+
+def set_up2_stats(enabled):
+    global _UP2_STATS
+    _UP2_STATS = bool(enabled)
+
+
+def bilinear_up2(x, stats_eps=None):
+    """x2 bilinear, align_corners=False.  stats_eps: the eps of the InstanceNorm that reads the result -- its statistics then ride on the
+    result (`_mrdis_in_stats` = (mean, rstd, eps), picked up by ops.gb_spade)."""
+    if stats_eps is None or not _UP2_STATS or not x.is_cuda or type(x) is not torch.Tensor:
+        return bilinear(x, (2 * x.shape[2], 2 * x.shape[3]), False)
+    y, mean, rstd = _BilinearUp2Stats.apply(x, float(stats_eps))
+    if mean.numel():
+        y._mrdis_in_stats = (mean, rstd, float(stats_eps))
+    return y
+
+
+def in_stats_of(z, eps):
+    """(mean, rstd) that ride on z for an InstanceNorm with this eps, or (None, None)"""
+    st = getattr(z, '_mrdis_in_stats', None)
+    if st is None or st[2] != float(eps) or st[0].numel() != z.shape[0] * z.shape[1]:
+        return None, None
+    return st[0], st[1]
 
 
 class _SoftmaxMaskDrop(Function):

@@ -343,14 +343,16 @@ def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
     assert torch.equal(res[True][1], res[False][1])
 
 
-@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace'])
+@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace', 'up2_stats'])
 def test_layout_switches_do_not_change_the_step(mrdis, switch):
     """MRDIS_PLANAR_INPUTS (modality-planar copy of the input batch), MRDIS_CAT_ELISION (skip concatenation written in place) and
     MRDIS_GB_INPLACE (d(mix) written into the beta half of [dgamma | dbeta]) only change where tensors live: one step with the switch
-    off and on gives the same loss and the same parameter gradients (same kernels' arithmetic on other strides)."""
+    off and on gives the same loss and the same parameter gradients (same kernels' arithmetic on other strides).  MRDIS_UP2_STATS (the
+    x2 resize in front of a SPADE block also takes that block's InstanceNorm statistics) changes the order of the partial sums only."""
     B, M, H, W = 2, 4, 64, 128
     cfg = _cfg(mrdis, M, H, W, B, adv=True)
-    holder = {'planar_inputs': (mrdis.trainer, '_PLANAR_INPUTS'), 'cat_elision': (mrdis.ops, '_CAT_ELISION'), 'gb_inplace': (mrdis.ops, '_GB_INPLACE')}[switch]
+    holder = {'planar_inputs': (mrdis.trainer, '_PLANAR_INPUTS'), 'cat_elision': (mrdis.ops, '_CAT_ELISION'), 'gb_inplace': (mrdis.ops, '_GB_INPLACE'),
+              'up2_stats': (mrdis.ops, '_UP2_STATS')}[switch]
     res = {}
     try:
         for on in (False, True):

@@ -1038,3 +1038,33 @@ def test_norms_resize_bf16_storage(mrdis, C, N, H, W):
     close(hip.lrelu_bwd(cl(gy).to(B16), cl(rb(ya)).to(B16), 0.2), torch.where(ya > 0, gy, 0.2 * gy), rtol=6e-3)
     t32 = cl(rnd((N, C, H, W), 21))
     assert torch.equal(hip.cast_view(hip.cast_view(t32, B16), torch.float32), t32.bfloat16().float())
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('N,C,H,W', [(3, 32, 5, 6), (2, 128, 9, 7), (4, 64, 16, 24), (2, 16, 33, 17)])
+def test_bilinear_up2_with_instance_statistics(mrdis, N, C, H, W, dtype):
+    """mrdis_bilinear_up2_stats_fwd (nn.Upsample(scale_factor=2, bilinear) in front of a SPADE block, model.py:2551-2573 + the
+    InstanceNorm statistics of :2440 in one pass): the map is mrdis_bilinear_fwd's (to the last bit or one: two instantiations of one expression), mean / rstd are those of the STORED
+    values (fp64 reference), equal to what mrdis_instnorm_stats computes from the map up to the order of its fp32 partial sums; and
+    mrdis_instnorm_spade_fwd with workspace = NULL applies exactly these statistics."""
+    hip = mrdis.hip
+    T = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    x = cl(rnd((N, C, H, W), 41) * 2.0 + 0.7).to(T)
+    res = hip.bilinear_up2_stats(x, 1e-5)
+    assert res is not None
+    y, mean, rstd = res
+    y0 = hip.bilinear_fwd(x, (2 * H, 2 * W), False)
+    # the same expression compiled in two template instantiations: hipcc may contract its multiply-adds differently (1 ulp)
+    assert y.dtype == T and float((y.float() - y0.float()).abs().max()) <= (8e-3 if dtype == 'bf16' else 3e-7) * float(y0.float().abs().max())
+    yd = y.double()
+    m64 = yd.mean((2, 3)).reshape(-1); v64 = yd.var((2, 3), unbiased=False).reshape(-1)
+    assert float((mean.double() - m64).abs().max()) <= 2e-6 * float(m64.abs().max() + 1)
+    assert float((rstd.double() - 1 / torch.sqrt(v64 + 1e-5)).abs().max()) <= 2e-5 * float((1 / torch.sqrt(v64 + 1e-5)).max())
+    g = cl(rnd((N, C, 2 * H, 2 * W), 42, 0.3)).to(T); b = cl(rnd((N, C, 2 * H, 2 * W), 43, 0.3)).to(T)
+    out_a, mean_a, rstd_a = hip.instnorm_spade_fwd(y, g, b, 1e-5)                          # statistics pass of its own
+    out_b, mean_b, rstd_b = hip.instnorm_spade_fwd(y, g, b, 1e-5, stats=(mean, rstd))       # the ones that came with the map
+    assert mean_b.data_ptr() == mean.data_ptr()
+    assert float((mean_a - mean).abs().max()) <= 2e-6 * float(mean.abs().max() + 1) and float((rstd_a - rstd).abs().max()) <= 2e-5 * float(rstd.max())
+    tol = 2e-2 if dtype == 'bf16' else 2e-5
+    assert float((out_a.float() - out_b.float()).abs().max()) <= tol * float(out_a.float().abs().max())
+
