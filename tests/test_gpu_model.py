@@ -120,7 +120,10 @@ def _cfg(mrdis, M, H, W, B, adv=False):
 
 # per-tensor gradient norms vs the reference: |ours - ref| <= a (ref + 4e-3 total).  The floor term is for tensors whose gradient is
 # rounding noise next to the step's total (conv biases in front of a norm layer: analytically zero), the relative term for the rest.
-PER_TENSOR_A = 5e-3
+# Measured (round 3, gpurun_out/f32_golden_measured.jsonl): a = 4.3e-5 / 3.8e-5 / 8.0e-5 for b2m4 / b4m2 / b2m4_drop (worst tensor: a
+# decoder head bias) and 1.7e-3 for b2m2_adv (discrim_s.discrim.0.bias: the discriminator's BatchNorm over a batch of two 5x6 maps
+# amplifies fp32 rounding; its total norm agrees to 1.7e-4).  Bars = 5x / 3x those, both inside north_star's 1e-3 on the totals.
+PER_TENSOR_A = {'b2m4': 4e-4, 'b4m2': 4e-4, 'b2m4_drop': 4e-4, 'b2m2_adv': 5e-3}
 
 
 @pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
@@ -165,7 +168,7 @@ def test_train_step_golden(mrdis, golden_dir, tag):
     except OSError:
         pass
     for k, v in hot.items():
-        assert abs(gn[k] - v) <= PER_TENSOR_A * (v + 4e-3 * ref_total), (k, gn[k], v)
+        assert abs(gn[k] - v) <= PER_TENSOR_A[tag] * (v + 4e-3 * ref_total), (k, gn[k], v)
     # clip + Adam on the arena vs the reference's weights after optimizer.step()
     step.optimizer.step(fused_clip=True)
     for k, v in meta['wsum_after'].items():
