@@ -152,8 +152,9 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         wb_f = hip.cast_bf16(wk) if bf else None
         wb_b = hip.cast_bf16(wt) if bf else None
         dt = hip.DT_F32_BF16M if bf else hip.DT_F32
-        fns = {'fwd': lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb_f),
-               'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b),
+        yo = hip.empty_nhwc(B, co, h, w, dev, el); dxo = hip.empty_nhwc(B, ci, h, w, dev, el)      # (outputs allocated once: the allocator is not timed)
+        fns = {'fwd': lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb_f, out=yo),
+               'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b, out=dxo),
                'wgrad': lambda: hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, dtype=dt)}
         flop = 2.0 * 9 * ci * co * B * h * w
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
@@ -175,7 +176,7 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
                 row[k_] = {'us': round(us, 1), 'direct_equiv_tflops': round(flop / us / 1e6, 1),
                            'frac_mfma': round(flop * 4 / 9 / us / 1e6 / MFMA_F32_PEAK_TF, 3)}
         out.append(row)
-        del x, dy
+        del x, dy, yo, dxo
     return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
             'pricing': 'fp32: direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) / time / 157.3 TF' if not bf else
                        'bf16: algorithmic bytes (x + dy in bf16) / time / 8 TB/s; direct FLOPs / time / 2500 TF beside it',
