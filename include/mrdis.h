@@ -153,15 +153,30 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
  *                        that the mixing launch writes for narrow layers under bf16 storage.  MRDIS_EUNSUPPORTED elsewhere.        */
 #define MRDIS_DT_XBF16_YF32 3
 #define MRDIS_DT_XF32_YBF16 4
+/* w_wino (fp32 paths, may be NULL): the filter already in the Winograd domain, the image mrdis_wino_u_jobs builds from w_tck (role:
+ * forward) -- used where the software-pipelined F(2x2,3x3) kernel takes the layer, ignored elsewhere; same results bit for bit. */
 int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                      void* y, int ldy, int N, int H, int W, int Ci, int Co,
-                     int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream);
+                     int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, void* stream);
+
+/* ---- filter images for the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip).  U = G g G^T of a 3x3 filter does not depend
+ * on the activations; a training step uses each mixed filter 8-16 times, so the transform is taken out of the convolution kernels:
+ * one launch over a job table builds, per (filter, role), the 16-point image in the order the kernel's (input-channel chunk, 64-cout
+ * tile) walk consumes it: [cout tile][chunk of 8][8][4][64][4] floats, zero-padded.  Job (`WinoUJob`, mrdis_wino_u_job_bytes() = 40):
+ *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk; }
+ * w = [9][R][S]: role forward: w_tck, R = Ci, S = Co, flip = 0; role data gradient: w_tkc, R = Co, S = Ci, flip = 1; role SPADE (the fused
+ * gamma | beta filter of mrdis_conv2d_fwd_spade): w_tck, R = Ci, S = 2 C, spadeC = C.  img: mrdis_wino_u_image_floats(R, S, spadeC) floats,
+ * 16-byte aligned.  block0 / nblk: the job's block range (mrdis_wino_u_job_blocks each), total_blocks = their sum.                     */
+size_t mrdis_wino_u_job_bytes(void);
+long long mrdis_wino_u_image_floats(int R, int S, int spadeC);
+int mrdis_wino_u_job_blocks(int R, int S, int spadeC);
+int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 
 /* data gradient (autograd convolution_backward, input part).
  * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
 int mrdis_conv2d_bwd_data(const void* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
                           void* dx, int lddx, int N, int H, int W, int Ci, int Co,
-                          int kh, int kw, int stride, int pad, int dtype, void* stream);
+                          int kh, int kw, int stride, int pad, int dtype, const float* w_wino /* role data gradient, or NULL */, void* stream);
 
 /* fp32 -> bf16, round to nearest even (the bf16 filter copies above); src 16-byte, dst 8-byte aligned. */
 int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
@@ -185,7 +200,7 @@ int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, float* save_r
                          int N, long long HW, int C, float eps, int dtype, void* stream);
 int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
                            const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
-                           int N, int H, int W, int Ci, int C, int dtype, void* stream);
+                           int N, int H, int W, int Ci, int C, int dtype, const float* w_wino /* role SPADE, or NULL */, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.

@@ -1123,11 +1123,11 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
 // 32 -> 32, 1.3-1.5x on the 64..512-channel layers; a 16-cout layer wastes half of its 32-wide cout tile (slower).
 // software-pipelined variant for Cout > 32 (mrdis_wino2.hip); option wino_pipe = 0 keeps the phase-by-phase kernel everywhere
 int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img);
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s) {
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr) {
     if (Co > 32 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {
-        const int rc = mrdis_run_wino2(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s);
+        const int rc = mrdis_run_wino2(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s, u_img);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     return mrdis_run_wino(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s);
@@ -1154,12 +1154,12 @@ static bool bf16m_wanted(int dtype, const void* w_bf16, int Cred, int Cout) {
 // (MRDIS_DT_BF16): the SPADE epilogue of the pipelined bf16 kernel (mrdis_bf16p.hip).  MRDIS_EUNSUPPORTED otherwise (the caller then runs
 // mrdis_conv2d_fwd + mrdis_instnorm_spade_fwd).
 int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
-                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
+                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
 int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
                            void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
 extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
                                       const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
-                                      int N, int H, int W, int Ci, int C, int dtype, void* stream) {
+                                      int N, int H, int W, int Ci, int C, int dtype, const float* w_wino, void* stream) {
     if (!x || !bias || !z || !mean || !rstd || !mix || !gamma || N < 1 || H < 1 || W < 1 || Ci < 1 || C < 1) return MRDIS_EINVAL;
     if (dtype == MRDIS_DT_BF16) {
         if (!w_bf16_tkc) return MRDIS_EINVAL;
@@ -1168,7 +1168,7 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
     if (dtype != MRDIS_DT_F32 || !w_tck) return dtype == MRDIS_DT_F32 ? MRDIS_EINVAL : MRDIS_EUNSUPPORTED;
     if (!mrdis_opt(MRDIS_OPT_WINO_PIPE) || !wino_wanted(N, H, W, Ci, 2 * C, 3, 3, 1, 1)) return MRDIS_EUNSUPPORTED;
     return mrdis_run_wino2_spade((const float*)x, ldx, w_tck, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, w_wino);
 }
 
 // mrdis_pointwise.hip: the 1x1 decoder head (16 -> <= 8 channels) as streaming kernels
@@ -1186,7 +1186,7 @@ int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, 
 
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                                 void* y_, int ldy, int N, int H, int W, int Ci, int Co,
-                                int kh, int kw, int stride, int pad, int epilogue, int dtype, void* stream) {
+                                int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, void* stream) {
     if (dtype < MRDIS_DT_F32 || dtype > MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); float* y = reinterpret_cast<float*>(y_);   // bf16 views when dtype == MRDIS_DT_BF16
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
@@ -1224,7 +1224,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
-        rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
+        rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream, w_wino);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     TapConvParams p{};
@@ -1245,7 +1245,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
 
 extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_tkc, const void* w_bf16_tck,
                                      void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
-                                     int kh, int kw, int stride, int pad, int dtype, void* stream) {
+                                     int kh, int kw, int stride, int pad, int dtype, const float* w_wino, void* stream) {
     if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32) return MRDIS_EUNSUPPORTED;
     const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
@@ -1284,7 +1284,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
         if (!st_bf16 && c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
-            rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream);
+            rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, w_wino);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
         TapConvParams p = base;

@@ -1489,6 +1489,7 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"wino", "MRDIS_WINO", 0, 1},            // 0 direct kernels only | 1 measured policy | 2 Winograd wherever it applies
     {"nt_mb", "MRDIS_NT_MB", 0, 128},        // outputs of at least this many MB leave the Winograd kernel with non-temporal stores
     {"wino_pipe", "MRDIS_WINO_PIPE", 0, 1},  // 1: the software-pipelined Winograd kernel (mrdis_wino2.hip) where it applies | 0: the phase-by-phase one
+    {"wino_u", "MRDIS_WINO_U", 0, 1},        // 1: the pipelined kernel reads a pre-transformed filter image when the caller passes one | 0: always transforms the taps itself
     {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
     {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
     {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},

@@ -33,6 +33,9 @@ struct Wino2Params {
     // out = (z - mean) * rstd * (1 + gamma) + beta and gamma itself (model.py:2440-2446) -- the 2C-channel tensor never exists
     const float* z; const float* mean; const float* rstd; float* gamma_out;
     int ldz, ldg, C;
+    // UIMG: the filter already in the Winograd domain (mrdis_wino_u_jobs): [cout tile][chunk][8 channels][4 point groups][64 couts][4 points],
+    // zero where the chunk / the tile runs past Cin / Cout -- what U = G g G^T of this kernel's (chunk, cout tile) walk needs, in its order
+    const float* u_img; unsigned u_bytes;
 };
 
 namespace {
@@ -51,7 +54,10 @@ constexpr unsigned W2_OOB = 0xfffffff0u;               // byte offset past every
 }  // namespace
 
 // ABL: timing-only ablations (results wrong): 1 no V transform, 2 no U transform, 4 no MFMAs, 8 no filter loads, 32 no raw loads, 16 no operand reads
-template <int ABL, bool SPADE = false>
+// UIMG: U comes pre-transformed from the filter image (four 16-byte loads per thread and chunk, no G g G^T in the loop) instead of nine
+// tap loads + the transform: the same 16 values (the image is built with the same expressions), ~40 VALU and 5 vector-memory
+// instructions fewer per thread and chunk in the MFMA shadows.
+template <int ABL, bool SPADE = false, bool UIMG = false>
 __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ub = smem;                           // [2][16][XI]
@@ -97,7 +103,8 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     // All global loads are buffer loads whose offset is W2_OOB where there is nothing to read (zeros come back): no branch
     // around a load, so the compiler's vmcnt bookkeeping stays exact and a wait covers only the loads it must.
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = UIMG ? __builtin_amdgcn_make_buffer_rsrc((void*)p.u_img, 0, p.u_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     unsigned xg[2] = {W2_OOB, W2_OOB};
     int rj = 0, rc = 0;
     auto raw_block = [&]() {
@@ -138,10 +145,12 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
 
     // ---- filter cursor (one iteration ahead)
     int fj = 0, fc = 0, f_co = 0; bool f_on = false;
+    unsigned f_tile = 0;                              // UIMG: byte offset of this thread's first 16 bytes inside chunk 0 of the block's cout tile
     auto filt_block = [&]() {
         f_on = false;
         if (fj < nmine) {
             int n, oy0, ox0, co0; decode(fj, n, oy0, ox0, co0);
+            if (UIMG) { f_on = true; f_tile = 4u * (unsigned)(((co0 >> 6) * nch) * (16 * XI) + (k_t * 4 * 64 + idx_t) * 4); return; }
             if (SPADE) {      // 16-cout blocks of the workgroup: gamma[c0..+15], beta[c0..+15], gamma[c0+16..+31], beta[c0+16..+31]
                 const int ch = co0 / 2 + 16 * (idx_t >> 5) + (idx_t & 15);
                 f_co = ((idx_t >> 4) & 1 ? p.C : 0) + ch; f_on = ch < p.C;
@@ -152,9 +161,21 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     float gr[9];
     unsigned f_wo = W2_OOB;                           // byte offset of tap 0 of this thread's (channel, cout) pair for the NEXT filter load
     auto filt_next = [&]() {                          // cursor bookkeeping (branches, divisions) apart from the loads themselves
+        if (UIMG) f_wo = f_on ? f_tile + 4u * (unsigned)(fc * 16 * XI) : W2_OOB;
+        else {
         const int k = ((ABL & 64) ? 0 : fc * KC) + k_t;      // 64: the same filter chunk every iteration (L1 hits)
         f_wo = (f_on && k < p.Cin) ? 4u * (unsigned)(k * p.Cout + f_co) : W2_OOB;
+        }
         if (++fc == nch) { fc = 0; ++fj; filt_block(); }
+    };
+    float4 ur[4];                                     // UIMG: points 4 a .. 4 a + 3 of this thread's (channel, cout) pair, a = 0..3
+    auto load_u = [&](int a) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(f_wo != W2_OOB ? f_wo + 1024u * (unsigned)a : W2_OOB), 0, 0);
+        ur[a] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto u_put = [&](float* Un, int a) {
+        float* up = Un + 4 * a * XI;
+        up[0] = ur[a].x; up[XI] = ur[a].y; up[2 * XI] = ur[a].z; up[3 * XI] = ur[a].w;
     };
     auto load_tap = [&](int t) {
         gr[t] = (ABL & 8) ? 0.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(f_wo != W2_OOB ? f_wo + (unsigned)(p.flip ? 8 - t : t) * tstride4 : W2_OOB), 0, 0));
@@ -198,13 +219,25 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
     // ---- prologue: U(0), V(0), raw(1) in LDS, raw(2) and filter(1) in register set 1; cursors at raw(3), filter(2)
     for (int c = threadIdx.x; c < BIASBUF; c += NT) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
     raw_block(); filt_block();
-    load_raw(IC<0>{}); filt_next(); load_filt();
+    load_raw(IC<0>{}); filt_next();
+    if (UIMG) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) load_u(a);
+    } else load_filt();
     load_raw(IC<1>{});
     raw_store(IC<0>{}, Rb);
+    if (UIMG) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) u_put(Ub + t_dst, a);
+        filt_next();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) load_u(a);        // U(1), as if issued in steps 11-14 of an iteration -1
+    } else {
     u_col();
 #pragma unroll
     for (int a = 0; a < 4; ++a) u_out(Ub + t_dst, a);
     filt_next(); load_filt();                         // filter(1), as if issued in step 11 of an iteration -1
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) v_row(Rb + v_src, i);
@@ -252,9 +285,12 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
             else if (s_ == 4) { if (!(ABL & 1)) { v_col(0); v_col(1); } }
             else if (s_ == 5) { if (!(ABL & 1)) { v_col(2); v_col(3); } }
             else if (s_ < 10) { if (!(ABL & 1)) v_out(Vn, s_ - 6); }
-            else if (s_ == 10) { if (!(ABL & 2)) u_col(); }
-            else if (s_ < 15) { load_tap(2 * (s_ - 11)); load_tap(2 * (s_ - 11) + 1); if (!(ABL & 2)) u_out(Un, s_ - 11); }
-            else { load_tap(8); raw_store(IC<P ^ 1>{}, Rw); }
+            else if (s_ == 10) { if (!UIMG && !(ABL & 2)) u_col(); }
+            else if (s_ < 15) {
+                if (UIMG) { u_put(Un, s_ - 11); load_u(s_ - 11); }       // U(i + 1) to LDS, then the same registers take U(i + 2)
+                else { load_tap(2 * (s_ - 11)); load_tap(2 * (s_ - 11) + 1); if (!(ABL & 2)) u_out(Un, s_ - 11); }
+            }
+            else { if (!UIMG) load_tap(8); raw_store(IC<P ^ 1>{}, Rw); }
             const int c_ = s_ % 3;
             if (!(ABL & 4)) {
                 acc[s_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c_].x, bv[c_].x, acc[s_][0], 0, 0, 0);
@@ -367,8 +403,10 @@ __global__ __launch_bounds__(512, 1) void wino2_kernel(const Wino2Params p) {
 }
 
 // returns MRDIS_EUNSUPPORTED when the layer is outside what this kernel covers (the caller then takes wino_conv_kernel)
+static unsigned wino_u_bytes(int R, int tiles) { return (unsigned)(4LL * tiles * mrdis_cdiv(R, KC) * 16 * XI); }
+
 int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s) {
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img) {
     if (Co <= 32 || Co > BIASBUF || Co % 4 != 0 || Ci % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W * ldx >= 0x3fffffffLL || 9LL * Ci * Co >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
     Wino2Params p{};
@@ -382,11 +420,14 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
     const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     p.nblk = (int)nblk;
+    if (!mrdis_opt(MRDIS_OPT_WINO_U) || (((uintptr_t)u_img) & 15) != 0) u_img = nullptr;
+    p.u_img = u_img; p.u_bytes = wino_u_bytes(Ci, p.coTiles);
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
         if (hipFuncSetAttribute((const void*)wino2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        if (hipFuncSetAttribute((const void*)wino2_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
 #ifdef WINO2_ABLATIONS
 #define W2A(a) hipFuncSetAttribute((const void*)wino2_kernel<a>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS);
         W2A(1) W2A(2) W2A(3) W2A(4) W2A(8) W2A(32) W2A(40) W2A(43) W2A(16) W2A(47) W2A(64) W2A(128) W2A(256)
@@ -401,7 +442,8 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
     W2A(1) W2A(2) W2A(3) W2A(4) W2A(8) W2A(32) W2A(40) W2A(43) W2A(16) W2A(47) W2A(64) W2A(128) W2A(256)
 #undef W2A
 #endif
-    hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    if (u_img) hipLaunchKernelGGL((wino2_kernel<0, false, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    else hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -409,7 +451,7 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
 // SPADE-fused form: x = si_out (N, H, W, Ci), w = fused gamma | beta filter [9][Ci][2 C], bias (2 C); z (N, H, W, C) with its instance
 // statistics; writes mix = (z - mean) rstd (1 + gamma) + beta and gamma.  MRDIS_EUNSUPPORTED: the caller runs the two-step path.
 int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
-                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s) {
+                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img) {
     const int Co = 2 * C;
     if (C < 16 || C % 16 != 0 || Co > BIASBUF || Ci % 4 != 0 || ldx % 4 != 0 || ldz % 4 != 0 || ldmix % 4 != 0 || ldg % 4 != 0) return MRDIS_EUNSUPPORTED;
     if (((((uintptr_t)x) | ((uintptr_t)z) | ((uintptr_t)mix) | ((uintptr_t)gamma) | ((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) != 0) return MRDIS_EUNSUPPORTED;
@@ -429,10 +471,73 @@ int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* 
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
         if (hipFuncSetAttribute((const void*)wino2_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        if (hipFuncSetAttribute((const void*)wino2_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO2_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (!mrdis_opt(MRDIS_OPT_WINO_U) || (((uintptr_t)u_img) & 15) != 0) u_img = nullptr;
+    p.u_img = u_img; p.u_bytes = wino_u_bytes(Ci, p.coTiles);
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
-    hipLaunchKernelGGL((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    if (u_img) hipLaunchKernelGGL((wino2_kernel<0, true, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    else hipLaunchKernelGGL((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// =========================================================================== filter images for wino2_kernel<.., UIMG>
+// One job = one (filter, role): w is [9][R][S] (forward: w_tck with R = Ci, S = Co; data gradient: w_tkc with R = Co, S = Ci and flip = 1;
+// fused gamma | beta filter of a SPADE block: R = Ci, S = 2 C, spadeC = C -- the cout order of wino2_kernel<.., SPADE>).  A thread builds the
+// sixteen points of one (reduction channel, cout slot) pair with the expressions of the in-kernel transform (u_col / u_out), so the
+// pipelined kernel computes the same values either way (option wino_u = 0 / 1 is bit-identical).
+struct WinoUJob { const float* w; float* img; int R, S, flip, spadeC, block0, nblk; };
+
+__global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                       // last job with block0 <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const WinoUJob j = jobs[lo];
+    const int nch = (j.R + KC - 1) / KC;
+    const int tiles = j.spadeC ? (j.spadeC + 31) / 32 : (j.S + 63) / 64;
+    const long long total = (long long)tiles * nch * KC * 64;
+    for (long long i = ((long long)blockIdx.x - j.block0) * 256 + threadIdx.x; i < total; i += (long long)j.nblk * 256) {
+        const int slot = (int)(i & 63), k = (int)((i >> 6) & 7);
+        const long long tc = i >> 9;                  // cot * nch + chunk
+        const int c = (int)(tc % nch), cot = (int)(tc / nch);
+        const int r = c * KC + k;
+        int co; bool ok;
+        if (j.spadeC) {
+            const int ch = cot * 32 + 16 * (slot >> 5) + (slot & 15);
+            co = (((slot >> 4) & 1) ? j.spadeC : 0) + ch; ok = ch < j.spadeC;
+        } else { co = cot * 64 + slot; ok = co < j.S; }
+        ok = ok && r < j.R;
+        float gr[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gr[t] = ok ? j.w[((long long)(j.flip ? 8 - t : t) * j.R + r) * j.S + co] : 0.f;
+        float t_[4][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                 // G g: G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+            const float g0 = gr[q], g1 = gr[3 + q], g2 = gr[6 + q];
+            t_[0][q] = g0; t_[1][q] = 0.5f * (g0 + g1 + g2); t_[2][q] = 0.5f * (g0 - g1 + g2); t_[3][q] = g2;
+        }
+        float* dst = j.img + ((tc * KC + k) * 4) * 256 + slot * 4;      // [tc][k][a][slot][4]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            *reinterpret_cast<float4*>(dst + a * 256) = make_float4(t_[a][0], 0.5f * (t_[a][0] + t_[a][1] + t_[a][2]),
+                                                                   0.5f * (t_[a][0] - t_[a][1] + t_[a][2]), t_[a][2]);
+    }
+}
+
+extern "C" size_t mrdis_wino_u_job_bytes(void) { return sizeof(WinoUJob); }
+static long long wino_u_elems(int R, int S, int spadeC) {
+    const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
+    return (long long)tiles * ((R + KC - 1) / KC) * KC * 64;
+}
+extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) { return 16 * wino_u_elems(R, S, spadeC); }
+extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
+    const long long b = (wino_u_elems(R, S, spadeC) + 255) / 256;
+    return (int)(b > 64 ? 64 : (b < 1 ? 1 : b));
+}
+extern "C" int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
+    if (!jobs || njobs < 1 || total_blocks < njobs) return MRDIS_EINVAL;
+    hipLaunchKernelGGL(wino_u_jobs_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const WinoUJob*>(jobs), njobs);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -39,7 +39,11 @@ _SIGS = {
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
     'mrdis_instnorm_stats': (_I, [_P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
-    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'mrdis_wino_u_job_bytes': (_Z, []),
+    'mrdis_wino_u_image_floats': (_L, [_I, _I, _I]),
+    'mrdis_wino_u_job_blocks': (_I, [_I, _I, _I]),
+    'mrdis_wino_u_jobs': (_I, [_P, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_mix_experts_routed_multi_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _I, _I, _P]),
@@ -47,8 +51,8 @@ _SIGS = {
     'mrdis_mix_job_blocks': (_I, [_I, _I, _I]),
     'mrdis_mix_jobs_fwd': (_I, [_P, _I, _I, _P, _I, _I, _P]),
     'mrdis_mix_jobs_bwd': (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
-    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P]),
-    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P]),
+    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P, _P]),
+    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P, _P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
     'mrdis_cast_view': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -274,6 +278,34 @@ class MixJob(_c.Structure):
                 ('block0', _c.c_int), ('nblk', _c.c_int), ('accumulate', _c.c_int), ('ci_pitch', _c.c_int)]
 
 
+class WinoUJob(_c.Structure):
+    """csrc/mrdis_wino2.hip `WinoUJob`: one (filter, role) of the Winograd filter-image launch (include/mrdis.h)."""
+    _fields_ = [('w', _c.c_void_p), ('img', _c.c_void_p), ('R', _c.c_int), ('S', _c.c_int), ('flip', _c.c_int), ('spadeC', _c.c_int),
+                ('block0', _c.c_int), ('nblk', _c.c_int)]
+
+
+def wino_u_table(jobs, device):
+    lib = load()
+    nb = _c.sizeof(WinoUJob)
+    if nb != lib.mrdis_wino_u_job_bytes():
+        raise MrdisError(f'WinoUJob layout mismatch: binding {nb} bytes, library {lib.mrdis_wino_u_job_bytes()}')
+    arr = (WinoUJob * len(jobs))(*jobs)
+    host = torch.frombuffer(bytearray(_c.string_at(_c.addressof(arr), nb * len(jobs))), dtype=torch.uint8)
+    return host.to(device)
+
+
+def wino_u_image_floats(R, S, spadeC=0):
+    return int(load().mrdis_wino_u_image_floats(R, S, spadeC))
+
+
+def wino_u_job_blocks(R, S, spadeC=0):
+    return int(load().mrdis_wino_u_job_blocks(R, S, spadeC))
+
+
+def wino_u_jobs(table, njobs, total_blocks):
+    _chk(load().mrdis_wino_u_jobs(_ptr(table), njobs, total_blocks, _stream()), 'wino_u_jobs')
+
+
 def mix_job_table(jobs, device):
     """list of MixJob -> device tensor holding the table (checked against the library's struct size)."""
     lib = load()
@@ -462,7 +494,7 @@ def cast_bf16(t):
     return out
 
 
-def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf16=None, out_dtype=None, may_decline=False):
+def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf16=None, out_dtype=None, may_decline=False, w_wino=None):
     """w_bf16: bf16 [T][Co][Ci] copy of the filter (reduction axis contiguous) -> bf16 MFMA operands, fp32 accumulate
     (MRDIS_DT_F32_BF16M) where the geometry allows; None -> exact fp32.
     Mixed storage (out / out_dtype differ from x.dtype): the 1x1 head reads bf16 and writes fp32 (MRDIS_DT_XBF16_YF32); the 3x3
@@ -481,16 +513,20 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     assert T == kh * kw and (Ci2 == Ci or (mixed == DT_XF32_YBF16 and Ci2 == max(Ci, 16))), (w_tck.shape, x.shape, kh, kw)
     if mixed in (DT_XBF16_YF32, DT_XF32_YBF16):
         rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), None, _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                                  1 if lrelu else 0, mixed, _stream())
+                                  1 if lrelu else 0, mixed, None, _stream())
         if rc == -2 and may_decline:
             return None
         _chk(rc, 'conv2d_fwd (mixed storage)')
         return out
+    if w_bf16 is not None and w_bf16.dtype is torch.float32:      # the auxiliary-filter slot carries the Winograd image on the fp32 path
+        w_wino, w_bf16 = w_bf16, None
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
+    if w_wino is not None:
+        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Ci, Co) and kh == 3 and kw == 3
     dt = DT_BF16 if mixed == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
     rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              1 if lrelu else 0, dt, _stream())
+                              1 if lrelu else 0, dt, _ptr(w_wino) if dt == DT_F32 else None, _stream())
     if rc == -2 and dt == DT_BF16:
         # a tile geometry the bf16 kernel cannot stage (or a view it cannot address): the fp32 kernel between two view casts
         y32 = conv2d_fwd(cast_view(x, torch.float32), w_tck, bias, kh, kw, stride, pad, lrelu)
@@ -500,7 +536,7 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     return out
 
 
-def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None):
+def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None, w_wino=None):
     """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co).  out: a dense NHWC (N, Ci, H, W) view to write into."""
     lib = load()
     dy, lddy = nhwc(dy)
@@ -514,13 +550,18 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
         dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
         assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W)
         if out.dtype != dy.dtype:    # the 1x1 head under bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32)
-            _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), _stream()),
+            _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, _stream()),
                  'conv2d_bwd_data (mixed storage)')
             return dx
+    if w_bf16 is not None and w_bf16.dtype is torch.float32:
+        w_wino, w_bf16 = w_bf16, None
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
+    if w_wino is not None:
+        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Co, Ci) and kh == 3 and kw == 3
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
-    rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, dt, _stream())
+    rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, dt,
+                                   _ptr(w_wino) if dt == DT_F32 else None, _stream())
     if rc == -2 and dt == DT_BF16:
         # a geometry outside the bf16 kernels (e.g. a reduction axis that is not a multiple of 16): fp32 kernel between two view casts
         res = cast_view(conv2d_bwd_data(cast_view(dy, torch.float32), w_tkc, in_hw, kh, kw, stride, pad), torch.bfloat16)
@@ -639,7 +680,7 @@ def instnorm_spade_fwd(z, gamma, beta, eps=1e-5, stats=None):
     return out, mean, rstd
 
 
-def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_ready=False):
+def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_ready=False, w_wino=None):
     """fused gamma | beta convolution + InstanceNorm modulation (mrdis_conv2d_fwd_spade): -> (mix, gamma, mean, rstd), or None where the
     fused kernel does not apply (the caller then runs conv2d_fwd + instnorm_spade_fwd).  fp32 views, or bf16 views with w_bf16 = the bf16
     [9][2C][Ci] filter.  out = (mix, gamma, mean, rstd) dense views to fill."""
@@ -666,8 +707,10 @@ def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_
     # (stats_ready: `out`'s mean / rstd already hold them -- the x2 resize that produced z took them on the way, bilinear_up2_stats)
     if not stats_ready:
         _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, dt, st), 'instnorm_stats')
+    if w_wino is not None:
+        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Ci, 2 * C, C)
     rc = lib.mrdis_conv2d_fwd_spade(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(mix), C, _ptr(gamma), C,
-                                    N, H, W, Ci, C, dt, st)
+                                    N, H, W, Ci, C, dt, _ptr(w_wino) if dt == DT_F32 else None, st)
     if rc == -2:
         return None
     _chk(rc, 'conv2d_fwd_spade')

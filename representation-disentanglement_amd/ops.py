@@ -240,6 +240,54 @@ class MixPlan:
         # parameters (written by that launch) and the layers' biases (written by the weight-gradient launches that produced its inputs)
         mods = list(singles) + [m for _, g, b in pairs for m in (g, b)]
         self.ready_params = list(self.params) + [m.bias for m in mods if m.bias is not None]
+        self._build_wino_images(device)
+
+    def _build_wino_images(self, device):
+        """fp32 path: the Winograd-domain images of the 3x3 stride-1 filters that the software-pipelined kernels read (include/mrdis.h,
+        mrdis_wino_u_jobs): per entry and label up to two roles -- 'fwd' (or 'spade' for a fused gamma | beta pair) and 'dgrad' -- built by
+        ONE launch per mixing group right behind the mixing launch, into persistent buffers (a job table like the mixing launch's own)."""
+        self.u_njobs = self.u_blocks = 0
+        self.u_imgs = {}                                # (entry, label) -> {role: image tensor}
+        if self.want_bf16 or not _WINO_U:
+            return
+        M, flat = self.M, self.flat
+        want = []                                      # (entry, label, role, src element offset, R, S, flip, spadeC)
+        nsing = len(self.singles)
+        for ei, (T, Ci, Cw) in enumerate(self.shapes):
+            if T != 9 or Ci % 4 != 0 or Cw % 4 != 0:
+                continue
+            if ei < nsing:
+                m = self.singles[ei]
+                if m.stride != (1, 1) or m.padding != (1, 1) or id(m) in self.padded:
+                    continue
+                C = 0
+            else:
+                C = Cw // 2
+                if C < 16 or C % 16 != 0:
+                    continue
+            sz, o = self.sizes[ei], self.offs[ei]
+            for mm in range(M):
+                tck_off, tkc_off = o + 2 * mm * sz, o + 2 * mm * sz + sz
+                if Cw > 32:
+                    want.append((ei, mm, 'spade' if C else 'fwd', tck_off, Ci, Cw, 0, C))
+                if Ci > 32:
+                    want.append((ei, mm, 'dgrad', tkc_off, Cw, Ci, 1, 0))
+        if not want:
+            return
+        sizes = [hip.wino_u_image_floats(R, S, C) for (_, _, _, _, R, S, _, C) in want]
+        self.u_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        jobs, blocks, pos = [], 0, 0
+        for (ei, mm, role, src, R, S, flip, C), n in zip(want, sizes):
+            img = self.u_flat[pos:pos + n]
+            self.u_imgs.setdefault((ei, mm), {})[role] = img
+            j = hip.WinoUJob()
+            j.w, j.img = flat.data_ptr() + 4 * src, img.data_ptr()
+            j.R, j.S, j.flip, j.spadeC = R, S, flip, C
+            j.block0, j.nblk = blocks, hip.wino_u_job_blocks(R, S, C)
+            blocks += j.nblk; pos += n
+            jobs.append(j)
+        self.u_table = hip.wino_u_table(jobs, device)
+        self.u_njobs, self.u_blocks = len(jobs), blocks
 
     def table_for_current_sinks(self):
         """the job table whose gradient sinks are the parameters' CURRENT .grad buffers (TrainStep attaches another optimizer's arena for
@@ -287,6 +335,8 @@ class _MixAllLayers(Function):
     def forward(ctx, holder, types, *params):
         plan = holder[0]
         hip.mix_jobs_fwd(plan.table, plan.njobs, plan.blocks, types)
+        if plan.u_njobs:
+            hip.wino_u_jobs(plan.u_table, plan.u_njobs, plan.u_blocks)      # the Winograd-domain images of this group's 3x3 filters
         ents, ents16 = plan.views()
         holder.append((ents, ents16))
         ctx.plan = plan
@@ -322,6 +372,15 @@ class _MixAllLayers(Function):
 
 
 _PREMIX = _os.environ.get('MRDIS_PREMIX', '1') != '0'
+_WINO_U = _os.environ.get('MRDIS_WINO_IMAGES', '1') != '0'      # build the Winograd filter images with the mixing launch (fp32 path)
+
+
+def wino_images(w_tck):
+    """{role: image} of a mixed filter whose Winograd-domain images the step's mixing launch built ('fwd' | 'spade', 'dgrad'), else {}"""
+    if _MIX_CACHE is None or _COMPUTE_DTYPE != hip.DT_F32:
+        return {}
+    hit = _MIX_CACHE.get(('winoU', id(w_tck)))
+    return hit[1] if hit is not None else {}
 
 
 _GROUP_READY = None
@@ -389,6 +448,11 @@ def premix_all(model, table, group=None, roots=None):
                 a = allw[2 * mm]
                 btck, btkc = ents16[ei][mm]
                 _MIX_CACHE[('bf16w', id(a))] = (a, btkc, btck)
+        if plan.u_njobs:
+            for mm in range(M):
+                imgs = plan.u_imgs.get((ei, mm))
+                if imgs:
+                    _MIX_CACHE[('winoU', id(allw[2 * mm]))] = (allw[2 * mm], imgs)
     _MIX_CACHE[('premixed', id(model), group)] = True
     return True
 
@@ -538,6 +602,9 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
     other layers (Cin = 4 / 7 first layers, heads with < 16 outputs) run the fp32 kernels between explicit view casts:
     fp32 in -> bf16 out for the layers that open a bf16 stretch, bf16 in -> fp32 out for the heads."""
     if _COMPUTE_DTYPE == hip.DT_F32:
+        im = wino_images(w_tck) if (kh == 3 and stride == 1) else {}
+        if im:      # the auxiliary-filter slots of the op carry the Winograd images on the fp32 path (bf16 copies in the bf16 modes)
+            return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, im.get('fwd'), im.get('dgrad'))
         return torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu)
     Ci, Co = w_tck.shape[1], w_tck.shape[2]
     wb_fwd, wb_bwd = bf16_filters(w_tck, w_tkc)
@@ -642,7 +709,11 @@ class _GroupedConvFn(Function):
             if padded:
                 tck, tkc, bg, wb_f, wb_b = _pad16_filters(tck, tkc, bias, Ci_p, Co_p)
             else:
-                wb_f, wb_b = bf16_filters(tck, tkc) if bm else (None, None)
+                if bm:
+                    wb_f, wb_b = bf16_filters(tck, tkc)
+                else:
+                    im = wino_images(tck) if kh == 3 else {}
+                    wb_f, wb_b = im.get('fwd'), im.get('dgrad')          # fp32: the Winograd-domain images (hip.conv2d_* tell them by dtype)
                 if bias is not None and bias.shape[0] < Co_p:
                     bg = _pad_bias16(bias, Co_p, detach=True)
             use_tkc.append(tkc); wbs.append(wb_b)
@@ -733,8 +804,9 @@ class _GbSpadeFn(Function):
             for g in range(G):
                 sl = slice(g * B, (g + 1) * B)
                 wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE == hip.DT_BF16 else (None, None)
-                wbs[g] = wb[1]
-                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps, w_bf16=wb[0], stats_ready=smean is not None,
+                im = wino_images(filt[2 * g])
+                wbs[g] = wb[1] if wb[1] is not None else im.get('dgrad')
+                ok = hip.gb_spade_fwd(si_out[sl], filt[2 * g], bias, z[sl], eps, w_bf16=wb[0], stats_ready=smean is not None, w_wino=im.get('spade'),
                                       out=(mix[sl], gamma[sl], mean[g * B * C:(g + 1) * B * C], rstd[g * B * C:(g + 1) * B * C]))
                 if ok is None:
                     assert g == 0                    # the decision depends on the geometry only
@@ -746,7 +818,7 @@ class _GbSpadeFn(Function):
                 zs = hip.cast_view(z, torch.bfloat16)
             gb = hip.empty_nhwc(G * B, 2 * C, H, W, z.device, si_out.dtype)
             for g in range(G):
-                wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE != hip.DT_F32 else (None, None)
+                wb = bf16_filters(filt[2 * g], filt[2 * g + 1]) if _COMPUTE_DTYPE != hip.DT_F32 else (None, wino_images(filt[2 * g]).get('dgrad'))
                 wbs[g] = wb[1]
                 hip.conv2d_fwd(si_out[g * B:(g + 1) * B], filt[2 * g], bias, 3, 3, 1, 1, out=gb[g * B:(g + 1) * B], w_bf16=wb[0])
             mix, mean, rstd = hip.instnorm_spade_fwd(zs, gb[:, :C], gb[:, C:], eps, stats=(smean, srstd) if (smean is not None and zs is z) else None)
@@ -1216,7 +1288,8 @@ class _Conv2dFn(Function):
             y = torch.ops.mrdis.conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu, wb_fwd, wb_bwd)
         ctx.geom = (kh, kw, stride, pad, lrelu, x.shape[2], x.shape[3])
         ctx.bias_param = bias                         # the Parameter object: its .grad may be an in-kernel gradient sink
-        ctx.dtype = hip.DT_F32 if wb_fwd is None else hip.DT_F32_BF16M
+        aux = wb_fwd if wb_fwd is not None else wb_bwd
+        ctx.dtype = hip.DT_F32_BF16M if (aux is not None and aux.dtype is torch.bfloat16) else hip.DT_F32
         ctx.save_for_backward(x, w_tkc, y if lrelu else None, wb_bwd)
         return y
 

@@ -1068,3 +1068,40 @@ def test_bilinear_up2_with_instance_statistics(mrdis, N, C, H, W, dtype):
     tol = 2e-2 if dtype == 'bf16' else 2e-5
     assert float((out_a.float() - out_b.float()).abs().max()) <= tol * float(out_a.float().abs().max())
 
+
+@pytest.mark.parametrize('R,S,flip,C', [(32, 64, 0, 0), (20, 100, 1, 0), (128, 256, 0, 128), (36, 96, 0, 48), (64, 40, 1, 0)])
+def test_winograd_filter_image(mrdis, R, S, flip, C):
+    """mrdis_wino_u_jobs: U = G g G^T of a [9][R][S] filter in the order wino2_kernel<.., UIMG> reads it -- [cout tile][chunk of 8][8][4][64][4],
+    zero-padded; roles forward (flip 0), data gradient (flip 1: taps reversed) and SPADE (the fused gamma | beta cout order) -- against the
+    transform written out in torch."""
+    hip = mrdis.hip
+    w = rnd((9, R, S), 77)
+    n = hip.wino_u_image_floats(R, S, C)
+    img = torch.full((n,), float('nan'), device=dev())
+    j = hip.WinoUJob()
+    wd = w.to(dev())
+    j.w, j.img, j.R, j.S, j.flip, j.spadeC, j.block0, j.nblk = wd.data_ptr(), img.data_ptr(), R, S, flip, C, 0, hip.wino_u_job_blocks(R, S, C)
+    hip.wino_u_jobs(hip.wino_u_table([j], dev()), 1, j.nblk)
+    G = torch.tensor([[1., 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1.]], dtype=torch.float64)
+    g = w.double().reshape(3, 3, R, S)
+    if flip:
+        g = g.flip(0, 1)
+    U = torch.einsum('ai,ijrs,bj->abrs', G, g, G).reshape(16, R, S)
+    tiles = (C + 31) // 32 if C else (S + 63) // 64
+    nch = (R + 7) // 8
+    want = torch.zeros(tiles, nch, 8, 4, 64, 4, dtype=torch.float64)
+    for cot in range(tiles):
+        for slot in range(64):
+            if C:
+                ch = cot * 32 + 16 * (slot >> 5) + (slot & 15)
+                co, ok = (C if (slot >> 4) & 1 else 0) + ch, ch < C
+            else:
+                co = cot * 64 + slot; ok = co < S
+            if not ok:
+                continue
+            col = torch.zeros(16, nch * 8, dtype=torch.float64); col[:, :R] = U[:, :, co]
+            want[cot, :, :, :, slot, :] = col.reshape(4, 4, nch, 8).permute(2, 3, 0, 1)          # [chunk][k][a][b]
+    got = img.cpu().double().reshape(want.shape)
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+

@@ -168,8 +168,8 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
     m = mrdis
     H = W = HW
     res = {}
-    for mode in ((1, 0), (0, 0), (1, 1)):                # (wino, debug_now16): default policy | direct kernels only | narrow-layer kernels off
-        m.hip.set_option('wino', mode[0]); m.hip.set_option('debug_now16', mode[1])
+    for mode in ((1, 0), (0, 0), (1, 1), (1, 0, 'no_u')):  # (wino, debug_now16): default policy | direct kernels only | narrow-layer kernels off | wino_u = 0
+        m.hip.set_option('wino', mode[0]); m.hip.set_option('debug_now16', mode[1]); m.hip.set_option('wino_u', 0 if len(mode) > 2 else 1)
         cfg = dict(m.DEFAULT_CONFIG); cfg.update(input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0, is_patch_gan=True)
         cfg = m.derive_config(cfg, DEV)
         torch.manual_seed(10); np.random.seed(10)
@@ -190,7 +190,12 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
                      {n: p.detach().clone() for n, p in model.named_parameters()})
         del model, step
         torch.cuda.empty_cache()
-    m.hip.set_option('wino', 1); m.hip.set_option('debug_now16', 0)
+    m.hip.set_option('wino', 1); m.hip.set_option('debug_now16', 0); m.hip.set_option('wino_u', 1)
+    # the pipelined Winograd kernels read the filter's 16-point image built behind the mixing launch, or transform the nine taps themselves
+    # (option wino_u = 0): the same expressions on the same values -- the whole step is bit-identical
+    (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0)], res[(1, 0, 'no_u')]
+    assert l1 == l0 and p1 == p0
+    assert all(torch.equal(a, c) for n in g0 for a, c in zip(g0[n], g1[n])) and all(torch.equal(w0[n], w1[n]) for n in w0)
     for other in ((0, 0), (1, 1)):
         (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0)], res[other]
         assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
