@@ -482,15 +482,22 @@ class GradAllReduce:
                 self._hook(p)
 
     def _launch(self, b):
-        if self.world == 1 or self.launched[b]:
+        """bucket b is complete.  Collectives must be issued in the SAME order on every rank (RCCL pairs them by order), and which
+        gradients a rank's backward produces first may depend on its batch (a modality missing from a rank's whole batch prunes
+        that decoder's loss terms): buckets therefore leave strictly in index order -- the arena is laid out in completion order,
+        so in the common case that IS the order in which they complete."""
+        if self.world == 1 or self.ready[b]:
             return
-        self.launched[b] = True
+        self.ready[b] = True
         t = self.target
-        hi = self.edges[b + 1] if b + 1 < self.nbuckets else t._g_full.numel()      # last bucket: + the gate flags
-        if self.armed:
-            self.early_buckets += 1
-        self.bytes_reduced += 4 * (hi - self.edges[b])
-        self.handles.append(dist.all_reduce(t._g_full[self.edges[b]:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        while self.next_bucket < self.nbuckets and self.ready[self.next_bucket]:
+            k = self.next_bucket
+            self.next_bucket += 1
+            hi = self.edges[k + 1] if k + 1 < self.nbuckets else t._g_full.numel()      # last bucket: + the gate flags
+            if self.armed:
+                self.early_buckets += 1
+            self.bytes_reduced += 4 * (hi - self.edges[k])
+            self.handles.append(dist.all_reduce(t._g_full[self.edges[k]:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin(self, target=None):
         """call before backward(); `target`: the optimizer whose gradient buffer receives this backward pass."""
@@ -499,7 +506,8 @@ class GradAllReduce:
             self._setup()
         if self.hooks:
             self.pending = list(self.pending0)
-            self.launched = [False] * self.nbuckets
+            self.ready = [False] * self.nbuckets
+            self.next_bucket = 0
             self.done = set()
         self.handles = []
         self.armed = True
