@@ -223,12 +223,15 @@ int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, 
 /* ---- BatchNorm2d, training mode: model.py:2132/2151, 2179/2191, 2776-2785 --
  * x view (P = N*H*W rows, C) ; writes y view, save_mean/save_rstd (C) and
  * updates running_mean/var (momentum 0.1, unbiased var) when non-NULL.
- * workspace: mrdis_norm_workspace(1, P, C) bytes.                             */
+ * groups = G > 1: the view holds G batches of P rows that the reference normalises in G separate calls of the SAME layer (the
+ * modalities of one encoder pass, model.py:3135-3157): statistics per group (save_mean / save_rstd, and dgamma / dbeta of the
+ * backward, hold G * C entries), the running statistics are updated group by group in order, rounded to fp32 in between.
+ * workspace: groups * mrdis_norm_workspace(1, P, C) bytes (each group is chunked as a call of its own: bit-identical statistics). */
 size_t mrdis_norm_workspace(int groups, long long P, int C);
 int mrdis_bn_train_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma,
                        const float* beta, float* running_mean, float* running_var,
                        float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                       long long P, int C, float eps, float momentum, int dtype, void* stream);
+                       long long P, int C, float eps, float momentum, int groups, int dtype, void* stream);
 /* inference mode (model.eval(), main_missing.py:338): y = (x - running_mean) * rsqrt(running_var + eps) * gamma + beta */
 int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long long P, int C, float eps, int dtype, void* stream);
@@ -237,7 +240,7 @@ int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const float* gam
 int mrdis_bn_train_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma,
                        const float* save_mean, const float* save_rstd, void* dx, int lddx,
                        float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
-                       void* workspace, size_t workspace_bytes, long long P, int C, int dtype, void* stream);
+                       void* workspace, size_t workspace_bytes, long long P, int C, int groups, int dtype, void* stream);
 
 /* ---- InstanceNorm2d(affine=False) fused with the SPADE modulation:
  * model.py:2431/2440 + 2446:  out = IN(z) * (1 + gamma) + beta ---------------

@@ -228,8 +228,9 @@ static int stat_final_lanes(int chunks) { int y = 4; while (y < 16 && y * 8 < ch
 
 template <int MODE, typename T>
 static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, int ldg, const float* mean,
-                        const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s) {
-    const StatPlan sp = stat_plan(groups, P);
+                        const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s, int plan_groups = 0) {
+    // plan_groups: take the chunking of a launch with that many groups (grouped BatchNorm chunks each group exactly as a call of its own would)
+    const StatPlan sp = stat_plan(plan_groups > 0 ? plan_groups : groups, P);
     const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || vec4_ok(b, ldb, C)) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
                      ((C >> 2) >= 256 ? (C >> 2) % 256 == 0 : 256 % (C >> 2) == 0);
     if (vec)
@@ -246,39 +247,86 @@ static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, in
 template <int V, typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                long long P, int C) {
+                                long long P, int C, long long Pg) {
+    // Pg: rows per statistics group (P for plain BatchNorm; P / G when the batch holds G groups that the reference normalises in G
+    // separate calls -- the modalities of one encoder pass): row r uses mean / rstd [(r / Pg) * C + c]
     const int Q = C / V;
     EW_LOOP(P * Q) {
         const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        const int so = (int)(r / Pg) * C + c;
         Vec<V> a, o; a.load(x + r * ldx + c);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float sc = rstd[c + k] * (gamma ? gamma[c + k] : 1.f);
-            o.v[k] = (a.v[k] - mean[c + k]) * sc + (beta ? beta[c + k] : 0.f);
+            const float sc = rstd[so + k] * (gamma ? gamma[c + k] : 1.f);
+            o.v[k] = (a.v[k] - mean[so + k]) * sc + (beta ? beta[c + k] : 0.f);
         }
         o.store(y + r * ldy + c);
     }
+}
+
+// the statistics of G groups of one BatchNorm layer in one launch: per group mean / rstd, and the running statistics updated group by group
+// in order (nn.BatchNorm2d called G times: running = (1 - momentum) running + momentum stat_g, g = 0 .. G - 1).  block (64, SY).
+__global__ void stat_final_groups_kernel(const float* __restrict__ part, int chunks, int C, int groups, long long P, float eps, float momentum,
+                                         float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ double red[2][16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, SY = blockDim.y;
+    const bool ok = c < C;
+    double rm = 0.0, rv = 0.0;
+    if (ok && run_mean && threadIdx.y == 0) { rm = (double)run_mean[c]; rv = (double)run_var[c]; }
+    for (int g = 0; g < groups; ++g) {
+        double s0 = 0.0, s1 = 0.0;
+        if (ok)
+            for (int k = threadIdx.y; k < chunks; k += SY) {
+                const float* src = part + ((long long)(g * chunks + k) * 2) * C;
+                s0 += (double)src[c]; s1 += (double)src[C + c];
+            }
+        red[0][threadIdx.y][threadIdx.x] = s0; red[1][threadIdx.y][threadIdx.x] = s1;
+        __syncthreads();
+        if (ok && threadIdx.y == 0) {
+            s0 = 0.0; s1 = 0.0;
+            for (int y = 0; y < SY; ++y) { s0 += red[0][y][threadIdx.x]; s1 += red[1][y][threadIdx.x]; }
+            const double m = s0 / (double)P;
+            double var = s1 / (double)P - m * m; if (var < 0.0) var = 0.0;
+            out0[g * C + c] = (float)m;
+            out1[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (run_mean) {
+                const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+                // each call of the reference rounds the running statistics to fp32: round between the groups as well
+                rm = (double)(float)((1.0 - momentum) * rm + momentum * m);
+                rv = (double)(float)((1.0 - momentum) * rv + momentum * unb);
+            }
+        }
+        __syncthreads();
+    }
+    if (ok && run_mean && threadIdx.y == 0) { run_mean[c] = (float)rm; run_var[c] = (float)rv; }
 }
 
 template <typename T>
 static int bn_train_fwd_impl(const T* x, int ldx, T* y, int ldy, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var,
                                   float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                                  long long P, int C, float eps, float momentum, void* stream) {
-    if (!x || !y || !save_mean || !save_rstd || !workspace || P < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
-    if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
+                                  long long P, int C, float eps, float momentum, int G, void* stream) {
+    // G groups of P rows each (G = 1: plain BatchNorm over P rows); save_mean / save_rstd hold G * C entries
+    if (!x || !y || !save_mean || !save_rstd || !workspace || P < 1 || C < 1 || ldx < C || ldy < C || G < 1 || G > 64) return MRDIS_EINVAL;
+    // every group is chunked as a call of its own would be (the same partial sums in the same order: grouped == G separate calls, bit for bit)
+    if (workspace_bytes < (size_t)G * mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<0, T>(x, ldx, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, 1, P, C, part, s);
+    int rc = launch_stats<0, T>(x, ldx, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, G, P, C, part, s, 1);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
-                       save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
-    MRDIS_CHECK_LAUNCH();
-    if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+    if (G == 1)
+        hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
+                           save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, P, C);
+        hipLaunchKernelGGL(stat_final_groups_kernel, dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, eps, momentum,
+                           save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
+    MRDIS_CHECK_LAUNCH();
+    const long long rows = P * G;
+    if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
+        hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -317,19 +365,22 @@ template <int V, typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ sdy, const float* __restrict__ sdyxh, T* __restrict__ dx, int lddx,
-                                    long long P, int C, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
+                                    long long P, int C, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta, long long Pg, int G) {
+    // Pg rows per statistics group, G groups (P = G * Pg rows): statistics and sums are indexed [group][channel]
     const int Q = C / V;
-    const float invP = 1.f / (float)P;
-    if (acc_dgamma != nullptr && blockIdx.x == 0)          // fold this call's parameter gradients into the running sums
-        for (int c = threadIdx.x; c < C; c += blockDim.x) { acc_dgamma[c] += sdyxh[c]; acc_dbeta[c] += sdy[c]; }
+    const float invP = 1.f / (float)Pg;
+    if (acc_dgamma != nullptr && blockIdx.x == 0)          // fold this call's parameter gradients into the running sums (groups in order)
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            for (int g = 0; g < G; ++g) { acc_dgamma[c] += sdyxh[g * C + c]; acc_dbeta[c] += sdy[g * C + c]; }
     EW_LOOP(P * Q) {
         const long long r = idx / Q; const int c = (int)(idx - r * Q) * V;
+        const int so = (int)(r / Pg) * C + c;
         Vec<V> d, a, o; d.load(dy + r * lddy + c); a.load(x + r * ldx + c);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float rs = rstd[c + k];
-            const float xh = (a.v[k] - mean[c + k]) * rs;
-            o.v[k] = (gamma ? gamma[c + k] : 1.f) * rs * (d.v[k] - sdy[c + k] * invP - xh * sdyxh[c + k] * invP);
+            const float rs = rstd[so + k];
+            const float xh = (a.v[k] - mean[so + k]) * rs;
+            o.v[k] = (gamma ? gamma[c + k] : 1.f) * rs * (d.v[k] - sdy[so + k] * invP - xh * sdyxh[so + k] * invP);
         }
         o.store(dx + r * lddx + c);
     }
@@ -339,23 +390,25 @@ template <typename T>
 static int bn_train_bwd_impl(const T* dy, int lddy, const T* x, int ldx, const float* gamma,
                                   const float* save_mean, const float* save_rstd, T* dx, int lddx,
                                   float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
-                                  void* workspace, size_t workspace_bytes, long long P, int C, void* stream) {
-    if (!dy || !x || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || P < 1 || C < 1) return MRDIS_EINVAL;
+                                  void* workspace, size_t workspace_bytes, long long P, int C, int G, void* stream) {
+    // G groups of P rows (see bn_train_fwd_impl); dgamma / dbeta receive G * C per-group sums
+    if (!dy || !x || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || P < 1 || C < 1 || G < 1 || G > 64) return MRDIS_EINVAL;
     if ((acc_dgamma == nullptr) != (acc_dbeta == nullptr)) return MRDIS_EINVAL;
-    if (workspace_bytes < mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
+    if (workspace_bytes < (size_t)G * mrdis_norm_workspace(1, P, C)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    int rc = launch_stats<1, T>(dy, lddy, x, ldx, (const T*)nullptr, 0, save_mean, save_rstd, 0, 1, P, C, part, s);
+    int rc = launch_stats<1, T>(dy, lddy, x, ldx, (const T*)nullptr, 0, save_mean, save_rstd, 1, G, P, C, part, s, 1);
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
-    // dbeta = sum dy ; dgamma = sum dy * xhat
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, 0.f, 0.f,
+    // dbeta = sum dy ; dgamma = sum dy * xhat  (per group)
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(G * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, 0.f, 0.f,
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
+    const long long rows = P * G;
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, P, C, acc_dgamma, acc_dbeta);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -878,10 +931,10 @@ static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, in
 typedef const __bf16* cbf; typedef __bf16* bf;
 extern "C" int mrdis_bn_train_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
-                                  long long P, int C, float eps, float momentum, int dtype, void* stream) {
+                                  long long P, int C, float eps, float momentum, int groups, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype,
-        bn_train_fwd_impl((const float*)x, ldx, (float*)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, stream),
-        bn_train_fwd_impl((cbf)x, ldx, (bf)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, stream));
+        bn_train_fwd_impl((const float*)x, ldx, (float*)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, groups, stream),
+        bn_train_fwd_impl((cbf)x, ldx, (bf)y, ldy, gamma, beta, running_mean, running_var, save_mean, save_rstd, workspace, workspace_bytes, P, C, eps, momentum, groups, stream));
 }
 extern "C" int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, const float* running_mean,
                                  const float* running_var, long long P, int C, float eps, int dtype, void* stream) {
@@ -890,10 +943,10 @@ extern "C" int mrdis_bn_eval_fwd(const void* x, int ldx, void* y, int ldy, const
 }
 extern "C" int mrdis_bn_train_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* save_mean,
                                   const float* save_rstd, void* dx, int lddx, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
-                                  void* workspace, size_t workspace_bytes, long long P, int C, int dtype, void* stream) {
+                                  void* workspace, size_t workspace_bytes, long long P, int C, int groups, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype,
-        bn_train_bwd_impl((const float*)dy, lddy, (const float*)x, ldx, gamma, save_mean, save_rstd, (float*)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, stream),
-        bn_train_bwd_impl((cbf)dy, lddy, (cbf)x, ldx, gamma, save_mean, save_rstd, (bf)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, stream));
+        bn_train_bwd_impl((const float*)dy, lddy, (const float*)x, ldx, gamma, save_mean, save_rstd, (float*)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, groups, stream),
+        bn_train_bwd_impl((cbf)dy, lddy, (cbf)x, ldx, gamma, save_mean, save_rstd, (bf)dx, lddx, dgamma, dbeta, acc_dgamma, acc_dbeta, workspace, workspace_bytes, P, C, groups, stream));
 }
 extern "C" int mrdis_instnorm_spade_fwd(const void* z, int ldz, const void* gamma, int ldg, const void* beta, int ldb, void* out, int ldo,
                                         float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,

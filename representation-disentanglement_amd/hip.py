@@ -59,9 +59,9 @@ _SIGS = {
     'mrdis_conv2d_bwd_weight': (_I, [_P, _I, _P, _I, _P, _P, _P, _Z] + [_I] * 11 + [_P]),
     'mrdis_lrelu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _F, _I, _P]),
     'mrdis_norm_workspace': (_Z, [_I, _L, _I]),
-    'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _I, _P]),
+    'mrdis_bn_train_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _L, _I, _F, _F, _I, _I, _P]),
     'mrdis_bn_eval_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
-    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _P]),
+    'mrdis_bn_train_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _L, _I, _I, _I, _P]),
     'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
     'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
@@ -614,21 +614,24 @@ def lrelu_bwd(dy, y, slope=0.2):
 
 
 # ---------------------------------------------------------------- norms
-def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=None):
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=None, groups=1):
+    """groups = G: the batch holds G equal sample blocks that the reference normalises in G separate calls of this layer
+    (statistics per block: mean / rstd are (G * C); running statistics updated block by block)."""
     lib = load()
     x, ldx = nhwc(x)
     N, C, H, W = x.shape
-    P = N * H * W
+    assert N % groups == 0
+    P = (N // groups) * H * W
     if out is None:
         out = empty_nhwc(N, C, H, W, x.device, x.dtype)
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr()
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    nb = _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
+    mean = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+    nb = groups * _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
     ws = _ws(nb, x.device)
     _chk(lib.mrdis_bn_train_fwd(_ptr(x), ldx, _ptr(y), ldy, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, _dt(x, y), _stream()), 'bn_train_fwd')
+                                _ptr(mean), _ptr(rstd), _ptr(ws), nb, P, C, eps, momentum, groups, _dt(x, y), _stream()), 'bn_train_fwd')
     return out, mean, rstd
 
 
@@ -642,20 +645,23 @@ def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps):
     return y
 
 
-def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None):
-    """-> (dx, dgamma, dbeta).  sink = (acc_dgamma, acc_dbeta): buffers this call's parameter gradients are also added to."""
+def bn_train_bwd(dy, x, gamma, mean, rstd, sink=None, groups=1):
+    """-> (dx, dgamma, dbeta).  sink = (acc_dgamma, acc_dbeta): buffers this call's parameter gradients are also added to.
+    groups: as bn_train_fwd (dgamma / dbeta are then summed over the groups here)."""
     lib = load()
     dy, lddy = nhwc(dy); x, ldx = nhwc(x)
     N, C, H, W = x.shape
-    P = N * H * W
+    P = (N // groups) * H * W
     dx = empty_nhwc(N, C, H, W, x.device, x.dtype)
-    dg = torch.empty(C, dtype=torch.float32, device=x.device)
-    db = torch.empty(C, dtype=torch.float32, device=x.device)
-    nb = _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
+    dg = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+    db = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+    nb = groups * _ws_bytes(lib.mrdis_norm_workspace, 1, P, C)
     ws = _ws(nb, x.device)
     ag, ab = sink if sink is not None else (None, None)
     _chk(lib.mrdis_bn_train_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), C, _ptr(dg), _ptr(db),
-                                _ptr(ag), _ptr(ab), _ptr(ws), nb, P, C, _dt(dy, x), _stream()), 'bn_train_bwd')
+                                _ptr(ag), _ptr(ab), _ptr(ws), nb, P, C, groups, _dt(dy, x), _stream()), 'bn_train_bwd')
+    if groups > 1 and sink is None:
+        dg, db = dg.view(groups, C).sum(0), db.view(groups, C).sum(0)
     return dx, dg, db
 
 

@@ -109,6 +109,19 @@ class CondConv2d(nn.Module):
         return torch.cat(outs, 0)
 
 
+    def forward_grouped(self, x, types, lrelu=False):
+        """x: G sample blocks (block g belongs to the batch-constant type tensor types[g]) -> the G outputs, batch-concatenated:
+        ONE op for the G calls of the reference's per-modality loop (ops.conv2d_grouped)."""
+        kh, kw = self.kernel_size
+        G = len(types)
+        if ops.storage_bf16() and self.stride[0] != 1 and min(self.in_channels, self.out_channels) < 16:
+            # the stride-2 first layers under bf16 storage keep ops.conv2d's policy (fp32 kernels between view casts), block by block
+            B = x.shape[0] // G
+            return torch.cat([self.forward(x[g * B:(g + 1) * B], types[g], lrelu) for g in range(G)], 0)
+        return ops.conv2d_grouped(x, [self.mixed_uniform(t) for t in types], self.bias, kh, kw, self.padding[0], lrelu=lrelu,
+                                  co=self.out_channels, stride=self.stride[0])
+
+
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d whose forward/backward run in the HIP kernels (discriminator,
     model.py:2773-2789).  Keeps nn.Conv2d's parameters, init and state_dict."""
@@ -141,13 +154,15 @@ class BatchNorm2d(nn.BatchNorm2d):
             self.weight._mrdis_sink = True         # gradients accumulated in-kernel (ops._grad_sink)
             self.bias._mrdis_sink = True
 
-    def forward(self, x, into=None):
-        """into = (buf, c0): training mode writes the result into channels [c0, c0 + C) of `buf` and returns that view"""
+    def forward(self, x, into=None, groups=1):
+        """into = (buf, c0): training mode writes the result into channels [c0, c0 + C) of `buf` and returns that view.
+        groups = G: x holds G sample blocks that the reference sends through this layer in G calls (statistics per block)."""
         if self.training:
             if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+                self.num_batches_tracked.add_(groups)
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                        self.eps, self.momentum, into)
+                                        self.eps, self.momentum, into, groups)
+        assert groups == 1
         if not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
             return ops.hip.bn_eval_fwd(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)   # evaluate()
         # eval-mode BatchNorm under autograd (fine-tuning with frozen statistics) is not on the path: plain torch
@@ -190,6 +205,21 @@ class Conv_BN_Act_New(nn.Module):
         return self.act(x)
 
 
+    def forward_grouped(self, x, types, skip=False):
+        """forward for G modality labels on the batch-concatenated input (block g: types[g]); BatchNorm statistics per block"""
+        G = len(types)
+        x = self.conv.forward_grouped(x, types)
+        if self.is_bn:
+            if (skip and self.training and x.is_cuda and ops.cat_elision() and isinstance(self.act, nn.Sequential) and len(self.act) == 0):
+                N, C, H, W = x.shape
+                buf = ops.hip.empty_nhwc(N, 2 * C, H, W, x.device, x.dtype)
+                x = self.bn(x, into=(buf, 0), groups=G)
+                x._mrdis_catbuf = buf
+                return x
+            x = self.bn(x, groups=G)
+        return self.act(x)
+
+
 class Act_Deconv_BN_Concat_New(nn.Module):
     """model.py:2155-2195.  identity act (same QUIRK) -> bilinear x2 align_corners=True ->
     conv3x3 -> [BN -> cat(skip)]; `bn` is created even when is_last (:2179)."""
@@ -222,6 +252,25 @@ class Act_Deconv_BN_Concat_New(nn.Module):
         return torch.cat([x_down, x_up], 1)
 
 
+    def forward_grouped(self, x_down, x_up, types):
+        G = len(types)
+        x_up = self.act(x_up)
+        x_up = ops.bilinear(x_up, (2 * x_up.shape[2], 2 * x_up.shape[3]), True)
+        x_up = self.conv.forward_grouped(x_up, types)
+        if self.is_last:
+            return x_up
+        if self.is_bn and self.training and x_up.is_cuda and ops.cat_elision() and x_down.dtype == x_up.dtype and isinstance(self.act, nn.Sequential) \
+                and x_down.shape[0] == x_up.shape[0] and x_down.shape[2:] == x_up.shape[2:]:
+            Cd, Cu = x_down.shape[1], x_up.shape[1]
+            buf = getattr(x_down, '_mrdis_catbuf', None)
+            if buf is not None and buf.shape[1] == Cd + Cu and buf.dtype == x_up.dtype:
+                x_up = self.bn(x_up, into=(buf, Cd), groups=G)
+                return ops.cat_join(x_down, x_up, buf)
+        if self.is_bn:
+            x_up = self.bn(x_up, groups=G)
+        return torch.cat([x_down, x_up], 1)
+
+
 class AnatomyEncoderEncNew(nn.Module):
     """model.py:2218-2245."""
 
@@ -242,6 +291,14 @@ class AnatomyEncoderEncNew(nn.Module):
         d3 = self.down_3(d2, inputs_type, skip=True)
         d4 = self.down_4(d3, inputs_type, skip=True)
         d5 = self.down_5(d4, inputs_type)
+        return [d1, d2, d3, d4, d5]
+
+    def forward_grouped(self, x, types):
+        d1 = self.down_1.forward_grouped(x, types, lrelu=True)
+        d2 = self.down_2.forward_grouped(d1, types, skip=True)
+        d3 = self.down_3.forward_grouped(d2, types, skip=True)
+        d4 = self.down_4.forward_grouped(d3, types, skip=True)
+        d5 = self.down_5.forward_grouped(d4, types)
         return [d1, d2, d3, d4, d5]
 
 
@@ -265,6 +322,14 @@ class AnatomyEncoderDecNew(nn.Module):
         u2 = self.up_2(down_list[1], u3, inputs_type)
         u1 = self.up_1(down_list[0], u2, inputs_type)
         out = self.output(None, u1, inputs_type)
+        return out, out
+
+    def forward_grouped(self, down_list, types):
+        u4 = self.up_4.forward_grouped(down_list[3], down_list[4], types)
+        u3 = self.up_3.forward_grouped(down_list[2], u4, types)
+        u2 = self.up_2.forward_grouped(down_list[1], u3, types)
+        u1 = self.up_1.forward_grouped(down_list[0], u2, types)
+        out = self.output.forward_grouped(None, u1, types)
         return out, out
 
 
@@ -299,6 +364,16 @@ class ModalityEncoderNew(nn.Module):
             x = conv(x, inputs_type, lrelu=True) if self.is_cond else conv(x, lrelu=True)   # :2374-2383
         # `view(-1, 5*6*128)` flattens NCHW order (:2396): make that order physical (tiny tensor)
         x = x.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1).float()     # bf16 storage: the Linears stay fp32
+        x = self.fcs(x)
+        return self.mean(x), self.log_var(x)
+
+    def forward_grouped(self, xi, types):
+        """the G per-modality calls on the batch-concatenated input (the Linear layers are type-independent)"""
+        assert self.s_num_ch == 0 and self.is_cond
+        x = xi
+        for i in range(5):
+            x = getattr(self, f'conv{i + 1}').forward_grouped(x, types, lrelu=True)
+        x = x.contiguous(memory_format=torch.contiguous_format).reshape(x.shape[0], -1).float()
         x = self.fcs(x)
         return self.mean(x), self.log_var(x)
 
@@ -720,7 +795,31 @@ class MultimodalModel(nn.Module):
         return t
 
     # ---- model.py:3135-3157
+    def _encoders_grouped(self):
+        """the per-modality encoder loops (model.py:3135-3157, 3164-3185) as ONE batch-concatenated pass with the kernels mixed per sample
+        block: applies inside a training step when the modalities share the encoder modules (config.yaml: shared_ana_enc / shared_mod_enc)"""
+        return ops.grouped_applies() and ops.grouped_encoders() and self.is_cond and self.shared_ana_enc and self.shared_mod_enc and self.modality_num > 1
+
+    @staticmethod
+    def _cat_inputs(inputs_list):
+        """the M input blocks as one batch-concatenated tensor: free when they are the consecutive blocks of the modality-planar copy"""
+        x0 = inputs_list[0]
+        base = x0._base
+        if base is not None and all(t._base is base for t in inputs_list) and base.dim() == 5 and base.is_contiguous() \
+                and base.shape[0] == len(inputs_list) and all(t.data_ptr() == base[i].data_ptr() for i, t in enumerate(inputs_list)):
+            M, B, H, W, c = base.shape
+            return base.view(M * B, H, W, c).permute(0, 3, 1, 2)
+        return torch.cat(list(inputs_list), 0)
+
     def compute_anatomy_encoding(self, inputs_list, mask_img):
+        if self._encoders_grouped():
+            M, B = self.modality_num, inputs_list[0].shape[0]
+            types = [self._type(i, B) for i in range(M)]
+            x = self._cat_inputs(inputs_list)
+            feats = self.anatomy_encoder_enc_list[0].forward_grouped(x, types)
+            si, _ = self.anatomy_encoder_dec.forward_grouped(feats, types)
+            m_all = mask_img if mask_img is None else mask_img.repeat(M, 1, 1)
+            return list(ops.split_batch(ops.softmax_mask_drop(si, m_all, 100.0), M))
         si_list = []
         B = inputs_list[0].shape[0]
         for i in range(self.modality_num):
@@ -740,6 +839,14 @@ class MultimodalModel(nn.Module):
     def compute_modality_encoding(self, inputs_list, si_list, phase='train'):
         zi_list, mu_list, lv_list = [], [], []
         B = inputs_list[0].shape[0]
+        if self._encoders_grouped() and self.modality_encoder_list[0].s_num_ch == 0:
+            M = self.modality_num
+            mu, lv = self.modality_encoder_list[0].forward_grouped(self._cat_inputs(inputs_list), [self._type(i, B) for i in range(M)])
+            for i in range(M):
+                mu_i, lv_i = mu[i * B:(i + 1) * B], lv[i * B:(i + 1) * B]
+                zi_list.append(self.sample(mu_i, lv_i) if phase == 'train' else mu_i)       # eps drawn per modality, in order (:3159-3162)
+                mu_list.append(mu_i); lv_list.append(lv_i)
+            return zi_list, mu_list, lv_list
         for i in range(self.modality_num):
             t = self._type(i, B)
             enc = self.modality_encoder_list[0 if self.shared_mod_enc else i]

@@ -654,6 +654,23 @@ def set_grouped(enabled):
     _GROUPED = bool(enabled)
 
 
+# Default OFF by measurement (round 3, same-box A/B at B = 32 / 256x256): with the encoders batch-concatenated over the four modality labels the
+# step takes 167.3 ms instead of 162.3 (bf16: 97.6 vs 93.2) although it issues ~450 launches fewer -- a modality's activations (134 MB at the
+# second level) stay in the 256 MiB Infinity Cache between a layer and its consumer, the 4x tensors of the batch-concatenated form do not; and
+# the G convolutions of a layer are still G launches, so the small maps fill the chip no better.  Kept as an option (bit-identical losses, tested).
+_GROUPED_ENC = _os.environ.get('MRDIS_GROUPED_ENC', '0') != '0'
+
+
+def set_grouped_encoders(enabled):
+    global _GROUPED_ENC
+    _GROUPED_ENC = bool(enabled)
+
+
+def grouped_encoders():
+    """the anatomy / modality encoders run batch-concatenated over the modality labels (MultimodalModel._encoders_grouped)"""
+    return _GROUPED_ENC
+
+
 def grouped_applies():
     """inside a training step (mixed-kernel cache open, autograd on), every compute dtype."""
     return _GROUPED and _MIX_CACHE is not None and torch.is_grad_enabled()
@@ -681,11 +698,12 @@ class _GroupedConvFn(Function):
     anatomy maps in, the 7-channel reconstruction out) zero-padded to 16."""
 
     @staticmethod
-    def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, co, *filt):
+    def forward(ctx, x, bias, G, share_x, kh, kw, pad, lrelu, co, stride, *filt):
         bm = _COMPUTE_DTYPE != hip.DT_F32
         st = _COMPUTE_DTYPE == hip.DT_BF16
         B = x.shape[0] if share_x else x.shape[0] // G
         H, W = x.shape[2], x.shape[3]
+        Ho, Wo = hip.conv_out_hw(H, W, kh, kw, stride, pad)
         Cif, Cof = filt[0].shape[1], filt[0].shape[2]           # the filters' channel counts: already zero-padded to 16 when they come from
         Ci, Co = x.shape[1], (int(co) if co else Cof)           # the all-layers mixing launch (MixPlan.padded); Ci, Co: the layer's own
         head = st and native_head(kh, kw, Cif, Cof) and pad == 0 and Ci == 16        # bf16 in, fp32 out on the streaming 1x1 kernels
@@ -697,14 +715,14 @@ class _GroupedConvFn(Function):
         xin = x
         if st and (x.dtype != torch.bfloat16 or Ci_p != Ci):
             xin = hip.cast_view(x, torch.bfloat16, Ci_p)           # fp32 -> bf16 view cast, zero channels up to 16
-        y = hip.empty_nhwc(G * B, Co_p, H, W, x.device, torch.float32 if head else xin.dtype)
+        y = hip.empty_nhwc(G * B, Co_p, Ho, Wo, x.device, torch.float32 if head else xin.dtype)
         use_tkc, wbs = [], []
         for g in range(G):
             tck, tkc = filt[2 * g], filt[2 * g + 1]
             bg = bias
             if head:
                 use_tkc.append(tkc); wbs.append(None)
-                hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B])
+                hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, stride, pad, lrelu, out=y[g * B:(g + 1) * B])
                 continue
             if padded:
                 tck, tkc, bg, wb_f, wb_b = _pad16_filters(tck, tkc, bias, Ci_p, Co_p)
@@ -717,10 +735,11 @@ class _GroupedConvFn(Function):
                 if bias is not None and bias.shape[0] < Co_p:
                     bg = _pad_bias16(bias, Co_p, detach=True)
             use_tkc.append(tkc); wbs.append(wb_b)
-            if si4 and hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, out=y[g * B:(g + 1) * B], may_decline=True) is not None:
+            if si4 and stride == 1 and hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, out=y[g * B:(g + 1) * B], may_decline=True) is not None:
                 continue
-            hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
+            hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, stride, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
+        ctx.stride = stride
         ctx.head = head
         ctx.dx_in_gb = bool(getattr(x, '_mrdis_want_dgb', False)) and _GB_INPLACE
         ctx.wbs = wbs
@@ -758,8 +777,8 @@ class _GroupedConvFn(Function):
             dyg = dy[g * B:(g + 1) * B]
             xg = xin if share_x else xin[g * B:(g + 1) * B]
             if need_x:
-                hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, 1, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
-            dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
+                hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
+            dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, ctx.stride, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
             if padded:
                 dw = dw[:, :Cif, :Cof].contiguous()
             dws += [dw, None]
@@ -776,7 +795,7 @@ class _GroupedConvFn(Function):
             dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci_p).sum(0).permute(0, 3, 1, 2) if share_x else dxb
             if dx.dtype != x_dtype or Ci_p != Ci:
                 dx = hip.cast_view(dx, x_dtype, Ci)
-        return (dx, db_total, None, None, None, None, None, None, None) + tuple(dws)
+        return (dx, db_total, None, None, None, None, None, None, None, None) + tuple(dws)
 
 
 class _GbSpadeFn(Function):
@@ -874,29 +893,32 @@ def gb_spade(si_out, z, filters, bias, eps):
     return mix
 
 
-def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False, co=None):
-    """x: (G * B, Ci, H, W) sample blocks (or (B, Ci, H, W) read by every group when share_x); filters: G pairs (w_tck, w_tkc);
-    stride 1.  -> (G * B, Co, H, W): block g = conv(x_g, filters[g]) + bias."""
+def conv2d_grouped(x, filters, bias, kh, kw, pad, lrelu=False, share_x=False, co=None, stride=1):
+    """x: (G * B, Ci, H, W) sample blocks (or (B, Ci, H, W) read by every group when share_x); filters: G pairs (w_tck, w_tkc).
+    -> (G * B, Co, H', W'): block g = conv(x_g, filters[g]) + bias."""
     flat = []
     for a, b in filters:
         flat += [a, b]
-    return _GroupedConvFn.apply(x, bias, len(filters), bool(share_x), kh, kw, pad, bool(lrelu), co, *flat)
+    return _GroupedConvFn.apply(x, bias, len(filters), bool(share_x), kh, kw, pad, bool(lrelu), co, int(stride), *flat)
 
 
 # --------------------------------------------------------------------------- norms
 class _BatchNormTrain(Function):
-    """nn.BatchNorm2d in training mode (model.py:2151, 2191, 2776-2785)."""
+    """nn.BatchNorm2d in training mode (model.py:2151, 2191, 2776-2785).  groups = G: the batch holds G sample blocks that the
+    reference puts through this layer in G separate calls (the modalities of an encoder pass): statistics per block, running
+    statistics updated block by block -- bit-identical to the G calls, in one launch per kernel."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, into=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, into=None, groups=1):
         # into = (buf, c0): the result is written into channels [c0, c0 + C) of the NHWC tensor `buf` (one half of a skip-connection
         # concatenation, model.py:2192) and returned as that view
         out = None
         if into is not None:
             out = into[0][:, into[1]:into[1] + x.shape[1]]
-        y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=out)
+        y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, out=out, groups=groups)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
+        ctx.groups = groups
         return y
 
     @staticmethod
@@ -904,14 +926,14 @@ class _BatchNormTrain(Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         sg, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
         if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            dx, _, _ = hip.bn_train_bwd(dy, x, gamma, mean, rstd, sink=(sg, sb))
-            return dx, None, None, None, None, None, None, None
-        dx, dg, db = hip.bn_train_bwd(dy, x, gamma, mean, rstd)
-        return dx, dg, db, None, None, None, None, None
+            dx, _, _ = hip.bn_train_bwd(dy, x, gamma, mean, rstd, sink=(sg, sb), groups=ctx.groups)
+            return dx, None, None, None, None, None, None, None, None
+        dx, dg, db = hip.bn_train_bwd(dy, x, gamma, mean, rstd, groups=ctx.groups)
+        return dx, dg, db, None, None, None, None, None, None
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, into=None):
-    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum, into)
+def batch_norm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, into=None, groups=1):
+    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum, into, groups)
 
 
 class _CatJoin(Function):

@@ -346,16 +346,19 @@ def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
     assert torch.equal(res[True][1], res[False][1])
 
 
-@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace', 'up2_stats'])
+@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace', 'up2_stats', 'grouped_enc'])
 def test_layout_switches_do_not_change_the_step(mrdis, switch):
     """MRDIS_PLANAR_INPUTS (modality-planar copy of the input batch), MRDIS_CAT_ELISION (skip concatenation written in place) and
     MRDIS_GB_INPLACE (d(mix) written into the beta half of [dgamma | dbeta]) only change where tensors live: one step with the switch
     off and on gives the same loss and the same parameter gradients (same kernels' arithmetic on other strides).  MRDIS_UP2_STATS (the
-    x2 resize in front of a SPADE block also takes that block's InstanceNorm statistics) changes the order of the partial sums only."""
+    x2 resize in front of a SPADE block also takes that block's InstanceNorm statistics) changes the order of the partial sums only.
+    MRDIS_GROUPED_ENC (off by default, by measurement): the per-modality encoder loops as one batch-concatenated pass -- grouped
+    BatchNorm (statistics per sample block, `groups` of mrdis_bn_train_fwd / _bwd) and the strided form of ops.conv2d_grouped."""
     B, M, H, W = 2, 4, 64, 128
     cfg = _cfg(mrdis, M, H, W, B, adv=True)
     holder = {'planar_inputs': (mrdis.trainer, '_PLANAR_INPUTS'), 'cat_elision': (mrdis.ops, '_CAT_ELISION'), 'gb_inplace': (mrdis.ops, '_GB_INPLACE'),
-              'up2_stats': (mrdis.ops, '_UP2_STATS')}[switch]
+              'up2_stats': (mrdis.ops, '_UP2_STATS'), 'grouped_enc': (mrdis.ops, '_GROUPED_ENC')}[switch]
+    default = getattr(holder[0], holder[1])
     res = {}
     try:
         for on in (False, True):
@@ -369,7 +372,7 @@ def test_layout_switches_do_not_change_the_step(mrdis, switch):
                 loss.backward()
             res[on] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     finally:
-        setattr(holder[0], holder[1], True)
+        setattr(holder[0], holder[1], default)
     assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-6 * abs(float(res[False][0]))
     assert res[True][1].keys() == res[False][1].keys()
     tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[False][1].values())))

@@ -1105,3 +1105,34 @@ def test_winograd_filter_image(mrdis, R, S, flip, C):
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('G,B,C,H,W', [(4, 2, 64, 9, 11), (3, 3, 32, 16, 16), (2, 1, 256, 5, 6)])
+def test_batchnorm_groups_equal_separate_calls(mrdis, G, B, C, H, W, dtype):
+    """mrdis_bn_train_fwd / _bwd with groups = G (the G per-modality calls of one BatchNorm layer, model.py:3135-3157, as one launch
+    per kernel): output, saved statistics, running statistics (updated block by block, rounded to fp32 in between), data gradient and
+    the parameter-gradient sums are BIT-IDENTICAL to G calls on the sample blocks."""
+    hip = mrdis.hip
+    T = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    x = cl(rnd((G * B, C, H, W), 51) * 1.7 + 0.3).to(T); dy = cl(rnd((G * B, C, H, W), 52)).to(T)
+    gamma = (rnd((C,), 53, 0.5) + 1).to(dev()); beta = rnd((C,), 54, 0.2).to(dev())
+    rm0 = rnd((C,), 55, 0.1).to(dev()); rv0 = (rnd((C,), 56, 0.1).abs() + 0.5).to(dev())
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    ys, dxs, dgs, dbs, means = [], [], [], [], []
+    for g in range(G):
+        sl = slice(g * B, (g + 1) * B)
+        y, mean, rstd = hip.bn_train_fwd(x[sl], gamma, beta, rm_a, rv_a, 1e-5, 0.1)
+        dx, dg, db = hip.bn_train_bwd(dy[sl], x[sl], gamma, mean, rstd)
+        ys.append(y); dxs.append(dx); dgs.append(dg); dbs.append(db); means.append(torch.cat([mean, rstd]))
+    rm_b, rv_b = rm0.clone(), rv0.clone()
+    y, mean, rstd = hip.bn_train_fwd(x, gamma, beta, rm_b, rv_b, 1e-5, 0.1, groups=G)
+    assert torch.equal(y, torch.cat(ys, 0)) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert torch.equal(mean.view(G, C), torch.stack([m_[:C] for m_ in means])) and torch.equal(rstd.view(G, C), torch.stack([m_[C:] for m_ in means]))
+    sink_g, sink_b = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    dx, _, _ = hip.bn_train_bwd(dy, x, gamma, mean, rstd, sink=(sink_g, sink_b), groups=G)
+    assert torch.equal(dx, torch.cat(dxs, 0))
+    acc_g, acc_b = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    for g in range(G):                                  # the order in which separate calls would fold their sums into the sink
+        acc_g += dgs[g]; acc_b += dbs[g]
+    assert torch.equal(sink_g, acc_g) and torch.equal(sink_b, acc_b)
+
