@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--hw', type=int, nargs=2, default=[256, 256])
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--no-wino-images', action='store_true', help='fp32: the pipelined Winograd kernels transform the filter taps themselves (as before round 3)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16m'],
                     help='bf16: bf16 activations + bf16 MFMA operands (fp32 kernels between view casts where the bf16 kernels do not apply: '
                          'timed with the casts); bf16m: bf16 MFMA operands on fp32 activations')
@@ -135,6 +136,19 @@ def main():
                     return hip.conv2d_bwd_weight(x32, hip.cast_view(dys, torch.float32), k, k, s, p)
             tf, td, tw = timeit(f_fwd, a.iters), timeit(f_dgrad, a.iters), timeit(f_wgrad, a.iters)
         else:
+            if a.dtype == 'f32' and k == 3 and s == 1 and not a.no_wino_images and ci % 4 == 0 and co % 4 == 0:
+                # as in the step: the filter's Winograd-domain images, built once behind the mixing launch (mrdis_wino_u_jobs)
+                jobs, imgs, blocks = [], [], 0
+                for src, R, S, flip in ((wt, ci, co, 0), (wk, co, ci, 1)):
+                    if S <= 32:
+                        imgs.append(None); continue
+                    img = torch.zeros(hip.wino_u_image_floats(R, S), device=dev)
+                    j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = src.data_ptr(), img.data_ptr(), R, S, flip, 0
+                    j.block0, j.nblk = blocks, hip.wino_u_job_blocks(R, S); blocks += j.nblk
+                    jobs.append(j); imgs.append(img)
+                if jobs:
+                    hip.wino_u_jobs(hip.wino_u_table(jobs, dev), len(jobs), blocks)
+                wb_f, wb_b = imgs
             tf = timeit(lambda: hip.conv2d_fwd(x, wt, bias, k, k, s, p, w_bf16=wb_f), a.iters)
             td = timeit(lambda: hip.conv2d_bwd_data(dy, wk, (hi, wi), k, k, s, p, w_bf16=wb_b), a.iters)
             tw = timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, k, s, p, dtype=dt), a.iters)
