@@ -23,7 +23,17 @@ typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bp_bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned bp_u32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
 namespace {
+// The two half-waves of a lane pair (e, half) hold the cout groups 8 q + 4 half .. + 3 of one position: two 8-byte pieces per 8 couts.  Swapping
+// group q of the upper half with group q + 1 of the lower half (v_permlane32_swap, one instruction per dword) leaves every lane with 8
+// CONSECUTIVE couts -- half 0: 8 q .. 8 q + 7, half 1: 8 (q + 1) .. 8 (q + 1) + 7 -- i.e. one 16-byte store per lane where there were two 8-byte
+// stores: half as many write requests of twice the size reach L2 (the epilogue is bound by them: 80 of 140 us on the 256x256 level).
+__device__ __forceinline__ bp_u32x4 bp_pair8(bp_u32x2 gq, bp_u32x2 gq1) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(gq[0], gq1[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(gq[1], gq1[1], false, false);
+    return bp_u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
 constexpr int P_KC = 32, P_PITCH = P_KC + 8, P_TH = 8, P_TW = 32, P_TINH = P_TH + 2, P_TINW = P_TW + 2, P_NPIX = P_TINH * P_TINW;
 constexpr int P_XS = P_NPIX * P_PITCH;                 // bf16 elements of one x image
 constexpr int P_BIAS = 1024;
@@ -44,6 +54,7 @@ struct BConv3Params {
     // (z - mean) * rstd * (1 + gamma) + beta and gamma (model.py:2440-2446)
     const void* z; const float* mean; const float* rstd; void* gamma_out;
     int ldz, ldg, C;
+    int wide;                                         // 16-byte output stores: Cout (C) % 8 == 0, output views 16-byte aligned with ld % 8 == 0
 };
 
 // ABL (timing-only, -DBCONV3_ABLATIONS): 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 operand reads at one address, 16 no output stores
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
                 }
                 __bf16* mixp = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout;
                 __bf16* gamp = reinterpret_cast<__bf16*>(p.gamma_out) + pix * p.ldg;
+                bp_u32x2 pko[4], pkg[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = c0 + 8 * q + 4 * half;
@@ -236,7 +248,16 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
                         og[k] = (__bf16)g[k];
                         o[k] = (__bf16)(((float)zq[q][k] - m_[k]) * r_[k] * (1.f + gr) + br);
                     }
-                    if (pos_ok && ch < p.C) { *reinterpret_cast<bp_bf16x4*>(mixp + ch) = o; *reinterpret_cast<bp_bf16x4*>(gamp + ch) = og; }
+                    if (p.wide) { pko[q] = __builtin_bit_cast(bp_u32x2, o); pkg[q] = __builtin_bit_cast(bp_u32x2, og); }
+                    else if (pos_ok && ch < p.C) { *reinterpret_cast<bp_bf16x4*>(mixp + ch) = o; *reinterpret_cast<bp_bf16x4*>(gamp + ch) = og; }
+                }
+                if (p.wide) {
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        const bp_u32x4 wo = bp_pair8(pko[q], pko[q + 1]), wg = bp_pair8(pkg[q], pkg[q + 1]);
+                        const int ch = c0 + 8 * (q + half);
+                        if (pos_ok && ch < p.C) { *reinterpret_cast<bp_u32x4*>(mixp + ch) = wo; *reinterpret_cast<bp_u32x4*>(gamp + ch) = wg; }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < WC; ++j)
@@ -245,6 +266,33 @@ __global__ __launch_bounds__(512, 1) void bconv3_kernel(const BConv3Params p) {
                 return;
             }
             __bf16* dst = reinterpret_cast<__bf16*>(p.out) + ((long long)(n * p.H + a) * p.W + b) * p.ldout;
+            if (p.wide && !(ABL & 16)) {
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    bp_u32x2 pk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = co0 + 32 * j + 8 * q + 4 * half;
+                        const float4 bb = *reinterpret_cast<const float4*>(Bs + (co < P_BIAS - 3 ? co : 0));
+                        float v[4] = {acc[j][4 * q] + bb.x, acc[j][4 * q + 1] + bb.y, acc[j][4 * q + 2] + bb.z, acc[j][4 * q + 3] + bb.w};
+                        if (p.lrelu) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+                        }
+                        bp_bf16x4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                        pk[q] = __builtin_bit_cast(bp_u32x2, o);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        const bp_u32x4 w8 = bp_pair8(pk[q], pk[q + 1]);
+                        const int co = co0 + 32 * j + 8 * (q + half);          // this lane's eight consecutive couts
+                        if (pos_ok && co < p.Cout) *reinterpret_cast<bp_u32x4*>(dst + co) = w8;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < WC; ++j) {
 #pragma unroll
@@ -293,6 +341,7 @@ int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s) {
     const long long units = (long long)t.N * p.tilesA * p.tilesB * p.coTiles;
     if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     p.units = (int)units; p.nchunks = t.Cin / P_KC; p.lrelu = (t.epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    p.wide = (t.Cout % 8 == 0 && t.ldout % 8 == 0 && ((uintptr_t)t.out & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;      // (debug_nopack = 1: 8-byte stores, as before)
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;
@@ -337,6 +386,7 @@ int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const flo
     const long long units = (long long)N * p.tilesA * p.tilesB * p.coTiles;
     if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     p.units = (int)units; p.nchunks = Ci / P_KC; p.lrelu = 0;
+    p.wide = (C % 8 == 0 && ldmix % 8 == 0 && ldg % 8 == 0 && ((((uintptr_t)mix) | ((uintptr_t)gamma)) & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0; hipDeviceProp_t prop;
