@@ -583,6 +583,9 @@ template <int V_> struct BwIC { static constexpr int value = V_; };
 constexpr unsigned BW_OOB = 0xfffffff0u;
 __device__ __forceinline__ int bw_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
 
+#ifndef BW2_AHEAD
+#define BW2_AHEAD 1
+#endif
 template <int WCI, int WCO>
 __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, const unsigned x_bytes, const unsigned dy_bytes) {
     constexpr int KS = 8 / (WCI * WCO), NSTEP = 8 / KS;
@@ -615,9 +618,10 @@ __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, c
         xa1[s_] = (wci * npix + (nb1 * p.TinH + ty1) * p.TinW + tx1) * 32 + chan;
         ya0[s_] = (wco * TP + m0) * 32 + chan;          // m1 = m0 + 4: + 128 elements
     }
-    int toff[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) toff[t] = t < p.ntaps ? ((p.dh[t] - p.dh_min) * p.TinW + (p.dw[t] - p.dw_min)) * 32 : 0;
+    // the host guarantees the canonical 3x3 tap order (tap t = row t / 3, column t % 3 of the window: mrdis_run_bwgrad): a tap's offset in the x
+    // image is (t / 3) * rowp + (t % 3) * 32 elements -- three row bases per step and lane, the column part is the read's immediate offset
+    // (one address add per tap and operand half, 72 per tile, became 24; and no `t < ntaps` branch around every MFMA)
+    const int rowp = p.TinW * 32;
 
     // staging roles (tile-invariant)
     int x_lds[XR], x_yx[XR]; unsigned x_rel[XR];      // x_yx = (nb << 16) | (iy << 8) | ix, or -1
@@ -716,28 +720,33 @@ __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, c
         // operands one slot ahead of the MFMA that uses them (two register sets; the sched_barriers keep hipcc from sinking the
         // reads back next to their use: left alone it emits read, read, wait, MFMA and every MFMA eats a full LDS round trip)
         union Op { bf16x8 v; s16x4 h[2]; };
-        Op aq[2], bq[2];
+        constexpr int AD = BW2_AHEAD;                 // slots between an A operand's LDS read and the MFMA that uses it
+        Op aq[AD + 1], bq[2];
+        const __bf16* r0 = xb; const __bf16* r1 = xb;   // row bases of the current (step, tap row): set when a tap row starts
         auto read_a = [&](Op& o, int s_, int t) {
-            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xb + xa0[s_] + toff[t]));
-            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xb + xa1[s_] + toff[t]));
+            if (t % 3 == 0) { r0 = xb + xa0[s_] + (t / 3) * rowp; r1 = xb + xa1[s_] + (t / 3) * rowp; }
+            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(r0 + 32 * (t % 3)));
+            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(r1 + 32 * (t % 3)));
         };
         auto read_b = [&](Op& o, int s_) {
             o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yb + ya0[s_]));
             o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yb + ya0[s_] + 128));
         };
-        read_b(bq[0], 0); read_a(aq[0], 0, 0);
+        read_b(bq[0], 0);
+#pragma unroll
+        for (int k = 0; k < AD; ++k) read_a(aq[k], k / 9, k % 9);
 #pragma unroll
         for (int slot = 0; slot < NM; ++slot) {
             const int s_ = slot / 9, t = slot - 9 * s_;
-            if (slot + 1 < NM) {
-                const int s1 = (slot + 1) / 9, t1 = (slot + 1) - 9 * s1;
-                read_a(aq[(slot + 1) & 1], s1, t1);
-                if (t1 == 0) read_b(bq[s1 & 1], s1);
+            if (slot + AD < NM) {
+                const int s1 = (slot + AD) / 9, t1 = (slot + AD) - 9 * s1;
+                read_a(aq[(slot + AD) % (AD + 1)], s1, t1);
             }
+            if (slot + 1 < NM && (slot + 1) % 9 == 0) read_b(bq[((slot + 1) / 9) & 1], (slot + 1) / 9);
             if (slot < NL) load1(BwIC<P>{}, slot);
             if (slot >= NM - NL) store1(BwIC<P ^ 1>{}, dyn, xn, slot - (NM - NL));
             __builtin_amdgcn_sched_barrier(0);
-            if (t < p.ntaps) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[slot & 1].v, bq[s_ & 1].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[slot % (AD + 1)].v, bq[s_ & 1].v, acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -898,7 +907,9 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     if (st_bf16 && Ci % 32 == 0 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {              // pipelined form (bwgrad2_kernel); needs both images twice in LDS
         const long long xb = 2LL * (((long long)N * H * W - 1) * ldx + Ci), yb = 2LL * (((long long)N * H * W - 1) * lddy + Co);
         const size_t lds2 = 2 * (size_t)pl.lds;
-        if (xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds2 <= 150 * 1024 && p.tiles >= 2 * p.splits) {
+        bool canon = p.ntaps == 9;                    // tap t = row t / 3, column t % 3 of the 3x3 window (what the kernel's addressing assumes)
+        for (int t_ = 0; canon && t_ < 9; ++t_) canon = (p.dh[t_] - p.dh_min == t_ / 3) && (p.dw[t_] - p.dw_min == t_ % 3);
+        if (canon && xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds2 <= 150 * 1024 && p.tiles >= 2 * p.splits) {
 #define BW2_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
             static bool attr2 = false; \
             if (!attr2) { if (hipFuncSetAttribute((const void*)bwgrad2_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr2 = true; } \
