@@ -161,7 +161,8 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}
         for k_, fn in fns.items():
-            fn(); fn()
+            for _ in range(30):                  # ~12 ms of warm-up per entry point: from idle the first launches run ~20 % slower (497 vs 407 us on this
+                fn()                             # layer, tools/rs_probe.py) until the chip has ramped its clocks; inside the training step it has
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
@@ -180,7 +181,7 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
     return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
             'pricing': 'fp32: direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) / time / 157.3 TF' if not bf else
                        'bf16: algorithmic bytes (x + dy in bf16) / time / 8 TB/s; direct FLOPs / time / 2500 TF beside it',
-            'timing': f'{iters} launches per entry point after 2 warm-ups, HIP events on the launch stream, shapes of the timed step',
+            'timing': f'{iters} launches per entry point after 30 warm-up launches (clock ramp), HIP events on the launch stream, shapes of the timed step',
             'layers': out}
 
 
@@ -258,9 +259,7 @@ def main():
     if a.recon_y:
         cfg.update(lambda_recon_y=1.0, out_num_ch=4)
     cfg = mrdis.derive_config(cfg, dev)
-    # the step's dominant kernels, timed BEFORE the model exists: measured after the training loop the 256x256 level reads ~20 % slower
-    # (494 vs 415 us forward; the smaller levels agree) than the same launches show inside the step (rocprofv3: profiles/r03*_bench_kernel_stats.md)
-    # or in a fresh process (tools/layer_bench.py) -- an artefact of where 0.8 GB of operands land once 46 GB of the step's blocks are live
+    # the step's dominant kernels at the step's shapes (before the model exists: 1.6 GB of operands of their own)
     rstep = roofline_step(mrdis, dev, B, H, W, a.dtype) if (rank == 0 and not a.no_roofline) else None
     torch.cuda.empty_cache()
     torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21; same init on every rank
