@@ -152,6 +152,18 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         wb_f = hip.cast_bf16(wk) if bf else None
         wb_b = hip.cast_bf16(wt) if bf else None
         dt = hip.DT_F32_BF16M if bf else hip.DT_F32
+        if not bf:      # as in the step: the filter's Winograd-domain images, built once per step behind the mixing launch (mrdis_wino_u_jobs)
+            jobs, imgs, blocks = [], [], 0
+            for src, R, S, flip in ((wt, ci, co, 0), (wk, co, ci, 1)):
+                if S <= 32:
+                    imgs.append(None); continue
+                img = torch.zeros(hip.wino_u_image_floats(R, S), device=dev)
+                j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = src.data_ptr(), img.data_ptr(), R, S, flip, 0
+                j.block0, j.nblk = blocks, hip.wino_u_job_blocks(R, S); blocks += j.nblk
+                jobs.append(j); imgs.append(img)
+            if jobs:
+                hip.wino_u_jobs(hip.wino_u_table(jobs, dev), len(jobs), blocks)
+            wb_f, wb_b = imgs
         yo = hip.empty_nhwc(B, co, h, w, dev, el); dxo = hip.empty_nhwc(B, ci, h, w, dev, el)      # (outputs allocated once: the allocator is not timed)
         fns = {'fwd': lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb_f, out=yo),
                'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b, out=dxo),
