@@ -399,12 +399,15 @@ struct BWgradParams {
     int tilesA, tilesB, tilesN, tiles;
     int nCiB, nCoB, splits;
     int dh_min, dw_min;
+    int rsx, isx;                                   // x row / image strides in elements (W * ldx, H * W * ldx; a stride-2 parity class: twice that)
+    int tstride, tbase;                             // slab [split][tstride taps][Ci][Co], this launch's taps start at tbase
 };
+struct BWgradPack { BWgradParams c[4]; };           // the four input-parity classes of a stride-2 layer (blockIdx.y)
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int WCI, int WCO, typename TS, bool HALF = false>      // HALF: Ci = 16, the upper half of the 32-channel image stays zero
-__global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
+template <int WCI, int WCO, typename TS, bool HALF>      // HALF: Ci = 16, the upper half of the 32-channel image stays zero
+__device__ __forceinline__ void bwgrad_body(const BWgradParams& p) {
     constexpr int KS = 8 / (WCI * WCO);            // waves sharing a channel block split the position steps
     constexpr int CIW = 32 * WCI, COW = 32 * WCO;
     constexpr int XQ = CIW / 8, YQ = COW / 8;       // 16-byte pieces per pixel
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
                 const int n = n0 + (x_desc[it] >> 16), h = a0 + p.dh_min + ((x_desc[it] >> 8) & 255), w_ = b0 + p.dw_min + (x_desc[it] & 255);
                 const int cq = ci0 + 8 * ((tid + it * 512) % XQ);
                 if (n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W && (!HALF || cq < p.Ci))
-                    xr[it].load(xin + ((long long)(n * p.H + h) * p.W + w_) * p.ldx + cq);
+                    xr[it].load(xin + (long long)n * p.isx + (long long)h * p.rsx + w_ * p.ldx + cq);
             }
         }
 #pragma unroll
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
         }
         __syncthreads();
         if (ks == 0 && co < p.Co) {
-            float* dst = p.slab + (((long long)split * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+            float* dst = p.slab + (((long long)split * p.tstride + p.tbase + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = tap_acc(t, r);
@@ -570,6 +573,17 @@ __global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) {
         }
     }
 }
+
+template <int WCI, int WCO, typename TS, bool HALF = false>
+__global__ __launch_bounds__(512) void bwgrad_kernel(const BWgradParams p) { bwgrad_body<WCI, WCO, TS, HALF>(p); }
+
+// stride-2 layers (4x4 / 3x3, pad 1: the encoders) on bf16 activations.  Input row 2a + r - pad of tap row r lies in the parity class
+// (r - pad) & 1 of the input rows, at row a + ((r - pad) >> 1) of that class: within one class (rows AND columns) the layer is a
+// stride-1 "same" correlation of the class view x[:, p::2, q::2] (pixel stride 2 ldx, row stride 2 W ldx) with dy over a 1x1 .. 2x2 window,
+// i.e. what bwgrad_body computes.  ONE launch, blockIdx.y = class; the classes share the tile shape, the split count and the slab
+// [split][all kh * kw taps, class-major][Ci][Co]; the reduction launch puts tap k of the slab at its place `map[k]` of dw.
+template <int WCI, int WCO, bool HALF>
+__global__ __launch_bounds__(512) void bwgrad_pack_kernel(const BWgradPack pk) { bwgrad_body<WCI, WCO, __bf16, HALF>(pk.c[blockIdx.y]); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // bwgrad2_kernel: bwgrad_kernel for bf16 activations with the pipeline of bconv3_kernel / wino_wgrad2_kernel.  bwgrad_kernel stages a
@@ -803,8 +817,10 @@ __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, c
 // out[i] = sum over s of slab[s][i]; the bias row likewise.  A block owns 64 consecutive outputs; its sixteen waves take the slabs
 // s = w, w + 16, ... (each wave reads 256 contiguous bytes per slab) and meet in LDS: fixed order, bit-reproducible.  (One thread
 // per output walking all S slabs serially was latency-bound: 60 us for the 18,432 outputs x 256 slabs of sp6.gamma+beta.)
+struct BWTapMap { int cico; int t[16]; };            // cico > 0: tap k of the slab is tap t[k] of the output (stride-2 classes); 0: identity
 __global__ __launch_bounds__(1024) void bwgrad_reduce_kernel(const float* __restrict__ slab, int S, long long n, float* __restrict__ out,
-                                                             const float* __restrict__ bias_slab, int SB, int Co, float* __restrict__ dbias, int accumulate_bias) {
+                                                             const float* __restrict__ bias_slab, int SB, int Co, float* __restrict__ dbias, int accumulate_bias,
+                                                             const BWTapMap map) {
     __shared__ float red[16][64];
     const int o = threadIdx.x & 63, w = threadIdx.x >> 6;          // 16 waves: wave w takes the slabs w, w + 16, ... (four loads in flight)
     const long long nblk_w = (n + 63) / 64;
@@ -829,11 +845,108 @@ __global__ __launch_bounds__(1024) void bwgrad_reduce_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][o];
         if (is_bias) dbias[i] = accumulate_bias ? dbias[i] + t : t;
+        else if (map.cico > 0) { const int k = (int)(i / map.cico); out[(long long)map.t[k] * map.cico + (i - (long long)k * map.cico)] = t; }
         else out[i] = t;
     }
 }
 
 struct BWgradPlan { BWgradParams p; int wci, wco, KS; size_t lds; long long slab_floats, bias_floats; };
+struct BWgradPlanS2 { BWgradPack pk; BWTapMap map; int wci, wco, grid; size_t lds; long long slab_floats, bias_floats; };
+
+// stride 2, pad 1, 3x3 / 4x4, even H and W, bf16 views: the four parity classes (comment at bwgrad_pack_kernel)
+static int plan_bwgrad_s2(BWgradPlanS2& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    if (stride != 2 || pad != 1 || kh != kw || (kh != 3 && kh != 4) || (H & 1) || (W & 1)) return MRDIS_EUNSUPPORTED;
+    if ((Ci % 32 != 0 && Ci != 16) || Co % 8 != 0 || Co < 16) return MRDIS_EUNSUPPORTED;
+    const int Hc = H / 2, Wc = W / 2;                               // class view = output map size
+    if ((H + 2 * pad - kh) / 2 + 1 != Hc || (W + 2 * pad - kw) / 2 + 1 != Wc) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * Hc * Wc < 2048) return MRDIS_EUNSUPPORTED;                                  // tiny maps: the fp32 kernels' slabs are cheaper
+    int tw = 32; while (tw > 1 && tw / 2 >= Wc) tw >>= 1;
+    int th = 128 / tw; while (th > 1 && th / 2 >= Hc) th >>= 1;
+    const int nb = 128 / (tw * th);
+    if (nb > 255) return MRDIS_EUNSUPPORTED;
+    pl.wci = (Ci % 64 == 0) ? 2 : 1;
+    pl.wco = (Co > 32) ? 2 : 1;
+    const int TT = kh * kw;
+    pl.map = BWTapMap{};
+    pl.map.cico = Ci * Co;
+    pl.lds = 8 * 16 * 64 * 4;                                        // the epilogue's wave-reduction buffer / bias scratch
+    int tbase = 0;
+    long long tiles = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pr = cls >> 1, pq = cls & 1;
+        BWgradParams& p = pl.pk.c[cls];
+        p = BWgradParams{};
+        p.N = N; p.H = Hc; p.W = Wc; p.Ci = Ci; p.Co = Co;
+        int dh_min = 9, dh_max = -9, dw_min = 9, dw_max = -9;
+        for (int r = 0; r < kh; ++r) for (int s_ = 0; s_ < kw; ++s_) {
+            if (((r - pad) & 1) != pr || ((s_ - pad) & 1) != pq) continue;
+            const int dh = (r - pad) >> 1, dw = (s_ - pad) >> 1;           // arithmetic shift: floor
+            p.dh[p.ntaps] = dh; p.dw[p.ntaps] = dw; pl.map.t[tbase + p.ntaps] = r * kw + s_; ++p.ntaps;
+            dh_min = dh < dh_min ? dh : dh_min; dh_max = dh > dh_max ? dh : dh_max;
+            dw_min = dw < dw_min ? dw : dw_min; dw_max = dw > dw_max ? dw : dw_max;
+        }
+        if (p.ntaps < 1) return MRDIS_EUNSUPPORTED;
+        p.dh_min = dh_min; p.dw_min = dw_min;
+        p.TW = tw; p.TH = th; p.NB = nb;
+        p.lgTW = 0; while ((1 << p.lgTW) < tw) ++p.lgTW;
+        p.lgTH = 0; while ((1 << p.lgTH) < th) ++p.lgTH;
+        p.TinH = th + dh_max - dh_min; p.TinW = tw + dw_max - dw_min;
+        p.tilesA = mrdis_cdiv(Hc, th); p.tilesB = mrdis_cdiv(Wc, tw); p.tilesN = mrdis_cdiv(N, nb);
+        tiles = (long long)p.tilesA * p.tilesB * p.tilesN;
+        if (tiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+        p.tiles = (int)tiles;
+        p.nCiB = mrdis_cdiv(Ci, 32 * pl.wci); p.nCoB = mrdis_cdiv(Co, 32 * pl.wco);
+        const long long npix = (long long)nb * p.TinH * p.TinW;
+        if (npix * (4 * pl.wci) > (long long)(pl.wci == 2 ? 4 : 2) * 512) return MRDIS_EUNSUPPORTED;
+        const size_t lds = 2 * 32 * ((size_t)pl.wco * 128 + (size_t)pl.wci * npix);
+        if (lds > pl.lds) pl.lds = lds;
+        p.tstride = TT; p.tbase = tbase;
+        tbase += p.ntaps;
+    }
+    if (tbase != TT) return MRDIS_EUNSUPPORTED;
+    // the four classes together fill the chip: a quarter of the workgroups each
+    long long splits = mrdis_cdiv(bconv_ncu(), 4LL * pl.pk.c[0].nCiB * pl.pk.c[0].nCoB);
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    for (int cls = 0; cls < 4; ++cls) pl.pk.c[cls].splits = (int)splits;
+    pl.grid = (int)splits * pl.pk.c[0].nCiB * pl.pk.c[0].nCoB;
+    pl.slab_floats = splits * TT * Ci * Co;
+    pl.bias_floats = splits * Co;
+    return MRDIS_OK;
+}
+
+static int run_bwgrad_s2(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                         int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s) {
+    BWgradPlanS2 pl;
+    int rc = plan_bwgrad_s2(pl, N, H, W, Ci, Co, kh, kw, stride, pad);
+    if (rc) return rc;
+    if (ldx % 8 != 0 || lddy % 8 != 0 || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)H * W * ldx > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256) return MRDIS_EWORKSPACE;
+    float* slab = reinterpret_cast<float*>(workspace);
+    for (int cls = 0; cls < 4; ++cls) {
+        BWgradParams& p = pl.pk.c[cls];
+        p.x = reinterpret_cast<const __bf16*>(x) + ((long long)(cls >> 1) * W + (cls & 1)) * ldx;       // x[:, p::2, q::2]
+        p.dy = dy; p.ldx = 2 * ldx; p.lddy = lddy;
+        p.rsx = 2 * W * ldx; p.isx = H * W * ldx;
+        p.slab = slab;
+        p.bias_slab = (dbias && cls == 0) ? slab + pl.slab_floats : nullptr;       // every class walks all of dy: one of them sums its columns
+    }
+#define BWP_CASE(a, b_, HF) if (pl.wci == a && pl.wco == b_ && (Ci == 16) == HF) { \
+        static bool attr_set = false; \
+        if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_pack_kernel<a, b_, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
+        hipLaunchKernelGGL((bwgrad_pack_kernel<a, b_, HF>), dim3(pl.grid, 4), dim3(512), pl.lds, s, pl.pk); }
+    BWP_CASE(1, 1, true) else BWP_CASE(1, 2, true) else BWP_CASE(1, 1, false) else BWP_CASE(1, 2, false) else BWP_CASE(2, 1, false) else BWP_CASE(2, 2, false)
+    else return MRDIS_EUNSUPPORTED;
+#undef BWP_CASE
+    MRDIS_CHECK_LAUNCH();
+    const long long n = (long long)kh * kw * Ci * Co;
+    const int splits = pl.pk.c[0].splits;
+    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, slab, splits, n, dw_tck,
+                       slab + pl.slab_floats, splits, Co, dbias, accumulate_bias, pl.map);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
 
 static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dtype = MRDIS_DT_F32_BF16M) {
     if (stride != 1 || kh * kw > 9 || kh != kw || 2 * pad != kh - 1) return MRDIS_EUNSUPPORTED;    // "same" convolutions only (Ho = H)
@@ -876,10 +989,16 @@ static int plan_bwgrad(BWgradPlan& pl, int N, int H, int W, int Ci, int Co, int 
     p.splits = (int)splits;
     pl.slab_floats = (long long)p.splits * p.ntaps * Ci * Co;
     pl.bias_floats = (long long)p.splits * Co;
+    p.tstride = p.ntaps; p.tbase = 0;
     return MRDIS_OK;
 }
 
 size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad) {
+    if (stride == 2) {
+        BWgradPlanS2 p2;
+        if (plan_bwgrad_s2(p2, N, H, W, Ci, Co, kh, kw, stride, pad)) return 0;
+        return sizeof(float) * (size_t)(p2.slab_floats + p2.bias_floats) + 256;
+    }
     BWgradPlan pl;
     if (plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad, MRDIS_DT_BF16)) return 0;          // the widest domain
     return sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256;
@@ -888,6 +1007,10 @@ size_t mrdis_bwgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int k
 int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                      int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, hipStream_t s) {
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
+    if (stride == 2) {
+        if (!st_bf16 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;      // fp32 views: the fp32 parity-class kernels (mrdis_conv.hip)
+        return run_bwgrad_s2(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, accumulate_bias, s);
+    }
     BWgradPlan pl;
     int rc = plan_bwgrad(pl, N, H, W, Ci, Co, kh, kw, stride, pad, dtype);
     if (rc) return rc;
@@ -895,6 +1018,8 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     if (workspace_bytes < sizeof(float) * (size_t)(pl.slab_floats + pl.bias_floats) + 256) return MRDIS_EWORKSPACE;
     BWgradParams& p = pl.p;
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
+    if ((long long)H * W * ldx > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.rsx = W * ldx; p.isx = H * W * ldx;
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
     const int grid = p.splits * p.nCiB * p.nCoB;
@@ -927,7 +1052,7 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)p.ntaps * Ci * Co;
     hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, p.slab, p.splits, n, dw_tck,
-                       p.bias_slab, p.splits, Co, dbias, accumulate_bias);
+                       p.bias_slab, p.splits, Co, dbias, accumulate_bias, BWTapMap{});
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -6,6 +6,7 @@ enqueues the hand-written gfx950 kernels on torch's current stream.  There is
 NO fallback: if the shared library is missing, importing the product path on
 a GPU box fails loudly (`MrdisLibraryError`).
 """
+import collections
 import ctypes
 import os
 
@@ -573,6 +574,9 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
     return dx
 
 
+fallbacks = collections.Counter()      # routes that left the bf16 kernels for fp32 kernels between view casts (tests read it)
+
+
 def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32):
     """-> (dw_tck, dbias).  bias_sink: a (Co,) buffer the bias gradient is ADDED to in the reduce launch
     (then dbias is returned as None).  dtype DT_F32_BF16M: bf16 MFMA operands where the geometry allows."""
@@ -595,7 +599,8 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
     if _dt(x, dy) == DT_BF16:
         rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
                                          N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, DT_BF16, _stream())
-        if rc == -2:      # stride-2 / narrow layers: the fp32 weight-gradient kernels on fp32 copies of the two views
+        if rc == -2:      # tiny maps / shapes outside the bf16 kernels' domain: the fp32 weight-gradient kernels on fp32 copies of the two views
+            fallbacks['conv2d_bwd_weight_bf16'] += 1
             return conv2d_bwd_weight(cast_view(x, torch.float32), cast_view(dy, torch.float32), kh, kw, stride, pad, need_bias, bias_sink, DT_F32)
         _chk(rc, 'conv2d_bwd_weight')
         return dw, db

@@ -965,6 +965,46 @@ def test_conv_bf16_mfma(mrdis, case):
     close(db, gy.sum((0, 2, 3)), rtol=2e-5, what='dbias (fp32 sum)')
 
 
+@pytest.mark.parametrize('case', [
+    # N, Ci, Co, H, W, k
+    (8, 32, 64, 64, 64, 4),          # the anatomy encoder's shape family (4x4 / stride 2 / pad 1)
+    (6, 64, 40, 52, 76, 4),          # ragged tiles (26 x 38 class maps), cout tail
+    (16, 16, 32, 32, 48, 3),         # Ci = 16: half-filled channel image (modality encoder, 3x3 / stride 2)
+    (8, 96, 128, 36, 60, 3),         # three 32-channel blocks, ragged
+    (64, 128, 24, 16, 16, 4),        # many-image tiles (8 x 8 class maps)
+], ids=lambda c: 'N%d_%dto%d_%dx%d_k%d' % c)
+def test_bf16_stride2_weight_gradient_parity_classes(mrdis, case):
+    """bwgrad_pack_kernel (mrdis_bf16.hip): the weight gradient of the stride-2 encoder layers on bf16 views, as four stride-1 "same"
+    correlations of the input's parity classes in one launch.  bf16 x bf16 products are exact in fp32, so the result equals torch fp32
+    on the same (bf16-valued) operands up to the order of the fp32 sums, and the fp32 parity-class kernels between view casts
+    (option debug_now16 = 1: the route before this kernel) likewise; the bias gradient is added to a sink when asked."""
+    hip = mrdis.hip
+    N, Ci, Co, H, W, k = case
+    B16 = torch.bfloat16
+    x = rnd((N, Ci, H, W), 5).bfloat16(); w0 = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    y = F.conv2d(x.float(), w0, None, 2, 1)
+    gy = rnd(tuple(y.shape), 6).bfloat16()
+    y.backward(gy.float())
+    xd, dyd = cl(x.float()).to(B16), cl(gy.float()).to(B16)
+    n0 = hip.fallbacks['conv2d_bwd_weight_bf16']
+    dw, db = hip.conv2d_bwd_weight(xd, dyd, k, k, 2, 1, need_bias=True)
+    assert hip.fallbacks['conv2d_bwd_weight_bf16'] == n0, 'the shape must be inside the bf16 kernel\'s domain'
+    close(dw, to_tck(w0.grad), rtol=2e-5, what='stride-2 bf16 wgrad vs torch')
+    close(db, gy.float().sum((0, 2, 3)), rtol=2e-5, what='stride-2 bf16 dbias vs torch')
+    with hip.option('debug_now16', 1):
+        dw1, db1 = hip.conv2d_bwd_weight(xd, dyd, k, k, 2, 1, need_bias=True)
+    assert hip.fallbacks['conv2d_bwd_weight_bf16'] == n0 + 1
+    close(dw, dw1, rtol=2e-5, what='parity-class bf16 kernel vs fp32 kernels between casts')
+    close(db, db1, rtol=2e-5, what='dbias, both routes')
+    sink = torch.full((Co,), 2.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(xd, dyd, k, k, 2, 1, need_bias=True, bias_sink=sink)
+    assert none is None and torch.equal(dw2, dw) and torch.equal(sink, db + 2.0)
+    # a channel slice of a wider tensor (pixel stride != channels), as the skip concatenation hands over
+    wide = torch.cat([xd, xd.flip(1)], 1).contiguous(memory_format=torch.channels_last)
+    dw3, _ = hip.conv2d_bwd_weight(wide[:, :Ci], dyd, k, k, 2, 1, need_bias=False)
+    assert torch.equal(dw3, dw)
+
+
 def test_conv_bf16_storage_random_shapes(mrdis):
     """MRDIS_DT_BF16 (bf16 activation views in and out) over a seeded sweep of geometries inside the bf16 kernels' domain
     (channels in multiples of 16, >= 16 outputs): no shape may be refused without a working fallback, and every result must
