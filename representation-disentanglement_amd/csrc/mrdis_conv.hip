@@ -2303,8 +2303,8 @@ static size_t wgrad_need(const WgradPlan& pl) {
 size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
 size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);     // mrdis_wgrad_s2.hip: Cin <= 7 stride-2 first layers
 size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co);              // mrdis_wgrad_s2.hip: the 4 -> C si_layers
-int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
+int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s);
 size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co, int x16_bf16);      // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
 int mrdis_run_pw_wgrad(const void* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        long long npix, int Ci, int Co, int accumulate_bias, int x16_bf16, hipStream_t s);
@@ -2377,7 +2377,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
                                        int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); const float* dy = reinterpret_cast<const float*>(dy_);
     WgradPlan pl;
     int rc = plan_wgrad(pl, N, H, W, ldx, Ci, Co, kh, kw, stride, pad);
@@ -2389,13 +2389,17 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
         if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
         return mrdis_run_pw_wgrad(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
     }
+    if (dtype == MRDIS_DT_XF32_YBF16) {       // the 4 -> C si_layers under bf16 storage: x the fp32 anatomy map, dy bf16
+        if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4)) return MRDIS_EUNSUPPORTED;
+        return mrdis_run_wgrad_c4(x, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
+    }
     if (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) {
         rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,
                               accumulate_bias, dtype, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED || dtype == MRDIS_DT_BF16) return rc;          // bf16 views never reach the fp32 kernels
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4) {
-        rc = mrdis_run_wgrad_c4(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        rc = mrdis_run_wgrad_c4(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co <= 16) {

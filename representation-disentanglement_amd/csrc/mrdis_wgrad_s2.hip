@@ -363,16 +363,16 @@ __global__ __launch_bounds__(256) void conv_s2_fwd_kernel(const ConvS2Params p) 
 // NT = C / 16 cout tiles.  An output row needs input rows oy - 1 .. oy + 1: a four-slot ring in LDS (row iy lives in slot (iy + 1) & 3,
 // memory image [pixel + 1][4 ch], one new row per output row), dy rows [pixel][C + 16]; two register sets in flight.
 struct WgradC4Params {
-    const float* x; const float* dy; float* slab; float* bias_slab;
+    const float* x; const void* dy; float* slab; float* bias_slab;      // dy: fp32, or bf16 (kernel template YB: MRDIS_DT_XF32_YBF16)
     int N, H, W, ldx, Co, lddy;
     int rowp, segs, R, splits;
     unsigned x_bytes, dy_bytes;
 };
 
-template <int NT>
+template <int NT, bool YB>
 __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
     constexpr int MT = 3, DYP = 16 * NT + 16, CO = 16 * NT;
-    constexpr int YI = 8;                             // dy float4 items per thread and row: W * C / 1024 <= 8 (host)
+    constexpr int YI = YB ? 4 : 8;                    // dy 16-byte items per thread and row: W * C / 1024 <= 8 fp32 quads (host), half as many bf16 octets
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                 // [4][rowp]
     float* dys = smem + 4 * p.rowp;                   // [W][DYP]
@@ -411,12 +411,17 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
         const bool xok = tid < W && iy <= oy1 && (unsigned)iy < (unsigned)p.H;
         xr[S] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xok ? 4u * (unsigned)(((n * p.H + iy) * W + tid) * p.ldx) : S2_OOB), 0, 0);
         const bool on = oy >= 0 && oy < oy1;
-        const unsigned ybase = 4u * (unsigned)((n * p.H + oy) * W * p.lddy);
+        const unsigned ybase = (YB ? 2u : 4u) * (unsigned)((n * p.H + oy) * W * p.lddy);
 #pragma unroll
         for (int j = 0; j < YI; ++j) {
-            const int idx = tid + 256 * j;            // valid while < W * 4 NT = 256 WQ NT
-            const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
-            yr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && j < WQ * NT) ? ybase + 4u * (unsigned)(pix * p.lddy + 4 * q) : S2_OOB), 0, 0);
+            const int idx = tid + 256 * j;            // valid while < W * 4 NT = 256 WQ NT (bf16: W * 2 NT octets)
+            if (YB) {
+                const int pix = idx / (2 * NT), q = idx - pix * (2 * NT);
+                yr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && 2 * j < WQ * NT) ? ybase + 2u * (unsigned)(pix * p.lddy + 8 * q) : S2_OOB), 0, 0);
+            } else {
+                const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
+                yr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && j < WQ * NT) ? ybase + 4u * (unsigned)(pix * p.lddy + 4 * q) : S2_OOB), 0, 0);
+            }
         }
     };
     auto store_set = [&](auto S_, int iy, bool with_dy) {
@@ -426,8 +431,17 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
 #pragma unroll
             for (int j = 0; j < YI; ++j) {
                 const int idx = tid + 256 * j;
-                const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
-                if (j < WQ * NT) *reinterpret_cast<u32x4*>(dys + pix * DYP + 4 * q) = yr[S][j];
+                if (YB) {                             // eight bf16 -> eight fp32 (exact): the LDS image and the MFMAs are those of the fp32 form
+                    const int pix = idx / (2 * NT), q = idx - pix * (2 * NT);
+                    if (2 * j < WQ * NT) {
+                        const u32x4 v = yr[S][j];
+                        *reinterpret_cast<u32x4*>(dys + pix * DYP + 8 * q) = u32x4{v.x << 16, v.x & 0xffff0000u, v.y << 16, v.y & 0xffff0000u};
+                        *reinterpret_cast<u32x4*>(dys + pix * DYP + 8 * q + 4) = u32x4{v.z << 16, v.z & 0xffff0000u, v.w << 16, v.w & 0xffff0000u};
+                    }
+                } else {
+                    const int pix = idx / (4 * NT), q = idx - pix * (4 * NT);
+                    if (j < WQ * NT) *reinterpret_cast<u32x4*>(dys + pix * DYP + 4 * q) = yr[S][j];
+                }
             }
         }
     };
@@ -726,12 +740,12 @@ size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co) {
 }
 
 // weight gradient of a 4 -> C 3x3 s1 p1 layer; MRDIS_EUNSUPPORTED outside what the kernel covers
-int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s) {
     WgradC4Params p;
     if (!plan_wgrad_c4(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
-    if (ldx % 4 != 0 || lddy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
-    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + 4), yb = 4LL * (((long long)N * H * W - 1) * lddy + Co);
+    if (ldx % 4 != 0 || lddy % (dy_bf16 ? 8 : 4) != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + 4), yb = (dy_bf16 ? 2LL : 4LL) * (((long long)N * H * W - 1) * lddy + Co);
     if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     if (workspace_bytes + 256 < mrdis_wgrad_c4_workspace(N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy; p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
@@ -744,15 +758,19 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const float* dy, int lddy, float
     if (lds > 72 * 1024) return MRDIS_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {          // > 64 KB of dynamic LDS needs the opt-in (4 -> 32 at W = 256: 65.7 KB)
-        if (hipFuncSetAttribute((const void*)wgrad_c4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wgrad_c4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wgrad_c4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)wgrad_c4_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wgrad_c4_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess)
             return MRDIS_EUNSUPPORTED;
         attr_set = true;
     }
-    if (NT == 2) hipLaunchKernelGGL((wgrad_c4_kernel<2>), dim3(p.splits), dim3(256), lds, s, p);
-    else if (NT == 4) hipLaunchKernelGGL((wgrad_c4_kernel<4>), dim3(p.splits), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((wgrad_c4_kernel<8>), dim3(p.splits), dim3(256), lds, s, p);
+#define WC4_LAUNCH(nt) { if (dy_bf16) hipLaunchKernelGGL((wgrad_c4_kernel<nt, true>), dim3(p.splits), dim3(256), lds, s, p); \
+                         else hipLaunchKernelGGL((wgrad_c4_kernel<nt, false>), dim3(p.splits), dim3(256), lds, s, p); }
+    if (NT == 2) WC4_LAUNCH(2) else if (NT == 4) WC4_LAUNCH(4) else WC4_LAUNCH(8)
+#undef WC4_LAUNCH
     MRDIS_CHECK_LAUNCH();
     return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
 }

@@ -577,9 +577,11 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
 fallbacks = collections.Counter()      # routes that left the bf16 kernels for fp32 kernels between view casts (tests read it)
 
 
-def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32):
+def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32, may_decline=False):
     """-> (dw_tck, dbias).  bias_sink: a (Co,) buffer the bias gradient is ADDED to in the reduce launch
-    (then dbias is returned as None).  dtype DT_F32_BF16M: bf16 MFMA operands where the geometry allows."""
+    (then dbias is returned as None).  dtype DT_F32_BF16M: bf16 MFMA operands where the geometry allows.
+    may_decline: mixed-storage views (x fp32 / dy bf16: the si_layers; x bf16 / dy fp32: the 1x1 head) only have their dedicated
+    kernels -- return None instead of raising when the geometry is outside them (the caller then casts a view)."""
     lib = load()
     x, ldx = nhwc(x)
     dy, lddy = nhwc(dy)
@@ -592,9 +594,12 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
         raise MrdisError('conv2d_bwd_weight: unsupported geometry')
     ws = _ws(nb, x.device)
     sink = bias_sink if (need_bias and bias_sink is not None) else None
-    if x.dtype is not dy.dtype:      # the 1x1 head under bf16 storage: x bf16, dy fp32 (MRDIS_DT_XBF16_YF32)
-        _chk(lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
-                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _dt_xy(x, dy), _stream()), 'conv2d_bwd_weight (mixed storage)')
+    if x.dtype is not dy.dtype:      # bf16 storage: the 1x1 head (x bf16, dy fp32: MRDIS_DT_XBF16_YF32), the si_layers (x fp32, dy bf16: MRDIS_DT_XF32_YBF16)
+        rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
+                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _dt_xy(x, dy), _stream())
+        if rc == -2 and may_decline:
+            return None
+        _chk(rc, 'conv2d_bwd_weight (mixed storage)')
         return dw, db
     if _dt(x, dy) == DT_BF16:
         rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,

@@ -614,7 +614,7 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
         return conv2d_grouped(cast_view(x, torch.bfloat16), [(w_tck, w_tkc)], bias, kh, kw, pad, lrelu)      # bf16 in, fp32 out
     if (kh, kw, stride, pad) == (3, 3, 1, 1) and Ci in (4, 16) and Co >= 16 and x.shape[1] == 4 and x.dtype == torch.float32 and not lrelu and type(x) is torch.Tensor:
         # the 4 -> C si_layers (filter as it is, or in the 16-row layout of the mixing launch): the route of the grouped decoders
-        # (forward on the Cin = 4 kernel: fp32 map in, bf16 out; backward on the zero-padded bf16 MFMA kernels)
+        # (forward and weight gradient on the Cin = 4 kernels: fp32 map, bf16 output / output gradient; data gradient on the zero-padded bf16 MFMA kernel)
         return conv2d_grouped(x, [(w_tck, w_tkc)], bias, kh, kw, pad, co=co)
     if hip.bconv_eligible(Ci, Co):
         # (a filter that the all-layers mixing launch wrote zero-padded to 16 channels -- MixPlan.padded -- meets a narrower input / bias /
@@ -710,12 +710,13 @@ class _GroupedConvFn(Function):
         Ci_p, Co_p = (max(Cif, 16), max(Cof, 16)) if (st and not head) else (Cif, Cof)
         padded = (Ci_p, Co_p) != (Cif, Cof)                     # the filters still need padding here
         # the 3x3 4 -> C si_layers with the filter in the 16-row layout of the mixing launch: the Cin = 4 kernel reads the fp32 anatomy
-        # map and writes bf16 (MRDIS_DT_XF32_YBF16) -- the zero-padded bf16 copy of x is only made for the weight gradient
+        # map and writes bf16, the weight gradient's reads the fp32 map and the bf16 gradient (MRDIS_DT_XF32_YBF16); maps narrower than 64 make the zero-padded bf16 copy
         si4 = st and x.dtype == torch.float32 and Ci == 4 and Ci_p == 16 and (kh, kw, pad) == (3, 3, 1) and Co_p == Cof and not lrelu
         xin = x
         if st and (x.dtype != torch.bfloat16 or Ci_p != Ci):
-            xin = hip.cast_view(x, torch.bfloat16, Ci_p)           # fp32 -> bf16 view cast, zero channels up to 16
-        y = hip.empty_nhwc(G * B, Co_p, Ho, Wo, x.device, torch.float32 if head else xin.dtype)
+            # fp32 -> bf16 view cast, zero channels up to 16; the si_layers make it only when a kernel asks for it
+            xin = None if (si4 and stride == 1) else hip.cast_view(x, torch.bfloat16, Ci_p)
+        y = hip.empty_nhwc(G * B, Co_p, Ho, Wo, x.device, torch.float32 if head else (torch.bfloat16 if st else x.dtype))
         use_tkc, wbs = [], []
         for g in range(G):
             tck, tkc = filt[2 * g], filt[2 * g + 1]
@@ -737,6 +738,8 @@ class _GroupedConvFn(Function):
             use_tkc.append(tkc); wbs.append(wb_b)
             if si4 and stride == 1 and hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, out=y[g * B:(g + 1) * B], may_decline=True) is not None:
                 continue
+            if xin is None:
+                xin = hip.cast_view(x, torch.bfloat16, Ci_p)
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, stride, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
         ctx.stride = stride
@@ -744,6 +747,9 @@ class _GroupedConvFn(Function):
         ctx.dx_in_gb = bool(getattr(x, '_mrdis_want_dgb', False)) and _GB_INPLACE
         ctx.wbs = wbs
         ctx.bias_param = bias
+        ctx.x32 = x if (si4 and stride == 1) else None          # the weight gradient's Cin = 4 kernel reads the fp32 map (MRDIS_DT_XF32_YBF16)
+        ctx.xshape = (x.shape[2], x.shape[3])
+        ctx.ydtype = y.dtype
         ctx.save_for_backward(xin, y if lrelu else None, *use_tkc)
         return y if Co_p == Co else hip.cast_view(y, torch.float32, Co)       # a padded head leaves as fp32 (the losses read it)
 
@@ -757,30 +763,43 @@ class _GroupedConvFn(Function):
             dy = hip.cast_view(dy, torch.float32)                 # fp32 reconstruction gradient in, bf16 trunk gradient out
         elif Co_p != Co:
             dy = hip.cast_view(dy, torch.bfloat16, Co_p)
-        elif dy.dtype != xin.dtype:
-            dy = hip.cast_view(dy, xin.dtype)
+        elif dy.dtype != ctx.ydtype:
+            dy = hip.cast_view(dy, ctx.ydtype)
         if lrelu:
             dy = hip.lrelu_bwd(dy, y, 0.2)
-        H, W = xin.shape[2], xin.shape[3]
+        H, W = ctx.xshape
+        x32 = ctx.x32
+        xdt = torch.bfloat16 if _COMPUTE_DTYPE == hip.DT_BF16 else x_dtype          # the (padded) input view's storage type
+        if xin is not None:
+            xdt = xin.dtype
         need_x = ctx.needs_input_grad[0]
         dxb = None
         if need_x:
-            if ctx.dx_in_gb and not share_x and Ci_p == Ci and xin.dtype == x_dtype:
+            if ctx.dx_in_gb and not share_x and Ci_p == Ci and xin is not None and xin.dtype == x_dtype:
                 # the input is the modulated map of a fused SPADE node (ops._GbSpadeFn): its gradient is also the beta half of that node's
                 # [dgamma | dbeta] buffer -- write it there, the node then fills in the other half (hip.gb_slot)
                 dxb = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, xin.dtype)[:, Ci:]
             else:
-                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, xin.device, xin.dtype)
+                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, dy.device, xdt)
         sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None
         dws, db_total = [], None
         for g in range(G):
             dyg = dy[g * B:(g + 1) * B]
-            xg = xin if share_x else xin[g * B:(g + 1) * B]
             if need_x:
                 hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
-            dw, db = hip.conv2d_bwd_weight(xg, dyg, kh, kw, ctx.stride, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
-            if padded:
-                dw = dw[:, :Cif, :Cof].contiguous()
+            res = None
+            if x32 is not None:          # si_layers: fp32 map x bf16 gradient on the Cin = 4 kernel -- (9, 4, C), no padded copy of the map
+                res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, may_decline=True)
+                if res is not None and Cif > Ci:
+                    res = (torch.nn.functional.pad(res[0], (0, 0, 0, Cif - Ci)), res[1])      # rows of the 16-row mixing layout beyond the map's channels: zero
+            if res is None:
+                if xin is None:
+                    xin = hip.cast_view(x32, torch.bfloat16, Ci_p)
+                xg = xin if share_x else xin[g * B:(g + 1) * B]
+                res = hip.conv2d_bwd_weight(xg, dyg, kh, kw, ctx.stride, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
+                if padded:
+                    res = (res[0][:, :Cif, :Cof].contiguous(), res[1])
+            dw, db = res
             dws += [dw, None]
             if db is not None:
                 db_total = db if db_total is None else db_total + db

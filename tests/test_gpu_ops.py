@@ -1005,6 +1005,29 @@ def test_bf16_stride2_weight_gradient_parity_classes(mrdis, case):
     assert torch.equal(dw3, dw)
 
 
+@pytest.mark.parametrize('case', [(2, 32, 256, 256), (9, 64, 128, 128), (32, 128, 64, 64), (3, 32, 250, 256)], ids=lambda c: 'N%d_4to%d_%dx%d' % c)
+def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
+    """MRDIS_DT_XF32_YBF16 weight gradient (wgrad_c4_kernel<NT, true>): the SPADE si_layers under bf16 storage multiply the fp32 anatomy
+    map with the bf16 gradient of their output.  The kernel widens dy to fp32 on its way into LDS (exact) and then IS the fp32 kernel:
+    bit-identical to the fp32 call on dy.float(), with and without a bias sink; shapes outside the kernel decline (may_decline)."""
+    hip = mrdis.hip
+    N, Co, H, W = case
+    x = cl(rnd((N, 4, H, W), 3))
+    dy = cl(rnd((N, Co, H, W), 4)).to(torch.bfloat16)
+    got = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True)
+    assert got is not None
+    want = hip.conv2d_bwd_weight(x, dy.float(), 3, 3, 1, 1, need_bias=True)
+    assert got[0].shape == (9, 4, Co) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    w0 = torch.zeros(Co, 4, 3, 3, requires_grad=True)
+    F.conv2d(x.cpu().contiguous(), w0, None, 1, 1).backward(dy.float().cpu().contiguous())
+    close(got[0], to_tck(w0.grad), rtol=2e-5, what='si wgrad vs torch')
+    sink = torch.full((Co,), -1.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, bias_sink=sink, may_decline=True)
+    assert none is None and torch.equal(dw2, got[0]) and torch.equal(sink, got[1] - 1.0)
+    assert hip.conv2d_bwd_weight(x[:, :, :, :40].contiguous(memory_format=torch.channels_last), dy[:, :, :, :40].contiguous(memory_format=torch.channels_last),
+                                 3, 3, 1, 1, may_decline=True) is None
+
+
 def test_conv_bf16_storage_random_shapes(mrdis):
     """MRDIS_DT_BF16 (bf16 activation views in and out) over a seeded sweep of geometries inside the bf16 kernels' domain
     (channels in multiples of 16, >= 16 outputs): no shape may be refused without a working fallback, and every result must
