@@ -296,8 +296,8 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
         dys = torch.zeros_like(dyd); dys[S] = dyd[S]
         _, _, dw_s, db_s = _run_bf16_layer(m, xd, w, b, dys, k, s, p, Co)
         wg_ref = ws.grad
-        if Ci == 4 and path == 'bf16' and W >= 64:
-            # ... and so does their weight gradient on the 256 / 128 / 64-wide maps (wgrad_c4_kernel: fp32 map x bf16 output gradient)
+        if Ci == 4 and path == 'bf16':
+            # ... and so does their weight gradient (wgrad_c4_kernel: fp32 map x bf16 output gradient; maps narrower than 64: the fp32 kernel on dy.float())
             w4 = w.clone().requires_grad_(True)
             F.conv2d(xd[S].float().cpu().contiguous(), w4, b, s, p).backward(dy_s)
             wg_ref = w4.grad

@@ -110,9 +110,11 @@ def main():
                 def f_fwd():
                     y = hip.conv2d_fwd(hip.cast_view(xs, B16, cip), wtp, bp, k, k, s, p, w_bf16=wbf)
                     return y if cop == co else hip.cast_view(y, torch.float32, co)
-                if ci == 4 and k == 3 and s == 1:        # the Cin = 4 kernel reads the fp32 map and writes bf16 (the zero-padded bf16 copy is still made: the weight gradient reads it)
+                if ci == 4 and k == 3 and s == 1:        # the Cin = 4 kernels read the fp32 map: bf16 out (forward), bf16 dy (weight gradient); maps
+                    c4w = hip.conv2d_bwd_weight(xs, dys, k, k, s, p, may_decline=True) is not None      # narrower than 64 make the zero-padded bf16 copy
                     def f_fwd():                         # noqa: F811
-                        hip.cast_view(xs, B16, cip)
+                        if not c4w:
+                            hip.cast_view(xs, B16, cip)
                         return hip.conv2d_fwd(xs, wtp, bp, k, k, s, p, out_dtype=B16)
 
                 def f_dgrad():
@@ -120,6 +122,8 @@ def main():
                     return g if cip == ci else hip.cast_view(g, torch.float32, ci)
 
                 def f_wgrad():
+                    if ci == 4 and k == 3 and s == 1:
+                        return hip.conv2d_bwd_weight(xs, dys, k, k, s, p, may_decline=True) if c4w else hip.conv2d_bwd_weight(xs, hip.cast_view(dys, torch.float32), k, k, s, p)
                     return hip.conv2d_bwd_weight(xin, dyp if cop == co else hip.cast_view(dys, B16, cop), k, k, s, p, dtype=hip.DT_F32_BF16M)
             else:
                 x32 = hip.cast_view(xs, torch.float32)
