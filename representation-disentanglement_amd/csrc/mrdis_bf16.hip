@@ -312,6 +312,20 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BCon
     // 16-channel chunks in LDS) on every wide layer: sp4.gamma+beta 153 -> 123 us, ana.up_3 106 -> 83 us
     if (p.Cout > 32) c = {1, 2, 2};               // 256 positions x 64 couts
     else c = {1, 2, 1};                           // 256 positions x 32 couts
+    // small maps (the 8x8 / 16x16 levels, B = 32: 2,048 / 8,192 positions): the layer is a latency chain per workgroup, not throughput --
+    // fewer than two workgroups per CU with the big tile means idle CUs AND a long chain, so the tile shrinks to 32 couts, then to 128
+    // positions (tools/tiny_probe.py: 128 -> 256 at 8x8 29 -> 16 us forward, 46 -> 22 us data gradient; 256 -> 256 at 16x16 38 -> 27 us)
+    {
+        const long long md = mrdis_opt(MRDIS_OPT_MODE);
+        auto blocks = [&](const Cfg& k) {
+            const long long bm = 32LL * k.wp * (4 / k.waves_c), bn = 32LL * k.wc * k.waves_c;
+            return (((long long)p.N * p.A * p.B + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
+        };
+        if (md != 0 && (long long)p.N * p.A * p.B <= 16384) {      // (64 -> 128 stride 2 onto 32x32 re-stages its big halo tile per cout tile: 44 -> 53 us)
+            if (c.wc == 2 && blocks(c) < 2LL * bconv_ncu()) c.wc = 1;
+            if (c.wp == 2 && blocks(c) < 2LL * bconv_ncu()) c.wp = 1;
+        }
+    }
     int BM = 32 * c.wp * (4 / c.waves_c);          // positions per workgroup
     const int BN = 32 * c.wc * c.waves_c;
     auto geom = [&](int bm) {
