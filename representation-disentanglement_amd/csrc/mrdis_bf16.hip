@@ -548,24 +548,23 @@ __device__ __forceinline__ void bwgrad_body(const BWgradParams& p) {
     const int half = lane >> 5, e = lane & 31;
     const int co = co0 + 32 * wco + e;
     float* red_acc = reinterpret_cast<float*>(smem_raw);            // [8 waves][16][64]
-    auto tap_acc = [&](int t, int r) -> float {
-        float v;
-        switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
-                     case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
-        return v;
-    };
-    for (int t = 0; t < p.ntaps; ++t) {
+    // (the tap loop is unrolled so that acc[t] is a fixed register block: with a run-time t every one of the 16 values went through a nine-way
+    //  branch chain, twice per tap -- 43 us of a 62-127 us launch, on every layer)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t >= p.ntaps) break;
         __syncthreads();
         if (ks > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = tap_acc(t, r);
+            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = acc[t][r];
         }
         __syncthreads();
         if (ks == 0 && co < p.Co) {
             float* dst = p.slab + (((long long)split * p.tstride + p.tbase + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = tap_acc(t, r);
+                float v = acc[t][r];
+#pragma unroll
                 for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (!HALF || ci0 + 32 * wci + row < p.Ci) dst[(long long)row * p.Co] = v;
@@ -789,24 +788,20 @@ __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, c
     const int half = lane >> 5, e = lane & 31;
     const int co = co0 + 32 * wco + e;
     float* red_acc = reinterpret_cast<float*>(smem_raw);            // [8 waves][16][64]
-    auto tap_acc = [&](int t, int r) -> float {
-        float v;
-        switch (t) { case 0: v = acc[0][r]; break; case 1: v = acc[1][r]; break; case 2: v = acc[2][r]; break; case 3: v = acc[3][r]; break;
-                     case 4: v = acc[4][r]; break; case 5: v = acc[5][r]; break; case 6: v = acc[6][r]; break; case 7: v = acc[7][r]; break; default: v = acc[8][r]; }
-        return v;
-    };
-    for (int t = 0; t < p.ntaps; ++t) {
-        __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                      // unrolled: acc[t] is a fixed register block (see bwgrad_body); the host launches this kernel with 9 taps only
+        __syncthreads();                               // (three taps per barrier pair: no faster -- the 37 MB of slab stores per launch are the cost)
         if (ks > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = tap_acc(t, r);
+            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = acc[t][r];
         }
         __syncthreads();
         if (ks == 0 && co < p.Co) {
-            float* dst = p.slab + (((long long)split * p.ntaps + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+            float* dst = p.slab + (((long long)split * 9 + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = tap_acc(t, r);
+                float v = acc[t][r];
+#pragma unroll
                 for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                 dst[(long long)row * p.Co] = v;
