@@ -552,7 +552,7 @@ __device__ __forceinline__ void bwgrad_body(const BWgradParams& p) {
     //  branch chain, twice per tap -- 43 us of a 62-127 us launch, on every layer)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        if (t >= p.ntaps) break;
+        if (t >= p.ntaps) continue;                    // (uniform; not `break`: the loop must unroll completely)
         __syncthreads();
         if (ks > 0) {
 #pragma unroll
