@@ -676,13 +676,14 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
     }
     if (p.dtype == MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
     TileChoice tc = choose_tile(p.N, p.A, p.B);
+    bool small_map = false;
     // small maps with many channels (the 16x16 / 8x8 levels of the encoders: 2048 output positions, K = 16 taps x 256 channels): 128-position
     // tiles give 16 x (Cout / 32) workgroups, a fraction of the chip, each with a long serial K loop.  Half-filled tiles (64 positions of
     // the 128 a workgroup can hold) double the workgroup count; the matrix pipe is far from busy there, the extra MFMA work is free
     if (p.Cout > 16 && (long long)mrdis_cdiv(p.A, tc.TH) * mrdis_cdiv(p.B, tc.TW) * mrdis_cdiv(p.N, tc.NB) * mrdis_cdiv(p.Cout, 32) < 200 &&
         (long long)p.N * p.A * p.B >= 256 && p.Cin >= 64 && p.os == 1 && !mrdis_opt(MRDIS_OPT_NOW16))      // (os == 2: the parity classes of a stride-2
                                                                                                     // data gradient already share one launch)
-        tc = choose_tile(p.N, p.A, p.B, 64);
+        { tc = choose_tile(p.N, p.A, p.B, 64); small_map = true; }
     p.NB = tc.NB; p.TH = tc.TH; p.TW = tc.TW;
     p.TinH = (p.TH - 1) * p.is + (dh_max - p.dh_min) + 1;
     p.TinW = (p.TW - 1) * p.is + (dw_max - p.dw_min) + 1;
@@ -727,11 +728,14 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
     int KC = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : 16);
-    { const int v = (int)mrdis_opt(MRDIS_OPT_KC); if ((v == 4 || v == 8 || v == 16) && v < KC) KC = v; }
     const size_t LDS_MAX = 64 * 1024;
     const long long npix_in = (long long)p.NB * p.TinH * p.TinW;
     auto fits_pf = [&](int kc, int bn) { return npix_in * (kc / 4) <= 6 * 256 && (long long)p.ntaps * kc * (bn / 4) <= 9 * 256; };
     const bool want_pf = p.vec_in && p.vec_w;
+    // small maps: a workgroup's time is its chain of chunks (two barriers + one exposed load round trip each, ~0.4 us per 16 channels
+    // whatever the tile holds) -- 32-channel chunks halve the chain where the staging registers and LDS still fit (3x3 taps, 32 couts)
+    if (small_map && BN == 32 && p.Cin % 32 == 0 && want_pf && fits_pf(32, 32) && tapconv_lds(p, 32, 32) <= LDS_MAX) KC = 32;
+    { const int v = (int)mrdis_opt(MRDIS_OPT_KC); if ((v == 4 || v == 8 || v == 16) && v < KC) KC = v; }
     while ((tapconv_lds(p, KC, BN) > LDS_MAX || (want_pf && !fits_pf(KC, BN))) && KC > 4) KC >>= 1;
     while (tapconv_lds(p, KC, BN) > LDS_MAX && BN > 32) BN >>= 1;
     if (tapconv_lds(p, KC, BN) > LDS_MAX) return MRDIS_EUNSUPPORTED;
@@ -772,6 +776,7 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
     TC_CASE(4, 32); TC_CASE(4, 64);
     TC_CASE(8, 32); TC_CASE(8, 64);
     TC_CASE(16, 32); TC_CASE(16, 64);
+    TC_CASE(32, 32);
 #undef TC_CASE
     return MRDIS_EUNSUPPORTED;
 }
