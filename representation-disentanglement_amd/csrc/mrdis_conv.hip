@@ -36,13 +36,19 @@ __device__ float g_mrdis_zero_page[64];
 
 // (bx, gx): workgroup index and count of THIS launch slice -- blockIdx.x / gridDim.x for a plain launch, the class's own range when the
 // four parity classes of a stride-2 data gradient share one launch (tapconv_pack_kernel)
-template <int KC, int BN, int MODE, int BM>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch; BM positions per workgroup
+// SK = 2 (half-filled 64-position tiles of the small maps, BN = 32): the two position waves that would multiply empty positions take the
+// second half of every chunk's channels instead and the pairs add their accumulators through LDS in a fixed order before the epilogue.  A
+// wave's tile is ONE accumulator, i.e. a chain of K / 2 dependent 64-cycle MFMAs (128 -> 256 at 8x8: 1152 of them = 35 us whatever the
+// staging does); two waves per tile halve the chain.
+template <int KC, int BN, int MODE, int BM, int SK = 1>   // staging: 0 generic loops | 1 hoisted descriptors + register prefetch; BM positions per workgroup
 __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int bx, const int gx) {
     constexpr int S = KC + 1;
     constexpr int WAVES_N = (BN == 32) ? 1 : 2;
     constexpr int WAVES_M = 4 / WAVES_N;
     constexpr int MSUB = (BM / 32) / WAVES_M;
     constexpr int NSUB = (BN / 32) / WAVES_N;
+    constexpr int KCW = KC / SK;                  // channels of a chunk one wave multiplies
+    static_assert(SK == 1 || (SK == 2 && BN == 32 && BM == 128 && MODE == 1 && KC >= 8), "split-K form: 64 positions x 32 couts, two waves per 32 x 32 block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* tab_in = reinterpret_cast<int*>(smem);
     int* tab_out = tab_in + BM;
@@ -52,7 +58,9 @@ __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int b
     float* xs = ws + p.ntaps * KC * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int wave_mr = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int wave_m = (SK == 2) ? (wave_mr & 1) : wave_mr;       // position block of the wave
+    const int khalf = (SK == 2) ? (wave_mr >> 1) : 0;             // which half of a chunk's channels
 
     int bid = mrdis_xcd_remap(bx, gx);
     const int cot = bid % p.coTiles;
@@ -88,8 +96,8 @@ __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int b
 
     int abase[MSUB];
 #pragma unroll
-    for (int i = 0; i < MSUB; ++i) abase[i] = tab_in[(wave_m * MSUB + i) * 32 + (lane & 31)] + (lane >> 5);
-    const int bbase = (lane >> 5) * BN + wave_n * NSUB * 32 + (lane & 31);
+    for (int i = 0; i < MSUB; ++i) abase[i] = tab_in[(wave_m * MSUB + i) * 32 + (lane & 31)] + (lane >> 5) + khalf * KCW;
+    const int bbase = ((lane >> 5) + khalf * KCW) * BN + wave_n * NSUB * 32 + (lane & 31);
 
     f32x16 acc[MSUB][NSUB];
 #pragma unroll
@@ -109,8 +117,8 @@ __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int b
     // fetched a whole tap ahead.
     constexpr int MPS = MSUB * NSUB;                         // MFMAs per k-step
     constexpr int G0 = MPS >= 4 ? 1 : (MPS == 2 ? 2 : 4);
-    constexpr int G = (KC / 2 < G0) ? KC / 2 : G0;           // k-steps per group (>= 256 MFMA cycles when possible)
-    constexpr int NG = (KC / 2) / G;
+    constexpr int G = (KCW / 2 < G0) ? KCW / 2 : G0;         // k-steps per group (>= 256 MFMA cycles when possible)
+    constexpr int NG = (KCW / 2) / G;
     auto compute_chunk = [&]() {
         float an[G][MSUB], bn[G][NSUB];
         int toff = tap_xoff[0];
@@ -300,6 +308,19 @@ __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int b
     // a lane owns ONE output position per M sub-tile (column lane&31) and the couts
     // (r&3) + 8*(r>>2) + 4*(lane>>5) -> groups of four consecutive couts = one 16-byte store.  One address
     // per lane and sub-tile, 4 stores per accumulator instead of 16 (the epilogue is issue-bound).
+    if constexpr (SK == 2) {
+        static_assert(MSUB == 1 && NSUB == 1, "one accumulator per wave");
+        __syncthreads();                              // the operand images are dead: the filter slab's first 8 KB carry the partials
+        float* red = ws;
+        if (khalf == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave_m * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (khalf == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(wave_m * 16 + r) * 64 + lane];
+    }
     const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
     const int half = lane >> 5;
     const bool vec_out = (p.ldout % 4 == 0) && (((uintptr_t)p.out & 15) == 0);
@@ -344,9 +365,9 @@ __device__ __forceinline__ void tapconv_body(const TapConvParams& p, const int b
     }
 }
 
-template <int KC, int BN, int MODE, int BM>
+template <int KC, int BN, int MODE, int BM, int SK = 1>
 __global__ __launch_bounds__(256) void tapconv_kernel(const TapConvParams p) {
-    tapconv_body<KC, BN, MODE, BM>(p, (int)blockIdx.x, (int)gridDim.x);
+    tapconv_body<KC, BN, MODE, BM, SK>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // The four output-parity classes of a stride-2 data gradient (each its own tap set and output grid, disjoint output pixels) in ONE
 // launch: blockIdx.y = class.  On the small maps of the encoders a class alone fills a quarter of the chip (128 workgroups at
@@ -630,7 +651,14 @@ __global__ __launch_bounds__(256) void tapconv16_kernel(const TapConvParams p) {
 
 // ------------------------------------------------------------------ host side
 template <int KC, int BN>
-static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM, hipStream_t s) {
+static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM, hipStream_t s, bool split_k = false) {
+    if constexpr (BN == 32 && KC >= 16) {
+        if (split_k && BM == 128 && p.prefetch == 1) {
+            hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 128, 2>), dim3(nblk), dim3(256), lds, s, p);
+            MRDIS_CHECK_LAUNCH();
+            return MRDIS_OK;
+        }
+    }
     if (BM == 256) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 256>), dim3(nblk), dim3(256), lds, s, p);      // BM 256 only with MODE 1
     else if (p.prefetch == 1) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 128>), dim3(nblk), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((tapconv_kernel<KC, BN, 0, 128>), dim3(nblk), dim3(256), lds, s, p);
@@ -680,6 +708,8 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
     // small maps with many channels (the 16x16 / 8x8 levels of the encoders: 2048 output positions, K = 16 taps x 256 channels): 128-position
     // tiles give 16 x (Cout / 32) workgroups, a fraction of the chip, each with a long serial K loop.  Half-filled tiles (64 positions of
     // the 128 a workgroup can hold) double the workgroup count; the matrix pipe is far from busy there, the extra MFMA work is free
+    // (round 3: the idle half of the waves takes half of each chunk's channels, tapconv_body SK = 2.  Widening the rule to launches of
+    //  256 workgroups -- the 16x16 level -- lost: 128 -> 128 37 -> 57 us, 256 -> 128 66 -> 103 us; those are staging-bound, not chain-bound)
     if (p.Cout > 16 && (long long)mrdis_cdiv(p.A, tc.TH) * mrdis_cdiv(p.B, tc.TW) * mrdis_cdiv(p.N, tc.NB) * mrdis_cdiv(p.Cout, 32) < 200 &&
         (long long)p.N * p.A * p.B >= 256 && p.Cin >= 64 && p.os == 1 && !mrdis_opt(MRDIS_OPT_NOW16))      // (os == 2: the parity classes of a stride-2
                                                                                                     // data gradient already share one launch)
@@ -772,7 +802,10 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
         }
     }
     if (defer) { defer->p = p; defer->KC = KC; defer->BN = BN; defer->BM = BM; defer->nblk = (int)nblk; defer->lds = lds; defer->set = true; return MRDIS_OK; }
-#define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, BM, s)
+    // half-filled small-map tiles: two waves per 32 x 32 block (tapconv_body, SK = 2); the partials need 8 KB of the filter slab
+    const bool split_k = small_map && BN == 32 && KC >= 16 && BM == 128 && p.prefetch == 1 && p.NB * p.TH * p.TW <= 64 &&
+                         (size_t)p.ntaps * KC * BN >= 2048 && !mrdis_opt(MRDIS_OPT_NOW16);
+#define TC_CASE(kc, bn) if (KC == kc && BN == bn) return launch_tapconv_t<kc, bn>(p, lds, (int)nblk, BM, s, split_k)
     TC_CASE(4, 32); TC_CASE(4, 64);
     TC_CASE(8, 32); TC_CASE(8, 64);
     TC_CASE(16, 32); TC_CASE(16, 64);
