@@ -876,8 +876,8 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // bf16 stretch).  A lane owns ONE cout, so a bf16 store of its own would be 2 bytes; adjacent lanes exchange one value per register pair
 // (DPP quad_perm 1,0,3,2) and each stores a packed cout PAIR: even lanes (m, m+1) of position r, odd lanes (m-1, m) of position r + 1 --
 // half the store instructions of the fp32 form, every one of them 4 bytes per lane.
-template <int NS, bool LRELU, bool FULL, bool OBF16 = false>   // FULL: the strips tile the image exactly (no per-store position checks)
-__global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
+template <int NS, bool LRELU, bool FULL, bool OBF16>   // FULL: the strips tile the image exactly (no per-store position checks)
+__device__ __forceinline__ void c4conv_body(const C4Params& p) {
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
     const unsigned ty = m / p.TW, tx = m - ty * p.TW;
     // wave-uniform strip bookkeeping lives in SGPRs (readfirstlane makes the uniformity provable)
@@ -926,7 +926,9 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
     const unsigned pix = 4u * p.ldx, rowbytes = pix * (unsigned)p.W, imgbytes = rowbytes * (unsigned)p.H;
     const unsigned opix = (OBF16 ? 2u : 4u) * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
     const unsigned lane_off = 8u * half;
-    const unsigned st_lane = OBF16 ? 2u * (m & ~1u) + 64u * NS * cot      // the cout pair this lane stores
+    // OBF16: the cout pair this lane stores; odd lanes store the pair of the NEXT position of the strip row (P(r) + 1 for even r never leaves
+    // the row), which is one output pixel further -- a lane constant, so the per-register part stays a wave-uniform scalar operand as in fp32
+    const unsigned st_lane = OBF16 ? 2u * (m & ~1u) + 64u * NS * cot + ((m & 1) ? opix : 0u)
                                    : 4u * m + 128u * NS * cot;             // cout m of this y-slice
     const unsigned uH = p.H, uW = p.W;
     // timing-only builds (-DC4_ABL_NOLOAD / _NOSTORE / _NOMFMA): a zero-record descriptor drops the traffic
@@ -941,8 +943,19 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #else
     const unsigned yrec = oimgbytes;
 #endif
-    auto x_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * (imgbytes / 4)), 0, xrec, 0x00020000); };
-    auto y_desc = [&](int n) { return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + (size_t)n * oimgbytes), 0, yrec, 0x00020000); };
+    // (readfirstlane: the strip bookkeeping is wave-uniform, but in the bf16-output instantiation the allocator moved the image index into a VGPR
+    //  and every buffer instruction became a waterfall loop -- one readfirstlane / compare / branch round per load and store: 88 vs 57 us)
+    auto uni64 = [](unsigned long long a) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    };
+    auto x_desc = [&](int n) {
+        const unsigned long long a = uni64((unsigned long long)(uintptr_t)(p.x + (size_t)n * (imgbytes / 4)));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)a, 0, __builtin_amdgcn_readfirstlane((int)xrec), 0x00020000);
+    };
+    auto y_desc = [&](int n) {
+        const unsigned long long a = uni64((unsigned long long)(uintptr_t)((char*)p.y + (size_t)n * oimgbytes));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)a, 0, __builtin_amdgcn_readfirstlane((int)yrec), 0x00020000);
+    };
     // 9 tap byte offsets of a strip: 3 row bases x 3 column offsets, each either valid or C4_OOB.
     auto strip_offsets = [&](int th, int tw, unsigned (&voff)[9]) {
         const unsigned h = (unsigned)(th * p.TH) + ty, w_ = (unsigned)(tw * p.TW) + tx;
@@ -980,12 +993,12 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
 #pragma unroll
             for (int k = 0; k < 4; k += 2) {
                 const int r0 = 4 * g + k, r1 = r0 + 1;                                  // P(r1) = P(r0) + 1: the next position of the strip row
-                const int P0 = (r0 & 3) + 8 * (r0 >> 2), P1 = P0 + 1;
-                const int pty0 = P0 / p.TW, ptx0 = P0 - pty0 * p.TW, pty1 = P1 / p.TW, ptx1 = P1 - pty1 * p.TW;
-                const unsigned soff = odd ? ((unsigned)pty1 * uW + (unsigned)ptx1) * opix : ((unsigned)pty0 * uW + (unsigned)ptx0) * opix;
+                const int P0 = (r0 & 3) + 8 * (r0 >> 2);
+                const int pty0 = P0 / p.TW, ptx0 = P0 - pty0 * p.TW;                     // wave-uniform
+                const unsigned soff = ((unsigned)pty0 * uW + (unsigned)ptx0) * opix;      // scalar operand (the odd lanes' + 1 pixel is in st_lane)
                 unsigned vo = so;
                 if (!FULL) {
-                    const unsigned h = (unsigned)(th * p.TH + (odd ? pty1 : pty0)), w_ = (unsigned)(tw * p.TW + (odd ? ptx1 : ptx0)) + 4u * half;
+                    const unsigned h = (unsigned)(th * p.TH + pty0), w_ = (unsigned)(tw * p.TW + ptx0) + (odd ? 1u : 0u) + 4u * half;
                     vo = ((int)(h < uH) & (int)(w_ < uW)) ? so : C4_OOB;
                 }
 #pragma unroll
@@ -997,7 +1010,7 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
                     bf16x2_t pk;
                     pk[0] = (__bf16)(odd ? recv : a0);                                 // the lower cout of the pair
                     pk[1] = (__bf16)(odd ? a1 : recv);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs, (int)(((vo == C4_OOB ? C4_OOB : vo + soff) | lane_ok_off[ns]) + 64u * ns), 0, C4_STORE_NT);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pk), rs, (int)((vo | lane_ok_off[ns]) + 64u * ns), (int)soff, C4_STORE_NT);
                 }
             }
             return;
@@ -1094,6 +1107,11 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) {
         for (int g = 0; g < 4; ++g) store_group(accB, rsy, pso, pth, ptw, g);
     }
 }
+template <int NS, bool LRELU, bool FULL, bool OBF16 = false>
+__global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) { c4conv_body<NS, LRELU, FULL, OBF16>(p); }
+// the 32-cout bf16-output form on exact strips (the si_layers' forward at 256x256): left alone the allocator takes 95 + 48 registers,
+// one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to four waves.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
 
 static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int obytes = 4) {
     if (!(Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16)) return false;
@@ -1137,9 +1155,9 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
 #define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
-    if (obf16) {       // (the data gradient never takes this form: flip = 0, no LeakyReLU in front of a SPADE block's si_layers either, but keep the switch)
+    if (obf16) {       // the si_layers' forward (flip = 0) and the C <- 4 data gradient (flip = 1: run time); no LeakyReLU follows either
         if (NS == 2) { if (fast) hipLaunchKernelGGL((c4conv_kernel<2, false, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<2, false, false, true>), grid, dim3(256), 0, s, p); }
-        else { if (fast) hipLaunchKernelGGL((c4conv_kernel<1, false, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }
+        else { if (fast) hipLaunchKernelGGL(c4conv_obf16_kernel, grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }
     } else
     if (NS == 2) {
         if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
@@ -1291,7 +1309,14 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!dy || !w_tkc || !dx || lddy < Co || lddx < Ci) return MRDIS_EINVAL;
-    if (dtype == MRDIS_DT_XBF16_YF32) {       // the 1x1 head under bf16 storage: dy fp32 (<= 8 channels) -> dx bf16 (16 channels)
+    if (dtype == MRDIS_DT_XBF16_YF32) {       // bf16 storage, dy fp32 -> dx bf16: the 1x1 head (<= 8 -> 16 channels) and the C <- 4 layer (ana_dec.output)
+        if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 4) {
+            // dx of a Ci -> 4 layer: a 4 -> Ci convolution of the fp32 dy with the taps reversed, bf16 out; w_tkc is [9][16][Ci] (rows >= 4 zero: the
+            // 16-row layout the padded bf16 kernels use for the same layer)
+            if (!c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad, 2) || Ci % 2 != 0 || lddx % 2 != 0 || (((uintptr_t)dx_) & 3) != 0 ||
+                mrdis_opt(MRDIS_OPT_NOC4)) return MRDIS_EUNSUPPORTED;
+            return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1, 16, true);
+        }
         if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
         return mrdis_run_pw_dgrad(dy, lddy, w_tkc, dx_, lddx, (long long)N * H * W, Ci, Co, 1, (hipStream_t)stream);
     }

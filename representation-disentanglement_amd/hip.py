@@ -537,22 +537,27 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     return out
 
 
-def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None, w_wino=None):
-    """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co).  out: a dense NHWC (N, Ci, H, W) view to write into."""
+def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None, w_wino=None, may_decline=False):
+    """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co).  out: a dense NHWC (N, Ci, H, W) view to write into.
+    Mixed storage (fp32 dy, bf16 out: the 1x1 head; the 3x3 C <- 4 layer with the filter in its 16-row layout [9][16][Ci]) has only
+    its dedicated kernels: may_decline returns None instead of raising outside them."""
     lib = load()
     dy, lddy = nhwc(dy)
     N, Co, Ho, Wo = dy.shape
     T, Co2, Ci = w_tkc.shape
     H, W = in_hw
-    assert Co2 == Co and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
+    mixed = out is not None and out.dtype != dy.dtype
+    assert (Co2 == Co or (mixed and Co2 == 16 and Co == 4 and kh == 3)) and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
     if out is None:
         dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype); ldo = Ci
     else:
         dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
         assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W)
-        if out.dtype != dy.dtype:    # the 1x1 head under bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32)
-            _chk(lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, _stream()),
-                 'conv2d_bwd_data (mixed storage)')
+        if mixed:                    # bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32)
+            rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, _stream())
+            if rc == -2 and may_decline:
+                return None
+            _chk(rc, 'conv2d_bwd_data (mixed storage)')
             return dx
     if w_bf16 is not None and w_bf16.dtype is torch.float32:
         w_wino, w_bf16 = w_bf16, None

@@ -616,6 +616,10 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
         # the 4 -> C si_layers (filter as it is, or in the 16-row layout of the mixing launch): the route of the grouped decoders
         # (forward and weight gradient on the Cin = 4 kernels: fp32 map, bf16 output / output gradient; data gradient on the zero-padded bf16 MFMA kernel)
         return conv2d_grouped(x, [(w_tck, w_tkc)], bias, kh, kw, pad, co=co)
+    if (kh, kw, stride, pad) == (3, 3, 1, 1) and (co or Co) == 4 and Ci % 16 == 0 and x.shape[1] == Ci and not lrelu and type(x) is torch.Tensor:
+        # the C -> 4 layer (ana_dec.output; filter as it is or in the 16-column layout of the mixing launch): the grouped node pads it like the
+        # branches below and sends the data gradient through the Cin = 4 kernel (fp32 dy, reversed taps, bf16 out: MRDIS_DT_XBF16_YF32)
+        return conv2d_grouped(x, [(w_tck, w_tkc)], bias, kh, kw, pad, co=4)
     if hip.bconv_eligible(Ci, Co):
         # (a filter that the all-layers mixing launch wrote zero-padded to 16 channels -- MixPlan.padded -- meets a narrower input / bias /
         #  true output width `co` here: the view cast pads the input, the bias is padded once per step, the output is sliced back to fp32)
@@ -759,9 +763,12 @@ class _GroupedConvFn(Function):
         xin, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         tkcs = ctx.saved_tensors[2:]
         bias = ctx.bias_param
+        dy4 = None
         if ctx.head:
             dy = hip.cast_view(dy, torch.float32)                 # fp32 reconstruction gradient in, bf16 trunk gradient out
         elif Co_p != Co:
+            if Co == 4 and dy.dtype == torch.float32 and (kh, kw, pad, ctx.stride) == (3, 3, 1, 1) and not lrelu and tkcs[0].shape[1] == 16:
+                dy4 = dy                                          # the data gradient's Cin = 4 kernel reads the fp32 gradient itself (below)
             dy = hip.cast_view(dy, torch.bfloat16, Co_p)
         elif dy.dtype != ctx.ydtype:
             dy = hip.cast_view(dy, ctx.ydtype)
@@ -786,7 +793,10 @@ class _GroupedConvFn(Function):
         for g in range(G):
             dyg = dy[g * B:(g + 1) * B]
             if need_x:
-                hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
+                # ana_dec.output (C -> 4): fp32 dy x reversed taps on the Cin = 4 kernel with a bf16 output (MRDIS_DT_XBF16_YF32), else the bf16 MFMA kernel
+                if dy4 is None or dxb.dtype != torch.bfloat16 or hip.conv2d_bwd_data(dy4[g * B:(g + 1) * B], tkcs[g], (H, W), 3, 3, 1, 1, out=dxb[g * B:(g + 1) * B],
+                                                                                      may_decline=True) is None:
+                    hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
             res = None
             if x32 is not None:          # si_layers: fp32 map x bf16 gradient on the Cin = 4 kernel -- (9, 4, C), no padded copy of the map
                 res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, may_decline=True)

@@ -1028,6 +1028,25 @@ def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
                                  3, 3, 1, 1, may_decline=True) is None
 
 
+@pytest.mark.parametrize('case', [(2, 64, 256, 256), (3, 64, 70, 96), (5, 32, 32, 40)], ids=lambda c: 'N%d_%dfrom4_%dx%d' % c)
+def test_c_from_4_data_gradient_fp32_dy_bf16_out(mrdis, case):
+    """MRDIS_DT_XBF16_YF32 data gradient of a C -> 4 3x3 layer (ana_dec.output under bf16 storage): the Cin = 4 kernel convolves the fp32
+    gradient with the reversed taps and writes bf16.  The filter arrives in the 16-row layout [9][16][C] of the padded bf16 kernels.
+    Same arithmetic as the fp32 call, rounded once at the store: bit-equal to its result cast to bf16."""
+    hip = mrdis.hip
+    N, C, H, W = case
+    w = rnd((4, C, 3, 3), 8, 0.1)
+    dy = cl(rnd((N, 4, H, W), 9))
+    tkc = to_tkc(w).to(dev())                                       # [9][4][C]
+    want = hip.conv2d_bwd_data(dy, tkc, (H, W), 3, 3, 1, 1)
+    close(want, torch.nn.grad.conv2d_input((N, C, H, W), w, dy.cpu().contiguous(), 1, 1), rtol=2e-5, what='fp32 C <- 4 dgrad vs torch')
+    tkc16 = F.pad(tkc, (0, 0, 0, 12))                               # rows >= 4 zero
+    out = hip.empty_nhwc(N, C, H, W, dev(), torch.bfloat16)
+    got = hip.conv2d_bwd_data(dy, tkc16, (H, W), 3, 3, 1, 1, out=out, may_decline=True)
+    assert got is not None and got.dtype == torch.bfloat16
+    assert torch.equal(got, want.to(torch.bfloat16))
+
+
 def test_conv_bf16_storage_random_shapes(mrdis):
     """MRDIS_DT_BF16 (bf16 activation views in and out) over a seeded sweep of geometries inside the bf16 kernels' domain
     (channels in multiples of 16, >= 16 outputs): no shape may be refused without a working fallback, and every result must

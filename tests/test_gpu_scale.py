@@ -292,7 +292,11 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
             assert rel(y[S], F.conv2d(xd[S].float().cpu(), w, b, s, p)) <= 4e-3, ('fwd (Cin = 4 kernel) vs torch', name)
         else:
             assert rel(y[S], ys) <= 4e-3, ('fwd vs torch', name, rel(y[S], ys))                   # a bf16 result: 2^-9 relative per element
-        assert rel(dx[S], xs.grad) <= 4e-3, ('dgrad vs torch', name, rel(dx[S], xs.grad))
+        dx_ref = xs.grad
+        if Co == 4 and k == 3 and s == 1 and path == 'bf16':
+            # the C -> 4 layer's data gradient runs on the Cin = 4 kernel: fp32 dy and fp32 filter in, bf16 out (MRDIS_DT_XBF16_YF32)
+            dx_ref = torch.nn.grad.conv2d_input(tuple(xs.shape), w, dyd[S].float().cpu().contiguous(), s, p)
+        assert rel(dx[S], dx_ref) <= 4e-3, ('dgrad vs torch', name, rel(dx[S], dx_ref))
         dys = torch.zeros_like(dyd); dys[S] = dyd[S]
         _, _, dw_s, db_s = _run_bf16_layer(m, xd, w, b, dys, k, s, p, Co)
         wg_ref = ws.grad

@@ -120,6 +120,10 @@ def main():
                 def f_dgrad():
                     g = hip.conv2d_bwd_data(hip.cast_view(dys, B16, cop), wkp, (hi, wi), k, k, s, p, w_bf16=wbb)
                     return g if cip == ci else hip.cast_view(g, torch.float32, ci)
+                if co == 4 and k == 3 and s == 1 and ci % 16 == 0:      # C -> 4 (ana_dec.output): the data gradient's Cin = 4 kernel reads the fp32 dy, bf16 out
+                    dxo4 = hip.empty_nhwc(B, ci, hi, wi, dev, B16)
+                    if hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True) is not None:
+                        f_dgrad = lambda: hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True)      # noqa: E731
 
                 def f_wgrad():
                     if ci == 4 and k == 3 and s == 1:
