@@ -273,8 +273,13 @@ int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, 
  * save_mean / save_rstd instead of computing them.                                                                                */
 size_t mrdis_bilinear_up2_stats_workspace(int N, int Hi, int C);
 int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C,
+                                 int out_block, long long out_block_stride,
                                  float* save_mean, float* save_rstd, float eps, void* workspace, size_t workspace_bytes,
                                  int dtype, void* stream);
+/* out_block = 0 (or >= N): y is the dense (N, 2 Hi, 2 Wi, ldy) view.  0 < out_block < N (N % out_block == 0): the N images leave as
+ * N / out_block blocks of out_block images, block k at y + k * out_block_stride elements (dense inside a block) -- the shared SPADE decoder
+ * writes its result for modality label j straight into the [decoder i][label j] arrangement the per-modality decoders read (model.py:3200-3224),
+ * which was a concatenation copy of 268 MB per decoder call.                                                                            */
 int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi,
                        int Ho, int Wo, int C, int align_corners, int dtype, void* stream);
 

@@ -756,7 +756,8 @@ __global__ void bilinear_bwd_tight_kernel(const T* __restrict__ dy, int lddy, T*
 // (model.py:2440), whose statistics pass would otherwise read the 4x tensor back from HBM.  Needs blockDim.x % (C / 4) == 0 (a thread
 // keeps its channel group); block reduction in LDS in a fixed order.
 template <typename T, bool STATS = false>
-__global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int Hi, int Wi, int C, float* __restrict__ part = nullptr) {
+__global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int Hi, int Wi, int C, float* __restrict__ part = nullptr,
+                                        int oblk = 0x7fffffff, long long oblk_stride = 0) {      // output image n lives in block n / oblk (blocks oblk_stride elements apart)
     __shared__ float red_[STATS ? 256 * 9 : 1];
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     const int Q = C / 4;
@@ -765,7 +766,7 @@ __global__ void bilinear_up2_fwd_kernel(const T* __restrict__ x, int ldx, T* __r
     const T* rm = x + ((long long)n * Hi + im) * Wi * ldx;
     const T* rc = x + ((long long)n * Hi + i) * Wi * ldx;
     const T* rp = x + ((long long)n * Hi + ip) * Wi * ldx;
-    T* y0 = y + ((long long)n * 2 * Hi + 2 * i) * (2 * Wi) * ldy;
+    T* y0 = y + (long long)(n / oblk) * oblk_stride + ((long long)(n % oblk) * 2 * Hi + 2 * i) * (2 * Wi) * ldy;
     T* y1 = y0 + (long long)(2 * Wi) * ldy;
     // row weights of the two output rows: (top, centre, bottom); at the borders the clamped neighbour IS the centre row
     const float a_t = i > 0 ? 0.25f : 0.f, a_c0 = i > 0 ? 0.75f : 1.f;              // out[2i]   = a_t x[im] + a_c0 x[i]   (src clamped to 0 at i = 0)
@@ -908,15 +909,17 @@ static int bilinear_bwd_impl(const T* dy, int lddy, T* dx, int lddx, int N, int 
 // (same fp64 combine of fp32 partial sums; the partial sums are taken in another order).
 extern "C" size_t mrdis_bilinear_up2_stats_workspace(int N, int Hi, int C) { return sizeof(float) * 2 * (size_t)N * Hi * C + 64; }
 template <typename T>
-static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, int Wi, int C, float* save_mean, float* save_rstd, float eps,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, int Wi, int C, int out_block, long long out_block_stride,
+                                   float* save_mean, float* save_rstd, float eps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !y || !save_mean || !save_rstd || !workspace || N < 1 || Hi < 1 || Wi < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
+    if (out_block <= 0 || out_block >= N) { out_block = 0x7fffffff; out_block_stride = 0; }       // dense output
+    else if (N % out_block != 0 || out_block_stride < 4LL * out_block * Hi * Wi * ldy || out_block_stride % 4 != 0) return MRDIS_EINVAL;
     if (workspace_bytes < mrdis_bilinear_up2_stats_workspace(N, Hi, C)) return MRDIS_EWORKSPACE;
     const int threads = bil_threads((long long)Wi * (C / 4));
     if (N > 65535 || C % 4 != 0 || !vec4_ok(x, ldx, C) || !vec4_ok(y, ldy, C) || threads % (C / 4) != 0) return MRDIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, true>), dim3(Hi, N), dim3(threads), 0, s, x, ldx, y, ldy, Hi, Wi, C, part);
+    hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, true>), dim3(Hi, N), dim3(threads), 0, s, x, ldx, y, ldy, Hi, Wi, C, part, out_block, out_block_stride);
     MRDIS_CHECK_LAUNCH();
     hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(Hi)), 0, s, part, Hi, C, N, 4LL * Hi * Wi, eps, 0.f,
                        save_mean, save_rstd, nullptr, nullptr);
@@ -988,11 +991,11 @@ extern "C" int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int 
     return MRDIS_BY_DTYPE(dtype, bilinear_fwd_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream),
                           bilinear_fwd_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, stream));
 }
-extern "C" int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C, float* save_mean, float* save_rstd, float eps,
-                                            void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+extern "C" int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C, int out_block, long long out_block_stride,
+                                            float* save_mean, float* save_rstd, float eps, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype,
-        bilinear_up2_stats_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, C, save_mean, save_rstd, eps, workspace, workspace_bytes, stream),
-        bilinear_up2_stats_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, C, save_mean, save_rstd, eps, workspace, workspace_bytes, stream));
+        bilinear_up2_stats_impl((const float*)x, ldx, (float*)y, ldy, N, Hi, Wi, C, out_block, out_block_stride, save_mean, save_rstd, eps, workspace, workspace_bytes, stream),
+        bilinear_up2_stats_impl((cbf)x, ldx, (bf)y, ldy, N, Hi, Wi, C, out_block, out_block_stride, save_mean, save_rstd, eps, workspace, workspace_bytes, stream));
 }
 extern "C" int mrdis_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype, bilinear_bwd_impl((const float*)dy, lddy, (float*)dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, stream),

@@ -69,7 +69,7 @@ _SIGS = {
     'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_up2_stats_workspace': (_Z, [_I, _I, _I]),
-    'mrdis_bilinear_up2_stats_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _Z, _I, _P]),
+    'mrdis_bilinear_up2_stats_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _Z, _I, _P]),
     'mrdis_softmax_mask_drop_fwd': (_I, [_P, _I, _P, _P, _I, _L, _I, _F, _P]),
     'mrdis_softmax_mask_drop_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
     'mrdis_recon_err_workspace': (_Z, [_I, _L, _I]),
@@ -792,31 +792,46 @@ def bilinear_fwd(x, out_hw, align_corners):
     return y
 
 
-def bilinear_up2_stats(x, eps):
-    """x2 bilinear (align_corners=False) + instance statistics of the result: -> (y, mean, rstd), or None where the fused kernel does not apply"""
+def bilinear_up2_stats(x, eps, out_blocks=None):
+    """x2 bilinear (align_corners=False) + instance statistics of the result: -> (y, mean, rstd), or None where the fused kernel does not apply.
+    out_blocks: a (G, Bb, C, 2 Hi, 2 Wi) view, G * Bb = N, each out_blocks[g] a dense NHWC block: image n is written to out_blocks[n // Bb][n % Bb]
+    (then y is out_blocks itself)."""
     lib = load()
     x, ldx = nhwc(x)
     N, C, Hi, Wi = x.shape
     if C % 4 != 0:
         return None
-    y = empty_nhwc(N, C, 2 * Hi, 2 * Wi, x.device, x.dtype)
+    blk, bstride = 0, 0
+    if out_blocks is None:
+        y = empty_nhwc(N, C, 2 * Hi, 2 * Wi, x.device, x.dtype)
+        yptr = _ptr(y)
+    else:
+        G, Bb = out_blocks.shape[0], out_blocks.shape[1]
+        y0, ld0 = nhwc(out_blocks[0])
+        assert G * Bb == N and tuple(out_blocks.shape[2:]) == (C, 2 * Hi, 2 * Wi) and out_blocks.dtype == x.dtype and ld0 == C
+        assert y0.data_ptr() == out_blocks.data_ptr(), 'blocks must be dense NHWC'
+        y, yptr, blk, bstride = out_blocks, _ptr(y0), Bb, out_blocks.stride(0)
     mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N * C, dtype=torch.float32, device=x.device)
     nb = _ws_bytes(lib.mrdis_bilinear_up2_stats_workspace, N, Hi, C)
     ws = _ws(nb, x.device)
-    rc = lib.mrdis_bilinear_up2_stats_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, C, _ptr(mean), _ptr(rstd), eps, _ptr(ws), nb, _dt(x), _stream())
+    rc = lib.mrdis_bilinear_up2_stats_fwd(_ptr(x), ldx, yptr, C, N, Hi, Wi, C, blk, bstride, _ptr(mean), _ptr(rstd), eps, _ptr(ws), nb, _dt(x), _stream())
     if rc == -2:
         return None
     _chk(rc, 'bilinear_up2_stats_fwd')
     return y, mean, rstd
 
 
-def bilinear_bwd(dy, in_hw, align_corners):
+def bilinear_bwd(dy, in_hw, align_corners, out=None):
     lib = load()
     dy, lddy = nhwc(dy)
     N, C, Ho, Wo = dy.shape
     Hi, Wi = in_hw
-    dx = empty_nhwc(N, C, Hi, Wi, dy.device, dy.dtype)
+    if out is None:
+        dx = empty_nhwc(N, C, Hi, Wi, dy.device, dy.dtype)
+    else:
+        dx, ldo = nhwc(out)
+        assert dx.data_ptr() == out.data_ptr() and ldo == C and tuple(out.shape) == (N, C, Hi, Wi) and out.dtype == dy.dtype
     _chk(lib.mrdis_bilinear_bwd(_ptr(dy), lddy, _ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _dt(dy), _stream()), 'bilinear_bwd')
     return dx
 

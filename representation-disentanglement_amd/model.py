@@ -481,12 +481,15 @@ class SPADENewShared(nn.Module):
         self.sp2 = SPADEBlockNew((H // 16, W // 16), z_num_ch, z_num_ch, s_num_ch, is_cond)
         self.sp3 = SPADEBlockNew((H // 8, W // 8), z_num_ch, z_num_ch, s_num_ch, is_cond)
 
-    def forward(self, si, zi, inputs_type=None):
+    def forward(self, si, zi, inputs_type=None, scatter=None):
         H, W = self.image_size
         x = ops.to_storage(self.zi_scaler(zi).reshape(-1, self.z_num_ch, H // 32, W // 32))     # opens the decoder's bf16 stretch
         x = self.sp1(si, x, inputs_type)
         x = self.sp2(si, _up2(x, self.sp2.zi_layers), inputs_type)
         x = self.sp3(si, _up2(x, self.sp3.zi_layers), inputs_type)
+        if scatter is not None and ops.up2_scatter_applies(x):
+            # scatter = (holder, j, M): the batch is M sample blocks for label j; block i goes straight to its place in decoder i's input
+            return ops.bilinear_up2_scatter(x, scatter[0], scatter[1], scatter[2], self.sp3.zi_layers.eps)
         return _up2(x, self.sp3.zi_layers)             # read by sp4 of a SPADENewNotShared (same InstanceNorm2d defaults)
 
 
@@ -868,8 +871,13 @@ class MultimodalModel(nn.Module):
             self.premix('dec_shared')
             s_cat = torch.cat(list(si_list), 0)
             mids = {}
+            holder = {}
             for j in range(M):
-                mid = self.input_decoder_list[-1](s_cat, zi_list[j].repeat(M, 1), self._type(j, M * B))
+                mid = self.input_decoder_list[-1](s_cat, zi_list[j].repeat(M, 1), self._type(j, M * B), scatter=(holder, j, M))
+                if isinstance(mid, list):                                 # blocks written in place into the [decoder i][label j] buffer (ops.bilinear_up2_scatter)
+                    for i, part in enumerate(mid):
+                        mids[(i, j)] = part
+                    continue
                 st = getattr(mid, '_mrdis_in_stats', None)                # instance statistics taken by the last x2 resize (ops.bilinear_up2)
                 for i, part in enumerate(ops.split_batch(mid, M)):        # one-pass adjoint instead of M zero-fills + adds
                     if st is not None:
@@ -896,7 +904,7 @@ class MultimodalModel(nn.Module):
             outs = {}
             for i in range(M):
                 self.premix(f'dec{i}')
-                z_cat = torch.cat([mids[(i, j)] for j in range(M)], 0)
+                z_cat = ops.join_blocks([mids[(i, j)] for j in range(M)])
                 sts = [getattr(mids[(i, j)], '_mrdis_in_stats', None) for j in range(M)]
                 if all(s_ is not None and s_[2] == sts[0][2] for s_ in sts):
                     z_cat._mrdis_in_stats = (torch.cat([s_[0] for s_ in sts]), torch.cat([s_[1] for s_ in sts]), sts[0][2])

@@ -1085,6 +1085,94 @@ class _BilinearUp2Stats(Function):
         return hip.bilinear_bwd(dy, ctx.geom, False), None
 
 
+class _Up2ScatterFn(Function):
+    """_BilinearUp2Stats for the LAST resize of the shared SPADE decoder (model.py:2573), whose batch holds M sample blocks (one per anatomy
+    source i) for ONE modality label j while the per-modality decoder i reads the M labels of ITS block (model.py:3200-3224): the kernel writes
+    block i straight into zbuf[i][j] (mrdis_bilinear_up2_stats_fwd, out_block), so that zbuf[i] IS decoder i's batch-concatenated input -- the
+    concatenation copy (268 MB per decoder call at B = 32) and the batch split disappear.  Outputs: the M block views + (mean, rstd)."""
+
+    @staticmethod
+    def forward(ctx, x, zbuf, j, eps):
+        M = zbuf.shape[0]
+        B = x.shape[0] // M
+        ctx.geom = (x.shape[2], x.shape[3]); ctx.M = M; ctx.B = B
+        blocks = zbuf[:, j * B:(j + 1) * B]                     # (M, B, C, 2H, 2W)
+        res = hip.bilinear_up2_stats(x, eps, out_blocks=blocks)
+        if res is None:
+            raise hip.MrdisError('bilinear_up2 (scatter): unsupported geometry')
+        _, mean, rstd = res
+        ctx.mark_non_differentiable(mean, rstd)
+        return tuple(blocks[i] for i in range(M)) + (mean, rstd)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        M, B = ctx.M, ctx.B
+        gs = grads[:M]
+        ref = next(g for g in gs if g is not None)
+        dx = hip.empty_nhwc(M * B, ref.shape[1], ctx.geom[0], ctx.geom[1], ref.device, ref.dtype)
+        for i in range(M):                                       # each block's gradient comes from another decoder's backward: no gather copy
+            if gs[i] is None:
+                dx[i * B:(i + 1) * B].zero_()
+            else:
+                hip.bilinear_bwd(gs[i], ctx.geom, False, out=dx[i * B:(i + 1) * B])
+        return dx, None, None, None
+
+
+class _JoinBlocksFn(Function):
+    """the M blocks that _Up2ScatterFn calls wrote side by side ARE their concatenation: hand out the enclosing view, split the gradient into views"""
+
+    @staticmethod
+    def forward(ctx, whole, *parts):
+        ctx.sizes = [p_.shape[0] for p_ in parts]
+        return whole.view(whole.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, o = [], 0
+        for n in ctx.sizes:
+            out.append(g[o:o + n]); o += n
+        return (None,) + tuple(out)
+
+
+_UP2_SCATTER = _os.environ.get('MRDIS_UP2_SCATTER', '1') != '0'
+
+
+def set_up2_scatter(enabled):
+    global _UP2_SCATTER
+    _UP2_SCATTER = bool(enabled)
+
+
+def up2_scatter_applies(x):
+    return _UP2_SCATTER and _UP2_STATS and x.is_cuda and type(x) is torch.Tensor and x.shape[1] % 4 == 0
+
+
+def bilinear_up2_scatter(x, holder, j, M, stats_eps):
+    """x: (M * B, C, H, W), block i = samples of anatomy source i, for label j of M.  holder: dict shared by the M calls of a step (the buffer
+    (M, M * B, C, 2H, 2W) is made by the first).  -> list of M block tensors (B, C, 2H, 2W), each carrying its instance statistics and its place."""
+    B = x.shape[0] // M
+    C, H2, W2 = x.shape[1], 2 * x.shape[2], 2 * x.shape[3]
+    zbuf = holder.get('buf')
+    if zbuf is None:
+        zbuf = torch.empty((M, M * B, H2, W2, C), dtype=x.dtype, device=x.device).permute(0, 1, 4, 2, 3)
+        holder['buf'] = zbuf
+    res = _Up2ScatterFn.apply(x, zbuf, int(j), float(stats_eps))
+    parts, mean, rstd = res[:M], res[M], res[M + 1]
+    n = B * C
+    for i, part in enumerate(parts):
+        part._mrdis_in_stats = (mean[i * n:(i + 1) * n], rstd[i * n:(i + 1) * n], float(stats_eps))
+        part._mrdis_block = (zbuf, i, int(j))
+    return list(parts)
+
+
+def join_blocks(parts):
+    """torch.cat(parts, 0) -- free when the parts are the label blocks 0 .. M-1 of one row of a bilinear_up2_scatter buffer"""
+    tags = [getattr(p_, '_mrdis_block', None) for p_ in parts]
+    if all(t is not None for t in tags) and all(t[0] is tags[0][0] and t[1] == tags[0][1] and t[2] == k for k, t in enumerate(tags)) \
+            and len(parts) * parts[0].shape[0] == tags[0][0].shape[1]:
+        return _JoinBlocksFn.apply(tags[0][0][tags[0][1]], *parts)
+    return torch.cat(list(parts), 0)
+
+
 _UP2_STATS = _os.environ.get('MRDIS_UP2_STATS', '1') != '0'
 
 

@@ -346,18 +346,20 @@ def test_all_layers_mixing_launch_is_bit_identical(mrdis, mode):
     assert torch.equal(res[True][1], res[False][1])
 
 
-@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace', 'up2_stats', 'grouped_enc'])
+@pytest.mark.parametrize('switch', ['planar_inputs', 'cat_elision', 'gb_inplace', 'up2_stats', 'up2_scatter', 'grouped_enc'])
 def test_layout_switches_do_not_change_the_step(mrdis, switch):
     """MRDIS_PLANAR_INPUTS (modality-planar copy of the input batch), MRDIS_CAT_ELISION (skip concatenation written in place) and
     MRDIS_GB_INPLACE (d(mix) written into the beta half of [dgamma | dbeta]) only change where tensors live: one step with the switch
     off and on gives the same loss and the same parameter gradients (same kernels' arithmetic on other strides).  MRDIS_UP2_STATS (the
     x2 resize in front of a SPADE block also takes that block's InstanceNorm statistics) changes the order of the partial sums only.
+    MRDIS_UP2_SCATTER: the shared decoder's last resize writes its blocks straight into the per-modality decoders' batch-concatenated
+    inputs (no concatenation copy, the adjoint runs per block): the same arithmetic per element -- bit-identical.
     MRDIS_GROUPED_ENC (off by default, by measurement): the per-modality encoder loops as one batch-concatenated pass -- grouped
     BatchNorm (statistics per sample block, `groups` of mrdis_bn_train_fwd / _bwd) and the strided form of ops.conv2d_grouped."""
     B, M, H, W = 2, 4, 64, 128
     cfg = _cfg(mrdis, M, H, W, B, adv=True)
     holder = {'planar_inputs': (mrdis.trainer, '_PLANAR_INPUTS'), 'cat_elision': (mrdis.ops, '_CAT_ELISION'), 'gb_inplace': (mrdis.ops, '_GB_INPLACE'),
-              'up2_stats': (mrdis.ops, '_UP2_STATS'), 'grouped_enc': (mrdis.ops, '_GROUPED_ENC')}[switch]
+              'up2_stats': (mrdis.ops, '_UP2_STATS'), 'up2_scatter': (mrdis.ops, '_UP2_SCATTER'), 'grouped_enc': (mrdis.ops, '_GROUPED_ENC')}[switch]
     default = getattr(holder[0], holder[1])
     res = {}
     try:
@@ -379,6 +381,8 @@ def test_layout_switches_do_not_change_the_step(mrdis, switch):
     for n, g0 in res[False][1].items():
         err = float((res[True][1][n] - g0).double().norm())
         assert err <= 1e-5 * float(g0.double().norm()) + 1e-7 * tot, (n, err, float(g0.norm()))
+        if switch == 'up2_scatter':
+            assert torch.equal(res[True][1][n], g0), n
 
 
 def test_gb_spade_fusion_matches_two_step_path(mrdis):

@@ -1218,3 +1218,21 @@ def test_batchnorm_groups_equal_separate_calls(mrdis, G, B, C, H, W, dtype):
         acc_g += dgs[g]; acc_b += dbs[g]
     assert torch.equal(sink_g, acc_g) and torch.equal(sink_b, acc_b)
 
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bilinear_up2_block_scattered_output(mrdis, dtype):
+    """mrdis_bilinear_up2_stats_fwd with out_block: image n of the result goes to block n // Bb of a strided block buffer (the shared SPADE
+    decoder writes label j's result into column j of the [decoder i][label j] buffer).  Values and statistics are those of the dense call."""
+    hip = mrdis.hip
+    T = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    M, Bb, C, H, W = 4, 3, 32, 10, 12
+    x = cl(rnd((M * Bb, C, H, W), 2)).to(T)
+    y0, m0, r0 = hip.bilinear_up2_stats(x, 1e-5)
+    zbuf = torch.full((M, M * Bb, 2 * H, 2 * W, C), -7.0, dtype=T, device=dev()).permute(0, 1, 4, 2, 3)
+    for j in (2, 0):
+        y, m1, r1 = hip.bilinear_up2_stats(x, 1e-5, out_blocks=zbuf[:, j * Bb:(j + 1) * Bb])
+        assert torch.equal(m1, m0) and torch.equal(r1, r0)
+        for i in range(M):
+            assert torch.equal(zbuf[i, j * Bb:(j + 1) * Bb], y0[i * Bb:(i + 1) * Bb])
+    assert float(zbuf[:, Bb:2 * Bb].float().max()) == -7.0 and float(zbuf[:, 3 * Bb:].float().min()) == -7.0        # other columns untouched
