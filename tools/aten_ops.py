@@ -1,5 +1,6 @@
 """Which ATen ops (torch glue between the HIP kernels) a training step issues: torch.profiler over 2 steps, grouped by op and input
-shape, sorted by call count.  HOSTPROF_SHAPE as in host_profile.py (op counts do not depend on the shape)."""
+shape, sorted by call count.  HOSTPROF_SHAPE as in host_profile.py (op counts do not depend on the shape).  ATEN_BY_GPU=1: also
+record device time and sort by it (run at the bench shape, HOSTPROF_SHAPE=32,4,256,256: which glue ops move the big tensors)."""
 import os
 import sys
 
@@ -28,7 +29,8 @@ for _ in range(2):
     step(xd, maskd, mimgd, mask)
 torch.cuda.synchronize()
 N = 2
-with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+BY_GPU = os.environ.get('ATEN_BY_GPU', '0') == '1'
+with profile(activities=[ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if BY_GPU else []), record_shapes=True) as prof:
     for _ in range(N):
         step(xd, maskd, mimgd, mask)
 torch.cuda.synchronize()
@@ -36,10 +38,10 @@ VIEWS = {'aten::as_strided', 'aten::slice', 'aten::select', 'aten::view', 'aten:
          'aten::empty_like', 'aten::empty_strided', 'aten::permute', 'aten::expand', 'aten::unsqueeze', 'aten::squeeze', 'aten::detach', 'aten::alias',
          'aten::contiguous', 'aten::to', 'aten::resize_', 'aten::linear', 'aten::zeros', 'aten::ones', 'aten::pad', 'aten::clone'}
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::') and e.key not in VIEWS]
-rows.sort(key=lambda e: -e.count)
+rows.sort(key=lambda e: -(e.self_device_time_total if BY_GPU else e.count))
 print(f'{"op":34s} {"calls/step":>10s} {"self cpu us/step":>16s}  input shapes')
 for e in rows[:70]:
-    print(f'{e.key:34s} {e.count / N:10.1f} {e.self_cpu_time_total / N:16.1f}  {str(e.input_shapes)[:110]}')
+    print(f'{e.key:34s} {e.count / N:10.1f} {e.self_cpu_time_total / N:16.1f}  ' + (f'gpu {e.self_device_time_total / N:9.1f} us/step  ' if BY_GPU else '') + f'{str(e.input_shapes)[:110]}')
 tot = {}
 for e in rows:
     t = tot.setdefault(e.key, [0, 0.0]); t[0] += e.count / N; t[1] += e.self_cpu_time_total / N
