@@ -1236,3 +1236,34 @@ def test_bilinear_up2_block_scattered_output(mrdis, dtype):
         for i in range(M):
             assert torch.equal(zbuf[i, j * Bb:(j + 1) * Bb], y0[i * Bb:(i + 1) * Bb])
     assert float(zbuf[:, Bb:2 * Bb].float().max()) == -7.0 and float(zbuf[:, 3 * Bb:].float().min()) == -7.0        # other columns untouched
+
+
+@pytest.mark.parametrize('case', [
+    # N, Ci, Co, H, W, k, stride
+    (32, 128, 256, 8, 8, 3, 1),        # the 8x8 SPADE level at the bench batch: 32-channel chunks + split-K
+    (3, 72, 40, 9, 11, 3, 1),          # ragged half tile (99 positions in 64-position tiles), partial last chunk (72 = 4.5 x 16), cout tail
+    (5, 64, 36, 7, 5, 3, 1),           # 35 positions per image: several images per tile
+    (32, 256, 256, 16, 16, 4, 2),      # 4x4 stride 2 onto 8x8: 16 taps, 16-channel chunks + split-K
+    (2, 96, 64, 12, 12, 1, 1),         # 1x1: the filter slab is smaller than the partial-sum buffer -> no split-K
+], ids=lambda c: 'N%d_%dto%d_%dx%d_k%d_s%d' % c)
+def test_small_map_direct_conv_split_k(mrdis, case):
+    """tapconv_body<.., SK = 2> (half-filled 64-position tiles of the small maps: the two otherwise idle position waves take half of every
+    chunk's channels, pairs add through LDS in a fixed order) and the 32-channel chunks of those launches: forward and data gradient
+    against torch, and against the same launch without the small-map forms (option debug_now16 = 1: full tiles, one wave per block)
+    to fp32 rounding (the split changes the order of the channel sum)."""
+    hip = mrdis.hip
+    N, Ci, Co, H, W, k, s = case
+    p = 0 if k == 1 else 1
+    x = rnd((N, Ci, H, W), 21); w = rnd((Co, Ci, k, k), 22, 1.0 / np.sqrt(Ci * k * k)); b = rnd((Co,), 23, 0.1)
+    want = F.conv2d(x, w, b, s, p)
+    with hip.option('wino', 0):
+        got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), k, k, s, p)
+        close(got, want, rtol=2e-5, what='small-map fwd vs torch')
+        gy = rnd(tuple(want.shape), 24)
+        dx = hip.conv2d_bwd_data(cl(gy), to_tkc(w).to(dev()), (H, W), k, k, s, p)
+        close(dx, torch.nn.grad.conv2d_input(x.shape, w, gy, s, p), rtol=2e-5, what='small-map dgrad vs torch')
+        with hip.option('debug_now16', 1):
+            got0 = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), k, k, s, p)
+            dx0 = hip.conv2d_bwd_data(cl(gy), to_tkc(w).to(dev()), (H, W), k, k, s, p)
+        close(got, got0, rtol=2e-6, what='split-K vs plain tiles, fwd')
+        close(dx, dx0, rtol=2e-6, what='split-K vs plain tiles, dgrad')
