@@ -741,8 +741,9 @@ def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_
 def gb_slot(t):
     """the (N, 2C, H, W) NHWC buffer whose channels [C, 2C) are exactly the NCHW-shaped tensor `t`, or None"""
     base = t._base
-    if base is None or base.dim() != 4 or t.dim() != 4:
-        return None
+    if base is None or base.dim() != 4 or t.dim() != 4 or not getattr(base, '_mrdis_gb_private', False):
+        return None      # only buffers a grouped convolution allocated for this purpose: any other upper-half channel slice (a torch.cat adjoint,
+                         # a skip-connection half) shares its lower half with another consumer
     N, C, H, W = t.shape
     if tuple(base.shape) != (N, 2 * C, H, W) or base.dtype != t.dtype or not base.is_contiguous(memory_format=torch.channels_last):
         return None

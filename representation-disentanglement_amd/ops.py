@@ -785,7 +785,9 @@ class _GroupedConvFn(Function):
             if ctx.dx_in_gb and not share_x and Ci_p == Ci and xin is not None and xin.dtype == x_dtype:
                 # the input is the modulated map of a fused SPADE node (ops._GbSpadeFn): its gradient is also the beta half of that node's
                 # [dgamma | dbeta] buffer -- write it there, the node then fills in the other half (hip.gb_slot)
-                dxb = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, xin.dtype)[:, Ci:]
+                gbuf = hip.empty_nhwc(G * B, 2 * Ci, H, W, xin.device, xin.dtype)
+                gbuf._mrdis_gb_private = True                  # hip.gb_slot takes the in-place path for tagged buffers only
+                dxb = gbuf[:, Ci:]
             else:
                 dxb = hip.empty_nhwc(G * B, Ci_p, H, W, dy.device, xdt)
         sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None

@@ -223,7 +223,9 @@ class Run:
                     self.log('Epoch[%3d], iter[%3d]: ' % (epoch, it) + ', '.join(f'{k}=[{float(v[i]):.4f}]' for i, k in enumerate(LOSS_KEYS)))
                 if max_iters_per_epoch is not None and n_iter >= max_iters_per_epoch:
                     break
-            mean = (acc / max(n_iter, 1)).cpu()
+            if n_iter == 0:
+                raise RuntimeError(f'epoch {epoch}: the train loader yielded no batch (dataset smaller than one batch, or an empty subject list)')
+            mean = (acc / n_iter).cpu()
             loss_all = {k: float(mean[i]) for i, k in enumerate(LOSS_KEYS)}
             if not np.isfinite(loss_all['all']):
                 raise FloatingPointError(f'epoch {epoch}: loss is {loss_all["all"]} (the reference stops in pdb, :265-266)')
@@ -266,7 +268,9 @@ class Run:
                 break
             if n_iter >= max_batches:
                 break
-        mean = (acc / max(n_iter, 1)).cpu()
+        if n_iter == 0:
+            raise RuntimeError(f'evaluate({phase!r}, {set_!r}): the loader yielded no batch')
+        mean = (acc / n_iter).cpu()
         stat = {k: float(mean[i]) for i, k in enumerate(LOSS_KEYS)}
         for k, v in met.items():                                            # :568-569
             stat[k] = float(torch.cat(v).double().mean()) if v else float('nan')

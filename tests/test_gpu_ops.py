@@ -569,6 +569,8 @@ def test_spade_bwd_beta_half_in_place(mrdis):
     mean = z.mean(dim=(2, 3)).reshape(-1).contiguous(); rstd = (1.0 / (z.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt()).reshape(-1).contiguous()
     buf = hip.empty_nhwc(N, 2 * C, H, W, dev()); buf.fill_(9.0)
     dmix_view = buf[:, C:]
+    assert hip.gb_slot(dmix_view) is None               # an untagged buffer: its lower half may belong to another consumer (torch.cat adjoint, skip half)
+    buf._mrdis_gb_private = True                        # what ops._GroupedConvFn sets on the buffer it allocates for this
     assert hip.gb_slot(dmix_view) is buf and hip.gb_slot(buf[:, :C]) is None
     hip.conv2d_bwd_data(dy, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1, out=dmix_view)
     dmix = hip.conv2d_bwd_data(dy, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
