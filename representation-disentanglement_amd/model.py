@@ -245,6 +245,7 @@ class Act_Deconv_BN_Concat_New(nn.Module):
             Cd, Cu = x_down.shape[1], x_up.shape[1]
             buf = getattr(x_down, '_mrdis_catbuf', None)
             if buf is not None and buf.shape[1] == Cd + Cu and buf.dtype == x_up.dtype:
+                x_down._mrdis_catbuf = None                   # one consumer only: a second decoder reading this skip tensor must not rewrite the upper half
                 x_up = self.bn(x_up, into=(buf, Cd))
                 return ops.cat_join(x_down, x_up, buf)
         if self.is_bn:
@@ -264,6 +265,7 @@ class Act_Deconv_BN_Concat_New(nn.Module):
             Cd, Cu = x_down.shape[1], x_up.shape[1]
             buf = getattr(x_down, '_mrdis_catbuf', None)
             if buf is not None and buf.shape[1] == Cd + Cu and buf.dtype == x_up.dtype:
+                x_down._mrdis_catbuf = None
                 x_up = self.bn(x_up, into=(buf, Cd), groups=G)
                 return ops.cat_join(x_down, x_up, buf)
         if self.is_bn:
