@@ -17,7 +17,7 @@ import torch.distributed as dist
 import yaml
 
 from . import hip, ops
-from .model import MultimodalModel
+from .model import MultimodalModel, flush_batch_counters
 
 # config.yaml of the reference, verbatim keys and defaults (src/config.yaml:1-91)
 DEFAULT_CONFIG = {
@@ -715,6 +715,7 @@ class TrainStep:
             od = self.optimizer_d_s
             od.step(fused_clip=False, grad_scale=scale)                                          # :287-289 (no clip on the d-step)
             od.zero_grad()
+        flush_batch_counters()                                                                   # BatchNorm2d.num_batches_tracked of this step's calls, one launch
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
 
     def losses_to_host(self, parts):

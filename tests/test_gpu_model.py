@@ -741,3 +741,21 @@ def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
         assert torch.isfinite(step.optimizer.flat_p).all()
     finally:
         mrdis.ops.set_compute_dtype('f32')
+
+
+def test_batchnorm_call_counter_is_flushed(mrdis):
+    """BatchNorm2d.num_batches_tracked (a state_dict key of the reference's layers) is advanced on the host and written by one fused add:
+    after a TrainStep, and whenever a state_dict is taken, it holds the number of training-mode calls, as nn.BatchNorm2d counts them."""
+    import torch.nn as nn
+    bn = mrdis.model.BatchNorm2d(8).to(DEV).train()
+    ref = nn.BatchNorm2d(8).to(DEV).train()
+    x = cl(torch.randn(4, 8, 6, 6))
+    for _ in range(3):
+        bn(x); ref(x)
+    sd = bn.state_dict()
+    assert int(sd['num_batches_tracked']) == int(ref.num_batches_tracked) == 3
+    bn(x, groups=1); bn(x)
+    mrdis.model.flush_batch_counters()
+    assert int(bn.num_batches_tracked) == 5
+    bn.load_state_dict(ref.state_dict())
+    assert int(bn.state_dict()['num_batches_tracked']) == 3
