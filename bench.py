@@ -173,8 +173,16 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}
         for k_, fn in fns.items():
-            for _ in range(30):                  # ~12 ms of warm-up per entry point: from idle the first launches run ~20 % slower (497 vs 407 us on this
-                fn()                             # layer, tools/rs_probe.py) until the chip has ramped its clocks; inside the training step it has
+            # >= 20 ms of warm-up per entry point (and >= 30 launches): from idle the first launches run ~20 % slower (497 vs 407 us on this
+            # layer, tools/rs_probe.py) until the chip has ramped its clocks; inside the training step it has.  (Thirty launches of a 120 us
+            # bf16 kernel were not enough: 161 us here against 118 us in tools/layer_bench.py.)
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record()
+            for _ in range(30):
+                fn()
+            w1.record(); torch.cuda.synchronize()
+            for _ in range(max(0, int(30 * (20.0 / max(w0.elapsed_time(w1), 0.1) - 1.0)))):
+                fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
@@ -193,7 +201,7 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
     return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
             'pricing': 'fp32: direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) / time / 157.3 TF' if not bf else
                        'bf16: algorithmic bytes (x + dy in bf16) / time / 8 TB/s; direct FLOPs / time / 2500 TF beside it',
-            'timing': f'{iters} launches per entry point after 30 warm-up launches (clock ramp), HIP events on the launch stream, shapes of the timed step',
+            'timing': f'{iters} launches per entry point after >= 20 ms / >= 30 launches of warm-up (clock ramp), HIP events on the launch stream, shapes of the timed step',
             'layers': out}
 
 
