@@ -15,8 +15,9 @@
 #include "mrdis_common.h"
 
 struct Co4Params {
-    const float* x; const float* w; const float* bias; float* y;
+    const void* x; const float* w; const float* bias; float* y;       // x: fp32, or bf16 (template XB: MRDIS_DT_XBF16_YF32 forward / MRDIS_DT_XF32_YBF16 data gradient)
     int N, H, W, Ci, ldx, ldy, flip, lrelu;
+    int wld;                  // filter row length: 4, or 16 for the zero-padded [tap][Ci][16] layout of the bf16 mode
     int R, segs;              // output rows per workgroup, workgroups per image
     unsigned x_bytes;
 };
@@ -26,10 +27,13 @@ constexpr unsigned CO4_OOB = 0xfffffff0u;
 typedef unsigned co4_u32x4 __attribute__((ext_vector_type(4)));
 }
 
-// HALVES = Ci / 16 (2 | 4), TPW = 16-pixel tiles per wave and row = W / 64 (1 | 2 | 4)
-template <int HALVES, int TPW>
+// HALVES = Ci / 16 (2 | 4), TPW = 16-pixel tiles per wave and row = W / 64 (1 | 2 | 4).  XB: the input is a bf16 view -- a lane's 16-byte
+// load then holds EIGHT channels (k-step 8 h' + j <-> channel 32 h' + 8 kq + j: the filter rows follow the same map), widened to fp32
+// in registers (exact), so the MFMAs and everything after them are those of the fp32 form.
+template <int HALVES, int TPW, bool XB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) {
     constexpr int CI = 16 * HALVES, KS = CI / 4;
+    constexpr int NLD = XB ? HALVES / 2 : HALVES;      // 16-byte loads per lane and tile
     extern __shared__ __attribute__((aligned(16))) float zs[];      // [9][W + 2][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
     const int W = p.W, WP = W + 2;
@@ -45,20 +49,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
             const int tap = 4 * rt + tl;
             const int tf = p.flip ? 8 - tap : tap;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                a[ks][rt] = tap < 9 ? p.w[(tf * CI + 16 * (ks >> 2) + 4 * kq + (ks & 3)) * 4 + co] : 0.f;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ch = XB ? 32 * (ks >> 3) + 8 * kq + (ks & 7) : 16 * (ks >> 2) + 4 * kq + (ks & 3);
+                a[ks][rt] = tap < 9 ? p.w[(tf * CI + ch) * p.wld + co] : 0.f;
+            }
         }
     }
     for (int i = tid; i < 9 * WP * 4; i += 256) zs[i] = 0.f;       // the halo columns stay zero
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
-    co4_u32x4 xr[TPW][HALVES];
+    co4_u32x4 xr[TPW][NLD];
     auto load_tile = [&](int t, int r) {              // tile t of the wave (pixels 16 (wave + 4 t) ..) of input row r; outside -> zeros
         const int px = 16 * (wave + 4 * t) + l16;
         const bool ok = (unsigned)r < (unsigned)p.H && r >= r0 - 1 && r <= r1;
-        const unsigned base = 4u * (unsigned)(((n * p.H + r) * W + px) * p.ldx + 4 * kq);
+        const unsigned base = (XB ? 2u : 4u) * (unsigned)(((n * p.H + r) * W + px) * p.ldx + (XB ? 8 : 4) * kq);
 #pragma unroll
-        for (int h = 0; h < HALVES; ++h) xr[t][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? base + 64u * h : CO4_OOB), 0, 0);
+        for (int h = 0; h < NLD; ++h) xr[t][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? base + 64u * h : CO4_OOB), 0, 0);
     };
     const float4 bias4 = p.bias ? make_float4(p.bias[0], p.bias[1], p.bias[2], p.bias[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 runA = make_float4(0.f, 0.f, 0.f, 0.f), runB = runA;   // output rows r + 1 and r so far, column tid
@@ -77,12 +83,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
         for (int t = 0; t < TPW; ++t) {
             f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int h = 0; h < HALVES; ++h) {
+            for (int h = 0; h < NLD; ++h) {
+                if (XB) {
+                    const unsigned u[4] = {xr[t][h].x, xr[t][h].y, xr[t][h].z, xr[t][h].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xv = __uint_as_float((j & 1) ? (u[j >> 1] & 0xffff0000u) : (u[j >> 1] << 16));
+#pragma unroll
+                        for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * h + j][rt], xv, acc[rt], 0, 0, 0);
+                    }
+                } else {
                 const float xv[4] = {__uint_as_float(xr[t][h].x), __uint_as_float(xr[t][h].y), __uint_as_float(xr[t][h].z), __uint_as_float(xr[t][h].w)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * h + j][rt], xv[j], acc[rt], 0, 0, 0);
+                }
             }
             load_tile(t, r + 1);                      // the registers just multiplied take the next row's pixels
             // Z[tap = 4 rt + reg][pixel][co = kq]: lanes (pixel, co) are 64 consecutive words
@@ -108,25 +124,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
 }
 
 // returns MRDIS_EUNSUPPORTED outside what the kernel covers
-int mrdis_run_co4(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
-                  int flip, int lrelu, hipStream_t s) {
-    if (Co != 4 || (Ci != 32 && Ci != 64) || (W != 64 && W != 128 && W != 256) || ldx % 4 != 0 || ldy % 4 != 0) return MRDIS_EUNSUPPORTED;
-    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;
+int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
+                  int flip, int lrelu, hipStream_t s, int x_bf16, int wld) {
+    if (Co != 4 || (Ci != 32 && Ci != 64) || (W != 64 && W != 128 && W != 256) || ldx % (x_bf16 ? 8 : 4) != 0 || ldy % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0 || mrdis_opt(MRDIS_OPT_NOW16) || (wld != 4 && wld != 16)) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W < 65536) return MRDIS_EUNSUPPORTED;
-    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci);
+    const long long xb = (x_bf16 ? 2LL : 4LL) * (((long long)N * H * W - 1) * ldx + Ci);
     if (xb >= 0x7fffffffLL || (long long)N * H * W * ldy >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     Co4Params p{};
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.ldy = ldy; p.flip = flip; p.lrelu = lrelu;
-    p.x_bytes = (unsigned)xb;
+    p.x_bytes = (unsigned)xb; p.wld = wld;
     int segs = mrdis_cdiv(512, N);                     // ~512 workgroups, each a run of consecutive rows of one image
     if (segs > H / 4) segs = H / 4 > 0 ? H / 4 : 1;
     p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
     const size_t lds = sizeof(float) * (size_t)9 * (W + 2) * 4;
     const dim3 grid(N * p.segs), block(256);
-#define CO4_LAUNCH(HV, TP) hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP>), grid, block, lds, s, p)
+#define CO4_LAUNCH(HV, TP) { if (x_bf16) hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
+                             else hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }
     const int tpw = W / 64;
-    if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4); else if (tpw == 2) CO4_LAUNCH(4, 2); else CO4_LAUNCH(4, 1); }
-    else { if (tpw == 4) CO4_LAUNCH(2, 4); else if (tpw == 2) CO4_LAUNCH(2, 2); else CO4_LAUNCH(2, 1); }
+    if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4) else if (tpw == 2) CO4_LAUNCH(4, 2) else CO4_LAUNCH(4, 1) }
+    else { if (tpw == 4) CO4_LAUNCH(2, 4) else if (tpw == 2) CO4_LAUNCH(2, 2) else CO4_LAUNCH(2, 1) }
 #undef CO4_LAUNCH
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

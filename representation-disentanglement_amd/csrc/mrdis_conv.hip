@@ -1235,7 +1235,8 @@ int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const flo
 int mrdis_run_dgrad_s2(const float* dy, int lddy, const float* w_tkc, float* dx, int lddx, int N, int H, int W, int Ci, int Co,
                        int kh, int kw, int stride, int pad, hipStream_t s);
 // mrdis_co4.hip: 3x3 s1 p1 with 4 output channels: window-free GEMM + tap gather
-int mrdis_run_co4(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s);
+int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s,
+                  int x_bf16 = 0, int wld = 4);
 // mrdis_c16.hip: 3x3 s1 p1 with 16 output channels, filter in registers
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu, hipStream_t s);
 int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, int lddx, long long npix, int Ci, int Co, int x16_bf16, hipStream_t s);
@@ -1250,7 +1251,9 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!x || !w_tck || !y || ldx < Ci || ldy < Co) return MRDIS_EINVAL;
-    if (dtype == MRDIS_DT_XBF16_YF32) {       // mixed storage, bf16 in / fp32 out: the 1x1 decoder head (16 -> <= 8)
+    if (dtype == MRDIS_DT_XBF16_YF32) {       // mixed storage, bf16 in / fp32 out: the 1x1 decoder head (16 -> <= 8); the 3x3 C -> 4 layer (ana_dec.output)
+        if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 4)       // w_tck is the [9][Ci][16] layout (columns >= 4 zero), bias 4 (or 16) floats
+            return mrdis_run_co4(x_, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream, 1, 16);
         if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
         return mrdis_run_pw_fwd(x_, ldx, w_tck, bias, y, ldy, (long long)N * H * W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, 1, (hipStream_t)stream);
     }
@@ -1302,13 +1305,18 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
 extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_tkc, const void* w_bf16_tck,
                                      void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
                                      int kh, int kw, int stride, int pad, int dtype, const float* w_wino, void* stream) {
-    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32) return MRDIS_EUNSUPPORTED;
+    if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
     int rc = check_conv_geom(N, H, W, Ci, Co, kh, kw, stride, pad, &Ho, &Wo);
     if (rc) return rc;
     if (!dy || !w_tkc || !dx || lddy < Co || lddx < Ci) return MRDIS_EINVAL;
+    if (dtype == MRDIS_DT_XF32_YBF16) {       // bf16 storage, dy bf16 -> dx fp32: the data gradient of the 4 -> C si_layers (a C -> 4 convolution of dy with the
+        // taps reversed); w_tkc is the [9][Co][16] layout (columns >= 4 zero)
+        if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4) || !dy_ || !w_tkc || !dx_) return MRDIS_EUNSUPPORTED;
+        return mrdis_run_co4(dy_, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, 1, 16);
+    }
     if (dtype == MRDIS_DT_XBF16_YF32) {       // bf16 storage, dy fp32 -> dx bf16: the 1x1 head (<= 8 -> 16 channels) and the C <- 4 layer (ana_dec.output)
         if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 4) {
             // dx of a Ci -> 4 layer: a 4 -> Ci convolution of the fp32 dy with the taps reversed, bf16 out; w_tkc is [9][16][Ci] (rows >= 4 zero: the

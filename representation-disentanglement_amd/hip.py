@@ -511,6 +511,8 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     y, ldy = nhwc(out)
     assert y.data_ptr() == out.data_ptr(), 'conv2d_fwd: `out` must already be an NHWC view'
     mixed = _dt_xy(x, y)
+    if mixed == DT_XBF16_YF32 and kh == 3 and Co == 16 and out.shape[1] == 4:
+        Co = 4                       # the C -> 4 layer with its filter in the column-padded [9][Ci][16] layout (ana_dec.output under bf16 storage)
     assert T == kh * kw and (Ci2 == Ci or (mixed == DT_XF32_YBF16 and Ci2 == max(Ci, 16))), (w_tck.shape, x.shape, kh, kw)
     if mixed in (DT_XBF16_YF32, DT_XF32_YBF16):
         rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), None, _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
@@ -539,21 +541,24 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
 
 def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None, w_wino=None, may_decline=False):
     """w_bf16: bf16 [T][Ci][Co] copy (the data gradient reduces over Co).  out: a dense NHWC (N, Ci, H, W) view to write into.
-    Mixed storage (fp32 dy, bf16 out: the 1x1 head; the 3x3 C <- 4 layer with the filter in its 16-row layout [9][16][Ci]) has only
-    its dedicated kernels: may_decline returns None instead of raising outside them."""
+    Mixed storage (fp32 dy, bf16 out: the 1x1 head; the 3x3 C <- 4 layer with the filter in its 16-row layout [9][16][Ci]; bf16 dy, fp32
+    out: the si_layers' 4 <- C data gradient with the filter as [9][Co][16]) has only its dedicated kernels: may_decline returns None
+    instead of raising outside them."""
     lib = load()
     dy, lddy = nhwc(dy)
     N, Co, Ho, Wo = dy.shape
     T, Co2, Ci = w_tkc.shape
     H, W = in_hw
     mixed = out is not None and out.dtype != dy.dtype
+    if mixed and kh == 3 and Ci == 16 and out.shape[1] == 4:
+        Ci = 4                       # the si_layers' data gradient with the filter in the column-padded [9][Co][16] layout (bf16 dy -> fp32 dx: MRDIS_DT_XF32_YBF16)
     assert (Co2 == Co or (mixed and Co2 == 16 and Co == 4 and kh == 3)) and conv_out_hw(H, W, kh, kw, stride, pad) == (Ho, Wo)
     if out is None:
         dx = empty_nhwc(N, Ci, H, W, dy.device, dy.dtype); ldo = Ci
     else:
         dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
         assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W)
-        if mixed:                    # bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32)
+        if mixed:                    # bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32), or dy bf16 -> dx fp32 (MRDIS_DT_XF32_YBF16)
             rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, _stream())
             if rc == -2 and may_decline:
                 return None

@@ -721,7 +721,12 @@ class _GroupedConvFn(Function):
             # fp32 -> bf16 view cast, zero channels up to 16; the si_layers make it only when a kernel asks for it
             xin = None if (si4 and stride == 1) else hip.cast_view(x, torch.bfloat16, Ci_p)
         y = hip.empty_nhwc(G * B, Co_p, Ho, Wo, x.device, torch.float32 if head else (torch.bfloat16 if st else x.dtype))
-        use_tkc, wbs = [], []
+        # the C -> 4 layer (ana_dec.output) under bf16 storage: the window-free 4-cout kernel reads the bf16 map and writes the fp32 result itself
+        # (MRDIS_DT_XBF16_YF32) -- no 16-channel bf16 intermediate, no slicing cast
+        y4 = None
+        if st and Co == 4 and Co_p == 16 and not head and (kh, kw, pad, stride) == (3, 3, 1, 1) and not lrelu and xin is not None and xin.dtype == torch.bfloat16:
+            y4 = hip.empty_nhwc(G * B, 4, Ho, Wo, x.device, torch.float32)
+        use_tkc, wbs, filt_p = [], [], []
         for g in range(G):
             tck, tkc = filt[2 * g], filt[2 * g + 1]
             bg = bias
@@ -740,10 +745,17 @@ class _GroupedConvFn(Function):
                 if bias is not None and bias.shape[0] < Co_p:
                     bg = _pad_bias16(bias, Co_p, detach=True)
             use_tkc.append(tkc); wbs.append(wb_b)
+            filt_p.append((tck, bg, wb_f))
             if si4 and stride == 1 and hip.conv2d_fwd(x if share_x else x[g * B:(g + 1) * B], tck, bg, kh, kw, 1, pad, out=y[g * B:(g + 1) * B], may_decline=True) is not None:
                 continue
             if xin is None:
                 xin = hip.cast_view(x, torch.bfloat16, Ci_p)
+            if y4 is not None:
+                if hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, 3, 3, 1, 1, out=y4[g * B:(g + 1) * B], may_decline=True) is not None:
+                    continue
+                y4 = None                                     # outside the kernel's shapes: the padded bf16 kernel for every group
+                for g2 in range(g):
+                    hip.conv2d_fwd(xin if share_x else xin[g2 * B:(g2 + 1) * B], filt_p[g2][0], filt_p[g2][1], kh, kw, stride, pad, lrelu, out=y[g2 * B:(g2 + 1) * B], w_bf16=filt_p[g2][2])
             hip.conv2d_fwd(xin if share_x else xin[g * B:(g + 1) * B], tck, bg, kh, kw, stride, pad, lrelu, out=y[g * B:(g + 1) * B], w_bf16=wb_f)
         ctx.meta = (G, B, share_x, kh, kw, pad, lrelu, hip.DT_F32_BF16M if bm else hip.DT_F32, Ci, Co, Ci_p, Co_p, x.dtype, padded, Cif, Cof)
         ctx.stride = stride
@@ -755,6 +767,8 @@ class _GroupedConvFn(Function):
         ctx.xshape = (x.shape[2], x.shape[3])
         ctx.ydtype = y.dtype
         ctx.save_for_backward(xin, y if lrelu else None, *use_tkc)
+        if y4 is not None:
+            return y4
         return y if Co_p == Co else hip.cast_view(y, torch.float32, Co)       # a padded head leaves as fp32 (the losses read it)
 
     @staticmethod
@@ -781,7 +795,15 @@ class _GroupedConvFn(Function):
             xdt = xin.dtype
         need_x = ctx.needs_input_grad[0]
         dxb = None
-        if need_x:
+        dx4 = None
+        if need_x and x32 is not None and dy.dtype == torch.bfloat16 and tkcs[0].shape[2] == 16:
+            # si_layers: dx of the 4-channel fp32 map straight from the window-free 4-cout kernel on the bf16 gradient (MRDIS_DT_XF32_YBF16)
+            dx4 = hip.empty_nhwc(G * B, 4, H, W, dy.device, torch.float32)
+            for g in range(G):
+                if hip.conv2d_bwd_data(dy[g * B:(g + 1) * B], tkcs[g], (H, W), 3, 3, 1, 1, out=dx4[g * B:(g + 1) * B], may_decline=True) is None:
+                    dx4 = None
+                    break
+        if need_x and dx4 is None:
             if ctx.dx_in_gb and not share_x and Ci_p == Ci and xin is not None and xin.dtype == x_dtype:
                 # the input is the modulated map of a fused SPADE node (ops._GbSpadeFn): its gradient is also the beta half of that node's
                 # [dgamma | dbeta] buffer -- write it there, the node then fills in the other half (hip.gb_slot)
@@ -794,7 +816,7 @@ class _GroupedConvFn(Function):
         dws, db_total = [], None
         for g in range(G):
             dyg = dy[g * B:(g + 1) * B]
-            if need_x:
+            if need_x and dx4 is None:
                 # ana_dec.output (C -> 4): fp32 dy x reversed taps on the Cin = 4 kernel with a bf16 output (MRDIS_DT_XBF16_YF32), else the bf16 MFMA kernel
                 if dy4 is None or dxb.dtype != torch.bfloat16 or hip.conv2d_bwd_data(dy4[g * B:(g + 1) * B], tkcs[g], (H, W), 3, 3, 1, 1, out=dxb[g * B:(g + 1) * B],
                                                                                       may_decline=True) is None:
@@ -826,7 +848,9 @@ class _GroupedConvFn(Function):
             if s_ is not None:
                 s_.add_(db_total); db_total = None
         dx = None
-        if need_x:
+        if need_x and dx4 is not None:
+            dx = dx4.permute(0, 2, 3, 1).reshape(G, B, H, W, 4).sum(0).permute(0, 3, 1, 2) if (share_x and G > 1) else dx4
+        elif need_x:
             # a shared input collects the gradients of all G uses: one reduction over the group axis
             dx = dxb.permute(0, 2, 3, 1).reshape(G, B, H, W, Ci_p).sum(0).permute(0, 3, 1, 2) if share_x else dxb
             if dx.dtype != x_dtype or Ci_p != Ci:

@@ -1269,3 +1269,37 @@ def test_small_map_direct_conv_split_k(mrdis, case):
             dx0 = hip.conv2d_bwd_data(cl(gy), to_tkc(w).to(dev()), (H, W), k, k, s, p)
         close(got, got0, rtol=2e-6, what='split-K vs plain tiles, fwd')
         close(dx, dx0, rtol=2e-6, what='split-K vs plain tiles, dgrad')
+
+
+@pytest.mark.parametrize('case', [(2, 64, 256, 256, False), (4, 32, 128, 128, True), (16, 64, 64, 64, True), (3, 32, 100, 256, False)],
+                         ids=lambda c: 'N%d_C%d_%dx%d_%s' % (c[0], c[1], c[2], c[3], 'dgrad' if c[4] else 'fwd'))
+def test_four_cout_kernel_on_bf16_input(mrdis, case):
+    """conv3x3_co4_kernel<.., XB>: the window-free 4-cout convolution reading a bf16 map (a lane's 16-byte load = eight channels, widened in
+    registers) with the filter in the column-padded [9][C][16] layout -- forward of the C -> 4 layer (MRDIS_DT_XBF16_YF32: bf16 x, fp32 y) and
+    data gradient of the 4 -> C si_layers (MRDIS_DT_XF32_YBF16: bf16 dy, fp32 dx, taps reversed): torch fp32 on the same bf16-valued operand
+    to fp32 rounding, and the fp32 kernel on the widened input likewise (only the order of the channel sum differs)."""
+    hip = mrdis.hip
+    N, C, H, W, dgrad = case
+    B16 = torch.bfloat16
+    if not dgrad:
+        x = rnd((N, C, H, W), 31).bfloat16(); w = rnd((4, C, 3, 3), 32, 0.1); b = rnd((4,), 33, 0.1)
+        want = F.conv2d(x.float(), w, b, 1, 1)
+        tck16 = F.pad(to_tck(w), (0, 12)).contiguous().to(dev())                 # [9][C][16]
+        b16 = F.pad(b, (0, 12)).to(dev())
+        out = hip.empty_nhwc(N, 4, H, W, dev(), torch.float32)
+        got = hip.conv2d_fwd(cl(x.float()).to(B16), tck16, b16, 3, 3, 1, 1, out=out, may_decline=True)
+        assert got is not None
+        close(got, want, rtol=2e-5, what='C -> 4 forward on bf16 input vs torch')
+        ref = hip.conv2d_fwd(cl(x.float()), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
+        close(got, ref, rtol=2e-6, what='vs the fp32 kernel on the widened input')
+    else:
+        w = rnd((C, 4, 3, 3), 34, 0.1)                                            # the 4 -> C layer
+        dy = rnd((N, C, H, W), 35).bfloat16()
+        want = torch.nn.grad.conv2d_input((N, 4, H, W), w, dy.float(), 1, 1)
+        tkc16 = F.pad(to_tkc(w), (0, 12)).contiguous().to(dev())                  # [9][C][16]
+        out = hip.empty_nhwc(N, 4, H, W, dev(), torch.float32)
+        got = hip.conv2d_bwd_data(cl(dy.float()).to(B16), tkc16, (H, W), 3, 3, 1, 1, out=out, may_decline=True)
+        assert got is not None
+        close(got, want, rtol=2e-5, what='4 <- C data gradient on bf16 dy vs torch')
+        ref = hip.conv2d_bwd_data(cl(dy.float()), to_tkc(w).to(dev()), (H, W), 3, 3, 1, 1)
+        close(got, ref, rtol=2e-6, what='vs the fp32 kernel on the widened gradient')

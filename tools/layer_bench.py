@@ -120,7 +120,15 @@ def main():
                 def f_dgrad():
                     g = hip.conv2d_bwd_data(hip.cast_view(dys, B16, cop), wkp, (hi, wi), k, k, s, p, w_bf16=wbb)
                     return g if cip == ci else hip.cast_view(g, torch.float32, ci)
-                if co == 4 and k == 3 and s == 1 and ci % 16 == 0:      # C -> 4 (ana_dec.output): the data gradient's Cin = 4 kernel reads the fp32 dy, bf16 out
+                if ci == 4 and k == 3 and s == 1:       # si_layers' data gradient: the 4-cout kernel reads the bf16 gradient, fp32 out (maps 64 .. 256 wide)
+                    dx4 = hip.empty_nhwc(B, 4, hi, wi, dev, torch.float32)
+                    if hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dx4, may_decline=True) is not None:
+                        f_dgrad = lambda: hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dx4, may_decline=True)      # noqa: E731
+                if co == 4 and k == 3 and s == 1 and ci % 16 == 0:      # C -> 4 (ana_dec.output): forward on the 4-cout kernel (bf16 in, fp32 out)
+                    y4 = hip.empty_nhwc(B, 4, ho, wo, dev, torch.float32)
+                    if hip.conv2d_fwd(xs, wtp, bp, k, k, s, p, out=y4, may_decline=True) is not None:
+                        f_fwd = lambda: hip.conv2d_fwd(xs, wtp, bp, k, k, s, p, out=y4, may_decline=True)      # noqa: E731
+                if co == 4 and k == 3 and s == 1 and ci % 16 == 0:      # ... and its data gradient's Cin = 4 kernel reads the fp32 dy, bf16 out
                     dxo4 = hip.empty_nhwc(B, ci, hi, wi, dev, B16)
                     if hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True) is not None:
                         f_dgrad = lambda: hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True)      # noqa: E731
