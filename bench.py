@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native hot path.
 
     python bench.py [--gpus N --steps K --warmup W]           # N = 1
@@ -59,6 +58,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
+    ap.add_argument('--roofline-only', action='store_true', help='only the roofline legs (north-star conv + the dominant kernels of the step), '
+                                                                 'no training step: what tools/profile_round.sh profiles separately from the step')
     return ap.parse_args()
 
 
@@ -282,6 +283,10 @@ def main():
     # the step's dominant kernels at the step's shapes (before the model exists: 1.6 GB of operands of their own)
     rstep = roofline_step(mrdis, dev, B, H, W, a.dtype) if (rank == 0 and not a.no_roofline) else None
     torch.cuda.empty_cache()
+    if a.roofline_only:
+        assert world == 1
+        print(json.dumps({'roofline': roofline_conv(mrdis, dev), 'roofline_step': rstep}), flush=True)
+        return
     torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21; same init on every rank
     model = mrdis.build_model(cfg).train()
     step = mrdis.TrainStep(model, cfg)

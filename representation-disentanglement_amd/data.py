@@ -117,13 +117,34 @@ class SliceDataset:
 class BatchLoader:
     """DataLoader(dataset, batch_size, shuffle, num_workers=0) of util.py:706-708; yields the reference's sample dict
     with device tensors: inputs (B, 7M, H, W) channels_last, targets (B, 1, H, W), mask (B, M), mask_img (B, H, W),
-    subj_id (list), slice_idx (B,)."""
+    subj_id (list), slice_idx (B,).
 
-    def __init__(self, dataset, batch_size, shuffle=False):
+    Data parallel (`world` > 1; the reference is single-device, main_missing.py:28): every rank walks the SAME batch sequence
+    -- the permutation and the per-item drop-off draws of ALL batches are made on every rank, in the single-process order, so
+    the host generators stay in step across the ranks -- and rank r assembles batches r, r + world, r + 2 world, ...
+    `equal_steps` (the train loader): the ragged tail is dropped -- incomplete batches, then whole batches beyond the last full
+    round of `world` -- so every rank runs the same number of optimizer steps on full batches (the gradient exchange is a
+    collective; BatchNorm and the roll-by-one negatives of sim_s / sim_z want B >= 2 on every rank).  Without it (val / test
+    loaders: no collective inside a batch) every batch is served, ranks may differ by one batch.  `generator`: a
+    torch.Generator the permutation seeds are drawn from instead of the default one (the entry point hands every rank an
+    identically seeded one, so that the default generator can be seeded per rank for the noise of `sample`)."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, rank=0, world=1, equal_steps=False, generator=None):
+        if not 0 <= rank < world:
+            raise ValueError(f'rank {rank} outside world {world}')
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.rank, self.world, self.equal_steps, self.generator = rank, world, equal_steps, generator
+
+    def global_batches(self):
+        """number of batches all ranks walk together per epoch."""
+        n, bs = len(self.dataset), self.batch_size
+        if self.world > 1 and self.equal_steps:
+            return n // bs // self.world * self.world
+        return (n + bs - 1) // bs
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        g = self.global_batches()
+        return (g - self.rank + self.world - 1) // self.world if g > self.rank else 0
 
     def _order(self):
         n = len(self.dataset)
@@ -131,21 +152,28 @@ class BatchLoader:
             return list(range(n))
         # DataLoader.__iter__ draws its `_base_seed` from the default generator first (used only by worker processes),
         # then RandomSampler.__iter__ (generator=None) draws the seed of the permutation on the first next()
-        torch.empty((), dtype=torch.int64).random_()
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        torch.empty((), dtype=torch.int64).random_(generator=self.generator)
+        seed = int(torch.empty((), dtype=torch.int64).random_(generator=self.generator).item())
         g = torch.Generator()
         g.manual_seed(seed)
         return torch.randperm(n, generator=g).tolist()
 
-    def __iter__(self):
+    def batch_plan(self):
+        """host half of an epoch: yields (global batch index, dataset indices, item metas) of THIS rank's batches."""
         order = self._order()
+        ds = self.dataset
+        for k in range(self.global_batches()):
+            idxs = order[k * self.batch_size:(k + 1) * self.batch_size]
+            metas = [ds.meta(i) for i in idxs]                        # every rank: the drop-off draws advance np.random for all batches
+            if k % self.world == self.rank:
+                yield k, idxs, metas
+
+    def __iter__(self):
         ds, st = self.dataset, self.dataset.store
         H, W, D = st.shape
         M, blk = len(ds.contrast_list), ds.block_size
         dev = st.device
-        for i0 in range(0, len(order), self.batch_size):
-            idxs = order[i0:i0 + self.batch_size]
-            metas = [ds.meta(i) for i in idxs]
+        for k, _, metas in self.batch_plan():
             B = len(metas)
             host = torch.empty((B, M + 3), dtype=torch.int64).pin_memory() if dev.type == 'cuda' else torch.empty((B, M + 3), dtype=torch.int64)
             mask_host = np.zeros((B, M), dtype=np.float32)                 # host twin of `mask`: the losses branch on it without a sync
@@ -163,4 +191,5 @@ class BatchLoader:
             if ds.dataset_name == 'BraTS':
                 targets = torch.where(targets == 4, torch.full_like(targets, 3.0), targets)      # util.py:533
             yield {'inputs': inputs, 'targets': targets, 'subj_id': [m[0] for m in metas],
-                   'slice_idx': slice_idx.to(torch.int64), 'mask': mask, 'mask_img': mask_img, 'mask_host': mask_host}
+                   'slice_idx': slice_idx.to(torch.int64), 'mask': mask, 'mask_img': mask_img, 'mask_host': mask_host,
+                   'batch_index': k}

@@ -7,6 +7,9 @@ hand-written gfx950 kernels of libmrdis_hip.so (see ops.py / hip.py).
 
 Reference quirks that parity depends on are reproduced and marked `QUIRK`.
 """
+import copy
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -145,17 +148,20 @@ def Conv2d(is_cond):
     return CondConv2d if is_cond else HipConv2d
 
 
-_BN_PENDING = set()          # BatchNorm2d modules whose num_batches_tracked is behind by `_nbt_pending` calls
+_BN_PENDING = weakref.WeakSet()   # BatchNorm2d modules whose num_batches_tracked is behind by `_nbt_pending` calls (weak: a discarded model is not kept alive)
 
 
 def flush_batch_counters():
-    """bring every BatchNorm2d.num_batches_tracked up to date (one fused add over all pending layers)"""
+    """bring every BatchNorm2d.num_batches_tracked up to date (one fused add over all pending layers).  Called at the end of a
+    TrainStep, by EvalStep, and by every way of reading the buffer out of a module: state_dict(), train(False) / eval(),
+    deepcopy (EMA copies) and pickling (torch.save(model))."""
     if not _BN_PENDING:
         return
-    mods = [m for m in _BN_PENDING if getattr(m, '_nbt_pending', 0) and m.num_batches_tracked is not None]
+    pend = list(_BN_PENDING)
+    mods = [m for m in pend if getattr(m, '_nbt_pending', 0) and m.num_batches_tracked is not None]
     if mods:
         torch._foreach_add_([m.num_batches_tracked for m in mods], [int(m._nbt_pending) for m in mods])
-    for m in _BN_PENDING:
+    for m in pend:
         m._nbt_pending = 0
     _BN_PENDING.clear()
 
@@ -171,6 +177,23 @@ class BatchNorm2d(nn.BatchNorm2d):
         self._nbt_pending = 0
         _BN_PENDING.discard(self)
         super()._load_from_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        if not mode:
+            flush_batch_counters()
+        return super().train(mode)
+
+    def __deepcopy__(self, memo):
+        flush_batch_counters()                     # the copy starts with an exact counter and nothing pending
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        flush_batch_counters()
+        return super().__getstate__() if hasattr(super(), '__getstate__') else self.__dict__
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

@@ -366,8 +366,8 @@ class _MixAllLayers(Function):
                 acc[k, mm] = g.data_ptr() + 4 * col0
         dev_tab = to_device(ptrs, types.device)
         hip.mix_jobs_bwd(plan.table_for_current_sinks(), plan.njobs, plan.blocks, dev_tab, types)
-        if _GROUP_READY is not None:
-            _GROUP_READY(plan.ready_params)            # in-kernel sinks fire no autograd hook: the exchange of this group's buckets starts here
+        for fn in tuple(_GROUP_READY.values()):
+            fn(plan.ready_params)                      # in-kernel sinks fire no autograd hook: the exchange of this group's buckets starts here
         return (None, None) + (None,) * (len(plan.params))
 
 
@@ -383,15 +383,17 @@ def wino_images(w_tck):
     return hit[1] if hit is not None else {}
 
 
-_GROUP_READY = None
+_GROUP_READY = {}           # key -> fn: one entry per armed trainer.GradAllReduce (two reducers in a process do not overwrite each other)
 
 
-def set_group_ready_hook(fn):
+def set_group_ready_hook(fn, key=None):
     """fn(list of parameters) is called from the backward of each all-layers mixing node, right after its launches: the gradients of
     those parameters (in-kernel sinks, which fire no post-accumulate hook) are complete in stream order.  trainer.GradAllReduce
-    starts the all-reduce of the buckets they fill from here.  None removes the hook."""
-    global _GROUP_READY
-    _GROUP_READY = fn
+    starts the all-reduce of the buckets they fill from here.  `key` names the subscriber; fn = None removes its hook."""
+    if fn is None:
+        _GROUP_READY.pop(key, None)
+    else:
+        _GROUP_READY[key] = fn
 
 
 def premix_all(model, table, group=None, roots=None):

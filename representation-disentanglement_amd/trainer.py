@@ -421,9 +421,13 @@ class GradAllReduce:
     compute stream idles for the exchange (`exposed_ms`) -- the number of buckets that had left before finish()
     (`early_buckets`) and the bytes reduced."""
 
-    def __init__(self, optim, group=None, buckets=6):
+    def __init__(self, optim, group=None, buckets=6, force_exchange=False):
+        """force_exchange: issue the collectives even in a group of one rank (the sum over one rank is the identity, so the
+        weights must not change by a bit): the way to run the RCCL code path -- async all-reduce of arena slices from the
+        autograd thread, the waits on the compute stream, the gate-flag tail -- on a box with a single GPU."""
         self.optim, self.group, self.nbuckets = optim, group, buckets
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchanging = self.world > 1 or (force_exchange and dist.is_initialized())
         self.target = optim
         self.handles = []
         self.hooks = []
@@ -486,7 +490,7 @@ class GradAllReduce:
         gradients a rank's backward produces first may depend on its batch (a modality missing from a rank's whole batch prunes
         that decoder's loss terms): buckets therefore leave strictly in index order -- the arena is laid out in completion order,
         so in the common case that IS the order in which they complete."""
-        if self.world == 1 or self.ready[b]:
+        if not self.exchanging or self.ready[b]:
             return
         self.ready[b] = True
         t = self.target
@@ -511,13 +515,20 @@ class GradAllReduce:
             self.done = set()
         self.handles = []
         self.armed = True
-        ops.set_group_ready_hook(self.mark_ready)
+        ops.set_group_ready_hook(self.mark_ready, key=id(self))
+
+    def abort(self):
+        """backward() raised: disarm (a later backward on this rank must not issue collectives the other ranks never
+        issue) and forget the outstanding handles -- the step is lost, the caller re-raises."""
+        self.armed = False
+        ops.set_group_ready_hook(None, key=id(self))
+        self.handles = []
 
     def finish(self):
         """call after backward(); returns the scale (1/world) the optimizer must apply."""
         self.armed = False
-        ops.set_group_ready_hook(None)
-        if self.world == 1:
+        ops.set_group_ready_hook(None, key=id(self))
+        if not self.exchanging:
             return 1.0
         self.calls += 1
         if not self.hooks:                       # arena built lazily, first step: reduce per tensor
@@ -645,7 +656,7 @@ class TrainStep:
     discriminator step uses the d-loss of the iteration on which the optimizers step.
     """
 
-    def __init__(self, model, config, ddp_group=None, ddp_buckets=6):
+    def __init__(self, model, config, ddp_group=None, ddp_buckets=6, force_exchange=False):
         self.model, self.config = model, config
         ops.set_compute_dtype(config.get('compute_dtype', 'f32'))
         self.accum = max(1, 16 // config['batch_size'])                                          # :282 (guarded for B > 16)
@@ -659,7 +670,7 @@ class TrainStep:
             if used is None:
                 raise RuntimeError('the adversarial step needs a model with a static trainable-parameter list')
             self.optimizer_d_s = ArenaAdam(model.parameters(), lr=config['lr'], weight_decay=0.0, share_weights_of=self.optimizer)
-        self.reducer = GradAllReduce(self.optimizer, ddp_group, ddp_buckets) \
+        self.reducer = GradAllReduce(self.optimizer, ddp_group, ddp_buckets, force_exchange=force_exchange) \
             if (dist.is_available() and dist.is_initialized()) else None
         self.acc = None                          # accumulated (already reduced, clipped) gradient when accum > 1
         self.iter = 0
@@ -678,20 +689,15 @@ class TrainStep:
             loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, targets=targets)
             if opt.used is not None and opt.n_flags:
                 opt.mark_active(ops.to_device(torch.from_numpy(model.active_decoders(mask_host)), mask.device))
-            if self.reducer:
-                self.reducer.begin(opt)
-            loss.backward(retain_graph=adv and do_step)                                          # :268-271
-            scale = self.reducer.finish() if self.reducer else 1.0
+            scale = self._backward(loss, opt, retain_graph=adv and do_step)                      # :268-271
             if adv and do_step:
                 # discriminator-loss gradients on the same (un-stepped) graph, into optimizer_d_s' own buffer
                 od = self.optimizer_d_s
                 od.attach_grads()
-                if self.reducer:
-                    self.reducer.begin(od)
-                parts['adv_s_d'].backward()
-                if self.reducer:
-                    self.reducer.finish()
-                opt.attach_grads()
+                try:
+                    self._backward(parts['adv_s_d'], od)
+                finally:
+                    opt.attach_grads()
         if opt.used is None:
             opt._build()
         opt.check_new_grads()
@@ -718,6 +724,21 @@ class TrainStep:
         flush_batch_counters()                                                                   # BatchNorm2d.num_batches_tracked of this step's calls, one launch
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
 
+    def _backward(self, loss, target, retain_graph=False):
+        """backward() with the gradient exchange armed around it; returns the scale the optimizer applies (1 / world).  A
+        backward that raises leaves the reducer disarmed and its mid-backward hook removed."""
+        red = self.reducer
+        if red is None:
+            loss.backward(retain_graph=retain_graph)
+            return 1.0
+        red.begin(target)
+        try:
+            loss.backward(retain_graph=retain_graph)
+        except BaseException:
+            red.abort()
+            raise
+        return red.finish()
+
     def losses_to_host(self, parts):
         """the 11 scalars of main_missing.py:253-263 in one D2H copy."""
         vec = torch.stack([parts[k].float().reshape(()) for k in LOSS_KEYS]).cpu()
@@ -741,6 +762,7 @@ class EvalStep:
         if mask_host is None:
             mask_host = mask.cpu()
         was = model.training
+        flush_batch_counters()
         model.eval()
         try:
             with ops.mix_cache():

@@ -55,3 +55,15 @@ def data_lists():
         for k in range(4):
             subj.append(f'BraTS20_Training_{s:03d}'); idx.append(DATA_SLICES[(3 * s + 5 * k) % len(DATA_SLICES)])
     return subj, idx
+
+
+def dump_measured(name, rec, mode='a'):
+    """opt-in record of measured margins: written only when MRDIS_DUMP_MEASURED names a directory (tests do not write into the tree)."""
+    import json
+    import os
+    d = os.environ.get('MRDIS_DUMP_MEASURED')
+    if not d:
+        return
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), mode) as f:
+        f.write(json.dumps(rec) + '\n')

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_model as R                                   # noqa: E402
-from fixtures import make_inputs, make_seg_targets, reinit_discriminator, seeded   # noqa: E402
+from fixtures import dump_measured, make_inputs, make_seg_targets, reinit_discriminator, seeded   # noqa: E402
 
 
 @pytest.fixture(scope='module')
@@ -161,12 +161,7 @@ def test_train_step_golden(mrdis, golden_dir, tag):
     ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
     assert abs(total - ref_total) <= 1e-3 * ref_total, (total, ref_total)
     worst = max((abs(gn[k] - v) / (v + 4e-3 * ref_total), k) for k, v in hot.items())
-    try:
-        os.makedirs('gpurun_out', exist_ok=True)
-        with open('gpurun_out/f32_golden_measured.jsonl', 'a') as f:
-            f.write(json.dumps(dict(tag=tag, worst_per_tensor=worst[0], tensor=worst[1], total_rel=abs(total - ref_total) / ref_total)) + '\n')
-    except OSError:
-        pass
+    dump_measured('f32_golden_measured.jsonl', dict(tag=tag, worst_per_tensor=worst[0], tensor=worst[1], total_rel=abs(total - ref_total) / ref_total))
     for k, v in hot.items():
         assert abs(gn[k] - v) <= PER_TENSOR_A[tag] * (v + 4e-3 * ref_total), (k, gn[k], v)
     # clip + Adam on the arena vs the reference's weights after optimizer.step()
@@ -725,12 +720,7 @@ def test_train_step_bf16_compute_vs_fp32_golden(mrdis, golden_dir, tag, mode):
         rec = dict(tag=tag, mode=mode, loss_rel=abs(float(loss) - meta['loss']) / abs(meta['loss']),
                    parts_rel={k: abs(float(parts[k]) - v) / (abs(v) + 1e-4) for k, v in meta['parts'].items()},
                    gnorm_rel=abs(total - ref_total) / ref_total, per_tensor_p98=pt[int(0.98 * (len(pt) - 1))], per_tensor_max=pt[-1])
-        try:
-            os.makedirs('gpurun_out', exist_ok=True)
-            with open('gpurun_out/bf16_golden_measured.jsonl', 'a') as f:
-                f.write(json.dumps(rec) + '\n')
-        except OSError:
-            pass
+        dump_measured('bf16_golden_measured.jsonl', rec)
         assert rec['loss_rel'] <= BF16_TOL['loss'], rec
         assert abs(float(loss) - meta['loss']) > 1e-7 * abs(meta['loss'])          # not the fp32 path
         for k, v in rec['parts_rel'].items():

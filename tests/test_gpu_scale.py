@@ -15,6 +15,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from fixtures import dump_measured   # noqa: E402
+
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
 B, HW = 32, 256
@@ -444,13 +446,7 @@ def test_full_step_at_bench_scale_bf16(mrdis):
     rec = dict(loss_bf16=l_b, loss_f32=l_f, loss_rel=abs(l_b - l_f) / abs(l_f), gnorm_bf16=g_b, gnorm_f32=g_f, gnorm_rel=abs(g_b - g_f) / g_f,
                parts_rel={k_: abs(p_b[k_] - p_f[k_]) / (abs(p_f[k_]) + 1e-12) for k_ in p_f if abs(p_f[k_]) > 0},
                w_mean_abs_diff=float((w_b - w_f).abs().mean()))
-    try:
-        import json, os
-        os.makedirs('gpurun_out', exist_ok=True)
-        with open('gpurun_out/bf16_scale_measured.json', 'w') as f:
-            json.dump(rec, f)
-    except OSError:
-        pass
+    dump_measured('bf16_scale_measured.json', rec, mode='w')
     # measured when written (round 3): loss 6.9e-5, gradient norm 1.6e-3, recon_x / recon_x_mix 9e-7, sim_z 7e-8, latent_z 8.6e-4,
     # sim_s 1.4e-3, adv_s / adv_s_d 6.6e-5
     assert rec['loss_rel'] <= 3.5e-4, rec

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A/B two builds of libmrdis_hip.so in ONE process on ONE device (devices and boxes differ by several
 percent, so timings from separate gpurun calls do not compare):
     python tools/ab_lib.py libA.so libB.so [--shape N Ci H W Co] [--iters 50] [--rounds 5]

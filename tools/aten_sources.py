@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where the small ATen ops of a training step's FORWARD come from (their autograd counterparts run on the engine's thread and roughly mirror
 them): a TorchDispatchMode records every non-view aten op with the innermost frame inside this package, over one step at a small shape."""
 import collections

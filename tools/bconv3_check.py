@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bf16-storage 3x3 convolution: the pipelined kernel (bconv3_kernel, option wino_pipe = 1) against bconv_kernel (wino_pipe = 0):
 bit-identical results expected (same products, same accumulation order); time per call forward / data gradient."""
 import os

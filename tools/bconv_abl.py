@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing-only ablations of the bf16 convolution kernels (library built with -DBCONV_ABLATIONS -DBCONV3_ABLATIONS; option debug_mode selects)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bf16-storage weight gradient: the pipelined kernel (bwgrad2_kernel, option wino_pipe = 1) against bwgrad_kernel (wino_pipe = 0):
 bit-identical results expected; time per call."""
 import os

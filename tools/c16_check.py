@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of sp6.out (32 -> 16, 3x3, 256x256, B = 32): mrdis_c16.hip against tapconv16_kernel (option debug_now16 = 1)."""
 import os
 import sys

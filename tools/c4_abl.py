@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing-only ablations of c4conv_kernel (builds with -DC4_ABL_NOSTORE / _NOMFMA / _NOLOAD, tools/micro/libmrdis_*.so) against the product
 library, fp32-out and bf16-out, in one process:  x (32, 4, 256, 256) fp32 -> y (32, 32, 256, 256)."""
 import ctypes, os, sys

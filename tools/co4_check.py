@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of the 4-cout 3x3 layers (ana_dec.output forward 64 -> 4 at 256x256; si_layers data gradients 32 -> 4 at 256x256, 64 -> 4 at
 128x128), B = 32: mrdis_co4.hip against tapconv16_kernel<., THIN4> (option debug_now16 = 1)."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Launch mrdis_conv2d_fwd (3x3 s1 p1) a few times on one shape: target for PMC passes.
     python tools/conv_once.py N Ci H W Co [iters]"""
 import os, sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Batch assembly: HBM-resident store + gather kernel vs the CPU restatement of the reference's loader
 (oracle/ref_data.py: numpy slicing / concatenate / collate, then the H2D copy the training loop does).
 BraTS geometry: 160x192x155 volumes, 4 contrasts, block 3, batch 32."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dispatches per training step by kernel family from a rocprofv3 kernel_stats.csv:  dispatch_counts.py <kernel_stats.csv> <steps>"""
 import collections
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the streaming (non-conv) kernels at the bench shapes and report achieved HBM bandwidth
 (algorithmic bytes / time): bilinear fwd/bwd, SPADE fwd/bwd, BatchNorm fwd/bwd.  EW_DTYPE=bf16: bf16 activation views (bytes counted at 2 per element)."""
 import os

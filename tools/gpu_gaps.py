@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """GPU idle time between kernels from a rocprofv3 kernel trace:  gpu_gaps.py <kernel_trace.csv>
 Prints busy time, span and the gap histogram of the busiest 60 % of the trace (the timed steps)."""
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-layer timing of the conv entry points at the bench configuration (B=32, M=4, 256x256):
 every distinct (Ci, Co, k, stride, H, W) of the hot path, forward / data-gradient /
 weight-gradient, HIP events on the launch stream.  Prints a table sorted by the layer's

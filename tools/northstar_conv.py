@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Launch only the north-star 3x3 conv forward (x 32x4x240x240 -> 32 ch, fp32 NHWC) a few times:
 the target of the PMC (FETCH_SIZE / WRITE_SIZE) passes whose result bench.py reports as
 `roofline.traffic`."""

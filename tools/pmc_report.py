@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Turn the two counter passes of tools/pmc_sq.sh into the MFMA-utilisation table kept under profiles/.
 
     python tools/pmc_report.py gpurun_out/pmc_<tag> "<title>" >> profiles/<file>.md

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A/B of the all-layers mixing launches (ops.premix_all) against the per-layer launches on one training step: loss, every parameter's
 gradient (bit-identical expected: same kernels' bodies, same order) and the dispatch / timing effect."""
 import os

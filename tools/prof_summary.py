@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Condense rocprofv3 CSV output into the small summaries committed under profiles/.
 
   prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title]
@@ -34,7 +33,10 @@ def stats(stats_csv, trace_csv, out, title):
     agg = collections.defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for r in csv.DictReader(open(trace_csv)):
         name = r['Kernel_Name'].split('(')[0][:60]
-        key = (name, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['LDS_Block_Size'], r['VGPR_Count'])
+        wgs = 1
+        for ax in 'XYZ':                               # grid sizes are in work-items per axis: workgroups = product over the three axes
+            wgs *= max(1, int(r.get(f'Grid_Size_{ax}', 1) or 1)) // max(1, int(r.get(f'Workgroup_Size_{ax}', 1) or 1))
+        key = (name, wgs, r['LDS_Block_Size'], r['VGPR_Count'])
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         a = agg[key]; a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     lines += ['', '## per (kernel, workgroups) from kernel_trace.csv (top 40 by total time)', '',

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of the 1x1 decoder head (16 -> 7 at 256x256, B = 32): streaming kernels (mrdis_pointwise.hip) against the generic tile kernels
 (option debug_now16 = 1)."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Sweep tapconv block configurations (cout tile BN x channel chunk KC x staging mode x positions-per-workgroup policy)
 per layer shape, fwd and dgrad, through the library's MRDIS_DEBUG_{BN,KC,MODE,BM} knobs."""
 import os, sys, itertools

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bf16 forward / data gradient of the small-map layers under tile-shape overrides (option debug_mode = 0: the big tiles everywhere, as before the small-map policy)."""
 import os, sys
 import torch

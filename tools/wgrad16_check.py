@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of sp6.out's weight gradient (32 -> 16, 3x3, 256x256, B = 32): wgrad16_kernel."""
 import os
 import sys

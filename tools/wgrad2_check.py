@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A/B of the pipelined Winograd weight-gradient kernel (wino_pipe = 1) against the phase-by-phase one and the direct kernels."""
 import os
 import sys

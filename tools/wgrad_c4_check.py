@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of the si_layers weight gradients (4 -> C, 3x3 s1) at B = 32: wgrad_c4_kernel against wgrad_thin_dma_kernel (option debug_now16 = 1)."""
 import os
 import sys

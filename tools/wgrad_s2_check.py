@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of the stride-2 first-layer weight gradients (mrdis_wgrad_s2.hip) against the generic split-K kernel (option now16 = 1),
 at the bench geometry: x = one modality's 7 channels of the (32, 28, 256, 256) batch tensor."""
 import os

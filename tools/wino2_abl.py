@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing-only ablations of wino2_kernel (library built with -DWINO2_ABLATIONS; option debug_mode selects the variant)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A/B of the software-pipelined Winograd kernel (option wino_pipe = 1, mrdis_wino2.hip) against the phase-by-phase one
 (wino_pipe = 0) and the direct kernel (wino = 0): max relative difference and time per call, forward and data gradient."""
 import os
