@@ -67,6 +67,7 @@ def test_single_rank_rccl_group_runs_every_collective_and_changes_nothing(mrdis)
         assert quiet.reducer is not None and not quiet.reducer.exchanging and quiet.reducer.exposed_ms()['bytes_reduced'] == 0
         # timing diagnostics: the event pair around the waits on the compute stream
         _, _, timed = _run(mrdis, dev, 1, 16, 'f32', True)
+        timed.reducer.exposed_ms()                                      # reset the counters of the step _run took
         timed.reducer.timing = True
         x, mask, mask_img = mrdis.synthetic_batch(4, 3, 64, 96, seed=3, drop=True)
         timed(x.to(dev).contiguous(memory_format=torch.channels_last), mask.to(dev), mask_img.to(dev), mask)
