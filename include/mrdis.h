@@ -52,6 +52,13 @@ int mrdis_version(void);
  *   "wino_pipe" (MRDIS_WINO_PIPE, default 1): 1 = the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip: forward / data
  *           gradient for Cout > 32, weight gradient for Ci, Co multiples of 64), 0 = the phase-by-phase kernels everywhere
  *           (same arithmetic; results agree to 1e-5);
+ *   "wino_u" (MRDIS_WINO_U, default 1): 1 = the pipelined kernels read the pre-transformed filter image a caller passes (w_wino), 0 = they
+ *           always transform the taps themselves (F(2x2): bit-identical either way; also keeps the F(4x4) kernel, which has no in-kernel
+ *           filter transform, out);
+ *   "wino4" (MRDIS_WINO4, default 1): 1 = Winograd F(4x4,3x3) (csrc/mrdis_wino4.hip: 1.78x fewer multiplies than F(2x2), results within
+ *           ~5e-6 of the maximum of the direct kernel's) for the 3x3 stride-1 filters mrdis_wino_u_format() names -- >= 32 reduction channels
+ *           (multiple of 8), >= 64 couts -- where the caller passes the filter image and the launch fills >= 3/4 of the chip; 0 = never
+ *           (F(2x2) everywhere); 2 = wherever that kernel applies (tests).  Read when a filter image is BUILT: set it before the images;
  *   "debug_now16" (MRDIS_DEBUG_NOW16, default 0): 1 = the dedicated narrow-layer kernels off -- Cout <= 16 weight gradient
  *           (mrdis_wgrad16.hip), stride-2 first layers and 4 -> C weight gradient (mrdis_wgrad_s2.hip), 1x1 head (mrdis_pointwise.hip),
  *           16-cout and 4-cout 3x3 layers (mrdis_c16.hip, mrdis_co4.hip): the generic tile kernels run those layers (tests and
@@ -160,7 +167,8 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
 #define MRDIS_DT_XBF16_YF32 3
 #define MRDIS_DT_XF32_YBF16 4
 /* w_wino (fp32 paths, may be NULL): the filter already in the Winograd domain, the image mrdis_wino_u_jobs builds from w_tck (role:
- * forward) -- used where the software-pipelined F(2x2,3x3) kernel takes the layer, ignored elsewhere; same results bit for bit. */
+ * forward) -- used where a software-pipelined Winograd kernel takes the layer, ignored elsewhere.  Format 2 (F(2x2,3x3)): same results
+ * bit for bit with or without it; format 4 (mrdis_wino_u_format): selects the F(4x4,3x3) kernel, which exists only on the image. */
 int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                      void* y, int ldy, int N, int H, int W, int Ci, int Co,
                      int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, void* stream);
@@ -168,12 +176,16 @@ int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_b
 /* ---- filter images for the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip).  U = G g G^T of a 3x3 filter does not depend
  * on the activations; a training step uses each mixed filter 8-16 times, so the transform is taken out of the convolution kernels:
  * one launch over a job table builds, per (filter, role), the 16-point image in the order the kernel's (input-channel chunk, 64-cout
- * tile) walk consumes it: [cout tile][chunk of 8][8][4][64][4] floats, zero-padded.  Job (`WinoUJob`, mrdis_wino_u_job_bytes() = 40):
- *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk; }
+ * tile) walk consumes it: [cout tile][chunk of 8][8][4][64][4] floats, zero-padded (format 2); format 4 is the 36-point image of the
+ * F(4x4,3x3) kernel, [cout tile][chunk of 4][18 point pairs][4][128] floats (csrc/mrdis_wino4.h).  mrdis_wino_u_format(R, S, spadeC) says
+ * which of the two a filter gets (a function of the filter's shape and the option "wino4" alone).
+ * Job (`WinoUJob`, mrdis_wino_u_job_bytes() = 48):
+ *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk, fmt, pad; }        fmt = mrdis_wino_u_format(R, S, spadeC)
  * w = [9][R][S]: role forward: w_tck, R = Ci, S = Co, flip = 0; role data gradient: w_tkc, R = Co, S = Ci, flip = 1; role SPADE (the fused
  * gamma | beta filter of mrdis_conv2d_fwd_spade): w_tck, R = Ci, S = 2 C, spadeC = C.  img: mrdis_wino_u_image_floats(R, S, spadeC) floats,
  * 16-byte aligned.  block0 / nblk: the job's block range (mrdis_wino_u_job_blocks each), total_blocks = their sum.                     */
 size_t mrdis_wino_u_job_bytes(void);
+int mrdis_wino_u_format(int R, int S, int spadeC);
 long long mrdis_wino_u_image_floats(int R, int S, int spadeC);
 int mrdis_wino_u_job_blocks(int R, int S, int spadeC);
 int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream);

@@ -1180,8 +1180,20 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
 // software-pipelined variant for Cout > 32 (mrdis_wino2.hip); option wino_pipe = 0 keeps the phase-by-phase kernel everywhere
 int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img);
+// F(4x4, 3x3) (mrdis_wino4.hip): takes the layers whose filter image is of format 4 (mrdis_wino_u_format; the image carries the flip, so
+// forward and data gradient are the same call); MRDIS_EUNSUPPORTED where its shape limits / grid test decline
+int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
+                    hipStream_t s, const float* u_img);
+int mrdis_wino_u_fmt(int R, int S, int spadeC);
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr) {
+    if (u_img && mrdis_wino_u_fmt(Ci, Co, 0) == 4) {
+        if (mrdis_opt(MRDIS_OPT_WINO_U)) {
+            const int rc = mrdis_run_wino4(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
+            if (rc != MRDIS_EUNSUPPORTED) return rc;
+        }
+        u_img = nullptr;                               // an F(4x4) image is of no use to the F(2x2) kernels: they transform the taps themselves
+    }
     if (Co > 32 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {
         const int rc = mrdis_run_wino2(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s, u_img);
         if (rc != MRDIS_EUNSUPPORTED) return rc;

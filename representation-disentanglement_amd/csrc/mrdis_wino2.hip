@@ -21,6 +21,7 @@
 //   half-wave (16 m x 2 kq) cover 64 distinct banks, and the transform writes (lane = (ks, 32 m)) are 64 consecutive words.
 //   raw block: channel planes [8][18 rows][24] + 8 floats between planes (planes 4 apart sit 32 banks apart).
 #include "mrdis_common.h"
+#include "mrdis_wino4.h"
 
 struct Wino2Params {
     const float* in; const float* w; const float* bias; float* out;
@@ -488,12 +489,32 @@ int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* 
 // fused gamma | beta filter of a SPADE block: R = Ci, S = 2 C, spadeC = C -- the cout order of wino2_kernel<.., SPADE>).  A thread builds the
 // sixteen points of one (reduction channel, cout slot) pair with the expressions of the in-kernel transform (u_col / u_out), so the
 // pipelined kernel computes the same values either way (option wino_u = 0 / 1 is bit-identical).
-struct WinoUJob { const float* w; float* img; int R, S, flip, spadeC, block0, nblk; };
+struct WinoUJob { const float* w; float* img; int R, S, flip, spadeC, block0, nblk, fmt, pad_; };   // fmt: 2 = the image above, 4 = mrdis_wino4.h
 
 __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;                       // last job with block0 <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const WinoUJob j = jobs[lo];
+    if (j.fmt == 4) {
+        // F(4x4, 3x3) image (mrdis_wino4.h): one thread = one (reduction channel, cout slot) pair = 36 values
+        const int nch4 = (j.R + MRDIS_W4_KC - 1) / MRDIS_W4_KC, tiles4 = (j.S + 63) / 64;
+        const long long total4 = (long long)tiles4 * nch4 * MRDIS_W4_KC * 64;
+        for (long long i = ((long long)blockIdx.x - j.block0) * 256 + threadIdx.x; i < total4; i += (long long)j.nblk * 256) {
+            const int m = (int)(i & 63), kq = (int)((i >> 6) & 3);
+            const long long tc = i >> 8;              // cot * nch4 + chunk
+            const int c = (int)(tc % nch4), cot = (int)(tc / nch4);
+            const int r = c * MRDIS_W4_KC + kq, co = cot * 64 + m;
+            const bool ok = r < j.R && co < j.S;
+            float gr[9], U[36];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gr[t] = ok ? j.w[((long long)(j.flip ? 8 - t : t) * j.R + r) * j.S + co] : 0.f;
+            mrdis_w4_filter_transform(gr, U);
+            float* dst = j.img + tc * MRDIS_W4_UCHUNK + kq * 128;
+#pragma unroll
+            for (int pt = 0; pt < 36; ++pt) dst[(pt >> 1) * MRDIS_W4_UPP + ((2 * m + (pt & 1) + 32 * kq) & 127)] = U[pt];
+        }
+        return;
+    }
     const int nch = (j.R + KC - 1) / KC;
     const int tiles = j.spadeC ? (j.spadeC + 31) / 32 : (j.S + 63) / 64;
     const long long total = (long long)tiles * nch * KC * 64;
@@ -527,13 +548,18 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
 
 extern "C" size_t mrdis_wino_u_job_bytes(void) { return sizeof(WinoUJob); }
 static long long wino_u_elems(int R, int S, int spadeC) {
+    if (mrdis_wino_u_fmt(R, S, spadeC) == 4) return (long long)((S + 63) / 64) * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_KC * 64;
     const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
     return (long long)tiles * ((R + KC - 1) / KC) * KC * 64;
 }
-extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) { return 16 * wino_u_elems(R, S, spadeC); }
+extern "C" int mrdis_wino_u_format(int R, int S, int spadeC) { return mrdis_wino_u_fmt(R, S, spadeC); }
+extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) {
+    return (mrdis_wino_u_fmt(R, S, spadeC) == 4 ? 36 : 16) * wino_u_elems(R, S, spadeC);
+}
 extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
     const long long b = (wino_u_elems(R, S, spadeC) + 255) / 256;
-    return (int)(b > 64 ? 64 : (b < 1 ? 1 : b));
+    const int cap = mrdis_wino_u_fmt(R, S, spadeC) == 4 ? 128 : 64;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 extern "C" int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
     if (!jobs || njobs < 1 || total_blocks < njobs) return MRDIS_EINVAL;

@@ -1,0 +1,412 @@
+// mrdis_wino4.hip -- fused Winograd F(4x4, 3x3) convolution for gfx950 (MI355X), fp32, NHWC: forward and data gradient of the
+// 3x3 / stride 1 / pad 1 layers with >= 64 couts (reference: F.conv2d inside CondConv2d._conv_forward, model.py:2104-2117).
+//
+// F(2x2, 3x3) (mrdis_wino2.hip) executes 16 multiplies per 4 outputs, F(4x4, 3x3) 36 per 16: 1.78x fewer MFMAs for the same
+// layer, at transforms that cost about the same per output (the 6x6 input transform is 12 FMAs per 6 values, the output transform
+// 10 per 4).  Y = A^T [(G g G^T) .* (B^T d B)] A with the interpolation points 0, +-1, +-2, inf; everything is fp32 (exact-fp32 MFMA
+// `v_mfma_f32_16x16x4_f32`); the transforms multiply by 2, 4, 5, 8 and (filter side, once per step) 1/4, 1/6, 1/12, 1/24, which moves the
+// result by ~5e-6 of its maximum against 1e-6 for the direct kernel (tests/test_gpu_wino4.py; the parity bar is 1e-3).
+//
+// Workgroup = 8 waves = 32 tiles (4 x 8 tiles = 16 x 32 outputs) x 64 couts; wave = 16 tiles x 16 couts for ALL 36 points: 144
+// accumulator registers (two waves per SIMD leave 256).  One iteration = one 4-channel chunk = ONE k-step: 36 MFMAs per wave, the A
+// operand (two points of U) and the B operand (two points of V) one ds_read_b64 each per two MFMAs.  Pipeline, one barrier per iteration:
+//     iteration i:   36 MFMAs on U(i), V(i)                                                          all waves
+//                    V(i+1) = B^T d B from the raw block in LDS (72 VALU + 15 reads + 9 writes per thread)   waves 0-3 ("T")
+//                    U(i+1): nine 1-KiB LDS-DMA pieces per wave straight from the filter image (no VGPRs)    waves 4-7 ("S")
+//                    raw block of the next 8-channel double chunk: global loads (odd i) / LDS stores (even i)  waves 4-7
+// A SIMD hosts one T and one S wave, so the VALU-heavy transform and the memory-side staging share its issue slots.
+// LDS: U 2 x 36 KB + V 2 x 18 KB + raw 2 x 22.5 KB + bias 2 KB = 155 KB, one persistent workgroup per CU walking (block, chunk)
+// pairs, so a block's prologue hides under its predecessor's MFMAs.
+//
+// LDS images (conflict-free without padding):
+//   U / V point pair pp (points 2 pp, 2 pp + 1): [4 channels kq][128 | 64 slots]; slot of (cout | tile m, parity) =
+//     (2 m + parity + 32 kq) & (127 | 63): a half-wave's b64 operand reads (16 m x 2 kq) cover 64 distinct banks.
+//   raw block: channel planes [8][18 rows][40] with rows of tile-row group g = row / 4 shifted by 2 * ((g >> 1) & 1) floats: the
+//     b64 reads of a transform wave (8 tile columns x 4 tile rows, row i of each tile) then hit {0, 32, 2, 34} + 4 tx: 64 distinct banks.
+#include "mrdis_common.h"
+#include "mrdis_wino4.h"
+
+struct Wino4Params {
+    const float* in; const float* bias; float* out; const float* u_img;
+    int N, H, W, Cin, ldin, Cout, ldout;
+    int lrelu, nt_out;
+    int nby, nbx, coTiles, nblk;      // 16 x 32-output blocks per image, 64-cout tiles, blocks in total
+    unsigned in_bytes;                // record count of the input's buffer descriptor
+};
+
+namespace {
+constexpr int NT4 = 512;
+constexpr int KC4 = MRDIS_W4_KC;
+constexpr int UPP = MRDIS_W4_UPP, UBUF = MRDIS_W4_UCHUNK;      // 512, 9216 floats
+constexpr int VPP = 256, VBUF = 18 * VPP;                      // 4608 floats
+constexpr int RWP = 40, PL = 18 * RWP, RAWBUF = 8 * PL;        // 720, 5760 floats
+constexpr int RBW = 34, RBH = 18, NITEM = RBW * RBH * 2;       // raw block: 18 x 34 pixels x two 4-channel quads
+constexpr int NIT = (NITEM + 255) / 256;                       // staging items per S thread (5)
+constexpr int BIAS4 = 512;
+constexpr size_t W4_LDS = sizeof(float) * (2 * UBUF + 2 * VBUF + 2 * RAWBUF + BIAS4);
+template <int V_> struct IC4 { static constexpr int value = V_; };
+typedef unsigned u32x4_w4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int w4_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
+constexpr unsigned W4_OOB = 0xfffffff0u;
+__device__ __forceinline__ int w4_skew(int g) { return 2 * ((g >> 1) & 1); }
+}  // namespace
+
+// ABL (timing-only builds, results wrong): 1 no V transform, 4 no MFMAs, 8 no filter DMA, 32 no raw loads
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ub = smem;                           // [2][18][UPP]
+    float* const Vb = smem + 2 * UBUF;                // [2][18][VPP]
+    float* const Rb = Vb + 2 * VBUF;                  // [2][8][PL]
+    float* const Bs = Rb + 2 * RAWBUF;                // [BIAS4]
+
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, tg = wave >> 2;
+    // MFMA role: A = U rows (couts 16 cg + l16), B = V columns (tiles 16 tg + l16), k = channel kq of the chunk
+    const int a_off = kq * 128 + ((2 * (16 * cg + l16) + 32 * kq) & 127);
+    const int b_off = kq * 64 + ((2 * (16 * tg + l16) + 32 * kq) & 63);
+    // The two roles keep their per-thread state in the SAME registers (a wave is a T wave or an S wave for the whole launch; the role
+    // branches are wave-uniform): ro[] = role constants, sc[] = T: patch rows d (30), B^T d (18), one output row (6) | S: the NIT staged float4
+    // T role (waves 0-3): rows 3 rh .. 3 rh + 2 of V for tile m_t, channel kq_t of the chunk
+    //   ro[0] = v_lo, ro[1] = v_hi (patch rows 0-3 / 4-5: the tile-row groups ty / ty + 1 carry different skews), ro[2] = t_dst
+    // S role (waves 4-7): NIT (pixel, quad) items of the 18 x 34 x 8-channel raw block
+    //   ro[it] = LDS offset of item it, ro[NIT + it] = byte offset of its pixel in the current block (W4_OOB: outside the image)
+    const int rh = wave & 1;
+    const int st = tid - 256;
+    int ro[2 * NIT];
+    float sc[54];
+    if (wave < 4) {
+        const int m_t = lane & 31, kq_t = 2 * ((wave >> 1) & 1) + (lane >> 5);
+        const int ty_t = m_t >> 3, tx_t = m_t & 7;
+        ro[0] = kq_t * PL + 4 * ty_t * RWP + w4_skew(ty_t) + 4 * tx_t;
+        ro[1] = kq_t * PL + 4 * ty_t * RWP + w4_skew(ty_t + 1) + 4 * tx_t;
+        ro[2] = kq_t * 64 + ((2 * m_t + 32 * kq_t) & 63);
+#pragma unroll
+        for (int it = 3; it < 2 * NIT; ++it) ro[it] = 0;
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = st + 256 * it, pi = idx >> 1, ry = pi / RBW, rx = pi - ry * RBW;
+            // an item beyond the block (the tail of the last round) stores into the unused columns 36-39 of row 0: no branch around a store
+            ro[it] = idx < NITEM ? 4 * (idx & 1) * PL + ry * RWP + w4_skew(ry >> 2) + rx : 36 + (lane & 3);
+            ro[NIT + it] = (int)W4_OOB;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 54; ++k) sc[k] = 0.f;
+#define W4_VLO ro[0]
+#define W4_VHI ro[1]
+#define W4_TDST ro[2]
+#define W4_SL(it) ro[it]
+#define W4_XG(it) ro[NIT + (it)]
+#define W4_D(ii, j) sc[6 * (ii) + (j)]
+#define W4_R(a, j) sc[30 + 6 * (a) + (j)]
+#define W4_VO(k) sc[48 + (k)]
+#define W4_XR(it, c) sc[4 * (it) + (c)]
+
+    const int grid = gridDim.x;
+    const int rb0 = mrdis_xcd_remap(blockIdx.x, grid);
+    const int nmine = (p.nblk - rb0 + grid - 1) / grid;           // host: grid <= nblk
+    const int nch = p.Cin / KC4;                                  // host: Cin % 8 == 0
+    const int total = nmine * nch;
+    auto decode = [&](int j, int& n, int& oy0, int& ox0, int& cot) {
+        int b = rb0 + j * grid;
+        cot = b % p.coTiles; b /= p.coTiles;
+        const int bx = b % p.nbx; b /= p.nbx;
+        const int by = b % p.nby;
+        n = b / p.nby; oy0 = 16 * by; ox0 = 32 * bx;
+    };
+
+    // ---- S: raw-block cursor.  Every global load is a buffer load whose offset is W4_OOB where there is nothing to read
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    int rj = 0, rc = 0;
+    auto raw_block = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) W4_XG(it) = (int)W4_OOB;
+        if (rj < nmine) {
+            int n, oy0, ox0, cot; decode(rj, n, oy0, ox0, cot);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = st + 256 * it, pi = idx >> 1, ry = pi / RBW, rx = pi - ry * RBW;
+                const int h = oy0 - 1 + ry, w_ = ox0 - 1 + rx;
+                if (idx < NITEM && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                    W4_XG(it) = (int)(4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldin + 4 * (idx & 1)));      // host: < 2^30 elements
+            }
+        }
+    };
+    auto load_raw1 = [&](int it, unsigned c0b) {      // c0b: byte offset of the double chunk's first channel
+        if (ABL & 32) { W4_XR(it, 0) = 0.f; W4_XR(it, 1) = 0.f; W4_XR(it, 2) = 0.f; W4_XR(it, 3) = 0.f; return; }
+        const unsigned xg = (unsigned)W4_XG(it);
+        const u32x4_w4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(xg != W4_OOB ? xg + c0b : W4_OOB), 0, 0);
+        W4_XR(it, 0) = __uint_as_float(v.x); W4_XR(it, 1) = __uint_as_float(v.y); W4_XR(it, 2) = __uint_as_float(v.z); W4_XR(it, 3) = __uint_as_float(v.w);
+    };
+    auto raw_advance = [&]() { if (++rc == nch / 2) { rc = 0; ++rj; raw_block(); } };
+    auto raw_store1 = [&](float* Rw, int it) {
+        float* d_ = Rw + W4_SL(it); d_[0] = W4_XR(it, 0); d_[PL] = W4_XR(it, 1); d_[2 * PL] = W4_XR(it, 2); d_[3 * PL] = W4_XR(it, 3);
+    };
+
+    // ---- S: filter cursor (the image piece of (cout tile, chunk) is one contiguous 36 KB block).  The copies are `global_load_lds_dwordx4`
+    // written as inline assembly: through the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of EVERY later LDS read of the kernel (it
+    // cannot tell which LDS bytes the copy lands on), which serialises the pipeline; inline assembly is invisible to its wait-count pass (the
+    // waits it inserts for the raw-block loads only become stricter, never wrong: vmcnt retires in order), and the S waves wait for their
+    // own copies explicitly before the iteration's barrier.  There is no destination register a late write-back could corrupt.
+    int fj = 0, fc = 0;
+    long long f_base = 0;                             // float offset of chunk 0 of the current block's cout tile (past the end: tile 0 again --
+    auto filt_block = [&]() {                         //  a copy nobody reads -- rather than a branch around the copy)
+        f_base = 0;
+        if (fj < nmine) { int n, oy0, ox0, cot; decode(fj, n, oy0, ox0, cot); f_base = (long long)cot * nch * UBUF; }
+    };
+    const float* f_chunk = p.u_img;                   // wave-uniform: image piece of the NEXT chunk
+    const unsigned f_voff = 16u * (unsigned)lane + 1024u * (unsigned)(wave & 3);        // this lane's bytes inside piece q = (wave - 4) + 4 k
+    const unsigned lds_u = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Ub;
+    auto filt_next = [&]() {
+        f_chunk = p.u_img + f_base + (long long)fc * UBUF;
+        if (++fc == nch) { fc = 0; ++fj; filt_block(); }
+    };
+    auto dma1 = [&](int buf, int k) {                 // piece q = (wave - 4) + 4 k of 36: 1 KiB, lane l lands at U[buf] + 1024 q + 16 l bytes
+        if (ABL & 8) return;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_u + 4u * (unsigned)(buf * UBUF) + 1024u * (unsigned)((wave & 3) + 4 * k));
+        const float* src = f_chunk + 1024 * k;        // + 4 KiB per round of the four S waves
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
+    };
+
+    // ---- T: input transform pieces
+    auto v_row = [&](const float* Rr, int ii, auto RH_) {           // patch row i = RH + ii (Rr: the chunk's channel planes of the raw block)
+        const int row = decltype(RH_)::value + ii;                  // compile-time after unrolling
+        const float* src = Rr + (row < 4 ? W4_VLO : W4_VHI) + row * RWP;
+        const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2), c = *reinterpret_cast<const float2*>(src + 4);
+        W4_D(ii, 0) = a.x; W4_D(ii, 1) = a.y; W4_D(ii, 2) = b.x; W4_D(ii, 3) = b.y; W4_D(ii, 4) = c.x; W4_D(ii, 5) = c.y;
+    };
+    auto v_col = [&](int j, auto RH_) {               // three rows of B^T d in column j: B^T rows 0-2 on patch rows 0-4, rows 3-5 on patch rows 1-5
+        const float e0 = W4_D(0, j), e1 = W4_D(1, j), e2 = W4_D(2, j), e3 = W4_D(3, j), e4 = W4_D(4, j);
+        if constexpr (decltype(RH_)::value == 0) {
+            const float a = fmaf(-4.f, e2, e4), b = fmaf(-4.f, e1, e3);
+            W4_R(0, j) = fmaf(4.f, e0, fmaf(-5.f, e2, e4)); W4_R(1, j) = a + b; W4_R(2, j) = a - b;
+        } else {
+            const float c = e3 - e1, e = e2 - e0;
+            W4_R(0, j) = fmaf(2.f, e, c); W4_R(1, j) = fmaf(-2.f, e, c); W4_R(2, j) = fmaf(4.f, e0, fmaf(-5.f, e2, e4));
+        }
+    };
+    auto v_rowop = [&](int a) {                       // (B^T d) B: the same combination along the row
+        const float r0 = W4_R(a, 0), r1 = W4_R(a, 1), r2 = W4_R(a, 2), r3 = W4_R(a, 3), r4 = W4_R(a, 4), r5 = W4_R(a, 5);
+        const float aa = fmaf(-4.f, r2, r4), bb = fmaf(-4.f, r1, r3), cc = r4 - r2, ee = r3 - r1;
+        W4_VO(0) = fmaf(4.f, r0, fmaf(-5.f, r2, r4)); W4_VO(1) = aa + bb; W4_VO(2) = aa - bb;
+        W4_VO(3) = fmaf(2.f, ee, cc); W4_VO(4) = fmaf(-2.f, ee, cc); W4_VO(5) = fmaf(4.f, r1, fmaf(-5.f, r3, r5));
+    };
+    auto v_put = [&](float* Vn, int a, auto RH_) {    // row 3 RH + a of V: point pairs 3 (3 RH + a) + 0..2
+        constexpr int RH = decltype(RH_)::value;
+        float* vp = Vn + (3 * (3 * RH + a)) * VPP;
+        *reinterpret_cast<float2*>(vp) = make_float2(W4_VO(0), W4_VO(1));
+        *reinterpret_cast<float2*>(vp + VPP) = make_float2(W4_VO(2), W4_VO(3));
+        *reinterpret_cast<float2*>(vp + 2 * VPP) = make_float2(W4_VO(4), W4_VO(5));
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: U(0), V(0) and raw double chunk 0 in LDS, raw double chunk 1 in registers
+    for (int c = tid; c < BIAS4; c += NT4) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+    if (wave >= 4) {
+        raw_block(); filt_block();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) load_raw1(it, 32u * (unsigned)rc);
+        raw_advance();
+        filt_next();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dma1(0, k);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) raw_store1(Rb, it);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) load_raw1(it, 32u * (unsigned)rc);      // double chunk 1: stored at the end of iteration 0
+        raw_advance();
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NIT);      // vmcnt(NIT): the filter pieces have landed, the second raw block may still be in flight
+    }
+    __syncthreads();
+    if (wave < 4) {
+        const float* Rr = Rb;
+        float* Vn = Vb + W4_TDST;
+        if (rh == 0) {
+#pragma unroll
+            for (int ii = 0; ii < 5; ++ii) v_row(Rr, ii, IC4<0>{});
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v_col(j, IC4<0>{});
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { v_rowop(a); v_put(Vn, a, IC4<0>{}); }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 5; ++ii) v_row(Rr, ii, IC4<1>{});
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v_col(j, IC4<1>{});
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { v_rowop(a); v_put(Vn, a, IC4<1>{}); }
+        }
+    }
+    __syncthreads();
+
+    // one iteration g of parity P = g & 1 in role ROLE (0 / 1: T wave, rows 0-2 / 3-5 of V; 2: S wave)
+    auto iteration = [&](auto P_, auto ROLE_, int g) {
+        constexpr int P = decltype(P_)::value, ROLE = decltype(ROLE_)::value;
+        const float* Ua = smem + w4_opaque(P * UBUF + a_off);
+        const float* Va = smem + w4_opaque(2 * UBUF + P * VBUF + b_off);
+        // T: V(g + 1) from channels 4 (P ^ 1) .. + 3 of raw double chunk (g + 1) / 2
+        const float* Rr = smem + w4_opaque(2 * UBUF + 2 * VBUF + (((g + 1) >> 1) & 1) * RAWBUF + (P ^ 1) * 4 * PL);
+        float* Vn = smem + w4_opaque(2 * UBUF + (P ^ 1) * VBUF + W4_TDST);
+        // S: U(g + 1) by DMA; odd g: loads of raw double chunk (g + 3) / 2; even g: LDS stores of raw double chunk g / 2 + 1
+        float* Rw = Rb + (((g >> 1) + 1) & 1) * RAWBUF;
+        unsigned c0b = 0;
+        if constexpr (ROLE == 2) {
+            filt_next();
+            if (P == 1) c0b = 32u * (unsigned)rc;
+        }
+
+        float2 av[3], bv[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            av[s_] = *reinterpret_cast<const float2*>(Ua + s_ * UPP);
+            bv[s_] = *reinterpret_cast<const float2*>(Va + s_ * VPP);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            if (s_ + 2 < 18) {
+                av[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Ua + (s_ + 2) * UPP);
+                bv[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Va + (s_ + 2) * VPP);
+            }
+            if constexpr (ROLE < 2) {
+                if (!(ABL & 1)) {
+                    if (s_ < 5) v_row(Rr, s_, IC4<ROLE>{});
+                    else if (s_ < 11) v_col(s_ - 5, IC4<ROLE>{});
+                    else if (s_ < 17) { if (((s_ - 11) & 1) == 0) v_rowop((s_ - 11) >> 1); else v_put(Vn, (s_ - 11) >> 1, IC4<ROLE>{}); }
+                }
+            } else {
+                if (s_ < 9) dma1(P ^ 1, s_);
+                else if (P == 1) { if (s_ - 9 < NIT) load_raw1(s_ - 9, c0b); }
+                else if (s_ >= 12 && s_ - 12 < NIT) raw_store1(Rw, s_ - 12);
+            }
+            const int c_ = s_ % 3;
+            if (!(ABL & 4)) {
+                acc[2 * s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].x, bv[c_].x, acc[2 * s_], 0, 0, 0);
+                acc[2 * s_ + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, bv[c_].y, acc[2 * s_ + 1], 0, 0, 0);
+            } else { acc[2 * s_][0] += av[c_].x * bv[c_].x; acc[2 * s_ + 1][0] += av[c_].y * bv[c_].y; }
+#pragma unroll
+            for (int g_ = 0; g_ < 2; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // then at most one vector-memory read,
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads,
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // two LDS writes
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // and six VALU instructions in its shadow
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (ROLE == 2) {
+            if (P == 1) { raw_advance(); __builtin_amdgcn_s_waitcnt(0x0F70 | NIT); }       // the DMA pieces are older than the NIT raw loads
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __syncthreads();
+    };
+
+    // the whole chunk loop once per role (a role branch INSIDE the loop makes the 144 accumulators a three-way phi at the loop header: hipcc
+    // then keeps two copies of them and spills ~350 registers)
+    auto run = [&](auto ROLE_) {
+    int mj = 0, mc = 0;
+    for (int g = 0; g < total; g += 2) {
+        iteration(IC4<0>{}, ROLE_, g); iteration(IC4<1>{}, ROLE_, g + 1);
+        mc += 2;
+        if (mc != nch) continue;
+        mc = 0;
+        // ---- epilogue of block mj: lane = tile 16 tg + l16, couts co0 + 16 cg + 4 kq + r;  Y = A^T M A,
+        //      A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+        int n, oy0, ox0, cot; decode(mj, n, oy0, ox0, cot);
+        ++mj;
+        const int co0 = 64 * cot, tile = 16 * tg + l16;
+        const int oy = oy0 + 4 * (tile >> 3), ox = ox0 + 4 * (tile & 7);
+        const int co = co0 + 16 * cg + 4 * kq;
+        const bool full = oy0 + 16 <= p.H && ox0 + 32 <= p.W && co0 + 64 <= p.Cout;          // block-uniform: no per-store tests
+        const f32x4 slope = p.lrelu ? f32x4{0.2f, 0.2f, 0.2f, 0.2f} : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (co < BIAS4 ? co : 0));
+        float* const o00 = p.out + ((long long)(n * p.H + oy) * p.W + ox) * p.ldout + co;
+        const long long rowp = (long long)p.W * p.ldout;
+        // one output row at a time (6 + 4 live vectors instead of 24: the 144 accumulators stay where they are until the last row is out)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 t[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const f32x4 m1 = acc[6 + b], m2 = acc[12 + b], m3 = acc[18 + b], m4 = acc[24 + b];
+                if (i == 0) t[b] = acc[b] + (m1 + m2) + (m3 + m4);
+                else if (i == 1) t[b] = (m1 - m2) + 2.f * (m3 - m4);
+                else if (i == 2) t[b] = (m1 + m2) + 4.f * (m3 + m4);
+                else t[b] = (m1 - m2) + 8.f * (m3 - m4) + acc[30 + b];
+            }
+            const f32x4 s12 = t[1] + t[2], d12 = t[1] - t[2], s34 = t[3] + t[4], d34 = t[3] - t[4];
+            f32x4 y[4];
+            y[0] = t[0] + s12 + s34; y[1] = d12 + 2.f * d34; y[2] = s12 + 4.f * s34; y[3] = d12 + 8.f * d34 + t[5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v = y[k] + b4;
+                v = __builtin_elementwise_max(v, v * slope);          // LeakyReLU(0.2), or the identity
+                float* dst = o00 + i * rowp + k * p.ldout;
+                if (full || (co < p.Cout && oy + i < p.H && ox + k < p.W)) {
+                    if (p.nt_out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                    else *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    };
+    if (wave >= 4) run(IC4<2>{});
+    else if (rh) run(IC4<1>{});
+    else run(IC4<0>{});
+}
+
+// the kernel's shape limits (the policy -- which layers SHOULD take it -- is mrdis_wino_u_fmt + the grid test below)
+int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
+                    hipStream_t s, const float* u_img) {
+    if (!u_img || (((uintptr_t)u_img) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (Ci % 8 != 0 || Ci < 16 || Co < 4 || Co % 4 != 0 || Co > BIAS4 || ldx % 4 != 0 || ldy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W * ldx >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
+    Wino4Params p{};
+    p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
+    p.in = x; p.bias = bias; p.out = y; p.u_img = u_img;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
+    p.lrelu = lrelu;
+    { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
+    p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
+    p.coTiles = mrdis_cdiv(Co, 64);
+    const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    // a persistent workgroup per CU: below ~3/4 of the chip (or on maps that leave most of a 16 x 32 block empty) the F(2x2) kernel's
+    // 16 x 16 blocks fill it better
+    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (nblk < 192 || H < 16 || W < 32)) return MRDIS_EUNSUPPORTED;
+    p.nblk = (int)nblk;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+#ifdef WINO4_ABLATIONS
+#define W4A(a) hipFuncSetAttribute((const void*)wino4_kernel<a>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS);
+        W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45)
+#undef W4A
+#endif
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = nblk < n_cu ? (int)nblk : n_cu;
+#ifdef WINO4_ABLATIONS
+    const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);          // debug_mode doubles as the ablation selector in this build
+#define W4A(a) if (abl == a) { hipLaunchKernelGGL(wino4_kernel<a>, dim3(grid), dim3(NT4), W4_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+    W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45)
+#undef W4A
+#endif
+    hipLaunchKernelGGL(wino4_kernel<0>, dim3(grid), dim3(NT4), W4_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+int mrdis_wino_u_fmt(int R, int S, int spadeC) {
+    if (!mrdis_opt(MRDIS_OPT_WINO4) || spadeC != 0) return 2;
+    return (R % 8 == 0 && R >= 32 && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
+}

@@ -42,6 +42,7 @@ _SIGS = {
     'mrdis_instnorm_stats': (_I, [_P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'mrdis_wino_u_job_bytes': (_Z, []),
+    'mrdis_wino_u_format': (_I, [_I, _I, _I]),
     'mrdis_wino_u_image_floats': (_L, [_I, _I, _I]),
     'mrdis_wino_u_job_blocks': (_I, [_I, _I, _I]),
     'mrdis_wino_u_jobs': (_I, [_P, _I, _I, _P]),
@@ -282,7 +283,13 @@ class MixJob(_c.Structure):
 class WinoUJob(_c.Structure):
     """csrc/mrdis_wino2.hip `WinoUJob`: one (filter, role) of the Winograd filter-image launch (include/mrdis.h)."""
     _fields_ = [('w', _c.c_void_p), ('img', _c.c_void_p), ('R', _c.c_int), ('S', _c.c_int), ('flip', _c.c_int), ('spadeC', _c.c_int),
-                ('block0', _c.c_int), ('nblk', _c.c_int)]
+                ('block0', _c.c_int), ('nblk', _c.c_int), ('fmt', _c.c_int), ('pad_', _c.c_int)]
+
+
+def wino_u_format(R, S, spadeC=0):
+    """2: the F(2x2,3x3) image (csrc/mrdis_wino2.hip), 4: the F(4x4,3x3) image (csrc/mrdis_wino4.hip) -- a function of the filter's shape and
+    the option 'wino4' alone, so the image built once per step fits every call of the layer."""
+    return int(load().mrdis_wino_u_format(R, S, spadeC))
 
 
 def wino_u_table(jobs, device):
@@ -290,6 +297,8 @@ def wino_u_table(jobs, device):
     nb = _c.sizeof(WinoUJob)
     if nb != lib.mrdis_wino_u_job_bytes():
         raise MrdisError(f'WinoUJob layout mismatch: binding {nb} bytes, library {lib.mrdis_wino_u_job_bytes()}')
+    for j in jobs:
+        j.fmt = wino_u_format(j.R, j.S, j.spadeC)
     arr = (WinoUJob * len(jobs))(*jobs)
     host = torch.frombuffer(bytearray(_c.string_at(_c.addressof(arr), nb * len(jobs))), dtype=torch.uint8)
     return host.to(device)
