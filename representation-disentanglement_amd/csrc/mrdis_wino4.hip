@@ -46,6 +46,12 @@ constexpr int BIAS4 = 512;
 constexpr size_t W4_LDS = sizeof(float) * (2 * UBUF + 2 * VBUF + 2 * RAWBUF + BIAS4);
 template <int V_> struct IC4 { static constexpr int value = V_; };
 typedef unsigned u32x4_w4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_w4 __attribute__((ext_vector_type(2)));
+// 8-byte LDS accesses that stay 8-byte accesses: volatile keeps hipcc from pairing neighbours into ds_read2_b64 / ds_write2st64_b64 (half the
+// rate of two ds_read_b64, banked by 32 where these images are laid out for the 64-bank rule of the 8-byte forms: 0.5 conflict cycles per LDS
+// instruction measured); the explicit LDS address space keeps a volatile access from becoming a flat one
+__device__ __forceinline__ f32x2_w4 w4_ld2(const float* p) { return *(const volatile __attribute__((address_space(3))) f32x2_w4*)p; }
+__device__ __forceinline__ void w4_st2(float* p, f32x2_w4 v) { *(volatile __attribute__((address_space(3))) f32x2_w4*)p = v; }
 __device__ __forceinline__ int w4_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
 constexpr unsigned W4_OOB = 0xfffffff0u;
 __device__ __forceinline__ int w4_skew(int g) { return 2 * ((g >> 1) & 1); }
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     auto v_row = [&](const float* Rr, int ii, auto RH_) {           // patch row i = RH + ii (Rr: the chunk's channel planes of the raw block)
         const int row = decltype(RH_)::value + ii;                  // compile-time after unrolling
         const float* src = Rr + (row < 4 ? W4_VLO : W4_VHI) + row * RWP;
-        const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2), c = *reinterpret_cast<const float2*>(src + 4);
+        const f32x2_w4 a = w4_ld2(src), b = w4_ld2(src + 2), c = w4_ld2(src + 4);
         W4_D(ii, 0) = a.x; W4_D(ii, 1) = a.y; W4_D(ii, 2) = b.x; W4_D(ii, 3) = b.y; W4_D(ii, 4) = c.x; W4_D(ii, 5) = c.y;
     };
     auto v_col = [&](int j, auto RH_) {               // three rows of B^T d in column j: B^T rows 0-2 on patch rows 0-4, rows 3-5 on patch rows 1-5
@@ -197,9 +203,9 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     auto v_put = [&](float* Vn, int a, auto RH_) {    // row 3 RH + a of V: point pairs 3 (3 RH + a) + 0..2
         constexpr int RH = decltype(RH_)::value;
         float* vp = Vn + (3 * (3 * RH + a)) * VPP;
-        *reinterpret_cast<float2*>(vp) = make_float2(W4_VO(0), W4_VO(1));
-        *reinterpret_cast<float2*>(vp + VPP) = make_float2(W4_VO(2), W4_VO(3));
-        *reinterpret_cast<float2*>(vp + 2 * VPP) = make_float2(W4_VO(4), W4_VO(5));
+        w4_st2(vp, f32x2_w4{W4_VO(0), W4_VO(1)});
+        w4_st2(vp + VPP, f32x2_w4{W4_VO(2), W4_VO(3)});
+        w4_st2(vp + 2 * VPP, f32x2_w4{W4_VO(4), W4_VO(5)});
     };
 
     f32x4 acc[36];
@@ -261,17 +267,17 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
             if (P == 1) c0b = 32u * (unsigned)rc;
         }
 
-        float2 av[3], bv[3];
+        f32x2_w4 av[3], bv[3];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
-            av[s_] = *reinterpret_cast<const float2*>(Ua + s_ * UPP);
-            bv[s_] = *reinterpret_cast<const float2*>(Va + s_ * VPP);
+            av[s_] = w4_ld2(Ua + s_ * UPP);
+            bv[s_] = w4_ld2(Va + s_ * VPP);
         }
 #pragma unroll
         for (int s_ = 0; s_ < 18; ++s_) {
             if (s_ + 2 < 18) {
-                av[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Ua + (s_ + 2) * UPP);
-                bv[(s_ + 2) % 3] = *reinterpret_cast<const float2*>(Va + (s_ + 2) * VPP);
+                av[(s_ + 2) % 3] = w4_ld2(Ua + (s_ + 2) * UPP);
+                bv[(s_ + 2) % 3] = w4_ld2(Va + (s_ + 2) * VPP);
             }
             if constexpr (ROLE < 2) {
                 if (!(ABL & 1)) {
@@ -408,5 +414,9 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
 
 int mrdis_wino_u_fmt(int R, int S, int spadeC) {
     if (!mrdis_opt(MRDIS_OPT_WINO4) || spadeC != 0) return 2;
-    return (R % 8 == 0 && R >= 32 && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
+    // measured (tools/wino4_check.py, B = 32): 64 -> 128 at 128x128 349 -> 299 us forward / 323 -> 271 us data gradient, 128 -> 256 at 64x64 322 -> 210 /
+    // 321 -> 205, 128 -> 64 at 64x64 85 -> 68 / 88 -> 74, 64 -> 64 at 128x128 171 -> 149 / 172 -> 158; 32 reduction channels (8 chunks per block: the
+    // output transform + stores come round too often) 386 -> 387: no gain; < 64 couts leave half of the 64-cout tile empty
+    const int rmin = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
+    return (R % 8 == 0 && R >= rmin && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
 }

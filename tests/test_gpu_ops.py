@@ -1159,6 +1159,7 @@ def test_winograd_filter_image(mrdis, R, S, flip, C):
     zero-padded; roles forward (flip 0), data gradient (flip 1: taps reversed) and SPADE (the fused gamma | beta cout order) -- against the
     transform written out in torch."""
     hip = mrdis.hip
+    hip.set_option('wino4', 0)                      # the 16-point format for every filter (the 36-point one: tests/test_gpu_wino4.py)
     w = rnd((9, R, S), 77)
     n = hip.wino_u_image_floats(R, S, C)
     img = torch.full((n,), float('nan'), device=dev())

@@ -170,8 +170,11 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
     m = mrdis
     H = W = HW
     res = {}
-    for mode in ((1, 0), (0, 0), (1, 1), (1, 0, 'no_u')):  # (wino, debug_now16): default policy | direct kernels only | narrow-layer kernels off | wino_u = 0
-        m.hip.set_option('wino', mode[0]); m.hip.set_option('debug_now16', mode[1]); m.hip.set_option('wino_u', 0 if len(mode) > 2 else 1)
+    # (wino, debug_now16[, tag]): default policy (F(4x4,3x3) on the wide 3x3 layers, F(2x2,3x3) elsewhere) | direct kernels only | narrow-layer kernels
+    # off | F(2x2) only (wino4 = 0) with the filter images | F(2x2) only, filters transformed in the kernels (wino_u = 0)
+    for mode in ((1, 0), (0, 0), (1, 1), (1, 0, 'f2'), (1, 0, 'f2_no_u')):
+        m.hip.set_option('wino', mode[0]); m.hip.set_option('debug_now16', mode[1])
+        m.hip.set_option('wino4', 0 if len(mode) > 2 else 1); m.hip.set_option('wino_u', 0 if mode[2:] == ('f2_no_u',) else 1)
         cfg = dict(m.DEFAULT_CONFIG); cfg.update(input_height=H, input_width=W, batch_size=B, lambda_adv_s=1.0, is_patch_gan=True)
         cfg = m.derive_config(cfg, DEV)
         torch.manual_seed(10); np.random.seed(10)
@@ -192,13 +195,14 @@ def test_full_step_at_bench_scale_winograd_vs_direct(mrdis):
                      {n: p.detach().clone() for n, p in model.named_parameters()})
         del model, step
         torch.cuda.empty_cache()
-    m.hip.set_option('wino', 1); m.hip.set_option('debug_now16', 0); m.hip.set_option('wino_u', 1)
-    # the pipelined Winograd kernels read the filter's 16-point image built behind the mixing launch, or transform the nine taps themselves
+    m.hip.set_option('wino', 1); m.hip.set_option('debug_now16', 0); m.hip.set_option('wino_u', 1); m.hip.set_option('wino4', 1)
+    # the pipelined F(2x2) kernels read the filter's 16-point image built behind the mixing launch, or transform the nine taps themselves
     # (option wino_u = 0): the same expressions on the same values -- the whole step is bit-identical
-    (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0)], res[(1, 0, 'no_u')]
+    (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0, 'f2')], res[(1, 0, 'f2_no_u')]
     assert l1 == l0 and p1 == p0
     assert all(torch.equal(a, c) for n in g0 for a, c in zip(g0[n], g1[n])) and all(torch.equal(w0[n], w1[n]) for n in w0)
-    for other in ((0, 0), (1, 1)):
+    assert any(not torch.equal(res[(1, 0)][2][n][0], g1[n][0]) for n in g1), 'option wino4 did not change any kernel'
+    for other in ((0, 0), (1, 1), (1, 0, 'f2')):
         (l1, p1, g1, w1), (l0, p0, g0, w0) = res[(1, 0)], res[other]
         assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
         for k_ in p0:
