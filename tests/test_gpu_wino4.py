@@ -96,7 +96,7 @@ def test_f44_conv_small_shapes(mrdis, B, ci, co, H, W):
 # every 3x3 s1 layer of the benchmarked step (B = 32, 256x256; 8 calls of the anatomy decoder run at B = 32 too) whose forward and / or data
 # gradient the default policy gives to the F(4x4) kernel: (name, Ci, Co, map)
 BENCH_LAYERS = [('sp5.gamma|beta (two-step path)', 64, 128, 128), ('sp4.gamma|beta', 128, 256, 64), ('sp3.gamma|beta', 128, 256, 32), ('sp4.out', 128, 64, 64),
-                ('ana.up_2', 256, 64, 64), ('ana.up_3', 512, 128, 32), ('sp5.out (data gradient only: 32 couts)', 64, 32, 128)]
+                ('ana.up_2', 256, 64, 64), ('ana.up_3', 512, 128, 32), ('sp5.gamma|beta at B = 8', 64, 128, 128)]
 
 
 @pytest.mark.parametrize('name,ci,co,hw', BENCH_LAYERS)
