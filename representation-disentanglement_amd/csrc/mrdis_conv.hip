@@ -1185,6 +1185,8 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
 int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
                     hipStream_t s, const float* u_img);
 int mrdis_wino_u_fmt(int R, int S, int spadeC);
+int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
+                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr) {
     if (u_img && mrdis_wino_u_fmt(Ci, Co, 0) == 4) {
@@ -1235,6 +1237,14 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
     }
     if (dtype != MRDIS_DT_F32 || !w_tck) return dtype == MRDIS_DT_F32 ? MRDIS_EINVAL : MRDIS_EUNSUPPORTED;
     if (!mrdis_opt(MRDIS_OPT_WINO_PIPE) || !wino_wanted(N, H, W, Ci, 2 * C, 3, 3, 1, 1)) return MRDIS_EUNSUPPORTED;
+    if (w_wino && mrdis_wino_u_fmt(Ci, 2 * C, C) == 4) {          // the image is the F(4x4) one (mrdis_wino4.hip)
+        if (mrdis_opt(MRDIS_OPT_WINO_U)) {
+            const int rc4 = mrdis_run_wino4_spade((const float*)x, ldx, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
+                                                  (hipStream_t)stream, w_wino);
+            if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
+        }
+        w_wino = nullptr;
+    }
     return mrdis_run_wino2_spade((const float*)x, ldx, w_tck, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
                                  (hipStream_t)stream, w_wino);
 }

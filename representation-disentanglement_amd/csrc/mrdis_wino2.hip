@@ -497,14 +497,19 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
     const WinoUJob j = jobs[lo];
     if (j.fmt == 4) {
         // F(4x4, 3x3) image (mrdis_wino4.h): one thread = one (reduction channel, cout slot) pair = 36 values
-        const int nch4 = (j.R + MRDIS_W4_KC - 1) / MRDIS_W4_KC, tiles4 = (j.S + 63) / 64;
+        const int nch4 = (j.R + MRDIS_W4_KC - 1) / MRDIS_W4_KC, tiles4 = j.spadeC ? (j.spadeC + 31) / 32 : (j.S + 63) / 64;
         const long long total4 = (long long)tiles4 * nch4 * MRDIS_W4_KC * 64;
         for (long long i = ((long long)blockIdx.x - j.block0) * 256 + threadIdx.x; i < total4; i += (long long)j.nblk * 256) {
             const int m = (int)(i & 63), kq = (int)((i >> 6) & 3);
             const long long tc = i >> 8;              // cot * nch4 + chunk
             const int c = (int)(tc % nch4), cot = (int)(tc / nch4);
-            const int r = c * MRDIS_W4_KC + kq, co = cot * 64 + m;
-            const bool ok = r < j.R && co < j.S;
+            const int r = c * MRDIS_W4_KC + kq;
+            int co; bool ok;
+            if (j.spadeC) {                           // slot m: 8-channel group m / 16, row m % 16: rows 0-7 gamma, rows 8-15 beta of the group's channels
+                const int ch = cot * 32 + 8 * (m >> 4) + (m & 7);
+                co = ((m & 8) ? j.spadeC : 0) + ch; ok = ch < j.spadeC;
+            } else { co = cot * 64 + m; ok = co < j.S; }
+            ok = ok && r < j.R;
             float gr[9], U[36];
 #pragma unroll
             for (int t = 0; t < 9; ++t) gr[t] = ok ? j.w[((long long)(j.flip ? 8 - t : t) * j.R + r) * j.S + co] : 0.f;
@@ -548,7 +553,8 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
 
 extern "C" size_t mrdis_wino_u_job_bytes(void) { return sizeof(WinoUJob); }
 static long long wino_u_elems(int R, int S, int spadeC) {
-    if (mrdis_wino_u_fmt(R, S, spadeC) == 4) return (long long)((S + 63) / 64) * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_KC * 64;
+    if (mrdis_wino_u_fmt(R, S, spadeC) == 4)
+        return (long long)(spadeC ? (spadeC + 31) / 32 : (S + 63) / 64) * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_KC * 64;
     const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
     return (long long)tiles * ((R + KC - 1) / KC) * KC * 64;
 }

@@ -32,6 +32,12 @@ struct Wino4Params {
     int lrelu, nt_out;
     int nby, nbx, coTiles, nblk;      // 16 x 32-output blocks per image, 64-cout tiles, blocks in total
     unsigned in_bytes;                // record count of the input's buffer descriptor
+    // SPADE epilogue (wino4_kernel<., true>): the image is that of the fused gamma | beta filter of a SPADE block (Cout = 2 C) in the cout order
+    // [32-channel tile][8-channel group cg][gamma of the 8 channels | beta of the 8 channels]: the lower half-wave of an accumulator holds gamma, the
+    // upper half-wave beta of the same four channels; one v_permlane32_swap per value pairs them up, and the epilogue writes
+    // out = (z - mean) * rstd * (1 + gamma) + beta and gamma itself (model.py:2440-2446) -- the 2C-channel tensor never exists
+    const float* z; const float* mean; const float* rstd; float* gamma_out;
+    int ldz, ldg, C;
 };
 
 namespace {
@@ -58,7 +64,7 @@ __device__ __forceinline__ int w4_skew(int g) { return 2 * ((g >> 1) & 1); }
 }  // namespace
 
 // ABL (timing-only builds, results wrong): 1 no V transform, 4 no MFMAs, 8 no filter DMA, 32 no raw loads
-template <int ABL>
+template <int ABL, bool SPADE = false>
 __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ub = smem;                           // [2][18][UPP]
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
 #pragma unroll
     for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: U(0), V(0) and raw double chunk 0 in LDS, raw double chunk 1 in registers
+    // ---- prologue: U(0), V(0) and the raw double chunks 0 and 1 in LDS
     for (int c = tid; c < BIAS4; c += NT4) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
     if (wave >= 4) {
         raw_block(); filt_block();
@@ -225,9 +231,11 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) raw_store1(Rb, it);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) load_raw1(it, 32u * (unsigned)rc);      // double chunk 1: stored at the end of iteration 0
+        for (int it = 0; it < NIT; ++it) load_raw1(it, 32u * (unsigned)rc);      // double chunk 1
         raw_advance();
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NIT);      // vmcnt(NIT): the filter pieces have landed, the second raw block may still be in flight
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) raw_store1(Rb + RAWBUF, it);
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the filter pieces have landed
     }
     __syncthreads();
     if (wave < 4) {
@@ -259,12 +267,14 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
         // T: V(g + 1) from channels 4 (P ^ 1) .. + 3 of raw double chunk (g + 1) / 2
         const float* Rr = smem + w4_opaque(2 * UBUF + 2 * VBUF + (((g + 1) >> 1) & 1) * RAWBUF + (P ^ 1) * 4 * PL);
         float* Vn = smem + w4_opaque(2 * UBUF + (P ^ 1) * VBUF + W4_TDST);
-        // S: U(g + 1) by DMA; odd g: loads of raw double chunk (g + 3) / 2; even g: LDS stores of raw double chunk g / 2 + 1
-        float* Rw = Rb + (((g >> 1) + 1) & 1) * RAWBUF;
+        // S: U(g + 1) by DMA; even g: loads of raw double chunk g / 2 + 2 (registers); odd g: their LDS stores, into the buffer whose block
+        // (double chunk (g - 1) / 2) the T waves finished with in iteration g - 1.  A block ends after an odd iteration: nothing staged is live
+        // in registers across the epilogue
+        float* Rw = Rb + ((((g + 1) >> 1) + 1) & 1) * RAWBUF;
         unsigned c0b = 0;
         if constexpr (ROLE == 2) {
             filt_next();
-            if (P == 1) c0b = 32u * (unsigned)rc;
+            if (P == 0) c0b = 32u * (unsigned)rc;
         }
 
         f32x2_w4 av[3], bv[3];
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
                 }
             } else {
                 if (s_ < 9) dma1(P ^ 1, s_);
-                else if (P == 1) { if (s_ - 9 < NIT) load_raw1(s_ - 9, c0b); }
+                else if (P == 0) { if (s_ - 9 < NIT) load_raw1(s_ - 9, c0b); }
                 else if (s_ >= 12 && s_ - 12 < NIT) raw_store1(Rw, s_ - 12);
             }
             const int c_ = s_ % 3;
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (ROLE == 2) {
-            if (P == 1) { raw_advance(); __builtin_amdgcn_s_waitcnt(0x0F70 | NIT); }       // the DMA pieces are older than the NIT raw loads
+            if (P == 0) { raw_advance(); __builtin_amdgcn_s_waitcnt(0x0F70 | NIT); }       // the DMA pieces are older than the NIT raw loads
             else __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         __syncthreads();
@@ -328,6 +338,54 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
         const int co0 = 64 * cot, tile = 16 * tg + l16;
         const int oy = oy0 + 4 * (tile >> 3), ox = ox0 + 4 * (tile & 7);
         const int co = co0 + 16 * cg + 4 * kq;
+        if constexpr (SPADE) {
+            // lane: channels ch .. ch + 3 of the block's 32; lower half-wave (kq 0, 1) = their gamma, upper half-wave (kq 2, 3) = their beta
+            const int ch = 32 * cot + 8 * cg + 4 * (kq & 1);
+            const bool ch_ok = ch < p.C;
+            const int up = lane >> 5;                   // after the swap: lower lanes own output rows 0, 1 of the tile, upper lanes rows 2, 3
+            const f32x4 mu = ch_ok ? *reinterpret_cast<const f32x4*>(p.mean + (long long)n * p.C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 rs = ch_ok ? *reinterpret_cast<const f32x4*>(p.rstd + (long long)n * p.C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(Bs + (ch_ok ? ch : 0));
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(Bs + (ch_ok ? p.C + ch : 0));
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                f32x4 yy[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = ip + 2 * h;
+                    f32x4 t[6];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const f32x4 m1 = acc[6 + b], m2 = acc[12 + b], m3 = acc[18 + b], m4 = acc[24 + b];
+                        if (i == 0) t[b] = acc[b] + (m1 + m2) + (m3 + m4);
+                        else if (i == 1) t[b] = (m1 - m2) + 2.f * (m3 - m4);
+                        else if (i == 2) t[b] = (m1 + m2) + 4.f * (m3 + m4);
+                        else t[b] = (m1 - m2) + 8.f * (m3 - m4) + acc[30 + b];
+                    }
+                    const f32x4 s12 = t[1] + t[2], d12 = t[1] - t[2], s34 = t[3] + t[4], d34 = t[3] - t[4];
+                    yy[h][0] = t[0] + s12 + s34; yy[h][1] = d12 + 2.f * d34; yy[h][2] = s12 + 4.f * s34; yy[h][3] = d12 + 8.f * d34 + t[5];
+                }
+                const int row = oy + ip + 2 * up;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 g, bt;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {       // (gamma row ip | beta row ip), (gamma row ip + 2 | beta row ip + 2) -> (gamma, gamma), (beta, beta)
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(yy[0][k][c]), __float_as_uint(yy[1][k][c]), false, false);
+                        g[c] = __uint_as_float(sw[0]); bt[c] = __uint_as_float(sw[1]);
+                    }
+                    if (!(ch_ok && row < p.H && ox + k < p.W)) continue;
+                    const long long pix = (long long)(n * p.H + row) * p.W + ox + k;
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + pix * p.ldz + ch);
+                    g = g + bg; bt = bt + bb;
+                    *reinterpret_cast<f32x4*>(p.out + pix * p.ldout + ch) = (zv - mu) * rs * (g + 1.f) + bt;
+                    *reinterpret_cast<f32x4*>(p.gamma_out + pix * p.ldg + ch) = g;
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         const bool full = oy0 + 16 <= p.H && ox0 + 32 <= p.W && co0 + 64 <= p.Cout;          // block-uniform: no per-store tests
         const f32x4 slope = p.lrelu ? f32x4{0.2f, 0.2f, 0.2f, 0.2f} : f32x4{1.f, 1.f, 1.f, 1.f};
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (co < BIAS4 ? co : 0));
@@ -412,8 +470,44 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
     return MRDIS_OK;
 }
 
+// SPADE-fused form (see Wino4Params): x = si_out (N, H, W, Ci), image of the fused gamma | beta filter [9][Ci][2 C] in the SPADE cout order, bias (2 C);
+// z (N, H, W, C) with its instance statistics; writes mix and gamma.  MRDIS_EUNSUPPORTED: the caller takes the F(2x2) form / the two-step path.
+int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
+                          float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img) {
+    if (!u_img || (((uintptr_t)u_img) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (C < 8 || C % 8 != 0 || 2 * C > BIAS4 || Ci % 8 != 0 || Ci < 16 || ldx % 4 != 0 || ldz % 4 != 0 || ldmix % 4 != 0 || ldg % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)z) | ((uintptr_t)mix) | ((uintptr_t)gamma) | ((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W * ldx >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
+    Wino4Params p{};
+    p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
+    p.in = x; p.bias = bias; p.out = mix; p.u_img = u_img;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
+    p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
+    p.coTiles = mrdis_cdiv(C, 32);
+    const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (nblk < 192 || H < 16 || W < 32)) return MRDIS_EUNSUPPORTED;
+    p.nblk = (int)nblk;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)wino4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    hipLaunchKernelGGL((wino4_kernel<0, true>), dim3(grid), dim3(NT4), W4_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 int mrdis_wino_u_fmt(int R, int S, int spadeC) {
-    if (!mrdis_opt(MRDIS_OPT_WINO4) || spadeC != 0) return 2;
+    if (!mrdis_opt(MRDIS_OPT_WINO4)) return 2;
+    if (spadeC != 0) {                                 // fused gamma | beta filter (S = 2 C)
+        const int rmin_s = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
+        return (R % 8 == 0 && R >= rmin_s && spadeC % 8 == 0 && spadeC >= 32 && 2 * spadeC <= BIAS4) ? 4 : 2;
+    }
     // measured (tools/wino4_check.py, B = 32): 64 -> 128 at 128x128 349 -> 299 us forward / 323 -> 271 us data gradient, 128 -> 256 at 64x64 322 -> 210 /
     // 321 -> 205, 128 -> 64 at 64x64 85 -> 68 / 88 -> 74, 64 -> 64 at 128x128 171 -> 149 / 172 -> 158; 32 reduction channels (8 chunks per block: the
     // output transform + stores come round too often) 386 -> 387: no gain; < 64 couts leave half of the 64-cout tile empty

@@ -125,3 +125,39 @@ def test_f44_layers_at_bench_scale(mrdis, name, ci, co, hw):
         assert not ran_f
     if fmt[1] != 4:
         assert not ran_b
+
+
+@pytest.mark.parametrize('case', [(3, 64, 64, 50, 72), (5, 128, 128, 33, 47), (2, 16, 40, 64, 80), (32, 128, 128, 64, 64), (8, 64, 64, 128, 128)], ids=str)
+def test_f44_spade_epilogue(mrdis, case):
+    """mrdis_conv2d_fwd_spade on the F(4x4) kernel (fused gamma | beta filter image in the SPADE cout order; gamma and beta of a channel meet in one
+    lane through v_permlane32_swap; epilogue = InstanceNorm modulation, model.py:2440-2446) against the two-step form on the direct kernel and
+    against torch: mix and gamma, ragged blocks, a channel count that is not a multiple of 32, and the two gamma | beta layers of the benchmarked
+    step that the policy gives to this kernel (sp4 at B = 32, sp5 at B = 8)."""
+    N, Ci, C, H, W = case
+    hip = mrdis.hip
+    x = cl(rnd((N, Ci, H, W), 1)); z = cl(rnd((N, C, H, W), 2))
+    w = rnd((2 * C, Ci, 3, 3), 3, 0.1); b = rnd((2 * C,), 4, 0.1).to(DEV)
+    wt = w.permute(2, 3, 1, 0).reshape(9, Ci, 2 * C).contiguous().to(DEV)
+    hip.set_option('wino', 0)
+    gb = hip.conv2d_fwd(x, wt, b, 3, 3, 1, 1)
+    mix_ref, mean_ref, rstd_ref = hip.instnorm_spade_fwd(z, gb[:, :C], gb[:, C:], 1e-5)
+    hip.set_option('wino', 2); hip.set_option('wino4', 2)
+    assert hip.wino_u_format(Ci, 2 * C, C) == 4
+    img = torch.full((hip.wino_u_image_floats(Ci, 2 * C, C),), float('nan'), device=DEV)
+    j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC, j.block0, j.nblk = wt.data_ptr(), img.data_ptr(), Ci, 2 * C, 0, C, 0, hip.wino_u_job_blocks(Ci, 2 * C, C)
+    hip.wino_u_jobs(hip.wino_u_table([j], DEV), 1, j.nblk)
+    assert torch.isfinite(img).all()
+    res = hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img)
+    assert res is not None
+    mix, gamma, mean, rstd = res
+    hip.set_option('wino4', 0)
+    res2 = hip.gb_spade_fwd(x, wt, b, z, 1e-5)
+    assert res2 is not None and not torch.equal(res2[0], mix), 'the F(4x4) SPADE kernel did not run'
+    tol = 5e-5
+    assert float((gamma - gb[:, :C]).abs().max()) <= tol * float(gb.abs().max())
+    assert float((mix - mix_ref).abs().max()) <= tol * float(mix_ref.abs().max())
+    assert torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+    if N * H * W <= 200000:
+        gr = F.conv2d(x.cpu(), w, b.cpu(), 1, 1)
+        ref = F.instance_norm(z.cpu(), eps=1e-5) * (1 + gr[:, :C]) + gr[:, C:]
+        assert float((mix.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
