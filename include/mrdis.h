@@ -177,7 +177,8 @@ int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_b
  * on the activations; a training step uses each mixed filter 8-16 times, so the transform is taken out of the convolution kernels:
  * one launch over a job table builds, per (filter, role), the 16-point image in the order the kernel's (input-channel chunk, 64-cout
  * tile) walk consumes it: [cout tile][chunk of 8][8][4][64][4] floats, zero-padded (format 2); format 4 is the 36-point image of the
- * F(4x4,3x3) kernel, [cout tile][chunk of 4][18 point pairs][4][128] floats (csrc/mrdis_wino4.h).  mrdis_wino_u_format(R, S, spadeC) says
+ * F(4x4,3x3) kernel, [cout tile][chunk of 4][18 point pairs][4][128] floats (csrc/mrdis_wino4.h), FOLLOWED by the format-2 image of the same filter
+ * (what a call runs on whose grid the F(4x4) kernel declines: small maps).  mrdis_wino_u_format(R, S, spadeC) says
  * which of the two a filter gets (a function of the filter's shape and the option "wino4" alone).
  * Job (`WinoUJob`, mrdis_wino_u_job_bytes() = 48):
  *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk, fmt, pad; }        fmt = mrdis_wino_u_format(R, S, spadeC)

@@ -1184,7 +1184,7 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
 // forward and data gradient are the same call); MRDIS_EUNSUPPORTED where its shape limits / grid test decline
 int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
                     hipStream_t s, const float* u_img);
-int mrdis_wino_u_fmt(int R, int S, int spadeC);
+#include "mrdis_wino4.h"
 int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
                           float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
@@ -1194,7 +1194,7 @@ static int run_wino(const float* x, int ldx, const float* w, const float* bias, 
             const int rc = mrdis_run_wino4(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
-        u_img = nullptr;                               // an F(4x4) image is of no use to the F(2x2) kernels: they transform the taps themselves
+        u_img += mrdis_wino4_image_floats(Ci, Co, 0);  // the 16-point image of the same filter follows the 36-point one
     }
     if (Co > 32 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {
         const int rc = mrdis_run_wino2(x, ldx, w, bias, y, ldy, N, H, W, Ci, Co, flip, lrelu, s, u_img);
@@ -1243,7 +1243,7 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
                                                   (hipStream_t)stream, w_wino);
             if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
         }
-        w_wino = nullptr;
+        w_wino += mrdis_wino4_image_floats(Ci, 2 * C, C);
     }
     return mrdis_run_wino2_spade((const float*)x, ldx, w_tck, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
                                  (hipStream_t)stream, w_wino);

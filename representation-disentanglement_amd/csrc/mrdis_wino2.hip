@@ -518,8 +518,9 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
 #pragma unroll
             for (int pt = 0; pt < 36; ++pt) dst[(pt >> 1) * MRDIS_W4_UPP + ((2 * m + (pt & 1) + 32 * kq) & 127)] = U[pt];
         }
-        return;
+        // ... followed by the 16-point image of the same filter: a call whose grid the F(4x4) kernel declines (small maps) runs the F(2x2) kernel on it
     }
+    float* const img2 = j.fmt == 4 ? j.img + mrdis_wino4_image_floats(j.R, j.S, j.spadeC) : j.img;
     const int nch = (j.R + KC - 1) / KC;
     const int tiles = j.spadeC ? (j.spadeC + 31) / 32 : (j.S + 63) / 64;
     const long long total = (long long)tiles * nch * KC * 64;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
             const float g0 = gr[q], g1 = gr[3 + q], g2 = gr[6 + q];
             t_[0][q] = g0; t_[1][q] = 0.5f * (g0 + g1 + g2); t_[2][q] = 0.5f * (g0 - g1 + g2); t_[3][q] = g2;
         }
-        float* dst = j.img + ((tc * KC + k) * 4) * 256 + slot * 4;      // [tc][k][a][slot][4]
+        float* dst = img2 + ((tc * KC + k) * 4) * 256 + slot * 4;       // [tc][k][a][slot][4]
 #pragma unroll
         for (int a = 0; a < 4; ++a)
             *reinterpret_cast<float4*>(dst + a * 256) = make_float4(t_[a][0], 0.5f * (t_[a][0] + t_[a][1] + t_[a][2]),
@@ -552,15 +553,13 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
 }
 
 extern "C" size_t mrdis_wino_u_job_bytes(void) { return sizeof(WinoUJob); }
-static long long wino_u_elems(int R, int S, int spadeC) {
-    if (mrdis_wino_u_fmt(R, S, spadeC) == 4)
-        return (long long)(spadeC ? (spadeC + 31) / 32 : (S + 63) / 64) * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_KC * 64;
+static long long wino_u_elems(int R, int S, int spadeC) {       // (reduction channel, cout slot) pairs of the 16-point image
     const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
     return (long long)tiles * ((R + KC - 1) / KC) * KC * 64;
 }
 extern "C" int mrdis_wino_u_format(int R, int S, int spadeC) { return mrdis_wino_u_fmt(R, S, spadeC); }
 extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) {
-    return (mrdis_wino_u_fmt(R, S, spadeC) == 4 ? 36 : 16) * wino_u_elems(R, S, spadeC);
+    return (mrdis_wino_u_fmt(R, S, spadeC) == 4 ? mrdis_wino4_image_floats(R, S, spadeC) : 0) + 16 * wino_u_elems(R, S, spadeC);
 }
 extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
     const long long b = (wino_u_elems(R, S, spadeC) + 255) / 256;

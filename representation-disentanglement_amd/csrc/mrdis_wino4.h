@@ -7,6 +7,7 @@
 // (the two points of a pair sit next to each other: one ds_read_b64 is the A operand of two MFMAs; the rotation by 32 kq spreads
 // the four k-rows of an MFMA operand over all 64 banks).  Zero where the chunk / tile runs past R / S.
 #pragma once
+#include <hip/hip_runtime.h>
 
 #define MRDIS_W4_KC 4                    // reduction channels per chunk (one MFMA k-step of v_mfma_f32_16x16x4_f32)
 #define MRDIS_W4_UPP 512                 // floats per point pair of the U image (4 channels x 64 couts x 2 points)
@@ -16,6 +17,12 @@
 // 2 = F(2x2, 3x3) (mrdis_wino2.hip).  A function of the filter alone -- the image is built once per step, before any call's shape is known;
 // a call whose shape the F(4x4) kernel declines runs the F(2x2) kernel with its in-kernel filter transform.
 int mrdis_wino_u_fmt(int R, int S, int spadeC);
+
+// floats of the 36-point part of a format-4 image (the 16-point image of the same filter follows it: the fallback for calls the F(4x4) kernel declines)
+static inline __host__ __device__ long long mrdis_wino4_image_floats(int R, int S, int spadeC) {
+    const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
+    return (long long)tiles * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_UCHUNK;
+}
 
 #ifdef __HIPCC__
 // the 36 values of one (reduction channel, cout) pair from its nine taps g[3 * row + col]

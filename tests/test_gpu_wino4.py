@@ -50,8 +50,10 @@ def test_f44_filter_image(mrdis, R, S, flip):
     assert hip.wino_u_format(R, S) == 4
     w = rnd((9, R, S), 5).to(DEV)
     tiles, nch = (S + 63) // 64, (R + 3) // 4
-    assert hip.wino_u_image_floats(R, S) == tiles * nch * 18 * 4 * 128
-    img = torch.full((hip.wino_u_image_floats(R, S),), float('nan'), device=DEV)
+    n4 = tiles * nch * 18 * 4 * 128
+    n2 = tiles * ((R + 7) // 8) * 8 * 64 * 16            # the 16-point image of the same filter follows (fallback for calls the F(4x4) kernel declines)
+    assert hip.wino_u_image_floats(R, S) == n4 + n2
+    img = torch.full((n4 + n2,), float('nan'), device=DEV)
     j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC, j.block0, j.nblk = w.data_ptr(), img.data_ptr(), R, S, flip, 0, 0, hip.wino_u_job_blocks(R, S)
     hip.wino_u_jobs(hip.wino_u_table([j], DEV), 1, j.nblk)
     g = w.double().cpu().reshape(3, 3, R, S)
@@ -66,9 +68,15 @@ def test_f44_filter_image(mrdis, R, S, flip):
         for par in range(2):
             slot = (2 * m + par + 32 * kq) & 127
             want[:, :, :, kq, slot] = Up[:, par, :, kq].permute(2, 1, 0, 3)        # [tile][chunk][pp][m]
-    got = img.cpu().double().reshape(want.shape)
+    got = img[:n4].cpu().double().reshape(want.shape)
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    hip.set_option('wino4', 0)                                      # the tail IS the format-2 image (tests/test_gpu_ops.py::test_winograd_filter_image)
+    assert hip.wino_u_format(R, S) == 2 and hip.wino_u_image_floats(R, S) == n2
+    img2 = torch.full((n2,), float('nan'), device=DEV)
+    j.img, j.nblk = img2.data_ptr(), hip.wino_u_job_blocks(R, S)
+    hip.wino_u_jobs(hip.wino_u_table([j], DEV), 1, j.nblk)
+    assert torch.equal(img[n4:], img2)
 
 
 @pytest.mark.parametrize('B,ci,co,H,W', [(2, 64, 64, 20, 37), (3, 72, 100, 50, 70), (1, 64, 128, 64, 64), (2, 16, 72, 33, 31), (1, 128, 256, 16, 32)])
