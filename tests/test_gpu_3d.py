@@ -217,3 +217,114 @@ def test_nvnet3d_vs_oracle_other_size(mrdis):
     gr = _grads(ref)
     for n, g in _grads(model).items():
         close(g, gr[n], 3e-3, n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at its own size: 4 x 4 x 128^3 volumes, init_channels 16 (tools/bench3d.py times exactly this).  The 2-D path needed tests
+# at the benchmarked scale to catch scale-only defects (grid policies, 32-bit offsets, persistent-workgroup walks); so does the 3-D one.
+def _geoms128(c=16, S=128):
+    g = [('conv1a', 4, c, S, 1)]
+    for lvl, mult in enumerate((1, 2, 4, 8)):
+        s = S >> lvl
+        g.append((f'block{lvl + 1}', c * mult, c * mult, s, 1))
+        if lvl < 3:
+            g.append((f'ds{lvl + 1}', c * mult, c * mult * 2, s, 2))
+    for lvl, mult in enumerate((8, 4, 2)):
+        g.append((f'vconv{3 - lvl}', c * mult, c * mult // 2, S >> (3 - lvl), 1))
+    g.append(('hidden_conv', c * 8, c * 4, S >> 3, 1))
+    return g
+
+
+@pytest.mark.parametrize('name,ci,co,s,st', _geoms128(), ids=[g[0] for g in _geoms128()])
+def test_conv3d_geometries_at_config4_size(mrdis, name, ci, co, s, st):
+    """every distinct Conv3d geometry of NVNet3D (model.py:1856-2060) at B = 4, 128^3 input, as the step issues it (default kernel policy): forward,
+    data gradient and weight gradient on the FULL tensors against (a) torch fp32 on the CPU on sampled sub-volumes -- two boxes, one at the
+    volume's corner (zero padding on three faces) and one in the last image's far corner (the largest offsets) -- and (b) the direct kernels
+    (wino = 0) on the full tensors."""
+    hip = mrdis.hip
+    B = 4
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B, s, s, s, ci, device=DEV, generator=gen).permute(0, 4, 1, 2, 3)
+    w = torch.randn(co, ci, 3, 3, 3, device=DEV, generator=gen) * 0.1
+    bias = torch.randn(co, device=DEV, generator=gen)
+    w_tck, w_tkc = hip.mix_experts_fwd(w.reshape(1, co, ci, 27, 1), torch.ones(1, device=DEV))
+    so = (s - 1) // st + 1
+    dy = torch.randn(B, so, so, so, co, device=DEV, generator=gen).permute(0, 4, 1, 2, 3)
+    y = hip.conv3d_fwd(x, w_tck, bias, 3, st, 1)
+    dx = hip.conv3d_bwd_data(dy, w_tkc, tuple(x.shape), 3, st, 1)
+    # weight gradient through a cotangent that is zero outside two sampled boxes (every workgroup still walks the whole volume)
+    e = min(so, 6)                                                    # box edge in output positions
+    boxes = [(0, 0), (B - 1, so - e)]
+    dyz = torch.zeros_like(dy)
+    for n, o in boxes:
+        dyz[n, :, o:o + e, o:o + e, o:o + e] = dy[n, :, o:o + e, o:o + e, o:o + e]
+    dw, db = hip.conv3d_bwd_weight(x, dyz, 3, st, 1, True)
+    wc, bc = w.cpu(), bias.cpu()
+    dw_ref = torch.zeros_like(wc); db_ref = torch.zeros_like(bc)
+    for n, o in boxes:
+        # input box that feeds output positions [o, o + e): rows st * o - 1 .. st * (o + e - 1) + 1, clipped to the volume, explicit zero padding
+        lo, hi = st * o - 1, st * (o + e - 1) + 1
+        a, b_ = max(lo, 0), min(hi, s - 1)
+        xb = x[n:n + 1, :, a:b_ + 1, a:b_ + 1, a:b_ + 1].cpu()
+        pad = (a - lo, hi - b_) * 3
+        xb = F.pad(xb, pad).requires_grad_(True)
+        wr = wc.clone().requires_grad_(True); br = bc.clone().requires_grad_(True)
+        yb = F.conv3d(xb, wr, br, stride=st)
+        assert yb.shape[2] == e
+        close(y[n:n + 1, :, o:o + e, o:o + e, o:o + e], yb, 1e-3, f'{name} fwd box {n}')
+        dyb = dy[n:n + 1, :, o:o + e, o:o + e, o:o + e].cpu()
+        yb.backward(dyb)
+        dw_ref += wr.grad; db_ref += br.grad
+        # data gradient: positions of x whose every reader lies inside the box (the box's interior) see only the box's cotangent
+        if e >= 3:
+            full = F.conv_transpose3d(dy[n:n + 1, :, max(o - 2, 0):o + e + 2, max(o - 2, 0):o + e + 2, max(o - 2, 0):o + e + 2].cpu(), wc, None, stride=st, padding=0)
+            # `full` is indexed from input row st * max(o - 2, 0) - 1; compare a 2^3 block of x rows well inside
+            base = st * max(o - 2, 0) - 1
+            r0 = st * (o + 1)
+            blk = full[:, :, r0 - base:r0 - base + 2, r0 - base:r0 - base + 2, r0 - base:r0 - base + 2]
+            close(dx[n:n + 1, :, r0:r0 + 2, r0:r0 + 2, r0:r0 + 2], blk, 1e-3, f'{name} dgrad box {n}')
+    close(dw.cpu().reshape(27, ci, co), dw_ref.permute(2, 3, 4, 1, 0).reshape(27, ci, co), 2e-3, f'{name} wgrad')
+    close(db, db_ref, 2e-3, f'{name} bgrad')
+    hip.set_option('wino', 0)
+    y0 = hip.conv3d_fwd(x, w_tck, bias, 3, st, 1)
+    dx0 = hip.conv3d_bwd_data(dy, w_tkc, tuple(x.shape), 3, st, 1)
+    dw0, db0 = hip.conv3d_bwd_weight(x, dy, 3, st, 1, True)
+    hip.set_option('wino', 1)
+    dw1, db1 = hip.conv3d_bwd_weight(x, dy, 3, st, 1, True)
+    close(y, y0, 1e-4, f'{name} fwd vs direct'); close(dx, dx0, 1e-4, f'{name} dgrad vs direct')
+    close(dw1, dw0, 5e-4, f'{name} wgrad vs direct'); close(db1, db0, 5e-4, f'{name} bgrad vs direct')
+
+
+def test_nvnet3d_step_at_config4_size(mrdis):
+    """one NVNet3D training step (forward, nvnet_loss, backward; p = 0) on 4 x 4 x 128^3 volumes under the default policy against the direct kernels
+    only (wino = 0): loss, loss parts, the four outputs and every parameter gradient."""
+    S, B, c = 128, 4, 16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, S, S, S, 4, generator=g).to(DEV).permute(0, 4, 1, 2, 3)
+    t = (torch.rand(B, S, S, S, 3, generator=g) > 0.7).float().to(DEV).permute(0, 4, 1, 2, 3)
+    res = {}
+    for mode in (1, 0):
+        mrdis.hip.set_option('wino', mode)
+        torch.manual_seed(10)
+        model = mrdis.NVNet3D((S, S, S), 4, 3, c, p=0.0).to(DEV).train()
+        torch.manual_seed(11)
+        out = model(x)
+        loss, parts = mrdis.nvnet_loss(*out, x, t)
+        loss.backward()
+        res[mode] = (float(loss), {k: float(v) for k, v in parts.items()}, [F.avg_pool3d(o, 8).detach() if o.dim() == 5 else o.detach() for o in out],
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        del model, out, loss
+        torch.cuda.empty_cache()
+    mrdis.hip.set_option('wino', 1)
+    (l1, p1, o1, g1), (l0, p0, o0, g0) = res[1], res[0]
+    assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0)
+    for k in p0:
+        assert abs(p1[k] - p0[k]) <= 2e-4 * abs(p0[k]) + 1e-7, k
+    for a, b in zip(o1, o0):
+        close(a, b, 1e-4, 'outputs')
+    assert set(g0) == set(g1) and len(g0) > 100
+    assert any(not torch.equal(g0[n], g1[n]) for n in g0), 'the default policy did not change any kernel'
+    tot = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g0.values())))
+    for n in g0:
+        err = float((g1[n] - g0[n]).double().norm())
+        assert err <= 2e-3 * float(g0[n].double().norm()) + 2e-5 * tot, (n, err)

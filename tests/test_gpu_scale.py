@@ -329,8 +329,10 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
         m.ops.set_compute_dtype('f32')
 
 
-def _one_step(m, mode, B_=B, H=HW, W=HW, opts=()):
-    """loss, loss parts, every parameter gradient (both backward passes) and the weights after Adam of ONE headline step"""
+def _one_step(m, mode, B_=B, H=HW, W=HW, opts=(), drop=None, extra=None):
+    """loss, loss parts, every parameter gradient (both backward passes) and the weights after Adam of ONE headline step.
+    drop: None | 'random' (BASELINE configs[3]: one random modality missing per slice, util.py:538-542) | 'absent3' (modality 3 missing from the
+    WHOLE batch, another one at random from every second slice); extra: dict that receives the weights before the step and the step's active decoders"""
     for o, v in opts:
         m.hip.set_option(o, v)
     try:
@@ -338,11 +340,22 @@ def _one_step(m, mode, B_=B, H=HW, W=HW, opts=()):
         cfg = m.derive_config(cfg, DEV)
         torch.manual_seed(10); np.random.seed(10)
         model = m.build_model(cfg).train()
-        x, mask, mask_img = m.synthetic_batch(B_, 4, 240, 240, seed=10)
+        x, mask, mask_img = m.synthetic_batch(B_, 4, 240, 240, seed=10, drop=(drop == 'random'))
+        if drop == 'absent3':
+            g = torch.Generator().manual_seed(77)
+            mask[:, 3] = 0; x[:, 21:28] = 0
+            for b_ in range(0, B_, 2):
+                d_ = int(torch.randint(0, 3, (1,), generator=g))
+                mask[b_, d_] = 0; x[b_, 7 * d_:7 * d_ + 7] = 0
         x = m.fit_to_model(x, (H, W), fill=-10.0); mask_img = (x[:, 0] == 0).float()
         step = m.TrainStep(model, cfg)
+        if extra is not None:
+            extra['w_before'] = step.optimizer.flat_p.detach().clone()
+            extra['active'] = model.active_decoders(mask.numpy())
         torch.manual_seed(11); np.random.seed(11)
         loss, parts, _ = step(cl(x), mask.to(DEV), mask_img.to(DEV), mask)
+        if extra is not None:
+            extra['m_after'] = step.optimizer.m.detach().clone(); extra['skipped'] = step.optimizer.skipped_steps()
         names = {id(p): n for n, p in model.named_parameters()}
         # the arena exists from the constructor: after the step the gradient buffers are zeroed, so read what the clip saw instead
         gnorm = float(step.last_grad_norm_sq[0].sqrt())
@@ -353,7 +366,7 @@ def _one_step(m, mode, B_=B, H=HW, W=HW, opts=()):
         return out
     finally:
         for o, v in opts:
-            m.hip.set_option(o, {'wino_pipe': 1, 'debug_nopack': 0, 'wino': 1}[o])
+            m.hip.set_option(o, {'wino_pipe': 1, 'debug_nopack': 0, 'wino': 1, 'wino4': 1}[o])
         m.ops.set_compute_dtype('f32')
 
 
@@ -458,3 +471,43 @@ def test_full_step_at_bench_scale_bf16(mrdis):
     tol = dict(recon_x=5e-6, recon_x_mix=5e-6, sim_z=5e-6, latent_z=4.5e-3, sim_s=7e-3, adv_s=3.5e-4, adv_s_d=3.5e-4, all=3.5e-4)
     for k_, v in rec['parts_rel'].items():
         assert v <= tol[k_], (k_, rec)
+
+
+@pytest.mark.parametrize('drop', ['random', 'absent3'])
+def test_full_step_at_bench_scale_missing_modality(mrdis, drop):
+    """BASELINE configs[3] at the benchmarked size (B = 32, M = 4, 256x256, what `bench.py --drop` times): the missing-modality step -- drop-off masks
+    in every loss (model.py:3262-3266, 3319-3341, 3388), pruned decoder groups, the gated Adam step -- under the default kernel policy against the direct
+    kernels only (wino = 0): loss, every loss part, the global gradient norm and the weights after Adam.  'absent3': a modality missing from the whole
+    batch -- its decoder receives no gradient in the reference (torch's Adam skips `grad is None`): every one of its weights must be untouched, its
+    moments zero, while every other group moves."""
+    m = mrdis
+    ex = {}
+    l1, p1, g1, w1, names, offs = _one_step(m, 'f32', drop=drop, extra=ex)
+    l0, p0, g0, w0, names0, offs0 = _one_step(m, 'f32', drop=drop, opts=(('wino', 0),))
+    assert names == names0 and offs == offs0 and ex['skipped'] == 0
+    assert np.isfinite(l1) and abs(l1 - l0) <= 1e-4 * abs(l0), (l1, l0)
+    for k_ in p0:
+        assert abs(p1[k_] - p0[k_]) <= 2e-4 * abs(p0[k_]) + 1e-7, (k_, p1[k_], p0[k_])
+    assert abs(g1 - g0) <= 1e-3 * g0, (g1, g0)
+    assert not torch.equal(w1, w0), 'the default policy did not change any kernel'
+    # Adam's first step moves a weight by ~lr = 2e-4 whatever the gradient's size: a noise-level gradient may flip its sign between the two policies
+    d = (w1 - w0).abs()
+    assert float(d.max()) <= 4.2e-4 and float((d > 1e-6).float().mean()) <= 2e-3, (float(d.max()), float((d > 1e-6).float().mean()))
+    act = ex['active']
+    assert act.shape == (4,)
+    if drop == 'random':
+        assert act.tolist() == [1, 1, 1, 1]
+    else:
+        assert act.tolist() == [1, 1, 1, 0]               # (with modality 3 -- the last one -- absent the mix loss's non-advancing index reads no decoder-3 output)
+    moved = (w1 - ex['w_before']).abs()
+    bounds = offs + [w1.numel()]
+    seen = {0: 0, 1: 0}
+    for k, n in enumerate(names):
+        seg = slice(bounds[k], bounds[k + 1])
+        dec = [i for i in range(4) if n.startswith(f'input_decoder_list.{i}.')]
+        if dec and not act[dec[0]]:
+            assert float(moved[seg].max()) == 0.0 and float(ex['m_after'][seg].abs().max()) == 0.0, n     # gated off: untouched, no moment
+            seen[0] += 1
+        elif dec:
+            seen[1] += int(float(moved[seg].max()) > 0)
+    assert seen[1] > 100 and (drop == 'random' or seen[0] > 30), seen
