@@ -490,9 +490,10 @@ def test_full_step_at_bench_scale_missing_modality(mrdis, drop):
         assert abs(p1[k_] - p0[k_]) <= 2e-4 * abs(p0[k_]) + 1e-7, (k_, p1[k_], p0[k_])
     assert abs(g1 - g0) <= 1e-3 * g0, (g1, g0)
     assert not torch.equal(w1, w0), 'the default policy did not change any kernel'
-    # Adam's first step moves a weight by ~lr = 2e-4 whatever the gradient's size: a noise-level gradient may flip its sign between the two policies
+    # Adam's first step moves a weight by ~lr = 2e-4 whatever the gradient's size, and there are two of them (generator + discriminator optimizer):
+    # a noise-level gradient may flip its sign between the two policies
     d = (w1 - w0).abs()
-    assert float(d.max()) <= 4.2e-4 and float((d > 1e-6).float().mean()) <= 2e-3, (float(d.max()), float((d > 1e-6).float().mean()))
+    assert float(d.max()) <= 8.4e-4 and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
     act = ex['active']
     assert act.shape == (4,)
     if drop == 'random':
