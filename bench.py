@@ -136,8 +136,8 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
     """The three kernel families that dominate the step -- the fused gamma | beta convolutions of the full-, half- and
     quarter-resolution SPADE blocks (reference model.py:2443-2444; 16 calls each per step, forward + data gradient + weight
     gradient = ~40 % of the step) -- timed live with HIP events at the shapes of the timed step and priced against the MFMA peak
-    of the arithmetic type.  fp32: Winograd F(2x2,3x3) executes 4/9 of the direct multiplies, so `frac` = direct-equivalent
-    FLOPs x 4/9 / time / 157.3 TF (the kernels' own MFMA work against the matrix pipe); bf16: direct FLOPs / time / bf16 peak,
+    of the arithmetic type.  fp32: Winograd F(2x2,3x3) executes 4/9 and F(4x4,3x3) 1/4 of the direct multiplies, so `frac` = direct-equivalent
+    FLOPs x that factor / time / 157.3 TF (the kernels' own MFMA work against the matrix pipe); bf16: direct FLOPs / time / bf16 peak,
     and the HBM fraction of the layer's algorithmic bytes beside it (these layers are HBM-bound in bf16)."""
     hip = mrdis.hip
     bf = dtype != 'f32'
@@ -170,6 +170,13 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
                'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b, out=dxo),
                'wgrad': lambda: hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, dtype=dt)}
         flop = 2.0 * 9 * ci * co * B * h * w
+
+        def algo(R, S):        # which Winograd kernel the library's policy gives the forward / data gradient of an (R -> S) filter at this size
+            nblk = B * ((h + 15) // 16) * ((w + 31) // 32) * ((S + 63) // 64)
+            if not bf and hip.wino_u_format(R, S) == 4 and nblk >= 192:
+                return 'winograd F(4x4,3x3)', 0.25
+            return 'winograd F(2x2,3x3)', 4.0 / 9.0
+        algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci), 'wgrad': ('winograd F(2x2,3x3)', 4.0 / 9.0)}
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}
@@ -195,12 +202,15 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
                 row[k_] = {'us': round(us, 1), 'tflops': round(flop / us / 1e6, 1), 'frac_mfma': round(flop / us / 1e6 / MFMA_BF16_PEAK_TF, 3),
                            'gbs': round(nbytes / us / 1e3, 0), 'frac_hbm': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3)}
             else:
-                row[k_] = {'us': round(us, 1), 'direct_equiv_tflops': round(flop / us / 1e6, 1),
-                           'frac_mfma': round(flop * 4 / 9 / us / 1e6 / MFMA_F32_PEAK_TF, 3)}
+                name_, fac = algos[k_]
+                row[k_] = {'us': round(us, 1), 'direct_equiv_tflops': round(flop / us / 1e6, 1), 'algorithm': name_,
+                           'executed_multiplies_per_direct_multiply': round(fac, 4),
+                           'frac_mfma': round(flop * fac / us / 1e6 / MFMA_F32_PEAK_TF, 3)}
         out.append(row)
         del x, dy, yo, dxo
     return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
-            'pricing': 'fp32: direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) / time / 157.3 TF' if not bf else
+            'pricing': 'fp32: the FLOPs the kernel EXECUTES on the matrix pipe = direct-equivalent FLOPs x 4/9 (Winograd F(2x2,3x3)) or x 1/4 (F(4x4,3x3), the 64+-channel '
+                       'forward / data gradient) / time / 157.3 TF; direct_equiv_tflops is the same time priced at the direct convolution\'s FLOPs' if not bf else
                        'bf16: algorithmic bytes (x + dy in bf16) / time / 8 TB/s; direct FLOPs / time / 2500 TF beside it',
             'timing': f'{iters} launches per entry point after >= 20 ms / >= 30 launches of warm-up (clock ramp), HIP events on the launch stream, shapes of the timed step',
             'layers': out}
@@ -245,6 +255,28 @@ def cpu_baseline(M, H, W, adv):
     return {'value': round(B / dt, 4), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
             'sample': f'oracle/ref_model.py train step, B={B}, M={M}, {H}x{W} fp32, 1 warm-up + {n} timed steps, '
                       f'{dt:.2f} s/step'}
+
+
+def host_unblocked_ms(mrdis, cfg, dev, B, M, adv, steps=4):
+    """What the HOST needs to enqueue one step when the launch queue never fills: the same step (same launch count: it does not depend on the
+    map size) on 64x64 slices, where the GPU finishes long before the host, timed per step between synchronisations.  `host_enqueue_ms_per_step` of the
+    timed region is mostly back-pressure from the full queue; this number is what decides whether N ranks on one host stay GPU-bound."""
+    small = dict(cfg); small.update(input_height=64, input_width=64)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(small).train()
+    step = mrdis.TrainStep(model, small)
+    x, mask, mask_img = mrdis.synthetic_batch(B, M, 64, 64, seed=10)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last); maskd, mimgd = mask.to(dev), mask_img.to(dev)
+    ts = []
+    for i in range(steps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(xd, maskd, mimgd, mask)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    del model, step
+    torch.cuda.empty_cache()
+    return round(float(np.median(ts[2:])), 1)
 
 
 def main():
@@ -406,6 +438,10 @@ def main():
         }
         log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
         out['host_enqueue_ms_per_step'] = round(host_ms, 1)
+        out['host_enqueue_note'] = 'host time inside step() during the timed region: mostly waiting on the full launch queue (the step is GPU-bound); host_ms_unblocked is the cost proper'
+        if world == 1 and not a.no_roofline:
+            out['host_ms_unblocked'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv)
+            log(f'host_ms_unblocked: {out["host_ms_unblocked"]} ms/step')
         if ddp is not None:
             out['ddp'] = ddp
             out['allreduce_wait_ms'] = ddp['allreduce_wait_ms']
