@@ -38,6 +38,7 @@ struct Wino4Params {
     // out = (z - mean) * rstd * (1 + gamma) + beta and gamma itself (model.py:2440-2446) -- the 2C-channel tensor never exists
     const float* z; const float* mean; const float* rstd; float* gamma_out;
     int ldz, ldg, C;
+    unsigned long long* dbg; int dbg_cap;    // diagnostic build (ABL & 64): per (workgroup, wave) s_memtime stamps, dbg_cap per wave
 };
 
 namespace {
@@ -217,6 +218,17 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     f32x4 acc[36];
 #pragma unroll
     for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ABL & 64: in-kernel stamps (the stamps go to a buffer nothing else reads; the build is for diagnosis only, its timings carry ~10 % of overhead)
+    int n_stamp = 0;
+    auto stamp = [&](int tag) {
+        if constexpr ((ABL & 64) != 0) {
+            if (p.dbg != nullptr && blockIdx.x < 4 && n_stamp < p.dbg_cap) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) p.dbg[((long long)(blockIdx.x * 8 + wave)) * p.dbg_cap + n_stamp] = (t << 4) | (unsigned)tag;
+                ++n_stamp;
+            }
+        }
+    };
 
     // ---- prologue: U(0), V(0) and the raw double chunks 0 and 1 in LDS
     for (int c = tid; c < BIAS4; c += NT4) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
             if (P == 0) c0b = 32u * (unsigned)rc;
         }
 
+        stamp(1);
         f32x2_w4 av[3], bv[3];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
@@ -290,10 +303,13 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
                 bv[(s_ + 2) % 3] = w4_ld2(Va + (s_ + 2) * VPP);
             }
             if constexpr (ROLE < 2) {
-                if (!(ABL & 1)) {
-                    if (s_ < 5) v_row(Rr, s_, IC4<ROLE>{});
-                    else if (s_ < 11) v_col(s_ - 5, IC4<ROLE>{});
-                    else if (s_ < 17) { if (((s_ - 11) & 1) == 0) v_rowop((s_ - 11) >> 1); else v_put(Vn, (s_ - 11) >> 1, IC4<ROLE>{}); }
+                if (!(ABL & 1)) {            // (diagnosis: 128 no patch reads, 256 no V writes, 512 no transform arithmetic)
+                    if (s_ < 5) { if (!(ABL & 128)) v_row(Rr, s_, IC4<ROLE>{}); }
+                    else if (s_ < 11) { if (!(ABL & 512)) v_col(s_ - 5, IC4<ROLE>{}); }
+                    else if (s_ < 17) {
+                        if (((s_ - 11) & 1) == 0) { if (!(ABL & 512)) v_rowop((s_ - 11) >> 1); }
+                        else if (!(ABL & 256)) v_put(Vn, (s_ - 11) >> 1, IC4<ROLE>{});
+                    }
                 }
             } else {
                 if (s_ < 9) dma1(P ^ 1, s_);
@@ -315,11 +331,14 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(2);
         if constexpr (ROLE == 2) {
             if (P == 0) { raw_advance(); __builtin_amdgcn_s_waitcnt(0x0F70 | NIT); }       // the DMA pieces are older than the NIT raw loads
             else __builtin_amdgcn_s_waitcnt(0x0F70);
         }
+        stamp(3);
         __syncthreads();
+        stamp(4);
     };
 
     // the whole chunk loop once per role (a role branch INSIDE the loop makes the 144 accumulators a three-way phi at the loop header: hipcc
@@ -331,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
         mc += 2;
         if (mc != nch) continue;
         mc = 0;
+        stamp(5);
         // ---- epilogue of block mj: lane = tile 16 tg + l16, couts co0 + 16 cg + 4 kq + r;  Y = A^T M A,
         //      A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
         int n, oy0, ox0, cot; decode(mj, n, oy0, ox0, cot);
@@ -419,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
         }
 #pragma unroll
         for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stamp(6);
     }
     };
     if (wave >= 4) run(IC4<2>{});
@@ -426,6 +447,10 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     else run(IC4<0>{});
 }
 
+#ifdef WINO4_ABLATIONS
+static unsigned long long* g_w4_dbg = nullptr; static int g_w4_dbg_cap = 0;
+extern "C" void mrdis_debug_wino4_stamps(void* buf, int cap_per_wave) { g_w4_dbg = (unsigned long long*)buf; g_w4_dbg_cap = cap_per_wave; }
+#endif
 // the kernel's shape limits (the policy -- which layers SHOULD take it -- is mrdis_wino_u_fmt + the grid test below)
 int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
                     hipStream_t s, const float* u_img) {
@@ -453,7 +478,7 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
         if (hipFuncSetAttribute((const void*)wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
 #ifdef WINO4_ABLATIONS
 #define W4A(a) hipFuncSetAttribute((const void*)wino4_kernel<a>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS);
-        W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45)
+        W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45) W4A(64) W4A(65) W4A(72) W4A(96) W4A(105) W4A(192) W4A(320) W4A(576) W4A(448) W4A(832)
 #undef W4A
 #endif
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -461,8 +486,9 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
 #ifdef WINO4_ABLATIONS
     const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);          // debug_mode doubles as the ablation selector in this build
+    p.dbg = g_w4_dbg; p.dbg_cap = g_w4_dbg_cap;
 #define W4A(a) if (abl == a) { hipLaunchKernelGGL(wino4_kernel<a>, dim3(grid), dim3(NT4), W4_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
-    W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45)
+    W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45) W4A(64) W4A(65) W4A(72) W4A(96) W4A(105) W4A(192) W4A(320) W4A(576) W4A(448) W4A(832)
 #undef W4A
 #endif
     hipLaunchKernelGGL(wino4_kernel<0>, dim3(grid), dim3(NT4), W4_LDS, s, p);
