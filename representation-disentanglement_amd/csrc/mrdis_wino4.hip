@@ -531,7 +531,9 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
 int mrdis_wino_u_fmt(int R, int S, int spadeC) {
     if (!mrdis_opt(MRDIS_OPT_WINO4)) return 2;
     if (spadeC != 0) {                                 // fused gamma | beta filter (S = 2 C)
-        const int rmin_s = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
+        // measured with the SPADE epilogue (tools/spade4_check.py, B = 32): 32 -> 2 x 32 at 256x256 532 -> 388 us, 64 -> 2 x 64 at 128x128 437 -> 301 us,
+        // 128 -> 2 x 128 at 64x64 359 -> 232 us, at 32x32 (4 B images) 343 -> 224 us
+        const int rmin_s = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 32;
         return (R % 8 == 0 && R >= rmin_s && spadeC % 8 == 0 && spadeC >= 32 && 2 * spadeC <= BIAS4) ? 4 : 2;
     }
     // measured (tools/wino4_check.py, B = 32): 64 -> 128 at 128x128 349 -> 299 us forward / 323 -> 271 us data gradient, 128 -> 256 at 64x64 322 -> 210 /
