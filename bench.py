@@ -156,7 +156,7 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         if not bf:      # as in the step: the filter's Winograd-domain images, built once per step behind the mixing launch (mrdis_wino_u_jobs)
             jobs, imgs, blocks = [], [], 0
             for src, R, S, flip in ((wt, ci, co, 0), (wk, co, ci, 1)):
-                if S <= 32:
+                if S <= 32 and hip.wino_u_format(R, S) != 5:
                     imgs.append(None); continue
                 img = torch.zeros(hip.wino_u_image_floats(R, S), device=dev)
                 j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = src.data_ptr(), img.data_ptr(), R, S, flip, 0
@@ -175,6 +175,8 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
             nblk = B * ((h + 15) // 16) * ((w + 31) // 32) * ((S + 63) // 64)
             if not bf and hip.wino_u_format(R, S) == 4 and nblk >= 192:
                 return 'winograd F(4x4,3x3)', 0.25
+            if not bf and hip.wino_u_format(R, S) == 5 and B * ((h + 31) // 32) * ((w + 31) // 32) >= 192:
+                return 'winograd F(4x4,3x3), 32-cout form', 0.25
             return 'winograd F(2x2,3x3)', 4.0 / 9.0
         algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci), 'wgrad': ('winograd F(2x2,3x3)', 4.0 / 9.0)}
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()

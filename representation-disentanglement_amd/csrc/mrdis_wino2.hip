@@ -495,6 +495,26 @@ __global__ __launch_bounds__(256) void wino_u_jobs_kernel(const WinoUJob* __rest
     int lo = 0, hi = njobs - 1;                       // last job with block0 <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const WinoUJob j = jobs[lo];
+    if (j.fmt == 5) {
+        // narrow F(4x4, 3x3) image (mrdis_wino4.h): 32-cout tiles
+        const int nch4 = (j.R + MRDIS_W4_KC - 1) / MRDIS_W4_KC, tiles4 = (j.S + 31) / 32;
+        const long long total4 = (long long)tiles4 * nch4 * MRDIS_W4_KC * 32;
+        for (long long i = ((long long)blockIdx.x - j.block0) * 256 + threadIdx.x; i < total4; i += (long long)j.nblk * 256) {
+            const int m = (int)(i & 31), kq = (int)((i >> 5) & 3);
+            const long long tc = i >> 7;
+            const int c = (int)(tc % nch4), cot = (int)(tc / nch4);
+            const int r = c * MRDIS_W4_KC + kq, co = cot * 32 + m;
+            const bool ok = r < j.R && co < j.S;
+            float gr[9], U[36];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gr[t] = ok ? j.w[((long long)(j.flip ? 8 - t : t) * j.R + r) * j.S + co] : 0.f;
+            mrdis_w4_filter_transform(gr, U);
+            float* dst = j.img + tc * MRDIS_W4N_UCHUNK + kq * 64;
+#pragma unroll
+            for (int pt = 0; pt < 36; ++pt) dst[(pt >> 1) * 256 + ((2 * m + (pt & 1) + 32 * kq) & 63)] = U[pt];
+        }
+        return;
+    }
     if (j.fmt == 4) {
         // F(4x4, 3x3) image (mrdis_wino4.h): one thread = one (reduction channel, cout slot) pair = 36 values
         const int nch4 = (j.R + MRDIS_W4_KC - 1) / MRDIS_W4_KC, tiles4 = j.spadeC ? (j.spadeC + 31) / 32 : (j.S + 63) / 64;
@@ -559,11 +579,13 @@ static long long wino_u_elems(int R, int S, int spadeC) {       // (reduction ch
 }
 extern "C" int mrdis_wino_u_format(int R, int S, int spadeC) { return mrdis_wino_u_fmt(R, S, spadeC); }
 extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) {
-    return (mrdis_wino_u_fmt(R, S, spadeC) == 4 ? mrdis_wino4_image_floats(R, S, spadeC) : 0) + 16 * wino_u_elems(R, S, spadeC);
+    const int fmt = mrdis_wino_u_fmt(R, S, spadeC);
+    if (fmt == 5) return mrdis_wino4n_image_floats(R, S);
+    return (fmt == 4 ? mrdis_wino4_image_floats(R, S, spadeC) : 0) + 16 * wino_u_elems(R, S, spadeC);
 }
 extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
     const long long b = (wino_u_elems(R, S, spadeC) + 255) / 256;
-    const int cap = mrdis_wino_u_fmt(R, S, spadeC) == 4 ? 128 : 64;
+    const int cap = mrdis_wino_u_fmt(R, S, spadeC) >= 4 ? 128 : 64;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 extern "C" int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {

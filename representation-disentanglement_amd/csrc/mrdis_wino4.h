@@ -23,6 +23,12 @@ static inline __host__ __device__ long long mrdis_wino4_image_floats(int R, int 
     const int tiles = spadeC ? (spadeC + 31) / 32 : (S + 63) / 64;
     return (long long)tiles * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4_UCHUNK;
 }
+// format 5 (the narrow form, <= 32 couts): [32-cout tile][chunk of 4][18 point pairs][4 kq][64 slots], slot of (cout m, parity) = (2 m + parity + 32 kq) & 63;
+// no 16-point image behind it (the F(2x2) kernel for 32 couts has no image path)
+#define MRDIS_W4N_UCHUNK (18 * 256)
+static inline __host__ __device__ long long mrdis_wino4n_image_floats(int R, int S) {
+    return (long long)((S + 31) / 32) * ((R + MRDIS_W4_KC - 1) / MRDIS_W4_KC) * MRDIS_W4N_UCHUNK;
+}
 
 #ifdef __HIPCC__
 // the 36 values of one (reduction channel, cout) pair from its nine taps g[3 * row + col]

@@ -447,6 +447,310 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     else run(IC4<0>{});
 }
 
+
+// =========================================================================== narrow form: 64 tiles x 32 couts per workgroup
+// The layers with <= 32 couts -- the data gradient of the full-resolution gamma | beta convolution (64 -> 32 at 256x256), sp5.out (64 -> 32), ana.up_1
+// (128 -> 32) -- ran on the phase-by-phase F(2x2) kernel for 32 couts (46 % matrix-pipe utilisation at 4/9 of the direct multiplies: 14 ms of the step).
+// Here: 8 x 8 tiles (32 x 32 outputs) x 32 couts, wave = 16 tiles x 16 couts x 36 points as above (4 tile groups x 2 cout groups), 4-channel chunks.
+// Every wave carries every role (twice the input-transform work per MFMA of the 64-cout form: 64 tiles per 32 couts): V rows 3 rh .. 3 rh + 2 of channel
+// wave / 2 for the tile of its lane, its share of the raw block (one 16-byte pixel piece per item, single 4-channel chunks) and of the 18 filter pieces.
+// LDS: U 2 x 18 KB + V 2 x 36 KB + raw 2 x 21.25 KB + bias = 152.5 KB.  Image (format 5): [32-cout tile][chunk][18 point pairs][4 kq][64 slots].
+namespace {
+constexpr int N_UPP = 256, N_UBUF = 18 * N_UPP;           // 4608 floats
+constexpr int N_VPP = 512, N_VBUF = 18 * N_VPP;           // 9216 floats
+constexpr int N_RB = 34, N_PL = N_RB * RWP, N_RAWBUF = 4 * N_PL;      // 34 x 34 raw block, 1360-float planes, 5440 floats per buffer
+constexpr int N_NITEM = N_RB * N_RB, N_NIT = (N_NITEM + 511) / 512;  // 1156 pixel pieces, 3 per thread
+constexpr size_t W4N_LDS = sizeof(float) * (2 * N_UBUF + 2 * N_VBUF + 2 * N_RAWBUF + BIAS4);
+}  // namespace
+
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void wino4n_kernel(const Wino4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ub = smem;                           // [2][18][N_UPP]
+    float* const Vb = smem + 2 * N_UBUF;              // [2][18][N_VPP]
+    float* const Rb = Vb + 2 * N_VBUF;                // [2][4][N_PL]
+    float* const Bs = Rb + 2 * N_RAWBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 1, tg = wave >> 1;
+    const int a_off = kq * 64 + ((2 * (16 * cg + l16) + 32 * kq) & 63);
+    const int b_off = kq * 128 + ((2 * (16 * tg + l16) + 32 * kq) & 127);
+    // transform role: rows 3 rh .. 3 rh + 2 of V, channel kq_t of the chunk, tile = lane (8 x 8 tiles)
+    const int rh = wave & 1, kq_t = wave >> 1, ty_t = lane >> 3, tx_t = lane & 7;
+    const int v_lo = kq_t * N_PL + 4 * ty_t * RWP + w4_skew(ty_t) + 4 * tx_t;
+    const int v_hi = kq_t * N_PL + 4 * ty_t * RWP + w4_skew(ty_t + 1) + 4 * tx_t;
+    const int t_dst = kq_t * 128 + ((2 * lane + 32 * kq_t) & 127);
+    // staging role: N_NIT pixels of the 34 x 34 raw block (an item past the block stores into the unused columns 36-39 of row 0)
+    int s_l[N_NIT]; unsigned xg[N_NIT];
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) {
+        const int idx = tid + 512 * it, ry = idx / N_RB, rx = idx - ry * N_RB;
+        s_l[it] = idx < N_NITEM ? ry * RWP + w4_skew(ry >> 2) + rx : 36 + (lane & 3);
+        xg[it] = W4_OOB;
+    }
+
+    const int grid = gridDim.x;
+    const int rb0 = mrdis_xcd_remap(blockIdx.x, grid);
+    const int nmine = (p.nblk - rb0 + grid - 1) / grid;
+    const int nch = p.Cin / KC4;                                  // host: Cin % 8 == 0
+    const int total = nmine * nch;
+    auto decode = [&](int j, int& n, int& oy0, int& ox0, int& cot) {
+        int b = rb0 + j * grid;
+        cot = b % p.coTiles; b /= p.coTiles;
+        const int bx = b % p.nbx; b /= p.nbx;
+        const int by = b % p.nby;
+        n = b / p.nby; oy0 = 32 * by; ox0 = 32 * bx;
+    };
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    int rj = 0, rc = 0;
+    auto raw_block = [&]() {
+#pragma unroll
+        for (int it = 0; it < N_NIT; ++it) xg[it] = W4_OOB;
+        if (rj < nmine) {
+            int n, oy0, ox0, cot; decode(rj, n, oy0, ox0, cot);
+#pragma unroll
+            for (int it = 0; it < N_NIT; ++it) {
+                const int idx = tid + 512 * it, ry = idx / N_RB, rx = idx - ry * N_RB;
+                const int h = oy0 - 1 + ry, w_ = ox0 - 1 + rx;
+                if (idx < N_NITEM && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
+                    xg[it] = 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldin);
+            }
+        }
+    };
+    float4 xr[N_NIT];
+    auto load_raw1 = [&](int it, unsigned c0b) {
+        if (ABL & 32) { xr[it] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+        const u32x4_w4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(xg[it] != W4_OOB ? xg[it] + c0b : W4_OOB), 0, 0);
+        xr[it] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto raw_advance = [&]() { if (++rc == nch) { rc = 0; ++rj; raw_block(); } };
+    auto raw_store1 = [&](float* Rw, int it) {
+        float* d_ = Rw + s_l[it]; d_[0] = xr[it].x; d_[N_PL] = xr[it].y; d_[2 * N_PL] = xr[it].z; d_[3 * N_PL] = xr[it].w;
+    };
+    int fj = 0, fc = 0;
+    long long f_base = 0;
+    auto filt_block = [&]() {
+        f_base = 0;
+        if (fj < nmine) { int n, oy0, ox0, cot; decode(fj, n, oy0, ox0, cot); f_base = (long long)cot * nch * N_UBUF; }
+    };
+    const float* f_chunk = p.u_img;
+    const unsigned f_voff = 16u * (unsigned)lane + 1024u * (unsigned)wave;      // piece q = wave + 8 k of 18
+    const unsigned lds_u = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Ub;
+    auto filt_next = [&]() {
+        f_chunk = p.u_img + f_base + (long long)fc * N_UBUF;
+        if (++fc == nch) { fc = 0; ++fj; filt_block(); }
+    };
+    auto dma1 = [&](int buf, int k) {
+        if ((ABL & 8) || wave + 8 * k >= 18) return;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_u + 4u * (unsigned)(buf * N_UBUF) + 1024u * (unsigned)(wave + 8 * k));
+        const float* src = f_chunk + 2048 * k;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
+    };
+
+    float d[5][6], r[3][6], vo[6];
+    auto v_row = [&](const float* Rr, int ii, auto RH_) {
+        const int row = decltype(RH_)::value + ii;
+        const float* src = Rr + (row < 4 ? v_lo : v_hi) + row * RWP;
+        const f32x2_w4 a = w4_ld2(src), b = w4_ld2(src + 2), c = w4_ld2(src + 4);
+        d[ii][0] = a.x; d[ii][1] = a.y; d[ii][2] = b.x; d[ii][3] = b.y; d[ii][4] = c.x; d[ii][5] = c.y;
+    };
+    auto v_col = [&](int j, auto RH_) {
+        const float e0 = d[0][j], e1 = d[1][j], e2 = d[2][j], e3 = d[3][j], e4 = d[4][j];
+        if constexpr (decltype(RH_)::value == 0) {
+            const float a = fmaf(-4.f, e2, e4), b = fmaf(-4.f, e1, e3);
+            r[0][j] = fmaf(4.f, e0, fmaf(-5.f, e2, e4)); r[1][j] = a + b; r[2][j] = a - b;
+        } else {
+            const float c = e3 - e1, e = e2 - e0;
+            r[0][j] = fmaf(2.f, e, c); r[1][j] = fmaf(-2.f, e, c); r[2][j] = fmaf(4.f, e0, fmaf(-5.f, e2, e4));
+        }
+    };
+    auto v_rowop = [&](int a) {
+        const float r0 = r[a][0], r1 = r[a][1], r2 = r[a][2], r3 = r[a][3], r4 = r[a][4], r5 = r[a][5];
+        const float aa = fmaf(-4.f, r2, r4), bb = fmaf(-4.f, r1, r3), cc = r4 - r2, ee = r3 - r1;
+        vo[0] = fmaf(4.f, r0, fmaf(-5.f, r2, r4)); vo[1] = aa + bb; vo[2] = aa - bb;
+        vo[3] = fmaf(2.f, ee, cc); vo[4] = fmaf(-2.f, ee, cc); vo[5] = fmaf(4.f, r1, fmaf(-5.f, r3, r5));
+    };
+    auto v_put = [&](float* Vn, int a, auto RH_) {
+        constexpr int RH = decltype(RH_)::value;
+        float* vp = Vn + (3 * (3 * RH + a)) * N_VPP;
+        w4_st2(vp, f32x2_w4{vo[0], vo[1]}); w4_st2(vp + N_VPP, f32x2_w4{vo[2], vo[3]}); w4_st2(vp + 2 * N_VPP, f32x2_w4{vo[4], vo[5]});
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: U(0), V(0), raw chunks 0 and 1 in LDS, raw chunk 2 in registers
+    for (int c = tid; c < BIAS4; c += NT4) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+    raw_block(); filt_block();
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) load_raw1(it, 16u * (unsigned)rc);
+    raw_advance();
+    filt_next();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dma1(0, k);
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) raw_store1(Rb, it);
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) load_raw1(it, 16u * (unsigned)rc);
+    raw_advance();
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) raw_store1(Rb + N_RAWBUF, it);
+#pragma unroll
+    for (int it = 0; it < N_NIT; ++it) load_raw1(it, 16u * (unsigned)rc);       // chunk 2: stored in iteration 0
+    raw_advance();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | N_NIT);
+    __syncthreads();
+    {
+        float* Vn = Vb + t_dst;
+        if (rh == 0) {
+#pragma unroll
+            for (int ii = 0; ii < 5; ++ii) v_row(Rb, ii, IC4<0>{});
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v_col(j, IC4<0>{});
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { v_rowop(a); v_put(Vn, a, IC4<0>{}); }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 5; ++ii) v_row(Rb, ii, IC4<1>{});
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v_col(j, IC4<1>{});
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { v_rowop(a); v_put(Vn, a, IC4<1>{}); }
+        }
+    }
+    __syncthreads();
+
+    auto iteration = [&](auto P_, auto RH_) {
+        constexpr int P = decltype(P_)::value;
+        const float* Ua = smem + w4_opaque(P * N_UBUF + a_off);
+        const float* Va = smem + w4_opaque(2 * N_UBUF + P * N_VBUF + b_off);
+        const float* Rr = smem + w4_opaque(2 * N_UBUF + 2 * N_VBUF + (P ^ 1) * N_RAWBUF);        // raw chunk g + 1
+        float* Vn = smem + w4_opaque(2 * N_UBUF + (P ^ 1) * N_VBUF + t_dst);
+        float* Rw = Rb + P * N_RAWBUF;                 // raw chunk g + 2 (in registers since iteration g - 1) goes where chunk g was
+        filt_next();
+        const unsigned c0b = 16u * (unsigned)rc;       // raw chunk g + 3
+        f32x2_w4 av[3], bv[3];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) { av[s_] = w4_ld2(Ua + s_ * N_UPP); bv[s_] = w4_ld2(Va + s_ * N_VPP); }
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            if (s_ + 2 < 18) { av[(s_ + 2) % 3] = w4_ld2(Ua + (s_ + 2) * N_UPP); bv[(s_ + 2) % 3] = w4_ld2(Va + (s_ + 2) * N_VPP); }
+            if (!(ABL & 1)) {
+                if (s_ < 5) v_row(Rr, s_, RH_);
+                else if (s_ < 11) v_col(s_ - 5, RH_);
+                else if (s_ < 17) { if (((s_ - 11) & 1) == 0) v_rowop((s_ - 11) >> 1); else v_put(Vn, (s_ - 11) >> 1, RH_); }
+            }
+            // staging: the stores first (their data was loaded an iteration ago), then the filter pieces, then the next raw chunk's loads
+            if (s_ < N_NIT) raw_store1(Rw, s_);
+            else if (s_ < N_NIT + 3) dma1(P ^ 1, s_ - N_NIT);
+            else if (s_ >= 9 && s_ - 9 < N_NIT) load_raw1(s_ - 9, c0b);
+            const int c_ = s_ % 3;
+            if (!(ABL & 4)) {
+                acc[2 * s_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].x, bv[c_].x, acc[2 * s_], 0, 0, 0);
+                acc[2 * s_ + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c_].y, bv[c_].y, acc[2 * s_ + 1], 0, 0, 0);
+            } else { acc[2 * s_][0] += av[c_].x * bv[c_].x; acc[2 * s_ + 1][0] += av[c_].y * bv[c_].y; }
+#pragma unroll
+            for (int g_ = 0; g_ < 2; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        raw_advance();
+        __builtin_amdgcn_s_waitcnt(0x0F70 | N_NIT);   // the filter pieces are older than the N_NIT raw loads
+        __syncthreads();
+    };
+
+    auto run = [&](auto RH_) {
+    int mj = 0, mc = 0;
+    for (int g = 0; g < total; g += 2) {
+        iteration(IC4<0>{}, RH_); iteration(IC4<1>{}, RH_);
+        mc += 2;
+        if (mc != nch) continue;                       // host: Cin % 8 == 0, so a block ends after an odd iteration
+        mc = 0;
+        {
+            int n, oy0, ox0, cot; decode(mj, n, oy0, ox0, cot);
+            ++mj;
+            const int co0 = 32 * cot, tile = 16 * tg + l16;
+            const int oy = oy0 + 4 * (tile >> 3), ox = ox0 + 4 * (tile & 7);
+            const int co = co0 + 16 * cg + 4 * kq;
+            const bool full = oy0 + 32 <= p.H && ox0 + 32 <= p.W && co0 + 32 <= p.Cout;
+            const f32x4 slope = p.lrelu ? f32x4{0.2f, 0.2f, 0.2f, 0.2f} : f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (co < BIAS4 ? co : 0));
+            float* const o00 = p.out + ((long long)(n * p.H + oy) * p.W + ox) * p.ldout + co;
+            const long long rowp = (long long)p.W * p.ldout;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 t[6];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const f32x4 m1 = acc[6 + b], m2 = acc[12 + b], m3 = acc[18 + b], m4 = acc[24 + b];
+                    if (i == 0) t[b] = acc[b] + (m1 + m2) + (m3 + m4);
+                    else if (i == 1) t[b] = (m1 - m2) + 2.f * (m3 - m4);
+                    else if (i == 2) t[b] = (m1 + m2) + 4.f * (m3 + m4);
+                    else t[b] = (m1 - m2) + 8.f * (m3 - m4) + acc[30 + b];
+                }
+                const f32x4 s12 = t[1] + t[2], d12 = t[1] - t[2], s34 = t[3] + t[4], d34 = t[3] - t[4];
+                f32x4 y[4];
+                y[0] = t[0] + s12 + s34; y[1] = d12 + 2.f * d34; y[2] = s12 + 4.f * s34; y[3] = d12 + 8.f * d34 + t[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 v = y[k] + b4;
+                    v = __builtin_elementwise_max(v, v * slope);
+                    float* dst = o00 + i * rowp + k * p.ldout;
+                    if (full || (co < p.Cout && oy + i < p.H && ox + k < p.W)) {
+                        if (p.nt_out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                        else *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    };
+    if (rh) run(IC4<1>{}); else run(IC4<0>{});
+}
+
+int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
+                     hipStream_t s, const float* u_img) {
+    if (!u_img || (((uintptr_t)u_img) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (Ci % 8 != 0 || Ci < 16 || Co < 4 || Co % 4 != 0 || Co > 32 || ldx % 4 != 0 || ldy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W * ldx >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
+    Wino4Params p{};
+    p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
+    p.in = x; p.bias = bias; p.out = y; p.u_img = u_img;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
+    p.lrelu = lrelu;
+    { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
+    p.nby = mrdis_cdiv(H, 32); p.nbx = mrdis_cdiv(W, 32);
+    p.coTiles = mrdis_cdiv(Co, 32);
+    const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;
+    if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (nblk < 192 || H < 32 || W < 32)) return MRDIS_EUNSUPPORTED;
+    // A chunk is 16 bytes of every pixel, so a cache line of the input is touched by 4-8 successive chunks, an iteration apart: that re-use is served by
+    // L2 / the Infinity Cache while the input fits there (64 -> 32 at 128x128, 134 MB: 124 -> 100 us; 128 -> 32: 228 -> 157 us) and by HBM when it does
+    // not (64 -> 32 at 256x256, 537 MB: 474 -> 511 us)
+    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (long long)N * H * W * Ci * 4 > 200000000LL) return MRDIS_EUNSUPPORTED;
+    p.nblk = (int)nblk;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MRDIS_ELAUNCH;
+        if (hipFuncSetAttribute((const void*)wino4n_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4N_LDS) != hipSuccess) return MRDIS_EUNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    hipLaunchKernelGGL(wino4n_kernel<0>, dim3(grid), dim3(NT4), W4N_LDS, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 #ifdef WINO4_ABLATIONS
 static unsigned long long* g_w4_dbg = nullptr; static int g_w4_dbg_cap = 0;
 extern "C" void mrdis_debug_wino4_stamps(void* buf, int cap_per_wave) { g_w4_dbg = (unsigned long long*)buf; g_w4_dbg_cap = cap_per_wave; }
@@ -540,5 +844,6 @@ int mrdis_wino_u_fmt(int R, int S, int spadeC) {
     // 321 -> 205, 128 -> 64 at 64x64 85 -> 68 / 88 -> 74, 64 -> 64 at 128x128 171 -> 149 / 172 -> 158; 32 reduction channels (8 chunks per block: the
     // output transform + stores come round too often) 386 -> 387: no gain; < 64 couts leave half of the 64-cout tile empty
     const int rmin = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
+    if (R % 8 == 0 && R >= rmin && S <= 32 && S >= (mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 4 : 32) && S % 4 == 0) return 5;       // the narrow form (wino4n_kernel)
     return (R % 8 == 0 && R >= rmin && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
 }

@@ -268,9 +268,10 @@ class MixPlan:
             sz, o = self.sizes[ei], self.offs[ei]
             for mm in range(M):
                 tck_off, tkc_off = o + 2 * mm * sz, o + 2 * mm * sz + sz
-                if Cw > 32:
+                # (<= 32 couts: only the narrow F(4x4) form -- format 5 -- reads an image; the F(2x2) kernel for 32 couts transforms the taps itself)
+                if Cw > 32 or (not C and hip.wino_u_format(Ci, Cw) == 5):
                     want.append((ei, mm, 'spade' if C else 'fwd', tck_off, Ci, Cw, 0, C))
-                if Ci > 32:
+                if Ci > 32 or hip.wino_u_format(Cw, Ci) == 5:
                     want.append((ei, mm, 'dgrad', tkc_off, Cw, Ci, 1, 0))
         if not want:
             return

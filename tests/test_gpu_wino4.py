@@ -27,7 +27,7 @@ def build_images(hip, wt, wk):
     ci, co = wt.shape[1], wt.shape[2]
     jobs, imgs, blocks = [], [], 0
     for src, R, S, flip in ((wt, ci, co, 0), (wk, co, ci, 1)):
-        if S <= 32:
+        if S <= 32 and hip.wino_u_format(R, S) != 5:         # (<= 32 couts: only the narrow F(4x4) form reads an image)
             imgs.append(None); continue
         img = torch.full((hip.wino_u_image_floats(R, S),), float('nan'), device=DEV)
         j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = src.data_ptr(), img.data_ptr(), R, S, flip, 0
@@ -169,3 +169,41 @@ def test_f44_spade_epilogue(mrdis, case):
         gr = F.conv2d(x.cpu(), w, b.cpu(), 1, 1)
         ref = F.instance_norm(z.cpu(), eps=1e-5) * (1 + gr[:, :C]) + gr[:, C:]
         assert float((mix.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('B,ci,co,H,W', [(2, 64, 32, 40, 37), (3, 72, 20, 50, 70), (1, 16, 8, 64, 64), (2, 128, 32, 33, 65)])
+def test_f44_narrow_form_small_shapes(mrdis, B, ci, co, H, W):
+    """wino4n_kernel (<= 32 couts: 8 x 8 tiles x 32 couts per workgroup, image format 5): forward (bias + LeakyReLU) vs torch and the direct kernel;
+    ragged 32 x 32 blocks, couts that do not fill the tile."""
+    hip = mrdis.hip
+    hip.set_option('wino', 2); hip.set_option('wino4', 2)
+    assert hip.wino_u_format(ci, co) == 5
+    x = rnd((B, ci, H, W), 1); w = rnd((co, ci, 3, 3), 2, 0.05); b = rnd((co,), 3, 0.1)
+    wt = w.permute(2, 3, 1, 0).reshape(9, ci, co).contiguous().to(DEV)
+    wk = wt.permute(0, 2, 1).contiguous()
+    im_f, _ = build_images(hip, wt, wk)
+    assert im_f is not None and torch.isfinite(im_f).all()
+    y = hip.conv2d_fwd(cl(x), wt, b.to(DEV), 3, 3, 1, 1, lrelu=True, w_wino=im_f)
+    want = F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.2)
+    assert float((y.cpu() - want).abs().max()) <= 5e-5 * float(want.abs().max())
+    y2 = hip.conv2d_fwd(cl(x), wt, b.to(DEV), 3, 3, 1, 1, lrelu=True)        # no image: the F(2x2) kernel for 32 couts
+    assert not torch.equal(y, y2), 'the narrow F(4x4) kernel did not run'
+
+
+@pytest.mark.parametrize('name,R,S,hw', [('sp5.out forward', 64, 32, 128), ('ana.up_1 forward', 128, 32, 128)])
+def test_f44_narrow_layers_at_bench_scale(mrdis, name, R, S, hw):
+    """the 32-cout layers of the benchmarked step (B = 32) that the default policy gives to the narrow form (the 64 -> 32 data gradient at 256x256 stays on
+    the F(2x2) kernel: its 537 MB input does not stay cached between the chunks) against the direct kernel: <= 1e-4 of the maximum."""
+    hip = mrdis.hip
+    x = cl(rnd((32, R, hw, hw), 1))
+    wt = (rnd((9, R, S), 3, 0.05)).to(DEV); b = rnd((S,), 4, 0.1).to(DEV)
+    hip.set_option('wino4', 1)
+    assert hip.wino_u_format(R, S) == 5
+    im_f, _ = build_images(hip, wt, wt.permute(0, 2, 1).contiguous())
+    y = hip.conv2d_fwd(x, wt, b, 3, 3, 1, 1, w_wino=im_f)
+    y2 = hip.conv2d_fwd(x, wt, b, 3, 3, 1, 1)
+    hip.set_option('wino', 0)
+    yd = hip.conv2d_fwd(x, wt, b, 3, 3, 1, 1)
+    assert not torch.equal(y, y2), f'{name}: the narrow F(4x4) kernel did not run'
+    e = float((y - yd).abs().max() / yd.abs().max())
+    assert e <= 1e-4, (name, e)

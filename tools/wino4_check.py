@@ -32,7 +32,7 @@ def images(wt, wk, dev):
     ci, co = wt.shape[1], wt.shape[2]
     jobs, imgs, blocks = [], [], 0
     for src, R, S, flip in ((wt, ci, co, 0), (wk, co, ci, 1)):
-        if S <= 32:
+        if S <= 32 and hip.wino_u_format(R, S) != 5:         # (<= 32 couts: only the narrow F(4x4) form reads an image)
             imgs.append(None); continue
         img = torch.zeros(hip.wino_u_image_floats(R, S), device=dev)
         j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = src.data_ptr(), img.data_ptr(), R, S, flip, 0
@@ -71,11 +71,11 @@ def image_reference(w_trs, flip):
 def main():
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    shapes = [(2, 32, 64, 20, 37), (3, 40, 72, 50, 70), (1, 64, 128, 64, 64), (32, 32, 64, 256, 256), (32, 64, 128, 128, 128), (32, 128, 256, 64, 64),
+    shapes = [(2, 64, 32, 40, 37), (32, 64, 32, 256, 256), (32, 64, 32, 128, 128), (32, 128, 32, 128, 128), (2, 32, 64, 20, 37), (3, 40, 72, 50, 70), (1, 64, 128, 64, 64), (32, 32, 64, 256, 256), (32, 64, 128, 128, 128), (32, 128, 256, 64, 64),
               (32, 128, 64, 64, 64), (32, 128, 256, 32, 32), (32, 128, 128, 32, 32), (8, 512, 128, 32, 32), (8, 256, 64, 64, 64), (32, 64, 64, 128, 128)]
     small = len(sys.argv) > 1 and sys.argv[1] == 'small'
     if small:
-        shapes = shapes[:3]
+        shapes = [shapes[0]] + shapes[4:7]
     ok = True
     for (B, ci, co, H, W) in shapes:
         x = torch.randn(B, ci, H, W, device=dev).contiguous(memory_format=torch.channels_last)
@@ -89,7 +89,7 @@ def main():
                 hip.set_option(k, v)
             fmts = (hip.wino_u_format(ci, co), hip.wino_u_format(co, ci))
             im_f, im_b = images(wt, wk, dev) if name != 'direct' else (None, None)
-            if name == 'f4' and fmts[0] == 4 and ci * co <= 64 * 128:
+            if name == 'f4' and fmts[0] == 4 and ci * co <= 64 * 128:       # (format 5 is checked through the convolution)
                 want = image_reference(wt, 0).float()
                 got = im_f.cpu()[:want.numel()]             # (the 16-point fallback image follows)
                 e = float((got - want).abs().max() / want.abs().max())
