@@ -734,9 +734,9 @@ int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int l
     if (nblk > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (nblk < 192 || H < 32 || W < 32)) return MRDIS_EUNSUPPORTED;
     // A chunk is 16 bytes of every pixel, so a cache line of the input is touched by 4-8 successive chunks, an iteration apart: that re-use is served by
-    // L2 / the Infinity Cache while the input fits there (64 -> 32 at 128x128, 134 MB: 124 -> 100 us; 128 -> 32: 228 -> 157 us) and by HBM when it does
+    // L2 / the Infinity Cache while the input (about) fits there (64 -> 32 at 128x128, 134 MB: 124 -> 100 us; 128 -> 32, 268 MB: 228 -> 157 us) and by HBM when it does
     // not (64 -> 32 at 256x256, 537 MB: 474 -> 511 us)
-    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (long long)N * H * W * Ci * 4 > 200000000LL) return MRDIS_EUNSUPPORTED;
+    if (mrdis_opt(MRDIS_OPT_WINO4) < 2 && (long long)N * H * W * Ci * 4 > 300000000LL) return MRDIS_EUNSUPPORTED;
     p.nblk = (int)nblk;
     static int n_cu = 0;
     if (!n_cu) {
