@@ -12,3 +12,6 @@ struct WinoWgradParams {
 
 // pipelined 64 x 64 (ci, co) weight-gradient kernel; MRDIS_EUNSUPPORTED -> the caller launches wino_wgrad_kernel<4, 2>
 int mrdis_launch_wino_wgrad2(const WinoWgradParams& p, hipStream_t s);
+
+// Winograd F(3x3, 4x4) weight gradient (mrdis_wino4w.hip) on the same plan; sets p.splits to the slabs it wrote; MRDIS_EUNSUPPORTED -> the F(2x2) kernels
+int mrdis_launch_wino4_wgrad(WinoWgradParams& p, int max_splits, hipStream_t s);

@@ -643,9 +643,14 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    const int nblk = p.splits * p.nCiB * p.nCoB;
     int rc2 = MRDIS_EUNSUPPORTED;
-    if (pl.wci == 4 && pl.wco == 2 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {         // software-pipelined form (mrdis_wino2.hip)
+    {   // Winograd F(3x3, 4x4) (mrdis_wino4w.hip): 1.78x fewer MFMAs; writes its own number of slabs (<= the plan's) and sets p.splits to it
+        const int rc4 = mrdis_launch_wino4_wgrad(p, p.splits, s);
+        if (rc4 == MRDIS_OK) rc2 = MRDIS_OK;
+        else if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
+    }
+    const int nblk = p.splits * p.nCiB * p.nCoB;
+    if (rc2 != MRDIS_OK && pl.wci == 4 && pl.wco == 2 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {         // software-pipelined form (mrdis_wino2.hip)
         rc2 = mrdis_launch_wino_wgrad2(p, s);
         if (rc2 != MRDIS_OK && rc2 != MRDIS_EUNSUPPORTED) return rc2;
     }

@@ -1,0 +1,12 @@
+#!/bin/bash
+# ab/libmrdis_abl.so: the library with the F(4x4) kernels built -DWINO4_ABLATIONS (timing-only variants selected by option debug_mode, in-kernel stamps);
+# cross-compiles without a GPU.  Used by tools/wino4_abl.py, wino4_stamps.py, wgrad4_stamps.py.
+set -e
+cd "$(dirname "$0")/../representation-disentanglement_amd/csrc"
+make -j8 libmrdis_hip.so > /dev/null
+mkdir -p ../../ab
+for f in mrdis_wino4 mrdis_wino4w; do
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -DWINO4_ABLATIONS -c -o ../../ab/${f}_abl.o $f.hip
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl.so $(ls *.o | grep -v "mrdis_wino4.o\|mrdis_wino4w.o") ../../ab/mrdis_wino4_abl.o ../../ab/mrdis_wino4w_abl.o
+ls -la ../../ab/libmrdis_abl.so
