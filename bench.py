@@ -178,7 +178,9 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
             if not bf and hip.wino_u_format(R, S) == 5 and B * ((h + 31) // 32) * ((w + 31) // 32) >= 192:
                 return 'winograd F(4x4,3x3), 32-cout form', 0.25
             return 'winograd F(2x2,3x3)', 4.0 / 9.0
-        algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci), 'wgrad': ('winograd F(2x2,3x3)', 4.0 / 9.0)}
+        w4 = (not bf) and ci % 32 == 0 and co % 64 == 0 and h % 8 == 0 and w % 8 == 0 and hip.get_option('wino4') != 0
+        algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci),
+                 'wgrad': ('winograd F(3x3,4x4)', 0.25) if w4 else ('winograd F(2x2,3x3)', 4.0 / 9.0)}
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}
