@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
         if (ABL & 8) return;
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_u + 4u * (unsigned)(buf * UBUF) + 1024u * (unsigned)((wave & 3) + 4 * k));
         const float* src = f_chunk + 1024 * k;        // + 4 KiB per round of the four S waves
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
+        unsigned keep;                                 // M0 is the compiler's: written and restored inside the one statement that reads it
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
     };
 
     // ---- T: input transform pieces
@@ -545,7 +546,8 @@ __global__ __launch_bounds__(512, 2) void wino4n_kernel(const Wino4Params p) {
         if ((ABL & 8) || wave + 8 * k >= 18) return;
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_u + 4u * (unsigned)(buf * N_UBUF) + 1024u * (unsigned)(wave + 8 * k));
         const float* src = f_chunk + 2048 * k;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
+        unsigned keep;                                 // M0 is the compiler's: written and restored inside the one statement that reads it
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
     };
 
     float d[5][6], r[3][6], vo[6];
