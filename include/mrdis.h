@@ -287,6 +287,8 @@ int mrdis_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, 
  * statistics on: mrdis_conv2d_fwd_spade takes them as arguments, mrdis_instnorm_spade_fwd with workspace = NULL uses the ones in
  * save_mean / save_rstd instead of computing them.                                                                                */
 size_t mrdis_bilinear_up2_stats_workspace(int N, int Hi, int C);
+/* 1 where mrdis_bilinear_up2_stats_fwd takes (N, Wi, C) on dense aligned views, 0 where it would return MRDIS_EUNSUPPORTED (callers choose their path beforehand) */
+int mrdis_bilinear_up2_stats_applies(int N, int Wi, int C);
 int mrdis_bilinear_up2_stats_fwd(const void* x, int ldx, void* y, int ldy, int N, int Hi, int Wi, int C,
                                  int out_block, long long out_block_stride,
                                  float* save_mean, float* save_rstd, float eps, void* workspace, size_t workspace_bytes,

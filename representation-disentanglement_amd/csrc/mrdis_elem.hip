@@ -927,6 +927,13 @@ static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, in
     return MRDIS_OK;
 }
 
+// 1 where mrdis_bilinear_up2_stats_fwd takes the geometry (dense, 16-byte aligned views assumed), 0 where it returns MRDIS_EUNSUPPORTED: the block size it
+// picks must hold whole rows of C / 4 channel groups, the grid's y extent is N
+extern "C" int mrdis_bilinear_up2_stats_applies(int N, int Wi, int C) {
+    if (N < 1 || N > 65535 || Wi < 1 || C < 4 || C % 4 != 0) return 0;
+    return bil_threads((long long)Wi * (C / 4)) % (C / 4) == 0 ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ softmax([scale*mask, s])[1:]
 
 // ---- C ABI: activation views are fp32 or bf16 by `dtype` (include/mrdis.h MRDIS_DT_*); statistics, parameters and their

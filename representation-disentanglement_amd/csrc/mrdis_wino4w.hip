@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void wino4_wgrad_kernel(const Wino4WgradPar
     f32x4 acc[36];
 #pragma unroll
     for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int n_stamp = 0;
+    [[maybe_unused]] int n_stamp = 0;
     auto stamp = [&](int tag) {
 #ifdef WINO4_ABLATIONS
         if (p.dbg != nullptr && blockIdx.x < 4 && n_stamp < p.dbg_cap) {

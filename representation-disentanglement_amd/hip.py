@@ -70,6 +70,7 @@ _SIGS = {
     'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_up2_stats_workspace': (_Z, [_I, _I, _I]),
+    'mrdis_bilinear_up2_stats_applies': (_I, [_I, _I, _I]),
     'mrdis_bilinear_up2_stats_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _Z, _I, _P]),
     'mrdis_softmax_mask_drop_fwd': (_I, [_P, _I, _P, _P, _I, _L, _I, _F, _P]),
     'mrdis_softmax_mask_drop_bwd': (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
@@ -805,6 +806,10 @@ def bilinear_fwd(x, out_hw, align_corners):
     y = empty_nhwc(N, C, Ho, Wo, x.device, x.dtype)
     _chk(lib.mrdis_bilinear_fwd(_ptr(x), ldx, _ptr(y), C, N, Hi, Wi, Ho, Wo, C, 1 if align_corners else 0, _dt(x), _stream()), 'bilinear_fwd')
     return y
+
+
+def bilinear_up2_stats_applies(N, Wi, C):
+    return bool(load().mrdis_bilinear_up2_stats_applies(int(N), int(Wi), int(C)))
 
 
 def bilinear_up2_stats(x, eps, out_blocks=None):

@@ -1131,6 +1131,8 @@ class _Up2ScatterFn(Function):
             raise hip.MrdisError('bilinear_up2 (scatter): unsupported geometry')
         _, mean, rstd = res
         ctx.mark_non_differentiable(mean, rstd)
+        # (zbuf is written in place but not marked dirty: mark_dirty wants the tensor itself among the outputs, and the outputs are its block views; nothing
+        #  saves zbuf for backward and it does not require grad, so autograd's version counters have nothing to protect before the j-loop ends)
         return tuple(blocks[i] for i in range(M)) + (mean, rstd)
 
     @staticmethod
@@ -1172,7 +1174,10 @@ def set_up2_scatter(enabled):
 
 
 def up2_scatter_applies(x):
-    return _UP2_SCATTER and _UP2_STATS and x.is_cuda and type(x) is torch.Tensor and x.shape[1] % 4 == 0
+    """the block-scattered resize has no fallback inside its autograd node: ask the library beforehand whether its kernel takes this geometry (channel
+    counts such as 24 or 48 do not divide its block size; the grid's y extent limits N) -- otherwise the caller runs the dense resize + concatenation"""
+    return (_UP2_SCATTER and _UP2_STATS and x.is_cuda and type(x) is torch.Tensor and x.shape[1] % 4 == 0
+            and hip.bilinear_up2_stats_applies(x.shape[0], x.shape[3], x.shape[1]))
 
 
 def bilinear_up2_scatter(x, holder, j, M, stats_eps):
