@@ -2,6 +2,7 @@
 
   prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title]
   prof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substr> <grid>
+  prof_summary.py step   <prefix>_kernel_trace.csv <out.txt.gz> <steps profiled>      the last step's dispatches in launch order
 """
 import collections
 import csv
@@ -65,8 +66,30 @@ def pmc(fetch_csv, write_csv, out, substr, grid):
     print(res)
 
 
+def step(trace_csv, out, steps):
+    """one line per dispatch of the LAST profiled step (total dispatches / steps of them), in start order: gap to the previous kernel's end, duration,
+    workgroups, kernel -- the per-call view the per-family tables fold away (which call of a family is the slow one, where the queue ran dry)"""
+    import gzip
+    rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r['Start_Timestamp']))
+    n = len(rows) // steps
+    rows = rows[-n:]
+    prev_end = int(rows[0]['Start_Timestamp'])
+    t0 = prev_end
+    with gzip.open(out, 'wt') as f:
+        f.write(f'# last of {steps} profiled steps: {n} dispatches; columns: start us (from the first), gap us, duration us, workgroups, kernel\n')
+        for r in rows:
+            st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            wgs = 1
+            for ax in 'XYZ':
+                wgs *= max(1, int(r.get(f'Grid_Size_{ax}', 1) or 1)) // max(1, int(r.get(f'Workgroup_Size_{ax}', 1) or 1))
+            f.write(f"{(st - t0) / 1e3:10.1f} {(st - prev_end) / 1e3:8.1f} {(en - st) / 1e3:9.1f} {wgs:7d} {r['Kernel_Name'].split('(')[0][:70]}\n")
+            prev_end = max(prev_end, en)
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'step':
+        step(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 summary')
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else '')

@@ -18,6 +18,7 @@ python tools/prof_summary.py stats $OUT/ns_kernel_stats.csv $OUT/ns_kernel_trace
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ns_fetch -- python tools/northstar_conv.py 10 > $OUT/ns_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ns_write -- python tools/northstar_conv.py 10 > $OUT/ns_write.log 2>&1
 python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --no-roofline ($TAG): the training step only"
+python tools/prof_summary.py step $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_last_step.txt.gz 7
 python tools/dispatch_counts.py $OUT/bench_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_f32.txt
 python tools/dispatch_counts.py $OUT/bf16_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt
 python tools/prof_summary.py pmc $OUT/ns_fetch_counter_collection.csv $OUT/ns_write_counter_collection.csv $OUT/northstar_conv_pmc.json c4conv ""

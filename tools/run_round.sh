@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised runner for the GPU box (through gpurun), replacing the per-round one-off scripts:
 #   bash tools/run_round.sh TAG step [step ...]
-# steps: tests | tests:<pytest -k expression> | smoke | bench | bench_bf16 | bench_drop | rehearsal | layers | layers_bf16
+# steps: tests | tests:<pytest -k expression> | smoke | bench | bench_fast | bench_bf16 | bench_drop | rehearsal | layers | layers_bf16 | ew | aten | stepprof
 # Every step writes under gpurun_out/TAG/ and stops the script when it fails (no GPU step after a failed one).
 set -o pipefail
 TAG=${1:?tag}; shift
@@ -20,6 +20,10 @@ for step in "$@"; do
     rehearsal)  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_rehearsal.py > $OUT/ddp_rehearsal.txt 2>&1; rc=$?; grep "ddp rehearsal" $OUT/ddp_rehearsal.txt ;;
     layers)     python tools/layer_bench.py > $OUT/layer_bench_f32.txt 2>&1; rc=$?; tail -5 $OUT/layer_bench_f32.txt ;;
     layers_bf16) python tools/layer_bench.py --dtype bf16 > $OUT/layer_bench_bf16.txt 2>&1; rc=$?; tail -5 $OUT/layer_bench_bf16.txt ;;
+    ew)         python tools/ew_bench.py > $OUT/ew_bench.txt 2>&1 && python tools/elem_once.py > $OUT/elem_once.txt 2>&1; rc=$?; tail -8 $OUT/elem_once.txt ;;
+    aten)       HOSTPROF_SHAPE=32,4,256,256 python tools/aten_sources.py > $OUT/aten_sources.txt 2>&1; rc=$?; head -3 $OUT/aten_sources.txt ;;
+    stepprof)   ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sp -- python bench.py --no-direct --no-cpu-baseline --no-roofline > $OUT/stepprof.json 2> $OUT/stepprof.err ); rc=$?
+                [ $rc -eq 0 ] && python tools/prof_summary.py step $OUT/sp_kernel_trace.csv $OUT/${TAG}_last_step.txt.gz 7 && python tools/dispatch_counts.py $OUT/sp_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts.txt; rm -f $OUT/sp_kernel_trace.csv; grep "timed:" $OUT/stepprof.err ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
   [ $rc -eq 0 ] || { echo "step $step failed (rc $rc)"; exit $rc; }
