@@ -175,8 +175,10 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
             nblk = B * ((h + 15) // 16) * ((w + 31) // 32) * ((S + 63) // 64)
             if not bf and hip.wino_u_format(R, S) == 4 and nblk >= 192:
                 return 'winograd F(4x4,3x3)', 0.25
-            if not bf and hip.wino_u_format(R, S) == 5 and B * ((h + 31) // 32) * ((w + 31) // 32) >= 192 and B * h * w * R * 4 <= 300000000:
-                return 'winograd F(4x4,3x3), 32-cout form', 0.25
+            if not bf and hip.wino_u_format(R, S) == 5 and B * ((h + 31) // 32) * ((w + 31) // 32) >= 192:
+                big = B * h * w * R * 4 > 300000000 and hip.get_option('wino4r') != 0
+                if big or B * h * w * R * 4 <= 300000000:
+                    return 'winograd F(4x4,3x3), 32-cout form' + (' (register-fed, channel-split)' if big else ''), 0.25
             return 'winograd F(2x2,3x3)', 4.0 / 9.0
         w4 = (not bf) and ci % 32 == 0 and co % 64 == 0 and h % 8 == 0 and w % 8 == 0 and hip.get_option('wino4') != 0
         algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci),
@@ -425,15 +427,16 @@ def main():
                        'parallelism': f'dp{world}', 'missing_modality': bool(a.drop),
                        'output_decoder': bool(a.recon_y),
                        'conv_algorithms': {
-                           'f32': 'fp32 throughout; direct MFMA kernels + fused Winograd F(2x2,3x3) for the big 3x3 stride-1 layers '
-                                  f'(option wino = {mrdis.hip.get_option("wino")}; 0 = direct only)',
+                           'f32': 'fp32 throughout; direct MFMA kernels + fused Winograd for the big 3x3 stride-1 layers: F(4x4,3x3) forward / data gradient and '
+                                  'F(3x3,4x4) weight gradient on the 64+-channel layers, F(2x2,3x3) on the rest '
+                                  f'(options wino = {mrdis.hip.get_option("wino")}, wino4 = {mrdis.hip.get_option("wino4")}; wino = 0: direct only)',
                            'bf16': 'bf16 activations in HBM, direct convolutions on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); fp32 kernels '
                                    'on the 4- / 7-channel boundary layers; fp32 statistics, losses, master weights, optimizer',
                            'bf16m': 'fp32 activations, bf16 MFMA operands (fp32 accumulate) in the direct convolution kernels'}[a.dtype]},
             'loss': round(host_losses['all'], 5),
             'step_tflops': round(FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms * 1e-3) / 1e12, 2),
             'step_tflops_note': 'direct-convolution-equivalent FLOPs / step time' + (
-                ' (the big 3x3 layers run as Winograd F(2x2,3x3): 4/9 of these multiplies are executed)' if a.dtype == 'f32' else ''),
+                ' (the big 3x3 layers run as Winograd F(4x4,3x3) / F(2x2,3x3): 1/4 / 4/9 of these multiplies are executed)' if a.dtype == 'f32' else ''),
             'mfma_peak_tflops': MFMA_F32_PEAK_TF if a.dtype == 'f32' else MFMA_BF16_PEAK_TF,
             'mfma_peak_dtype': 'f32' if a.dtype == 'f32' else 'bf16',
             'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),

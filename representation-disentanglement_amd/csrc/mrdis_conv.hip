@@ -1187,13 +1187,16 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
 #include "mrdis_wino4.h"
 int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
                      hipStream_t s, const float* u_img);
+int mrdis_run_wino4r(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
+                     hipStream_t s, const float* u_img);     // the register-fed form of the same layers (mrdis_wino4r.hip)
 int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
                           float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr) {
     if (u_img && mrdis_wino_u_fmt(Ci, Co, 0) == 5) {       // <= 32 couts: the narrow F(4x4) form; declined -> the F(2x2) kernel for 32 couts (no image path)
         if (mrdis_opt(MRDIS_OPT_WINO_U)) {
-            const int rc = mrdis_run_wino4n(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
+            int rc = mrdis_run_wino4r(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
+            if (rc == MRDIS_EUNSUPPORTED) rc = mrdis_run_wino4n(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
         u_img = nullptr;

@@ -41,5 +41,6 @@ def _restore_library_options():
         m.hip.set_option('wino_pipe', int(os.environ.get('MRDIS_WINO_PIPE', '1')))
         m.hip.set_option('wino_u', int(os.environ.get('MRDIS_WINO_U', '1')))
         m.hip.set_option('wino4', int(os.environ.get('MRDIS_WINO4', '1')))
+        m.hip.set_option('wino4r', int(os.environ.get('MRDIS_WINO4R', '1')))
         m.hip.set_option('debug_now16', 1 if 'MRDIS_DEBUG_NOW16' in os.environ else 0)
         m.hip.set_option('debug_nopack', 1 if 'MRDIS_DEBUG_NOPACK' in os.environ else 0)

@@ -190,10 +190,54 @@ def test_f44_narrow_form_small_shapes(mrdis, B, ci, co, H, W):
     assert not torch.equal(y, y2), 'the narrow F(4x4) kernel did not run'
 
 
+@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('B,ci,co,H,W', [(2, 64, 32, 40, 37), (3, 72, 20, 50, 70), (1, 16, 8, 64, 64), (2, 128, 32, 33, 65), (1, 24, 32, 17, 96)])
+def test_f44_register_fed_form_small_shapes(mrdis, B, ci, co, H, W, mode):
+    """wino4r_kernel (mrdis_wino4r.hip: every wave transforms its own 16 tiles x 4 channels and feeds the MFMAs from registers), option wino4r = 2: 64-tile
+    workgroups, 3: channel-split wave pairs that add their partial outputs through LDS; ragged blocks, couts that do not fill the tile, odd stage counts."""
+    hip = mrdis.hip
+    hip.set_option('wino', 2); hip.set_option('wino4', 2)
+    assert hip.wino_u_format(ci, co) == 5
+    x = rnd((B, ci, H, W), 1); w = rnd((co, ci, 3, 3), 2, 0.05); b = rnd((co,), 3, 0.1)
+    wt = w.permute(2, 3, 1, 0).reshape(9, ci, co).contiguous().to(DEV)
+    im_f, _ = build_images(hip, wt, wt.permute(0, 2, 1).contiguous())
+    hip.set_option('wino4r', 0)
+    y0 = hip.conv2d_fwd(cl(x), wt, b.to(DEV), 3, 3, 1, 1, lrelu=True, w_wino=im_f)           # the shared-transform form
+    hip.set_option('wino4r', mode)
+    y = hip.conv2d_fwd(cl(x), wt, b.to(DEV), 3, 3, 1, 1, lrelu=True, w_wino=im_f)
+    hip.set_option('wino4r', 1)
+    want = F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.2)
+    assert float((y.cpu() - want).abs().max()) <= 5e-5 * float(want.abs().max())
+    if mode == 2:
+        assert torch.equal(y, y0)            # the same arithmetic in the same order as the shared-transform form: the same bits
+    else:
+        assert not torch.equal(y, y0), 'the channel-split form did not run'
+
+
+def test_f44_register_fed_form_at_bench_scale(mrdis):
+    """the data gradient of the full-resolution gamma | beta convolution (64 -> 32 at 256x256, B = 32: a 537 MB input): the default policy gives it to the
+    channel-split form of wino4r_kernel; against the direct kernel: <= 1e-4 of the maximum."""
+    hip = mrdis.hip
+    R, S, hw = 64, 32, 256
+    x = cl(rnd((32, R, hw, hw), 1))
+    wt = (rnd((9, R, S), 3, 0.05)).to(DEV)
+    hip.set_option('wino4', 1); hip.set_option('wino4r', 1)
+    assert hip.wino_u_format(R, S) == 5
+    im_f, _ = build_images(hip, wt, wt.permute(0, 2, 1).contiguous())
+    y = hip.conv2d_fwd(x, wt, None, 3, 3, 1, 1, w_wino=im_f)
+    hip.set_option('wino4r', 0)
+    y2 = hip.conv2d_fwd(x, wt, None, 3, 3, 1, 1, w_wino=im_f)     # (declined by the shared-transform form at this size: the F(2x2) kernel)
+    hip.set_option('wino4r', 1); hip.set_option('wino', 0)
+    yd = hip.conv2d_fwd(x, wt, None, 3, 3, 1, 1)
+    assert not torch.equal(y, y2), 'the register-fed F(4x4) kernel did not run'
+    e = float((y - yd).abs().max() / yd.abs().max())
+    assert e <= 1e-4, e
+
+
 @pytest.mark.parametrize('name,R,S,hw', [('sp5.out forward', 64, 32, 128), ('ana.up_1 forward', 128, 32, 128)])
 def test_f44_narrow_layers_at_bench_scale(mrdis, name, R, S, hw):
-    """the 32-cout layers of the benchmarked step (B = 32) that the default policy gives to the narrow form (the 64 -> 32 data gradient at 256x256 stays on
-    the F(2x2) kernel: its 537 MB input does not stay cached between the chunks) against the direct kernel: <= 1e-4 of the maximum."""
+    """the 32-cout layers of the benchmarked step (B = 32) that the default policy gives to the shared-transform narrow form (the 64 -> 32 data gradient at 256x256:
+    test_f44_register_fed_form_at_bench_scale) against the direct kernel: <= 1e-4 of the maximum."""
     hip = mrdis.hip
     x = cl(rnd((32, R, hw, hw), 1))
     wt = (rnd((9, R, S), 3, 0.05)).to(DEV); b = rnd((S,), 4, 0.1).to(DEV)
