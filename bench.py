@@ -176,9 +176,9 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
             if not bf and hip.wino_u_format(R, S) == 4 and nblk >= 192:
                 return 'winograd F(4x4,3x3)', 0.25
             if not bf and hip.wino_u_format(R, S) == 5 and B * ((h + 31) // 32) * ((w + 31) // 32) >= 192:
-                big = B * h * w * R * 4 > 300000000 and hip.get_option('wino4r') != 0
-                if big or B * h * w * R * 4 <= 300000000:
-                    return 'winograd F(4x4,3x3), 32-cout form' + (' (register-fed, channel-split)' if big else ''), 0.25
+                regfed = hip.get_option('wino4r') != 0 and (R <= 64 or B * h * w * R * 4 > 300000000)
+                if regfed or B * h * w * R * 4 <= 300000000:
+                    return 'winograd F(4x4,3x3), 32-cout form' + (' (register-fed)' if regfed else ''), 0.25
             return 'winograd F(2x2,3x3)', 4.0 / 9.0
         w4 = (not bf) and ci % 32 == 0 and co % 64 == 0 and h % 8 == 0 and w % 8 == 0 and hip.get_option('wino4') != 0
         algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci),

@@ -1554,7 +1554,7 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"wino_pipe", "MRDIS_WINO_PIPE", 0, 1},  // 1: the software-pipelined Winograd kernel (mrdis_wino2.hip) where it applies | 0: the phase-by-phase one
     {"wino_u", "MRDIS_WINO_U", 0, 1},        // 1: the pipelined kernel reads a pre-transformed filter image when the caller passes one | 0: always transforms the taps itself
     {"wino4", "MRDIS_WINO4", 0, 1},          // 1: F(4x4, 3x3) (mrdis_wino4.hip) for the filters mrdis_wino_u_format() names, where the grid fills the chip | 0: never | 2: wherever the kernel applies
-    {"wino4r", "MRDIS_WINO4R", 0, 1},        // <= 32 couts: 1: the register-fed F(4x4, 3x3) form (mrdis_wino4r.hip), channel-split wave pairs where the input is beyond the Infinity Cache | 0: the shared-transform form | 2 / 3: always its 64-tile / channel-split form
+    {"wino4r", "MRDIS_WINO4R", 0, 1},        // <= 32 couts: 1: the register-fed F(4x4, 3x3) form (mrdis_wino4r.hip) for <= 64 reduction channels and inputs beyond the Infinity Cache | 0: the shared-transform form | 2 / 3: always its 64-tile / channel-split form
     {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
     {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
     {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},

@@ -15,11 +15,10 @@
 //            L2 until the stages that need the rest of them (32 workgroups x 18 x 34 lines = 2.5 MB of 4 MB; with 64 tiles 4.7 MB: every
 //            line re-fetched from the Infinity Cache by all its 8 chunks -- 64 -> 32 at 256x256 then runs at the Infinity Cache's rate).
 //   NKH = 1: 4 tile groups x 2 cout halves, 64 tiles (32 x 32 outputs), each wave both chunks of a stage: no exchange, half the filter traffic.
-// Stage = 8 channels: two 4-channel groups of the raw block [rows][40 pixel slots][4 channels] by `buffer_load_dwordx4 ... lds` (a lane outside
+// Stage = 8 channels: the raw block [rows][40 pixels][2 quads][4 channels] by `buffer_load_dwordx4 ... lds` (a lane outside
 // the image reads beyond the descriptor: zeros = the padding) + two 18 KB filter chunks by `global_load_lds_dwordx4`, double-buffered; the next
 // block's first stage is in flight during a block's epilogue.
-// Raw block: pixel (y, x) at slot 40 y + ((y >> 2) & 3) + x: for a fixed patch position the 16 tiles of a wave (origins 4 ty, 4 tx) then sit at
-// 16 different slots mod 16 and lane (tile, k) reads dword k of its slot: 64 distinct banks per ds_read_b32.
+// Raw block: pixel (y, x) has index 40 y + ((y >> 2) & 3) + x (the skew keeps the 16 tiles of a wave -- origins 4 ty, 4 tx -- on different banks; see r_b).
 #include "mrdis_common.h"
 #include "mrdis_wino4.h"
 
@@ -44,8 +43,8 @@ template <int NKH> struct RGeo {
     static constexpr int BH = 16 * TGY;                     // output rows per block
     static constexpr int RBH = BH + 2;                      // raw rows
     static constexpr int RSLOTS = RBH * R_RWP;              // 16-byte slots per 4-channel group
-    static constexpr int PPG = (RSLOTS + 63) / 64;          // 1-KiB copy pieces per group (the last one moved back to end with the group)
-    static constexpr int NRP = (2 * PPG + 7) / 8;           // raw pieces per wave and stage (both groups; piece wave + 8 i, clamped to the last: a duplicate copy)
+    static constexpr int PPS = (2 * RSLOTS + 63) / 64;      // 1-KiB raw copy pieces per stage (the last one moved back to end with the block)
+    static constexpr int NRP = (PPS + 7) / 8;               // raw pieces per wave and stage (piece wave + 8 i, clamped to the last: a duplicate copy)
     static constexpr int NP = 5 + NRP;                      // + five of the 36 filter pieces
     static constexpr int NCH = NKH == 2 ? 1 : 2;            // chunks per wave and stage
     static constexpr int RGF = RSLOTS * 4;                  // floats per group
@@ -55,6 +54,8 @@ template <int NKH> struct RGeo {
     static constexpr size_t LDS = sizeof(float) * (2 * SBUF + EXTRA);
 };
 __device__ __forceinline__ f32x2_r r_ld2(const float* p) { return *(const volatile __attribute__((address_space(3))) f32x2_r*)p; }
+// (volatile: one ds_read_b32 each -- hipcc otherwise pairs neighbours into ds_read2_b32, which the LDS serves by the 32-bank rule: two tiles per bank here)
+__device__ __forceinline__ float r_ld1(const float* p) { return *(const volatile __attribute__((address_space(3))) float*)p; }
 }  // namespace
 
 template <int NKH, int ABL>
@@ -70,8 +71,17 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
     const int a_off = kq * 64 + ((2 * (16 * cq + l16) + 32 * kq) & 63);
     const int ty = l16 >> 2, tx = l16 & 3;
     const int ry0 = 16 * tgy + 4 * ty, rx0 = 16 * tgx + 4 * tx;
-    const int r_lo = 4 * (ry0 * R_RWP + ((ry0 >> 2) & 3) + rx0) + kq;                  // patch rows 0-3
-    const int r_hi = 4 * (ry0 * R_RWP + (((ry0 >> 2) + 1) & 3) + rx0) + kq;            // patch rows 4-5: the next tile-row group's skew
+    // raw block (8 channels of a stage): pixel (y, x) has index pidx = 40 y + ((y >> 2) & 3) + x and its two 4-channel quads sit in the neighbouring 16-byte slots
+    // 2 pidx + (q ^ ((x >> 3) & 1)) -- two lanes of a copy read the 32 contiguous bytes of a pixel (one fill of its 128-byte line instead of two: the copies
+    // are bound by the L1's line fills, a lane per line), and for a fixed patch position and quad the 16 tiles of a wave still sit at 16 different slots mod 16
+    // (2 (skew + 4 (tx & 1)) + quad ^ (tx >> 1 | (tx + 1) >> 1 for patch columns 4, 5)): 64 distinct banks per ds_read_b32.  Four bases: patch rows 0-3 / 4-5
+    // (the next tile-row group's skew) x patch columns 0-3 / 4-5; the quad of this wave's chunk is folded in (channel-split form) or XORed in per chunk.
+    int r_b[2][2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+            r_b[hi][ch] = (8 * (ry0 * R_RWP + (((ry0 >> 2) + hi) & 3) + rx0) + kq + 4 * (((tx + ch) >> 1) & 1)) ^ (NKH == 2 ? 4 * kh : 0);
 
     const int grid = gridDim.x;
     const int rb0 = mrdis_xcd_remap(blockIdx.x, grid);
@@ -86,24 +96,24 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
         n = b / p.nby; oy0 = G::BH * by; ox0 = 32 * bx;
     };
 
-    // ---- staging: a stage's copies are 36 filter pieces + 2 PPG raw pieces of 1 KiB (64 lanes x 16 bytes, landing at M0 + 16 lane); wave w issues filter
+    // ---- staging: a stage's copies are 36 filter pieces + PPS raw pieces of 1 KiB (64 lanes x 16 bytes, landing at M0 + 16 lane); wave w issues filter
     //      pieces w + 8 k and raw pieces w + 8 i, one or two per row step of its chunk(s) so that they queue behind the MFMAs instead of in front of them
     //      (issued in one burst at the top of the stage they held every wave for 1000-2000 cycles: the texture addresser takes 16 cycles per piece).
     //      An index past the last piece repeats the last piece (same bytes to the same place) rather than branching around the copy.
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     int s_yx[G::NRP]; unsigned s_off[G::NRP];
-    auto raw_piece = [&](int i, int& g, int& start) {
+    auto raw_piece = [&](int i, int& start) {
         int r = wave + 8 * i;
-        if (r > 2 * G::PPG - 1) r = 2 * G::PPG - 1;
-        g = r >= G::PPG ? 1 : 0;
-        start = 64 * (r - g * G::PPG);
-        if (start + 64 > G::RSLOTS) start = G::RSLOTS - 64;
+        if (r > G::PPS - 1) r = G::PPS - 1;
+        start = 64 * r;
+        if (start + 64 > 2 * G::RSLOTS) start = 2 * G::RSLOTS - 64;
     };
 #pragma unroll
     for (int i = 0; i < G::NRP; ++i) {
-        int g, start; raw_piece(i, g, start);
-        const int slot = start + lane, y = slot / R_RWP, xs = slot - y * R_RWP - ((y >> 2) & 3);
-        s_yx[i] = (xs >= 0 && xs < 34) ? ((y << 8) | xs) : -1;
+        int start; raw_piece(i, start);
+        const int slot = start + lane, pidx = slot >> 1, y = pidx / R_RWP, xs = pidx - y * R_RWP - ((y >> 2) & 3);
+        const int q = (slot & 1) ^ ((xs >> 3) & 1);
+        s_yx[i] = (xs >= 0 && xs < 34) ? ((q << 16) | (y << 8) | xs) : -1;
         s_off[i] = R_OOB;
     }
     int dj = 0, ds = 0;                                            // staging cursor: block index, stage
@@ -117,9 +127,9 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
             f_blk = p.u_img + (long long)cot * (2 * nst) * R_UCH;
 #pragma unroll
             for (int i = 0; i < G::NRP; ++i) {
-                const int h = oy0 - 1 + (s_yx[i] >> 8), w_ = ox0 - 1 + (s_yx[i] & 255);
+                const int h = oy0 - 1 + ((s_yx[i] >> 8) & 255), w_ = ox0 - 1 + (s_yx[i] & 255);
                 if (s_yx[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W)
-                    s_off[i] = 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldin);          // host: < 2^30 elements
+                    s_off[i] = 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldin) + 16u * (unsigned)(s_yx[i] >> 16);          // host: < 2^30 elements
             }
         }
     };
@@ -138,9 +148,9 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
                          : "=&s"(keep) : "s"(m0v), "v"(f_voff), "s"(src) : "memory");
         } else {
             if (ABL & 32) return;
-            int g, start; raw_piece(i - 5, g, start);
-            const unsigned soff = __builtin_amdgcn_readfirstlane(4u * (unsigned)(8 * ds + 4 * g));
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(base + 4u * (unsigned)(2 * R_UCH + g * G::RGF) + 16u * (unsigned)start);
+            int start; raw_piece(i - 5, start);
+            const unsigned soff = __builtin_amdgcn_readfirstlane(32u * (unsigned)ds);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(base + 4u * (unsigned)(2 * R_UCH) + 16u * (unsigned)start);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(s_off[i - 5]), "s"(m0v), "s"(rs_in), "s"(soff) : "memory");
@@ -167,15 +177,21 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
     //      MFMAs of row a_ + row a_ + 1 of B^T d (only the column arithmetic that row needs: 12 / 18 / 6 / 18 / 6 / 12 VALU for rows 0-5, so the MFMAs start
     //      24 VALU after the patch has landed instead of 84) and its row transform (12 VALU) + the three filter reads of row a_ + 3 + this wave's share of
     //      the next stage's copies, fenced so nothing leaves its step.  CI: index of the chunk in the stage (which copy pieces its steps issue into buffer nbuf).
+    float d[36];                                                   // the patch: d[6 r + c] = pixel (r, c) of this lane's (tile, channel)
+    auto patch_rows = [&](const float* Rg, int q, int par) {       // rows par, par + 2, par + 4 of quad q
+#pragma unroll
+        for (int r = par; r < 6; r += 2)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d[6 * r + c] = (ABL & 1) ? 1.f : r_ld1(Rg + (r_b[r >= 4][c >= 4] ^ (q ? 4 : 0)) + 8 * (r * R_RWP + c));
+    };
     auto chunk = [&](const float* Uc, const float* Rg, auto CI_, int nbuf) {
         constexpr int CI = decltype(CI_)::value;
-        float d[36], ca[6], cb[6], tr[6], v[2][6];
+        float ca[6], cb[6], tr[6], v[2][6];
         f32x2_r u[4][3];
         const float* Ua = Uc + a_off;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) d[6 * r + c] = (ABL & 1) ? 1.f : Rg[(r < 4 ? r_lo : r_hi) + 4 * (r * R_RWP + c)];
+        // 64-tile form: the second chunk's patch is read during the first chunk's MFMAs (rows 0, 2, 4 in step 3, rows 1, 3, 5 in step 5: into the registers
+        // the first patch has vacated by then), so only one patch read per stage stands in front of the MFMAs
+        if (NKH == 2 || CI == 0) { patch_rows(Rg, 0, 0); patch_rows(Rg, 0, 1); }
 #pragma unroll
         for (int a_ = 0; a_ < 3; ++a_)
 #pragma unroll
@@ -213,6 +229,8 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
                 for (int b2 = 0; b2 < 3; ++b2) u[(a_ + 3) & 3][b2] = (ABL & 2) ? f32x2_r{1.f, 1.f} : r_ld2(Ua + (3 * (a_ + 3) + b2) * 256);
             }
             if (a_ + 1 < 6) { col_row(a_ + 1); row_op(v[(a_ + 1) & 1]); }
+            if (NKH == 1 && CI == 0 && a_ == 3) patch_rows(Rg, 1, 0);
+            if (NKH == 1 && CI == 0 && a_ == 5) patch_rows(Rg, 1, 1);
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2) {
                 const int pp = 3 * a_ + b2;
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
             for (int g_ = 0; g_ < 6; ++g_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA,
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // at most one copy,
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // up to three LDS reads
                 __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // and five VALU in its shadow
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
     };
 
     // ---- prologue
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                  // the second-dispatched half loses every arbitration on its SIMD otherwise (MI355X_MICROARCH.md, two waves per SIMD)
     stage_block();
 #pragma unroll
     for (int i = 0; i < G::NP; ++i) stage_piece(0, i);
@@ -248,10 +267,10 @@ __global__ __launch_bounds__(512, 2) void wino4r_kernel(const Wino4rParams p) {
         const int nbuf = buf ^ 1;                                  // (past the last stage the cursor's copies read zeros / filter chunk 0 into a buffer nobody reads)
         const float* Sb = smem + buf * G::BSTRIDE;
         if constexpr (NKH == 2) {
-            chunk(Sb + kh * R_UCH, Sb + 2 * R_UCH + kh * G::RGF, ICR<0>{}, nbuf);
+            chunk(Sb + kh * R_UCH, Sb + 2 * R_UCH, ICR<0>{}, nbuf);
         } else {
             chunk(Sb, Sb + 2 * R_UCH, ICR<0>{}, nbuf);
-            chunk(Sb + R_UCH, Sb + 2 * R_UCH + G::RGF, ICR<1>{}, nbuf);
+            chunk(Sb + R_UCH, Sb + 2 * R_UCH, ICR<1>{}, nbuf);
         }
         stage_advance();
         stamp(3);
@@ -381,9 +400,10 @@ static int launch_wino4r(Wino4rParams& p, hipStream_t s) {
     return MRDIS_OK;
 }
 
-// u_img: the format-5 image of the layer's filter (mrdis_wino2.hip builds it).  Option wino4r: 0 = never, 1 = the channel-split form where the input is beyond
-// the Infinity Cache (64 -> 32 at 256x256: 395 us against 498 for the shared-transform form of mrdis_wino4.hip and 476 for F(2x2); smaller inputs stay on the
-// shared-transform form, which is as fast there), 2 / 3 = always the 64-tile / the channel-split form
+// u_img: the format-5 image of the layer's filter (mrdis_wino2.hip builds it).  Option wino4r: 0 = never (the shared-transform form of mrdis_wino4.hip where that
+// applies), 1 = the 64-tile form for <= 64 reduction channels and for inputs beyond the Infinity Cache, which the shared-transform form declines (B = 32: 64 -> 32
+// at 256x256 346 us against 476 for F(2x2) and 497 for the shared-transform form; at 128x128 88 against 101; 128 -> 32 at 128x128 level, 16 -> 32 behind), 2 / 3 =
+// always the 64-tile / the channel-split form
 int mrdis_run_wino4r(const float* x, int ldx, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu,
                      hipStream_t s, const float* u_img) {
     const long long mode = mrdis_opt(MRDIS_OPT_WINO4R);
@@ -397,6 +417,6 @@ int mrdis_run_wino4r(const float* x, int ldx, const float* bias, float* y, int l
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
     p.lrelu = lrelu;
     { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
-    if (mode == 1 && (long long)N * H * W * Ci * 4 <= 300000000LL) return MRDIS_EUNSUPPORTED;
-    return mode == 2 ? launch_wino4r<1>(p, s) : launch_wino4r<2>(p, s);
+    if (mode == 1 && Ci > 64 && (long long)N * H * W * Ci * 4 <= 300000000LL) return MRDIS_EUNSUPPORTED;
+    return mode == 3 ? launch_wino4r<2>(p, s) : launch_wino4r<1>(p, s);
 }

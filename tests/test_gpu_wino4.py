@@ -216,7 +216,7 @@ def test_f44_register_fed_form_small_shapes(mrdis, B, ci, co, H, W, mode):
 
 def test_f44_register_fed_form_at_bench_scale(mrdis):
     """the data gradient of the full-resolution gamma | beta convolution (64 -> 32 at 256x256, B = 32: a 537 MB input): the default policy gives it to the
-    channel-split form of wino4r_kernel; against the direct kernel: <= 1e-4 of the maximum."""
+    64-tile form of wino4r_kernel; against the direct kernel: <= 1e-4 of the maximum."""
     hip = mrdis.hip
     R, S, hw = 64, 32, 256
     x = cl(rnd((32, R, hw, hw), 1))
@@ -234,9 +234,9 @@ def test_f44_register_fed_form_at_bench_scale(mrdis):
     assert e <= 1e-4, e
 
 
-@pytest.mark.parametrize('name,R,S,hw', [('sp5.out forward', 64, 32, 128), ('ana.up_1 forward', 128, 32, 128)])
+@pytest.mark.parametrize('name,R,S,hw', [('sp5.out forward (register-fed form)', 64, 32, 128), ('ana.up_1 forward', 128, 32, 128)])
 def test_f44_narrow_layers_at_bench_scale(mrdis, name, R, S, hw):
-    """the 32-cout layers of the benchmarked step (B = 32) that the default policy gives to the shared-transform narrow form (the 64 -> 32 data gradient at 256x256:
+    """the 32-cout layers of the benchmarked step (B = 32) that the default policy gives to the two 32-cout forms (the 64 -> 32 data gradient at 256x256:
     test_f44_register_fed_form_at_bench_scale) against the direct kernel: <= 1e-4 of the maximum."""
     hip = mrdis.hip
     x = cl(rnd((32, R, hw, hw), 1))
