@@ -513,6 +513,113 @@ static int instnorm_spade_bwd_impl(const T* dout, int lddo, const T* z, int ldz,
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
+// SPADE backward whose z is the result of nn.Upsample(scale_factor=2, bilinear) (model.py:2551-2573 in front of :2440-2446): the apply pass of
+// instnorm_spade_bwd and the adjoint of the resize (bilinear_up2_bwd_kernel) in one kernel.  A workgroup owns 8 x 8 pixels of the LOW-resolution map x
+// 32 channels: phase 1 forms dz at the 18 x 18 full-resolution pixels that read them (each once: 3 streaming loads, d gamma / d beta stored by the
+// workgroup whose 16 x 16 block holds the pixel) into LDS, phase 2 sums the 4 x 4 neighbourhood of every low-resolution pixel (rows 2i-1 .. 2i+2, weights
+// 0.25 0.75 0.75 0.25; at a border the clamped row / column) from LDS -- the full-resolution dz (N x 2H x 2W x C, 268 MB on the last level at B = 32)
+// is neither written nor read back; the one-pixel halo is read by two workgroups (1.27 x the loads, the second mostly from L2).  Same expressions as
+// spade_bwd_kernel and bilinear_up2_bwd_kernel in the same order.  (A plain gather -- every thread forming the 16 dz of its pixel itself -- was 2 x slower
+// than the two kernels it replaces: 48 dependent-latency loads per output.)
+constexpr int UB_T = 8, UB_R = 2 * UB_T + 2, UB_CC = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
+                                                            const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
+                                                            T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) float tile[UB_R * UB_R * UB_CC];         // dz of the 18 x 18 pixels x 32 channels: 41.5 KB
+    const int tix = blockIdx.x % tiles_x, tiy = blockIdx.x / tiles_x, n = blockIdx.y;
+    const int c0 = UB_CC * blockIdx.z, cw = (C - c0 < UB_CC ? C - c0 : UB_CC), Q = cw / 4;
+    const int i0 = UB_T * tiy, j0 = UB_T * tix;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const float inv = 1.f / (float)((long long)Ho * Wo);
+    const long long img = (long long)n * Ho * Wo;
+    const int tid = threadIdx.x;
+    // ---- phase 1: dz (and d gamma, d beta) of the full-resolution pixels (2 i0 - 1 + ry, 2 j0 - 1 + rx), ry, rx < 18
+    const int q1 = tid % Q, p1 = tid / Q, pstep = 256 / Q;                            // host: 256 % Q == 0
+    float mu[4], rs[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int si = n * C + c0 + 4 * q1 + k; mu[k] = mean[si]; rs[k] = rstd[si]; a0[k] = s0[si] * inv; a1[k] = s1[si] * inv; }
+    for (int px = p1; px < UB_R * UB_R; px += pstep) {
+        const int ry = px / UB_R, rx = px - ry * UB_R;
+        const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
+        if ((unsigned)h >= (unsigned)Ho || (unsigned)w_ >= (unsigned)Wo) continue;
+        const long long pix = img + (long long)h * Wo + w_;
+        const int c = c0 + 4 * q1;
+        Vec<4> d, zz, gg, og; d.load(dout + pix * lddo + c); zz.load(z + pix * ldz + c); gg.load(g + pix * ldg + c);
+        float4 dz;
+        float* dzp = &dz.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float zh = (zz.v[k] - mu[k]) * rs[k];
+            const float dzh = d.v[k] * (1.f + gg.v[k]);
+            og.v[k] = d.v[k] * zh;                                                    // d gamma
+            dzp[k] = rs[k] * (dzh - a0[k] - zh * a1[k]);                              // instance-norm backward
+        }
+        *reinterpret_cast<float4*>(tile + (px * (UB_CC / 4) + q1) * 4) = dz;
+        if (ry >= 1 && ry <= 2 * UB_T && rx >= 1 && rx <= 2 * UB_T) {                 // this workgroup's own 16 x 16 pixels
+            og.store(dgm + pix * lddg + c);
+            if (dbt) d.store(dbt + pix * lddb + c);                                   // d beta = dout
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: the resize's adjoint from LDS
+    for (int it = tid; it < UB_T * UB_T * Q; it += 256) {
+        const int q = it % Q, lp = it / Q, li = lp / UB_T, lj = lp - li * UB_T;
+        const int i = i0 + li, j = j0 + lj;
+        if (i >= Hi || j >= Wi) continue;
+        int rr[4] = {2 * li, 2 * li + 1, 2 * li + 2, 2 * li + 3};                     // tile rows of full-resolution rows 2i-1 .. 2i+2
+        int cc[4] = {2 * lj, 2 * lj + 1, 2 * lj + 2, 2 * lj + 3};
+        if (i == 0) rr[0] = 1;                                                        // out[0] = 1.0 x[0]: the missing 0.25 comes from row 0 itself
+        if (i == Hi - 1) rr[3] = rr[2];                                               // out[Ho-1] = 1.0 x[Hi-1]
+        if (j == 0) cc[0] = 1;
+        if (j == Wi - 1) cc[3] = cc[2];
+        const float wr[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        Vec<4> acc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc.v[k] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float4 t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[b] = *reinterpret_cast<const float4*>(tile + ((rr[a] * UB_R + cc[b]) * (UB_CC / 4) + q) * 4);
+            const float* t0 = &t[0].x; const float* t1 = &t[1].x; const float* t2 = &t[2].x; const float* t3 = &t[3].x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc.v[k] += wr[a] * ((0.25f * t0[k] + 0.75f * t1[k]) + (0.75f * t2[k] + 0.25f * t3[k]));
+        }
+        acc.store(dxl + (((long long)n * Hi + i) * Wi + j) * lddx + c0 + 4 * q);
+    }
+}
+
+template <typename T>
+static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int ldz, const T* gamma, int ldg, const float* save_mean, const float* save_rstd,
+                                       T* dx, int lddx, T* dgamma, int lddg, T* dbeta, int lddb, void* workspace, size_t workspace_bytes,
+                                       int N, int Hi, int Wi, int C, void* stream) {
+    if (!dout || !z || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !workspace || N < 1 || Hi < 1 || Wi < 1 || C < 1) return MRDIS_EINVAL;
+    const long long HW = 4LL * Hi * Wi;
+    const size_t pbytes = mrdis_norm_workspace(N, HW, C);
+    const size_t need = pbytes + sizeof(float) * 2 * (size_t)N * C;
+    if (workspace_bytes < need) return MRDIS_EWORKSPACE;
+    const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dx, lddx, C) &&
+                   vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
+    // channel chunks of 32: the last one may be narrower; 256 threads split as (pixel, quad) need 256 % quads == 0: quads in {1, 2, 4, 8}
+    const int lastq = ((C - 1) % UB_CC + 1) / 4;
+    if (!v || N > 65535 || C > 65535 * UB_CC || (lastq & (lastq - 1)) != 0) return MRDIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = reinterpret_cast<float*>(workspace);
+    float* s0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
+    float* s1 = s0 + (size_t)N * C;
+    int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
+    if (rc) return rc;
+    const StatPlan sp = stat_plan(N, HW);
+    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    MRDIS_CHECK_LAUNCH();
+    const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
+    hipLaunchKernelGGL((spade_bwd_up2_kernel<T>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
+                       dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
 extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C) {
     return mrdis_norm_workspace(N, HW, C) + sizeof(float) * 2 * (size_t)N * C;
 }
@@ -989,6 +1096,13 @@ extern "C" int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* 
     return MRDIS_BY_DTYPE(dtype,
         instnorm_spade_bwd_impl((const float*)dout, lddo, (const float*)z, ldz, (const float*)gamma, ldg, save_mean, save_rstd, (float*)dz, lddz, (float*)dgamma, lddg, (float*)dbeta, lddb, workspace, workspace_bytes, N, HW, C, stream),
         instnorm_spade_bwd_impl((cbf)dout, lddo, (cbf)z, ldz, (cbf)gamma, ldg, save_mean, save_rstd, (bf)dz, lddz, (bf)dgamma, lddg, (bf)dbeta, lddb, workspace, workspace_bytes, N, HW, C, stream));
+}
+extern "C" int mrdis_instnorm_spade_bwd_up2(const void* dout, int lddo, const void* z, int ldz, const void* gamma, int ldg, const float* save_mean,
+                                            const float* save_rstd, void* dx, int lddx, void* dgamma, int lddg, void* dbeta, int lddb,
+                                            void* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int C, int dtype, void* stream) {
+    return MRDIS_BY_DTYPE(dtype,
+        instnorm_spade_bwd_up2_impl((const float*)dout, lddo, (const float*)z, ldz, (const float*)gamma, ldg, save_mean, save_rstd, (float*)dx, lddx, (float*)dgamma, lddg, (float*)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, stream),
+        instnorm_spade_bwd_up2_impl((cbf)dout, lddo, (cbf)z, ldz, (cbf)gamma, ldg, save_mean, save_rstd, (bf)dx, lddx, (bf)dgamma, lddg, (bf)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, stream));
 }
 extern "C" int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, long long P, int C, float slope, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype, lrelu_bwd_impl((const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, P, C, slope, stream),

@@ -29,7 +29,7 @@
 struct Wino4Params {
     const float* in; const float* bias; float* out; const float* u_img;
     int N, H, W, Cin, ldin, Cout, ldout;
-    int lrelu, nt_out;
+    int lrelu, nt_out, prio;
     int nby, nbx, coTiles, nblk;      // 16 x 32-output blocks per image, 64-cout tiles, blocks in total
     unsigned in_bytes;                // record count of the input's buffer descriptor
     // SPADE epilogue (wino4_kernel<., true>): the image is that of the fused gamma | beta filter of a SPADE block (Cout = 2 C) in the cout order
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     };
 
     // ---- prologue: U(0), V(0) and the raw double chunks 0 and 1 in LDS
+    if ((p.prio == 1 && wave >= 4) || (p.prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(1);
     for (int c = tid; c < BIAS4; c += NT4) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
     if (wave >= 4) {
         raw_block(); filt_block();
@@ -728,7 +729,7 @@ int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int l
     p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
     p.in = x; p.bias = bias; p.out = y; p.u_img = u_img;
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
-    p.lrelu = lrelu;
+    p.lrelu = lrelu; p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
     p.nby = mrdis_cdiv(H, 32); p.nbx = mrdis_cdiv(W, 32);
     p.coTiles = mrdis_cdiv(Co, 32);
@@ -767,7 +768,7 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
     p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
     p.in = x; p.bias = bias; p.out = y; p.u_img = u_img;
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = Co; p.ldout = ldy;
-    p.lrelu = lrelu;
+    p.lrelu = lrelu; p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     { const long long mb = mrdis_opt(MRDIS_OPT_NT_MB); p.nt_out = (long long)N * H * W * ldy * 4 >= mb * 1000000LL ? 1 : 0; }
     p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
     p.coTiles = mrdis_cdiv(Co, 64);
@@ -814,6 +815,7 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
     p.in_bytes = (unsigned)(4LL * ((long long)(N * H) * W - 1) * ldx + 4LL * Ci);
     p.in = x; p.bias = bias; p.out = mix; p.u_img = u_img;
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
+    p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
     p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
     p.coTiles = mrdis_cdiv(C, 32);

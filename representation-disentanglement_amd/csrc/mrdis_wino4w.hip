@@ -43,6 +43,7 @@ struct Wino4WgradParams {
     int N, H, W, Ci, ldx, Co, lddy;
     int ngy, ngx, ngroups;            // 8 x 8-position groups per image column / row, total
     int nCiB, nCoB, splits;
+    int prio;                         // experiment: 1 = s_setprio 1 for waves 4-7, 2 = for waves 0-3
     int s_n, s_gy, s_gx;              // `splits` groups as (images, group rows, group columns): the cursors advance by it with carries
     unsigned long long* dbg; int dbg_cap;      // diagnostic build (-DWINO4_ABLATIONS): s_memtime stamps of workgroups 0-3
 };
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void wino4_wgrad_kernel(const Wino4WgradPar
 #define WW_T(i, j) sc[32 + 4 * (i) + (j)]
 #define WW_ZO(k) sc[56 + (k)]
     float bsum = 0.f;
+    if ((p.prio == 1 && wave >= 4) || (p.prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(1);
 
     // ---- V waves: the raw x block by LDS-DMA (`buffer_load_dwordx4 ... offen lds`: 64 lanes x 16 bytes land at M0 + 16 lane; a lane whose pixel lies outside the
     //      image gets an offset beyond the descriptor's range, i.e. zeros: the convolution's zero padding).  Piece k = (wave & 3) + 4 j holds pixel slots 8 k .. 8 k + 7;
@@ -333,6 +335,7 @@ int mrdis_launch_wino4_wgrad(WinoWgradParams& base, int max_splits, hipStream_t 
     if (base.Ci % 32 != 0 || base.Co % 64 != 0 || base.ldx % 4 != 0 || (((uintptr_t)base.x) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if ((long long)base.N * base.H * base.W * base.ldx >= 0x3fffffffLL || (long long)base.N * base.H * base.W * base.lddy >= 0x3fffffffLL) return MRDIS_EUNSUPPORTED;
     Wino4WgradParams p{};
+    p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     p.x = base.x; p.dy = base.dy; p.slab = base.slab; p.bias_slab = base.bias_slab;
     p.N = base.N; p.H = base.H; p.W = base.W; p.Ci = base.Ci; p.ldx = base.ldx; p.Co = base.Co; p.lddy = base.lddy;
     p.ngy = mrdis_cdiv(p.H, 8); p.ngx = mrdis_cdiv(p.W, 8);

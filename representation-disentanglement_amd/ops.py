@@ -868,8 +868,10 @@ class _GbSpadeFn(Function):
     The backward is that of the two-step form (it needs gamma, which the fused kernel stores)."""
 
     @staticmethod
-    def forward(ctx, si_out, z, bias, G, eps, smean, srstd, *filt):
+    def forward(ctx, si_out, z, bias, G, eps, smean, srstd, up2_src, *filt):
         # smean / srstd: the instance statistics of z when its producer already took them (ops.bilinear_up2), else None
+        # up2_src: the map x with z = bilinear_up2(x), or None.  Given, z arrives DETACHED and the node's backward returns d x instead of d z: the resize's
+        # adjoint runs inside the SPADE backward kernel (hip.instnorm_spade_bwd up2=True) and the full-resolution d z never exists.
         bm = _COMPUTE_DTYPE == hip.DT_F32_BF16M
         B = z.shape[0] // G
         C, H, W = z.shape[1], z.shape[2], z.shape[3]
@@ -911,6 +913,7 @@ class _GbSpadeFn(Function):
             ctx.z_cast = False
         ctx.meta = (G, B, hip.DT_F32_BF16M if _COMPUTE_DTYPE != hip.DT_F32 else hip.DT_F32)
         ctx.wbs = wbs
+        ctx.up2 = up2_src is not None
         ctx.save_for_backward(si_out, z, gamma, mean, rstd, *[filt[2 * g + 1] for g in range(G)])
         return mix
 
@@ -920,9 +923,19 @@ class _GbSpadeFn(Function):
         si_out, z, gamma, mean, rstd = ctx.saved_tensors[:5]
         tkcs = ctx.saved_tensors[5:]
         H, W = z.shape[2], z.shape[3]
-        dz, dgb = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True)
-        if ctx.z_cast:
-            dz = hip.cast_view(dz, torch.float32)
+        dxs = None
+        if ctx.up2:
+            res = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True, up2=True) if not ctx.z_cast else None
+            if res is not None:
+                dxs, dgb = res
+                dz = None
+        if dxs is None:
+            dz, dgb = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True)
+            if ctx.z_cast:
+                dz = hip.cast_view(dz, torch.float32)
+            if ctx.up2:                              # the library declined the fused form: the resize's adjoint as a kernel of its own
+                dxs = hip.bilinear_bwd(dz, (H // 2, W // 2), False)
+                dz = None
         need_x = ctx.needs_input_grad[0]
         dx = hip.empty_nhwc(G * B, si_out.shape[1], H, W, z.device, si_out.dtype) if need_x else None
         dws, db_total = [], None
@@ -933,10 +946,17 @@ class _GbSpadeFn(Function):
             dw, db = hip.conv2d_bwd_weight(si_out[sl], dgb[sl], 3, 3, 1, 1, need_bias=True, dtype=dt)
             dws += [dw, None]
             db_total = db if db_total is None else db_total + db
-        return (dx, dz, db_total, None, None, None, None) + tuple(dws)
+        return (dx, dz, db_total, None, None, None, None, dxs) + tuple(dws)
 
 
 _GB_SPADE = _os.environ.get('MRDIS_GB_SPADE', '1') != '0'
+_UP2_BWD_FUSED = _os.environ.get('MRDIS_UP2_BWD_FUSED', '1') != '0'      # SPADE backward + the adjoint of the x2 resize in front of it as one kernel
+
+
+def set_up2_bwd_fused(enabled):
+    global _UP2_BWD_FUSED
+    _UP2_BWD_FUSED = bool(enabled)
+
 _GB_INPLACE = _os.environ.get('MRDIS_GB_INPLACE', '1') != '0'      # d(mix) written straight into the beta half of [dgamma | dbeta]
 
 
@@ -951,7 +971,11 @@ def gb_spade(si_out, z, filters, bias, eps):
     for a, b in filters:
         flat += [a, b]
     smean, srstd = in_stats_of(z, eps)
-    mix = _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, smean, srstd, *flat)
+    src = getattr(z, '_mrdis_up2_src', None) if _UP2_BWD_FUSED else None
+    if src is not None and src.requires_grad and torch.is_grad_enabled() and src.shape[0] == z.shape[0] and src.dtype == z.dtype:
+        mix = _GbSpadeFn.apply(si_out, z.detach(), bias, len(filters), eps, smean, srstd, src, *flat)
+    else:
+        mix = _GbSpadeFn.apply(si_out, z, bias, len(filters), eps, smean, srstd, None, *flat)
     mix._mrdis_want_dgb = True                       # a grouped convolution that reads `mix` writes d(mix) into the node's [dgamma | dbeta] buffer
     return mix
 
@@ -1223,6 +1247,7 @@ def bilinear_up2(x, stats_eps=None):
     y, mean, rstd = _BilinearUp2Stats.apply(x, float(stats_eps))
     if mean.numel():
         y._mrdis_in_stats = (mean, rstd, float(stats_eps))
+    y._mrdis_up2_src = x                                 # ops.gb_spade: the SPADE node takes x's gradient itself (no full-resolution d z)
     return y
 
 

@@ -581,6 +581,71 @@ def test_spade_bwd_beta_half_in_place(mrdis):
     assert torch.equal(dz, dz_ref) and torch.equal(dgb, dgb_ref)
 
 
+@pytest.mark.parametrize('N,C,h,w', [(3, 32, 20, 28), (2, 64, 7, 5), (1, 16, 1, 9), (2, 128, 16, 16)])
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('slot', [False, True])
+def test_spade_bwd_with_the_resize_adjoint_inside(mrdis, N, C, h, w, mode, slot):
+    """mrdis_instnorm_spade_bwd_up2: the SPADE backward whose z is a x2 bilinear resize, with the resize's adjoint applied inside the kernel, against the two
+    kernels it replaces (mrdis_instnorm_spade_bwd + mrdis_bilinear_bwd): [dgamma | dbeta] bit-identical, d x equal to rounding (fp32: the same expressions in
+    the same order; bf16: the two-kernel form rounds the full-resolution d z to bf16 on the way); one-pixel-wide and odd low-resolution maps (every border
+    clamp), the in-place beta half."""
+    hip = mrdis.hip
+    H, W = 2 * h, 2 * w
+    T = torch.bfloat16 if mode == 'bf16' else torch.float32
+    x = cl(rnd((N, C, h, w), 11)).to(T).contiguous(memory_format=torch.channels_last)
+    z = hip.bilinear_fwd(x, (H, W), False)
+    gamma = cl(rnd((N, C, H, W), 12, 0.3)).to(T).contiguous(memory_format=torch.channels_last)
+    zf = z.float()
+    mean = zf.mean(dim=(2, 3)).reshape(-1).contiguous(); rstd = (1.0 / (zf.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt()).reshape(-1).contiguous()
+    dsrc = cl(rnd((N, C, H, W), 13)).to(T).contiguous(memory_format=torch.channels_last)
+
+    def grad_in():
+        if not slot:
+            return dsrc
+        buf = hip.empty_nhwc(N, 2 * C, H, W, dev(), T); buf.fill_(9.0); buf._mrdis_gb_private = True
+        buf[:, C:].copy_(dsrc)
+        return buf[:, C:]
+    d1 = grad_in()
+    dz, dgb_ref = hip.instnorm_spade_bwd(d1, z, gamma, mean, rstd, fused_gb=True)
+    dx_ref = hip.bilinear_bwd(dz, (h, w), False)
+    d2 = grad_in()
+    res = hip.instnorm_spade_bwd(d2, z, gamma, mean, rstd, fused_gb=True, up2=True)
+    assert res is not None
+    dx, dgb = res
+    assert dx.shape == x.shape and dgb.shape == dgb_ref.shape
+    if slot:
+        assert dgb is d2._base
+    assert torch.equal(dgb, dgb_ref)
+    if mode == 'f32':
+        close(dx, dx_ref, rtol=2e-6, what='dx')
+    else:
+        ref64 = hip.bilinear_bwd(hip.instnorm_spade_bwd(d1.float(), z.float(), gamma.float(), mean, rstd, fused_gb=True)[0], (h, w), False)
+        e_new = float((dx.float() - ref64).abs().max()); e_old = float((dx_ref.float() - ref64).abs().max())
+        assert e_new <= 1.5 * e_old + 1e-3 * float(ref64.abs().max()), (e_new, e_old)
+
+
+def test_gb_spade_takes_the_gradient_of_the_resize_input(mrdis):
+    """ops.gb_spade on z = ops.bilinear_up2(x): the node receives z detached and returns d x itself (no full-resolution d z, no bilinear backward node);
+    the gradients of x, of the anatomy features and of the filters against the unfused graph."""
+    ops, hip = mrdis.ops, mrdis.hip
+    B, C, h, w = 2, 32, 12, 10
+    x0 = cl(rnd((B, C, h, w), 21)); si0 = cl(rnd((B, C, 2 * h, 2 * w), 22))
+    wt = rnd((9, C, 2 * C), 23, 0.05).to(dev()); bias = rnd((2 * C,), 24, 0.1).to(dev())
+    wk = wt.permute(0, 2, 1).contiguous()
+    outs = []
+    for fused in (False, True):
+        ops.set_up2_bwd_fused(fused)
+        x = x0.clone().requires_grad_(True); si = si0.clone().requires_grad_(True)
+        a, b = wt.clone().requires_grad_(True), wk.clone()
+        z = ops.bilinear_up2(x, 1e-5)
+        mix = ops.gb_spade(si, z, [(a, b)], bias, 1e-5)
+        (mix * cl(rnd(tuple(mix.shape), 25))).sum().backward()
+        outs.append((mix.detach(), x.grad, si.grad, a.grad))
+    ops.set_up2_bwd_fused(True)
+    assert torch.equal(outs[0][0], outs[1][0])
+    close(outs[1][1], outs[0][1], rtol=2e-6, what='dx'); close(outs[1][2], outs[0][2], rtol=2e-6, what='dsi'); close(outs[1][3], outs[0][3], rtol=2e-6, what='dw')
+
+
 @pytest.mark.parametrize('case', [(32, 256, 256, 16, 16, 4), (8, 64, 128, 64, 64, 4), (6, 128, 128, 16, 16, 3), (5, 32, 64, 37, 29, 3), (3, 16, 32, 128, 128, 3)], ids=str)
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 def test_stride2_dgrad_parity_classes_in_one_launch(mrdis, case, mode):
