@@ -277,13 +277,15 @@ int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz,
                              int N, long long HW, int C, int dtype, void* stream);
 /* The same backward when z = nn.Upsample(scale_factor=2, bilinear)(x) (model.py:2551-2573 in front of a SPADE block): z, dout, gamma, dgamma, dbeta
  * are (N, 2 Hi, 2 Wi, C); dx (N, Hi, Wi, C) receives the gradient of x -- the apply pass and the resize's adjoint in one kernel, the full-resolution
- * d z is neither written nor read back.  workspace as mrdis_instnorm_spade_bwd_workspace(N, 4 Hi Wi, C).  MRDIS_EUNSUPPORTED: views that are not
- * 16-byte aligned / C % 4 != 0 (the caller runs mrdis_instnorm_spade_bwd + mrdis_bilinear_bwd). */
+ * d z is neither written nor read back.  xlo != NULL: x itself (N, Hi, Wi, C); z may then be NULL -- both passes interpolate z from x exactly as
+ * mrdis_bilinear_fwd stored it, so the up-sampled map need not be kept for the backward.  workspace as
+ * mrdis_instnorm_spade_bwd_workspace(N, 4 Hi Wi, C).  MRDIS_EUNSUPPORTED: views that are not 16-byte aligned / C % 4 != 0 / a last 32-channel chunk
+ * whose width is not 4, 8, 16 or 32 (the caller runs mrdis_instnorm_spade_bwd + mrdis_bilinear_bwd). */
 int mrdis_instnorm_spade_bwd_up2(const void* dout, int lddo, const void* z, int ldz,
                                  const void* gamma, int ldg, const float* save_mean, const float* save_rstd,
                                  void* dx, int lddx, void* dgamma, int lddg, void* dbeta, int lddb,
                                  void* workspace, size_t workspace_bytes,
-                                 int N, int Hi, int Wi, int C, int dtype, void* stream);
+                                 int N, int Hi, int Wi, int C, const void* xlo, int ldxlo, int dtype, void* stream);
 
 /* ---- bilinear resize: nn.Upsample at model.py:2175 (align_corners=True),
  * 2432 / 2501-2509 (align_corners=False, arbitrary output size) --------------*/

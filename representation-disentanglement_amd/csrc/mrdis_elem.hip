@@ -51,6 +51,24 @@ static inline int ew_blocks(long long n) { long long b = (n + 255) / 256; if (b 
 
 #define EW_LOOP(total) for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (total); idx += (long long)gridDim.x * blockDim.x)
 
+// value (4 channels) at pixel (h, w) of the x2 bilinear resize (align_corners = False) of one image x (Hi x Wi, leading dimension ldx, pointer at the
+// image's channel group), exactly as bilinear_up2_fwd_kernel forms and STORES it (same products, same association, rounded to T): the kernels that read a
+// SPADE block's up-sampled input without its ever having been written (mrdis_instnorm_spade_bwd_up2 with xlo) take it from here.
+template <typename T>
+__device__ __forceinline__ void up2_value(const T* __restrict__ x, int ldx, int Hi, int Wi, int h, int w, float out[4]) {
+    const int i = h >> 1, j = w >> 1;
+    int r0, r1, c0, c1; float A0, A1, B0, B1;
+    if (h & 1) { r0 = i; r1 = i < Hi - 1 ? i + 1 : Hi - 1; A0 = 0.75f; A1 = 0.25f; }
+    else { r0 = i > 0 ? i - 1 : 0; r1 = i; A0 = i > 0 ? 0.25f : 0.f; A1 = i > 0 ? 0.75f : 1.f; }
+    if (w & 1) { c0 = j; c1 = j < Wi - 1 ? j + 1 : Wi - 1; B0 = 0.75f; B1 = 0.25f; }
+    else { c0 = j > 0 ? j - 1 : 0; c1 = j; B0 = j > 0 ? 0.25f : 0.f; B1 = j > 0 ? 0.75f : 1.f; }
+    const float4 p00 = ld4(x + ((long long)r0 * Wi + c0) * ldx), p01 = ld4(x + ((long long)r0 * Wi + c1) * ldx);
+    const float4 p10 = ld4(x + ((long long)r1 * Wi + c0) * ldx), p11 = ld4(x + ((long long)r1 * Wi + c1) * ldx);
+    const float* a = &p00.x; const float* b = &p01.x; const float* c = &p10.x; const float* d = &p11.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (float)(T)(A0 * (B0 * a[k] + B1 * b[k]) + A1 * (B0 * c[k] + B1 * d[k]));
+}
+
 // ------------------------------------------------------------------ grouped column statistics
 // rows of group g: [g*P, (g+1)*P).  part[((g*chunks + chunk)*2 + k)*C + c]
 struct StatPlan { int chunks, rpb; };
@@ -117,7 +135,9 @@ template <int MODE, typename T>
 __global__ __launch_bounds__(256) void stat_partial_vec_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
                                                                const T* __restrict__ g, int ldg, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int stat_per_group,
-                                                               long long P, int C, int rpb, float* __restrict__ part) {
+                                                               long long P, int C, int rpb, float* __restrict__ part,
+                                                               const T* __restrict__ xlo = nullptr, int ldxlo = 0, int Wlo = 0) {
+    // xlo (MODE 2): b is not stored -- it is the x2 bilinear resize of the (group, P / 4 pixels, Wlo wide) map xlo and is interpolated here (up2_value)
     __shared__ float red[256][9];                      // [thread][8 sums], padded
     const int grp = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     const long long r0 = (long long)chunk * rpb;
@@ -147,8 +167,14 @@ __global__ __launch_bounds__(256) void stat_partial_vec_kernel(const T* __restri
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { s0[k] += aa[k]; s1[k] += aa[k] * aa[k]; }
                 } else {
-                    const float4 bv = ld4(b + row * ldb + c);
-                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    float bb[4];
+                    if (MODE == 2 && xlo != nullptr) {
+                        const int Wo_ = 2 * Wlo, h_ = (int)(r / Wo_), w_ = (int)(r - (long long)h_ * Wo_);
+                        up2_value<T>(xlo + (long long)grp * (P >> 2) * ldxlo + c, ldxlo, (int)(P / (4LL * Wlo)), Wlo, h_, w_, bb);
+                    } else {
+                        const float4 bv = ld4(b + row * ldb + c);
+                        bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+                    }
                     float gg[4] = {0.f, 0.f, 0.f, 0.f};
                     if (MODE == 2) { const float4 gv = ld4(g + row * ldg + c); gg[0] = gv.x; gg[1] = gv.y; gg[2] = gv.z; gg[3] = gv.w; }
 #pragma unroll
@@ -228,14 +254,16 @@ static int stat_final_lanes(int chunks) { int y = 4; while (y < 16 && y * 8 < ch
 
 template <int MODE, typename T>
 static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, int ldg, const float* mean,
-                        const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s, int plan_groups = 0) {
+                        const float* rstd, int stat_per_group, int groups, long long P, int C, float* part, hipStream_t s, int plan_groups = 0,
+                        const T* xlo = nullptr, int ldxlo = 0, int Wlo = 0) {
     // plan_groups: take the chunking of a launch with that many groups (grouped BatchNorm chunks each group exactly as a call of its own would)
     const StatPlan sp = stat_plan(plan_groups > 0 ? plan_groups : groups, P);
-    const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || vec4_ok(b, ldb, C)) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
+    const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || (xlo ? vec4_ok(xlo, ldxlo, C) : vec4_ok(b, ldb, C))) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
                      ((C >> 2) >= 256 ? (C >> 2) % 256 == 0 : 256 % (C >> 2) == 0);
+    if (xlo && !vec) return MRDIS_EUNSUPPORTED;
     if (vec)
         hipLaunchKernelGGL((stat_partial_vec_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
-                           stat_per_group, P, C, sp.rpb, part);
+                           stat_per_group, P, C, sp.rpb, part, xlo, ldxlo, Wlo);
     else
     hipLaunchKernelGGL((stat_partial_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                        stat_per_group, P, C, sp.rpb, part);
@@ -526,8 +554,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
-                                                            T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x) {
+                                                            T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x,
+                                                            const T* __restrict__ xlo, int ldxlo) {
+    // xlo: z is not stored -- it is the x2 resize of xlo (N, Hi, Wi, C); the workgroup's 10 x 10 low-resolution neighbourhood goes through LDS and every
+    // full-resolution z is interpolated from it exactly as bilinear_up2_fwd_kernel formed (and stored) it
     __shared__ __attribute__((aligned(16))) float tile[UB_R * UB_R * UB_CC];         // dz of the 18 x 18 pixels x 32 channels: 41.5 KB
+    __shared__ __attribute__((aligned(16))) float xt[(UB_T + 2) * (UB_T + 2) * UB_CC];   // low-resolution rows i0-1 .. i0+8, columns j0-1 .. j0+8 (clamped): 12.8 KB
     const int tix = blockIdx.x % tiles_x, tiy = blockIdx.x / tiles_x, n = blockIdx.y;
     const int c0 = UB_CC * blockIdx.z, cw = (C - c0 < UB_CC ? C - c0 : UB_CC), Q = cw / 4;
     const int i0 = UB_T * tiy, j0 = UB_T * tix;
@@ -540,13 +572,39 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
     float mu[4], rs[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int si = n * C + c0 + 4 * q1 + k; mu[k] = mean[si]; rs[k] = rstd[si]; a0[k] = s0[si] * inv; a1[k] = s1[si] * inv; }
+    if (xlo != nullptr) {
+        for (int px = p1; px < (UB_T + 2) * (UB_T + 2); px += pstep) {
+            const int ly = px / (UB_T + 2), lx = px - ly * (UB_T + 2);
+            int i = i0 - 1 + ly, j = j0 - 1 + lx;
+            i = i < 0 ? 0 : (i > Hi - 1 ? Hi - 1 : i); j = j < 0 ? 0 : (j > Wi - 1 ? Wi - 1 : j);
+            *reinterpret_cast<float4*>(xt + (px * (UB_CC / 4) + q1) * 4) = ld4(xlo + (((long long)n * Hi + i) * Wi + j) * ldxlo + c0 + 4 * q1);
+        }
+        __syncthreads();
+    }
     for (int px = p1; px < UB_R * UB_R; px += pstep) {
         const int ry = px / UB_R, rx = px - ry * UB_R;
         const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
         if ((unsigned)h >= (unsigned)Ho || (unsigned)w_ >= (unsigned)Wo) continue;
         const long long pix = img + (long long)h * Wo + w_;
         const int c = c0 + 4 * q1;
-        Vec<4> d, zz, gg, og; d.load(dout + pix * lddo + c); zz.load(z + pix * ldz + c); gg.load(g + pix * ldg + c);
+        Vec<4> d, zz, gg, og; d.load(dout + pix * lddo + c); gg.load(g + pix * ldg + c);
+        if (xlo != nullptr) {
+            // (h, w) -> low-resolution rows / columns and weights as up2_value; tile coordinates = low-resolution index - (i0 - 1), clamped rows are copies
+            const int i = h >> 1, j = w_ >> 1;
+            int r0, r1, q0_, q1_; float A0, A1, B0, B1;
+            if (h & 1) { r0 = i; r1 = i < Hi - 1 ? i + 1 : Hi - 1; A0 = 0.75f; A1 = 0.25f; }
+            else { r0 = i > 0 ? i - 1 : 0; r1 = i; A0 = i > 0 ? 0.25f : 0.f; A1 = i > 0 ? 0.75f : 1.f; }
+            if (w_ & 1) { q0_ = j; q1_ = j < Wi - 1 ? j + 1 : Wi - 1; B0 = 0.75f; B1 = 0.25f; }
+            else { q0_ = j > 0 ? j - 1 : 0; q1_ = j; B0 = j > 0 ? 0.25f : 0.f; B1 = j > 0 ? 0.75f : 1.f; }
+            r0 -= i0 - 1; r1 -= i0 - 1; q0_ -= j0 - 1; q1_ -= j0 - 1;
+            const float4 p00 = *reinterpret_cast<const float4*>(xt + ((r0 * (UB_T + 2) + q0_) * (UB_CC / 4) + q1) * 4);
+            const float4 p01 = *reinterpret_cast<const float4*>(xt + ((r0 * (UB_T + 2) + q1_) * (UB_CC / 4) + q1) * 4);
+            const float4 p10 = *reinterpret_cast<const float4*>(xt + ((r1 * (UB_T + 2) + q0_) * (UB_CC / 4) + q1) * 4);
+            const float4 p11 = *reinterpret_cast<const float4*>(xt + ((r1 * (UB_T + 2) + q1_) * (UB_CC / 4) + q1) * 4);
+            const float* a_ = &p00.x; const float* b_ = &p01.x; const float* c_ = &p10.x; const float* d_ = &p11.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zz.v[k] = (float)(T)(A0 * (B0 * a_[k] + B1 * b_[k]) + A1 * (B0 * c_[k] + B1 * d_[k]));
+        } else zz.load(z + pix * ldz + c);
         float4 dz;
         float* dzp = &dz.x;
 #pragma unroll
@@ -594,13 +652,13 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
 template <typename T>
 static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int ldz, const T* gamma, int ldg, const float* save_mean, const float* save_rstd,
                                        T* dx, int lddx, T* dgamma, int lddg, T* dbeta, int lddb, void* workspace, size_t workspace_bytes,
-                                       int N, int Hi, int Wi, int C, void* stream) {
-    if (!dout || !z || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !workspace || N < 1 || Hi < 1 || Wi < 1 || C < 1) return MRDIS_EINVAL;
+                                       int N, int Hi, int Wi, int C, const T* xlo, int ldxlo, void* stream) {
+    if (!dout || (!z && !xlo) || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !workspace || N < 1 || Hi < 1 || Wi < 1 || C < 1) return MRDIS_EINVAL;
     const long long HW = 4LL * Hi * Wi;
     const size_t pbytes = mrdis_norm_workspace(N, HW, C);
     const size_t need = pbytes + sizeof(float) * 2 * (size_t)N * C;
     if (workspace_bytes < need) return MRDIS_EWORKSPACE;
-    const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dx, lddx, C) &&
+    const bool v = vec4_ok(dout, lddo, C) && (xlo ? vec4_ok(xlo, ldxlo, C) : vec4_ok(z, ldz, C)) && vec4_ok(gamma, ldg, C) && vec4_ok(dx, lddx, C) &&
                    vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
     // channel chunks of 32: the last one may be narrower; 256 threads split as (pixel, quad) need 256 % quads == 0: quads in {1, 2, 4, 8}
     const int lastq = ((C - 1) % UB_CC + 1) / 4;
@@ -609,14 +667,14 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     float* part = reinterpret_cast<float*>(workspace);
     float* s0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
     float* s1 = s0 + (size_t)N * C;
-    int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
+    int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s, 0, xlo, ldxlo, Wi);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
     hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
     hipLaunchKernelGGL((spade_bwd_up2_kernel<T>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
-                       dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x);
+                       dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1099,10 +1157,10 @@ extern "C" int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* 
 }
 extern "C" int mrdis_instnorm_spade_bwd_up2(const void* dout, int lddo, const void* z, int ldz, const void* gamma, int ldg, const float* save_mean,
                                             const float* save_rstd, void* dx, int lddx, void* dgamma, int lddg, void* dbeta, int lddb,
-                                            void* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int C, int dtype, void* stream) {
+                                            void* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int C, const void* xlo, int ldxlo, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype,
-        instnorm_spade_bwd_up2_impl((const float*)dout, lddo, (const float*)z, ldz, (const float*)gamma, ldg, save_mean, save_rstd, (float*)dx, lddx, (float*)dgamma, lddg, (float*)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, stream),
-        instnorm_spade_bwd_up2_impl((cbf)dout, lddo, (cbf)z, ldz, (cbf)gamma, ldg, save_mean, save_rstd, (bf)dx, lddx, (bf)dgamma, lddg, (bf)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, stream));
+        instnorm_spade_bwd_up2_impl((const float*)dout, lddo, (const float*)z, ldz, (const float*)gamma, ldg, save_mean, save_rstd, (float*)dx, lddx, (float*)dgamma, lddg, (float*)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, (const float*)xlo, ldxlo, stream),
+        instnorm_spade_bwd_up2_impl((cbf)dout, lddo, (cbf)z, ldz, (cbf)gamma, ldg, save_mean, save_rstd, (bf)dx, lddx, (bf)dgamma, lddg, (bf)dbeta, lddb, workspace, workspace_bytes, N, Hi, Wi, C, (cbf)xlo, ldxlo, stream));
 }
 extern "C" int mrdis_lrelu_bwd(const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, long long P, int C, float slope, int dtype, void* stream) {
     return MRDIS_BY_DTYPE(dtype, lrelu_bwd_impl((const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, P, C, slope, stream),

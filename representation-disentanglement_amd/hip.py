@@ -67,7 +67,7 @@ _SIGS = {
     'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
     'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
-    'mrdis_instnorm_spade_bwd_up2': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    'mrdis_instnorm_spade_bwd_up2': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _I, _I, _I, _P, _I, _I, _P]),
     'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_up2_stats_workspace': (_Z, [_I, _I, _I]),
@@ -768,30 +768,41 @@ def gb_slot(t):
     return base
 
 
-def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False, up2=False):
+def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False, up2=False, xlo=None):
     """returns (dz, dgamma); dbeta == dout and is not materialised.
     fused_gb=True: returns (dz, dgb) with dgb (N,2C,H,W) = [dgamma | dout] in one buffer (the gradient of
     a fused gamma+beta convolution output).
     up2=True (with fused_gb): z is the x2 bilinear resize of a map x -- the first result is d x (N, C, H/2, W/2), the resize's adjoint applied inside
-    the kernel (mrdis_instnorm_spade_bwd_up2); None when the library declines the geometry."""
+    the kernel (mrdis_instnorm_spade_bwd_up2); None when the library declines the geometry.  xlo = x: z may be None, the kernels interpolate it from x."""
     lib = load()
-    dout, lddo = nhwc(dout); z, ldz = nhwc(z); gamma, ldg = nhwc(gamma)
-    N, C, H, W = z.shape
+    dout, lddo = nhwc(dout); gamma, ldg = nhwc(gamma)
+    N, C, H, W = gamma.shape
+    if z is not None:
+        z, ldz = nhwc(z)
+    else:
+        assert up2 and xlo is not None
+        ldz = 0
     nb = _ws_bytes(lib.mrdis_instnorm_spade_bwd_workspace, N, H * W, C)
-    ws = _ws(nb, z.device)
-    dt = _dt(dout, z, gamma)
+    ws = _ws(nb, gamma.device)
+    dt = _dt(dout, gamma) if z is None else _dt(dout, z, gamma)
     if up2:
         assert fused_gb and H % 2 == 0 and W % 2 == 0
-        dx = empty_nhwc(N, C, H // 2, W // 2, z.device, z.dtype)
+        dx = empty_nhwc(N, C, H // 2, W // 2, gamma.device, gamma.dtype)
+        xl, ldxl = (None, 0)
+        if xlo is not None:
+            xl, ldxl = nhwc(xlo)
+            assert tuple(xl.shape) == (N, C, H // 2, W // 2) and xl.dtype == gamma.dtype
+        zp = _ptr(z) if z is not None else None
+        xp = _ptr(xl) if xl is not None else None
         base = gb_slot(dout)
         if base is not None:
-            rc = lib.mrdis_instnorm_spade_bwd_up2(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dx), C,
-                                                  base.data_ptr(), 2 * C, None, 0, _ptr(ws), nb, N, H // 2, W // 2, C, dt, _stream())
+            rc = lib.mrdis_instnorm_spade_bwd_up2(_ptr(dout), lddo, zp, ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dx), C,
+                                                  base.data_ptr(), 2 * C, None, 0, _ptr(ws), nb, N, H // 2, W // 2, C, xp, ldxl, dt, _stream())
             dgb = base
         else:
-            dgb = empty_nhwc(N, 2 * C, H, W, z.device, z.dtype)
-            rc = lib.mrdis_instnorm_spade_bwd_up2(_ptr(dout), lddo, _ptr(z), ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dx), C,
-                                                  dgb.data_ptr(), 2 * C, dgb.data_ptr() + dgb.element_size() * C, 2 * C, _ptr(ws), nb, N, H // 2, W // 2, C, dt, _stream())
+            dgb = empty_nhwc(N, 2 * C, H, W, gamma.device, gamma.dtype)
+            rc = lib.mrdis_instnorm_spade_bwd_up2(_ptr(dout), lddo, zp, ldz, _ptr(gamma), ldg, _ptr(mean), _ptr(rstd), _ptr(dx), C,
+                                                  dgb.data_ptr(), 2 * C, dgb.data_ptr() + dgb.element_size() * C, 2 * C, _ptr(ws), nb, N, H // 2, W // 2, C, xp, ldxl, dt, _stream())
         if rc == -2:
             return None
         _chk(rc, 'instnorm_spade_bwd_up2')

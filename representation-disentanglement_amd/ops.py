@@ -914,7 +914,9 @@ class _GbSpadeFn(Function):
         ctx.meta = (G, B, hip.DT_F32_BF16M if _COMPUTE_DTYPE != hip.DT_F32 else hip.DT_F32)
         ctx.wbs = wbs
         ctx.up2 = up2_src is not None
-        ctx.save_for_backward(si_out, z, gamma, mean, rstd, *[filt[2 * g + 1] for g in range(G)])
+        # the backward of the resized form interpolates z from the resize's input: the up-sampled map is not kept (a quarter of the bytes saved and read)
+        ctx.z_is_src = ctx.up2 and not ctx.z_cast and up2_src.dtype == z.dtype
+        ctx.save_for_backward(si_out, up2_src if ctx.z_is_src else z, gamma, mean, rstd, *[filt[2 * g + 1] for g in range(G)])
         return mix
 
     @staticmethod
@@ -922,10 +924,15 @@ class _GbSpadeFn(Function):
         G, B, dt = ctx.meta
         si_out, z, gamma, mean, rstd = ctx.saved_tensors[:5]
         tkcs = ctx.saved_tensors[5:]
-        H, W = z.shape[2], z.shape[3]
+        H, W = gamma.shape[2], gamma.shape[3]
         dxs = None
         if ctx.up2:
-            res = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True, up2=True) if not ctx.z_cast else None
+            if ctx.z_is_src:
+                res = hip.instnorm_spade_bwd(dmix, None, gamma, mean, rstd, fused_gb=True, up2=True, xlo=z)
+                if res is None:
+                    z = hip.bilinear_fwd(z, (H, W), False)
+            else:
+                res = hip.instnorm_spade_bwd(dmix, z, gamma, mean, rstd, fused_gb=True, up2=True) if not ctx.z_cast else None
             if res is not None:
                 dxs, dgb = res
                 dz = None
@@ -937,7 +944,7 @@ class _GbSpadeFn(Function):
                 dxs = hip.bilinear_bwd(dz, (H // 2, W // 2), False)
                 dz = None
         need_x = ctx.needs_input_grad[0]
-        dx = hip.empty_nhwc(G * B, si_out.shape[1], H, W, z.device, si_out.dtype) if need_x else None
+        dx = hip.empty_nhwc(G * B, si_out.shape[1], H, W, gamma.device, si_out.dtype) if need_x else None
         dws, db_total = [], None
         for g in range(G):
             sl = slice(g * B, (g + 1) * B)

@@ -616,12 +616,22 @@ def test_spade_bwd_with_the_resize_adjoint_inside(mrdis, N, C, h, w, mode, slot)
     if slot:
         assert dgb is d2._base
     assert torch.equal(dgb, dgb_ref)
+    ref64 = None
     if mode == 'f32':
         close(dx, dx_ref, rtol=2e-6, what='dx')
     else:
         ref64 = hip.bilinear_bwd(hip.instnorm_spade_bwd(d1.float(), z.float(), gamma.float(), mean, rstd, fused_gb=True)[0], (h, w), False)
         e_new = float((dx.float() - ref64).abs().max()); e_old = float((dx_ref.float() - ref64).abs().max())
         assert e_new <= 1.5 * e_old + 1e-3 * float(ref64.abs().max()), (e_new, e_old)
+    # z not stored: both passes interpolate it from x as the forward kernel formed it
+    d3 = grad_in()
+    dx3, dgb3 = hip.instnorm_spade_bwd(d3, None, gamma, mean, rstd, fused_gb=True, up2=True, xlo=x)
+    if mode == 'f32':
+        close(dgb3, dgb_ref, rtol=2e-6, what='dgb from x'); close(dx3, dx_ref, rtol=4e-6, what='dx from x')
+    else:
+        close(dgb3, dgb_ref, rtol=1e-2, what='dgb from x')
+        e3 = float((dx3.float() - ref64).abs().max())
+        assert e3 <= 1.5 * float((dx_ref.float() - ref64).abs().max()) + 1e-3 * float(ref64.abs().max())
 
 
 def test_gb_spade_takes_the_gradient_of_the_resize_input(mrdis):

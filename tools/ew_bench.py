@@ -50,7 +50,9 @@ def main():
         print(f'spade_bwd(+stats) C={C:3d} {h}x{h}: {t:7.1f} us  {9 * mb / t:6.2f} TB/s (9 passes)')
         t2 = timeit(lambda: hip.bilinear_bwd(hip.instnorm_spade_bwd(go, z, gb[:, :C], mean, rstd, fused_gb=True)[0], (h // 2, h // 2), False))
         t3 = timeit(lambda: hip.instnorm_spade_bwd(go, z, gb[:, :C], mean, rstd, fused_gb=True, up2=True))
-        print(f'spade_bwd(+stats) + x2 resize adjoint C={C:3d} {h}x{h}: two kernels {t2:7.1f} us, one kernel {t3:7.1f} us')
+        xl = cl(B, C, h // 2, h // 2)
+        t4 = timeit(lambda: hip.instnorm_spade_bwd(go, None, gb[:, :C], mean, rstd, fused_gb=True, up2=True, xlo=xl))
+        print(f'spade_bwd(+stats) + x2 resize adjoint C={C:3d} {h}x{h}: two kernels {t2:7.1f} us, one kernel {t3:7.1f} us, z interpolated from x {t4:7.1f} us')
 
 
 if __name__ == '__main__':
