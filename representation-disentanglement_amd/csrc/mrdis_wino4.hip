@@ -848,6 +848,8 @@ int mrdis_wino_u_fmt(int R, int S, int spadeC) {
     // 321 -> 205, 128 -> 64 at 64x64 85 -> 68 / 88 -> 74, 64 -> 64 at 128x128 171 -> 149 / 172 -> 158; 32 reduction channels (8 chunks per block: the
     // output transform + stores come round too often) 386 -> 387: no gain; < 64 couts leave half of the 64-cout tile empty
     const int rmin = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
-    if (R % 8 == 0 && R >= rmin && S <= 32 && S >= (mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 4 : 32) && S % 4 == 0) return 5;       // the narrow form (wino4n_kernel)
+    // <= 32 couts: the 32-cout forms (wino4r_kernel / wino4n_kernel) from 16 reduction channels on -- the data gradient of sp6.out (16 -> 32 at 256x256) 152 us on
+    // the F(2x2) phase kernel, 118-126 us here
+    if (R % 8 == 0 && R >= 16 && S <= 32 && S >= (mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 4 : 32) && S % 4 == 0) return 5;
     return (R % 8 == 0 && R >= rmin && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
 }
