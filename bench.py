@@ -170,6 +170,19 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
                'dgrad': lambda: hip.conv2d_bwd_data(dy, wk, (h, w), 3, 3, 1, 1, w_bf16=wb_b, out=dxo),
                'wgrad': lambda: hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, dtype=dt)}
         flop = 2.0 * 9 * ci * co * B * h * w
+        if not bf and co == 2 * ci:
+            # the forward AS THE STEP RUNS IT: the gamma | beta convolution with the SPADE modulation in its epilogue (model.py:2440-2446 as one kernel,
+            # mrdis_conv2d_fwd_spade: z in, mix and gamma out, the 2C-channel tensor never written), statistics of z already taken by the resize in front
+            C_ = ci
+            simg = torch.zeros(hip.wino_u_image_floats(ci, co, C_), device=dev)
+            j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC = wt.data_ptr(), simg.data_ptr(), ci, co, 0, C_
+            j.block0, j.nblk = 0, hip.wino_u_job_blocks(ci, co, C_)
+            hip.wino_u_jobs(hip.wino_u_table([j], dev), 1, j.nblk)
+            z_ = torch.randn(B, C_, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+            so = (hip.empty_nhwc(B, C_, h, w, dev, el), hip.empty_nhwc(B, C_, h, w, dev, el),
+                  z_.mean(dim=(2, 3)).reshape(-1).contiguous(), (1.0 / (z_.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt()).reshape(-1).contiguous())
+            if hip.gb_spade_fwd(x, wt, bias, z_, 1e-5, out=so, stats_ready=True, w_wino=simg) is not None:
+                fns['fwd_spade'] = lambda: hip.gb_spade_fwd(x, wt, bias, z_, 1e-5, out=so, stats_ready=True, w_wino=simg)
 
         def algo(R, S):        # which Winograd kernel the library's policy gives the forward / data gradient of an (R -> S) filter at this size
             nblk = B * ((h + 15) // 16) * ((w + 31) // 32) * ((S + 63) // 64)
@@ -183,6 +196,10 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         w4 = (not bf) and ci % 32 == 0 and co % 64 == 0 and h % 8 == 0 and w % 8 == 0 and hip.get_option('wino4') != 0
         algos = {'fwd': algo(ci, co), 'dgrad': algo(co, ci),
                  'wgrad': ('winograd F(3x3,4x4)', 0.25) if w4 else ('winograd F(2x2,3x3)', 4.0 / 9.0)}
+        if not bf and co == 2 * ci:
+            s4 = hip.wino_u_format(ci, co, ci) == 4 and B * ((h + 15) // 16) * ((w + 31) // 32) * ((ci + 31) // 32) >= 192
+            algos['fwd_spade'] = (('winograd F(4x4,3x3)' if s4 else 'winograd F(2x2,3x3)') + ' + SPADE modulation in the epilogue (the forward the step runs: z in, mix + gamma out)',
+                                  0.25 if s4 else 4.0 / 9.0)
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}

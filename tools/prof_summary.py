@@ -1,7 +1,7 @@
 """Condense rocprofv3 CSV output into the small summaries committed under profiles/.
 
   prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title]
-  prof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substr> <grid>
+  prof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substr> <grid> [tag]   (commit: profiles/HEAD_COMMIT, written before the snapshot leaves)
   prof_summary.py step   <prefix>_kernel_trace.csv <out.txt.gz> <steps profiled>      the last step's dispatches in launch order
 """
 import collections
@@ -47,7 +47,7 @@ def stats(stats_csv, trace_csv, out, title):
     open(out, 'w').write('\n'.join(lines) + '\n')
 
 
-def pmc(fetch_csv, write_csv, out, substr, grid):
+def pmc(fetch_csv, write_csv, out, substr, grid, tag=''):
     def mean(path, counter):
         v = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
              if r['Counter_Name'] == counter and substr in r['Kernel_Name'] and (not grid or r['Grid_Size'] == grid)]
@@ -56,7 +56,13 @@ def pmc(fetch_csv, write_csv, out, substr, grid):
     w, nw = mean(write_csv, 'WRITE_SIZE')
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half
     # of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane and dword stores.
-    res = {'kernel': substr, 'grid_size': grid, 'launches_fetch': nf, 'launches_write': nw,
+    import os
+    commit = ''
+    try:
+        commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'HEAD_COMMIT')).read().strip()
+    except OSError:
+        pass
+    res = {'tag': tag or 'untagged', 'commit': commit or 'n/a', 'kernel': substr, 'grid_size': grid, 'launches_fetch': nf, 'launches_write': nw,
            'FETCH_SIZE_KiB_per_launch': f, 'WRITE_SIZE_KiB_per_launch': w,
            'hbm_read_bytes_per_launch': None if f is None else 2 * f * 1024,
            'hbm_write_bytes_per_launch': None if w is None else w * 1024,
@@ -92,4 +98,4 @@ if __name__ == '__main__':
     elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 summary')
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else '')
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else '', sys.argv[7] if len(sys.argv) > 7 else '')

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): collects the rocprofv3 summaries that profiles/ keeps.
+# Before the call: git rev-parse --short HEAD > profiles/HEAD_COMMIT (the snapshot carries no .git; the PMC summary records that id).
 #   tools/profile_round.sh r04
 # The training step is profiled WITHOUT the roofline legs (their ~500 extra Winograd launches used to inflate the step's
 # kernel table, round-3 verdict); the legs get their own profile (roofline_*).
@@ -21,6 +22,6 @@ python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel
 python tools/prof_summary.py step $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_last_step.txt.gz 7
 python tools/dispatch_counts.py $OUT/bench_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_f32.txt
 python tools/dispatch_counts.py $OUT/bf16_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt
-python tools/prof_summary.py pmc $OUT/ns_fetch_counter_collection.csv $OUT/ns_write_counter_collection.csv $OUT/northstar_conv_pmc.json c4conv ""
+python tools/prof_summary.py pmc $OUT/ns_fetch_counter_collection.csv $OUT/ns_write_counter_collection.csv $OUT/northstar_conv_pmc.json c4conv "" $TAG
 rm -f $OUT/*_kernel_trace.csv $OUT/*_counter_collection.csv
 ls -la $OUT
