@@ -131,7 +131,7 @@ __global__ void stat_partial_kernel(const T* __restrict__ a, int lda, const T* _
 // and walks rows with float4 loads, `rows_pp` = 256 / (C/4) rows per pass of the block, 4 rows in flight per
 // thread.  The scalar kernel keeps 4 bytes per lane in flight and reached 1.9 TB/s on the 268 MB maps; the
 // statistics passes are pure streaming reads.  Block reduction in LDS, fixed order.
-template <int MODE, typename T>
+template <int MODE, typename T, bool INTERP = false>
 __global__ __launch_bounds__(256) void stat_partial_vec_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
                                                                const T* __restrict__ g, int ldg, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int stat_per_group,
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void stat_partial_vec_kernel(const T* __restri
                     for (int k = 0; k < 4; ++k) { s0[k] += aa[k]; s1[k] += aa[k] * aa[k]; }
                 } else {
                     float bb[4];
-                    if (MODE == 2 && xlo != nullptr) {
+                    if (MODE == 2 && INTERP) {
                         const int Wo_ = 2 * Wlo, h_ = (int)(r / Wo_), w_ = (int)(r - (long long)h_ * Wo_);
                         up2_value<T>(xlo + (long long)grp * (P >> 2) * ldxlo + c, ldxlo, (int)(P / (4LL * Wlo)), Wlo, h_, w_, bb);
                     } else {
@@ -261,9 +261,14 @@ static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, in
     const bool vec = vec4_ok(a, lda, C) && (MODE == 0 || (xlo ? vec4_ok(xlo, ldxlo, C) : vec4_ok(b, ldb, C))) && (MODE != 2 || vec4_ok(g, ldg, C)) &&
                      ((C >> 2) >= 256 ? (C >> 2) % 256 == 0 : 256 % (C >> 2) == 0);
     if (xlo && !vec) return MRDIS_EUNSUPPORTED;
-    if (vec)
+    if (vec && xlo) {
+        if constexpr (MODE == 2)                          // (its own instantiation: the interpolation's registers do not ride on the plain statistics passes)
+            hipLaunchKernelGGL((stat_partial_vec_kernel<2, T, true>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+                               stat_per_group, P, C, sp.rpb, part, xlo, ldxlo, Wlo);
+        else return MRDIS_EINVAL;
+    } else if (vec)
         hipLaunchKernelGGL((stat_partial_vec_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
-                           stat_per_group, P, C, sp.rpb, part, xlo, ldxlo, Wlo);
+                           stat_per_group, P, C, sp.rpb, part, nullptr, 0, 0);
     else
     hipLaunchKernelGGL((stat_partial_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                        stat_per_group, P, C, sp.rpb, part);

@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 VIEWS = ('as_strided', 'slice', 'select', 'view', 'empty', 't.', 'transpose', 'narrow', 'reshape', 'permute', 'expand', 'unsqueeze', 'squeeze', 'detach',
          'alias', '_unsafe_view', 'unfold', 'resize_', 'lift_fresh', 'is_', '_local_scalar', 'sym_', 'stride', 'size', 'numel', 'dim', 'record_stream',
          'split', 'chunk', 'unbind', 'contiguous', '_to_copy', 'to.', 'flatten', 'empty_like', 'empty_strided', 'new_empty', 'set_', 'item', 'is_pinned', 'pin_memory')
-agg = collections.Counter(); ops_at = collections.defaultdict(collections.Counter)
+agg = collections.Counter(); ops_at = collections.defaultdict(collections.Counter); big = collections.Counter()
 
 
 class Rec(TorchDispatchMode):
@@ -45,6 +45,11 @@ class Rec(TorchDispatchMode):
                     where = f'{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}'
                     break
             agg[where] += 1; ops_at[where][name.split('.')[0]] += 1
+            out = func(*args, **(kwargs or {}))
+            o = out[0] if isinstance(out, (tuple, list)) and out else out
+            if isinstance(o, torch.Tensor) and o.numel() * o.element_size() >= (8 << 20):
+                big[(where, name.split('.')[0], tuple(o.shape), str([tuple(a.stride()) for a in args if isinstance(a, torch.Tensor)][:2]))] += 1
+            return out
         return func(*args, **(kwargs or {}))
 
 
@@ -54,3 +59,6 @@ torch.cuda.synchronize()
 print(f'{sum(agg.values())} non-view ATen ops on device tensors in one step (main thread: forward + optimizer)')
 for w, c in agg.most_common(50):
     print(f'{c:6d}  {w[:70]:70s} ' + ', '.join(f'{k} {v}' for k, v in ops_at[w].most_common(5)))
+print('ATen ops whose result is >= 8 MiB (source, op, result shape, argument strides): count')
+for k, c in sorted(big.items(), key=lambda kv: -kv[1] * 1)[:40]:
+    print(f'{c:4d}  {k[0][:50]:50s} {k[1]:12s} {k[2]}  {k[3]}')
