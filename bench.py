@@ -456,6 +456,7 @@ def main():
                 ' (the big 3x3 layers run as Winograd F(4x4,3x3) / F(2x2,3x3): 1/4 / 4/9 of these multiplies are executed)' if a.dtype == 'f32' else ''),
             'mfma_peak_tflops': MFMA_F32_PEAK_TF if a.dtype == 'f32' else MFMA_BF16_PEAK_TF,
             'mfma_peak_dtype': 'f32' if a.dtype == 'f32' else 'bf16',
+            'key_aliases': {'step_tflops_f32': 'step_tflops', 'mfma_f32_peak_tflops': 'mfma_peak_tflops', 'step_tflops_f32_direct_only': 'step_tflops_direct_only'},      # round-2 names of the same fields
             'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),
             'step_tflops_direct_only': None if ms_direct is None else round(
                 FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
