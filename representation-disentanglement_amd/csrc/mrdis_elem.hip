@@ -5,6 +5,7 @@
 // Reductions are two-level with a fixed summation order (partials in fp32 over
 // short runs, combination in fp64) so every result is bit-reproducible.
 #include "mrdis_common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -554,13 +555,18 @@ static int instnorm_spade_bwd_impl(const T* dout, int lddo, const T* z, int ldz,
 // is neither written nor read back; the one-pixel halo is read by two workgroups (1.27 x the loads, the second mostly from L2).  Same expressions as
 // spade_bwd_kernel and bilinear_up2_bwd_kernel in the same order.  (A plain gather -- every thread forming the 16 dz of its pixel itself -- was 2 x slower
 // than the two kernels it replaces: 48 dependent-latency loads per output.)
+// ONEPASS (fp32, xlo given): no statistics pass at all.  d z = rstd (dzh - s0 / HW - zh s1 / HW) is linear in its three terms and so is the resize's adjoint U^T:
+//   d x = rstd (U^T dzh - 4 s0 / HW - (s1 / HW) rstd (U^T U x - 4 mean)),      dzh = dout (1 + gamma), U^T 1 = 4, U^T zh = rstd (U^T z - 4 mean), z = U x
+// so this kernel writes A = U^T dzh into dx and the partial sums of (dzh, dzh zh) over its own 16 x 16 pixels (one `part` chunk per tile, the layout
+// stat_final_kernel<1> reads), and spade_bwd_up2_final_kernel finishes d x in place from A, the sums and the 3 x 3 stencil U^T U of the LOW-resolution x:
+// dout and gamma are read once instead of twice, z never (0.7 GB less per full-resolution block at B = 32).
 constexpr int UB_T = 8, UB_R = 2 * UB_T + 2, UB_CC = 32;
-template <typename T>
+template <typename T, bool ONEPASS = false>
 __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
                                                             T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x,
-                                                            const T* __restrict__ xlo, int ldxlo) {
+                                                            const T* __restrict__ xlo, int ldxlo, float* __restrict__ part = nullptr) {
     // xlo: z is not stored -- it is the x2 resize of xlo (N, Hi, Wi, C); the workgroup's 10 x 10 low-resolution neighbourhood goes through LDS and every
     // full-resolution z is interpolated from it exactly as bilinear_up2_fwd_kernel formed (and stored) it
     __shared__ __attribute__((aligned(16))) float tile[UB_R * UB_R * UB_CC];         // dz of the 18 x 18 pixels x 32 channels: 41.5 KB
@@ -576,7 +582,11 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
     const int q1 = tid % Q, p1 = tid / Q, pstep = 256 / Q;                            // host: 256 % Q == 0
     float mu[4], rs[4], a0[4], a1[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int si = n * C + c0 + 4 * q1 + k; mu[k] = mean[si]; rs[k] = rstd[si]; a0[k] = s0[si] * inv; a1[k] = s1[si] * inv; }
+    for (int k = 0; k < 4; ++k) {
+        const int si = n * C + c0 + 4 * q1 + k; mu[k] = mean[si]; rs[k] = rstd[si];
+        a0[k] = ONEPASS ? 0.f : s0[si] * inv; a1[k] = ONEPASS ? 0.f : s1[si] * inv;
+    }
+    float ps0[4] = {0.f, 0.f, 0.f, 0.f}, ps1[4] = {0.f, 0.f, 0.f, 0.f};
     if (xlo != nullptr) {
         for (int px = p1; px < (UB_T + 2) * (UB_T + 2); px += pstep) {
             const int ly = px / (UB_T + 2), lx = px - ly * (UB_T + 2);
@@ -617,12 +627,33 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
             const float zh = (zz.v[k] - mu[k]) * rs[k];
             const float dzh = d.v[k] * (1.f + gg.v[k]);
             og.v[k] = d.v[k] * zh;                                                    // d gamma
-            dzp[k] = rs[k] * (dzh - a0[k] - zh * a1[k]);                              // instance-norm backward
+            dzp[k] = ONEPASS ? dzh : rs[k] * (dzh - a0[k] - zh * a1[k]);              // instance-norm backward (ONEPASS: its first term only)
         }
         *reinterpret_cast<float4*>(tile + (px * (UB_CC / 4) + q1) * 4) = dz;
         if (ry >= 1 && ry <= 2 * UB_T && rx >= 1 && rx <= 2 * UB_T) {                 // this workgroup's own 16 x 16 pixels
             og.store(dgm + pix * lddg + c);
             if (dbt) d.store(dbt + pix * lddb + c);                                   // d beta = dout
+            if (ONEPASS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ps0[k] += dzp[k]; ps1[k] += dzp[k] * ((zz.v[k] - mu[k]) * rs[k]); }
+            }
+        }
+    }
+    if (ONEPASS) {
+        // the 256 / Q threads of a channel quad, added in thread order (fixed order: bit-reproducible); the sums go through the x tile (read for the last time above)
+        __syncthreads();
+        float* red = xt;                                                              // [256][8] <= 10 x 10 x 32 floats
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = ps0[k]; red[tid * 8 + 4 + k] = ps1[k]; }
+        __syncthreads();
+        if (tid < Q) {
+            float t_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int u = tid; u < 256; u += Q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t_[k] += red[u * 8 + k];
+            float* dst = part + ((long long)(n * (int)gridDim.x + (int)blockIdx.x) * 2) * C + c0;      // group = image n, chunk = tile
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst[4 * tid + k] = t_[k]; dst[C + 4 * tid + k] = t_[4 + k]; }
         }
     }
     __syncthreads();
@@ -654,6 +685,59 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
     }
 }
 
+// d x = rstd (A - 4 s0 / HW - (s1 / HW) rstd (U^T U x - 4 mean)) in place on dx (which holds A = U^T dzh); U^T U along one axis is the 3-tap stencil that the x2
+// resize followed by its adjoint makes of x -- (0.375, 1.25, 0.375) inside, built here from the same clamped rows and weights as the two kernels (so every border
+// case, down to a one-pixel axis, is the composition of what they do)
+__device__ __forceinline__ void up2_gram_axis(int i, int Hi, float c[3], int idx[3]) {
+    const int Ho = 2 * Hi;
+    int rr[4] = {2 * i - 1, 2 * i, 2 * i + 1, 2 * i + 2};
+    const float wr[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (i == 0) rr[0] = 0;
+    if (i == Hi - 1) rr[3] = Ho - 1;
+    c[0] = c[1] = c[2] = 0.f;
+    idx[0] = i > 0 ? i - 1 : 0; idx[1] = i; idx[2] = i < Hi - 1 ? i + 1 : Hi - 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int h = rr[a], ii = h >> 1;
+        int r0, r1; float A0, A1;
+        if (h & 1) { r0 = ii; r1 = ii < Hi - 1 ? ii + 1 : Hi - 1; A0 = 0.75f; A1 = 0.25f; }
+        else { r0 = ii > 0 ? ii - 1 : 0; r1 = ii; A0 = ii > 0 ? 0.25f : 0.f; A1 = ii > 0 ? 0.75f : 1.f; }
+        c[r0 - i + 1] += wr[a] * A0; c[r1 - i + 1] += wr[a] * A1;                    // r0, r1 in {i - 1, i, i + 1}
+    }
+}
+__global__ void spade_bwd_up2_final_kernel(float* __restrict__ dx, int lddx, const float* __restrict__ xlo, int ldxlo, const float* __restrict__ mean,
+                                           const float* __restrict__ rstd, const float* __restrict__ s0, const float* __restrict__ s1,
+                                           int N, int Hi, int Wi, int C) {
+    const int Q = C / 4;
+    const float inv = 1.f / (4.f * (float)Hi * (float)Wi);
+    EW_LOOP((long long)N * Hi * Wi * Q) {
+        const long long pix = idx / Q; const int c = (int)(idx - pix * Q) * 4;
+        const int j = (int)(pix % Wi); const long long t = pix / Wi; const int i = (int)(t % Hi), n = (int)(t / Hi);
+        float cr[3], cc[3]; int ir[3], ic[3];
+        up2_gram_axis(i, Hi, cr, ir); up2_gram_axis(j, Wi, cc, ic);
+        float T[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float rowv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float4 v = ld4(xlo + (((long long)n * Hi + ir[a]) * Wi + ic[b]) * ldxlo + c);
+                rowv[0] += cc[b] * v.x; rowv[1] += cc[b] * v.y; rowv[2] += cc[b] * v.z; rowv[3] += cc[b] * v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) T[k] += cr[a] * rowv[k];
+        }
+        Vec<4> A, o; A.load(dx + pix * lddx + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int si = n * C + c + k;
+            const float rs = rstd[si];
+            o.v[k] = rs * (A.v[k] - 4.f * (s0[si] * inv) - (s1[si] * inv) * (rs * (T[k] - 4.f * mean[si])));
+        }
+        o.store(dx + pix * lddx + c);
+    }
+}
+
 template <typename T>
 static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int ldz, const T* gamma, int ldg, const float* save_mean, const float* save_rstd,
                                        T* dx, int lddx, T* dgamma, int lddg, T* dbeta, int lddb, void* workspace, size_t workspace_bytes,
@@ -669,6 +753,25 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     const int lastq = ((C - 1) % UB_CC + 1) / 4;
     if (!v || N > 65535 || C > 65535 * UB_CC || (lastq & (lastq - 1)) != 0) return MRDIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
+    if constexpr (std::is_same<T, float>::value) {
+        // one pass over the full-resolution tensors (see spade_bwd_up2_kernel ONEPASS): needs x itself and room for one partial pair per (image, tile, channel)
+        const size_t p1bytes = sizeof(float) * 2 * (size_t)N * tiles_x * tiles_y * C + 64;
+        if (xlo && workspace_bytes >= p1bytes + sizeof(float) * 2 * (size_t)N * C && mrdis_opt(MRDIS_OPT_MODE) != 2001) {
+            float* part1 = reinterpret_cast<float*>(workspace);
+            float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p1bytes);
+            float* t1 = t0 + (size_t)N * C;
+            hipLaunchKernelGGL((spade_bwd_up2_kernel<float, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                               save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1);
+            MRDIS_CHECK_LAUNCH();
+            const int chunks = tiles_x * tiles_y;
+            hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
+            MRDIS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(spade_bwd_up2_final_kernel, dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C);
+            MRDIS_CHECK_LAUNCH();
+            return MRDIS_OK;
+        }
+    }
     float* part = reinterpret_cast<float*>(workspace);
     float* s0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pbytes);
     float* s1 = s0 + (size_t)N * C;
@@ -677,7 +780,6 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     const StatPlan sp = stat_plan(N, HW);
     hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
-    const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
     hipLaunchKernelGGL((spade_bwd_up2_kernel<T>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
                        dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
     MRDIS_CHECK_LAUNCH();
@@ -685,6 +787,11 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
 }
 extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C) {
     return mrdis_norm_workspace(N, HW, C) + sizeof(float) * 2 * (size_t)N * C;
+}
+extern "C" size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C) {
+    const size_t two_pass = mrdis_instnorm_spade_bwd_workspace(N, 4LL * Hi * Wi, C);
+    const size_t one_pass = sizeof(float) * 2 * (size_t)N * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C;
+    return one_pass > two_pass ? one_pass : two_pass;
 }
 
 // ------------------------------------------------------------------ LeakyReLU backward

@@ -627,7 +627,13 @@ def test_spade_bwd_with_the_resize_adjoint_inside(mrdis, N, C, h, w, mode, slot)
     d3 = grad_in()
     dx3, dgb3 = hip.instnorm_spade_bwd(d3, None, gamma, mean, rstd, fused_gb=True, up2=True, xlo=x)
     if mode == 'f32':
-        close(dgb3, dgb_ref, rtol=2e-6, what='dgb from x'); close(dx3, dx_ref, rtol=4e-6, what='dx from x')
+        close(dgb3, dgb_ref, rtol=2e-6, what='dgb from x'); close(dx3, dx_ref, rtol=1e-5, what='dx from x (one pass: U^T dzh, sums, 3 x 3 stencil of x)')
+        hip.set_option('debug_mode', 2001)          # the two-pass form with z interpolated
+        try:
+            dx4, dgb4 = hip.instnorm_spade_bwd(grad_in(), None, gamma, mean, rstd, fused_gb=True, up2=True, xlo=x)
+        finally:
+            hip.set_option('debug_mode', -1)
+        close(dgb4, dgb_ref, rtol=2e-6, what='dgb from x, two passes'); close(dx4, dx_ref, rtol=4e-6, what='dx from x, two passes')
     else:
         close(dgb3, dgb_ref, rtol=1e-2, what='dgb from x')
         e3 = float((dx3.float() - ref64).abs().max())
