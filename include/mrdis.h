@@ -281,10 +281,11 @@ int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz,
  * mrdis_bilinear_fwd stored it, so the up-sampled map need not be kept for the backward.  workspace as
  * mrdis_instnorm_spade_bwd_workspace(N, 4 Hi Wi, C).  MRDIS_EUNSUPPORTED: views that are not 16-byte aligned / C % 4 != 0 / a last 32-channel chunk
  * whose width is not 4, 8, 16 or 32 (the caller runs mrdis_instnorm_spade_bwd + mrdis_bilinear_bwd).
- * fp32 with xlo and a workspace of mrdis_instnorm_spade_bwd_up2_workspace(N, Hi, Wi, C) bytes: ONE pass over the full-resolution tensors -- d z is linear
+ * With xlo and a workspace of mrdis_instnorm_spade_bwd_up2_workspace(N, Hi, Wi, C, dtype) bytes: ONE pass over the full-resolution tensors -- d z is linear
  * in (dzh, 1, zh) and so is the resize's adjoint, so the kernel writes U^T dzh and the partial sums, and a kernel over the LOW-resolution map finishes
- * d x = rstd (U^T dzh - 4 s0 / HW - (s1 / HW) rstd (U^T U x - 4 mean)) in place: dout and gamma are read once, z never. */
-size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C);
+ * d x = rstd (U^T dzh - 4 s0 / HW - (s1 / HW) rstd (U^T U x - 4 mean)): dout and gamma are read once, z never (bf16 maps: U^T dzh travels in fp32
+ * through the workspace). */
+size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C, int dtype);
 int mrdis_instnorm_spade_bwd_up2(const void* dout, int lddo, const void* z, int ldz,
                                  const void* gamma, int ldg, const float* save_mean, const float* save_rstd,
                                  void* dx, int lddx, void* dgamma, int lddg, void* dbeta, int lddb,

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
                                                             T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x,
-                                                            const T* __restrict__ xlo, int ldxlo, float* __restrict__ part = nullptr) {
+                                                            const T* __restrict__ xlo, int ldxlo, float* __restrict__ part = nullptr,
+                                                            float* __restrict__ abuf = nullptr) {      // abuf (ONEPASS, bf16 maps): A leaves in fp32, dense (N, Hi, Wi, C)
     // xlo: z is not stored -- it is the x2 resize of xlo (N, Hi, Wi, C); the workgroup's 10 x 10 low-resolution neighbourhood goes through LDS and every
     // full-resolution z is interpolated from it exactly as bilinear_up2_fwd_kernel formed (and stored) it
     __shared__ __attribute__((aligned(16))) float tile[UB_R * UB_R * UB_CC];         // dz of the 18 x 18 pixels x 32 channels: 41.5 KB
@@ -681,7 +682,8 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc.v[k] += wr[a] * ((0.25f * t0[k] + 0.75f * t1[k]) + (0.75f * t2[k] + 0.25f * t3[k]));
         }
-        acc.store(dxl + (((long long)n * Hi + i) * Wi + j) * lddx + c0 + 4 * q);
+        if (ONEPASS && abuf != nullptr) *reinterpret_cast<float4*>(abuf + (((long long)n * Hi + i) * Wi + j) * C + c0 + 4 * q) = make_float4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+        else acc.store(dxl + (((long long)n * Hi + i) * Wi + j) * lddx + c0 + 4 * q);
     }
 }
 
@@ -705,9 +707,10 @@ __device__ __forceinline__ void up2_gram_axis(int i, int Hi, float c[3], int idx
         c[r0 - i + 1] += wr[a] * A0; c[r1 - i + 1] += wr[a] * A1;                    // r0, r1 in {i - 1, i, i + 1}
     }
 }
-__global__ void spade_bwd_up2_final_kernel(float* __restrict__ dx, int lddx, const float* __restrict__ xlo, int ldxlo, const float* __restrict__ mean,
+template <typename T>
+__global__ void spade_bwd_up2_final_kernel(T* __restrict__ dx, int lddx, const T* __restrict__ xlo, int ldxlo, const float* __restrict__ mean,
                                            const float* __restrict__ rstd, const float* __restrict__ s0, const float* __restrict__ s1,
-                                           int N, int Hi, int Wi, int C) {
+                                           int N, int Hi, int Wi, int C, const float* __restrict__ abuf) {
     const int Q = C / 4;
     const float inv = 1.f / (4.f * (float)Hi * (float)Wi);
     EW_LOOP((long long)N * Hi * Wi * Q) {
@@ -715,7 +718,7 @@ __global__ void spade_bwd_up2_final_kernel(float* __restrict__ dx, int lddx, con
         const int j = (int)(pix % Wi); const long long t = pix / Wi; const int i = (int)(t % Hi), n = (int)(t / Hi);
         float cr[3], cc[3]; int ir[3], ic[3];
         up2_gram_axis(i, Hi, cr, ir); up2_gram_axis(j, Wi, cc, ic);
-        float T[4] = {0.f, 0.f, 0.f, 0.f};
+        float Tg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float rowv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -725,14 +728,16 @@ __global__ void spade_bwd_up2_final_kernel(float* __restrict__ dx, int lddx, con
                 rowv[0] += cc[b] * v.x; rowv[1] += cc[b] * v.y; rowv[2] += cc[b] * v.z; rowv[3] += cc[b] * v.w;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) T[k] += cr[a] * rowv[k];
+            for (int k = 0; k < 4; ++k) Tg[k] += cr[a] * rowv[k];
         }
-        Vec<4> A, o; A.load(dx + pix * lddx + c);
+        Vec<4> A, o;
+        if (abuf != nullptr) { const float4 av = *reinterpret_cast<const float4*>(abuf + pix * C + c); A.v[0] = av.x; A.v[1] = av.y; A.v[2] = av.z; A.v[3] = av.w; }
+        else A.load(dx + pix * lddx + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int si = n * C + c + k;
             const float rs = rstd[si];
-            o.v[k] = rs * (A.v[k] - 4.f * (s0[si] * inv) - (s1[si] * inv) * (rs * (T[k] - 4.f * mean[si])));
+            o.v[k] = rs * (A.v[k] - 4.f * (s0[si] * inv) - (s1[si] * inv) * (rs * (Tg[k] - 4.f * mean[si])));
         }
         o.store(dx + pix * lddx + c);
     }
@@ -754,20 +759,24 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     if (!v || N > 65535 || C > 65535 * UB_CC || (lastq & (lastq - 1)) != 0) return MRDIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
-    if constexpr (std::is_same<T, float>::value) {
-        // one pass over the full-resolution tensors (see spade_bwd_up2_kernel ONEPASS): needs x itself and room for one partial pair per (image, tile, channel)
+    {
+        // one pass over the full-resolution tensors (see spade_bwd_up2_kernel ONEPASS): needs x itself and room for one partial pair per (image, tile, channel);
+        // bf16 maps: A = U^T dzh goes through an fp32 buffer (rounding it to bf16 before the subtraction of the mean terms would cost the result's leading bits)
+        constexpr bool f32 = std::is_same<T, float>::value;
         const size_t p1bytes = sizeof(float) * 2 * (size_t)N * tiles_x * tiles_y * C + 64;
-        if (xlo && workspace_bytes >= p1bytes + sizeof(float) * 2 * (size_t)N * C && mrdis_opt(MRDIS_OPT_MODE) != 2001) {
+        const size_t abytes = f32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C;
+        if (xlo && workspace_bytes >= p1bytes + sizeof(float) * 2 * (size_t)N * C + abytes && mrdis_opt(MRDIS_OPT_MODE) != 2001) {
             float* part1 = reinterpret_cast<float*>(workspace);
             float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p1bytes);
             float* t1 = t0 + (size_t)N * C;
-            hipLaunchKernelGGL((spade_bwd_up2_kernel<float, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
-                               save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1);
+            float* abuf = f32 ? nullptr : t1 + (size_t)N * C;
+            hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                               save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
             MRDIS_CHECK_LAUNCH();
             const int chunks = tiles_x * tiles_y;
             hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
             MRDIS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(spade_bwd_up2_final_kernel, dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C);
+            hipLaunchKernelGGL((spade_bwd_up2_final_kernel<T>), dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C, abuf);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }
@@ -788,9 +797,10 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
 extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C) {
     return mrdis_norm_workspace(N, HW, C) + sizeof(float) * 2 * (size_t)N * C;
 }
-extern "C" size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C) {
+extern "C" size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C, int dtype) {
     const size_t two_pass = mrdis_instnorm_spade_bwd_workspace(N, 4LL * Hi * Wi, C);
-    const size_t one_pass = sizeof(float) * 2 * (size_t)N * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C;
+    const size_t one_pass = sizeof(float) * 2 * (size_t)N * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C +
+                            (dtype == MRDIS_DT_F32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C);
     return one_pass > two_pass ? one_pass : two_pass;
 }
 

@@ -67,7 +67,7 @@ _SIGS = {
     'mrdis_instnorm_spade_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_instnorm_spade_bwd_workspace': (_Z, [_I, _L, _I]),
     'mrdis_instnorm_spade_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _L, _I, _I, _P]),
-    'mrdis_instnorm_spade_bwd_up2_workspace': (_Z, [_I, _I, _I, _I]),
+    'mrdis_instnorm_spade_bwd_up2_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'mrdis_instnorm_spade_bwd_up2': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _I, _I, _I, _I, _P, _I, _I, _P]),
     'mrdis_bilinear_fwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
     'mrdis_bilinear_bwd': (_I, [_P, _I, _P, _I] + [_I] * 8 + [_P]),
@@ -783,9 +783,9 @@ def instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=False, up2=False, xl
     else:
         assert up2 and xlo is not None
         ldz = 0
-    nb = _ws_bytes(lib.mrdis_instnorm_spade_bwd_up2_workspace, N, H // 2, W // 2, C) if up2 else _ws_bytes(lib.mrdis_instnorm_spade_bwd_workspace, N, H * W, C)
-    ws = _ws(nb, gamma.device)
     dt = _dt(dout, gamma) if z is None else _dt(dout, z, gamma)
+    nb = _ws_bytes(lib.mrdis_instnorm_spade_bwd_up2_workspace, N, H // 2, W // 2, C, dt) if up2 else _ws_bytes(lib.mrdis_instnorm_spade_bwd_workspace, N, H * W, C)
+    ws = _ws(nb, gamma.device)
     if up2:
         assert fused_gb and H % 2 == 0 and W % 2 == 0
         dx = empty_nhwc(N, C, H // 2, W // 2, gamma.device, gamma.dtype)

@@ -958,7 +958,7 @@ class _GbSpadeFn(Function):
 
 _GB_SPADE = _os.environ.get('MRDIS_GB_SPADE', '1') != '0'
 _UP2_BWD_FUSED = _os.environ.get('MRDIS_UP2_BWD_FUSED', '1') != '0'
-_UP2_BWD_FUSED_BF16 = _os.environ.get('MRDIS_UP2_BWD_FUSED', '1') == '2'      # (experiment: the fused form on bf16 maps too)      # SPADE backward + the adjoint of the x2 resize in front of it as one kernel
+_UP2_BWD_FUSED_BF16 = _os.environ.get('MRDIS_UP2_BWD_FUSED_BF16', '0') != '0'      # the fused form on bf16 maps too (measured level with the kernels it replaces, one pass or two)      # SPADE backward + the adjoint of the x2 resize in front of it as one kernel
 
 
 def set_up2_bwd_fused(enabled):
@@ -980,7 +980,7 @@ def gb_spade(si_out, z, filters, bias, eps):
         flat += [a, b]
     smean, srstd = in_stats_of(z, eps)
     src = getattr(z, '_mrdis_up2_src', None) if _UP2_BWD_FUSED else None
-    # (fp32 maps only: on bf16 maps the fused kernel measured 0.5 ms per step SLOWER than the two it replaces -- half the bytes to save, the same arithmetic)
+    # (fp32 maps only by default: on bf16 maps -- half the bytes to save, the same LDS and ALU work -- both fused forms measured level with the kernels they replace: 80.6-80.8 vs 80.2-80.5 ms)
     if src is not None and src.requires_grad and torch.is_grad_enabled() and src.shape[0] == z.shape[0] and src.dtype == z.dtype and (z.dtype == torch.float32 or _UP2_BWD_FUSED_BF16):
         mix = _GbSpadeFn.apply(si_out, z.detach(), bias, len(filters), eps, smean, srstd, src, *flat)
     else:
