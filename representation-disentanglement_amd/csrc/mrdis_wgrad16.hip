@@ -20,7 +20,7 @@ struct Wgrad16Params {
 #define W16_NPX ((W16_TH + 2) * W16_RW)
 
 template <int NS>
-__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Params p) {
+__global__ __launch_bounds__(256, 2) void wgrad16_kernel(const Wgrad16Params p) {      // (two waves per SIMD = 256 registers: with the default 512 hipcc parks the 36 accumulators in AGPRs between iterations, 72 moves per box)
     // NS = 16-channel slices of x handled by one workgroup (2 for Ci = 32: dy is staged and read once for both)
     constexpr int S = NS == 1 ? 16 : 48, QX = 4 * NS;           // pixel pitch = 16 mod 64: the four positions of a k-step land 16 banks apart
     constexpr int XR = (W16_NPX * QX + 255) / 256;          // 180 pixels x QX float4
