@@ -1,3 +1,4 @@
+"""bf16-operand convolution entry points (fwd / dgrad / wgrad, fp32 and bf16 storage) against torch on bf16-rounded operands: error table over a shape list."""
 import sys; sys.path.insert(0, '/root/repo')
 import torch, torch.nn.functional as F, mrdis
 hip = mrdis.hip; dev = torch.device('cuda:0')

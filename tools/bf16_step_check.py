@@ -1,3 +1,4 @@
+"""One training step in each compute dtype (f32, bf16m, bf16) against the fp32 reference golden step_b2m4: loss and gradient-norm deviations (the measured bf16 tolerances)."""
 import sys; sys.path.insert(0, '/root/repo')
 import json, numpy as np, torch, mrdis
 from oracle.gen_golden import make_inputs

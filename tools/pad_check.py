@@ -1,3 +1,4 @@
+"""bf16 layers with 16 input channels (padded to 32 inside the kernels): timing of the padded path at the bench shapes."""
 import sys; sys.path.insert(0, '/root/repo')
 import torch, mrdis
 hip = mrdis.hip; dev = torch.device('cuda:0'); B16 = torch.bfloat16

@@ -1,3 +1,4 @@
+"""Clock ramp probe: the same convolution timed after different amounts of warm-up (why roofline_step warms every entry point up for >= 20 ms)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 import mrdis
