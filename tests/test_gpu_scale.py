@@ -150,6 +150,30 @@ def test_winograd_nontemporal_store_path_runs(mrdis):
     assert float((y_nt - y_direct).abs().max()) <= 1e-4 * float(y_direct.abs().max())
 
 
+@pytest.mark.parametrize('N,C,h', [(32, 32, 128), (32, 64, 64), (128, 32, 128)])
+def test_spade_backward_with_resize_adjoint_at_bench_scale(mrdis, N, C, h):
+    """The SPADE backward of the benchmarked step's full-resolution blocks (one label: N = 32; the batch-concatenated decoders: N = 128 -- 8.6 G elements of traffic):
+    the one-pass form (mrdis_instnorm_spade_bwd_up2 with xlo: U^T dzh + per-tile partial sums, finished on the low-resolution map) against the kernels it
+    replaces (statistics pass + apply pass + the resize's adjoint): [d gamma | d beta] within 2e-6, d x within 2e-5 of the maximum; the step-level comparisons
+    (default policy vs direct kernels) run the fused form on both sides, so this is the check that is independent of it."""
+    hip = mrdis.hip
+    H = 2 * h
+    x = cl(rnd((N, C, h, h), 41))
+    z = hip.bilinear_fwd(x, (H, H), False)
+    gamma = cl(rnd((N, C, H, H), 42, 0.3))
+    dout = cl(rnd((N, C, H, H), 43))
+    mean = torch.stack([z[i:i + 8].mean(dim=(2, 3)) for i in range(0, N, 8)]).reshape(-1).contiguous()
+    var = torch.stack([z[i:i + 8].var(dim=(2, 3), unbiased=False) for i in range(0, N, 8)]).reshape(-1)
+    rstd = (1.0 / (var + 1e-5).sqrt()).contiguous()
+    dz, dgb_ref = hip.instnorm_spade_bwd(dout, z, gamma, mean, rstd, fused_gb=True)
+    dx_ref = hip.bilinear_bwd(dz, (h, h), False)
+    del dz
+    dx, dgb = hip.instnorm_spade_bwd(dout, None, gamma, mean, rstd, fused_gb=True, up2=True, xlo=x)
+    e_g = float((dgb - dgb_ref).abs().max() / dgb_ref.abs().max())
+    e_x = float((dx - dx_ref).abs().max() / dx_ref.abs().max())
+    assert e_g <= 2e-6 and e_x <= 2e-5, (e_g, e_x)
+
+
 def test_north_star_conv_output(mrdis):
     """BASELINE.json north star: 3x3 s1 conv, x (32,4,240,240) -> (32,32,240,240) fp32, every output value vs torch."""
     hip = mrdis.hip
