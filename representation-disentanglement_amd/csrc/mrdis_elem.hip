@@ -641,20 +641,17 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
         }
     }
     if (ONEPASS) {
-        // the 256 / Q threads of a channel quad, added in thread order (fixed order: bit-reproducible); the sums go through the x tile (read for the last time above)
-        __syncthreads();
-        float* red = xt;                                                              // [256][8] <= 10 x 10 x 32 floats
+        // the 64 / Q lanes of a wave that share a channel quad (lane % Q: Q divides 64) are added by a butterfly of fixed shape, each wave writes its own `part` chunk
+        // (chunk = 4 tile + wave): no LDS round trip, no extra barrier; bit-reproducible
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int o = Q; o < 64; o <<= 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = ps0[k]; red[tid * 8 + 4 + k] = ps1[k]; }
-        __syncthreads();
-        if (tid < Q) {
-            float t_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int u = tid; u < 256; u += Q)
+            for (int k = 0; k < 4; ++k) { ps0[k] += __shfl_xor(ps0[k], o, 64); ps1[k] += __shfl_xor(ps1[k], o, 64); }
+        }
+        if (lane < Q) {
+            float* dst = part + ((long long)((n * (int)gridDim.x + (int)blockIdx.x) * 4 + wv) * 2) * C + c0;      // group = image n, chunk = 4 tile + wave
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t_[k] += red[u * 8 + k];
-            float* dst = part + ((long long)(n * (int)gridDim.x + (int)blockIdx.x) * 2) * C + c0;      // group = image n, chunk = tile
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { dst[4 * tid + k] = t_[k]; dst[C + 4 * tid + k] = t_[4 + k]; }
+            for (int k = 0; k < 4; ++k) { dst[4 * lane + k] = ps0[k]; dst[C + 4 * lane + k] = ps1[k]; }
         }
     }
     __syncthreads();
@@ -763,7 +760,7 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
         // one pass over the full-resolution tensors (see spade_bwd_up2_kernel ONEPASS): needs x itself and room for one partial pair per (image, tile, channel);
         // bf16 maps: A = U^T dzh goes through an fp32 buffer (rounding it to bf16 before the subtraction of the mean terms would cost the result's leading bits)
         constexpr bool f32 = std::is_same<T, float>::value;
-        const size_t p1bytes = sizeof(float) * 2 * (size_t)N * tiles_x * tiles_y * C + 64;
+        const size_t p1bytes = sizeof(float) * 2 * (size_t)N * 4 * tiles_x * tiles_y * C + 64;
         const size_t abytes = f32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C;
         if (xlo && workspace_bytes >= p1bytes + sizeof(float) * 2 * (size_t)N * C + abytes && mrdis_opt(MRDIS_OPT_MODE) != 2001) {
             float* part1 = reinterpret_cast<float*>(workspace);
@@ -773,7 +770,7 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
             hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
                                save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
             MRDIS_CHECK_LAUNCH();
-            const int chunks = tiles_x * tiles_y;
+            const int chunks = 4 * tiles_x * tiles_y;
             hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
             MRDIS_CHECK_LAUNCH();
             hipLaunchKernelGGL((spade_bwd_up2_final_kernel<T>), dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C, abuf);
@@ -799,7 +796,7 @@ extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C)
 }
 extern "C" size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C, int dtype) {
     const size_t two_pass = mrdis_instnorm_spade_bwd_workspace(N, 4LL * Hi * Wi, C);
-    const size_t one_pass = sizeof(float) * 2 * (size_t)N * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C +
+    const size_t one_pass = sizeof(float) * 2 * (size_t)N * 4 * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C +
                             (dtype == MRDIS_DT_F32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C);
     return one_pass > two_pass ? one_pass : two_pass;
 }
