@@ -1,6 +1,6 @@
 """bench.py -- headline benchmark of the MI355X-native hot path.
 
-    python bench.py [--gpus N --steps K --warmup W]           # N = 1
+    python bench.py [--gpus N --steps K --warmup W]           # N = 1; N > 1 without a launcher: starts the N ranks itself (child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W  # N > 1, one rank per GPU (RCCL)
 
@@ -58,6 +58,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
+    ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: every rank joins a gloo group and reports in; rank 0 prints the '
+                                                           'ranks it heard from (tests/test_bench_launch.py)')
     ap.add_argument('--roofline-only', action='store_true', help='only the roofline legs (north-star conv + the dominant kernels of the step), '
                                                                  'no training step: what tools/profile_round.sh profiles separately from the step')
     return ap.parse_args()
@@ -302,11 +304,51 @@ def host_unblocked_ms(mrdis, cfg, dev, B, M, adv, steps=4):
     return round(float(np.median(ts[2:])), 1)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD `torch.distributed.run` (never exec: the parent has
+    not touched a GPU and does not), forward its output, exit with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(8, (os.cpu_count() or 1) // a.gpus))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, world, rank):
+    """Launcher rehearsal (no GPU): the ranks rendezvous over gloo exactly as they would over RCCL and rank 0 prints who reported."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29555')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = torch.tensor([rank], dtype=torch.int64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'rccl_ranks': dist.get_world_size(), 'backend': 'gloo (dry run)',
+                          'ranks_reported': sorted(int(t) for t in got), 'steps': a.steps, 'warmup': a.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        print(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE = {world} ranks; refusing to report a number for the wrong job',
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.dry_run:
+        return dry_run(a, world, rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -320,7 +362,9 @@ def main():
         local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
         torch.set_num_threads(max(1, min(8, ncpu // max(1, local_world))))
     if world > 1:
+        assert torch.cuda.device_count() >= world, f'--gpus {world} but only {torch.cuda.device_count()} GPUs are visible'
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == a.gpus
     import mrdis
     mrdis.hip.load()
 
@@ -432,7 +476,8 @@ def main():
     if rank == 0:
         out = {
             'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
-            'value': round(value, 3), 'unit': 'slices/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'value': round(value, 3), 'unit': 'slices/s', 'n_gpus': world,
+            'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(ms, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f32': 'f32', 'bf16': 'bf16 (bf16 activations + MFMA operands, f32 accumulate / statistics / master weights)',
                       'bf16m': 'bf16 MFMA operands / f32 accumulate / f32 storage'}[a.dtype], 'data': 'synthetic',
