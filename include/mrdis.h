@@ -55,10 +55,17 @@ int mrdis_version(void);
  *   "wino_u" (MRDIS_WINO_U, default 1): 1 = the pipelined kernels read the pre-transformed filter image a caller passes (w_wino), 0 = they
  *           always transform the taps themselves (F(2x2): bit-identical either way; also keeps the F(4x4) kernel, which has no in-kernel
  *           filter transform, out);
- *   "wino4" (MRDIS_WINO4, default 1): 1 = Winograd F(4x4,3x3) (csrc/mrdis_wino4.hip: 1.78x fewer multiplies than F(2x2), results within
- *           ~5e-6 of the maximum of the direct kernel's) for the 3x3 stride-1 filters mrdis_wino_u_format() names -- >= 32 reduction channels
- *           (multiple of 8), >= 64 couts -- where the caller passes the filter image and the launch fills >= 3/4 of the chip; 0 = never
- *           (F(2x2) everywhere); 2 = wherever that kernel applies (tests).  Read when a filter image is BUILT: set it before the images;
+ *   "wino4" (MRDIS_WINO4, default 1): 1 = Winograd F(4x4,3x3) (csrc/mrdis_wino4.hip, mrdis_wino4r.hip: 1.78x fewer multiplies than F(2x2),
+ *           results within ~5e-6 of the maximum of the direct kernel's) for the 3x3 stride-1 filters whose image mrdis_wino_u_format() gives
+ *           format 4 or 5, where the caller passes that image and the launch fills >= 3/4 of the chip (>= 192 workgroups, maps >= 16 x 32):
+ *             format 4 (36-point image + the 16-point one): reduction channels R % 8 == 0, couts S >= 64, S % 4 == 0, and R >= 64 for a plain
+ *                       filter, R >= 32 for the fused gamma | beta filter of mrdis_conv2d_fwd_spade (C % 8 == 0, C >= 32);
+ *             format 5 (36-point image of the 32-cout forms, wino4r / wino4n kernels): R % 8 == 0, R >= 16, S == 32;
+ *             format 2 (16-point F(2x2) image) otherwise;
+ *           the same option gates the F(3x3,4x4) weight gradient (csrc/mrdis_wino4w.hip) inside mrdis_conv2d_bwd_weight (Ci % 32 == 0, Co % 64 == 0, H and W
+ *           multiples of 8, >= 192 workgroups of >= 24 iterations each); 0 = never (F(2x2) everywhere, every image format 2); 2 = wherever those kernels apply (tests: R >= 16,
+ *           format 5 from 4 couts).  The option picks the format when an image is BUILT; a built image keeps its format, which the caller
+ *           passes beside the pointer (w_wino_fmt) -- changing the option later never makes a kernel read an image in another layout;
  *   "debug_now16" (MRDIS_DEBUG_NOW16, default 0): 1 = the dedicated narrow-layer kernels off -- Cout <= 16 weight gradient
  *           (mrdis_wgrad16.hip), stride-2 first layers and 4 -> C weight gradient (mrdis_wgrad_s2.hip), 1x1 head (mrdis_pointwise.hip),
  *           16-cout and 4-cout 3x3 layers (mrdis_c16.hip, mrdis_co4.hip): the generic tile kernels run those layers (tests and
@@ -70,6 +77,12 @@ int mrdis_version(void);
  * in flight on other threads. */
 int mrdis_set_option(const char* name, long long value);
 long long mrdis_get_option(const char* name);
+/* Launches since load / the last reset of one Winograd kernel family (counted on the host at launch): "wino" | "wino_spade" (phase-by-phase F(2x2)),
+ * "wino2" | "wino2_spade" (pipelined F(2x2)), "wino4" | "wino4_spade" (F(4x4) 64-cout forms), "wino4n" | "wino4r" (32-cout forms: shared transform / register-fed),
+ * "wino_wgrad" | "wino_wgrad2" (F(2x2) weight gradient), "wino4_wgrad" (F(3x3,4x4)).  MRDIS_EINVAL for an unknown name.  Diagnostics: the parity tests
+ * use it to prove that the form under test is the one that ran. */
+long long mrdis_launch_count(const char* family);
+void mrdis_launch_count_reset(void);
 
 /* ---- expert mixing: model.py:2111-2113 --------------------------------------
  * W   : (E, Co, Ci, kh, kw) checkpoint layout (OIHW with leading expert dim)
@@ -167,27 +180,32 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
 #define MRDIS_DT_XBF16_YF32 3
 #define MRDIS_DT_XF32_YBF16 4
 /* w_wino (fp32 paths, may be NULL): the filter already in the Winograd domain, the image mrdis_wino_u_jobs builds from w_tck (role:
- * forward) -- used where a software-pipelined Winograd kernel takes the layer, ignored elsewhere.  Format 2 (F(2x2,3x3)): same results
- * bit for bit with or without it; format 4 (mrdis_wino_u_format): selects the F(4x4,3x3) kernel, which exists only on the image. */
+ * forward) -- used where a software-pipelined Winograd kernel takes the layer, ignored elsewhere.  w_wino_fmt: the format that image was
+ * BUILT in (the job's fmt: 2 | 4 | 5; ignored when w_wino is NULL); MRDIS_EINVAL if no image of this filter shape can have it.  Format 2
+ * (F(2x2,3x3)): same results bit for bit with or without the image; formats 4 / 5: select the F(4x4,3x3) kernels, which exist only on the
+ * image (with the option "wino4" at 0 a format-4 image is read through its trailing 16-point part, a format-5 image is ignored). */
 int mrdis_conv2d_fwd(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                      void* y, int ldy, int N, int H, int W, int Ci, int Co,
-                     int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, void* stream);
+                     int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, int w_wino_fmt, void* stream);
 
 /* ---- filter images for the software-pipelined Winograd kernels (csrc/mrdis_wino2.hip).  U = G g G^T of a 3x3 filter does not depend
  * on the activations; a training step uses each mixed filter 8-16 times, so the transform is taken out of the convolution kernels:
  * one launch over a job table builds, per (filter, role), the 16-point image in the order the kernel's (input-channel chunk, 64-cout
  * tile) walk consumes it: [cout tile][chunk of 8][8][4][64][4] floats, zero-padded (format 2); format 4 is the 36-point image of the
  * F(4x4,3x3) kernel, [cout tile][chunk of 4][18 point pairs][4][128] floats (csrc/mrdis_wino4.h), FOLLOWED by the format-2 image of the same filter
- * (what a call runs on whose grid the F(4x4) kernel declines: small maps).  mrdis_wino_u_format(R, S, spadeC) says
- * which of the two a filter gets (a function of the filter's shape and the option "wino4" alone).
+ * (what a call runs on whose grid the F(4x4) kernel declines: small maps); format 5 is the 36-point image of the 32-cout F(4x4) forms alone.
+ * mrdis_wino_u_format(R, S, spadeC) says which one a filter gets NOW (a function of the filter's shape and the current value of the option
+ * "wino4"); the job records it, mrdis_wino_u_image_floats_fmt sizes an image of a given format (-1: that shape never has it), and the
+ * convolution entry points take it beside the image pointer (w_wino_fmt).
  * Job (`WinoUJob`, mrdis_wino_u_job_bytes() = 48):
- *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk, fmt, pad; }        fmt = mrdis_wino_u_format(R, S, spadeC)
+ *   { const float* w; float* img; int R, S, flip, spadeC, block0, nblk, fmt, pad; }        fmt = mrdis_wino_u_format(R, S, spadeC) when built
  * w = [9][R][S]: role forward: w_tck, R = Ci, S = Co, flip = 0; role data gradient: w_tkc, R = Co, S = Ci, flip = 1; role SPADE (the fused
  * gamma | beta filter of mrdis_conv2d_fwd_spade): w_tck, R = Ci, S = 2 C, spadeC = C.  img: mrdis_wino_u_image_floats(R, S, spadeC) floats,
  * 16-byte aligned.  block0 / nblk: the job's block range (mrdis_wino_u_job_blocks each), total_blocks = their sum.                     */
 size_t mrdis_wino_u_job_bytes(void);
 int mrdis_wino_u_format(int R, int S, int spadeC);
-long long mrdis_wino_u_image_floats(int R, int S, int spadeC);
+long long mrdis_wino_u_image_floats(int R, int S, int spadeC);                 /* = _fmt(..., mrdis_wino_u_format(R, S, spadeC)) */
+long long mrdis_wino_u_image_floats_fmt(int R, int S, int spadeC, int fmt);
 int mrdis_wino_u_job_blocks(int R, int S, int spadeC);
 int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 
@@ -195,7 +213,7 @@ int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* strea
  * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
 int mrdis_conv2d_bwd_data(const void* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,
                           void* dx, int lddx, int N, int H, int W, int Ci, int Co,
-                          int kh, int kw, int stride, int pad, int dtype, const float* w_wino /* role data gradient, or NULL */, void* stream);
+                          int kh, int kw, int stride, int pad, int dtype, const float* w_wino /* role data gradient, or NULL */, int w_wino_fmt, void* stream);
 
 /* fp32 -> bf16, round to nearest even (the bf16 filter copies above); src 16-byte, dst 8-byte aligned. */
 int mrdis_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
@@ -219,7 +237,7 @@ int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, float* save_r
                          int N, long long HW, int C, float eps, int dtype, void* stream);
 int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
                            const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
-                           int N, int H, int W, int Ci, int C, int dtype, const float* w_wino /* role SPADE, or NULL */, void* stream);
+                           int N, int H, int W, int Ci, int C, int dtype, const float* w_wino /* role SPADE, or NULL */, int w_wino_fmt /* 2 | 4 */, void* stream);
 
 /* weight gradient.  Two-pass, bit-reproducible: partial slabs in `workspace`
  * (size from mrdis_conv2d_bwd_weight_workspace) then an ordered reduction.
@@ -278,8 +296,9 @@ int mrdis_instnorm_spade_bwd(const void* dout, int lddo, const void* z, int ldz,
 /* The same backward when z = nn.Upsample(scale_factor=2, bilinear)(x) (model.py:2551-2573 in front of a SPADE block): z, dout, gamma, dgamma, dbeta
  * are (N, 2 Hi, 2 Wi, C); dx (N, Hi, Wi, C) receives the gradient of x -- the apply pass and the resize's adjoint in one kernel, the full-resolution
  * d z is neither written nor read back.  xlo != NULL: x itself (N, Hi, Wi, C); z may then be NULL -- both passes interpolate z from x exactly as
- * mrdis_bilinear_fwd stored it, so the up-sampled map need not be kept for the backward.  workspace as
- * mrdis_instnorm_spade_bwd_workspace(N, 4 Hi Wi, C).  MRDIS_EUNSUPPORTED: views that are not 16-byte aligned / C % 4 != 0 / a last 32-channel chunk
+ * mrdis_bilinear_fwd stored it, so the up-sampled map need not be kept for the backward.  Workspace: ALWAYS size it with
+ * mrdis_instnorm_spade_bwd_up2_workspace (>= mrdis_instnorm_spade_bwd_workspace(N, 4 Hi Wi, C), which is all the two-pass form needs: with the
+ * smaller size the entry point takes the two-pass form).  MRDIS_EUNSUPPORTED: views that are not 16-byte aligned / C % 4 != 0 / a last 32-channel chunk
  * whose width is not 4, 8, 16 or 32 (the caller runs mrdis_instnorm_spade_bwd + mrdis_bilinear_bwd).
  * With xlo and a workspace of mrdis_instnorm_spade_bwd_up2_workspace(N, Hi, Wi, C, dtype) bytes: ONE pass over the full-resolution tensors -- d z is linear
  * in (dzh, 1, zh) and so is the resize's adjoint, so the kernel writes U^T dzh and the partial sums, and a kernel over the LOW-resolution map finishes

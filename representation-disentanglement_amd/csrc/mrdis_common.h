@@ -23,6 +23,12 @@ enum {
 };
 long long mrdis_opt(int id);      // mrdis_elem.hip
 
+// Launch counters of the Winograd kernel families (host side, one increment per launch): what a test asks to know which form actually ran
+// (mrdis_launch_count("wino4") ...; mrdis_elem.hip).
+enum { MRDIS_CNT_WINO, MRDIS_CNT_WINO_SPADE, MRDIS_CNT_WINO2, MRDIS_CNT_WINO2_SPADE, MRDIS_CNT_WINO4, MRDIS_CNT_WINO4_SPADE, MRDIS_CNT_WINO4N, MRDIS_CNT_WINO4R,
+       MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_COUNT };
+void mrdis_count(int id);
+
 static inline int mrdis_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Bijective XCD-aware remap (cdna_hip_programming.md T1): workgroups b and b+8 share an XCD, so

@@ -1191,18 +1191,22 @@ int mrdis_run_wino4r(const float* x, int ldx, const float* bias, float* y, int l
                      hipStream_t s, const float* u_img);     // the register-fed form of the same layers (mrdis_wino4r.hip)
 int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const float* z, int ldz, const float* mean, const float* rstd,
                           float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
+// u_fmt: the format the image u_img was BUILT in (2 | 4 | 5: mrdis_wino_u_format at build time; it travels with the pointer, the option
+// 'wino4' may have changed since).  The option decides only whether the F(4x4) kernels run; the layout read is always the image's own.
 static int run_wino(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr) {
-    if (u_img && mrdis_wino_u_fmt(Ci, Co, 0) == 5) {       // <= 32 couts: the narrow F(4x4) form; declined -> the F(2x2) kernel for 32 couts (no image path)
-        if (mrdis_opt(MRDIS_OPT_WINO_U)) {
+                    int N, int H, int W, int Ci, int Co, int flip, int lrelu, hipStream_t s, const float* u_img = nullptr, int u_fmt = 0) {
+    if (u_img && !mrdis_wino_u_fmt_valid(Ci, Co, 0, u_fmt)) return MRDIS_EINVAL;
+    const bool f4 = mrdis_opt(MRDIS_OPT_WINO4) != 0 && mrdis_opt(MRDIS_OPT_WINO_U);
+    if (u_img && u_fmt == 5) {       // <= 32 couts: the narrow F(4x4) form; declined -> the F(2x2) kernel for 32 couts (no image path)
+        if (f4) {
             int rc = mrdis_run_wino4r(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
             if (rc == MRDIS_EUNSUPPORTED) rc = mrdis_run_wino4n(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
         u_img = nullptr;
     }
-    if (u_img && mrdis_wino_u_fmt(Ci, Co, 0) == 4) {
-        if (mrdis_opt(MRDIS_OPT_WINO_U)) {
+    if (u_img && u_fmt == 4) {
+        if (f4) {
             const int rc = mrdis_run_wino4(x, ldx, bias, y, ldy, N, H, W, Ci, Co, lrelu, s, u_img);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
@@ -1241,7 +1245,7 @@ int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const flo
                            void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
 extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
                                       const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
-                                      int N, int H, int W, int Ci, int C, int dtype, const float* w_wino, void* stream) {
+                                      int N, int H, int W, int Ci, int C, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (!x || !bias || !z || !mean || !rstd || !mix || !gamma || N < 1 || H < 1 || W < 1 || Ci < 1 || C < 1) return MRDIS_EINVAL;
     if (dtype == MRDIS_DT_BF16) {
         if (!w_bf16_tkc) return MRDIS_EINVAL;
@@ -1249,8 +1253,10 @@ extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck
     }
     if (dtype != MRDIS_DT_F32 || !w_tck) return dtype == MRDIS_DT_F32 ? MRDIS_EINVAL : MRDIS_EUNSUPPORTED;
     if (!mrdis_opt(MRDIS_OPT_WINO_PIPE) || !wino_wanted(N, H, W, Ci, 2 * C, 3, 3, 1, 1)) return MRDIS_EUNSUPPORTED;
-    if (w_wino && mrdis_wino_u_fmt(Ci, 2 * C, C) == 4) {          // the image is the F(4x4) one (mrdis_wino4.hip)
-        if (mrdis_opt(MRDIS_OPT_WINO_U)) {
+    if (w_wino && !mrdis_wino_u_fmt_valid(Ci, 2 * C, C, w_wino_fmt)) return MRDIS_EINVAL;
+    if (w_wino && w_wino_fmt == 5) return MRDIS_EINVAL;           // a fused gamma | beta image is never the narrow form
+    if (w_wino && w_wino_fmt == 4) {          // the image is the F(4x4) one (mrdis_wino4.hip), followed by the 16-point one
+        if (mrdis_opt(MRDIS_OPT_WINO_U) && mrdis_opt(MRDIS_OPT_WINO4)) {
             const int rc4 = mrdis_run_wino4_spade((const float*)x, ldx, bias, (const float*)z, ldz, mean, rstd, (float*)mix, ldmix, (float*)gamma, ldg, N, H, W, Ci, C,
                                                   (hipStream_t)stream, w_wino);
             if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
@@ -1277,7 +1283,7 @@ int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, 
 
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
                                 void* y_, int ldy, int N, int H, int W, int Ci, int Co,
-                                int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, void* stream) {
+                                int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (dtype < MRDIS_DT_F32 || dtype > MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); float* y = reinterpret_cast<float*>(y_);   // bf16 views when dtype == MRDIS_DT_BF16
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
@@ -1317,7 +1323,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
-        rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream, w_wino);
+        rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream, w_wino, w_wino_fmt);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     TapConvParams p{};
@@ -1338,7 +1344,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
 
 extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_tkc, const void* w_bf16_tck,
                                      void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
-                                     int kh, int kw, int stride, int pad, int dtype, const float* w_wino, void* stream) {
+                                     int kh, int kw, int stride, int pad, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
@@ -1389,7 +1395,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
         if (!st_bf16 && c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
         if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
-            rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, w_wino);
+            rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, w_wino, w_wino_fmt);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
         TapConvParams p = base;

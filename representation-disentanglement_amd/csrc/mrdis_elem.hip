@@ -1884,6 +1884,22 @@ extern "C" long long mrdis_get_option(const char* name) {
     return i < 0 ? (long long)MRDIS_EINVAL : opt_table()[i];
 }
 
+namespace {
+const char* const CNT_NAMES[MRDIS_CNT_COUNT] = {"wino", "wino_spade", "wino2", "wino2_spade", "wino4", "wino4_spade", "wino4n", "wino4r",
+                                                "wino_wgrad", "wino_wgrad2", "wino4_wgrad"};
+long long g_counts[MRDIS_CNT_COUNT];
+}  // namespace
+void mrdis_count(int id) { __atomic_fetch_add(&g_counts[id], 1LL, __ATOMIC_RELAXED); }
+extern "C" long long mrdis_launch_count(const char* family) {
+    if (!family) return MRDIS_EINVAL;
+    for (int i = 0; i < MRDIS_CNT_COUNT; ++i)
+        if (!strcmp(family, CNT_NAMES[i])) return __atomic_load_n(&g_counts[i], __ATOMIC_RELAXED);
+    return MRDIS_EINVAL;
+}
+extern "C" void mrdis_launch_count_reset(void) {
+    for (int i = 0; i < MRDIS_CNT_COUNT; ++i) __atomic_store_n(&g_counts[i], 0LL, __ATOMIC_RELAXED);
+}
+
 extern "C" const char* mrdis_strerror(int code) {
     switch (code) {
         case MRDIS_OK: return "ok";

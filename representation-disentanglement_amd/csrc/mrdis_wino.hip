@@ -311,6 +311,7 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
         attr_set = true;
     }
     const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
+    mrdis_count(MRDIS_CNT_WINO);
     if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), dim3((int)nblk), dim3(512), lds, s, p);
     else hipLaunchKernelGGL((wino_conv_kernel<1, 4>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
@@ -341,6 +342,7 @@ int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias,
         attr_set = true;
     }
     const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
+    mrdis_count(MRDIS_CNT_WINO_SPADE);
     if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4, true>), dim3((int)nblk), dim3(512), lds, s, p);
     else hipLaunchKernelGGL((wino_conv_kernel<1, 4, true>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
@@ -655,9 +657,9 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
         if (rc2 != MRDIS_OK && rc2 != MRDIS_EUNSUPPORTED) return rc2;
     }
     if (rc2 == MRDIS_OK) {}
-    else if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p);
-    else if (pl.wci == 4) hipLaunchKernelGGL((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p);
-    else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p);
+    else if (pl.wci == 4 && pl.wco == 2) { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p); }
+    else if (pl.wci == 4) { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p); }
+    else { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p); }
     MRDIS_CHECK_LAUNCH();
     const long long n = 9LL * Ci * Co;
     int SL = 1;

@@ -443,6 +443,7 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
     W2A(1) W2A(2) W2A(3) W2A(4) W2A(8) W2A(32) W2A(40) W2A(43) W2A(16) W2A(47) W2A(64) W2A(128) W2A(256)
 #undef W2A
 #endif
+    mrdis_count(MRDIS_CNT_WINO2);
     if (u_img) hipLaunchKernelGGL((wino2_kernel<0, false, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
     else hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
@@ -478,6 +479,7 @@ int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* 
     if (!mrdis_opt(MRDIS_OPT_WINO_U) || (((uintptr_t)u_img) & 15) != 0) u_img = nullptr;
     p.u_img = u_img; p.u_bytes = wino_u_bytes(Ci, p.coTiles);
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    mrdis_count(MRDIS_CNT_WINO2_SPADE);
     if (u_img) hipLaunchKernelGGL((wino2_kernel<0, true, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
     else hipLaunchKernelGGL((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
@@ -578,11 +580,12 @@ static long long wino_u_elems(int R, int S, int spadeC) {       // (reduction ch
     return (long long)tiles * ((R + KC - 1) / KC) * KC * 64;
 }
 extern "C" int mrdis_wino_u_format(int R, int S, int spadeC) { return mrdis_wino_u_fmt(R, S, spadeC); }
-extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) {
-    const int fmt = mrdis_wino_u_fmt(R, S, spadeC);
+extern "C" long long mrdis_wino_u_image_floats_fmt(int R, int S, int spadeC, int fmt) {
+    if (!mrdis_wino_u_fmt_valid(R, S, spadeC, fmt)) return -1;
     if (fmt == 5) return mrdis_wino4n_image_floats(R, S);
     return (fmt == 4 ? mrdis_wino4_image_floats(R, S, spadeC) : 0) + 16 * wino_u_elems(R, S, spadeC);
 }
+extern "C" long long mrdis_wino_u_image_floats(int R, int S, int spadeC) { return mrdis_wino_u_image_floats_fmt(R, S, spadeC, mrdis_wino_u_fmt(R, S, spadeC)); }
 extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
     const long long b = (wino_u_elems(R, S, spadeC) + 255) / 256;
     const int cap = mrdis_wino_u_fmt(R, S, spadeC) >= 4 ? 128 : 64;
@@ -842,6 +845,7 @@ int mrdis_launch_wino_wgrad2(const WinoWgradParams& p, hipStream_t s) {
     const int s_bx = t % p.nbx; t /= p.nbx;
     const int s_by = t % p.nby;
     const int s_n = t / p.nby;
+    mrdis_count(MRDIS_CNT_WINO_WGRAD2);
     hipLaunchKernelGGL(wino_wgrad2_kernel, dim3(p.splits * p.nCiB * p.nCoB), dim3(NT), WGRAD2_LDS, s, p, s_n, s_by, s_bx);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -17,6 +17,8 @@
 // 2 = F(2x2, 3x3) (mrdis_wino2.hip).  A function of the filter alone -- the image is built once per step, before any call's shape is known;
 // a call whose shape the F(4x4) kernel declines runs the F(2x2) kernel with its in-kernel filter transform.
 int mrdis_wino_u_fmt(int R, int S, int spadeC);
+int mrdis_wino_u_fmt_at(int R, int S, int spadeC, int level);
+bool mrdis_wino_u_fmt_valid(int R, int S, int spadeC, int fmt);
 
 // floats of the 36-point part of a format-4 image (the 16-point image of the same filter follows it: the fallback for calls the F(4x4) kernel declines)
 static inline __host__ __device__ long long mrdis_wino4_image_floats(int R, int S, int spadeC) {

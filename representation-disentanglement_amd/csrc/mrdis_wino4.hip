@@ -749,6 +749,7 @@ int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int l
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    mrdis_count(MRDIS_CNT_WINO4N);
     hipLaunchKernelGGL(wino4n_kernel<0>, dim3(grid), dim3(NT4), W4N_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -798,6 +799,7 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
     W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45) W4A(64) W4A(65) W4A(72) W4A(96) W4A(105) W4A(192) W4A(320) W4A(576) W4A(448) W4A(832)
 #undef W4A
 #endif
+    mrdis_count(MRDIS_CNT_WINO4);
     hipLaunchKernelGGL(wino4_kernel<0>, dim3(grid), dim3(NT4), W4_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -831,25 +833,32 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
+    mrdis_count(MRDIS_CNT_WINO4_SPADE);
     hipLaunchKernelGGL((wino4_kernel<0, true>), dim3(grid), dim3(NT4), W4_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
-int mrdis_wino_u_fmt(int R, int S, int spadeC) {
-    if (!mrdis_opt(MRDIS_OPT_WINO4)) return 2;
+// the format of a filter's Winograd image at policy level `level` (the value of option 'wino4': 0 | 1 | 2)
+int mrdis_wino_u_fmt_at(int R, int S, int spadeC, int level) {
+    if (!level) return 2;
     if (spadeC != 0) {                                 // fused gamma | beta filter (S = 2 C)
         // measured with the SPADE epilogue (tools/spade4_check.py, B = 32): 32 -> 2 x 32 at 256x256 532 -> 388 us, 64 -> 2 x 64 at 128x128 437 -> 301 us,
         // 128 -> 2 x 128 at 64x64 359 -> 232 us, at 32x32 (4 B images) 343 -> 224 us
-        const int rmin_s = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 32;
+        const int rmin_s = level >= 2 ? 16 : 32;
         return (R % 8 == 0 && R >= rmin_s && spadeC % 8 == 0 && spadeC >= 32 && 2 * spadeC <= BIAS4) ? 4 : 2;
     }
     // measured (tools/wino4_check.py, B = 32): 64 -> 128 at 128x128 349 -> 299 us forward / 323 -> 271 us data gradient, 128 -> 256 at 64x64 322 -> 210 /
     // 321 -> 205, 128 -> 64 at 64x64 85 -> 68 / 88 -> 74, 64 -> 64 at 128x128 171 -> 149 / 172 -> 158; 32 reduction channels (8 chunks per block: the
     // output transform + stores come round too often) 386 -> 387: no gain; < 64 couts leave half of the 64-cout tile empty
-    const int rmin = mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 16 : 64;
+    const int rmin = level >= 2 ? 16 : 64;
     // <= 32 couts: the 32-cout forms (wino4r_kernel / wino4n_kernel) from 16 reduction channels on -- the data gradient of sp6.out (16 -> 32 at 256x256) 152 us on
     // the F(2x2) phase kernel, 118-126 us here
-    if (R % 8 == 0 && R >= 16 && S <= 32 && S >= (mrdis_opt(MRDIS_OPT_WINO4) >= 2 ? 4 : 32) && S % 4 == 0) return 5;
+    if (R % 8 == 0 && R >= 16 && S <= 32 && S >= (level >= 2 ? 4 : 32) && S % 4 == 0) return 5;
     return (R % 8 == 0 && R >= rmin && S >= 64 && S % 4 == 0 && S <= BIAS4) ? 4 : 2;
+}
+int mrdis_wino_u_fmt(int R, int S, int spadeC) { return mrdis_wino_u_fmt_at(R, S, spadeC, (int)mrdis_opt(MRDIS_OPT_WINO4)); }
+// can an image of a (R, S, spadeC) filter be of format `fmt` at all (under some value of the option)?  What the entry points check on the format a caller passes.
+bool mrdis_wino_u_fmt_valid(int R, int S, int spadeC, int fmt) {
+    return fmt == 2 || ((fmt == 4 || fmt == 5) && (fmt == mrdis_wino_u_fmt_at(R, S, spadeC, 1) || fmt == mrdis_wino_u_fmt_at(R, S, spadeC, 2)));
 }

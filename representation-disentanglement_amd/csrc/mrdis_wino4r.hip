@@ -390,11 +390,13 @@ static int launch_wino4r(Wino4rParams& p, hipStream_t s) {
     }
     if (g_w4r_dbg != nullptr) {
         p.dbg = g_w4r_dbg; p.dbg_cap = g_w4r_dbg_cap;
+        mrdis_count(MRDIS_CNT_WINO4R);
         hipLaunchKernelGGL((wino4r_kernel<NKH, 64>), dim3(grid), dim3(NTR), G::LDS, s, p);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
 #endif
+    mrdis_count(MRDIS_CNT_WINO4R);
     hipLaunchKernelGGL((wino4r_kernel<NKH, 0>), dim3(grid), dim3(NTR), G::LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -360,6 +360,7 @@ int mrdis_launch_wino4_wgrad(WinoWgradParams& base, int max_splits, hipStream_t 
 #ifdef WINO4_ABLATIONS
     p.dbg = g_w4w_dbg; p.dbg_cap = g_w4w_dbg_cap;
 #endif
+    mrdis_count(MRDIS_CNT_WINO4_WGRAD);
     hipLaunchKernelGGL(wino4_wgrad_kernel, dim3(splits * p.nCiB * p.nCoB), dim3(W_NT), W4W_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     base.splits = splits;

@@ -33,6 +33,8 @@ _SIGS = {
     'mrdis_version': (_I, []),
     'mrdis_set_option': (_I, [_c.c_char_p, _L]),
     'mrdis_get_option': (_L, [_c.c_char_p]),
+    'mrdis_launch_count': (_L, [_c.c_char_p]),
+    'mrdis_launch_count_reset': (None, []),
     'mrdis_mix_experts_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_bwd_workspace': (_Z, [_I, _I, _I, _I]),
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
@@ -40,10 +42,11 @@ _SIGS = {
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
     'mrdis_instnorm_stats': (_I, [_P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
-    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     'mrdis_wino_u_job_bytes': (_Z, []),
     'mrdis_wino_u_format': (_I, [_I, _I, _I]),
     'mrdis_wino_u_image_floats': (_L, [_I, _I, _I]),
+    'mrdis_wino_u_image_floats_fmt': (_L, [_I, _I, _I, _I]),
     'mrdis_wino_u_job_blocks': (_I, [_I, _I, _I]),
     'mrdis_wino_u_jobs': (_I, [_P, _I, _I, _P]),
     'mrdis_mix_experts_routed_multi_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
@@ -53,8 +56,8 @@ _SIGS = {
     'mrdis_mix_job_blocks': (_I, [_I, _I, _I]),
     'mrdis_mix_jobs_fwd': (_I, [_P, _I, _I, _P, _I, _I, _P]),
     'mrdis_mix_jobs_bwd': (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
-    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P, _P]),
-    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P, _P]),
+    'mrdis_conv2d_fwd': (_I, [_P, _I, _P, _P, _P, _P, _I] + [_I] * 11 + [_P, _I, _P]),
+    'mrdis_conv2d_bwd_data': (_I, [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P, _I, _P]),
     'mrdis_cast_bf16': (_I, [_P, _P, _L, _P]),
     'mrdis_cast_view': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _P]),
     'mrdis_conv2d_bwd_weight_workspace': (_Z, [_I] * 9),
@@ -130,6 +133,18 @@ def set_option(name, value):
 
 def get_option(name):
     return int(load().mrdis_get_option(name.encode()))
+
+
+WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad')
+
+
+def launch_counts(reset=False):
+    """{family: launches since load / the last reset} of the Winograd kernel families (include/mrdis.h mrdis_launch_count)"""
+    lib = load()
+    out = {f: int(lib.mrdis_launch_count(f.encode())) for f in WINO_FAMILIES}
+    if reset:
+        lib.mrdis_launch_count_reset()
+    return out
 
 
 class option:
@@ -301,14 +316,34 @@ def wino_u_table(jobs, device):
     if nb != lib.mrdis_wino_u_job_bytes():
         raise MrdisError(f'WinoUJob layout mismatch: binding {nb} bytes, library {lib.mrdis_wino_u_job_bytes()}')
     for j in jobs:
-        j.fmt = wino_u_format(j.R, j.S, j.spadeC)
+        if not j.fmt:                              # a caller may pin the format (MixPlan records the one it sized the image for)
+            j.fmt = wino_u_format(j.R, j.S, j.spadeC)
     arr = (WinoUJob * len(jobs))(*jobs)
     host = torch.frombuffer(bytearray(_c.string_at(_c.addressof(arr), nb * len(jobs))), dtype=torch.uint8)
     return host.to(device)
 
 
-def wino_u_image_floats(R, S, spadeC=0):
-    return int(load().mrdis_wino_u_image_floats(R, S, spadeC))
+def wino_u_image_floats(R, S, spadeC=0, fmt=None):
+    """floats of the filter image in format `fmt` (default: the format an image built NOW gets); -1 if that shape never has the format"""
+    if fmt is None:
+        return int(load().mrdis_wino_u_image_floats(R, S, spadeC))
+    return int(load().mrdis_wino_u_image_floats_fmt(R, S, spadeC, fmt))
+
+
+def wino_image_fmt(img, R, S, spadeC=0):
+    """The format a Winograd filter image was BUILT in: it travels with the image (attribute `mrdis_fmt`, set by whoever built it) and goes to
+    the library beside the pointer -- never re-derived from the current value of the option 'wino4', which may have changed since.  Images
+    without the attribute (tests, tools) are recognised by their size, which differs between the formats of one filter shape."""
+    fmt = getattr(img, 'mrdis_fmt', None)
+    n = img.numel()
+    if fmt is None:
+        hits = [f for f in (2, 4, 5) if wino_u_image_floats(R, S, spadeC, f) == n]
+        if len(hits) != 1:
+            raise MrdisError(f'Winograd image of {n} floats fits no single format of a [9][{R}][{S}] filter (spadeC {spadeC}): candidates {hits}')
+        fmt = hits[0]
+    elif wino_u_image_floats(R, S, spadeC, fmt) != n:
+        raise MrdisError(f'Winograd image tagged format {fmt} has {n} floats, a [9][{R}][{S}] filter (spadeC {spadeC}) needs {wino_u_image_floats(R, S, spadeC, fmt)}')
+    return fmt
 
 
 def wino_u_job_blocks(R, S, spadeC=0):
@@ -528,7 +563,7 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
     assert T == kh * kw and (Ci2 == Ci or (mixed == DT_XF32_YBF16 and Ci2 == max(Ci, 16))), (w_tck.shape, x.shape, kh, kw)
     if mixed in (DT_XBF16_YF32, DT_XF32_YBF16):
         rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), None, _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                                  1 if lrelu else 0, mixed, None, _stream())
+                                  1 if lrelu else 0, mixed, None, 0, _stream())
         if rc == -2 and may_decline:
             return None
         _chk(rc, 'conv2d_fwd (mixed storage)')
@@ -537,11 +572,13 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
         w_wino, w_bf16 = w_bf16, None
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
+    wfmt = 0
     if w_wino is not None:
-        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Ci, Co) and kh == 3 and kw == 3
+        assert w_wino.dtype == torch.float32 and kh == 3 and kw == 3
+        wfmt = wino_image_fmt(w_wino, Ci, Co)
     dt = DT_BF16 if mixed == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
     rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
-                              1 if lrelu else 0, dt, _ptr(w_wino) if dt == DT_F32 else None, _stream())
+                              1 if lrelu else 0, dt, _ptr(w_wino) if dt == DT_F32 else None, wfmt, _stream())
     if rc == -2 and dt == DT_BF16:
         # a tile geometry the bf16 kernel cannot stage (or a view it cannot address): the fp32 kernel between two view casts
         y32 = conv2d_fwd(cast_view(x, torch.float32), w_tck, bias, kh, kw, stride, pad, lrelu)
@@ -571,7 +608,7 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
         dx, ldo = nhwc(out)          # a channel slice of a wider NHWC buffer is fine (ldo > Ci)
         assert dx.data_ptr() == out.data_ptr() and ldo >= Ci and tuple(out.shape) == (N, Ci, H, W)
         if mixed:                    # bf16 storage: dy fp32 -> dx bf16 (MRDIS_DT_XBF16_YF32), or dy bf16 -> dx fp32 (MRDIS_DT_XF32_YBF16)
-            rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, _stream())
+            rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), None, _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, _dt_xy(dx, dy), None, 0, _stream())
             if rc == -2 and may_decline:
                 return None
             _chk(rc, 'conv2d_bwd_data (mixed storage)')
@@ -580,11 +617,13 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
         w_wino, w_bf16 = w_bf16, None
     if w_bf16 is not None:
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
+    wfmt = 0
     if w_wino is not None:
-        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Co, Ci) and kh == 3 and kw == 3
+        assert w_wino.dtype == torch.float32 and kh == 3 and kw == 3
+        wfmt = wino_image_fmt(w_wino, Co, Ci)
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
     rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, dt,
-                                   _ptr(w_wino) if dt == DT_F32 else None, _stream())
+                                   _ptr(w_wino) if dt == DT_F32 else None, wfmt, _stream())
     if rc == -2 and dt == DT_BF16:
         # a geometry outside the bf16 kernels (e.g. a reduction axis that is not a multiple of 16): fp32 kernel between two view casts
         res = cast_view(conv2d_bwd_data(cast_view(dy, torch.float32), w_tkc, in_hw, kh, kw, stride, pad), torch.bfloat16)
@@ -745,10 +784,12 @@ def gb_spade_fwd(si_out, w_tck, bias, z, eps=1e-5, out=None, w_bf16=None, stats_
     # (stats_ready: `out`'s mean / rstd already hold them -- the x2 resize that produced z took them on the way, bilinear_up2_stats)
     if not stats_ready:
         _chk(lib.mrdis_instnorm_stats(_ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(ws), nb, N, H * W, C, eps, dt, st), 'instnorm_stats')
+    wfmt = 0
     if w_wino is not None:
-        assert w_wino.dtype == torch.float32 and w_wino.numel() == wino_u_image_floats(Ci, 2 * C, C)
+        assert w_wino.dtype == torch.float32
+        wfmt = wino_image_fmt(w_wino, Ci, 2 * C, C)
     rc = lib.mrdis_conv2d_fwd_spade(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(z), ldz, _ptr(mean), _ptr(rstd), _ptr(mix), C, _ptr(gamma), C,
-                                    N, H, W, Ci, C, dt, _ptr(w_wino) if dt == DT_F32 else None, st)
+                                    N, H, W, Ci, C, dt, _ptr(w_wino) if dt == DT_F32 else None, wfmt, st)
     if rc == -2:
         return None
     _chk(rc, 'conv2d_fwd_spade')

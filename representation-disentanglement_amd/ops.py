@@ -247,10 +247,12 @@ class MixPlan:
         mrdis_wino_u_jobs): per entry and label up to two roles -- 'fwd' (or 'spade' for a fused gamma | beta pair) and 'dgrad' -- built by
         ONE launch per mixing group right behind the mixing launch, into persistent buffers (a job table like the mixing launch's own)."""
         self.u_njobs = self.u_blocks = 0
+        self.u_opts = None
         self.u_imgs = {}                                # (entry, label) -> {role: image tensor}
         if self.want_bf16 or not _WINO_U:
             return
         M, flat = self.M, self.flat
+        self.u_opts = (hip.get_option('wino4'),)       # what the formats below were chosen under: still_valid() rebuilds the plan when it changes
         want = []                                      # (entry, label, role, src element offset, R, S, flip, spadeC)
         nsing = len(self.singles)
         for ei, (T, Ci, Cw) in enumerate(self.shapes):
@@ -275,15 +277,17 @@ class MixPlan:
                     want.append((ei, mm, 'dgrad', tkc_off, Cw, Ci, 1, 0))
         if not want:
             return
-        sizes = [hip.wino_u_image_floats(R, S, C) for (_, _, _, _, R, S, _, C) in want]
+        fmts = [hip.wino_u_format(R, S, C) for (_, _, _, _, R, S, _, C) in want]
+        sizes = [hip.wino_u_image_floats(R, S, C, f) for (_, _, _, _, R, S, _, C), f in zip(want, fmts)]
         self.u_flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
         jobs, blocks, pos = [], 0, 0
-        for (ei, mm, role, src, R, S, flip, C), n in zip(want, sizes):
+        for (ei, mm, role, src, R, S, flip, C), n, fmt in zip(want, sizes, fmts):
             img = self.u_flat[pos:pos + n]
+            img.mrdis_fmt = fmt                        # the format travels with the image (hip.wino_image_fmt -> w_wino_fmt of the C ABI)
             self.u_imgs.setdefault((ei, mm), {})[role] = img
             j = hip.WinoUJob()
             j.w, j.img = flat.data_ptr() + 4 * src, img.data_ptr()
-            j.R, j.S, j.flip, j.spadeC = R, S, flip, C
+            j.R, j.S, j.flip, j.spadeC, j.fmt = R, S, flip, C, fmt
             j.block0, j.nblk = blocks, hip.wino_u_job_blocks(R, S, C)
             blocks += j.nblk; pos += n
             jobs.append(j)
@@ -307,6 +311,8 @@ class MixPlan:
 
     def still_valid(self):
         """the expert weights are views of the optimizer's arena: re-check (cheaply) that they have not moved"""
+        if getattr(self, 'u_opts', None) is not None and self.u_opts != (hip.get_option('wino4'),):
+            return False                               # the image formats were chosen under another value of 'wino4': rebuild (images keep the format they were built in)
         return all(j.W == m.weight.data_ptr() for j, (ei, m, col0, ld) in zip(self.jobs[:4], self.specs[:4])) and self.probe.grad is not None
 
     def views(self):

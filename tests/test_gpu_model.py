@@ -126,12 +126,36 @@ def _cfg(mrdis, M, H, W, B, adv=False):
 PER_TENSOR_A = {'b2m4': 4e-4, 'b4m2': 4e-4, 'b2m4_drop': 4e-4, 'b2m2_adv': 5e-3}
 
 
-@pytest.mark.parametrize('tag', ['b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv'])
-def test_train_step_golden(mrdis, golden_dir, tag):
-    """One full training step at the reference's own size vs vectors from the real reference."""
+# Kernel-selection policies the reference goldens are run under (the goldens are B = 2 at 160x192, where the default grid policy declines most
+# F(4x4) forms: the forced policies put EVERY Winograd form in front of reference-generated vectors; hip.launch_counts() proves which ran).
+#   default: what a user gets | f4: Winograd wherever a kernel applies, F(4x4) forward / data gradient / SPADE-fused / F(3x3,4x4) weight gradient,
+#   32-cout layers on the register-fed 64-tile form | f4r3: the same with the register-fed channel-split form | f4n: the shared-transform 32-cout form
+WINO_POLICIES = {'default': {}, 'f4': dict(wino=2, wino4=2, wino4r=2), 'f4r3': dict(wino=2, wino4=2, wino4r=3), 'f4n': dict(wino=2, wino4=2, wino4r=0)}
+WINO_MUST_RUN = {'default': (), 'f4': ('wino4', 'wino4_spade', 'wino4r', 'wino4_wgrad'), 'f4r3': ('wino4', 'wino4_spade', 'wino4r', 'wino4_wgrad'),
+                 'f4n': ('wino4', 'wino4_spade', 'wino4n', 'wino4_wgrad')}
+GOLDEN_CASES = [(t, 'default') for t in ('b2m4', 'b4m2', 'b2m4_drop', 'b2m2_adv')] + [(t, pol) for t in ('b2m4', 'b2m2_adv') for pol in ('f4', 'f4r3', 'f4n')]
+
+
+def _apply_policy(mrdis, policy):
+    for k, v in WINO_POLICIES[policy].items():
+        mrdis.hip.set_option(k, v)
+    mrdis.hip.launch_counts(reset=True)
+
+
+def _check_policy_ran(mrdis, policy, what):
+    counts = mrdis.hip.launch_counts()
+    dump_measured('wino_launch_counts.jsonl', dict(what=what, policy=policy, **counts))
+    for fam in WINO_MUST_RUN[policy]:
+        assert counts[fam] > 0, (policy, fam, counts)
+
+
+@pytest.mark.parametrize('tag,policy', GOLDEN_CASES)
+def test_train_step_golden(mrdis, golden_dir, tag, policy):
+    """One full training step at the reference's own size vs vectors from the real reference, under each kernel-selection policy."""
     meta = json.load(open(os.path.join(golden_dir, f'step_{tag}.json')))
     arrs = np.load(os.path.join(golden_dir, f'step_{tag}.npz'))
     B, M, adv = meta['B'], meta['M'], meta['adv']
+    _apply_policy(mrdis, policy)
     cfg = _cfg(mrdis, M, 160, 192, B, adv)
     torch.manual_seed(10); np.random.seed(10)
     model = mrdis.build_model(cfg).train()        # same constructor RNG order as the reference
@@ -161,9 +185,10 @@ def test_train_step_golden(mrdis, golden_dir, tag):
     ref_total = float(np.sqrt(sum(v * v for v in hot.values())))
     assert abs(total - ref_total) <= 1e-3 * ref_total, (total, ref_total)
     worst = max((abs(gn[k] - v) / (v + 4e-3 * ref_total), k) for k, v in hot.items())
-    dump_measured('f32_golden_measured.jsonl', dict(tag=tag, worst_per_tensor=worst[0], tensor=worst[1], total_rel=abs(total - ref_total) / ref_total))
+    dump_measured('f32_golden_measured.jsonl', dict(tag=tag, policy=policy, worst_per_tensor=worst[0], tensor=worst[1], total_rel=abs(total - ref_total) / ref_total))
     for k, v in hot.items():
         assert abs(gn[k] - v) <= PER_TENSOR_A[tag] * (v + 4e-3 * ref_total), (k, gn[k], v)
+    _check_policy_ran(mrdis, policy, f'golden {tag}')
     # clip + Adam on the arena vs the reference's weights after optimizer.step()
     step.optimizer.step(fused_clip=True)
     for k, v in meta['wsum_after'].items():
@@ -175,6 +200,121 @@ def test_train_step_golden(mrdis, golden_dir, tag):
         # gradient is rounding noise) to land on the other side, on top of the relative tolerance
         flips = 2 * cfg['lr'] * np.ceil(1e-3 * t.numel())
         assert abs(got - v) <= 2e-4 * max(1.0, abs(v)) + flips, ('after step', k, got, v)
+
+
+def test_train_step_vs_oracle_at_256_default_policy(mrdis):
+    """The benchmarked map size under the DEFAULT policy: B = 8, M = 4, 256x256 gives the F(4x4) kernels the >= 192-workgroup grids they take at
+    B = 32 (sp4 / sp5 / sp6 forward, data gradient, SPADE-fused; F(3x3,4x4) weight gradient on the full-resolution layers), so the kernels that
+    carry ~45 % of the benchmarked step meet the CPU oracle (pinned to the reference at 160x192) in one full step: loss, parts, every gradient.
+    Reference ops: model.py:2104-2117 (CondConv2d), :2438-2454 (SPADEBlockNew)."""
+    B, M, H, W = 8, 4, 256, 256
+    cfg = _cfg(mrdis, M, H, W, B, adv=True)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    torch.manual_seed(10)
+    ref = R.RefMultimodalModel((H, W), M, is_discrim_s=True).train()
+    reinit_discriminator(ref.discrim_s)
+    assert not mrdis.load_checkpoint_model(model, ref.state_dict())
+    inputs, mask, mask_img = make_inputs(B, M, H, W, seed=6, drop=False)
+    lam = dict(R.DEFAULT_LAMBDAS, adv_s=1.0)
+    torch.manual_seed(11); np.random.seed(11)
+    rloss, rparts, raux = R.ref_forward_losses(ref, inputs, mask, mask_img, lam)
+    rloss.backward()
+    mrdis.TrainStep(model, cfg)
+    mrdis.hip.launch_counts(reset=True)
+    torch.manual_seed(11); np.random.seed(11)
+    with mrdis.ops.mix_cache():
+        loss, parts, aux = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+        loss.backward()
+    counts = mrdis.hip.launch_counts()
+    dump_measured('wino_launch_counts.jsonl', dict(what='oracle 256x256 B8 M4', policy='default', **counts))
+    for fam in ('wino4', 'wino4_spade', 'wino4_wgrad', 'wino2'):
+        assert counts[fam] > 0, (fam, counts)
+    assert counts['wino4r'] + counts['wino4n'] > 0, counts
+    assert abs(float(loss) - float(rloss)) <= 1e-3 * abs(float(rloss))
+    for k, v in rparts.items():
+        assert abs(float(parts[k]) - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, k
+    for a, b in zip(aux['xi_fake_mix_list'], raux['xmix']):
+        close(a, b.detach(), 1e-3, 'xmix')
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in rg.values())))
+    worst = (0.0, '')
+    for n, p in model.named_parameters():
+        if n in rg:
+            err = float((p.grad.detach().cpu() - rg[n]).double().norm())
+            worst = max(worst, (err / (float(rg[n].double().norm()) + 1e-2 * tot), n))
+            assert err <= 2e-3 * float(rg[n].double().norm()) + 2e-5 * tot, (n, err, float(rg[n].norm()))
+        else:
+            assert p.grad is None, n
+    dump_measured('f32_golden_measured.jsonl', dict(tag='oracle_256_b8m4', policy='default', worst_per_tensor=worst[0], tensor=worst[1]))
+
+
+def test_winograd_image_keeps_its_format_when_the_option_changes(mrdis):
+    """the format of a Winograd filter image travels with the image.  A model that has run a step under wino4 = 1 and is then
+    run under wino4 = 0 (and back) must (a) rebuild its mixing plan -- the images are of the format the option named when they were built -- and
+    (b) give the F(2x2)-only result of a fresh model; an image handed to the library with a format its shape cannot have is MRDIS_EINVAL, and an
+    image of format 4 run under wino4 = 0 is read through its trailing 16-point part (bit-identical to the image-free F(2x2) call)."""
+    hip = mrdis.hip
+    B, M, H, W = 2, 2, 64, 64
+    cfg = _cfg(mrdis, M, H, W, B)
+    inputs, mask, mask_img = make_inputs(B, M, H, W, seed=3, drop=False)
+
+    def run(model):
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        torch.manual_seed(11); np.random.seed(11)
+        with mrdis.ops.mix_cache():
+            loss, _, _ = mrdis.forward_losses(model, cfg, cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+            loss.backward()
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    hip.set_option('wino', 2); hip.set_option('wino4', 2)
+    torch.manual_seed(10); np.random.seed(10)
+    model = mrdis.build_model(cfg).train()
+    mrdis.TrainStep(model, cfg)
+    hip.launch_counts(reset=True)
+    l4, g4 = run(model)
+    assert hip.launch_counts()['wino4'] > 0
+    plans4 = dict(model._mrdis_mix_plans)
+    hip.set_option('wino4', 0)
+    hip.launch_counts(reset=True)
+    l2, g2 = run(model)                                              # the SAME model object: its plans were built under wino4 = 2
+    c = hip.launch_counts()
+    assert c['wino4'] == c['wino4_spade'] == c['wino4r'] == c['wino4n'] == 0 and c['wino2'] > 0, c
+    assert all(model._mrdis_mix_plans[k] is not plans4[k] for k in plans4), 'the mixing plans (and their images) were not rebuilt'
+    torch.manual_seed(10); np.random.seed(10)
+    fresh = mrdis.build_model(cfg).train()
+    mrdis.TrainStep(fresh, cfg)
+    lf, gf = run(fresh)
+    assert l2 == lf and all(torch.equal(g2[n], gf[n]) for n in gf), 'toggling wino4 on a warm model differs from a fresh model under the new value'
+    hip.set_option('wino4', 2)
+    l4b, g4b = run(model)
+    assert l4b == l4 and all(torch.equal(g4b[n], g4[n]) for n in g4)
+    # the library itself: format checked against the shape; a format-4 image under wino4 = 0 is read through its 16-point tail
+    R_, S_ = 64, 64
+    w = torch.randn(9, R_, S_, device=DEV) * 0.05
+    x = cl(torch.randn(2, R_, 64, 64))
+    img = torch.zeros(hip.wino_u_image_floats(R_, S_, 0, 4), device=DEV)
+    j = hip.WinoUJob(); j.w, j.img, j.R, j.S, j.flip, j.spadeC, j.block0, j.nblk, j.fmt = w.data_ptr(), img.data_ptr(), R_, S_, 0, 0, 0, hip.wino_u_job_blocks(R_, S_), 4
+    hip.wino_u_jobs(hip.wino_u_table([j], DEV), 1, j.nblk)
+    assert hip.wino_image_fmt(img, R_, S_) == 4
+    hip.launch_counts(reset=True)
+    y4 = hip.conv2d_fwd(x, w, None, 3, 3, 1, 1, w_wino=img)
+    assert hip.launch_counts()['wino4'] == 1
+    hip.set_option('wino4', 0)
+    y2 = hip.conv2d_fwd(x, w, None, 3, 3, 1, 1, w_wino=img)        # same image, option off: the 16-point part of the SAME image
+    y2_plain = hip.conv2d_fwd(x, w, None, 3, 3, 1, 1)
+    assert torch.equal(y2, y2_plain)
+    assert float((y4 - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
+    img.mrdis_fmt = 5                                                # a 64-cout filter never has the 32-cout format
+    with pytest.raises(mrdis.hip.MrdisError):
+        hip.conv2d_fwd(x, w, None, 3, 3, 1, 1, w_wino=img)
+    lib = hip.load()
+    y = hip.empty_nhwc(2, S_, 64, 64, DEV)
+    rc = lib.mrdis_conv2d_fwd(x.data_ptr(), R_, w.data_ptr(), None, None, y.data_ptr(), S_, 2, 64, 64, R_, S_, 3, 3, 1, 1, 0, 0, img.data_ptr(), 5,
+                              torch.cuda.current_stream().cuda_stream)
+    assert rc == -1                                                  # MRDIS_EINVAL, from the library itself
 
 
 def test_train_step_golden_with_output_decoder(mrdis, golden_dir):

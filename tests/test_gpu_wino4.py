@@ -74,7 +74,7 @@ def test_f44_filter_image(mrdis, R, S, flip):
     hip.set_option('wino4', 0)                                      # the tail IS the format-2 image (tests/test_gpu_ops.py::test_winograd_filter_image)
     assert hip.wino_u_format(R, S) == 2 and hip.wino_u_image_floats(R, S) == n2
     img2 = torch.full((n2,), float('nan'), device=DEV)
-    j.img, j.nblk = img2.data_ptr(), hip.wino_u_job_blocks(R, S)
+    j.img, j.nblk, j.fmt = img2.data_ptr(), hip.wino_u_job_blocks(R, S), 2     # (a job keeps the format it was first tabled with unless told otherwise)
     hip.wino_u_jobs(hip.wino_u_table([j], DEV), 1, j.nblk)
     assert torch.equal(img[n4:], img2)
 

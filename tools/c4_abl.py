@@ -35,7 +35,7 @@ for Co, Ci_w in ((32, 16), (64, 16)):
         r = []
         for tag, w, y, dt in (('f32 out', w4, y32, hip.DT_F32), ('bf16 out', w16, y16, hip.DT_XF32_YBF16)):
             def run():
-                rc = lib.mrdis_conv2d_fwd(x.data_ptr(), 4, w.data_ptr(), None, b.data_ptr(), y.data_ptr(), Co, N, H, W, 4, Co, 3, 3, 1, 1, 0, dt, None, st)
+                rc = lib.mrdis_conv2d_fwd(x.data_ptr(), 4, w.data_ptr(), None, b.data_ptr(), y.data_ptr(), Co, N, H, W, 4, Co, 3, 3, 1, 1, 0, dt, None, 0, st)
                 assert rc == 0, rc
             for _ in range(5):
                 run()
