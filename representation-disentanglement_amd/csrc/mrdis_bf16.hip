@@ -290,6 +290,7 @@ static int bconv_ncu() {
 }
 
 int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s);      // mrdis_bf16p.hip
+int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s);      // mrdis_bf16q.hip
 
 // Eligibility: reduction axis a multiple of 16, 16-byte aligned views, cout a multiple of 4 (16-byte stores).
 int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BConvLaunch* defer) {
@@ -297,6 +298,8 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BCon
     if (!p.w_bf16 || (p.dtype != MRDIS_DT_F32_BF16M && p.dtype != MRDIS_DT_BF16)) return MRDIS_EUNSUPPORTED;
     const bool st_bf16 = p.dtype == MRDIS_DT_BF16;
     if (st_bf16 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {               // 3x3 s1 layers on bf16 activations: the pipelined kernel (mrdis_bf16p.hip)
+        const int rc4 = mrdis_run_bconv4(p, s);                    // LDS-DMA form where the launch fills the chip
+        if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
         const int rc3 = mrdis_run_bconv3(p, s);
         if (rc3 != MRDIS_EUNSUPPORTED) return rc3;
     }

@@ -361,6 +361,7 @@ int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s) {
 #undef BA
     }
 #endif
+    mrdis_count(MRDIS_CNT_BCONV3);
     if (WC == 2) hipLaunchKernelGGL(bconv3_kernel<2>, dim3(grid), dim3(512), lds, s, p);
     else hipLaunchKernelGGL(bconv3_kernel<1>, dim3(grid), dim3(512), lds, s, p);
     MRDIS_CHECK_LAUNCH();
@@ -396,6 +397,7 @@ int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const flo
     }
     const int grid = units < n_cu ? (int)units : n_cu;
     const size_t lds = 2 * (size_t)(2 * 9 * 64 * P_PITCH + 2 * P_XS) + sizeof(float) * P_BIAS;
+    mrdis_count(MRDIS_CNT_BCONV3_SPADE);
     hipLaunchKernelGGL((bconv3_kernel<2, 0, true>), dim3(grid), dim3(512), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

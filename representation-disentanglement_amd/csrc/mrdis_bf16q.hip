@@ -1,0 +1,390 @@
+// mrdis_bf16q.hip -- bf16 3x3 / stride 1 / pad 1 convolution on bf16 activations (MRDIS_DT_BF16), LDS-DMA form: forward, data gradient (flipped taps)
+// and the SPADE-fused gamma | beta form of the layers with Cin a multiple of 32 on maps at least 32 wide.
+//
+// Why a second pipelined kernel.  Timing-only builds of bconv3_kernel (mrdis_bf16p.hip; tools/bconv_abl.py, 128 -> 256 at 64x64, B = 32: 94 us) said:
+// without its MFMAs 97 us, without its LDS stores 57 us, without its global loads 66 us, the bare MFMA loop + epilogue 56 us.  The matrix pipe is not
+// what it waits for; the LDS is: per 288 MFMAs a workgroup reads 432 KB of operands (a wave's 32 positions x 64 couts take 1.5 ds_read_b128 per MFMA) and stores
+// 58 KB from registers (64 ds_write_b128 wave-instructions, whose VGPR -> LDS transfer is paced at 13 cycles each), ~95 % of the LDS cycles the MFMAs leave.
+// Here:
+//   * a wave owns 64 positions (two rows of a 16 x 32 tile) x all 64 couts of the workgroup: four MFMAs share two A and two B operand reads -- 1.0
+//     ds_read_b128 per MFMA; the halo of the 512-position tile is 1.20x (8 x 32: 1.33x);
+//   * the operand images reach LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write, no wait of the MFMA stream on a load; a lane
+//     whose pixel / cout lies outside gets an offset beyond the descriptor (zeros: the convolution's padding, ragged tiles, cout tails);
+//   * the images are UNPADDED 64-byte rows ([pixel][32 ch], [tap][cout][32 ch]) with the 16-byte piece p of row R stored at slot p ^ ((R >> 2) & 3): a DMA
+//     wave-instruction fills 16 consecutive rows (lane l: row l / 4, slot l % 4, i.e. it fetches piece (l % 4) ^ ((R >> 2) & 3)), and the 16 lanes that one
+//     ds_read_b128 cycle serves (lanes 0-3, 12-15, 20-27 of consecutive rows) touch all 64 banks once for any base row;
+//   * two stages of (filter image 36 KB + pixel image 39 KB) are double-buffered: the DMA of item i + 1 is issued in the first ten steps of item i, every
+//     wave waits for its own pieces (vmcnt(0)) before the ONE barrier per item.
+// Arithmetic: the same products in the same accumulation order as bconv3_kernel / bconv_kernel (taps 0..8, two 16-channel k-steps per tap, 32-channel chunks in
+// order): results are bit-identical to theirs.
+#include "mrdis_tapconv.h"
+
+typedef __bf16 bq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bq_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bq_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bq_u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int Q_KC = 32, Q_TH = 16, Q_TW = 32, Q_INH = Q_TH + 2, Q_INW = Q_TW + 2, Q_NPIX = Q_INH * Q_INW;      // 18 x 34 = 612 halo pixels
+constexpr int Q_XP = (Q_NPIX + 15) / 16;               // 39 DMA pieces (1 KB = 16 rows of 64 B) per pixel image
+constexpr int Q_XBYTES = Q_XP * 1024;                  // 39,936
+constexpr int Q_NXI = 5;                               // pixel pieces per wave: k = wave + 8 i (k < 39)
+constexpr int Q_BIAS = 1024;
+constexpr unsigned Q_OOB = 0xfffffff0u;
+template <int V_> struct QIC { static constexpr int value = V_; };
+__device__ __forceinline__ int q_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }
+// see bp_pair8 (mrdis_bf16p.hip): the two half-waves of a position swap one 4-cout piece so that every lane holds 8 consecutive couts (one 16-byte store)
+__device__ __forceinline__ bq_u32x4 bq_pair8(bq_u32x2 gq, bq_u32x2 gq1) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(gq[0], gq1[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(gq[1], gq1[1], false, false);
+    return bq_u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+}  // namespace
+
+struct BConv4Params {
+    const void* in; const void* w; const float* bias; void* out;       // bf16 activations, bf16 filter [tap][Cout][Cin], fp32 bias
+    int N, H, W, Cin, ldin, Cout, ldout;
+    int tilesA, tilesB, coTiles, units;               // units = N * tilesA * tilesB * coTiles
+    int nchunks, lrelu;
+    int dh[9], dw[9], widx[9];
+    unsigned in_bytes, w_bytes;
+    // SPADE epilogue (see BConv3Params): Cout = 2 C, a workgroup owns 32 channels = 32 gamma + 32 beta couts
+    const void* z; const float* mean; const float* rstd; void* gamma_out;
+    int ldz, ldg, C;
+    int wide;                                         // 16-byte output stores: Cout (C) % 8 == 0, output views 16-byte aligned with ld % 8 == 0
+};
+
+// WC: 32-cout groups per workgroup (2: 64 couts, 1: the layers with <= 32 couts)
+// ABL (timing-only, -DBCONV4_ABLATIONS): 1 no MFMAs, 2 no DMA after the prologue, 4 no output stores, 8 no wait for the DMA before the barrier
+template <int WC, bool SPADE = false, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
+    static_assert(!SPADE || WC == 2, "SPADE: 32 gamma + 32 beta couts per workgroup");
+    constexpr int BN = 32 * WC, NT = 512;
+    constexpr int WROWS = 9 * BN;                      // rows of the filter image
+    constexpr int WP = WROWS / 16;                     // its DMA pieces (36 | 18)
+    constexpr int NWI = (WP + 7) / 8;                  // per wave (5 | 3): k = wave + 8 i (k < WP)
+    constexpr int WBYTES = WROWS * 64;                 // 36,864 | 18,432
+    constexpr int XBASE = 2 * WBYTES;                  // LDS: [filter stage 0][filter stage 1][pixels stage 0][pixels stage 1][bias]
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_q[];
+    float* const Bs = reinterpret_cast<float*>(smem_q + XBASE + 2 * Q_XBYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
+    // ---- MFMA role: positions (rows 2 wave + r, column e) of the 16 x 32 tile, k-group `half` (channels 8 half .. + 7 of a 16-channel k-step)
+    int xaddr[2][9];                                   // byte address of piece `half` (k-step 0) of this lane's pixel, per (row r, tap t); k-step 1: ^ 32
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pix = (2 * wave + r + 1 + p.dh[t]) * Q_INW + (e + 1 + p.dw[t]);
+            xaddr[r][t] = XBASE + pix * 64 + ((half ^ ((pix >> 2) & 3)) << 4);
+        }
+    const int aaddr = e * 64 + ((half ^ ((e >> 2) & 3)) << 4);           // filter row e of a 32-cout group: + (t * BN + 32 j) * 64, k-step 1: ^ 32 (the row offsets are multiples of 2048)
+
+    // ---- DMA roles (item-invariant): which (row, piece) of the images lane `lane` of this wave copies with its i-th wave-instruction
+    unsigned x_rel[Q_NXI]; int x_yx[Q_NXI];            // x_yx = (iy << 8) | ix, or -1
+#pragma unroll
+    for (int i = 0; i < Q_NXI; ++i) {
+        const int k = wave + 8 * i, R = 16 * k + (lane >> 2), pc = (lane & 3) ^ ((R >> 2) & 3);
+        const int iy = R / Q_INW, ix = R - iy * Q_INW;
+        x_yx[i] = (k < Q_XP && R < Q_NPIX) ? ((iy << 8) | ix) : -1;
+        x_rel[i] = 2u * (unsigned)((iy * p.W + ix) * p.ldin + 8 * pc);
+    }
+    unsigned w_rel[NWI]; int w_co[NWI];                // w_co: cout within the tile, or -1
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int k = wave + 8 * i, R = 16 * k + (lane >> 2), pc = (lane & 3) ^ ((R >> 2) & 3);
+        const int t = R / BN, co = R - t * BN;
+        w_co[i] = k < WP ? co : -1;
+        // SPADE: local couts 0..31 are the gamma couts of the workgroup's 32 channels, 32..63 their beta couts (C further on in the filter)
+        const int co_g = SPADE ? ((co >> 5) ? p.C : 0) + (co & 31) : co;
+        w_rel[i] = 2u * (unsigned)((p.widx[t < 9 ? t : 0] * p.Cout + co_g) * p.Cin + 8 * pc);
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    for (int c = tid; c < Q_BIAS; c += NT) Bs[c] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+    const unsigned lds_raw = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem_q;
+
+    const int grid = gridDim.x;
+    const int u0 = mrdis_xcd_remap(blockIdx.x, grid);
+    const int nmine = (p.units - u0 + grid - 1) / grid;           // host: grid <= units
+    const int total = nmine * p.nchunks;
+    auto decode = [&](int j, int& n, int& a0, int& b0, int& co0) {
+        int u = u0 + j * grid;
+        const int cot = u % p.coTiles; u /= p.coTiles;
+        const int tb = u % p.tilesB; u /= p.tilesB;
+        const int ta = u % p.tilesA;
+        n = u / p.tilesA; a0 = ta * Q_TH; b0 = tb * Q_TW; co0 = cot * BN;
+    };
+
+    // ---- DMA cursor: unit lj, chunk lc
+    int lj = 0, lc = 0;
+    int l_h0 = 0, l_w0 = 0, l_co0 = 0; unsigned l_xorg = 0; bool l_live = false;
+    auto load_unit = [&]() {
+        l_live = lj < nmine;
+        if (l_live) {
+            int n, a0, b0, co0; decode(lj, n, a0, b0, co0);
+            l_h0 = a0 - 1; l_w0 = b0 - 1; l_co0 = co0;
+            l_xorg = 2u * (unsigned)(((n * p.H + l_h0) * p.W + l_w0) * p.ldin);        // wraps for halo origins; added mod 2^32 below
+        }
+    };
+    unsigned xo[Q_NXI], wo[NWI];                       // byte offsets of the next item's pieces
+    auto next_offsets = [&]() {
+        const unsigned c0b = 2u * (unsigned)(lc * Q_KC);
+#pragma unroll
+        for (int i = 0; i < Q_NXI; ++i) {
+            const int h = l_h0 + (x_yx[i] >> 8), w_ = l_w0 + (x_yx[i] & 255);
+            const bool ok = l_live && x_yx[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            xo[i] = ok ? l_xorg + x_rel[i] + c0b : Q_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const bool ok = l_live && w_co[i] >= 0 && (SPADE ? l_co0 / 2 + (w_co[i] & 31) < p.C : l_co0 + w_co[i] < p.Cout);
+            wo[i] = ok ? w_rel[i] + 2u * (unsigned)((SPADE ? l_co0 / 2 : l_co0) * p.Cin) + c0b : Q_OOB;
+        }
+        if (++lc == p.nchunks) { lc = 0; ++lj; load_unit(); }
+    };
+    // one DMA wave-instruction: 64 lanes x 16 bytes land at LDS byte m0v + 16 lane.  Inline assembly: the compiler neither tracks these in vmcnt (the wait
+    // before the barrier below is explicit) nor orders LDS reads behind them.
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned lds_byte) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_raw + lds_byte);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(m0v), "s"(rs) : "memory");
+    };
+    auto dma_x = [&](int stage, int i) { if (wave + 8 * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, xo[i], (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + 8 * i))); };
+    auto dma_w = [&](int stage, int i) { if (wave + 8 * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, wo[i], (unsigned)(stage * WBYTES + 1024 * (wave + 8 * i))); };
+
+    f32x16 acc[2][WC];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < WC; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[r][j][k] = 0.f;
+
+    // ---- prologue: item 0 into stage 0
+    load_unit();
+    next_offsets();
+#pragma unroll
+    for (int i = 0; i < Q_NXI; ++i) dma_x(0, i);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) dma_w(0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int mj = 0, mc = 0;
+    auto iteration = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const unsigned char* wa0 = smem_q + q_opaque(P * WBYTES + aaddr);
+        const unsigned char* wa1 = smem_q + q_opaque(P * WBYTES + (aaddr ^ 32));
+        const unsigned char* xs = smem_q + P * Q_XBYTES;                // + xaddr[r][t] (^ 32): the stage offset stays in the instruction's immediate
+        next_offsets();                                // item i + 1: its DMA goes out in the first steps below, into stage P ^ 1
+        // operand registers in a ring of three: the reads of step s + 2 are issued in step s (a full step of MFMAs -- this wave's and its SIMD partner's --
+        // covers their LDS latency; one step ahead left the matrix pipe waiting: 68 us of MFMA + operand reads + barriers against 37 us of MFMAs on 128 -> 256 at 64x64)
+        bq_bf16x8 af[3][WC], bf[3][2];
+        auto ld_ops = [&](int slot, int s1) {
+            const int t1 = s1 >> 1, ks1 = s1 & 1;
+#pragma unroll
+            for (int j = 0; j < WC; ++j) af[slot][j] = *reinterpret_cast<const bq_bf16x8*>((ks1 ? wa1 : wa0) + (t1 * BN + 32 * j) * 64);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bf[slot][r] = *reinterpret_cast<const bq_bf16x8*>(xs + (xaddr[r][t1] ^ (ks1 << 5)));
+        };
+        ld_ops(0, 0); ld_ops(1, 1);
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            const int c_ = s_ % 3;
+            if (s_ + 2 < 18) ld_ops((s_ + 2) % 3, s_ + 2);
+            if (s_ < Q_NXI) dma_x(P ^ 1, s_);
+            else if (s_ < Q_NXI + NWI) dma_w(P ^ 1, s_ - Q_NXI);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < WC; ++j) { if (ABL & 1) acc[r][j][0] += (float)af[c_][j][0] * (float)bf[c_][r][0]; else acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c_][j], bf[c_][r], acc[r][j], 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of item i + 1 have landed
+        __syncthreads();
+
+        if (++mc == p.nchunks) {
+            // ---- epilogue of unit mj: D[cout][position]; a lane owns positions (2 wave + r, e) and the couts 8 g + 4 half .. + 3 (g = 0..3) of each 32-cout block
+            int n, a0, b0, co0; decode(mj, n, a0, b0, co0);
+            mc = 0; ++mj;
+            const int b = b0 + e;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int a = a0 + 2 * wave + r;
+                const bool pos_ok = a < p.H && b < p.W && !((ABL & 4) && acc[r][0][0] != 1.2345f);
+                const long long pix = (long long)(n * p.H + a) * p.W + b;
+                if (SPADE) {
+                    const int c0 = co0 / 2;                          // the workgroup's first channel
+                    const __bf16* zp = reinterpret_cast<const __bf16*>(p.z) + pix * p.ldz;
+                    bq_bf16x4 zq[4]; float4 mu[4], rs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                  // loads first
+                        const int ch = c0 + 8 * q + 4 * half;
+                        const bool ok = pos_ok && ch < p.C;
+                        zq[q] = ok ? *reinterpret_cast<const bq_bf16x4*>(zp + ch) : bq_bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                        mu[q] = ch < p.C ? *reinterpret_cast<const float4*>(p.mean + (long long)n * p.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rs[q] = ch < p.C ? *reinterpret_cast<const float4*>(p.rstd + (long long)n * p.C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    __bf16* mixp = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout;
+                    __bf16* gamp = reinterpret_cast<__bf16*>(p.gamma_out) + pix * p.ldg;
+                    bq_u32x2 pko[4], pkg[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = c0 + 8 * q + 4 * half;
+                        const float4 bg = *reinterpret_cast<const float4*>(Bs + (ch < p.C ? ch : 0));
+                        const float4 bb = *reinterpret_cast<const float4*>(Bs + (ch < p.C ? p.C + ch : 0));
+                        const float g[4] = {acc[r][0][4 * q] + bg.x, acc[r][0][4 * q + 1] + bg.y, acc[r][0][4 * q + 2] + bg.z, acc[r][0][4 * q + 3] + bg.w};
+                        const float bt[4] = {acc[r][WC - 1][4 * q] + bb.x, acc[r][WC - 1][4 * q + 1] + bb.y, acc[r][WC - 1][4 * q + 2] + bb.z, acc[r][WC - 1][4 * q + 3] + bb.w};
+                        const float m_[4] = {mu[q].x, mu[q].y, mu[q].z, mu[q].w}, r_[4] = {rs[q].x, rs[q].y, rs[q].z, rs[q].w};
+                        bq_bf16x4 o, og;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // gamma and beta reach the modulation kernel of the two-step path as bf16: round them the same way
+                            const float gr = (float)(__bf16)g[k], br = (float)(__bf16)bt[k];
+                            og[k] = (__bf16)g[k];
+                            o[k] = (__bf16)(((float)zq[q][k] - m_[k]) * r_[k] * (1.f + gr) + br);
+                        }
+                        if (p.wide) { pko[q] = __builtin_bit_cast(bq_u32x2, o); pkg[q] = __builtin_bit_cast(bq_u32x2, og); }
+                        else if (pos_ok && ch < p.C) { *reinterpret_cast<bq_bf16x4*>(mixp + ch) = o; *reinterpret_cast<bq_bf16x4*>(gamp + ch) = og; }
+                    }
+                    if (p.wide) {
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const bq_u32x4 wo_ = bq_pair8(pko[q], pko[q + 1]), wg = bq_pair8(pkg[q], pkg[q + 1]);
+                            const int ch = c0 + 8 * (q + half);
+                            if (pos_ok && ch < p.C) { *reinterpret_cast<bq_u32x4*>(mixp + ch) = wo_; *reinterpret_cast<bq_u32x4*>(gamp + ch) = wg; }
+                        }
+                    }
+                } else {
+                    __bf16* dst = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout;
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) {
+                        bq_u32x2 pk[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int co = co0 + 32 * j + 8 * q + 4 * half;
+                            const float4 bb = *reinterpret_cast<const float4*>(Bs + (co < Q_BIAS - 3 ? co : 0));
+                            float v[4] = {acc[r][j][4 * q] + bb.x, acc[r][j][4 * q + 1] + bb.y, acc[r][j][4 * q + 2] + bb.z, acc[r][j][4 * q + 3] + bb.w};
+                            if (p.lrelu) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+                            }
+                            bq_bf16x4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                            if (p.wide) pk[q] = __builtin_bit_cast(bq_u32x2, o);
+                            else if (pos_ok && co < p.Cout) *reinterpret_cast<bq_bf16x4*>(dst + co) = o;
+                        }
+                        if (p.wide) {
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2) {
+                                const bq_u32x4 w8 = bq_pair8(pk[q], pk[q + 1]);
+                                const int co = co0 + 32 * j + 8 * (q + half);          // this lane's eight consecutive couts
+                                if (pos_ok && co < p.Cout) *reinterpret_cast<bq_u32x4*>(dst + co) = w8;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < WC; ++j)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[r][j][k] = 0.f;
+            }
+        }
+    };
+    for (int i = 0; i < total; i += 2) {
+        iteration(QIC<0>{});
+        if (i + 1 < total) iteration(QIC<1>{});
+    }
+}
+
+namespace {
+int q_ncu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)bconv4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+size_t q_lds(int WC) { return 2 * (size_t)(9 * 32 * WC * 64) + 2 * (size_t)Q_XBYTES + sizeof(float) * Q_BIAS; }
+}  // namespace
+
+// MRDIS_EUNSUPPORTED: the caller (mrdis_run_bconv) takes bconv3_kernel / bconv_kernel
+int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
+    if (!mrdis_opt(MRDIS_OPT_BCONV4)) return MRDIS_EUNSUPPORTED;
+    if (t.dtype != MRDIS_DT_BF16 || !t.w_bf16 || t.ntaps != 9 || t.is != 1 || t.os != 1 || t.oh0 != 0 || t.ow0 != 0) return MRDIS_EUNSUPPORTED;
+    if (t.A != t.Hin || t.B != t.Win || t.Hout != t.Hin || t.Wout != t.Win) return MRDIS_EUNSUPPORTED;
+    if (t.Cin % 32 != 0 || t.Cout % 4 != 0 || t.Cout < 16 || t.Cout > Q_BIAS || t.Win < 32 || t.Hin < 8 || t.ldin % 8 != 0 || t.ldout % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if ((((uintptr_t)t.in | (uintptr_t)t.w_bf16) & 15) != 0 || ((uintptr_t)t.out & 7) != 0) return MRDIS_EUNSUPPORTED;
+    BConv4Params p{};
+    int wt = 0;
+    for (int k = 0; k < 9; ++k) {
+        if (t.dh[k] < -1 || t.dh[k] > 1 || t.dw[k] < -1 || t.dw[k] > 1) return MRDIS_EUNSUPPORTED;
+        p.dh[k] = t.dh[k]; p.dw[k] = t.dw[k]; p.widx[k] = t.widx[k];
+        if (t.widx[k] + 1 > wt) wt = t.widx[k] + 1;
+    }
+    const long long in_b = 2LL * (((long long)t.N * t.Hin * t.Win - 1) * t.ldin + t.Cin), w_b = 2LL * wt * t.Cin * t.Cout;
+    if (in_b >= 0xffffffe0LL || w_b >= 0xffffffe0LL) return MRDIS_EUNSUPPORTED;
+    p.in = t.in; p.w = t.w_bf16; p.bias = t.bias; p.out = t.out;
+    p.N = t.N; p.H = t.Hin; p.W = t.Win; p.Cin = t.Cin; p.ldin = t.ldin; p.Cout = t.Cout; p.ldout = t.ldout;
+    p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
+    const int WC = t.Cout > 32 ? 2 : 1, BN = 32 * WC;
+    p.tilesA = mrdis_cdiv(t.Hin, Q_TH); p.tilesB = mrdis_cdiv(t.Win, Q_TW); p.coTiles = mrdis_cdiv(t.Cout, BN);
+    const long long units = (long long)t.N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    const int n_cu = q_ncu();
+    if (n_cu < 0) return n_cu == -1 ? MRDIS_ELAUNCH : MRDIS_EUNSUPPORTED;
+    // the 512-position tile needs the launch to fill the chip: below one unit per CU the 256-position tiles of bconv3_kernel spread the layer over twice the CUs
+    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < n_cu) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = t.Cin / Q_KC; p.lrelu = (t.epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    p.wide = (t.Cout % 8 == 0 && t.ldout % 8 == 0 && ((uintptr_t)t.out & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
+    const int grid = units < n_cu ? (int)units : n_cu;
+    mrdis_count(MRDIS_CNT_BCONV4);
+#ifdef BCONV4_ABLATIONS
+    if (WC == 2) {
+        const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
+#define QA(a) if (abl == a) { (void)hipFuncSetAttribute((const void*)bconv4_kernel<2, false, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((bconv4_kernel<2, false, a>), dim3(grid), dim3(512), q_lds(2), s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        QA(1) QA(2) QA(4) QA(8) QA(6) QA(10) QA(14) QA(7) QA(15)
+#undef QA
+    }
+#endif
+    if (WC == 2) hipLaunchKernelGGL(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2), s, p);
+    else hipLaunchKernelGGL(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1), s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// SPADE-fused form (see mrdis_run_bconv3_spade, whose contract this keeps).  MRDIS_EUNSUPPORTED: the caller takes bconv3_kernel<2, 0, true>.
+int mrdis_run_bconv4_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
+                           void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s) {
+    if (!mrdis_opt(MRDIS_OPT_BCONV4) || !mrdis_opt(MRDIS_OPT_WINO_PIPE) || Ci % 32 != 0 || C % 4 != 0 || C < 16 || 2 * C > Q_BIAS || W < 32 || H < 8) return MRDIS_EUNSUPPORTED;
+    if (ldx % 8 != 0 || ldz % 4 != 0 || ldmix % 4 != 0 || ldg % 4 != 0) return MRDIS_EUNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)w_bf16) | ((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) != 0 || ((((uintptr_t)z) | ((uintptr_t)mix) | ((uintptr_t)gamma)) & 7) != 0) return MRDIS_EUNSUPPORTED;
+    BConv4Params p{};
+    for (int k = 0; k < 9; ++k) { p.dh[k] = k / 3 - 1; p.dw[k] = k % 3 - 1; p.widx[k] = k; }
+    const long long in_b = 2LL * (((long long)N * H * W - 1) * ldx + Ci), w_b = 2LL * 9 * Ci * 2 * C;
+    if (in_b >= 0xffffffe0LL || w_b >= 0xffffffe0LL) return MRDIS_EUNSUPPORTED;
+    p.in = x; p.w = w_bf16; p.bias = bias; p.out = mix;
+    p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
+    p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
+    p.tilesA = mrdis_cdiv(H, Q_TH); p.tilesB = mrdis_cdiv(W, Q_TW); p.coTiles = mrdis_cdiv(C, 32);
+    const long long units = (long long)N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    const int n_cu = q_ncu();
+    if (n_cu < 0) return n_cu == -1 ? MRDIS_ELAUNCH : MRDIS_EUNSUPPORTED;
+    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < n_cu) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = Ci / Q_KC; p.lrelu = 0;
+    p.wide = (C % 8 == 0 && ldmix % 8 == 0 && ldg % 8 == 0 && ((((uintptr_t)mix) | ((uintptr_t)gamma)) & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
+    const int grid = units < n_cu ? (int)units : n_cu;
+    mrdis_count(MRDIS_CNT_BCONV4_SPADE);
+    hipLaunchKernelGGL((bconv4_kernel<2, true>), dim3(grid), dim3(512), q_lds(2), s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}

@@ -16,7 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Process-wide switches.  Each is read from its environment variable ONCE (first use) and afterwards only changes through
 // mrdis_set_option(): no getenv() on the launch path.  Boolean debug switches: variable present = 1.  Value switches: -1 = unset.
 enum {
-    MRDIS_OPT_WINO, MRDIS_OPT_NT_MB, MRDIS_OPT_WINO_PIPE, MRDIS_OPT_WINO_U, MRDIS_OPT_WINO4, MRDIS_OPT_WINO4R,
+    MRDIS_OPT_WINO, MRDIS_OPT_NT_MB, MRDIS_OPT_WINO_PIPE, MRDIS_OPT_WINO_U, MRDIS_OPT_WINO4, MRDIS_OPT_WINO4R, MRDIS_OPT_BCONV4,
     MRDIS_OPT_NO16, MRDIS_OPT_NOTHIN, MRDIS_OPT_NOC4, MRDIS_OPT_NODMA, MRDIS_OPT_NO16_3D, MRDIS_OPT_BILGEN, MRDIS_OPT_NOW16, MRDIS_OPT_NOPACK,
     MRDIS_OPT_MODE, MRDIS_OPT_BN, MRDIS_OPT_KC, MRDIS_OPT_BM, MRDIS_OPT_C4_TW, MRDIS_OPT_WGSPLIT, MRDIS_OPT_BN3, MRDIS_OPT_KC3,
     MRDIS_OPT_COUNT
@@ -26,7 +26,7 @@ long long mrdis_opt(int id);      // mrdis_elem.hip
 // Launch counters of the Winograd kernel families (host side, one increment per launch): what a test asks to know which form actually ran
 // (mrdis_launch_count("wino4") ...; mrdis_elem.hip).
 enum { MRDIS_CNT_WINO, MRDIS_CNT_WINO_SPADE, MRDIS_CNT_WINO2, MRDIS_CNT_WINO2_SPADE, MRDIS_CNT_WINO4, MRDIS_CNT_WINO4_SPADE, MRDIS_CNT_WINO4N, MRDIS_CNT_WINO4R,
-       MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_COUNT };
+       MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_BCONV3, MRDIS_CNT_BCONV3_SPADE, MRDIS_CNT_BCONV4, MRDIS_CNT_BCONV4_SPADE, MRDIS_CNT_COUNT };
 void mrdis_count(int id);
 
 static inline int mrdis_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

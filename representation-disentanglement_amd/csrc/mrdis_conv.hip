@@ -1243,12 +1243,16 @@ int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* 
                           float* mix, int ldmix, float* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s, const float* u_img);
 int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
                            void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
+int mrdis_run_bconv4_spade(const void* x, int ldx, const void* w_bf16, const float* bias, const void* z, int ldz, const float* mean, const float* rstd,
+                           void* mix, int ldmix, void* gamma, int ldg, int N, int H, int W, int Ci, int C, hipStream_t s);
 extern "C" int mrdis_conv2d_fwd_spade(const void* x, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias, const void* z, int ldz,
                                       const float* mean, const float* rstd, void* mix, int ldmix, void* gamma, int ldg,
                                       int N, int H, int W, int Ci, int C, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (!x || !bias || !z || !mean || !rstd || !mix || !gamma || N < 1 || H < 1 || W < 1 || Ci < 1 || C < 1) return MRDIS_EINVAL;
     if (dtype == MRDIS_DT_BF16) {
         if (!w_bf16_tkc) return MRDIS_EINVAL;
+        const int rc4 = mrdis_run_bconv4_spade(x, ldx, w_bf16_tkc, bias, z, ldz, mean, rstd, mix, ldmix, gamma, ldg, N, H, W, Ci, C, (hipStream_t)stream);
+        if (rc4 != MRDIS_EUNSUPPORTED) return rc4;
         return mrdis_run_bconv3_spade(x, ldx, w_bf16_tkc, bias, z, ldz, mean, rstd, mix, ldmix, gamma, ldg, N, H, W, Ci, C, (hipStream_t)stream);
     }
     if (dtype != MRDIS_DT_F32 || !w_tck) return dtype == MRDIS_DT_F32 ? MRDIS_EINVAL : MRDIS_EUNSUPPORTED;

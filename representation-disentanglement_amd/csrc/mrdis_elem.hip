@@ -561,8 +561,12 @@ static int instnorm_spade_bwd_impl(const T* dout, int lddo, const T* z, int ldz,
 // stat_final_kernel<1> reads), and spade_bwd_up2_final_kernel finishes d x in place from A, the sums and the 3 x 3 stencil U^T U of the LOW-resolution x:
 // dout and gamma are read once instead of twice, z never (0.7 GB less per full-resolution block at B = 32).
 constexpr int UB_T = 8, UB_R = 2 * UB_T + 2, UB_CC = 32;
-template <typename T, bool ONEPASS = false>
-__global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
+// NT threads per workgroup (256 | 512): the two LDS tiles (54 KB) allow two workgroups per CU either way, so 512 threads double the waves that hide the
+// latency of phase 1's streaming loads; those loads (dout, gamma of every pixel a thread visits: <= UB_IT<NT> pixels) are ALL issued before the first is
+// used (coordinates clamped, a flag instead of a branch), so a thread has 2 x UB_IT 16-byte (fp32) loads in flight instead of 2.
+template <int NT> struct UB_IT { static constexpr int value = (UB_R * UB_R + NT / 8 - 1) / (NT / 8); };      // pixels per thread at 8 channel quads (fewer quads: fewer pixels)
+template <typename T, bool ONEPASS = false, int NT = 256, bool XLO = true>
+__global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ z, int ldz, const T* __restrict__ g, int ldg,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
                                                             T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x,
@@ -580,7 +584,23 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
     const long long img = (long long)n * Ho * Wo;
     const int tid = threadIdx.x;
     // ---- phase 1: dz (and d gamma, d beta) of the full-resolution pixels (2 i0 - 1 + ry, 2 j0 - 1 + rx), ry, rx < 18
-    const int q1 = tid % Q, p1 = tid / Q, pstep = 256 / Q;                            // host: 256 % Q == 0
+    const int q1 = tid % Q, p1 = tid / Q, pstep = NT / Q;                             // host: NT % Q == 0
+    constexpr int MAXIT = UB_IT<NT>::value;
+    const int c = c0 + 4 * q1;
+    // all streaming loads of this thread first (a pixel outside the image / past the tile: the image's pixel 0, flagged off)
+    Vec<4> dv[MAXIT], gv[MAXIT], zv[XLO ? 1 : MAXIT];
+    long long pixv[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int px = p1 + it * pstep;
+        const int ry = px / UB_R, rx = px - ry * UB_R;
+        const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
+        const bool ok = px < UB_R * UB_R && (unsigned)h < (unsigned)Ho && (unsigned)w_ < (unsigned)Wo;
+        pixv[it] = ok ? img + (long long)h * Wo + w_ : -1;
+        const long long pix = ok ? pixv[it] : img;
+        dv[it].load(dout + pix * lddo + c); gv[it].load(g + pix * ldg + c);
+        if (!XLO) zv[it].load(z + pix * ldz + c);
+    }
     float mu[4], rs[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -588,7 +608,7 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
         a0[k] = ONEPASS ? 0.f : s0[si] * inv; a1[k] = ONEPASS ? 0.f : s1[si] * inv;
     }
     float ps0[4] = {0.f, 0.f, 0.f, 0.f}, ps1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (xlo != nullptr) {
+    if (XLO) {
         for (int px = p1; px < (UB_T + 2) * (UB_T + 2); px += pstep) {
             const int ly = px / (UB_T + 2), lx = px - ly * (UB_T + 2);
             int i = i0 - 1 + ly, j = j0 - 1 + lx;
@@ -597,14 +617,16 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
         }
         __syncthreads();
     }
-    for (int px = p1; px < UB_R * UB_R; px += pstep) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int px = p1 + it * pstep;
+        if (pixv[it] < 0) continue;
         const int ry = px / UB_R, rx = px - ry * UB_R;
         const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
-        if ((unsigned)h >= (unsigned)Ho || (unsigned)w_ >= (unsigned)Wo) continue;
-        const long long pix = img + (long long)h * Wo + w_;
-        const int c = c0 + 4 * q1;
-        Vec<4> d, zz, gg, og; d.load(dout + pix * lddo + c); gg.load(g + pix * ldg + c);
-        if (xlo != nullptr) {
+        const long long pix = pixv[it];
+        const Vec<4>& d = dv[it]; const Vec<4>& gg = gv[it];
+        Vec<4> zz, og;
+        if (XLO) {
             // (h, w) -> low-resolution rows / columns and weights as up2_value; tile coordinates = low-resolution index - (i0 - 1), clamped rows are copies
             const int i = h >> 1, j = w_ >> 1;
             int r0, r1, q0_, q1_; float A0, A1, B0, B1;
@@ -620,7 +642,7 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
             const float* a_ = &p00.x; const float* b_ = &p01.x; const float* c_ = &p10.x; const float* d_ = &p11.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) zz.v[k] = (float)(T)(A0 * (B0 * a_[k] + B1 * b_[k]) + A1 * (B0 * c_[k] + B1 * d_[k]));
-        } else zz.load(z + pix * ldz + c);
+        } else zz = zv[XLO ? 0 : it];
         float4 dz;
         float* dzp = &dz.x;
 #pragma unroll
@@ -642,21 +664,21 @@ __global__ __launch_bounds__(256) void spade_bwd_up2_kernel(const T* __restrict_
     }
     if (ONEPASS) {
         // the 64 / Q lanes of a wave that share a channel quad (lane % Q: Q divides 64) are added by a butterfly of fixed shape, each wave writes its own `part` chunk
-        // (chunk = 4 tile + wave): no LDS round trip, no extra barrier; bit-reproducible
+        // (chunk = (NT / 64) tile + wave): no LDS round trip, no extra barrier; bit-reproducible
         const int lane = tid & 63, wv = tid >> 6;
         for (int o = Q; o < 64; o <<= 1) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { ps0[k] += __shfl_xor(ps0[k], o, 64); ps1[k] += __shfl_xor(ps1[k], o, 64); }
         }
         if (lane < Q) {
-            float* dst = part + ((long long)((n * (int)gridDim.x + (int)blockIdx.x) * 4 + wv) * 2) * C + c0;      // group = image n, chunk = 4 tile + wave
+            float* dst = part + ((long long)((n * (int)gridDim.x + (int)blockIdx.x) * (NT / 64) + wv) * 2) * C + c0;      // group = image n, chunk = (NT / 64) tile + wave
 #pragma unroll
             for (int k = 0; k < 4; ++k) { dst[4 * lane + k] = ps0[k]; dst[C + 4 * lane + k] = ps1[k]; }
         }
     }
     __syncthreads();
     // ---- phase 2: the resize's adjoint from LDS
-    for (int it = tid; it < UB_T * UB_T * Q; it += 256) {
+    for (int it = tid; it < UB_T * UB_T * Q; it += NT) {
         const int q = it % Q, lp = it / Q, li = lp / UB_T, lj = lp - li * UB_T;
         const int i = i0 + li, j = j0 + lj;
         if (i >= Hi || j >= Wi) continue;
@@ -751,7 +773,7 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     if (workspace_bytes < need) return MRDIS_EWORKSPACE;
     const bool v = vec4_ok(dout, lddo, C) && (xlo ? vec4_ok(xlo, ldxlo, C) : vec4_ok(z, ldz, C)) && vec4_ok(gamma, ldg, C) && vec4_ok(dx, lddx, C) &&
                    vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
-    // channel chunks of 32: the last one may be narrower; 256 threads split as (pixel, quad) need 256 % quads == 0: quads in {1, 2, 4, 8}
+    // channel chunks of 32: the last one may be narrower; the threads split as (pixel, quad) need NT % quads == 0: quads in {1, 2, 4, 8}
     const int lastq = ((C - 1) % UB_CC + 1) / 4;
     if (!v || N > 65535 || C > 65535 * UB_CC || (lastq & (lastq - 1)) != 0) return MRDIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -760,17 +782,22 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
         // one pass over the full-resolution tensors (see spade_bwd_up2_kernel ONEPASS): needs x itself and room for one partial pair per (image, tile, channel);
         // bf16 maps: A = U^T dzh goes through an fp32 buffer (rounding it to bf16 before the subtraction of the mean terms would cost the result's leading bits)
         constexpr bool f32 = std::is_same<T, float>::value;
-        const size_t p1bytes = sizeof(float) * 2 * (size_t)N * 4 * tiles_x * tiles_y * C + 64;
+        const int NW = mrdis_opt(MRDIS_OPT_MODE) == 2002 ? 4 : 8;         // waves per workgroup (debug_mode 2002: the 256-thread form, for A/B)
+        const size_t p1bytes = sizeof(float) * 2 * (size_t)N * NW * tiles_x * tiles_y * C + 64;
         const size_t abytes = f32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C;
         if (xlo && workspace_bytes >= p1bytes + sizeof(float) * 2 * (size_t)N * C + abytes && mrdis_opt(MRDIS_OPT_MODE) != 2001) {
             float* part1 = reinterpret_cast<float*>(workspace);
             float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p1bytes);
             float* t1 = t0 + (size_t)N * C;
             float* abuf = f32 ? nullptr : t1 + (size_t)N * C;
-            hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
-                               save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
+            if (NW == 8)       // (reading a stored z instead of interpolating it from xlo was measured level to slower: the kernel is not bound by the interpolation)
+                hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                                   save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
+            else
+                hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true, 256, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                                   save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
             MRDIS_CHECK_LAUNCH();
-            const int chunks = 4 * tiles_x * tiles_y;
+            const int chunks = NW * tiles_x * tiles_y;
             hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
             MRDIS_CHECK_LAUNCH();
             hipLaunchKernelGGL((spade_bwd_up2_final_kernel<T>), dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C, abuf);
@@ -786,8 +813,12 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     const StatPlan sp = stat_plan(N, HW);
     hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((spade_bwd_up2_kernel<T>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
-                       dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
+    if (xlo)
+        hipLaunchKernelGGL((spade_bwd_up2_kernel<T, false, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
+                           dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
+    else
+        hipLaunchKernelGGL((spade_bwd_up2_kernel<T, false, 512, false>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
+                           dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -796,7 +827,7 @@ extern "C" size_t mrdis_instnorm_spade_bwd_workspace(int N, long long HW, int C)
 }
 extern "C" size_t mrdis_instnorm_spade_bwd_up2_workspace(int N, int Hi, int Wi, int C, int dtype) {
     const size_t two_pass = mrdis_instnorm_spade_bwd_workspace(N, 4LL * Hi * Wi, C);
-    const size_t one_pass = sizeof(float) * 2 * (size_t)N * 4 * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C +
+    const size_t one_pass = sizeof(float) * 2 * (size_t)N * 8 * mrdis_cdiv(Wi, UB_T) * mrdis_cdiv(Hi, UB_T) * C + 64 + sizeof(float) * 2 * (size_t)N * C +
                             (dtype == MRDIS_DT_F32 ? 0 : sizeof(float) * (size_t)N * Hi * Wi * C);
     return one_pass > two_pass ? one_pass : two_pass;
 }
@@ -1846,6 +1877,7 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"wino_u", "MRDIS_WINO_U", 0, 1},        // 1: the pipelined kernel reads a pre-transformed filter image when the caller passes one | 0: always transforms the taps itself
     {"wino4", "MRDIS_WINO4", 0, 1},          // 1: F(4x4, 3x3) (mrdis_wino4.hip) for the filters mrdis_wino_u_format() names, where the grid fills the chip | 0: never | 2: wherever the kernel applies
     {"wino4r", "MRDIS_WINO4R", 0, 1},        // <= 32 couts: 1: the register-fed F(4x4, 3x3) form (mrdis_wino4r.hip) for <= 64 reduction channels and inputs beyond the Infinity Cache | 0: the shared-transform form | 2 / 3: always its 64-tile / channel-split form
+    {"bconv4", "MRDIS_BCONV4", 0, 1},        // bf16 3x3 stride-1 layers: 1: the LDS-DMA kernel (mrdis_bf16q.hip) where the launch fills the chip | 0: bconv3_kernel (mrdis_bf16p.hip) | 2: wherever it applies
     {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
     {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
     {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},
@@ -1886,7 +1918,7 @@ extern "C" long long mrdis_get_option(const char* name) {
 
 namespace {
 const char* const CNT_NAMES[MRDIS_CNT_COUNT] = {"wino", "wino_spade", "wino2", "wino2_spade", "wino4", "wino4_spade", "wino4n", "wino4r",
-                                                "wino_wgrad", "wino_wgrad2", "wino4_wgrad"};
+                                                "wino_wgrad", "wino_wgrad2", "wino4_wgrad", "bconv3", "bconv3_spade", "bconv4", "bconv4_spade"};
 long long g_counts[MRDIS_CNT_COUNT];
 }  // namespace
 void mrdis_count(int id) { __atomic_fetch_add(&g_counts[id], 1LL, __ATOMIC_RELAXED); }

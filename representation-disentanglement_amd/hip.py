@@ -135,7 +135,7 @@ def get_option(name):
     return int(load().mrdis_get_option(name.encode()))
 
 
-WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad')
+KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade')
 
 
 def launch_counts(reset=False):

@@ -164,6 +164,67 @@ def test_bf16_pipelined_conv_bit_identical(mrdis, case):
     close(out[1][0].float(), ref, rtol=1.5e-2, what='bf16 pipelined fwd vs torch on bf16-rounded operands')
 
 
+BCONV4_CASES = [(2, 32, 64, 23, 37), (3, 64, 40, 50, 33), (1, 96, 16, 9, 70), (6, 128, 256, 64, 64), (2, 64, 32, 40, 96), (5, 32, 72, 16, 32), (1, 64, 128, 130, 67),
+                (9, 32, 16, 48, 64)]
+
+
+@pytest.mark.parametrize('case', BCONV4_CASES, ids=str)
+def test_bf16_lds_dma_conv_bit_identical(mrdis, case):
+    """bconv4_kernel (mrdis_bf16q.hip: operand images by LDS-DMA into swizzled 64-byte rows, 16 x 32 tiles, a wave = 64 positions x 64 couts; option bconv4 = 2:
+    wherever it applies) against bconv3_kernel (bconv4 = 0): the same products in the same order, so forward (+ bias, LeakyReLU) and data gradient are
+    BIT-IDENTICAL -- ragged tiles in both directions, maps of a single tile row, cout tails (40, 72), <= 32 couts (the 32-cout instantiation), several
+    units and chunks per workgroup; and agree with torch on the bf16-rounded operands.  hip.launch_counts() proves which kernel ran."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    B16 = torch.bfloat16
+    x = rnd((N, Ci, H, W), 1); w = rnd((Co, Ci, 3, 3), 2, 0.2); b = rnd((Co,), 3, 0.1); gy = rnd((N, Co, H, W), 4)
+    xb, gyb = cl(x).to(B16), cl(gy).to(B16)
+    w_tck, w_tkc = to_tck(w).to(dev()), to_tkc(w).to(dev())
+    wb_f, wb_b = hip.cast_bf16(w_tkc), hip.cast_bf16(w_tck)
+    out = {}
+    for mode in (0, 2):
+        hip.set_option('bconv4', mode)
+        hip.launch_counts(reset=True)
+        y = hip.conv2d_fwd(xb, w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f)
+        y0 = hip.conv2d_fwd(xb, w_tck, None, 3, 3, 1, 1, w_bf16=wb_f)
+        g = hip.conv2d_bwd_data(gyb, w_tkc, (H, W), 3, 3, 1, 1, w_bf16=wb_b) if Co % 32 == 0 else None
+        c = hip.launch_counts()
+        assert (c['bconv4'] > 0) == (mode == 2) and (c['bconv3'] > 0) == (mode == 0), (mode, c)
+        out[mode] = (y, y0, g)
+    assert out[2][0].dtype == B16 and torch.equal(out[0][0], out[2][0]) and torch.equal(out[0][1], out[2][1])
+    if out[2][2] is not None:
+        assert torch.equal(out[0][2], out[2][2])
+    ref = F.leaky_relu(F.conv2d(x.to(B16).float(), w.to(B16).float(), b, 1, 1), 0.2)
+    close(out[2][0].float(), ref, rtol=1.5e-2, what='bf16 LDS-DMA fwd vs torch on bf16-rounded operands')
+    # a channel-slice input view (ld > Cin) whose last pixel ends exactly at the descriptor's record count, and an output slice of a wider buffer
+    if Co % 8 == 0:
+        hip.set_option('bconv4', 2)
+        wide_in = cl(torch.cat([rnd((N, 8, H, W), 9), x], 1)).to(B16)
+        wide_out = hip.empty_nhwc(N, Co + 8, H, W, dev(), B16); wide_out.zero_()
+        hip.conv2d_fwd(wide_in[:, 8:], w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f, out=wide_out[:, 8:])
+        assert torch.equal(wide_out[:, 8:], out[0][0]) and float(wide_out[:, :8].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case', [(8, 32, 32, 64, 96), (3, 64, 64, 50, 72), (5, 128, 128, 33, 47), (2, 32, 48, 64, 80), (4, 32, 16, 16, 32)], ids=str)
+def test_gb_spade_fused_epilogue_bf16_lds_dma(mrdis, case):
+    """the SPADE-fused form of bconv4_kernel against bconv3_kernel<2, 0, true>: mix and gamma bit-identical (ragged tiles, a channel count that is not a multiple of 32)."""
+    N, Ci, C, H, W = case
+    hip = mrdis.hip
+    x = cl(rnd((N, Ci, H, W), 1)).to(torch.bfloat16); z = cl(rnd((N, C, H, W), 2)).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last); z = z.contiguous(memory_format=torch.channels_last)
+    w = rnd((2 * C, Ci, 3, 3), 3, 0.2); b = rnd((2 * C,), 4, 0.1).to(dev())
+    w_tck = to_tck(w).to(dev()); wb = hip.cast_bf16(to_tkc(w).to(dev()))
+    res = {}
+    for mode in (0, 2):
+        hip.set_option('bconv4', mode)
+        hip.launch_counts(reset=True)
+        res[mode] = hip.gb_spade_fwd(x, w_tck, b, z, 1e-5, w_bf16=wb)
+        c = hip.launch_counts()
+        assert res[mode] is not None and (c['bconv4_spade'] > 0) == (mode == 2) and (c['bconv3_spade'] > 0) == (mode == 0), (mode, c)
+    for a, b_ in zip(res[0], res[2]):
+        assert torch.equal(a, b_)
+
+
 def test_to_device_mailbox_ring(mrdis):
     """ops.to_device for small tensors: pinned ring slot + copy kernel (no copy engine).  More transfers than ring slots, mixed dtypes
     and sizes, all checked only at the end (the GPU consumes the slots while the host keeps refilling them)."""

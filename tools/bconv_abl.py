@@ -6,6 +6,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mrdis  # noqa: E402
+
+mrdis.hip.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ab', 'libmrdis_abl_bf16.so'))   # tools/build_abl.sh
 from tools.wino2_check import timeit  # noqa: E402
 
 hip = mrdis.hip

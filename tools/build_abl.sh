@@ -10,3 +10,7 @@ for f in mrdis_wino4 mrdis_wino4r mrdis_wino4w; do
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl.so $(ls *.o | grep -v "mrdis_wino4.o\|mrdis_wino4r.o\|mrdis_wino4w.o") ../../ab/mrdis_wino4_abl.o ../../ab/mrdis_wino4r_abl.o ../../ab/mrdis_wino4w_abl.o
 ls -la ../../ab/libmrdis_abl.so
+# ab/libmrdis_abl_bf16.so: the pipelined bf16 convolution built -DBCONV3_ABLATIONS (tools/bconv_abl.py)
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DBCONV3_ABLATIONS -c -o ../../ab/mrdis_bf16p_abl.o mrdis_bf16p.hip
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DBCONV4_ABLATIONS -c -o ../../ab/mrdis_bf16q_abl.o mrdis_bf16q.hip
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl_bf16.so $(ls *.o | grep -v "mrdis_bf16p.o\|mrdis_bf16q.o") ../../ab/mrdis_bf16p_abl.o ../../ab/mrdis_bf16q_abl.o
