@@ -90,7 +90,10 @@ class SliceDataset:
     def __len__(self):
         return len(self.subj_list)
 
-    def meta(self, idx):
+    def meta(self, idx, rng=None):
+        """rng: where the drop-off draws come from -- None = the global np.random (the reference's own stream, util.py:538-542: single-process runs reproduce
+        it draw for draw), or a np.random.RandomState of the loader's own (data-parallel runs, see BatchLoader)."""
+        rng = np.random if rng is None else rng
         subj_id = str(self.subj_list[idx])
         s = int(self.idx_list[idx])
         b = self.block_size
@@ -107,8 +110,8 @@ class SliceDataset:
         mask = np.array([1 if p else 0 for p in ptrs])
         drop = -1
         if self.dropoff and mask.sum() > 1:                           # :538-542, same RNG call order
-            if np.random.rand() > 0.8:
-                drop = int(np.random.choice(np.where(mask == 1)[0], 1)[0])
+            if rng.rand() > 0.8:
+                drop = int(rng.choice(np.where(mask == 1)[0], 1)[0])
         target_key = {'ZeroDose': '/PET', 'BraTS': '/seg', 'Tau': '/pet_nifti/fulldose'}.get(self.dataset_name)
         tptr = self.store.ptr(subj_id + target_key) if target_key else 0
         return subj_id, s, ptrs, drop, tptr
@@ -120,8 +123,15 @@ class BatchLoader:
     subj_id (list), slice_idx (B,).
 
     Data parallel (`world` > 1; the reference is single-device, main_missing.py:28): every rank walks the SAME batch sequence
-    -- the permutation and the per-item drop-off draws of ALL batches are made on every rank, in the single-process order, so
-    the host generators stay in step across the ranks -- and rank r assembles batches r, r + world, r + 2 world, ...
+    -- the permutation and the per-item drop-off draws of ALL batches are made on every rank -- and rank r assembles batches
+    r, r + world, r + 2 world, ...  The drop-off draws then come from a np.random.RandomState OF THE LOADER (seeded once, from the
+    global np.random at the first epoch: identical on every rank because the entry point seeds every rank alike), not from the global
+    np.random: the model draws from the global stream inside every training step (the sim_s / adversarial pair picks, model.py:3487,
+    :3567), and a rank consumes the metas of `world` batches between two steps, so on the shared stream the masks of batch k would
+    depend on the rank and on `world`.  With the loader's own stream every rank sees the same masks for batch k and the global stream
+    carries only the model's draws (identical on every rank).  world == 1 keeps the reference's single stream, draw for draw
+    (tests/golden/data_b4.npz).  `limit` (batches(limit)): stop after that many GLOBAL batches on every rank -- the reference's
+    evaluation loop breaks after batch 501 (main_missing.py:562-563); no meta of a later batch is drawn on any rank.
     `equal_steps` (the train loader): the ragged tail is dropped -- incomplete batches, then whole batches beyond the last full
     round of `world` -- so every rank runs the same number of optimizer steps on full batches (the gradient exchange is a
     collective; BatchNorm and the roll-by-one negatives of sim_s / sim_z want B >= 2 on every rank).  Without it (val / test
@@ -134,6 +144,7 @@ class BatchLoader:
             raise ValueError(f'rank {rank} outside world {world}')
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.rank, self.world, self.equal_steps, self.generator = rank, world, equal_steps, generator
+        self._drop_rng = None                          # world > 1: the loader's own drop-off stream (see the class docstring)
 
     def global_batches(self):
         """number of batches all ranks walk together per epoch."""
@@ -158,22 +169,31 @@ class BatchLoader:
         g.manual_seed(seed)
         return torch.randperm(n, generator=g).tolist()
 
-    def batch_plan(self):
-        """host half of an epoch: yields (global batch index, dataset indices, item metas) of THIS rank's batches."""
+    def batch_plan(self, limit=None):
+        """host half of an epoch: yields (global batch index, dataset indices, item metas) of THIS rank's batches (of the first `limit` global batches)."""
         order = self._order()
         ds = self.dataset
-        for k in range(self.global_batches()):
+        rng = None
+        if self.world > 1:
+            if self._drop_rng is None:
+                self._drop_rng = np.random.RandomState(int(np.random.randint(0, 2 ** 31 - 1)))      # one draw from the (identically seeded) global stream, on every rank
+            rng = self._drop_rng
+        g = self.global_batches()
+        for k in range(g if limit is None else min(g, limit)):
             idxs = order[k * self.batch_size:(k + 1) * self.batch_size]
-            metas = [ds.meta(i) for i in idxs]                        # every rank: the drop-off draws advance np.random for all batches
+            metas = [ds.meta(i, rng) for i in idxs]                   # every rank draws the metas of ALL batches: the streams stay in step
             if k % self.world == self.rank:
                 yield k, idxs, metas
 
     def __iter__(self):
+        return self.batches()
+
+    def batches(self, limit=None):
         ds, st = self.dataset, self.dataset.store
         H, W, D = st.shape
         M, blk = len(ds.contrast_list), ds.block_size
         dev = st.device
-        for k, _, metas in self.batch_plan():
+        for k, _, metas in self.batch_plan(limit):
             B = len(metas)
             host = torch.empty((B, M + 3), dtype=torch.int64).pin_memory() if dev.type == 'cuda' else torch.empty((B, M + 3), dtype=torch.int64)
             mask_host = np.zeros((B, M), dtype=np.float32)                 # host twin of `mask`: the losses branch on it without a sync

@@ -361,7 +361,13 @@ class Run:
         loader = self.loaders['val'] if phase == 'val' else self.loaders[set_]
         cfg = self.config
         acc, n_iter, met = None, 0, {'rmse': [], 'psnr': [], 'ssim': []}
-        for it, sample in enumerate(loader):
+        # the reference stops after global batch 501 (:562-563).  The cap is applied by the loader, on the GLOBAL batch index and before any meta of a later
+        # batch is drawn, so every rank walks the same `max_batches` batches and leaves the host generators in the same state (a cap tested per rank after
+        # the step let world = 8 evaluate up to batch 508 and end the ranks' np.random streams apart)
+        batches = loader.batches(limit=max_batches) if hasattr(loader, 'batches') else loader
+        for it, sample in enumerate(batches):
+            if sample.get('batch_index', it) >= max_batches:
+                break
             targets = sample['targets'] if cfg['lambda_recon_y'] > 0 else None
             loss, parts, metrics, _ = self.eval_step(sample['inputs'], sample['mask'], sample['mask_img'], sample.get('mask_host'), targets=targets)
             vec = torch.stack([parts[k].float().reshape(()) for k in LOSS_KEYS])
@@ -369,10 +375,6 @@ class Run:
             for k in met:
                 met[k].append(metrics[k])
             n_iter += 1
-            if sample.get('batch_index', it) > 500:                         # :562-563 (the loader's own batch count, not this rank's)
-                break
-            if n_iter >= max_batches:
-                break
         # sums and counts over the ranks (a rank may hold one batch fewer than its neighbour, or none): the result is the mean over
         # every batch / every image of the loader, identical on all ranks
         nk = len(LOSS_KEYS)

@@ -53,13 +53,50 @@ def test_train_loader_shards_are_disjoint_equal_and_cover_the_single_process_ord
     seen = [i for s in shards for _, idxs, _ in s for i in idxs]
     assert len(seen) == len(set(seen))                                # disjoint
     merged = sorted((b for s in shards for b in s), key=lambda b: b[0])
-    assert merged == single[:rounds * world]                          # union = the single-process sequence, incl. the drop-off draws
+    assert [(k, idxs) for k, idxs, _ in merged] == [(k, idxs) for k, idxs, _ in single[:rounds * world]]      # union = the single-process batch sequence
+    # the drop-off draws of a data-parallel run come from the loader's own stream (seeded by ONE draw from the identically seeded global stream):
+    # what every rank must see for batch k, computed independently here
+    torch.manual_seed(7); np.random.seed(7)
+    probe = mrdis.data.BatchLoader(ds, bs, shuffle=True, rank=0, world=world, equal_steps=True)
+    order = probe._order()
+    rs = np.random.RandomState(int(np.random.randint(0, 2 ** 31 - 1)))
+    want = [[ds.meta(i, rs)[3] for i in order[k * bs:(k + 1) * bs]] for k in range(rounds * world)]
+    assert [drops for _, _, drops in merged] == want
+    assert any(d >= 0 for drops in want for d in drops)               # the fixture does drop modalities
+    # ... and they do not depend on what the MODEL draws from the global stream between two batches (sim_s / adversarial pair picks, model.py:3487, :3567):
+    # a rank takes the metas of `world` batches between two steps, so on a shared stream its masks would depend on rank and world
+    for r in range(world):
+        torch.manual_seed(7); np.random.seed(7)
+        noisy = []
+        for k, idxs, metas in mrdis.data.BatchLoader(ds, bs, shuffle=True, rank=r, world=world, equal_steps=True).batch_plan():
+            noisy.append((k, idxs, [m[3] for m in metas]))
+            np.random.choice(8, 2, replace=False)                     # the model's draw inside the training step
+        assert noisy == shards[r]
     # the host generators end the epoch in the same state on every rank (next epoch's permutation, the sim_s pair draws)
     states = []
     for r in range(world):
         _epoch(mrdis.data.BatchLoader(ds, bs, shuffle=True, rank=r, world=world, equal_steps=True), 7)
         states.append((float(np.random.rand()), int(torch.empty((), dtype=torch.int64).random_())))
     assert all(s == states[0] for s in states)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_evaluation_cap_is_on_the_global_batch_index(world):
+    """main_missing.py:562-563 stops the evaluation loop after batch 501; under data parallelism every rank must stop at the same GLOBAL batch (a per-rank test
+    after the step let world = 8 run up to batch 508) and leave the host generators in the same state (no meta of a later batch is drawn anywhere)."""
+    import mrdis
+    ds = _dataset(mrdis, n_items=61, dropoff=True)
+    cap = 13
+    seen, states = [], []
+    for r in range(world):
+        torch.manual_seed(5); np.random.seed(5)
+        got = [k for k, _, _ in mrdis.data.BatchLoader(ds, 2, rank=r, world=world).batch_plan(limit=cap)]
+        assert got == list(range(r, cap, world))
+        seen += got
+        states.append(float(np.random.rand()))
+    assert sorted(seen) == list(range(cap)) and all(s == states[0] for s in states)
+    torch.manual_seed(5); np.random.seed(5)
+    assert [k for k, _, _ in mrdis.data.BatchLoader(ds, 2).batch_plan(limit=cap)] == list(range(cap))      # single process: batches 0 .. cap - 1, as the reference
 
 
 def test_eval_loader_serves_every_batch_once():

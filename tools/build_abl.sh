@@ -5,9 +5,11 @@ set -e
 cd "$(dirname "$0")/../representation-disentanglement_amd/csrc"
 make -j8 libmrdis_hip.so > /dev/null
 mkdir -p ../../ab
-for f in mrdis_wino4 mrdis_wino4r mrdis_wino4w; do
+# same code generation flags as the production Makefile: no SLP vectorisation for mrdis_wino4 / mrdis_wino4r only
+for f in mrdis_wino4 mrdis_wino4r; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -Wno-unused-value -Wno-unused-variable -DWINO4_ABLATIONS -c -o ../../ab/${f}_abl.o $f.hip
 done
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DWINO4_ABLATIONS -c -o ../../ab/mrdis_wino4w_abl.o mrdis_wino4w.hip
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl.so $(ls *.o | grep -v "mrdis_wino4.o\|mrdis_wino4r.o\|mrdis_wino4w.o") ../../ab/mrdis_wino4_abl.o ../../ab/mrdis_wino4r_abl.o ../../ab/mrdis_wino4w_abl.o
 ls -la ../../ab/libmrdis_abl.so
 # ab/libmrdis_abl_bf16.so: the pipelined bf16 convolution built -DBCONV3_ABLATIONS (tools/bconv_abl.py)
