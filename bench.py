@@ -57,6 +57,7 @@ def parse():
                          "fp32 accumulate / statistics / master weights / optimizer) | bf16m (bf16 MFMA operands on fp32 activations)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (the stored number is reported instead)')
     ap.add_argument('--no-direct', action='store_true', help='skip the extra direct-kernels-only (wino = 0) timing')
     ap.add_argument('--dry-run', action='store_true', help='launcher rehearsal without a GPU: every rank joins a gloo group and reports in; rank 0 prints the '
                                                            'ranks it heard from (tests/test_bench_launch.py)')
@@ -81,7 +82,54 @@ def _time_conv(hip, xs, w, b, ys, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def roofline_conv(mrdis, dev, iters=24, extras=True):
+def measure_traffic_inrun(timeout_s=240):
+    """HBM bytes per launch of the north-star kernel from the PMC counters, measured IN THIS RUN: two child processes (never an exec: this process has
+    initialised the GPU), `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/northstar_conv.py 12` and the same with WRITE_SIZE (separate passes, the
+    program itself after `--`), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950, both in KiB).  Returns (bytes, provenance), or
+    (None, reason) when rocprofv3 is missing / a pass fails (the caller then reports the stored number of profiles/northstar_conv_pmc.json and says so)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    if os.environ.get('MRDIS_BENCH_NO_PMC'):
+        return None, 'MRDIS_BENCH_NO_PMC set'
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    got = {}
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(prefix='mrdis_pmc_', dir='/tmp') as d:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', counter.lower(), '--',
+                   sys.executable if os.path.basename(sys.executable).startswith('python') else 'python3', os.path.join(ROOT, 'tools', 'northstar_conv.py'), '12']
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            except Exception as ex:                                   # noqa: BLE001 -- a profiler that cannot run must not take the benchmark down
+                return None, f'{counter} pass: {type(ex).__name__}'
+            if r.returncode != 0:
+                return None, f'{counter} pass: rc {r.returncode}: ' + (r.stdout or '')[-160:].replace('\n', ' ')
+            path = None
+            for root_, _, files in os.walk(d):
+                for f in files:
+                    if f.startswith(counter.lower()) and f.endswith('counter_collection.csv'):
+                        path = os.path.join(root_, f)
+            if path is None:
+                return None, f'{counter} pass: no counter_collection.csv'
+            vals = [float(row['Counter_Value']) for row in csv.DictReader(open(path)) if row['Counter_Name'] == counter and 'c4conv' in row['Kernel_Name']]
+            if len(vals) < 8:
+                return None, f'{counter} pass: {len(vals)} north-star launches in the counter file'
+            vals = vals[-12:]                                         # the timed launches (the check / warm-up launches come first)
+            got[counter] = sum(vals) / len(vals)
+    rd, wr = 2.0 * got['FETCH_SIZE'] * 1024.0, got['WRITE_SIZE'] * 1024.0
+    return rd + wr, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of tools/northstar_conv.py, '
+                     f'{time.time() - t0:.0f} s), mean over 12 launches; read = 2 x FETCH_SIZE x 1024 = {rd / 1e6:.1f} MB (gfx950 half-count correction), '
+                     f'write = WRITE_SIZE x 1024 = {wr / 1e6:.1f} MB')
+
+
+def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     """The north-star 3x3 conv forward.  Its output is checked against torch fp32 on the host first.  Timed
     three ways: `achieved` = ROTATING buffers (4 x/y pairs, 1.06 GB > the 256 MiB Infinity Cache, so every launch reads and
     writes HBM), `single_buffer` = one x/y pair re-used (the 236 MB output partly lives in the Infinity Cache between
@@ -113,13 +161,14 @@ def roofline_conv(mrdis, dev, iters=24, extras=True):
     us6 = _time_conv(hip, xs6, w, b, ys6, iters)
     del xs6, ys6
     achieved = NS_BYTES / (us_rot * 1e-6) / 1e9
-    traffic, traffic_src = None, None
+    traffic, traffic_src = measure_traffic_inrun() if pmc_inrun else (None, None)
     pmc = os.path.join(ROOT, 'profiles', 'northstar_conv_pmc.json')
-    if os.path.exists(pmc):
+    if traffic is None and os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic = rec.get('hbm_bytes_per_launch')
-            traffic_src = f"profiles/northstar_conv_pmc.json ({rec.get('tag', 'untagged')}, commit {rec.get('commit', 'n/a')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run"
+            traffic_src = (f"profiles/northstar_conv_pmc.json ({rec.get('tag', 'untagged')}, commit {rec.get('commit', 'n/a')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                           f"passes, STORED -- not measured in this run" + (f' (the in-run passes failed: {traffic_src})' if traffic_src else ''))
         except Exception:
             traffic = None
     gbs = lambda nbytes, us: round(nbytes / (us * 1e-6) / 1e9, 1)
@@ -512,12 +561,13 @@ def main():
         if world == 1 and not a.no_roofline:
             out['host_ms_unblocked'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv)
             log(f'host_ms_unblocked: {out["host_ms_unblocked"]} ms/step')
+        out['dynamic_lds_bytes'] = mrdis.hip.dynamic_lds()         # per kernel family: what rocprofv3's LDS column cannot show (tools/prof_summary.py merges it in)
         if ddp is not None:
             out['ddp'] = ddp
             out['allreduce_wait_ms'] = ddp['allreduce_wait_ms']
             out['bytes_reduced'] = ddp['bytes_reduced_per_step']
         if not a.no_roofline:
-            out['roofline'] = roofline_conv(mrdis, dev)
+            out['roofline'] = roofline_conv(mrdis, dev, pmc_inrun=(world == 1 and not a.no_pmc))
             log(f'roofline: {out["roofline"]}')
             out['roofline_step'] = rstep
             log(f'roofline_step: {rstep}')

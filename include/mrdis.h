@@ -83,6 +83,9 @@ long long mrdis_get_option(const char* name);
  * use it to prove that the form under test is the one that ran. */
 long long mrdis_launch_count(const char* family);
 void mrdis_launch_count_reset(void);
+/* The largest DYNAMIC LDS size each kernel was launched with so far, as "kernel expression=bytes" lines (at most cap - 1 characters); returns the number of
+ * kernels recorded.  rocprofv3's kernel trace only shows the static group segment (0 for the kernels that size their LDS at launch). */
+int mrdis_dynamic_lds_table(char* buf, int cap);
 
 /* ---- expert mixing: model.py:2111-2113 --------------------------------------
  * W   : (E, Co, Ci, kh, kw) checkpoint layout (OIHW with leading expert dim)

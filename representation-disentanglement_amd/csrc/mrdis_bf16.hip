@@ -248,7 +248,7 @@ static int launch_bconv_pack_t(const BConvLaunch (&L)[4], hipStream_t s) {
     BConvPack pk;
     int gx = 0; size_t lds = 0;
     for (int k = 0; k < 4; ++k) { pk.c[k] = L[k].p; pk.g[k] = L[k].g; pk.grid[k] = L[k].grid; if (L[k].grid > gx) gx = L[k].grid; if (L[k].lds > lds) lds = L[k].lds; }
-    hipLaunchKernelGGL((bconv_pack_kernel<KC, WAVES_C, WP, WC, TS>), dim3(gx, 4), dim3(256), lds, s, pk);
+    MRDIS_LAUNCH((bconv_pack_kernel<KC, WAVES_C, WP, WC, TS>), dim3(gx, 4), dim3(256), lds, s, pk);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -265,12 +265,12 @@ static int launch_bconv_t(const TapConvParams& p, const BConvGeom& g, int grid, 
     if (KC == 32 && WP == 2 && WC == 2) {
         const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
 #define BA(a) if (abl == a) { hipFuncSetAttribute((const void*)bconv_kernel<KC, WAVES_C, WP, WC, TS, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
-        hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC, TS, a>), dim3(grid), dim3(256), lds, s, p, g); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        MRDIS_LAUNCH((bconv_kernel<KC, WAVES_C, WP, WC, TS, a>), dim3(grid), dim3(256), lds, s, p, g); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
         BA(1) BA(2) BA(4) BA(8) BA(16) BA(6) BA(14) BA(15) BA(30)
 #undef BA
     }
 #endif
-    hipLaunchKernelGGL((bconv_kernel<KC, WAVES_C, WP, WC, TS>), dim3(grid), dim3(256), lds, s, p, g);
+    MRDIS_LAUNCH((bconv_kernel<KC, WAVES_C, WP, WC, TS>), dim3(grid), dim3(256), lds, s, p, g);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -389,7 +389,7 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 }
 extern "C" int mrdis_cast_bf16(const float* src, void* dst, long long n, void* stream) {
     if (!src || !dst || n < 1 || (((uintptr_t)src & 15) != 0) || (((uintptr_t)dst & 7) != 0)) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(dst), n);
+    MRDIS_LAUNCH(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(dst), n);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -947,14 +947,14 @@ static int run_bwgrad_s2(const void* x, int ldx, const void* dy, int lddy, float
 #define BWP_CASE(a, b_, HF) if (pl.wci == a && pl.wco == b_ && (Ci == 16) == HF) { \
         static bool attr_set = false; \
         if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_pack_kernel<a, b_, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
-        hipLaunchKernelGGL((bwgrad_pack_kernel<a, b_, HF>), dim3(pl.grid, 4), dim3(512), pl.lds, s, pl.pk); }
+        MRDIS_LAUNCH((bwgrad_pack_kernel<a, b_, HF>), dim3(pl.grid, 4), dim3(512), pl.lds, s, pl.pk); }
     BWP_CASE(1, 1, true) else BWP_CASE(1, 2, true) else BWP_CASE(1, 1, false) else BWP_CASE(1, 2, false) else BWP_CASE(2, 1, false) else BWP_CASE(2, 2, false)
     else return MRDIS_EUNSUPPORTED;
 #undef BWP_CASE
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)kh * kw * Ci * Co;
     const int splits = pl.pk.c[0].splits;
-    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, slab, splits, n, dw_tck,
+    MRDIS_LAUNCH(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, slab, splits, n, dw_tck,
                        slab + pl.slab_floats, splits, Co, dbias, accumulate_bias, pl.map);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1038,7 +1038,7 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
 #define BW_CASE_H(a, b_, TS, HF) if (pl.wci == a && pl.wco == b_) { \
         static bool attr_set = false; \
         if (!attr_set) { if (hipFuncSetAttribute((const void*)bwgrad_kernel<a, b_, TS, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr_set = true; } \
-        hipLaunchKernelGGL((bwgrad_kernel<a, b_, TS, HF>), dim3(grid), dim3(512), pl.lds, s, p); }
+        MRDIS_LAUNCH((bwgrad_kernel<a, b_, TS, HF>), dim3(grid), dim3(512), pl.lds, s, p); }
 #define BW_CASE(a, b_, TS) BW_CASE_H(a, b_, TS, false)
     bool done2 = false;
     if (st_bf16 && Ci % 32 == 0 && mrdis_opt(MRDIS_OPT_WINO_PIPE)) {              // pipelined form (bwgrad2_kernel); needs both images twice in LDS
@@ -1050,7 +1050,7 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
 #define BW2_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
             static bool attr2 = false; \
             if (!attr2) { if (hipFuncSetAttribute((const void*)bwgrad2_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr2 = true; } \
-            hipLaunchKernelGGL((bwgrad2_kernel<a, b_>), dim3(grid), dim3(512), lds2 < 32768 ? 32768 : lds2, s, p, (unsigned)xb, (unsigned)yb); done2 = true; }
+            MRDIS_LAUNCH((bwgrad2_kernel<a, b_>), dim3(grid), dim3(512), lds2 < 32768 ? 32768 : lds2, s, p, (unsigned)xb, (unsigned)yb); done2 = true; }
             BW2_CASE(1, 1) else BW2_CASE(1, 2) else BW2_CASE(2, 1) else BW2_CASE(2, 2)
 #undef BW2_CASE
         }
@@ -1063,7 +1063,7 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
 #undef BW_CASE_H
     MRDIS_CHECK_LAUNCH();
     const long long n = (long long)p.ntaps * Ci * Co;
-    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, p.slab, p.splits, n, dw_tck,
+    MRDIS_LAUNCH(bwgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64 + (dbias ? (Co + 63) / 64 : 0))), dim3(1024), 0, s, p.slab, p.splits, n, dw_tck,
                        p.bias_slab, p.splits, Co, dbias, accumulate_bias, BWTapMap{});
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -356,14 +356,14 @@ int mrdis_run_bconv3(const TapConvParams& t, hipStream_t s) {
     if (WC == 2) {
         const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
 #define BA(a) if (abl == a) { (void)hipFuncSetAttribute((const void*)bconv3_kernel<2, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((bconv3_kernel<2, a>), dim3(grid), dim3(512), lds, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        MRDIS_LAUNCH((bconv3_kernel<2, a>), dim3(grid), dim3(512), lds, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
         BA(1) BA(2) BA(4) BA(8) BA(16) BA(6) BA(14) BA(15) BA(30)
 #undef BA
     }
 #endif
     mrdis_count(MRDIS_CNT_BCONV3);
-    if (WC == 2) hipLaunchKernelGGL(bconv3_kernel<2>, dim3(grid), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL(bconv3_kernel<1>, dim3(grid), dim3(512), lds, s, p);
+    if (WC == 2) MRDIS_LAUNCH(bconv3_kernel<2>, dim3(grid), dim3(512), lds, s, p);
+    else MRDIS_LAUNCH(bconv3_kernel<1>, dim3(grid), dim3(512), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -398,7 +398,7 @@ int mrdis_run_bconv3_spade(const void* x, int ldx, const void* w_bf16, const flo
     const int grid = units < n_cu ? (int)units : n_cu;
     const size_t lds = 2 * (size_t)(2 * 9 * 64 * P_PITCH + 2 * P_XS) + sizeof(float) * P_BIAS;
     mrdis_count(MRDIS_CNT_BCONV3_SPADE);
-    hipLaunchKernelGGL((bconv3_kernel<2, 0, true>), dim3(grid), dim3(512), lds, s, p);
+    MRDIS_LAUNCH((bconv3_kernel<2, 0, true>), dim3(grid), dim3(512), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -349,13 +349,13 @@ int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
     if (WC == 2) {
         const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
 #define QA(a) if (abl == a) { (void)hipFuncSetAttribute((const void*)bconv4_kernel<2, false, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((bconv4_kernel<2, false, a>), dim3(grid), dim3(512), q_lds(2), s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        MRDIS_LAUNCH((bconv4_kernel<2, false, a>), dim3(grid), dim3(512), q_lds(2), s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
         QA(1) QA(2) QA(4) QA(8) QA(6) QA(10) QA(14) QA(7) QA(15)
 #undef QA
     }
 #endif
-    if (WC == 2) hipLaunchKernelGGL(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2), s, p);
-    else hipLaunchKernelGGL(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1), s, p);
+    if (WC == 2) MRDIS_LAUNCH(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2), s, p);
+    else MRDIS_LAUNCH(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1), s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -384,7 +384,7 @@ int mrdis_run_bconv4_spade(const void* x, int ldx, const void* w_bf16, const flo
     p.wide = (C % 8 == 0 && ldmix % 8 == 0 && ldg % 8 == 0 && ((((uintptr_t)mix) | ((uintptr_t)gamma)) & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
     const int grid = units < n_cu ? (int)units : n_cu;
     mrdis_count(MRDIS_CNT_BCONV4_SPADE);
-    hipLaunchKernelGGL((bconv4_kernel<2, true>), dim3(grid), dim3(512), q_lds(2), s, p);
+    MRDIS_LAUNCH((bconv4_kernel<2, true>), dim3(grid), dim3(512), q_lds(2), s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

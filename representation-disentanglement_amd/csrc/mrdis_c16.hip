@@ -147,8 +147,8 @@ int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias
     p.ntiles = (int)nt; p.x_bytes = (unsigned)xb;
     const int grid = p.ntiles < 512 ? p.ntiles : 512;
     const size_t lds = sizeof(float) * (size_t)C16_NPX * (Ci + 4);
-    if (Ci == 32) hipLaunchKernelGGL((conv3x3_c16_kernel<2>), dim3(grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv3x3_c16_kernel<1>), dim3(grid), dim3(256), lds, s, p);
+    if (Ci == 32) MRDIS_LAUNCH((conv3x3_c16_kernel<2>), dim3(grid), dim3(256), lds, s, p);
+    else MRDIS_LAUNCH((conv3x3_c16_kernel<1>), dim3(grid), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

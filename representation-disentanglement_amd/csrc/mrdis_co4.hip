@@ -139,8 +139,8 @@ int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, flo
     p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
     const size_t lds = sizeof(float) * (size_t)9 * (W + 2) * 4;
     const dim3 grid(N * p.segs), block(256);
-#define CO4_LAUNCH(HV, TP) { if (x_bf16) hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
-                             else hipLaunchKernelGGL((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }
+#define CO4_LAUNCH(HV, TP) { if (x_bf16) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
+                             else MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }
     const int tpw = W / 64;
     if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4) else if (tpw == 2) CO4_LAUNCH(4, 2) else CO4_LAUNCH(4, 1) }
     else { if (tpw == 4) CO4_LAUNCH(2, 4) else if (tpw == 2) CO4_LAUNCH(2, 2) else CO4_LAUNCH(2, 1) }

@@ -654,14 +654,14 @@ template <int KC, int BN>
 static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM, hipStream_t s, bool split_k = false) {
     if constexpr (BN == 32 && KC >= 16) {
         if (split_k && BM == 128 && p.prefetch == 1) {
-            hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 128, 2>), dim3(nblk), dim3(256), lds, s, p);
+            MRDIS_LAUNCH((tapconv_kernel<KC, BN, 1, 128, 2>), dim3(nblk), dim3(256), lds, s, p);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }
     }
-    if (BM == 256) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 256>), dim3(nblk), dim3(256), lds, s, p);      // BM 256 only with MODE 1
-    else if (p.prefetch == 1) hipLaunchKernelGGL((tapconv_kernel<KC, BN, 1, 128>), dim3(nblk), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((tapconv_kernel<KC, BN, 0, 128>), dim3(nblk), dim3(256), lds, s, p);
+    if (BM == 256) MRDIS_LAUNCH((tapconv_kernel<KC, BN, 1, 256>), dim3(nblk), dim3(256), lds, s, p);      // BM 256 only with MODE 1
+    else if (p.prefetch == 1) MRDIS_LAUNCH((tapconv_kernel<KC, BN, 1, 128>), dim3(nblk), dim3(256), lds, s, p);
+    else MRDIS_LAUNCH((tapconv_kernel<KC, BN, 0, 128>), dim3(nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -674,9 +674,9 @@ static int launch_tapconv_pack_t(const TapLaunch (&L)[4], hipStream_t s) {
     int gx = 0; size_t lds = 0;
     for (int k = 0; k < 4; ++k) { pk.c[k] = L[k].p; pk.nblk[k] = L[k].nblk; if (L[k].nblk > gx) gx = L[k].nblk; if (L[k].lds > lds) lds = L[k].lds; }
     const int BM = L[0].BM, pf = L[0].p.prefetch;
-    if (BM == 256) hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 1, 256>), dim3(gx, 4), dim3(256), lds, s, pk);
-    else if (pf == 1) hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 1, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
-    else hipLaunchKernelGGL((tapconv_pack_kernel<KC, BN, 0, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
+    if (BM == 256) MRDIS_LAUNCH((tapconv_pack_kernel<KC, BN, 1, 256>), dim3(gx, 4), dim3(256), lds, s, pk);
+    else if (pf == 1) MRDIS_LAUNCH((tapconv_pack_kernel<KC, BN, 1, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
+    else MRDIS_LAUNCH((tapconv_pack_kernel<KC, BN, 0, 128>), dim3(gx, 4), dim3(256), lds, s, pk);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -743,10 +743,10 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
         }
         if (ptiles > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
         const bool thin4 = p.Cout <= 4 && KC == 16 && !mrdis_opt(MRDIS_OPT_NOTHIN);
-        if (thin4) hipLaunchKernelGGL((tapconv16_kernel<16, true>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
-        else if (KC == 16) hipLaunchKernelGGL((tapconv16_kernel<16, false>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
-        else if (KC == 8) hipLaunchKernelGGL((tapconv16_kernel<8, false>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
-        else hipLaunchKernelGGL((tapconv16_kernel<4, false>), dim3((int)ptiles), dim3(256), lds16(4), s, p);
+        if (thin4) MRDIS_LAUNCH((tapconv16_kernel<16, true>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
+        else if (KC == 16) MRDIS_LAUNCH((tapconv16_kernel<16, false>), dim3((int)ptiles), dim3(256), lds16(16), s, p);
+        else if (KC == 8) MRDIS_LAUNCH((tapconv16_kernel<8, false>), dim3((int)ptiles), dim3(256), lds16(8), s, p);
+        else MRDIS_LAUNCH((tapconv16_kernel<4, false>), dim3((int)ptiles), dim3(256), lds16(4), s, p);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
@@ -1154,10 +1154,10 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     if (blocks > cap) blocks = cap;
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
-#define C4_LAUNCH(ns, lr, fa) hipLaunchKernelGGL((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
+#define C4_LAUNCH(ns, lr, fa) MRDIS_LAUNCH((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
     if (obf16) {       // the si_layers' forward (flip = 0) and the C <- 4 data gradient (flip = 1: run time); no LeakyReLU follows either
-        if (NS == 2) { if (fast) hipLaunchKernelGGL((c4conv_kernel<2, false, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<2, false, false, true>), grid, dim3(256), 0, s, p); }
-        else { if (fast) hipLaunchKernelGGL(c4conv_obf16_kernel, grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }
+        if (NS == 2) { if (fast) MRDIS_LAUNCH((c4conv_kernel<2, false, true, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_kernel<2, false, false, true>), grid, dim3(256), 0, s, p); }
+        else { if (fast) MRDIS_LAUNCH(c4conv_obf16_kernel, grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }
     } else
     if (NS == 2) {
         if (p.lrelu) { if (fast) C4_LAUNCH(2, true, true); else C4_LAUNCH(2, true, false); }
@@ -2478,12 +2478,12 @@ static int launch_wgrad_t(const WgradPlan& pl, hipStream_t s) {
         const bool x_ok = (pl.p.ldx % 4 == 0) && (((uintptr_t)pl.p.x & 15) == 0);
         const bool dy_ok = (pl.p.lddy % 4 == 0) && (((uintptr_t)pl.p.dy & 15) == 0);
         if (x_ok && dy_ok) {
-            hipLaunchKernelGGL((wgrad_dma_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds_dma, s, pl.p, pl.XR);
+            MRDIS_LAUNCH((wgrad_dma_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds_dma, s, pl.p, pl.XR);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }
     }
-    hipLaunchKernelGGL((wgrad_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
+    MRDIS_LAUNCH((wgrad_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -2550,15 +2550,15 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
                 return MRDIS_ELAUNCH;
             attr_set = true;
         }
-        if (pl.thin == 1) hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, false>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
-        else if (pl.thin_nt == 4) hipLaunchKernelGGL((wgrad_thin_dma_kernel<4, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
-        else hipLaunchKernelGGL((wgrad_thin_dma_kernel<9, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        if (pl.thin == 1) MRDIS_LAUNCH((wgrad_thin_dma_kernel<9, 4, false>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        else if (pl.thin_nt == 4) MRDIS_LAUNCH((wgrad_thin_dma_kernel<4, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
+        else MRDIS_LAUNCH((wgrad_thin_dma_kernel<9, 4, true>), dim3(p.splits * p.base), dim3(256), pl.lds_dma, s, p, pl.J, pl.XR);
         MRDIS_CHECK_LAUNCH();
         rc = MRDIS_OK;
     } else
     if (pl.pointwise) {
         const int vx = (Ci == 16) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
-        hipLaunchKernelGGL(wgrad_pointwise_kernel, dim3(p.splits), dim3(256), 0, s, x, ldx, dy, lddy, (long long)N * H * W, Ci, Co,
+        MRDIS_LAUNCH(wgrad_pointwise_kernel, dim3(p.splits), dim3(256), 0, s, x, ldx, dy, lddy, (long long)N * H * W, Ci, Co,
                            p.slab, p.bias_slab, vx);
         MRDIS_CHECK_LAUNCH();
         rc = MRDIS_OK;
@@ -2577,7 +2577,7 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     const long long nout = (long long)pl.out_taps * Ci * Co + (dbias ? Co : 0);
     int SL = 1;
     while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;           // >= 8 slabs per lane before another lane is added
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, pl.out_taps, Ci, Co,
+    MRDIS_LAUNCH(wgrad_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, pl.out_taps, Ci, Co,
                        p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits, pl.map, p.bias_slab, dbias, accumulate_bias ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2850,7 +2850,7 @@ extern "C" int mrdis_mix_experts_fwd(const float* W, const float* r, float* w_tc
                                      int E, int Co, int Ci, int T, void* stream) {
     if (!W || !r || E < 1 || E > 8 || Co < 1 || Ci < 1 || T < 1) return MRDIS_EINVAL;
     const long long total = (long long)Co * Ci * T;
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, r, w_tck, w_tkc, E, Co, Ci, T);
+    MRDIS_LAUNCH(mix_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, r, w_tck, w_tkc, E, Co, Ci, T);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -2867,10 +2867,10 @@ extern "C" int mrdis_mix_experts_bwd(const float* dw_tck, const float* W, const 
     const long long total = (long long)Co * Ci * T;
     const int nb = mix_blocks(total);
     if (workspace_bytes < sizeof(float) * 8 * (size_t)nb) return MRDIS_EWORKSPACE;
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
+    MRDIS_LAUNCH(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
                        reinterpret_cast<float*>(workspace), E, Co, Ci, T);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mix_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(mix_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, E, dr);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2880,7 +2880,7 @@ extern "C" int mrdis_mix_experts_routed_fwd(const float* W, const float* fc_w, c
                                             float* r_out, float* w_tck, float* w_tkc, int E, int Co, int Ci, int T, void* stream) {
     if (!W || !fc_w || !fc_b || !type_row || !r_out || !w_tck || !w_tkc || E < 1 || E > 8 || emb < 1 || emb > 16) return MRDIS_EINVAL;
     const long long total = (long long)Co * Ci * T;
-    hipLaunchKernelGGL(mix_routed_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, type_row, emb,
+    MRDIS_LAUNCH(mix_routed_fwd_kernel, dim3(mix_blocks(total)), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, type_row, emb,
                        r_out, w_tck, w_tkc, E, Co, Ci, T);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2893,10 +2893,10 @@ extern "C" int mrdis_mix_experts_routed_bwd(const float* dw_tck, const float* W,
     const long long total = (long long)Co * Ci * T;
     const int nb = mix_blocks(total);
     if (workspace_bytes < sizeof(float) * 8 * (size_t)nb) return MRDIS_EWORKSPACE;
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
+    MRDIS_LAUNCH(mix_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dw_tck, W, r, dW,
                        reinterpret_cast<float*>(workspace), E, Co, Ci, T);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mix_routed_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(mix_routed_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, E, r, type_row, emb, dfc_w, dfc_b);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2922,7 +2922,7 @@ extern "C" int mrdis_mix_experts_routed_multi_fwd(const float* W, const float* f
     if (ld_tck <= 0) ld_tck = Co;
     if (tap_tkc <= 0) tap_tkc = (long long)Co * Ci;
     if (ld_tck < Co || tap_tkc < (long long)Co * Ci) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(mix_routed_multi_fwd_kernel, dim3(mix_blocks(total), M), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, types, emb,
+    MRDIS_LAUNCH(mix_routed_multi_fwd_kernel, dim3(mix_blocks(total), M), dim3(256), 0, (hipStream_t)stream, W, fc_w, fc_b, types, emb,
                        r_out, out, E, Co, Ci, T, ld_tck, tap_tkc);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2943,10 +2943,10 @@ extern "C" int mrdis_mix_experts_routed_multi_bwd(const float* const* dw_tck, co
     if (workspace_bytes < mrdis_mix_experts_routed_multi_bwd_workspace(M, E, Co, Ci, T)) return MRDIS_EWORKSPACE;
     MixCPtrs dw{};
     for (int m = 0; m < M; ++m) dw.p[m] = dw_tck[m];
-    hipLaunchKernelGGL(mix_multi_bwd_kernel, dim3(nb, M), dim3(256), 0, (hipStream_t)stream, dw, W, r, dW,
+    MRDIS_LAUNCH(mix_multi_bwd_kernel, dim3(nb, M), dim3(256), 0, (hipStream_t)stream, dw, W, r, dW,
                        reinterpret_cast<float*>(workspace), M, E, Co, Ci, T, accumulate ? 1 : 0, ld_dw > 0 ? ld_dw : Co);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mix_multi_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(mix_multi_bwd_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float*>(workspace), nb, M, E, r, types, emb, dfc_w, dfc_b, accumulate ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -2957,17 +2957,17 @@ extern "C" int mrdis_mix_job_blocks(int Co, int Ci, int T) { return mix_blocks((
 
 extern "C" int mrdis_mix_jobs_fwd(const void* jobs, int njobs, int total_blocks, const float* types, int emb, int M, void* stream) {
     if (!jobs || !types || njobs < 1 || total_blocks < njobs || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(mix_jobs_fwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs, types, emb);
+    MRDIS_LAUNCH(mix_jobs_fwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs, types, emb);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 
 extern "C" int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void* dw_table, const float* types, int emb, int M, void* stream) {
     if (!jobs || !dw_table || !types || njobs < 1 || total_blocks < njobs || emb < 1 || emb > 16 || M < 1 || M > MIX_MAX_TYPES) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(mix_jobs_bwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs,
+    MRDIS_LAUNCH(mix_jobs_bwd_kernel, dim3(total_blocks, M), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), njobs,
                        reinterpret_cast<const float* const*>(dw_table), M);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(mix_jobs_bwd_final_kernel, dim3(njobs), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), types, emb, M);
+    MRDIS_LAUNCH(mix_jobs_bwd_final_kernel, dim3(njobs), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const MixJob*>(jobs), types, emb, M);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

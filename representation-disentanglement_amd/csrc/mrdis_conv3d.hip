@@ -316,7 +316,7 @@ static int launch_tapconv3d_t(const Conv3dParams& p, size_t lds, int nblk, hipSt
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((tapconv3d_kernel<KC, BN>), dim3(nblk), dim3(256), lds, s, p);
+    MRDIS_LAUNCH((tapconv3d_kernel<KC, BN>), dim3(nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -475,7 +475,7 @@ static int launch_conv3d16_t(const Conv3dParams& p, size_t lds, int nblk, int nb
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d16_kernel<KC>), dim3(nblk), dim3(256), lds, s, p, nboxes);
+    MRDIS_LAUNCH((conv3d16_kernel<KC>), dim3(nblk), dim3(256), lds, s, p, nboxes);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1254,7 +1254,7 @@ static int launch_wgrad3d_t(const Wgrad3dPlan& pl, hipStream_t s) {
             return MRDIS_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad3d_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
+    MRDIS_LAUNCH((wgrad3d_kernel<J>), dim3(pl.p.splits * pl.p.base), dim3(256), pl.lds, s, pl.p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1283,14 +1283,14 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
             q.slab = reinterpret_cast<float*>(workspace);
             q.bias_slab = dbias ? q.slab + p16.slab_floats : nullptr;
             const int nblk = q.splits * q.nCi * q.nCo;
-            if (p16.CW == 16) hipLaunchKernelGGL((wgrad3d16_kernel<16>), dim3(nblk), dim3(256), p16.lds, s, q);
-            else if (p16.CW == 8) hipLaunchKernelGGL((wgrad3d16_kernel<8>), dim3(nblk), dim3(256), p16.lds, s, q);
-            else hipLaunchKernelGGL((wgrad3d16_kernel<4>), dim3(nblk), dim3(256), p16.lds, s, q);
+            if (p16.CW == 16) MRDIS_LAUNCH((wgrad3d16_kernel<16>), dim3(nblk), dim3(256), p16.lds, s, q);
+            else if (p16.CW == 8) MRDIS_LAUNCH((wgrad3d16_kernel<8>), dim3(nblk), dim3(256), p16.lds, s, q);
+            else MRDIS_LAUNCH((wgrad3d16_kernel<4>), dim3(nblk), dim3(256), p16.lds, s, q);
             MRDIS_CHECK_LAUNCH();
             const long long nout16 = (long long)T3_TAPS * Ci * Co + (dbias ? Co : 0);
             int SL = 1;
             while (SL < 16 && SL * 8 <= q.splits) SL <<= 1;
-            hipLaunchKernelGGL(wgrad3d16_reduce_kernel, dim3(mrdis_cdiv(nout16, 64)), dim3(64, SL), 0, s, q.slab, dw_tck, Ci, Co, p16.CW,
+            MRDIS_LAUNCH(wgrad3d16_reduce_kernel, dim3(mrdis_cdiv(nout16, 64)), dim3(64, SL), 0, s, q.slab, dw_tck, Ci, Co, p16.CW,
                                q.nCi, q.nCo, q.splits, q.bias_slab, dbias);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
@@ -1315,7 +1315,7 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
     const long long nout = (long long)T3_TAPS * Ci * Co + (dbias ? Co : 0);
     int SL = 1;
     while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;
-    hipLaunchKernelGGL(wgrad3d_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co,
+    MRDIS_LAUNCH(wgrad3d_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co,
                        p.CW, p.TPS, pl.J, p.nCi, p.nCo, p.base, p.splits, pl.map, p.bias_slab, dbias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -8,6 +8,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 // ------------------------------------------------------------------ small vector helper
 // Activations are stored as fp32 or bf16 (MRDIS_DT_BF16: BASELINE.json configs[2]); the arithmetic is fp32 either way:
@@ -264,14 +265,14 @@ static int launch_stats(const T* a, int lda, const T* b, int ldb, const T* g, in
     if (xlo && !vec) return MRDIS_EUNSUPPORTED;
     if (vec && xlo) {
         if constexpr (MODE == 2)                          // (its own instantiation: the interpolation's registers do not ride on the plain statistics passes)
-            hipLaunchKernelGGL((stat_partial_vec_kernel<2, T, true>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+            MRDIS_LAUNCH((stat_partial_vec_kernel<2, T, true>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                                stat_per_group, P, C, sp.rpb, part, xlo, ldxlo, Wlo);
         else return MRDIS_EINVAL;
     } else if (vec)
-        hipLaunchKernelGGL((stat_partial_vec_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+        MRDIS_LAUNCH((stat_partial_vec_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(256), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                            stat_per_group, P, C, sp.rpb, part, nullptr, 0, 0);
     else
-    hipLaunchKernelGGL((stat_partial_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
+    MRDIS_LAUNCH((stat_partial_kernel<MODE, T>), dim3(sp.chunks, groups), dim3(64, 4), 0, s, a, lda, b, ldb, g, ldg, mean, rstd,
                        stat_per_group, P, C, sp.rpb, part);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -350,17 +351,17 @@ static int bn_train_fwd_impl(const T* x, int ldx, T* y, int ldy, const float* ga
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     if (G == 1)
-        hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
+        MRDIS_LAUNCH((stat_final_kernel<0>), dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, 1, P, eps, momentum,
                            save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     else
-        hipLaunchKernelGGL(stat_final_groups_kernel, dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, eps, momentum,
+        MRDIS_LAUNCH(stat_final_groups_kernel, dim3(mrdis_cdiv(C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, eps, momentum,
                            save_mean, save_rstd, running_mean, running_mean ? running_var : nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = P * G;
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
+        MRDIS_LAUNCH((bn_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
+        MRDIS_LAUNCH((bn_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, save_mean, save_rstd, rows, C, P);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -388,9 +389,9 @@ static int bn_eval_fwd_impl(const T* x, int ldx, T* y, int ldy, const float* gam
     if (!x || !y || !running_mean || !running_var || P < 1 || C < 1 || ldx < C || ldy < C) return MRDIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bn_eval_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+        MRDIS_LAUNCH((bn_eval_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
     else
-        hipLaunchKernelGGL((bn_eval_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
+        MRDIS_LAUNCH((bn_eval_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta, running_mean, running_var, eps, P, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -435,14 +436,14 @@ static int bn_train_bwd_impl(const T* dy, int lddy, const T* x, int ldx, const f
     if (rc) return rc;
     const StatPlan sp = stat_plan(1, P);
     // dbeta = sum dy ; dgamma = sum dy * xhat  (per group)
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(G * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, 0.f, 0.f,
+    MRDIS_LAUNCH((stat_final_kernel<1>), dim3(mrdis_cdiv(G * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, G, P, 0.f, 0.f,
                        dbeta, dgamma, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = P * G;
     if (vec4_ok(dy, lddy, C) && vec4_ok(x, ldx, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
+        MRDIS_LAUNCH((bn_bwd_apply_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
+        MRDIS_LAUNCH((bn_bwd_apply_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, lddy, x, ldx, gamma, save_mean, save_rstd, dbeta, dgamma, dx, lddx, rows, C, acc_dgamma, acc_dbeta, P, G);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -479,15 +480,15 @@ static int instnorm_spade_fwd_impl(const T* z, int ldz, const T* gamma, int ldg,
         int rc = launch_stats<0, T>(z, ldz, (const T*)nullptr, 0, (const T*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
         if (rc) return rc;
         const StatPlan sp = stat_plan(N, HW);
-        hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+        MRDIS_LAUNCH((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
                            save_mean, save_rstd, nullptr, nullptr);
         MRDIS_CHECK_LAUNCH();
     }
     const long long rows = (long long)N * HW;
     if (vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(beta, ldb, C) && vec4_ok(out, ldo, C))
-        hipLaunchKernelGGL((spade_fwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+        MRDIS_LAUNCH((spade_fwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
     else
-        hipLaunchKernelGGL((spade_fwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
+        MRDIS_LAUNCH((spade_fwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, z, ldz, gamma, ldg, beta, ldb, out, ldo, save_mean, save_rstd, HW, rows, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -535,15 +536,15 @@ static int instnorm_spade_bwd_impl(const T* dout, int lddo, const T* z, int ldz,
     int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    MRDIS_LAUNCH((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     const long long rows = (long long)N * HW;
     const bool v = vec4_ok(dout, lddo, C) && vec4_ok(z, ldz, C) && vec4_ok(gamma, ldg, C) && vec4_ok(dz, lddz, C) &&
                    vec4_ok(dgamma, lddg, C) && (!dbeta || vec4_ok(dbeta, lddb, C));
     if (v)
-        hipLaunchKernelGGL((spade_bwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+        MRDIS_LAUNCH((spade_bwd_kernel<4, T>), dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
     else
-        hipLaunchKernelGGL((spade_bwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
+        MRDIS_LAUNCH((spade_bwd_kernel<1, T>), dim3(ew_blocks(rows * C)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1, dz, lddz, dgamma, lddg, dbeta, lddb, HW, rows, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -791,16 +792,16 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
             float* t1 = t0 + (size_t)N * C;
             float* abuf = f32 ? nullptr : t1 + (size_t)N * C;
             if (NW == 8)       // (reading a stored z instead of interpolating it from xlo was measured level to slower: the kernel is not bound by the interpolation)
-                hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                MRDIS_LAUNCH((spade_bwd_up2_kernel<T, true, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg,
                                    save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
             else
-                hipLaunchKernelGGL((spade_bwd_up2_kernel<T, true, 256, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
+                MRDIS_LAUNCH((spade_bwd_up2_kernel<T, true, 256, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
                                    save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
             MRDIS_CHECK_LAUNCH();
             const int chunks = NW * tiles_x * tiles_y;
-            hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
+            MRDIS_LAUNCH((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(chunks)), 0, s, part1, chunks, C, N, HW, 0.f, 0.f, t0, t1, nullptr, nullptr);
             MRDIS_CHECK_LAUNCH();
-            hipLaunchKernelGGL((spade_bwd_up2_final_kernel<T>), dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C, abuf);
+            MRDIS_LAUNCH((spade_bwd_up2_final_kernel<T>), dim3(ew_blocks((long long)N * Hi * Wi * (C / 4))), dim3(256), 0, s, dx, lddx, xlo, ldxlo, save_mean, save_rstd, t0, t1, N, Hi, Wi, C, abuf);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }
@@ -811,13 +812,13 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     int rc = launch_stats<2, T>(dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, 1, N, HW, C, part, s, 0, xlo, ldxlo, Wi);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
+    MRDIS_LAUNCH((stat_final_kernel<1>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, 0.f, 0.f, s0, s1, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     if (xlo)
-        hipLaunchKernelGGL((spade_bwd_up2_kernel<T, false, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
+        MRDIS_LAUNCH((spade_bwd_up2_kernel<T, false, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
                            dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
     else
-        hipLaunchKernelGGL((spade_bwd_up2_kernel<T, false, 512, false>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
+        MRDIS_LAUNCH((spade_bwd_up2_kernel<T, false, 512, false>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg, save_mean, save_rstd, s0, s1,
                            dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -851,9 +852,9 @@ static int lrelu_bwd_impl(const T* dy, int lddy, const T* y, int ldy, T* dx, int
     if (!dy || !y || !dx || P < 1 || C < 1) return MRDIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (vec4_ok(dy, lddy, C) && vec4_ok(y, ldy, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((lrelu_bwd_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+        MRDIS_LAUNCH((lrelu_bwd_kernel<4, T>), dim3(ew_blocks(P * C / 4)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
     else
-        hipLaunchKernelGGL((lrelu_bwd_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
+        MRDIS_LAUNCH((lrelu_bwd_kernel<1, T>), dim3(ew_blocks(P * C)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, P, C, slope);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1180,14 +1181,14 @@ static int bilinear_fwd_impl(const T* x, int ldx, T* y, int ldy, int N, int Hi, 
     const float sh = bil_scale(Hi, Ho, align_corners), sw = bil_scale(Wi, Wo, align_corners);
     hipStream_t s = (hipStream_t)stream;
     if (!align_corners && Ho == 2 * Hi && Wo == 2 * Wi && vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C) && !mrdis_opt(MRDIS_OPT_BILGEN)) {
-        hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, x, ldx, y, ldy, Hi, Wi, C);
+        MRDIS_LAUNCH((bilinear_up2_fwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, x, ldx, y, ldy, Hi, Wi, C);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
     if (vec4_ok(x, ldx, C) && vec4_ok(y, ldy, C))
-        hipLaunchKernelGGL((bilinear_fwd_kernel<4, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * (C / 4))), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_fwd_kernel<4, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * (C / 4))), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else
-        hipLaunchKernelGGL((bilinear_fwd_kernel<1, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * C)), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_fwd_kernel<1, T>), dim3(Ho, N), dim3(bil_threads((long long)Wo * C)), 0, s, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1202,19 +1203,19 @@ static int bilinear_bwd_impl(const T* dy, int lddy, T* dx, int lddx, int N, int 
     const float smin = sh < sw ? sh : sw;
     const bool big = (long long)N * Hi * Wi * C >= 6000000LL;          // measured: 108 vs 129 us at 16 M elements, a wash below 6 M
     if (!align_corners && Ho == 2 * Hi && Wo == 2 * Wi && vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && !mrdis_opt(MRDIS_OPT_BILGEN)) {
-        hipLaunchKernelGGL((bilinear_up2_bwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, Hi, Wi, C);
+        MRDIS_LAUNCH((bilinear_up2_bwd_kernel<T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, Hi, Wi, C);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
     const bool tight3 = big && sh >= 1.f && sw >= 1.f, tight5 = big && smin > 0.4975f && !mrdis_opt(MRDIS_OPT_BILGEN);
     if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight3 && !mrdis_opt(MRDIS_OPT_BILGEN))
-        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 3, 3, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_bwd_tight_kernel<4, 3, 3, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C) && tight5)
-        hipLaunchKernelGGL((bilinear_bwd_tight_kernel<4, 5, 5, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_bwd_tight_kernel<4, 5, 5, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else if (vec4_ok(dy, lddy, C) && vec4_ok(dx, lddx, C))
-        hipLaunchKernelGGL((bilinear_bwd_kernel<4, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_bwd_kernel<4, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * (C / 4))), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     else
-        hipLaunchKernelGGL((bilinear_bwd_kernel<1, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * C)), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
+        MRDIS_LAUNCH((bilinear_bwd_kernel<1, T>), dim3(Hi, N), dim3(bil_threads((long long)Wi * C)), 0, s, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, align_corners, sh, sw);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1234,9 +1235,9 @@ static int bilinear_up2_stats_impl(const T* x, int ldx, T* y, int ldy, int N, in
     if (N > 65535 || C % 4 != 0 || !vec4_ok(x, ldx, C) || !vec4_ok(y, ldy, C) || threads % (C / 4) != 0) return MRDIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL((bilinear_up2_fwd_kernel<T, true>), dim3(Hi, N), dim3(threads), 0, s, x, ldx, y, ldy, Hi, Wi, C, part, out_block, out_block_stride);
+    MRDIS_LAUNCH((bilinear_up2_fwd_kernel<T, true>), dim3(Hi, N), dim3(threads), 0, s, x, ldx, y, ldy, Hi, Wi, C, part, out_block, out_block_stride);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(Hi)), 0, s, part, Hi, C, N, 4LL * Hi * Wi, eps, 0.f,
+    MRDIS_LAUNCH((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(Hi)), 0, s, part, Hi, C, N, 4LL * Hi * Wi, eps, 0.f,
                        save_mean, save_rstd, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1293,7 +1294,7 @@ extern "C" int mrdis_instnorm_stats(const void* z, int ldz, float* save_mean, fl
     else rc = launch_stats<0, float>((const float*)z, ldz, (const float*)nullptr, 0, (const float*)nullptr, 0, nullptr, nullptr, 0, N, HW, C, part, s);
     if (rc) return rc;
     const StatPlan sp = stat_plan(N, HW);
-    hipLaunchKernelGGL((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
+    MRDIS_LAUNCH((stat_final_kernel<0>), dim3(mrdis_cdiv(N * C, 64)), dim3(64, stat_final_lanes(sp.chunks)), 0, s, part, sp.chunks, C, N, HW, eps, 0.f,
                        save_mean, save_rstd, nullptr, nullptr);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1353,9 +1354,9 @@ template <typename TS, typename TD>
 static int cast_view_impl(const TS* src, int lds_, int Cs, TD* dst, int ldd, int Cd, long long P, void* stream) {
     if (!src || !dst || P < 1 || Cs < 1 || Cd < 1 || lds_ < Cs || ldd < Cd) return MRDIS_EINVAL;
     if (vec4_ok(dst, ldd, Cd) && (Cs >= Cd ? vec4_ok(src, lds_, Cd) : (lds_ % 4 == 0 && Cs % 4 == 0 && (((uintptr_t)src & (4 * sizeof(TS) - 1)) == 0))))
-        hipLaunchKernelGGL((cast_view_kernel<4, TS, TD>), dim3(ew_blocks(P * Cd / 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
+        MRDIS_LAUNCH((cast_view_kernel<4, TS, TD>), dim3(ew_blocks(P * Cd / 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
     else
-        hipLaunchKernelGGL((cast_view_kernel<1, TS, TD>), dim3(ew_blocks(P * Cd)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
+        MRDIS_LAUNCH((cast_view_kernel<1, TS, TD>), dim3(ew_blocks(P * Cd)), dim3(256), 0, (hipStream_t)stream, src, lds_, Cs, dst, ldd, Cd, P);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1394,14 +1395,14 @@ __global__ void softmax_md_bwd_kernel(const float* __restrict__ dout, int lddo, 
 extern "C" int mrdis_softmax_mask_drop_fwd(const float* s, int lds_, const float* mask_img, float* out, int ldo,
                                            long long P, int C, float mask_scale, void* stream) {
     if (!s || !out || P < 1 || C < 1 || C > SM_MAXC) return C > SM_MAXC ? MRDIS_EUNSUPPORTED : MRDIS_EINVAL;
-    hipLaunchKernelGGL(softmax_md_fwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, s, lds_, mask_img, out, ldo, P, C, mask_scale);
+    MRDIS_LAUNCH(softmax_md_fwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, s, lds_, mask_img, out, ldo, P, C, mask_scale);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
 extern "C" int mrdis_softmax_mask_drop_bwd(const float* dout, int lddo, const float* out, int ldo,
                                            float* ds, int ldds, long long P, int C, void* stream) {
     if (!dout || !out || !ds || P < 1 || C < 1 || C > SM_MAXC) return C > SM_MAXC ? MRDIS_EUNSUPPORTED : MRDIS_EINVAL;
-    hipLaunchKernelGGL(softmax_md_bwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out, ldo, ds, ldds, P, C);
+    MRDIS_LAUNCH(softmax_md_bwd_kernel, dim3(ew_blocks(P)), dim3(256), 0, (hipStream_t)stream, dout, lddo, out, ldo, ds, ldds, P, C);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1485,12 +1486,12 @@ extern "C" int mrdis_slice_gather(const void* vol_ptrs, const int* slice_idx, co
     int gx = (int)((items + 255) / 256); if (gx > 1024) gx = 1024;
     const int C = M * (2 * block + 1);
     if (C % 4 == 0 && C <= 32 && ld_in % 4 == 0 && (((uintptr_t)inputs & 15) == 0)) {
-        hipLaunchKernelGGL(slice_gather_px_kernel<32>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream,
+        MRDIS_LAUNCH(slice_gather_px_kernel<32>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const unsigned long long*>(vol_ptrs), slice_idx, drop, inputs, ld_in, mask, mask_img, B, M, H, W, D, block);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
-    hipLaunchKernelGGL(slice_gather_kernel, dim3(gx, B, M), dim3(256), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(slice_gather_kernel, dim3(gx, B, M), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned long long*>(vol_ptrs), slice_idx, drop, inputs, ld_in, mask, mask_img, B, M, H, W, D, block);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1592,11 +1593,11 @@ extern "C" int mrdis_recon_metrics(const float* target, int ldt, const float* pr
     hipStream_t s = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(workspace);
     float* mm = reinterpret_cast<float*>(part + 2 * (size_t)n_img * H);
-    hipLaunchKernelGGL(metrics_minmax_kernel, dim3(n_img), dim3(256), 0, s, target, ldt, pred, ldp, (long long)H * W, mm);
+    MRDIS_LAUNCH(metrics_minmax_kernel, dim3(n_img), dim3(256), 0, s, target, ldt, pred, ldp, (long long)H * W, mm);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_rows_kernel, dim3(H, n_img), dim3(256), sizeof(float) * MET_WIN * 2 * W, s, target, ldt, pred, ldp, H, W, mm, part);
+    MRDIS_LAUNCH(metrics_rows_kernel, dim3(H, n_img), dim3(256), sizeof(float) * MET_WIN * 2 * W, s, target, ldt, pred, ldp, H, W, mm, part);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(metrics_final_kernel, dim3(mrdis_cdiv(n_img, 64)), dim3(64), 0, s, part, mm, n_img, H, W, out);
+    MRDIS_LAUNCH(metrics_final_kernel, dim3(mrdis_cdiv(n_img, 64)), dim3(64), 0, s, part, mm, n_img, H, W, out);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1646,9 +1647,9 @@ extern "C" int mrdis_recon_err_fwd(const float* gt, int ldgt, const float* x, in
     int epb; const int ch = recon_chunks(N, HW * C, &epb);
     hipStream_t s = (hipStream_t)stream;
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(recon_partial_kernel, dim3(ch, N), dim3(256), 0, s, gt, ldgt, x, ldx, HW, C, p, epb, part);
+    MRDIS_LAUNCH(recon_partial_kernel, dim3(ch, N), dim3(256), 0, s, gt, ldgt, x, ldx, HW, C, p, epb, part);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(recon_final_kernel, dim3(mrdis_cdiv(N, 64)), dim3(64), 0, s, part, ch, N, 1.0 / ((double)HW * C), out);
+    MRDIS_LAUNCH(recon_final_kernel, dim3(mrdis_cdiv(N, 64)), dim3(64), 0, s, part, ch, N, 1.0 / ((double)HW * C), out);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1665,7 +1666,7 @@ __global__ void recon_bwd_kernel(const float* __restrict__ gt, int ldgt, const f
 extern "C" int mrdis_recon_err_bwd(const float* gt, int ldgt, const float* x, int ldx, const float* w,
                                    float* dx, int lddx, int N, long long HW, int C, int p, void* stream) {
     if (!gt || !x || !w || !dx || N < 1 || HW < 1 || C < 1 || (p != 1 && p != 2)) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(recon_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, gt, ldgt, x, ldx, w, dx, lddx,
+    MRDIS_LAUNCH(recon_bwd_kernel, dim3(ew_blocks((long long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, gt, ldgt, x, ldx, w, dx, lddx,
                        N, HW, C, p, (float)(1.0 / ((double)HW * C)));
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1700,7 +1701,7 @@ extern "C" int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* arg
                                  int k, void* stream) {
     if (!x || !y || !argmax || N < 1 || C < 1 || k < 1 || H < k || W < k) return MRDIS_EINVAL;
     const int Ho = H / k, Wo = W / k;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, argmax, N, H, W, C, k, Ho, Wo);
+    MRDIS_LAUNCH(maxpool_fwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, argmax, N, H, W, C, k, Ho, Wo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1712,7 +1713,7 @@ extern "C" int mrdis_maxpool_bwd(const float* dy, const int32_t* argmax, float* 
     // dx is a dense (N,H,W,C) view: zero it first (async, capture-safe)
     if (lddx == C) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, s) != hipSuccess) return MRDIS_ELAUNCH; }
     else return MRDIS_EUNSUPPORTED;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, s, dy, argmax, dx, lddx, N, H, W, C, Ho, Wo);
+    MRDIS_LAUNCH(maxpool_bwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, s, dy, argmax, dx, lddx, N, H, W, C, Ho, Wo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1743,9 +1744,9 @@ extern "C" int mrdis_sumsq_finite(const float* g, long long n, float* out, void*
     if (workspace_bytes < mrdis_sumsq_workspace()) return MRDIS_EWORKSPACE;
     int nb = ew_blocks(n); if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_finite_kernel, dim3(nb), dim3(256), 0, s, g, n, reinterpret_cast<float*>(workspace));
+    MRDIS_LAUNCH(sumsq_finite_kernel, dim3(nb), dim3(256), 0, s, g, n, reinterpret_cast<float*>(workspace));
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float*>(workspace), nb, out);
+    MRDIS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float*>(workspace), nb, out);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -1834,14 +1835,14 @@ extern "C" int mrdis_adam_amsgrad_step(float* p, const float* g, float* m, float
     for (int k = 0; k < n_gates; ++k) { gates.lo[k] = gate_ranges[2 * k]; gates.hi[k] = gate_ranges[2 * k + 1]; gates.flag[k] = gate_flag_index[k]; }
     float bc1 = 1.f, sbc2 = 1.f;
     if (step_state) {
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, norm_finite,
+        MRDIS_LAUNCH(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, norm_finite,
                            gate_steps, n_gates > 0 ? gate_flags : (const float*)nullptr, n_flags, beta1, beta2);
         MRDIS_CHECK_LAUNCH();
     } else {
         bc1 = 1.f - powf(beta1, (float)step_count);
         sbc2 = sqrtf(1.f - powf(beta2, (float)step_count));
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
+    MRDIS_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, sbc2, norm_finite, max_norm, grad_scale, (const float*)step_state,
                        n_gates > 0 ? gate_flags : (const float*)nullptr, gates, (const float*)gate_steps, n_flags);
     MRDIS_CHECK_LAUNCH();
@@ -1860,7 +1861,7 @@ extern "C" int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, vo
     if (!src || !dst || nbytes < 1 || (nbytes & 3) != 0 || (((uintptr_t)src | (uintptr_t)dst) & 3) != 0) return MRDIS_EINVAL;
     const long long nw = nbytes / 4;
     long long nb = (nw + 255) / 256; if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(src),
+    MRDIS_LAUNCH(copy_bytes_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(src),
                        reinterpret_cast<unsigned*>(dst), nw);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -1930,6 +1931,28 @@ extern "C" long long mrdis_launch_count(const char* family) {
 }
 extern "C" void mrdis_launch_count_reset(void) {
     for (int i = 0; i < MRDIS_CNT_COUNT; ++i) __atomic_store_n(&g_counts[i], 0LL, __ATOMIC_RELAXED);
+}
+
+namespace {
+struct LdsNote { const char* expr; size_t bytes; };
+LdsNote g_lds[128]; int g_nlds = 0;
+}  // namespace
+void mrdis_note_lds(const char* kernel_expr, size_t bytes) {       // host, launch path: a pointer compare per known kernel (string literals are unique per call site)
+    for (int i = 0; i < g_nlds; ++i)
+        if (g_lds[i].expr == kernel_expr) { if (bytes > g_lds[i].bytes) g_lds[i].bytes = bytes; return; }
+    if (g_nlds < 128) { g_lds[g_nlds].expr = kernel_expr; g_lds[g_nlds].bytes = bytes; ++g_nlds; }
+}
+// "kernel expression=bytes" lines, at most cap - 1 characters; returns the number of entries
+extern "C" int mrdis_dynamic_lds_table(char* buf, int cap) {
+    int pos = 0;
+    if (!buf || cap < 1) return MRDIS_EINVAL;
+    buf[0] = 0;
+    for (int i = 0; i < g_nlds; ++i) {
+        const int n = snprintf(buf + pos, (size_t)(cap - pos), "%s=%zu\n", g_lds[i].expr, g_lds[i].bytes);
+        if (n < 0 || pos + n >= cap) break;
+        pos += n;
+    }
+    return g_nlds;
 }
 
 extern "C" const char* mrdis_strerror(int code) {

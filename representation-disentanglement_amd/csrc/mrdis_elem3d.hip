@@ -237,15 +237,15 @@ extern "C" int mrdis_groupnorm_relu_fwd(const float* x, int ldx, float* y, int l
     float* partial = reinterpret_cast<float*>(workspace);
     size_t part = sizeof(float) * (size_t)N * nchunk * C * 2; part = (part + 15) & ~(size_t)15;
     double* chan = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
-    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+    MRDIS_LAUNCH(gn_partial_kernel<0>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                        partial, P, C, G, 0);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
+    MRDIS_LAUNCH(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_stat_kernel, dim3(mrdis_cdiv((long long)N * G, 64)), dim3(64), 0, s, chan, save_mean, save_rstd, N, C, G, P, eps);
+    MRDIS_LAUNCH(gn_stat_kernel, dim3(mrdis_cdiv((long long)N * G, 64)), dim3(64), 0, s, chan, save_mean, save_rstd, N, C, G, P, eps);
     MRDIS_CHECK_LAUNCH();
     int rpb; const int nb = gn_row_blocks(P, C, N, 4, &rpb);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, N), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta,
+    MRDIS_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(256), 0, s, x, ldx, y, ldy, gamma, beta,
                        save_mean, save_rstd, P, C, G, rpb, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -266,15 +266,15 @@ extern "C" int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* 
     size_t part = sizeof(float) * (size_t)N * nchunk * C * 2; part = (part + 15) & ~(size_t)15;
     double* chan = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
     float* coef = reinterpret_cast<float*>(chan + (size_t)N * C * 2);
-    hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, dy, lddy, gamma, beta, save_mean, save_rstd,
+    MRDIS_LAUNCH(gn_partial_kernel<1>, dim3(nchunk, N), dim3(256), 0, s, x, ldx, dy, lddy, gamma, beta, save_mean, save_rstd,
                        partial, P, C, G, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
+    MRDIS_LAUNCH(gn_chan_kernel, dim3(N * C), dim3(64), 0, s, partial, chan, N, nchunk, C);
     MRDIS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(mrdis_cdiv((long long)N * G + C, 64)), dim3(64), 0, s, chan, gamma, coef, dgamma, dbeta, N, C, G, P);
+    MRDIS_LAUNCH(gn_bwd_coef_kernel, dim3(mrdis_cdiv((long long)N * G + C, 64)), dim3(64), 0, s, chan, gamma, coef, dgamma, dbeta, N, C, G, P);
     MRDIS_CHECK_LAUNCH();
     int rpb; const int nb = gn_row_blocks(P, C, N, 2, &rpb);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nb, N), dim3(256), 0, s, dy, lddy, x, ldx, dx, lddx,
+    MRDIS_LAUNCH(gn_bwd_apply_kernel, dim3(nb, N), dim3(256), 0, s, dy, lddy, x, ldx, dx, lddx,
                        gamma, beta, save_mean, save_rstd, coef, P, C, G, rpb, relu ? 1 : 0);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -326,7 +326,7 @@ extern "C" int mrdis_upsample2x_add_fwd(const float* x, const float* skip, float
     if (!x || !y || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MRDIS_EINVAL;
     if (C % 4 != 0) return MRDIS_EUNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)skip) & 15) != 0) return MRDIS_EALIGN;
-    hipLaunchKernelGGL(up2_fwd_kernel, dim3(ew_blocks((long long)N * 8 * D * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(up2_fwd_kernel, dim3(ew_blocks((long long)N * 8 * D * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                        x, skip, y, N, D, H, W, C / 4);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -336,7 +336,7 @@ extern "C" int mrdis_upsample2x_bwd(const float* dy, float* dx, int N, int D, in
     if (!dy || !dx || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MRDIS_EINVAL;
     if (C % 4 != 0) return MRDIS_EUNSUPPORTED;
     if ((((uintptr_t)dy | (uintptr_t)dx) & 15) != 0) return MRDIS_EALIGN;
-    hipLaunchKernelGGL(up2_bwd_kernel, dim3(ew_blocks((long long)N * D * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+    MRDIS_LAUNCH(up2_bwd_kernel, dim3(ew_blocks((long long)N * D * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                        dy, dx, N, D, H, W, C / 4);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

@@ -209,12 +209,12 @@ int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float*
     const size_t lds = sizeof(float) * (size_t)(4 * 9 * 256);           // reduction buffer (36 KB) >= dys + x box (19.5 KB)
     // (two slices per workgroup -- dy staged once, wgrad16_kernel<2> -- measured slower: 338 vs 289 us on 32 -> 16 at 256x256, B = 32;
     //  the kernel lives on workgroup-level overlap of its staging and MFMA phases, and half as many workgroups overlap less)
-    hipLaunchKernelGGL(wgrad16_kernel<1>, dim3(p.splits * p.nCi), dim3(256), lds, s, p);
+    MRDIS_LAUNCH(wgrad16_kernel<1>, dim3(p.splits * p.nCi), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     const long long nout = 9LL * Ci * Co + (dbias ? Co : 0);
     int SL = 1;
     while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;
-    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co, p.nCi, p.splits,
+    MRDIS_LAUNCH(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co, p.nCi, p.splits,
                        p.bias_slab, dbias, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;

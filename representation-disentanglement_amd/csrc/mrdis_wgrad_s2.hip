@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgradS2Params p)
 int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
                              hipStream_t s) {
     const int nout = total + (dbias ? Co : 0);
-    hipLaunchKernelGGL(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias);
+    MRDIS_LAUNCH(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -688,10 +688,10 @@ int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float
     const size_t red = sizeof(float) * (size_t)(4 * NT * 256);
     if (lds < red) lds = red;
     if (lds > 64 * 1024) return MRDIS_EUNSUPPORTED;
-    if (kh == 4 && NT == 2) hipLaunchKernelGGL((wgrad_s2_kernel<4, 2>), dim3(p.splits), dim3(256), lds, s, p);
-    else if (kh == 4) hipLaunchKernelGGL((wgrad_s2_kernel<4, 1>), dim3(p.splits), dim3(256), lds, s, p);
-    else if (NT == 2) hipLaunchKernelGGL((wgrad_s2_kernel<3, 2>), dim3(p.splits), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((wgrad_s2_kernel<3, 1>), dim3(p.splits), dim3(256), lds, s, p);
+    if (kh == 4 && NT == 2) MRDIS_LAUNCH((wgrad_s2_kernel<4, 2>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (kh == 4) MRDIS_LAUNCH((wgrad_s2_kernel<4, 1>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (NT == 2) MRDIS_LAUNCH((wgrad_s2_kernel<3, 2>), dim3(p.splits), dim3(256), lds, s, p);
+    else MRDIS_LAUNCH((wgrad_s2_kernel<3, 1>), dim3(p.splits), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     const int total = p.M * Co;
     return mrdis_launch_slab_reduce(p.slab, dw_tck, total, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
@@ -710,10 +710,10 @@ int mrdis_run_conv_s2_fwd(const float* x, int ldx, const float* w_tck, const flo
     p.Hout = q.Hout; p.Wout = q.Wout; p.lrelu = lrelu; p.rowp = q.rowp; p.segs = q.segs; p.R = q.R; p.M = q.M; p.x_bytes = (unsigned)xb;
     const size_t lds = sizeof(float) * (size_t)4 * p.rowp;
     const int NT = Co / 16;
-    if (kh == 4 && NT == 2) hipLaunchKernelGGL((conv_s2_fwd_kernel<4, 2>), dim3(q.splits), dim3(256), lds, s, p);
-    else if (kh == 4) hipLaunchKernelGGL((conv_s2_fwd_kernel<4, 1>), dim3(q.splits), dim3(256), lds, s, p);
-    else if (NT == 2) hipLaunchKernelGGL((conv_s2_fwd_kernel<3, 2>), dim3(q.splits), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_s2_fwd_kernel<3, 1>), dim3(q.splits), dim3(256), lds, s, p);
+    if (kh == 4 && NT == 2) MRDIS_LAUNCH((conv_s2_fwd_kernel<4, 2>), dim3(q.splits), dim3(256), lds, s, p);
+    else if (kh == 4) MRDIS_LAUNCH((conv_s2_fwd_kernel<4, 1>), dim3(q.splits), dim3(256), lds, s, p);
+    else if (NT == 2) MRDIS_LAUNCH((conv_s2_fwd_kernel<3, 2>), dim3(q.splits), dim3(256), lds, s, p);
+    else MRDIS_LAUNCH((conv_s2_fwd_kernel<3, 1>), dim3(q.splits), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -767,8 +767,8 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float*
             return MRDIS_EUNSUPPORTED;
         attr_set = true;
     }
-#define WC4_LAUNCH(nt) { if (dy_bf16) hipLaunchKernelGGL((wgrad_c4_kernel<nt, true>), dim3(p.splits), dim3(256), lds, s, p); \
-                         else hipLaunchKernelGGL((wgrad_c4_kernel<nt, false>), dim3(p.splits), dim3(256), lds, s, p); }
+#define WC4_LAUNCH(nt) { if (dy_bf16) MRDIS_LAUNCH((wgrad_c4_kernel<nt, true>), dim3(p.splits), dim3(256), lds, s, p); \
+                         else MRDIS_LAUNCH((wgrad_c4_kernel<nt, false>), dim3(p.splits), dim3(256), lds, s, p); }
     if (NT == 2) WC4_LAUNCH(2) else if (NT == 4) WC4_LAUNCH(4) else WC4_LAUNCH(8)
 #undef WC4_LAUNCH
     MRDIS_CHECK_LAUNCH();
@@ -804,10 +804,10 @@ int mrdis_run_dgrad_s2(const float* dy, int lddy, const float* w_tkc, float* dx,
         attr_set = true;
     }
     const dim3 grid(N * p.segs), block(256);
-    if (kh == 4 && Co == 32) hipLaunchKernelGGL((dgrad_s2_kernel<4, 2>), grid, block, lds, s, p);
-    else if (kh == 4) hipLaunchKernelGGL((dgrad_s2_kernel<4, 1>), grid, block, lds, s, p);
-    else if (Co == 32) hipLaunchKernelGGL((dgrad_s2_kernel<3, 2>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((dgrad_s2_kernel<3, 1>), grid, block, lds, s, p);
+    if (kh == 4 && Co == 32) MRDIS_LAUNCH((dgrad_s2_kernel<4, 2>), grid, block, lds, s, p);
+    else if (kh == 4) MRDIS_LAUNCH((dgrad_s2_kernel<4, 1>), grid, block, lds, s, p);
+    else if (Co == 32) MRDIS_LAUNCH((dgrad_s2_kernel<3, 2>), grid, block, lds, s, p);
+    else MRDIS_LAUNCH((dgrad_s2_kernel<3, 1>), grid, block, lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

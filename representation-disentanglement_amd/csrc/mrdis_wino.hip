@@ -312,8 +312,8 @@ int mrdis_run_wino(const float* x, int ldx, const float* w, const float* bias, f
     }
     const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
     mrdis_count(MRDIS_CNT_WINO);
-    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), dim3((int)nblk), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((wino_conv_kernel<1, 4>), dim3((int)nblk), dim3(256), lds, s, p);
+    if (CG == 2) MRDIS_LAUNCH((wino_conv_kernel<2, 4>), dim3((int)nblk), dim3(512), lds, s, p);
+    else MRDIS_LAUNCH((wino_conv_kernel<1, 4>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -343,8 +343,8 @@ int mrdis_run_wino3d(const float* x, int ldx, const float* w, const float* bias,
     }
     const size_t lds = CG == 2 ? wino_lds<2, 4>(p.TBH, p.TBW) : wino_lds<1, 4>(p.TBH, p.TBW);
     mrdis_count(MRDIS_CNT_WINO_SPADE);
-    if (CG == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 4, true>), dim3((int)nblk), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((wino_conv_kernel<1, 4, true>), dim3((int)nblk), dim3(256), lds, s, p);
+    if (CG == 2) MRDIS_LAUNCH((wino_conv_kernel<2, 4, true>), dim3((int)nblk), dim3(512), lds, s, p);
+    else MRDIS_LAUNCH((wino_conv_kernel<1, 4, true>), dim3((int)nblk), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -657,14 +657,14 @@ int mrdis_run_wino_wgrad(const float* x, int ldx, const float* dy, int lddy, flo
         if (rc2 != MRDIS_OK && rc2 != MRDIS_EUNSUPPORTED) return rc2;
     }
     if (rc2 == MRDIS_OK) {}
-    else if (pl.wci == 4 && pl.wco == 2) { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p); }
-    else if (pl.wci == 4) { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p); }
-    else { mrdis_count(MRDIS_CNT_WINO_WGRAD); hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p); }
+    else if (pl.wci == 4 && pl.wco == 2) { mrdis_count(MRDIS_CNT_WINO_WGRAD); MRDIS_LAUNCH((wino_wgrad_kernel<4, 2>), dim3(nblk), dim3(512), pl.lds, s, p); }
+    else if (pl.wci == 4) { mrdis_count(MRDIS_CNT_WINO_WGRAD); MRDIS_LAUNCH((wino_wgrad_kernel<4, 1>), dim3(nblk), dim3(256), pl.lds, s, p); }
+    else { mrdis_count(MRDIS_CNT_WINO_WGRAD); MRDIS_LAUNCH((wino_wgrad_kernel<2, 2>), dim3(nblk), dim3(256), pl.lds, s, p); }
     MRDIS_CHECK_LAUNCH();
     const long long n = 9LL * Ci * Co;
     int SL = 1;
     while (SL < 16 && SL * 4 <= p.splits) SL <<= 1;
-    hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck, n, p.splits,
+    MRDIS_LAUNCH(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (dbias ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck, n, p.splits,
                        p.bias_slab, dbias, Co, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
@@ -698,12 +698,12 @@ int mrdis_run_wino_wgrad3d(const float* x, int ldx, const float* dy, int lddy, f
     for (int kd = 0; kd < 3; ++kd) {
         p.kd = kd;
         p.bias_slab = (dbias && kd == 1) ? bias_slab : nullptr;
-        if (pl.wci == 4 && pl.wco == 2) hipLaunchKernelGGL((wino_wgrad_kernel<4, 2, true>), dim3(nblk), dim3(512), pl.lds, s, p);
-        else if (pl.wci == 4) hipLaunchKernelGGL((wino_wgrad_kernel<4, 1, true>), dim3(nblk), dim3(256), pl.lds, s, p);
-        else hipLaunchKernelGGL((wino_wgrad_kernel<2, 2, true>), dim3(nblk), dim3(256), pl.lds, s, p);
+        if (pl.wci == 4 && pl.wco == 2) MRDIS_LAUNCH((wino_wgrad_kernel<4, 2, true>), dim3(nblk), dim3(512), pl.lds, s, p);
+        else if (pl.wci == 4) MRDIS_LAUNCH((wino_wgrad_kernel<4, 1, true>), dim3(nblk), dim3(256), pl.lds, s, p);
+        else MRDIS_LAUNCH((wino_wgrad_kernel<2, 2, true>), dim3(nblk), dim3(256), pl.lds, s, p);
         MRDIS_CHECK_LAUNCH();
         float* db = p.bias_slab ? dbias : nullptr;
-        hipLaunchKernelGGL(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (db ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck + kd * n, n, p.splits,
+        MRDIS_LAUNCH(wino_sum_slabs_kernel, dim3(mrdis_cdiv(n + (db ? Co : 0), 64)), dim3(64, SL), 0, s, p.slab, dw_tck + kd * n, n, p.splits,
                            p.bias_slab, db, Co, 0);
         MRDIS_CHECK_LAUNCH();
     }

@@ -439,13 +439,13 @@ int mrdis_run_wino2(const float* x, int ldx, const float* w, const float* bias, 
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
 #ifdef WINO2_ABLATIONS
     const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);          // debug_mode doubles as the ablation selector in this build
-#define W2A(a) if (abl == a) { hipLaunchKernelGGL(wino2_kernel<a>, dim3(grid), dim3(NT), WINO2_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+#define W2A(a) if (abl == a) { MRDIS_LAUNCH(wino2_kernel<a>, dim3(grid), dim3(NT), WINO2_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
     W2A(1) W2A(2) W2A(3) W2A(4) W2A(8) W2A(32) W2A(40) W2A(43) W2A(16) W2A(47) W2A(64) W2A(128) W2A(256)
 #undef W2A
 #endif
     mrdis_count(MRDIS_CNT_WINO2);
-    if (u_img) hipLaunchKernelGGL((wino2_kernel<0, false, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
-    else hipLaunchKernelGGL(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    if (u_img) MRDIS_LAUNCH((wino2_kernel<0, false, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    else MRDIS_LAUNCH(wino2_kernel<0>, dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -480,8 +480,8 @@ int mrdis_run_wino2_spade(const float* x, int ldx, const float* w, const float* 
     p.u_img = u_img; p.u_bytes = wino_u_bytes(Ci, p.coTiles);
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
     mrdis_count(MRDIS_CNT_WINO2_SPADE);
-    if (u_img) hipLaunchKernelGGL((wino2_kernel<0, true, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
-    else hipLaunchKernelGGL((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    if (u_img) MRDIS_LAUNCH((wino2_kernel<0, true, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
+    else MRDIS_LAUNCH((wino2_kernel<0, true>), dim3(grid), dim3(NT), WINO2_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -593,7 +593,7 @@ extern "C" int mrdis_wino_u_job_blocks(int R, int S, int spadeC) {
 }
 extern "C" int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream) {
     if (!jobs || njobs < 1 || total_blocks < njobs) return MRDIS_EINVAL;
-    hipLaunchKernelGGL(wino_u_jobs_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const WinoUJob*>(jobs), njobs);
+    MRDIS_LAUNCH(wino_u_jobs_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const WinoUJob*>(jobs), njobs);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -846,7 +846,7 @@ int mrdis_launch_wino_wgrad2(const WinoWgradParams& p, hipStream_t s) {
     const int s_by = t % p.nby;
     const int s_n = t / p.nby;
     mrdis_count(MRDIS_CNT_WINO_WGRAD2);
-    hipLaunchKernelGGL(wino_wgrad2_kernel, dim3(p.splits * p.nCiB * p.nCoB), dim3(NT), WGRAD2_LDS, s, p, s_n, s_by, s_bx);
+    MRDIS_LAUNCH(wino_wgrad2_kernel, dim3(p.splits * p.nCiB * p.nCoB), dim3(NT), WGRAD2_LDS, s, p, s_n, s_by, s_bx);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

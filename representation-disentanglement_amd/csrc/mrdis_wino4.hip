@@ -750,7 +750,7 @@ int mrdis_run_wino4n(const float* x, int ldx, const float* bias, float* y, int l
     }
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
     mrdis_count(MRDIS_CNT_WINO4N);
-    hipLaunchKernelGGL(wino4n_kernel<0>, dim3(grid), dim3(NT4), W4N_LDS, s, p);
+    MRDIS_LAUNCH(wino4n_kernel<0>, dim3(grid), dim3(NT4), W4N_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -795,12 +795,12 @@ int mrdis_run_wino4(const float* x, int ldx, const float* bias, float* y, int ld
 #ifdef WINO4_ABLATIONS
     const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);          // debug_mode doubles as the ablation selector in this build
     p.dbg = g_w4_dbg; p.dbg_cap = g_w4_dbg_cap;
-#define W4A(a) if (abl == a) { hipLaunchKernelGGL(wino4_kernel<a>, dim3(grid), dim3(NT4), W4_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+#define W4A(a) if (abl == a) { MRDIS_LAUNCH(wino4_kernel<a>, dim3(grid), dim3(NT4), W4_LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
     W4A(1) W4A(4) W4A(5) W4A(8) W4A(32) W4A(41) W4A(45) W4A(64) W4A(65) W4A(72) W4A(96) W4A(105) W4A(192) W4A(320) W4A(576) W4A(448) W4A(832)
 #undef W4A
 #endif
     mrdis_count(MRDIS_CNT_WINO4);
-    hipLaunchKernelGGL(wino4_kernel<0>, dim3(grid), dim3(NT4), W4_LDS, s, p);
+    MRDIS_LAUNCH(wino4_kernel<0>, dim3(grid), dim3(NT4), W4_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -834,7 +834,7 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
     }
     const int grid = nblk < n_cu ? (int)nblk : n_cu;
     mrdis_count(MRDIS_CNT_WINO4_SPADE);
-    hipLaunchKernelGGL((wino4_kernel<0, true>), dim3(grid), dim3(NT4), W4_LDS, s, p);
+    MRDIS_LAUNCH((wino4_kernel<0, true>), dim3(grid), dim3(NT4), W4_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -384,20 +384,20 @@ static int launch_wino4r(Wino4rParams& p, hipStream_t s) {
 #ifdef WINO4_ABLATIONS
     {   // timing-only variants (results wrong), selected by option debug_mode: 1 no patch reads, 2 no filter reads, 4 no MFMAs, 8 | 32 no copies
         const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
-#define W4RA(a) if (abl == a) { hipLaunchKernelGGL((wino4r_kernel<NKH, a>), dim3(grid), dim3(NTR), G::LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+#define W4RA(a) if (abl == a) { MRDIS_LAUNCH((wino4r_kernel<NKH, a>), dim3(grid), dim3(NTR), G::LDS, s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
         W4RA(1) W4RA(2) W4RA(3) W4RA(4) W4RA(40) W4RA(43) W4RA(47)
 #undef W4RA
     }
     if (g_w4r_dbg != nullptr) {
         p.dbg = g_w4r_dbg; p.dbg_cap = g_w4r_dbg_cap;
         mrdis_count(MRDIS_CNT_WINO4R);
-        hipLaunchKernelGGL((wino4r_kernel<NKH, 64>), dim3(grid), dim3(NTR), G::LDS, s, p);
+        MRDIS_LAUNCH((wino4r_kernel<NKH, 64>), dim3(grid), dim3(NTR), G::LDS, s, p);
         MRDIS_CHECK_LAUNCH();
         return MRDIS_OK;
     }
 #endif
     mrdis_count(MRDIS_CNT_WINO4R);
-    hipLaunchKernelGGL((wino4r_kernel<NKH, 0>), dim3(grid), dim3(NTR), G::LDS, s, p);
+    MRDIS_LAUNCH((wino4r_kernel<NKH, 0>), dim3(grid), dim3(NTR), G::LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -361,7 +361,7 @@ int mrdis_launch_wino4_wgrad(WinoWgradParams& base, int max_splits, hipStream_t 
     p.dbg = g_w4w_dbg; p.dbg_cap = g_w4w_dbg_cap;
 #endif
     mrdis_count(MRDIS_CNT_WINO4_WGRAD);
-    hipLaunchKernelGGL(wino4_wgrad_kernel, dim3(splits * p.nCiB * p.nCoB), dim3(W_NT), W4W_LDS, s, p);
+    MRDIS_LAUNCH(wino4_wgrad_kernel, dim3(splits * p.nCiB * p.nCoB), dim3(W_NT), W4W_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
     base.splits = splits;
     return MRDIS_OK;

@@ -35,6 +35,7 @@ _SIGS = {
     'mrdis_get_option': (_L, [_c.c_char_p]),
     'mrdis_launch_count': (_L, [_c.c_char_p]),
     'mrdis_launch_count_reset': (None, []),
+    'mrdis_dynamic_lds_table': (_I, [_c.c_char_p, _I]),
     'mrdis_mix_experts_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_bwd_workspace': (_Z, [_I, _I, _I, _I]),
     'mrdis_mix_experts_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
@@ -136,6 +137,19 @@ def get_option(name):
 
 
 KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade')
+
+
+def dynamic_lds():
+    """{kernel family: largest dynamic LDS bytes it was launched with in this process} (include/mrdis.h mrdis_dynamic_lds_table; template arguments folded)"""
+    import re
+    buf = _c.create_string_buffer(16384)
+    load().mrdis_dynamic_lds_table(buf, 16384)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        expr, _, b = line.rpartition('=')
+        name = re.sub(r'<.*', '', expr.strip().lstrip('(')).strip()
+        out[name] = max(out.get(name, 0), int(b))
+    return out
 
 
 def launch_counts(reset=False):

@@ -1,6 +1,6 @@
 """Condense rocprofv3 CSV output into the small summaries committed under profiles/.
 
-  prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title]
+  prof_summary.py stats  <prefix>_kernel_stats.csv <prefix>_kernel_trace.csv <out.md> [title] [bench json with dynamic_lds_bytes]
   prof_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substr> <grid> [tag]   (commit: profiles/HEAD_COMMIT, written before the snapshot leaves)
   prof_summary.py step   <prefix>_kernel_trace.csv <out.txt.gz> <steps profiled>      the last step's dispatches in launch order
 """
@@ -10,7 +10,16 @@ import json
 import sys
 
 
-def stats(stats_csv, trace_csv, out, title):
+def stats(stats_csv, trace_csv, out, title, bench_json=None):
+    # dynamic LDS per kernel family from the profiled run's own JSON line (bench.py: dynamic_lds_bytes); the kernel trace only has the static segment
+    dyn = {}
+    if bench_json:
+        try:
+            for line in open(bench_json):
+                if line.startswith('{'):
+                    dyn = json.loads(line).get('dynamic_lds_bytes', {}) or dyn
+        except OSError:
+            pass
     rows = list(csv.DictReader(open(stats_csv)))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     lines = [f'# {title}', '', f'total kernel time {tot / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in rows)} dispatches', '',
@@ -37,11 +46,16 @@ def stats(stats_csv, trace_csv, out, title):
         wgs = 1
         for ax in 'XYZ':                               # grid sizes are in work-items per axis: workgroups = product over the three axes
             wgs *= max(1, int(r.get(f'Grid_Size_{ax}', 1) or 1)) // max(1, int(r.get(f'Workgroup_Size_{ax}', 1) or 1))
-        key = (name, wgs, r['LDS_Block_Size'], r['VGPR_Count'])
+        fam_ = name.replace('void ', '').split('<')[0].strip()
+        m_ = __import__('re').match(r'_Z(\d+)', fam_)
+        if m_:
+            fam_ = fam_[2 + len(m_.group(1)):2 + len(m_.group(1)) + int(m_.group(1))]
+        lds_ = f"{r['LDS_Block_Size']} + {dyn[fam_]} dyn" if fam_ in dyn else r['LDS_Block_Size']
+        key = (name, wgs, lds_, r['VGPR_Count'])
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         a = agg[key]; a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     lines += ['', '## per (kernel, workgroups) from kernel_trace.csv (top 40 by total time)', '',
-              '| kernel | workgroups | LDS B | VGPR | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|---|---|---|']
+              '| kernel | workgroups | LDS B (static + dynamic at launch) | VGPR | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|---|---|---|']
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         lines.append(f'| `{k[0]}` | {k[1]} | {k[2]} | {k[3]} | {a[0]} | {a[1] / 1e3:.3f} | {a[1] / a[0]:.2f} | {a[2]:.2f} | {a[3]:.2f} |')
     open(out, 'w').write('\n'.join(lines) + '\n')
@@ -96,6 +110,6 @@ if __name__ == '__main__':
     if sys.argv[1] == 'step':
         step(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     elif sys.argv[1] == 'stats':
-        stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 summary')
+        stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else 'rocprofv3 summary', sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else '', sys.argv[7] if len(sys.argv) > 7 else '')

@@ -12,13 +12,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py --no-direct --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_profiled.json 2> $OUT/bench_profiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bf16 -- python bench.py --dtype bf16 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_bf16_profiled.json 2> $OUT/bench_bf16_profiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o roof -- python bench.py --roofline-only > $OUT/${TAG}_roofline_profiled.json 2> $OUT/roofline_profiled.err
-python tools/prof_summary.py stats $OUT/bf16_kernel_stats.csv $OUT/bf16_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 --no-roofline ($TAG)"
+python tools/prof_summary.py stats $OUT/bf16_kernel_stats.csv $OUT/bf16_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 --no-roofline ($TAG)" $OUT/${TAG}_bench_bf16_profiled.json
 python tools/prof_summary.py stats $OUT/roof_kernel_stats.csv $OUT/roof_kernel_trace.csv $OUT/${TAG}_roofline_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only ($TAG): north-star conv + the step's dominant kernels, no training step"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ns -- python tools/northstar_conv.py 20 > $OUT/ns_stats.log 2>&1
 python tools/prof_summary.py stats $OUT/ns_kernel_stats.csv $OUT/ns_kernel_trace.csv $OUT/${TAG}_northstar_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python tools/northstar_conv.py 20 ($TAG): north-star conv only"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o ns_fetch -- python tools/northstar_conv.py 10 > $OUT/ns_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o ns_write -- python tools/northstar_conv.py 10 > $OUT/ns_write.log 2>&1
-python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --no-roofline ($TAG): the training step only"
+python tools/prof_summary.py stats $OUT/bench_kernel_stats.csv $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --no-roofline ($TAG): the training step only" $OUT/${TAG}_bench_profiled.json
 python tools/prof_summary.py step $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_last_step.txt.gz 7
 python tools/dispatch_counts.py $OUT/bench_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_f32.txt
 python tools/dispatch_counts.py $OUT/bf16_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt

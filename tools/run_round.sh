@@ -25,7 +25,7 @@ for step in "$@"; do
     stepprof)   ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o sp -- python bench.py --no-direct --no-cpu-baseline --no-roofline > $OUT/stepprof.json 2> $OUT/stepprof.err ); rc=$?
                 [ $rc -eq 0 ] && python tools/prof_summary.py step $OUT/sp_kernel_trace.csv $OUT/${TAG}_last_step.txt.gz 7 && python tools/dispatch_counts.py $OUT/sp_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts.txt; rm -f $OUT/sp_kernel_trace.csv; grep "timed:" $OUT/stepprof.err ;;
     stepprof_bf16) ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o spb -- python bench.py --dtype bf16 --no-direct --no-cpu-baseline --no-roofline > $OUT/stepprof_bf16.json 2> $OUT/stepprof_bf16.err ); rc=$?
-                [ $rc -eq 0 ] && python tools/prof_summary.py step $OUT/spb_kernel_trace.csv $OUT/${TAG}_last_step_bf16.txt.gz 7 && python tools/prof_summary.py stats $OUT/spb_kernel_stats.csv $OUT/spb_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 --no-roofline ($TAG)" && python tools/dispatch_counts.py $OUT/spb_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt; rm -f $OUT/spb_kernel_trace.csv; grep "timed:" $OUT/stepprof_bf16.err ;;
+                [ $rc -eq 0 ] && python tools/prof_summary.py step $OUT/spb_kernel_trace.csv $OUT/${TAG}_last_step_bf16.txt.gz 7 && python tools/prof_summary.py stats $OUT/spb_kernel_stats.csv $OUT/spb_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 --no-roofline ($TAG)" $OUT/stepprof_bf16.json && python tools/dispatch_counts.py $OUT/spb_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt; rm -f $OUT/spb_kernel_trace.csv; grep "timed:" $OUT/stepprof_bf16.err ;;
     bconv_abl)  python tools/bconv_abl.py > $OUT/bconv_abl.txt 2>&1; rc=$?; cat $OUT/bconv_abl.txt ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
