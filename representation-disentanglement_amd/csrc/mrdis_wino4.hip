@@ -38,6 +38,7 @@ struct Wino4Params {
     // out = (z - mean) * rstd * (1 + gamma) + beta and gamma itself (model.py:2440-2446) -- the 2C-channel tensor never exists
     const float* z; const float* mean; const float* rstd; float* gamma_out;
     int ldz, ldg, C;
+    unsigned z_bytes;                 // record count of z's buffer descriptor (0: no prefetch of z, see the block loop)
     unsigned long long* dbg; int dbg_cap;    // diagnostic build (ABL & 64): per (workgroup, wave) s_memtime stamps, dbg_cap per wave
 };
 
@@ -50,7 +51,8 @@ constexpr int RWP = 40, PL = 18 * RWP, RAWBUF = 8 * PL;        // 720, 5760 floa
 constexpr int RBW = 34, RBH = 18, NITEM = RBW * RBH * 2;       // raw block: 18 x 34 pixels x two 4-channel quads
 constexpr int NIT = (NITEM + 255) / 256;                       // staging items per S thread (5)
 constexpr int BIAS4 = 512;
-constexpr size_t W4_LDS = sizeof(float) * (2 * UBUF + 2 * VBUF + 2 * RAWBUF + BIAS4);
+constexpr int W4_SINK = 8 * 64;                                // floats: a 256-byte landing strip per wave for the z prefetch (SPADE form; never read)
+constexpr size_t W4_LDS = sizeof(float) * (2 * UBUF + 2 * VBUF + 2 * RAWBUF + BIAS4 + W4_SINK);
 template <int V_> struct IC4 { static constexpr int value = V_; };
 typedef unsigned u32x4_w4 __attribute__((ext_vector_type(4)));
 typedef float f32x2_w4 __attribute__((ext_vector_type(2)));
@@ -348,6 +350,32 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
     auto run = [&](auto ROLE_) {
     int mj = 0, mc = 0;
     for (int g = 0; g < total; g += 2) {
+        if constexpr (SPADE) {
+            if (mc + 2 == nch && p.z_bytes != 0) {
+                // The block's last two chunks: touch the z values its epilogue will read, so that they come into L2 / the Infinity Cache while the MFMAs of
+                // these chunks run.  The epilogue's own loads cannot be hoisted over its 144 live accumulators (hoisting four of them spilled 25-63 registers)
+                // and sit behind a bounds branch: eight exposed HBM round trips per block.  The prefetch needs a destination that is not a register (a load in
+                // flight into a register the allocator has meanwhile given to another value would clobber it): one dword per lane by LDS-DMA into a
+                // 256-byte strip per wave that nothing reads.  These loads are OLDER than every load of the two iterations, so the counted waits there cover them.
+                int n_, oy0_, ox0_, cot_; decode(mj, n_, oy0_, ox0_, cot_);
+                const int tile_ = 16 * tg + l16, oy_ = oy0_ + 4 * (tile_ >> 3), ox_ = ox0_ + 4 * (tile_ & 7);
+                const int ch_ = 32 * cot_ + 8 * cg + 4 * (kq & 1);
+                const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.z, 0, p.z_bytes, 0x00020000);
+                const unsigned m0s = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(Bs + BIAS4) + 256u * (unsigned)wave);
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const int row_ = oy_ + ip + 2 * (lane >> 5);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool ok_ = ch_ < p.C && row_ < p.H && ox_ + k < p.W;
+                        const unsigned off_ = ok_ ? 4u * (unsigned)(((n_ * p.H + row_) * p.W + ox_ + k) * p.ldz + ch_) : W4_OOB;
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(off_), "s"(m0s), "s"(rs_z) : "memory");
+                    }
+                }
+            }
+        }
         iteration(IC4<0>{}, ROLE_, g); iteration(IC4<1>{}, ROLE_, g + 1);
         mc += 2;
         if (mc != nch) continue;
@@ -819,6 +847,7 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
     p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    { const long long zb = 4LL * ((long long)(N * H) * W - 1) * ldz + 4LL * C; p.z_bytes = (zb < 0xffffffe0LL && mrdis_opt(MRDIS_OPT_MODE) != 2005) ? (unsigned)zb : 0u; }      // (debug_mode 2005: no z prefetch, for A/B)
     p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
     p.coTiles = mrdis_cdiv(C, 32);
     const long long nblk = (long long)N * p.nby * p.nbx * p.coTiles;

@@ -7,6 +7,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mrdis  # noqa: E402
+
+if len(sys.argv) > 1:
+    mrdis.hip.load(sys.argv[1])                       # another build of the library (A/B)
 from tools.wino4_check import timeit  # noqa: E402
 
 hip = mrdis.hip
@@ -28,6 +31,14 @@ for (N, Ci, C, H) in [(32, 32, 32, 256), (32, 64, 64, 128), (32, 128, 128, 64), 
             out.append(f'{name} declined'); continue
         bufs = res
         t = timeit(lambda: hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img, out=bufs, stats_ready=True))
+        if w4:
+            hip.set_option('debug_mode', 2005)          # F(4x4): without the z prefetch
+            t_np = timeit(lambda: hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img, out=bufs, stats_ready=True))
+            r_np = hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img)
+            hip.set_option('debug_mode', -1)
+            t2 = timeit(lambda: hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img, out=bufs, stats_ready=True))
+            assert torch.equal(r_np[0], res[0]) and torch.equal(r_np[1], res[1])
+            name = f'{name} [no z prefetch {t_np:.1f} us, again with {t2:.1f} us]'
         if ref is None:
             ref = res[0].clone()
             out.append(f'{name} fmt {hip.wino_u_format(Ci, 2 * C, C)}: {t:.1f} us')
