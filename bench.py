@@ -153,6 +153,18 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     if not extras:          # tools/northstar_conv.py under rocprofv3 --pmc: only launches of the north-star shape
         return {'us_per_launch': round(us_rot, 2), 'achieved': round(NS_BYTES / (us_rot * 1e-6) / 1e9, 1)}
     us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
+    # the ceiling of a store-only kernel on THIS device, over the same rotating output buffers (236 MB each): the layer's algorithmic traffic is 89 % stores
+    for i in range(4):
+        hip.stream_fill(ys[i % nrot])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(iters):
+        hip.stream_fill(ys[i % nrot])
+    e1.record()
+    torch.cuda.synchronize()
+    us_fill = e0.elapsed_time(e1) * 1e3 / iters
+    fill_gbs = ys[0].numel() * 4 / (us_fill * 1e-6) / 1e9
     del xs, ys
     n6 = NS['N'] * 256 * 256
     bytes6 = 4 * (n6 * NS['Ci'] + n6 * NS['Co'] + NS['Co'] * NS['Ci'] * 9 + NS['Co'])
@@ -177,6 +189,10 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
             'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us_rot, 2),
             'timing': f'{iters} launches over {nrot} rotating x/y pairs (1.06 GB, beyond the 256 MiB Infinity Cache), HIP events',
             'output_checked': f'vs torch fp32 conv2d on the host, max rel err {err:.1e}',
+            'store_only_ceiling': {'gbs': round(fill_gbs, 1), 'us_for_this_output': round(us_fill, 2), 'kernel_time_over_it': round(us_rot / us_fill, 3),
+                                   'note': 'mrdis_stream_fill: a kernel that ONLY writes the 236 MB output (non-temporal 16-byte stores, contiguous run per workgroup, nothing '
+                                           'read, same rotating buffers, this run): the rate this device takes stores at.  The convolution writes the same bytes, reads 30 MB and '
+                                           'computes in kernel_time_over_it x that time; the headline frac stays achieved / 8 TB/s'},
             'single_buffer': {'us_per_launch': round(us_one, 2), 'achieved': gbs(NS_BYTES, us_one), 'frac': round(gbs(NS_BYTES, us_one) / HBM_PEAK_GBS, 4)},
             'in_step_256': {'shape': '32x4x256x256 -> 32ch', 'algorithmic_bytes': bytes6, 'us_per_launch': round(us6, 2),
                             'achieved': gbs(bytes6, us6), 'frac': round(gbs(bytes6, us6) / HBM_PEAK_GBS, 4)},

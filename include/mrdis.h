@@ -230,6 +230,9 @@ int mrdis_cast_view(const void* src, int ld_src, int src_dtype, int C_src, void*
 /* Word-wise copy src -> dst by a kernel (nbytes % 4 == 0, 4-byte aligned).  src may be pinned host memory: the way small
  * host -> device transfers inside a step avoid the copy engine's host round trip (the reference's CPU-drawn eps, model.py:3159-3162). */
 int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, void* stream);
+/* Measurement probe: fills n_floats (multiple of 4, 16-byte aligned) with `value` by non-temporal 16-byte stores and reads nothing: the rate a store-only kernel
+ * reaches on this device (bench.py reports it beside the north-star convolution, whose traffic is 89 % stores). */
+int mrdis_stream_fill(float* dst, long long n_floats, float value, void* stream);
 
 /* A SPADE block's  InstanceNorm(z) * (1 + gamma(s)) + beta(s)  (model.py:2440-2446) with the gamma | beta convolution and the modulation in
  * ONE launch: x = the si_layers output (N, H, W, Ci), w_tck = the fused [9][Ci][2 C] filter (gamma couts first), bias (2 C), z (N, H, W, C)

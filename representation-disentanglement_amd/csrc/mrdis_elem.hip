@@ -1867,6 +1867,25 @@ extern "C" int mrdis_copy_bytes(const void* src, void* dst, long long nbytes, vo
     return MRDIS_OK;
 }
 
+// Streaming-store probe: n_vec4 float4 written with non-temporal 16-byte stores, nothing read -- what the memory system takes when a kernel ONLY writes
+// (bench.py times it over the north-star conv's own output buffers: that layer is 89 % stores, so this, not the 8 TB/s of the data sheet, is its ceiling).
+__global__ __launch_bounds__(256) void stream_fill_kernel(f32x4* __restrict__ dst, long long n_vec4, float value) {
+    // a workgroup owns one contiguous run of the buffer (XCD-aware: neighbouring runs on the same XCD), a wave-instruction writes 1 KB of it
+    const f32x4 v = {value, value, value, value};
+    const long long per = (n_vec4 + gridDim.x - 1) / gridDim.x;
+    const long long b = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const long long lo = b * per, hi = lo + per < n_vec4 ? lo + per : n_vec4;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(v, dst + i);
+}
+extern "C" int mrdis_stream_fill(float* dst, long long n_floats, float value, void* stream) {
+    if (!dst || n_floats < 4 || (n_floats & 3) != 0 || (((uintptr_t)dst) & 15) != 0) return MRDIS_EINVAL;
+    const long long nv = n_floats / 4;
+    long long nb = (nv + 255) / 256; if (nb > 2048) nb = 2048;
+    MRDIS_LAUNCH(stream_fill_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4*>(dst), nv, value);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // ------------------------------------------------------------------ misc
 // ---------------------------------------------------------------------------------------------- process-wide switches
 namespace {

@@ -42,6 +42,7 @@ _SIGS = {
     'mrdis_mix_experts_routed_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'mrdis_mix_experts_routed_bwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     'mrdis_copy_bytes': (_I, [_P, _P, _L, _P]),
+    'mrdis_stream_fill': (_I, [_P, _L, _F, _P]),
     'mrdis_instnorm_stats': (_I, [_P, _I, _P, _P, _P, _Z, _I, _L, _I, _F, _I, _P]),
     'mrdis_conv2d_fwd_spade': (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     'mrdis_wino_u_job_bytes': (_Z, []),
@@ -137,6 +138,13 @@ def get_option(name):
 
 
 KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade')
+
+
+def stream_fill(t, value=0.0):
+    """store-only probe over a dense fp32 tensor (include/mrdis.h mrdis_stream_fill)"""
+    assert t.dtype == torch.float32 and t.numel() % 4 == 0
+    _chk(load().mrdis_stream_fill(t.data_ptr(), t.numel(), float(value), _stream()), 'stream_fill')
+    return t
 
 
 def dynamic_lds():
