@@ -25,10 +25,21 @@ typedef unsigned bq_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned bq_u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
-constexpr int Q_KC = 32, Q_TH = 16, Q_TW = 32, Q_INH = Q_TH + 2, Q_INW = Q_TW + 2, Q_NPIX = Q_INH * Q_INW;      // 18 x 34 = 612 halo pixels
-constexpr int Q_XP = (Q_NPIX + 15) / 16;               // 39 DMA pieces (1 KB = 16 rows of 64 B) per pixel image
-constexpr int Q_XBYTES = Q_XP * 1024;                  // 39,936
-constexpr int Q_NXI = 5;                               // pixel pieces per wave: k = wave + 8 i (k < 39)
+constexpr int Q_TW = 32, Q_INW = Q_TW + 2;
+// geometry of one instantiation: NW waves per workgroup (each owns two rows of 32 positions), KC channels per item
+template <int NW, int KC> struct QGeo {
+    static constexpr int TH = 2 * NW, INH = TH + 2, NPIX = INH * Q_INW;          // 16 x 32 tile: 18 x 34 = 612 halo pixels | 8 x 32 tile: 340
+    static constexpr int RB = 2 * KC;                  // bytes of an image row (a pixel's / a cout's KC channels): 64 | 32
+    static constexpr int PR = RB / 16;                 // 16-byte pieces per row: 4 | 2
+    static constexpr int RPP = 1024 / RB;              // rows per DMA piece: 16 | 32
+    static constexpr int XP = (NPIX + RPP - 1) / RPP;  // DMA pieces of a pixel image: 39 | 11
+    static constexpr int XBYTES = XP * 1024;
+    static constexpr int NXI = (XP + NW - 1) / NW;     // per wave: k = wave + NW i (k < XP)
+    static constexpr int KS = KC / 16;                 // 16-channel k-steps per tap
+    // swizzle of piece p of row R: slot = p ^ f(R); f makes the 16 lanes that one ds_read_b128 cycle serves (lanes 0-3, 12-15, 20-27 | 4-11, 16-19, 28-31 of consecutive
+    // rows) hit all 64 banks once: 64-byte rows: f = (R >> 2) & 3; 32-byte rows: f = (R >> 3) & 1 (rows 8 and 24 apart share a bank group: both flip the bit)
+    __device__ static __forceinline__ int f(int R) { return RB == 64 ? ((R >> 2) & 3) : ((R >> 3) & 1); }
+};
 constexpr int Q_BIAS = 1024;
 constexpr unsigned Q_OOB = 0xfffffff0u;
 template <int V_> struct QIC { static constexpr int value = V_; };
@@ -52,18 +63,25 @@ struct BConv4Params {
     const void* z; const float* mean; const float* rstd; void* gamma_out;
     int ldz, ldg, C;
     int wide;                                         // 16-byte output stores: Cout (C) % 8 == 0, output views 16-byte aligned with ld % 8 == 0
+    int prio;                                         // 1: s_setprio 1 for waves 4-7 (the younger wave of every SIMD), 2: for waves 0-3, 0: none
+    unsigned long long* dbg; int dbg_cap;             // diagnostic build (-DBCONV4_ABLATIONS, ABL & 64): per (workgroup < 4, wave) s_memtime stamps
 };
 
 // WC: 32-cout groups per workgroup (2: 64 couts, 1: the layers with <= 32 couts)
 // ABL (timing-only, -DBCONV4_ABLATIONS): 1 no MFMAs, 2 no DMA after the prologue, 4 no output stores, 8 no wait for the DMA before the barrier
-template <int WC, bool SPADE = false, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
+// NW, KC: 8 waves x 32-channel items (ONE workgroup per CU: 16 x 32 tiles) | 4 waves x 16-channel items (TWO independent workgroups per CU, 8 x 32 tiles: the
+// epilogue, the DMA wait and the barrier of one run under the MFMAs of the other -- in-kernel stamps of the 8-wave form showed the two waves of a SIMD in lockstep,
+// the older one done after ~4,000 cycles of an item and idle at the barrier for ~2,400 while the younger one needed ~6,100, and both in their epilogues together)
+template <int WC, bool SPADE = false, int ABL = 0, int NW = 8, int KC = 32>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const BConv4Params p) {
     static_assert(!SPADE || WC == 2, "SPADE: 32 gamma + 32 beta couts per workgroup");
-    constexpr int BN = 32 * WC, NT = 512;
+    using G = QGeo<NW, KC>;
+    constexpr int BN = 32 * WC, NT = 64 * NW;
+    constexpr int Q_TH = G::TH, Q_NPIX = G::NPIX, Q_XP = G::XP, Q_XBYTES = G::XBYTES, Q_NXI = G::NXI, Q_KC = KC, RB = G::RB;
     constexpr int WROWS = 9 * BN;                      // rows of the filter image
-    constexpr int WP = WROWS / 16;                     // its DMA pieces (36 | 18)
-    constexpr int NWI = (WP + 7) / 8;                  // per wave (5 | 3): k = wave + 8 i (k < WP)
-    constexpr int WBYTES = WROWS * 64;                 // 36,864 | 18,432
+    constexpr int WP = WROWS * RB / 1024;              // its DMA pieces (36 | 18 at 64-byte rows, 18 | 9 at 32-byte rows)
+    constexpr int NWI = (WP + NW - 1) / NW;            // per wave: k = wave + NW i (k < WP)
+    constexpr int WBYTES = WROWS * RB;
     constexpr int XBASE = 2 * WBYTES;                  // LDS: [filter stage 0][filter stage 1][pixels stage 0][pixels stage 1][bias]
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_q[];
     float* const Bs = reinterpret_cast<float*>(smem_q + XBASE + 2 * Q_XBYTES);
@@ -76,15 +94,15 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int pix = (2 * wave + r + 1 + p.dh[t]) * Q_INW + (e + 1 + p.dw[t]);
-            xaddr[r][t] = XBASE + pix * 64 + ((half ^ ((pix >> 2) & 3)) << 4);
+            xaddr[r][t] = XBASE + pix * RB + ((half ^ G::f(pix)) << 4);
         }
-    const int aaddr = e * 64 + ((half ^ ((e >> 2) & 3)) << 4);           // filter row e of a 32-cout group: + (t * BN + 32 j) * 64, k-step 1: ^ 32 (the row offsets are multiples of 2048)
+    const int aaddr = e * RB + ((half ^ G::f(e)) << 4);                  // filter row e of a 32-cout group: + (t * BN + 32 j) * RB, k-step 1: ^ 32 (the row offsets do not touch the swizzle bits)
 
     // ---- DMA roles (item-invariant): which (row, piece) of the images lane `lane` of this wave copies with its i-th wave-instruction
     unsigned x_rel[Q_NXI]; int x_yx[Q_NXI];            // x_yx = (iy << 8) | ix, or -1
 #pragma unroll
     for (int i = 0; i < Q_NXI; ++i) {
-        const int k = wave + 8 * i, R = 16 * k + (lane >> 2), pc = (lane & 3) ^ ((R >> 2) & 3);
+        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR, pc = (lane % G::PR) ^ G::f(R);
         const int iy = R / Q_INW, ix = R - iy * Q_INW;
         x_yx[i] = (k < Q_XP && R < Q_NPIX) ? ((iy << 8) | ix) : -1;
         x_rel[i] = 2u * (unsigned)((iy * p.W + ix) * p.ldin + 8 * pc);
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
     unsigned w_rel[NWI]; int w_co[NWI];                // w_co: cout within the tile, or -1
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-        const int k = wave + 8 * i, R = 16 * k + (lane >> 2), pc = (lane & 3) ^ ((R >> 2) & 3);
+        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR, pc = (lane % G::PR) ^ G::f(R);
         const int t = R / BN, co = R - t * BN;
         w_co[i] = k < WP ? co : -1;
         // SPADE: local couts 0..31 are the gamma couts of the workgroup's 32 channels, 32..63 their beta couts (C further on in the filter)
@@ -151,8 +169,8 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(off), "s"(m0v), "s"(rs) : "memory");
     };
-    auto dma_x = [&](int stage, int i) { if (wave + 8 * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, xo[i], (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + 8 * i))); };
-    auto dma_w = [&](int stage, int i) { if (wave + 8 * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, wo[i], (unsigned)(stage * WBYTES + 1024 * (wave + 8 * i))); };
+    auto dma_x = [&](int stage, int i) { if (wave + NW * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, xo[i], (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + NW * i))); };
+    auto dma_w = [&](int stage, int i) { if (wave + NW * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, wo[i], (unsigned)(stage * WBYTES + 1024 * (wave + NW * i))); };
 
     f32x16 acc[2][WC];
 #pragma unroll
@@ -162,6 +180,7 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[r][j][k] = 0.f;
 
+    if ((p.prio == 1 && wave >= NW / 2) || (p.prio == 2 && wave < NW / 2)) __builtin_amdgcn_s_setprio(1);
     // ---- prologue: item 0 into stage 0
     load_unit();
     next_offsets();
@@ -172,9 +191,20 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int n_stamp = 0;
+    auto stamp = [&](int tag) {
+        if constexpr ((ABL & 64) != 0) {
+            if (p.dbg != nullptr && blockIdx.x < 4 && n_stamp < p.dbg_cap) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) p.dbg[((long long)(blockIdx.x * 8 + wave)) * p.dbg_cap + n_stamp] = (t << 4) | (unsigned)tag;
+                ++n_stamp;
+            }
+        }
+    };
     int mj = 0, mc = 0;
     auto iteration = [&](auto P_) {
         constexpr int P = decltype(P_)::value;
+        stamp(1);
         const unsigned char* wa0 = smem_q + q_opaque(P * WBYTES + aaddr);
         const unsigned char* wa1 = smem_q + q_opaque(P * WBYTES + (aaddr ^ 32));
         const unsigned char* xs = smem_q + P * Q_XBYTES;                // + xaddr[r][t] (^ 32): the stage offset stays in the instruction's immediate
@@ -182,18 +212,20 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
         // operand registers in a ring of three: the reads of step s + 2 are issued in step s (a full step of MFMAs -- this wave's and its SIMD partner's --
         // covers their LDS latency; one step ahead left the matrix pipe waiting: 68 us of MFMA + operand reads + barriers against 37 us of MFMAs on 128 -> 256 at 64x64)
         bq_bf16x8 af[3][WC], bf[3][2];
+        constexpr int NSTEP = 9 * G::KS;
         auto ld_ops = [&](int slot, int s1) {
-            const int t1 = s1 >> 1, ks1 = s1 & 1;
+            const int t1 = s1 / G::KS, ks1 = s1 % G::KS;
 #pragma unroll
-            for (int j = 0; j < WC; ++j) af[slot][j] = *reinterpret_cast<const bq_bf16x8*>((ks1 ? wa1 : wa0) + (t1 * BN + 32 * j) * 64);
+            for (int j = 0; j < WC; ++j) af[slot][j] = *reinterpret_cast<const bq_bf16x8*>((ks1 ? wa1 : wa0) + (t1 * BN + 32 * j) * RB);
 #pragma unroll
             for (int r = 0; r < 2; ++r) bf[slot][r] = *reinterpret_cast<const bq_bf16x8*>(xs + (xaddr[r][t1] ^ (ks1 << 5)));
         };
         ld_ops(0, 0); ld_ops(1, 1);
+        static_assert(Q_NXI + NWI <= NSTEP, "one DMA piece per step");
 #pragma unroll
-        for (int s_ = 0; s_ < 18; ++s_) {
+        for (int s_ = 0; s_ < NSTEP; ++s_) {
             const int c_ = s_ % 3;
-            if (s_ + 2 < 18) ld_ops((s_ + 2) % 3, s_ + 2);
+            if (s_ + 2 < NSTEP) ld_ops((s_ + 2) % 3, s_ + 2);
             if (s_ < Q_NXI) dma_x(P ^ 1, s_);
             else if (s_ < Q_NXI + NWI) dma_w(P ^ 1, s_ - Q_NXI);
 #pragma unroll
@@ -202,14 +234,83 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
                 for (int j = 0; j < WC; ++j) { if (ABL & 1) acc[r][j][0] += (float)af[c_][j][0] * (float)bf[c_][r][0]; else acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c_][j], bf[c_][r], acc[r][j], 0, 0, 0); }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(2);
         if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of item i + 1 have landed
+        stamp(3);
         __syncthreads();
+        stamp(4);
 
         if (++mc == p.nchunks) {
             // ---- epilogue of unit mj: D[cout][position]; a lane owns positions (2 wave + r, e) and the couts 8 g + 4 half .. + 3 (g = 0..3) of each 32-cout block
+            stamp(5);
             int n, a0, b0, co0; decode(mj, n, a0, b0, co0);
             mc = 0; ++mj;
             const int b = b0 + e;
+            // block-uniform fast path: the whole 16 x 32 tile and all BN couts lie inside, 16-byte stores -- no per-lane predicates, no branches per store (the
+            // general path below tests every store: its epilogue took ~4,200 cycles per unit, a third of an item's time on the 256x256 level)
+            const bool full = p.wide && a0 + Q_TH <= p.H && b0 + Q_TW <= p.W && (SPADE ? co0 / 2 + 32 <= p.C : co0 + BN <= p.Cout) && !(ABL & 4);
+            if (full) {
+                const float slope = p.lrelu ? 0.2f : 1.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const long long pix = (long long)(n * p.H + a0 + 2 * wave + r) * p.W + b;
+                    if (SPADE) {
+                        const int c0 = co0 / 2;
+                        const __bf16* zp = reinterpret_cast<const __bf16*>(p.z) + pix * p.ldz + c0 + 4 * half;
+                        bq_bf16x4 zq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) zq[q] = *reinterpret_cast<const bq_bf16x4*>(zp + 8 * q);
+                        __bf16* mixp = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout + c0;
+                        __bf16* gamp = reinterpret_cast<__bf16*>(p.gamma_out) + pix * p.ldg + c0;
+                        bq_u32x2 pko[4], pkg[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ch = c0 + 8 * q + 4 * half;
+                            const float4 mu = *reinterpret_cast<const float4*>(p.mean + (long long)n * p.C + ch);
+                            const float4 rs = *reinterpret_cast<const float4*>(p.rstd + (long long)n * p.C + ch);
+                            const float4 bg = *reinterpret_cast<const float4*>(Bs + ch);
+                            const float4 bb = *reinterpret_cast<const float4*>(Bs + p.C + ch);
+                            const float g[4] = {acc[r][0][4 * q] + bg.x, acc[r][0][4 * q + 1] + bg.y, acc[r][0][4 * q + 2] + bg.z, acc[r][0][4 * q + 3] + bg.w};
+                            const float bt[4] = {acc[r][WC - 1][4 * q] + bb.x, acc[r][WC - 1][4 * q + 1] + bb.y, acc[r][WC - 1][4 * q + 2] + bb.z, acc[r][WC - 1][4 * q + 3] + bb.w};
+                            const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, r_[4] = {rs.x, rs.y, rs.z, rs.w};
+                            bq_bf16x4 o, og;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float gr = (float)(__bf16)g[k], br = (float)(__bf16)bt[k];
+                                og[k] = (__bf16)g[k];
+                                o[k] = (__bf16)(((float)zq[q][k] - m_[k]) * r_[k] * (1.f + gr) + br);
+                            }
+                            pko[q] = __builtin_bit_cast(bq_u32x2, o); pkg[q] = __builtin_bit_cast(bq_u32x2, og);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const bq_u32x4 wo_ = bq_pair8(pko[q], pko[q + 1]), wg = bq_pair8(pkg[q], pkg[q + 1]);
+                            *reinterpret_cast<bq_u32x4*>(mixp + 8 * (q + half)) = wo_; *reinterpret_cast<bq_u32x4*>(gamp + 8 * (q + half)) = wg;
+                        }
+                    } else {
+                        __bf16* dst = reinterpret_cast<__bf16*>(p.out) + pix * p.ldout + co0;
+#pragma unroll
+                        for (int j = 0; j < WC; ++j) {
+                            bq_u32x2 pk[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 bb = *reinterpret_cast<const float4*>(Bs + co0 + 32 * j + 8 * q + 4 * half);
+                                float v[4] = {acc[r][j][4 * q] + bb.x, acc[r][j][4 * q + 1] + bb.y, acc[r][j][4 * q + 2] + bb.z, acc[r][j][4 * q + 3] + bb.w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], slope * v[k]);      // LeakyReLU(0.2), or the identity (slope 1): same values as the select
+                                bq_bf16x4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                                pk[q] = __builtin_bit_cast(bq_u32x2, o);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2) *reinterpret_cast<bq_u32x4*>(dst + 32 * j + 8 * (q + half)) = bq_pair8(pk[q], pk[q + 1]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < WC; ++j)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[r][j][k] = 0.f;
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int a = a0 + 2 * wave + r;
@@ -290,6 +391,8 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) acc[r][j][k] = 0.f;
             }
+            }
+            stamp(6);
         }
     };
     for (int i = 0; i < total; i += 2) {
@@ -299,6 +402,9 @@ __global__ __launch_bounds__(512, 1) void bconv4_kernel(const BConv4Params p) {
 }
 
 namespace {
+constexpr size_t q_lds(int WC, int NW, int KC) {
+    return 2 * (size_t)(9 * 32 * WC * 2 * KC) + 2 * (size_t)((((2 * NW + 2) * Q_INW + 1024 / (2 * KC) - 1) / (1024 / (2 * KC))) * 1024) + sizeof(float) * Q_BIAS;
+}
 int q_ncu() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -311,9 +417,16 @@ int q_ncu() {
     }
     return n_cu;
 }
-size_t q_lds(int WC) { return 2 * (size_t)(9 * 32 * WC * 64) + 2 * (size_t)Q_XBYTES + sizeof(float) * Q_BIAS; }
+// The kernel is written for NW waves x KC-channel items (QGeo); only 8 x 32 is instantiated.  Measured and dropped (round 5): TWO independent 4-wave workgroups per CU
+// on 8 x 32 tiles with 16-channel items (63 KB of LDS each), so that one workgroup's epilogue / DMA wait / barrier would run under the other's MFMAs: 102 vs 84 us
+// (128 -> 256 at 64x64), 134 vs 107 us (32 -> 64 at 256x256) -- every workgroup stages its own filter image and an item is half as long (twice the barriers per MFMA).
+constexpr bool q_two_per_cu(long long) { return false; }
 }  // namespace
 
+#ifdef BCONV4_ABLATIONS
+static unsigned long long* g_q_dbg = nullptr; static int g_q_dbg_cap = 0;
+extern "C" void mrdis_debug_bconv4_stamps(void* buf, int cap_per_wave) { g_q_dbg = (unsigned long long*)buf; g_q_dbg_cap = cap_per_wave; }
+#endif
 // MRDIS_EUNSUPPORTED: the caller (mrdis_run_bconv) takes bconv3_kernel / bconv_kernel
 int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
     if (!mrdis_opt(MRDIS_OPT_BCONV4)) return MRDIS_EUNSUPPORTED;
@@ -334,28 +447,33 @@ int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
     p.N = t.N; p.H = t.Hin; p.W = t.Win; p.Cin = t.Cin; p.ldin = t.ldin; p.Cout = t.Cout; p.ldout = t.ldout;
     p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
     const int WC = t.Cout > 32 ? 2 : 1, BN = 32 * WC;
-    p.tilesA = mrdis_cdiv(t.Hin, Q_TH); p.tilesB = mrdis_cdiv(t.Win, Q_TW); p.coTiles = mrdis_cdiv(t.Cout, BN);
-    const long long units = (long long)t.N * p.tilesA * p.tilesB * p.coTiles;
-    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     const int n_cu = q_ncu();
     if (n_cu < 0) return n_cu == -1 ? MRDIS_ELAUNCH : MRDIS_EUNSUPPORTED;
-    // the 512-position tile needs the launch to fill the chip: below one unit per CU the 256-position tiles of bconv3_kernel spread the layer over twice the CUs
-    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < n_cu) return MRDIS_EUNSUPPORTED;
-    p.units = (int)units; p.nchunks = t.Cin / Q_KC; p.lrelu = (t.epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    const bool two = q_two_per_cu(0);
+    const int TH = two ? 8 : 16, KC = two ? 16 : 32;
+    p.tilesA = mrdis_cdiv(t.Hin, TH); p.tilesB = mrdis_cdiv(t.Win, Q_TW); p.coTiles = mrdis_cdiv(t.Cout, BN);
+    const long long units = (long long)t.N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    // the launch has to fill the chip: below one unit per workgroup slot bconv3_kernel / bconv_kernel's smaller tiles spread the layer over more CUs
+    const int slots = two ? 2 * n_cu : n_cu;
+    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < slots) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = t.Cin / KC; p.lrelu = (t.epilogue & MRDIS_EPI_LRELU) ? 1 : 0;
+    p.prio = mrdis_opt(MRDIS_OPT_MODE) == 3001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 3002 ? 2 : 0);
     p.wide = (t.Cout % 8 == 0 && t.ldout % 8 == 0 && ((uintptr_t)t.out & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
-    const int grid = units < n_cu ? (int)units : n_cu;
+    const int grid = units < slots ? (int)units : slots;
     mrdis_count(MRDIS_CNT_BCONV4);
 #ifdef BCONV4_ABLATIONS
+    p.dbg = g_q_dbg; p.dbg_cap = g_q_dbg_cap;
     if (WC == 2) {
         const int abl = (int)mrdis_opt(MRDIS_OPT_MODE);
 #define QA(a) if (abl == a) { (void)hipFuncSetAttribute((const void*)bconv4_kernel<2, false, a>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        MRDIS_LAUNCH((bconv4_kernel<2, false, a>), dim3(grid), dim3(512), q_lds(2), s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
-        QA(1) QA(2) QA(4) QA(8) QA(6) QA(10) QA(14) QA(7) QA(15)
+        MRDIS_LAUNCH((bconv4_kernel<2, false, a>), dim3(grid), dim3(512), q_lds(2, 8, 32), s, p); MRDIS_CHECK_LAUNCH(); return MRDIS_OK; }
+        QA(1) QA(2) QA(4) QA(8) QA(6) QA(14) QA(64) QA(78)
 #undef QA
     }
 #endif
-    if (WC == 2) MRDIS_LAUNCH(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2), s, p);
-    else MRDIS_LAUNCH(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1), s, p);
+    if (WC == 2) MRDIS_LAUNCH(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2, 8, 32), s, p);
+    else MRDIS_LAUNCH(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1, 8, 32), s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -374,17 +492,21 @@ int mrdis_run_bconv4_spade(const void* x, int ldx, const void* w_bf16, const flo
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
     p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
     p.in_bytes = (unsigned)in_b; p.w_bytes = (unsigned)w_b;
-    p.tilesA = mrdis_cdiv(H, Q_TH); p.tilesB = mrdis_cdiv(W, Q_TW); p.coTiles = mrdis_cdiv(C, 32);
-    const long long units = (long long)N * p.tilesA * p.tilesB * p.coTiles;
-    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     const int n_cu = q_ncu();
     if (n_cu < 0) return n_cu == -1 ? MRDIS_ELAUNCH : MRDIS_EUNSUPPORTED;
-    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < n_cu) return MRDIS_EUNSUPPORTED;
-    p.units = (int)units; p.nchunks = Ci / Q_KC; p.lrelu = 0;
+    const bool two = q_two_per_cu(0);
+    const int TH = two ? 8 : 16, KC = two ? 16 : 32;
+    p.tilesA = mrdis_cdiv(H, TH); p.tilesB = mrdis_cdiv(W, Q_TW); p.coTiles = mrdis_cdiv(C, 32);
+    const long long units = (long long)N * p.tilesA * p.tilesB * p.coTiles;
+    if (units > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    const int slots = two ? 2 * n_cu : n_cu;
+    if (mrdis_opt(MRDIS_OPT_BCONV4) < 2 && units < slots) return MRDIS_EUNSUPPORTED;
+    p.units = (int)units; p.nchunks = Ci / KC; p.lrelu = 0;
+    p.prio = mrdis_opt(MRDIS_OPT_MODE) == 3001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 3002 ? 2 : 0);
     p.wide = (C % 8 == 0 && ldmix % 8 == 0 && ldg % 8 == 0 && ((((uintptr_t)mix) | ((uintptr_t)gamma)) & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) ? 1 : 0;
-    const int grid = units < n_cu ? (int)units : n_cu;
+    const int grid = units < slots ? (int)units : slots;
     mrdis_count(MRDIS_CNT_BCONV4_SPADE);
-    MRDIS_LAUNCH((bconv4_kernel<2, true>), dim3(grid), dim3(512), q_lds(2), s, p);
+    MRDIS_LAUNCH((bconv4_kernel<2, true>), dim3(grid), dim3(512), q_lds(2, 8, 32), s, p);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
