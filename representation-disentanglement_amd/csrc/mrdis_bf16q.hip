@@ -27,8 +27,8 @@ typedef unsigned bq_u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int Q_TW = 32, Q_INW = Q_TW + 2;
 // geometry of one instantiation: NW waves per workgroup (each owns two rows of 32 positions), KC channels per item
-template <int NW, int KC> struct QGeo {
-    static constexpr int TH = 2 * NW, INH = TH + 2, NPIX = INH * Q_INW;          // 16 x 32 tile: 18 x 34 = 612 halo pixels | 8 x 32 tile: 340
+template <int NW, int KC, int RPW = 2> struct QGeo {
+    static constexpr int TH = RPW * NW, INH = TH + 2, NPIX = INH * Q_INW;          // 16 x 32 tile: 18 x 34 = 612 halo pixels | 8 x 32 tile: 340
     static constexpr int RB = 2 * KC;                  // bytes of an image row (a pixel's / a cout's KC channels): 64 | 32
     static constexpr int PR = RB / 16;                 // 16-byte pieces per row: 4 | 2
     static constexpr int RPP = 1024 / RB;              // rows per DMA piece: 16 | 32
@@ -36,9 +36,10 @@ template <int NW, int KC> struct QGeo {
     static constexpr int XBYTES = XP * 1024;
     static constexpr int NXI = (XP + NW - 1) / NW;     // per wave: k = wave + NW i (k < XP)
     static constexpr int KS = KC / 16;                 // 16-channel k-steps per tap
-    // swizzle of piece p of row R: slot = p ^ f(R); f makes the 16 lanes that one ds_read_b128 cycle serves (lanes 0-3, 12-15, 20-27 | 4-11, 16-19, 28-31 of consecutive
-    // rows) hit all 64 banks once: 64-byte rows: f = (R >> 2) & 3; 32-byte rows: f = (R >> 3) & 1 (rows 8 and 24 apart share a bank group: both flip the bit)
-    __device__ static __forceinline__ int f(int R) { return RB == 64 ? ((R >> 2) & 3) : ((R >> 3) & 1); }
+    // swizzle of piece p of a row: slot = p ^ f(c), c = the row's index along the axis the lanes of a read walk (filter image: the cout row; pixel image: the
+    // COLUMN of the pixel -- not its linear index, so that the tap rows of a lane differ by an immediate offset only).  f makes the 16 lanes that one ds_read_b128
+    // cycle serves (lanes 0-3, 12-15, 20-27 | 4-11, 16-19, 28-31: consecutive c) hit all 64 banks once: 64-byte rows f = (c >> 2) & 3; 32-byte rows f = (c >> 3) & 1
+    __device__ static __forceinline__ int f(int c) { return RB == 64 ? ((c >> 2) & 3) : ((c >> 3) & 1); }
 };
 constexpr int Q_BIAS = 1024;
 constexpr unsigned Q_OOB = 0xfffffff0u;
@@ -72,10 +73,12 @@ struct BConv4Params {
 // NW, KC: 8 waves x 32-channel items (ONE workgroup per CU: 16 x 32 tiles) | 4 waves x 16-channel items (TWO independent workgroups per CU, 8 x 32 tiles: the
 // epilogue, the DMA wait and the barrier of one run under the MFMAs of the other -- in-kernel stamps of the 8-wave form showed the two waves of a SIMD in lockstep,
 // the older one done after ~4,000 cycles of an item and idle at the barrier for ~2,400 while the younger one needed ~6,100, and both in their epilogues together)
-template <int WC, bool SPADE = false, int ABL = 0, int NW = 8, int KC = 32>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const BConv4Params p) {
+// RPW: rows of 32 positions per wave (2: two waves per SIMD share the matrix pipe | 4 with NW = 4: ONE wave per SIMD owns 128 positions x 64 couts, 8 MFMAs per 6 operand reads)
+// FLIP: the tap table is the data gradient's (tap t reads pixel (1 - t / 3, 1 - t % 3) instead of (t / 3 - 1, t % 3 - 1)); p.widx[t] names the filter tap either way
+template <int WC, bool SPADE = false, int ABL = 0, int NW = 8, int KC = 32, int RPW = 2, bool FLIP = false>
+__global__ __launch_bounds__(64 * NW, 1) void bconv4_kernel(const BConv4Params p) {
     static_assert(!SPADE || WC == 2, "SPADE: 32 gamma + 32 beta couts per workgroup");
-    using G = QGeo<NW, KC>;
+    using G = QGeo<NW, KC, RPW>;
     constexpr int BN = 32 * WC, NT = 64 * NW;
     constexpr int Q_TH = G::TH, Q_NPIX = G::NPIX, Q_XP = G::XP, Q_XBYTES = G::XBYTES, Q_NXI = G::NXI, Q_KC = KC, RB = G::RB;
     constexpr int WROWS = 9 * BN;                      // rows of the filter image
@@ -88,22 +91,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, e = lane & 31;
     // ---- MFMA role: positions (rows 2 wave + r, column e) of the 16 x 32 tile, k-group `half` (channels 8 half .. + 7 of a 16-channel k-step)
-    int xaddr[2][9];                                   // byte address of piece `half` (k-step 0) of this lane's pixel, per (row r, tap t); k-step 1: ^ 32
+    // pixel (row RPW wave + r + 1 + dh, column e + 1 + dw) of the halo tile: a base per dw (the swizzle depends on the column only), rows as immediate offsets
+    int xbase[3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int pix = (2 * wave + r + 1 + p.dh[t]) * Q_INW + (e + 1 + p.dw[t]);
-            xaddr[r][t] = XBASE + pix * RB + ((half ^ G::f(pix)) << 4);
-        }
+    for (int d = 0; d < 3; ++d) {
+        const int col = e + d;                                            // e + 1 + dw, dw = d - 1
+        xbase[d] = XBASE + ((RPW * wave) * Q_INW + col) * RB + ((half ^ G::f(col)) << 4);
+    }
+    auto tap_dh = [](int t) { return FLIP ? 1 - t / 3 : t / 3 - 1; };
+    auto tap_dw = [](int t) { return FLIP ? 1 - t % 3 : t % 3 - 1; };
     const int aaddr = e * RB + ((half ^ G::f(e)) << 4);                  // filter row e of a 32-cout group: + (t * BN + 32 j) * RB, k-step 1: ^ 32 (the row offsets do not touch the swizzle bits)
 
     // ---- DMA roles (item-invariant): which (row, piece) of the images lane `lane` of this wave copies with its i-th wave-instruction
     unsigned x_rel[Q_NXI]; int x_yx[Q_NXI];            // x_yx = (iy << 8) | ix, or -1
 #pragma unroll
     for (int i = 0; i < Q_NXI; ++i) {
-        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR, pc = (lane % G::PR) ^ G::f(R);
-        const int iy = R / Q_INW, ix = R - iy * Q_INW;
+        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR;
+        const int iy = R / Q_INW, ix = R - iy * Q_INW, pc = (lane % G::PR) ^ G::f(ix);
         x_yx[i] = (k < Q_XP && R < Q_NPIX) ? ((iy << 8) | ix) : -1;
         x_rel[i] = 2u * (unsigned)((iy * p.W + ix) * p.ldin + 8 * pc);
     }
@@ -145,21 +149,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
             l_xorg = 2u * (unsigned)(((n * p.H + l_h0) * p.W + l_w0) * p.ldin);        // wraps for halo origins; added mod 2^32 below
         }
     };
-    unsigned xo[Q_NXI], wo[NWI];                       // byte offsets of the next item's pieces
+    // the item whose DMA is being issued: a snapshot of the cursor (wave-uniform scalars); the piece offsets are formed when a piece is issued (kept in registers
+    // they cost 2 x 19 VGPRs in the one-wave-per-SIMD form)
+    int c_h0 = 0, c_w0 = 0, c_co0 = 0; unsigned c_xorg = 0, c_c0b = 0; bool c_live = false;
     auto next_offsets = [&]() {
-        const unsigned c0b = 2u * (unsigned)(lc * Q_KC);
-#pragma unroll
-        for (int i = 0; i < Q_NXI; ++i) {
-            const int h = l_h0 + (x_yx[i] >> 8), w_ = l_w0 + (x_yx[i] & 255);
-            const bool ok = l_live && x_yx[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
-            xo[i] = ok ? l_xorg + x_rel[i] + c0b : Q_OOB;
-        }
-#pragma unroll
-        for (int i = 0; i < NWI; ++i) {
-            const bool ok = l_live && w_co[i] >= 0 && (SPADE ? l_co0 / 2 + (w_co[i] & 31) < p.C : l_co0 + w_co[i] < p.Cout);
-            wo[i] = ok ? w_rel[i] + 2u * (unsigned)((SPADE ? l_co0 / 2 : l_co0) * p.Cin) + c0b : Q_OOB;
-        }
+        c_h0 = l_h0; c_w0 = l_w0; c_co0 = l_co0; c_xorg = l_xorg; c_live = l_live; c_c0b = 2u * (unsigned)(lc * Q_KC);
         if (++lc == p.nchunks) { lc = 0; ++lj; load_unit(); }
+    };
+    auto x_off = [&](int i) -> unsigned {
+        const int h = c_h0 + (x_yx[i] >> 8), w_ = c_w0 + (x_yx[i] & 255);
+        const bool ok = c_live && x_yx[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+        return ok ? c_xorg + x_rel[i] + c_c0b : Q_OOB;
+    };
+    auto w_off = [&](int i) -> unsigned {
+        const bool ok = c_live && w_co[i] >= 0 && (SPADE ? c_co0 / 2 + (w_co[i] & 31) < p.C : c_co0 + w_co[i] < p.Cout);
+        return ok ? w_rel[i] + 2u * (unsigned)((SPADE ? c_co0 / 2 : c_co0) * p.Cin) + c_c0b : Q_OOB;
     };
     // one DMA wave-instruction: 64 lanes x 16 bytes land at LDS byte m0v + 16 lane.  Inline assembly: the compiler neither tracks these in vmcnt (the wait
     // before the barrier below is explicit) nor orders LDS reads behind them.
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(off), "s"(m0v), "s"(rs) : "memory");
     };
-    auto dma_x = [&](int stage, int i) { if (wave + NW * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, xo[i], (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + NW * i))); };
-    auto dma_w = [&](int stage, int i) { if (wave + NW * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, wo[i], (unsigned)(stage * WBYTES + 1024 * (wave + NW * i))); };
+    auto dma_x = [&](int stage, int i) { if (wave + NW * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, x_off(i), (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + NW * i))); };
+    auto dma_w = [&](int stage, int i) { if (wave + NW * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, w_off(i), (unsigned)(stage * WBYTES + 1024 * (wave + NW * i))); };
 
-    f32x16 acc[2][WC];
+    f32x16 acc[RPW][WC];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
         for (int j = 0; j < WC; ++j)
 #pragma unroll
@@ -207,29 +211,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
         stamp(1);
         const unsigned char* wa0 = smem_q + q_opaque(P * WBYTES + aaddr);
         const unsigned char* wa1 = smem_q + q_opaque(P * WBYTES + (aaddr ^ 32));
-        const unsigned char* xs = smem_q + P * Q_XBYTES;                // + xaddr[r][t] (^ 32): the stage offset stays in the instruction's immediate
+        const unsigned char* xs = smem_q + P * Q_XBYTES;                // + xbase[dw] (^ 32) + the tap row: stage and row offsets stay in the instruction's immediate
         next_offsets();                                // item i + 1: its DMA goes out in the first steps below, into stage P ^ 1
         // operand registers in a ring of three: the reads of step s + 2 are issued in step s (a full step of MFMAs -- this wave's and its SIMD partner's --
         // covers their LDS latency; one step ahead left the matrix pipe waiting: 68 us of MFMA + operand reads + barriers against 37 us of MFMAs on 128 -> 256 at 64x64)
-        bq_bf16x8 af[3][WC], bf[3][2];
+        bq_bf16x8 af[3][WC], bf[3][RPW];
         constexpr int NSTEP = 9 * G::KS;
         auto ld_ops = [&](int slot, int s1) {
             const int t1 = s1 / G::KS, ks1 = s1 % G::KS;
 #pragma unroll
             for (int j = 0; j < WC; ++j) af[slot][j] = *reinterpret_cast<const bq_bf16x8*>((ks1 ? wa1 : wa0) + (t1 * BN + 32 * j) * RB);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) bf[slot][r] = *reinterpret_cast<const bq_bf16x8*>(xs + (xaddr[r][t1] ^ (ks1 << 5)));
+            for (int r = 0; r < RPW; ++r) bf[slot][r] = *reinterpret_cast<const bq_bf16x8*>(xs + (xbase[tap_dw(t1) + 1] ^ (ks1 << 5)) + (r + 1 + tap_dh(t1)) * (Q_INW * RB));
         };
         ld_ops(0, 0); ld_ops(1, 1);
-        static_assert(Q_NXI + NWI <= NSTEP, "one DMA piece per step");
+        static_assert(Q_NXI <= NSTEP && NWI <= NSTEP, "at most one pixel and one filter piece per step");
+        constexpr bool TWO_DMA = Q_NXI + NWI > NSTEP;     // (the 4-wave form: 10 + 9 pieces per wave in 18 steps)
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP; ++s_) {
             const int c_ = s_ % 3;
             if (s_ + 2 < NSTEP) ld_ops((s_ + 2) % 3, s_ + 2);
-            if (s_ < Q_NXI) dma_x(P ^ 1, s_);
+            if (TWO_DMA) { if (s_ < Q_NXI) dma_x(P ^ 1, s_); if (s_ < NWI) dma_w(P ^ 1, s_); }
+            else if (s_ < Q_NXI) dma_x(P ^ 1, s_);
             else if (s_ < Q_NXI + NWI) dma_w(P ^ 1, s_ - Q_NXI);
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < RPW; ++r)
 #pragma unroll
                 for (int j = 0; j < WC; ++j) { if (ABL & 1) acc[r][j][0] += (float)af[c_][j][0] * (float)bf[c_][r][0]; else acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c_][j], bf[c_][r], acc[r][j], 0, 0, 0); }
             __builtin_amdgcn_sched_barrier(0);
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
             if (full) {
                 const float slope = p.lrelu ? 0.2f : 1.f;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const long long pix = (long long)(n * p.H + a0 + 2 * wave + r) * p.W + b;
+                for (int r = 0; r < RPW; ++r) {
+                    const long long pix = (long long)(n * p.H + a0 + RPW * wave + r) * p.W + b;
                     if (SPADE) {
                         const int c0 = co0 / 2;
                         const __bf16* zp = reinterpret_cast<const __bf16*>(p.z) + pix * p.ldz + c0 + 4 * half;
@@ -312,8 +318,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
                 }
             } else {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int a = a0 + 2 * wave + r;
+            for (int r = 0; r < RPW; ++r) {
+                const int a = a0 + RPW * wave + r;
                 const bool pos_ok = a < p.H && b < p.W && !((ABL & 4) && acc[r][0][0] != 1.2345f);
                 const long long pix = (long long)(n * p.H + a) * p.W + b;
                 if (SPADE) {
@@ -402,8 +408,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void bconv4_kernel(const 
 }
 
 namespace {
-constexpr size_t q_lds(int WC, int NW, int KC) {
-    return 2 * (size_t)(9 * 32 * WC * 2 * KC) + 2 * (size_t)((((2 * NW + 2) * Q_INW + 1024 / (2 * KC) - 1) / (1024 / (2 * KC))) * 1024) + sizeof(float) * Q_BIAS;
+constexpr size_t q_lds(int WC, int NW, int KC, int RPW = 2) {
+    return 2 * (size_t)(9 * 32 * WC * 2 * KC) + 2 * (size_t)((((RPW * NW + 2) * Q_INW + 1024 / (2 * KC) - 1) / (1024 / (2 * KC))) * 1024) + sizeof(float) * Q_BIAS;
 }
 int q_ncu() {
     static int n_cu = 0;
@@ -412,14 +418,19 @@ int q_ncu() {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)bconv4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)bconv4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)bconv4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+            hipFuncSetAttribute((const void*)bconv4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<2, false, 0, 8, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<1, false, 0, 8, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            false) return -2;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     return n_cu;
 }
 // The kernel is written for NW waves x KC-channel items (QGeo); only 8 x 32 is instantiated.  Measured and dropped (round 5): TWO independent 4-wave workgroups per CU
 // on 8 x 32 tiles with 16-channel items (63 KB of LDS each), so that one workgroup's epilogue / DMA wait / barrier would run under the other's MFMAs: 102 vs 84 us
-// (128 -> 256 at 64x64), 134 vs 107 us (32 -> 64 at 256x256) -- every workgroup stages its own filter image and an item is half as long (twice the barriers per MFMA).
+// (128 -> 256 at 64x64), 134 vs 107 us (32 -> 64 at 256x256) -- every workgroup stages its own filter image and an item is half as long (twice the barriers per MFMA);
+// and ONE wave per SIMD (4 waves x 4 rows: 128 positions x 64 couts, 8 MFMAs per 6 operand reads, accumulators in AGPRs): 107 vs 78 us / 134 vs 121 us -- a lone wave
+// does not keep the matrix pipe busy through its own operand waits, DMA issue and epilogue.
 constexpr bool q_two_per_cu(long long) { return false; }
 }  // namespace
 
@@ -436,11 +447,16 @@ int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
     if ((((uintptr_t)t.in | (uintptr_t)t.w_bf16) & 15) != 0 || ((uintptr_t)t.out & 7) != 0) return MRDIS_EUNSUPPORTED;
     BConv4Params p{};
     int wt = 0;
+    bool canon = true, flipped = true;                // the kernel walks the taps in table order with compile-time pixel offsets: the forward's or the data gradient's table
     for (int k = 0; k < 9; ++k) {
-        if (t.dh[k] < -1 || t.dh[k] > 1 || t.dw[k] < -1 || t.dw[k] > 1) return MRDIS_EUNSUPPORTED;
+        canon = canon && t.dh[k] == k / 3 - 1 && t.dw[k] == k % 3 - 1;
+        flipped = flipped && t.dh[k] == 1 - k / 3 && t.dw[k] == 1 - k % 3;
         p.dh[k] = t.dh[k]; p.dw[k] = t.dw[k]; p.widx[k] = t.widx[k];
+        if (t.widx[k] < 0) return MRDIS_EUNSUPPORTED;
         if (t.widx[k] + 1 > wt) wt = t.widx[k] + 1;
     }
+    if (!canon && !flipped) return MRDIS_EUNSUPPORTED;
+    const bool flip = !canon;
     const long long in_b = 2LL * (((long long)t.N * t.Hin * t.Win - 1) * t.ldin + t.Cin), w_b = 2LL * wt * t.Cin * t.Cout;
     if (in_b >= 0xffffffe0LL || w_b >= 0xffffffe0LL) return MRDIS_EUNSUPPORTED;
     p.in = t.in; p.w = t.w_bf16; p.bias = t.bias; p.out = t.out;
@@ -472,8 +488,10 @@ int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
 #undef QA
     }
 #endif
-    if (WC == 2) MRDIS_LAUNCH(bconv4_kernel<2>, dim3(grid), dim3(512), q_lds(2, 8, 32), s, p);
-    else MRDIS_LAUNCH(bconv4_kernel<1>, dim3(grid), dim3(512), q_lds(1, 8, 32), s, p);
+#define Q_GO(WC_, NW_, RPW_, FL_) MRDIS_LAUNCH((bconv4_kernel<WC_, false, 0, NW_, 32, RPW_, FL_>), dim3(grid), dim3(64 * NW_), q_lds(WC_, NW_, 32, RPW_), s, p)
+    if (WC == 2) { if (flip) Q_GO(2, 8, 2, true); else Q_GO(2, 8, 2, false); }
+    else { if (flip) Q_GO(1, 8, 2, true); else Q_GO(1, 8, 2, false); }
+#undef Q_GO
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
