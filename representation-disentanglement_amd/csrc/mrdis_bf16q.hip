@@ -27,14 +27,14 @@ typedef unsigned bq_u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int Q_TW = 32, Q_INW = Q_TW + 2;
 // geometry of one instantiation: NW waves per workgroup (each owns two rows of 32 positions), KC channels per item
-template <int NW, int KC, int RPW = 2> struct QGeo {
+template <int NW, int KC, int RPW = 2, int DMAW = NW> struct QGeo {
     static constexpr int TH = RPW * NW, INH = TH + 2, NPIX = INH * Q_INW;          // 16 x 32 tile: 18 x 34 = 612 halo pixels | 8 x 32 tile: 340
     static constexpr int RB = 2 * KC;                  // bytes of an image row (a pixel's / a cout's KC channels): 64 | 32
     static constexpr int PR = RB / 16;                 // 16-byte pieces per row: 4 | 2
     static constexpr int RPP = 1024 / RB;              // rows per DMA piece: 16 | 32
     static constexpr int XP = (NPIX + RPP - 1) / RPP;  // DMA pieces of a pixel image: 39 | 11
     static constexpr int XBYTES = XP * 1024;
-    static constexpr int NXI = (XP + NW - 1) / NW;     // per wave: k = wave + NW i (k < XP)
+    static constexpr int NXI = (XP + DMAW - 1) / DMAW; // per DMA wave: k = wave + DMAW i (k < XP)
     static constexpr int KS = KC / 16;                 // 16-channel k-steps per tap
     // swizzle of piece p of a row: slot = p ^ f(c), c = the row's index along the axis the lanes of a read walk (filter image: the cout row; pixel image: the
     // COLUMN of the pixel -- not its linear index, so that the tap rows of a lane differ by an immediate offset only).  f makes the 16 lanes that one ds_read_b128
@@ -75,15 +75,17 @@ struct BConv4Params {
 // the older one done after ~4,000 cycles of an item and idle at the barrier for ~2,400 while the younger one needed ~6,100, and both in their epilogues together)
 // RPW: rows of 32 positions per wave (2: two waves per SIMD share the matrix pipe | 4 with NW = 4: ONE wave per SIMD owns 128 positions x 64 couts, 8 MFMAs per 6 operand reads)
 // FLIP: the tap table is the data gradient's (tap t reads pixel (1 - t / 3, 1 - t % 3) instead of (t / 3 - 1, t % 3 - 1)); p.widx[t] names the filter tap either way
-template <int WC, bool SPADE = false, int ABL = 0, int NW = 8, int KC = 32, int RPW = 2, bool FLIP = false>
+// DMAW: the waves that issue the DMA (8: all | 4: waves 0-3 only -- the OLDER wave of every SIMD, which wins the matrix pipe's arbitration and would otherwise idle
+// at the item's barrier while its partner catches up)
+template <int WC, bool SPADE = false, int ABL = 0, int NW = 8, int KC = 32, int RPW = 2, bool FLIP = false, int DMAW = 4>
 __global__ __launch_bounds__(64 * NW, 1) void bconv4_kernel(const BConv4Params p) {
     static_assert(!SPADE || WC == 2, "SPADE: 32 gamma + 32 beta couts per workgroup");
-    using G = QGeo<NW, KC, RPW>;
+    using G = QGeo<NW, KC, RPW, DMAW>;
     constexpr int BN = 32 * WC, NT = 64 * NW;
     constexpr int Q_TH = G::TH, Q_NPIX = G::NPIX, Q_XP = G::XP, Q_XBYTES = G::XBYTES, Q_NXI = G::NXI, Q_KC = KC, RB = G::RB;
     constexpr int WROWS = 9 * BN;                      // rows of the filter image
     constexpr int WP = WROWS * RB / 1024;              // its DMA pieces (36 | 18 at 64-byte rows, 18 | 9 at 32-byte rows)
-    constexpr int NWI = (WP + NW - 1) / NW;            // per wave: k = wave + NW i (k < WP)
+    constexpr int NWI = (WP + DMAW - 1) / DMAW;        // per DMA wave: k = wave + DMAW i (k < WP)
     constexpr int WBYTES = WROWS * RB;
     constexpr int XBASE = 2 * WBYTES;                  // LDS: [filter stage 0][filter stage 1][pixels stage 0][pixels stage 1][bias]
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_q[];
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64 * NW, 1) void bconv4_kernel(const BConv4Params p
     unsigned x_rel[Q_NXI]; int x_yx[Q_NXI];            // x_yx = (iy << 8) | ix, or -1
 #pragma unroll
     for (int i = 0; i < Q_NXI; ++i) {
-        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR;
+        const int k = wave + DMAW * i, R = G::RPP * k + lane / G::PR;
         const int iy = R / Q_INW, ix = R - iy * Q_INW, pc = (lane % G::PR) ^ G::f(ix);
         x_yx[i] = (k < Q_XP && R < Q_NPIX) ? ((iy << 8) | ix) : -1;
         x_rel[i] = 2u * (unsigned)((iy * p.W + ix) * p.ldin + 8 * pc);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * NW, 1) void bconv4_kernel(const BConv4Params p
     unsigned w_rel[NWI]; int w_co[NWI];                // w_co: cout within the tile, or -1
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-        const int k = wave + NW * i, R = G::RPP * k + lane / G::PR, pc = (lane % G::PR) ^ G::f(R);
+        const int k = wave + DMAW * i, R = G::RPP * k + lane / G::PR, pc = (lane % G::PR) ^ G::f(R);
         const int t = R / BN, co = R - t * BN;
         w_co[i] = k < WP ? co : -1;
         // SPADE: local couts 0..31 are the gamma couts of the workgroup's 32 channels, 32..63 their beta couts (C further on in the filter)
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(64 * NW, 1) void bconv4_kernel(const BConv4Params p
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(off), "s"(m0v), "s"(rs) : "memory");
     };
-    auto dma_x = [&](int stage, int i) { if (wave + NW * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, x_off(i), (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + NW * i))); };
-    auto dma_w = [&](int stage, int i) { if (wave + NW * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, w_off(i), (unsigned)(stage * WBYTES + 1024 * (wave + NW * i))); };
+    auto dma_x = [&](int stage, int i) { if (wave < DMAW && wave + DMAW * i < Q_XP && !((ABL & 2) && stage >= 0 && lj > 1)) dma(rs_in, x_off(i), (unsigned)(XBASE + stage * Q_XBYTES + 1024 * (wave + DMAW * i))); };
+    auto dma_w = [&](int stage, int i) { if (wave < DMAW && wave + DMAW * i < WP && !((ABL & 2) && lj > 1)) dma(rs_w, w_off(i), (unsigned)(stage * WBYTES + 1024 * (wave + DMAW * i))); };
 
     f32x16 acc[RPW][WC];
 #pragma unroll
@@ -421,6 +423,10 @@ int q_ncu() {
             hipFuncSetAttribute((const void*)bconv4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)bconv4_kernel<2, false, 0, 8, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)bconv4_kernel<1, false, 0, 8, 32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<2, false, 0, 8, 32, 2, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<1, false, 0, 8, 32, 2, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<2, false, 0, 8, 32, 2, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)bconv4_kernel<1, false, 0, 8, 32, 2, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             false) return -2;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
@@ -488,7 +494,8 @@ int mrdis_run_bconv4(const TapConvParams& t, hipStream_t s) {
 #undef QA
     }
 #endif
-#define Q_GO(WC_, NW_, RPW_, FL_) MRDIS_LAUNCH((bconv4_kernel<WC_, false, 0, NW_, 32, RPW_, FL_>), dim3(grid), dim3(64 * NW_), q_lds(WC_, NW_, 32, RPW_), s, p)
+#define Q_GO(WC_, NW_, RPW_, FL_) do { if (mrdis_opt(MRDIS_OPT_MODE) == 3003) MRDIS_LAUNCH((bconv4_kernel<WC_, false, 0, NW_, 32, RPW_, FL_, 8>), dim3(grid), dim3(64 * NW_), q_lds(WC_, NW_, 32, RPW_), s, p); \
+    else MRDIS_LAUNCH((bconv4_kernel<WC_, false, 0, NW_, 32, RPW_, FL_>), dim3(grid), dim3(64 * NW_), q_lds(WC_, NW_, 32, RPW_), s, p); } while (0)
     if (WC == 2) { if (flip) Q_GO(2, 8, 2, true); else Q_GO(2, 8, 2, false); }
     else { if (flip) Q_GO(1, 8, 2, true); else Q_GO(1, 8, 2, false); }
 #undef Q_GO

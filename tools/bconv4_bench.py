@@ -27,6 +27,11 @@ for (B, ci, co, H, W, spade) in [(32, 128, 256, 64, 64, 1), (32, 64, 128, 128, 1
         t[mode] = timeit(lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb), iters=20)
         outs[mode] = hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb)
     fl = 2.0 * B * H * W * ci * co * 9
+    hip.set_option('bconv4', 1); hip.set_option('debug_mode', 3003)
+    t8 = timeit(lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb), iters=20)
+    hip.set_option('debug_mode', -1)
+    t4 = timeit(lambda: hip.conv2d_fwd(x, wt, bias, 3, 3, 1, 1, w_bf16=wb), iters=20)
+    print(f'      DMA from all 8 waves: {t8:.1f} us | from waves 0-3: {t4:.1f} us')
     d4 = float((outs[2].float() - outs[0].float()).abs().max()) / float(outs[0].float().abs().max())
     print(f'fwd   {B}x{ci}->{co} {H}x{W}'.ljust(30) + f' | {t[0]:9.1f} | {t[1]:9.1f} | {t[2]:9.1f} | {fl / t[2] / 1e6:8.1f} | {torch.equal(outs[0], outs[1])} | forced vs bconv3: max diff {d4:.1e}, '
           f'{float((outs[2] != outs[0]).float().mean()):.1e} of the values differ', flush=True)
