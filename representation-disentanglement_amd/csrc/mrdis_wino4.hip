@@ -428,8 +428,13 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const Wino4Params p) {
                     const long long pix = (long long)(n * p.H + row) * p.W + ox + k;
                     const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + pix * p.ldz + ch);
                     g = g + bg; bt = bt + bb;
-                    *reinterpret_cast<f32x4*>(p.out + pix * p.ldout + ch) = (zv - mu) * rs * (g + 1.f) + bt;
-                    *reinterpret_cast<f32x4*>(p.gamma_out + pix * p.ldg + ch) = g;
+                    const f32x4 mixv = (zv - mu) * rs * (g + 1.f) + bt;
+                    // gamma is read again only by the backward pass: non-temporal; mix feeds the next convolution: non-temporal only when the tensor is beyond
+                    // what stays cached anyway (nt_out; debug_mode 2006 / 2007: neither / both, for A/B)
+                    if (p.nt_out & 1) __builtin_nontemporal_store(mixv, reinterpret_cast<f32x4*>(p.out + pix * p.ldout + ch));
+                    else *reinterpret_cast<f32x4*>(p.out + pix * p.ldout + ch) = mixv;
+                    if (p.nt_out & 2) __builtin_nontemporal_store(g, reinterpret_cast<f32x4*>(p.gamma_out + pix * p.ldg + ch));
+                    else *reinterpret_cast<f32x4*>(p.gamma_out + pix * p.ldg + ch) = g;
                 }
             }
 #pragma unroll
@@ -847,6 +852,9 @@ int mrdis_run_wino4_spade(const float* x, int ldx, const float* bias, const floa
     p.N = N; p.H = H; p.W = W; p.Cin = Ci; p.ldin = ldx; p.Cout = 2 * C; p.ldout = ldmix;
     p.prio = mrdis_opt(MRDIS_OPT_MODE) == 1001 ? 1 : (mrdis_opt(MRDIS_OPT_MODE) == 1002 ? 2 : 0);
     p.z = z; p.ldz = ldz; p.mean = mean; p.rstd = rstd; p.gamma_out = gamma; p.ldg = ldg; p.C = C;
+    { const long long md = mrdis_opt(MRDIS_OPT_MODE), mb = mrdis_opt(MRDIS_OPT_NT_MB);
+      const int big = (long long)N * H * W * ldmix * 4 >= mb * 1000000LL ? 1 : 0;
+      p.nt_out = md == 2006 ? 0 : (md == 2007 ? 3 : (md == 2008 ? 2 : (2 | big))); }
     { const long long zb = 4LL * ((long long)(N * H) * W - 1) * ldz + 4LL * C; p.z_bytes = (zb < 0xffffffe0LL && mrdis_opt(MRDIS_OPT_MODE) != 2005) ? (unsigned)zb : 0u; }      // (debug_mode 2005: no z prefetch, for A/B)
     p.nby = mrdis_cdiv(H, 16); p.nbx = mrdis_cdiv(W, 32);
     p.coTiles = mrdis_cdiv(C, 32);

@@ -38,7 +38,12 @@ for (N, Ci, C, H) in [(32, 32, 32, 256), (32, 64, 64, 128), (32, 128, 128, 64), 
             hip.set_option('debug_mode', -1)
             t2 = timeit(lambda: hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img, out=bufs, stats_ready=True))
             assert torch.equal(r_np[0], res[0]) and torch.equal(r_np[1], res[1])
-            name = f'{name} [no z prefetch {t_np:.1f} us, again with {t2:.1f} us]'
+            ts = []
+            for md in (2006, 2008, 2007, -1):          # stores: plain | gamma non-temporal | both non-temporal | default (gamma nt, mix nt when the tensor is >= nt_mb)
+                hip.set_option('debug_mode', md)
+                ts.append(timeit(lambda: hip.gb_spade_fwd(x, wt, b, z, 1e-5, w_wino=img, out=bufs, stats_ready=True)))
+            hip.set_option('debug_mode', -1)
+            name = f'{name} [no z prefetch {t_np:.1f} us, again with {t2:.1f} us; stores plain / gamma nt / both nt / default: ' + ' / '.join(f'{v:.1f}' for v in ts) + ']'
         if ref is None:
             ref = res[0].clone()
             out.append(f'{name} fmt {hip.wino_u_format(Ci, 2 * C, C)}: {t:.1f} us')
