@@ -826,6 +826,235 @@ __global__ __launch_bounds__(512, 1) void bwgrad2_kernel(const BWgradParams p, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bwgrad3_kernel (round 5): bwgrad2_kernel with both images staged by LDS-DMA (`buffer_load_dwordx4 ... lds`) into a ring of THREE stages.
+// bwgrad2 keeps two tiles in LDS and a third in registers (XR + YR 16-byte loads per thread, each followed by a ds_write_b128); the same diagnosis as for
+// bconv3_kernel applies (mrdis_bf16q.hip): the LDS stores and the waits of the MFMA stream on loads, not the matrix pipe, bound it.  Here a tile goes from
+// HBM / L2 straight into its stage: no staging registers, no ds_write, and a copy has two tile times to land (it is issued while tile i is multiplied and
+// first read in tile i + 2).  The images are the unpadded [pixel][32 ch] 64-byte rows the transposing operand reads want, so a DMA wave-instruction simply
+// fills 16 consecutive rows (lane l: row l / 4, piece l % 4); every wave issues the same number of pieces per tile (pieces beyond an image go, with
+// out-of-range offsets, to a 1 KB strip nothing reads), so the wait before the tile's barrier is a counted vmcnt.  dbias: the column sums of dy are taken
+// from the LDS image (the same 16-byte pieces in the same thread order as bwgrad2's staging registers: bit-identical).  Same products, same order: dw
+// bit-identical to bwgrad2_kernel's.
+template <int WCI, int WCO>
+__global__ __launch_bounds__(512, 1) void bwgrad3_kernel(const BWgradParams p, const unsigned x_bytes, const unsigned dy_bytes) {
+    constexpr int KS = 8 / (WCI * WCO), NSTEP = 8 / KS;
+    constexpr int CIW = 32 * WCI, COW = 32 * WCO;
+    constexpr int YQ = COW / 8;
+    constexpr int YR = (WCO == 2) ? 2 : 1, NM = NSTEP * 9;
+    constexpr int TP = 128, DYS = WCO * TP * 32;      // bf16 elements of the dy image
+    constexpr int NDY = WCO;                           // dy pieces per wave: WCO * 8 pieces of 1 KB over 8 waves
+    constexpr int NXM = 4;                             // x pieces per wave (<= 32 pieces: WCI * npix <= 512 rows, plan_bwgrad)
+    constexpr int NL = NXM + NDY;
+    static_assert(NL <= NM && NL <= 15, "one DMA per MFMA slot, counted vmcnt");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave % WCI, wco = (wave / WCI) % WCO, ks = wave / (WCI * WCO);
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int cob = bid % p.nCoB, cib = bid / p.nCoB;
+    const int ci0 = cib * CIW, co0 = cob * COW;
+    const int tinHW = p.TinH * p.TinW, npix = p.NB * tinHW;
+    const int xrows = WCI * npix, xpieces = (xrows + 15) >> 4;
+    const int XS = xpieces * 512;                      // bf16 elements of the x image, rounded up to whole 1 KB pieces
+    const int STAGE = DYS + XS;                        // a stage: [dy image][x image]; three stages, then the 1 KB strip of the out-of-range pieces
+    const unsigned lds_raw = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem_raw;
+    const unsigned sink = lds_raw + 2u * 3u * (unsigned)STAGE;
+
+    // lane constants of the transposing reads (as bwgrad2_kernel)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int chan = 16 * (g & 1) + 4 * pc, kbase = 8 * (g >> 1) + q;
+    int xa0[NSTEP], xa1[NSTEP], ya0[NSTEP];
+#pragma unroll
+    for (int s_ = 0; s_ < NSTEP; ++s_) {
+        const int m0 = 16 * (ks + s_ * KS) + kbase, m1 = m0 + 4;
+        const int tx0 = m0 & (p.TW - 1), ty0 = (m0 >> p.lgTW) & (p.TH - 1), nb0 = m0 >> (p.lgTW + p.lgTH);
+        const int tx1 = m1 & (p.TW - 1), ty1 = (m1 >> p.lgTW) & (p.TH - 1), nb1 = m1 >> (p.lgTW + p.lgTH);
+        xa0[s_] = DYS + (wci * npix + (nb0 * p.TinH + ty0) * p.TinW + tx0) * 32 + chan;
+        xa1[s_] = DYS + (wci * npix + (nb1 * p.TinH + ty1) * p.TinW + tx1) * 32 + chan;
+        ya0[s_] = (wco * TP + m0) * 32 + chan;
+    }
+    const int rowp = p.TinW * 32;
+
+    // DMA roles (tile-invariant): piece k = wave + 8 i of an image, lane l -> row 16 k + l / 4, 16-byte piece l % 4 (8 channels)
+    int x_yx[NXM]; unsigned x_rel[NXM];               // x_yx = (nb << 16) | (iy << 8) | ix, or -1 (row beyond the image / channels beyond Ci)
+#pragma unroll
+    for (int i = 0; i < NXM; ++i) {
+        const int k = wave + 8 * i, r = 16 * k + (lane >> 2), qq = lane & 3;
+        const int grp = r / npix, pi = r - grp * npix;
+        const int nb = pi / tinHW, rem = pi - nb * tinHW, iy = rem / p.TinW, ix = rem - iy * p.TinW;
+        const bool on = k < xpieces && r < xrows && ci0 + 32 * grp + 8 * qq < p.Ci;
+        x_yx[i] = on ? ((nb << 16) | (iy << 8) | ix) : -1;
+        x_rel[i] = 2u * (unsigned)(((nb * p.H + iy) * p.W + ix) * p.ldx + ci0 + 32 * grp + 8 * qq);
+    }
+    int y_pos[NDY]; unsigned y_rel[NDY];
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+        const int k = wave + 8 * i, r = 16 * k + (lane >> 2), qq = lane & 3;      // k < WCO * 8 by construction
+        const int grp = r / TP, m = r - grp * TP;
+        const int tx = m & (p.TW - 1), ty = (m >> p.lgTW) & (p.TH - 1), nb = m >> (p.lgTW + p.lgTH);
+        y_pos[i] = (co0 + 32 * grp + 8 * qq < p.Co) ? ((nb << 16) | (ty << 8) | tx) : -1;
+        y_rel[i] = 2u * (unsigned)(((nb * p.H + ty) * p.W + tx) * p.lddy + co0 + 32 * grp + 8 * qq);
+    }
+    // dbias read-back roles: the pieces this thread staged in bwgrad2_kernel (idx = tid + it * 512 -> position idx / YQ, piece idx % YQ)
+    int b_lds[YR];
+#pragma unroll
+    for (int it = 0; it < YR; ++it) {
+        const int idx = tid + it * 512, m = idx / YQ, qq = idx - m * YQ;
+        b_lds[it] = ((qq >> 2) * TP + m) * 32 + 8 * (qq & 3);
+    }
+    const bool want_bias = p.bias_slab != nullptr && cib == 0;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, dy_bytes, 0x00020000);
+
+    // cursor of the tile whose copy is being issued (wave-uniform scalars)
+    int ltile = split;
+    bool c_live = false; int c_n0 = 0, c_h0 = 0, c_w0 = 0, c_a0 = 0, c_b0 = 0; unsigned c_xorg = 0, c_yorg = 0;
+    auto next_tile = [&]() {
+        c_live = ltile < p.tiles;
+        int t_ = c_live ? ltile : 0;
+        const int tb = t_ % p.tilesB; t_ /= p.tilesB;
+        const int ta = t_ % p.tilesA;
+        c_n0 = (t_ / p.tilesA) * p.NB; c_a0 = ta * p.TH; c_b0 = tb * p.TW;
+        c_h0 = c_a0 + p.dh_min; c_w0 = c_b0 + p.dw_min;
+        c_xorg = 2u * (unsigned)(((c_n0 * p.H + c_h0) * p.W + c_w0) * p.ldx);         // may wrap for halo origins: added mod 2^32
+        c_yorg = 2u * (unsigned)(((c_n0 * p.H + c_a0) * p.W + c_b0) * p.lddy);
+        ltile += p.splits;
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned lds_byte) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(m0v), "s"(rs) : "memory");
+    };
+    auto dma1 = [&](int stage, int k_) {               // DMA k_ of NL of the cursor's tile into `stage`: x pieces first, then dy pieces
+        if (k_ < NXM) {
+            const int i = k_, k = wave + 8 * i;
+            const int n = c_n0 + (x_yx[i] >> 16), h = c_h0 + ((x_yx[i] >> 8) & 255), w_ = c_w0 + (x_yx[i] & 255);
+            const bool ok = c_live && x_yx[i] >= 0 && n < p.N && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            const bool piece_ok = k < xpieces;          // wave-uniform
+            dma(rs_x, (ok && piece_ok) ? c_xorg + x_rel[i] : BW_OOB, piece_ok ? lds_raw + 2u * (unsigned)(stage * STAGE + DYS) + 1024u * (unsigned)k : sink);
+        } else {
+            const int i = k_ - NXM, k = wave + 8 * i;
+            const int n = c_n0 + (y_pos[i] >> 16), a = c_a0 + ((y_pos[i] >> 8) & 255), b = c_b0 + (y_pos[i] & 255);
+            const bool ok = c_live && y_pos[i] >= 0 && n < p.N && a < p.H && b < p.W;
+            dma(rs_dy, ok ? c_yorg + y_rel[i] : BW_OOB, lds_raw + 2u * (unsigned)(stage * STAGE) + 1024u * (unsigned)k);
+        }
+    };
+    float bsum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- prologue: tiles 0 and 1 on their way into stages 0 and 1; tile 0 landed
+    next_tile();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dma1(0, k);
+    next_tile();
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dma1(1, k);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | NL);
+    __syncthreads();
+
+    const int ntile = (p.tiles - split + p.splits - 1) / p.splits;
+    auto iteration = [&](auto P_) {
+        constexpr int P = decltype(P_)::value;          // stage of the tile being multiplied; its copy two tiles ahead goes into stage (P + 2) % 3
+        const __bf16* sb = lds + bw_opaque(P * STAGE);
+        next_tile();
+        union Op { bf16x8 v; s16x4 h[2]; };
+        constexpr int AD = BW2_AHEAD;
+        Op aq[AD + 1], bq[2];
+        const __bf16* r0 = sb; const __bf16* r1 = sb;
+        auto read_a = [&](Op& o, int s_, int t) {
+            if (t % 3 == 0) { r0 = sb + xa0[s_] + (t / 3) * rowp; r1 = sb + xa1[s_] + (t / 3) * rowp; }
+            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(r0 + 32 * (t % 3)));
+            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(r1 + 32 * (t % 3)));
+        };
+        auto read_b = [&](Op& o, int s_) {
+            o.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + ya0[s_]));
+            o.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sb + ya0[s_] + 128));
+        };
+        read_b(bq[0], 0);
+#pragma unroll
+        for (int k = 0; k < AD; ++k) read_a(aq[k], k / 9, k % 9);
+        if (want_bias) {                               // column sums of this tile's dy image (block-uniform branch)
+#pragma unroll
+            for (int it = 0; it < YR; ++it) {
+                union { bw_u32x4 u; bf16x8 v; } c;
+                c.u = *reinterpret_cast<const bw_u32x4*>(sb + b_lds[it]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += (float)c.v[j];
+            }
+        }
+#pragma unroll
+        for (int slot = 0; slot < NM; ++slot) {
+            const int s_ = slot / 9, t = slot - 9 * s_;
+            if (slot + AD < NM) {
+                const int s1 = (slot + AD) / 9, t1 = (slot + AD) - 9 * s1;
+                read_a(aq[(slot + AD) % (AD + 1)], s1, t1);
+            }
+            if (slot + 1 < NM && (slot + 1) % 9 == 0) read_b(bq[((slot + 1) / 9) & 1], (slot + 1) / 9);
+            if (slot < NL) dma1((P + 2) % 3, slot);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[slot % (AD + 1)].v, bq[s_ & 1].v, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70 | NL);       // all but the NL pieces just issued (tile i + 2) have landed: tile i + 1 is complete
+        __syncthreads();
+    };
+    for (int i = 0; i < ntile; i += 3) {
+        iteration(BwIC<0>{});
+        if (i + 1 < ntile) iteration(BwIC<1>{});
+        if (i + 2 < ntile) iteration(BwIC<2>{});
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // the copies of the tiles past the end (zeros) must not land on the reduction buffer below
+    __syncthreads();
+
+    // ---- the KS waves of a channel block add their partials through LDS, then the ks = 0 wave writes the block (as bwgrad2_kernel)
+    const int half = lane >> 5, e = lane & 31;
+    const int co = co0 + 32 * wco + e;
+    float* red_acc = reinterpret_cast<float*>(smem_raw);            // [8 waves][16][64]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        if (ks > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red_acc[(wave * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (ks == 0 && co < p.Co) {
+            float* dst = p.slab + (((long long)split * 9 + t) * p.Ci + ci0 + 32 * wci) * p.Co + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) v += red_acc[((wave + k * WCI * WCO) * 16 + r) * 64 + lane];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[(long long)row * p.Co] = v;
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);            // [512][8]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bsum[k];
+        __syncthreads();
+        if (tid < COW) {
+            const int qq = tid / 8, k = tid % 8;
+            float sum = 0.f;
+            for (int th = qq; th < 512; th += YQ) sum += red[th * 8 + k];
+            if (co0 + tid < p.Co) p.bias_slab[(long long)split * p.Co + co0 + tid] = sum;
+        }
+    }
+}
+
 // out[i] = sum over s of slab[s][i]; the bias row likewise.  A block owns 64 consecutive outputs; its sixteen waves take the slabs
 // s = w, w + 16, ... (each wave reads 256 contiguous bytes per slab) and meet in LDS: fixed order, bit-reproducible.  (One thread
 // per output walking all S slabs serially was latency-bound: 60 us for the 18,432 outputs x 256 slabs of sp6.gamma+beta.)
@@ -1046,7 +1275,19 @@ int mrdis_run_bwgrad(const void* x, int ldx, const void* dy, int lddy, float* dw
         const size_t lds2 = 2 * (size_t)pl.lds;
         bool canon = p.ntaps == 9;                    // tap t = row t / 3, column t % 3 of the 3x3 window (what the kernel's addressing assumes)
         for (int t_ = 0; canon && t_ < 9; ++t_) canon = (p.dh[t_] - p.dh_min == t_ / 3) && (p.dw[t_] - p.dw_min == t_ % 3);
-        if (canon && xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds2 <= 150 * 1024 && p.tiles >= 2 * p.splits) {
+        // round 5: the LDS-DMA form (three stages + a 1 KB strip); debug_mode 3010 keeps bwgrad2_kernel (A/B)
+        const long long npix3 = (long long)p.NB * p.TinH * p.TinW;
+        const size_t stage3 = 2 * ((size_t)pl.wco * 128 * 32 + (size_t)(((pl.wci * npix3 + 15) / 16) * 512));
+        const size_t lds3 = 3 * stage3 + 1024 < 32768 ? 32768 : 3 * stage3 + 1024;
+        if (canon && xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds3 <= 160 * 1024 && pl.wci * npix3 <= 512 && p.tiles >= 3 * p.splits && mrdis_opt(MRDIS_OPT_MODE) != 3010) {
+#define BW3_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
+            static bool attr3 = false; \
+            if (!attr3) { if (hipFuncSetAttribute((const void*)bwgrad3_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr3 = true; } \
+            MRDIS_LAUNCH((bwgrad3_kernel<a, b_>), dim3(grid), dim3(512), lds3, s, p, (unsigned)xb, (unsigned)yb); done2 = true; }
+            BW3_CASE(1, 1) else BW3_CASE(1, 2) else BW3_CASE(2, 1) else BW3_CASE(2, 2)
+#undef BW3_CASE
+        }
+        if (!done2 && canon && xb < 0xffffffe0LL && yb < 0xffffffe0LL && lds2 <= 150 * 1024 && p.tiles >= 2 * p.splits) {
 #define BW2_CASE(a, b_) if (pl.wci == a && pl.wco == b_) { \
             static bool attr2 = false; \
             if (!attr2) { if (hipFuncSetAttribute((const void*)bwgrad2_kernel<a, b_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return MRDIS_ELAUNCH; attr2 = true; } \

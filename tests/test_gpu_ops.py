@@ -1111,6 +1111,27 @@ def test_conv_bf16_mfma(mrdis, case):
     close(db, gy.sum((0, 2, 3)), rtol=2e-5, what='dbias (fp32 sum)')
 
 
+@pytest.mark.parametrize('case', [(8, 64, 128, 64, 64), (5, 32, 64, 50, 70), (3, 128, 256, 33, 47), (16, 64, 32, 32, 32), (2, 32, 40, 96, 128), (40, 128, 128, 16, 16)], ids=str)
+def test_bf16_weight_gradient_lds_dma_bit_identical(mrdis, case):
+    """bwgrad3_kernel (mrdis_bf16.hip, round 5: both images by LDS-DMA into a ring of three stages, dbias from the LDS image) against bwgrad2_kernel
+    (register staging; option debug_mode 3010 keeps it): dw and dbias BIT-IDENTICAL on bf16 views -- ragged tiles, a cout tail (40), every (ci, co) block shape,
+    many-image tiles; and against torch fp32 on the bf16-valued operands up to the order of the fp32 sums."""
+    N, Ci, Co, H, W = case
+    hip = mrdis.hip
+    B16 = torch.bfloat16
+    x = rnd((N, Ci, H, W), 1).to(B16); gy = rnd((N, Co, H, W), 2).to(B16)
+    xd, gyd = cl(x), cl(gy)
+    hip.set_option('debug_mode', 3010)
+    dw2, db2 = hip.conv2d_bwd_weight(xd, gyd, 3, 3, 1, 1, need_bias=True)
+    hip.set_option('debug_mode', -1)
+    dw3, db3 = hip.conv2d_bwd_weight(xd, gyd, 3, 3, 1, 1, need_bias=True)
+    assert torch.equal(dw2, dw3) and torch.equal(db2, db3)
+    wz = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x.float(), wz, None, 1, 1).backward(gy.float())
+    close(dw3, to_tck(wz.grad), rtol=4e-5, what='bf16 wgrad vs torch fp32 on the bf16-valued operands')
+    close(db3, gy.float().sum((0, 2, 3)), rtol=2e-5, what='dbias')
+
+
 @pytest.mark.parametrize('case', [
     # N, Ci, Co, H, W, k
     (8, 32, 64, 64, 64, 4),          # the anatomy encoder's shape family (4x4 / stride 2 / pad 1)
