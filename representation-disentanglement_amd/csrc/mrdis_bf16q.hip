@@ -436,7 +436,8 @@ int q_ncu() {
 // on 8 x 32 tiles with 16-channel items (63 KB of LDS each), so that one workgroup's epilogue / DMA wait / barrier would run under the other's MFMAs: 102 vs 84 us
 // (128 -> 256 at 64x64), 134 vs 107 us (32 -> 64 at 256x256) -- every workgroup stages its own filter image and an item is half as long (twice the barriers per MFMA);
 // and ONE wave per SIMD (4 waves x 4 rows: 128 positions x 64 couts, 8 MFMAs per 6 operand reads, accumulators in AGPRs): 107 vs 78 us / 134 vs 121 us -- a lone wave
-// does not keep the matrix pipe busy through its own operand waits, DMA issue and epilogue.
+// does not keep the matrix pipe busy through its own operand waits, DMA issue and epilogue; s_setprio 1 for either half of the waves, or alternating between the two
+// waves of a SIMD step by step: within the noise.
 constexpr bool q_two_per_cu(long long) { return false; }
 }  // namespace
 
