@@ -82,3 +82,62 @@ def test_device_loader_vs_oracle_unshuffled_other_shape(mrdis):
     with pytest.raises(IndexError):                                       # the reference's ragged 6-slice item
         ds2 = mrdis.SliceDataset('BraTS', store, subj[:1], [154], block_size=3, contrast_list=['T1', 'T2'])
         next(iter(mrdis.BatchLoader(ds2, 1)))
+
+
+def test_volume_store_from_h5_walks_the_file_like_the_reference(monkeypatch):
+    """VolumeStore.from_h5 (the reference opens its h5 file and indexes it by 'subject/contrast', util.py:455-470, 648-660).  h5py is not in this image, so the
+    code path had never executed: here it runs against a stand-in module that implements exactly the h5py surface it uses (File as a context manager,
+    visititems over nested groups, Dataset[...]) over nested dicts of arrays -- the walk, the key filter, the (H, W, D) -> (D, H, W) layout, the shape check and the
+    missing-h5py error are what is tested; parsing the HDF5 container itself stays h5py's job."""
+    import sys
+    import types
+    import mrdis
+
+    class Dataset:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, idx):
+            assert idx is Ellipsis
+            return self.a
+
+    class File:
+        def __init__(self, path, mode):
+            assert mode == 'r'
+            self.tree = FILES[path]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def visititems(self, fn):
+            def walk(prefix, node):
+                for k, v in node.items():
+                    name = f'{prefix}/{k}' if prefix else k
+                    if isinstance(v, dict):
+                        fn(name, object())                              # a group: not a Dataset
+                        walk(name, v)
+                    else:
+                        fn(name, Dataset(v))
+            walk('', self.tree)
+
+    g = np.random.RandomState(3)
+    vols = {s: {c: g.randn(6, 5, 9).astype(np.float32) for c in ('T1', 'T2', 'seg')} for s in ('S0', 'S1')}
+    FILES = {'brats.h5': vols, 'bad.h5': {'S0': {'T1': np.zeros((6, 5, 9), np.float32), 'T2': np.zeros((6, 5, 8), np.float32)}}}
+    stub = types.ModuleType('h5py')
+    stub.File, stub.Dataset = File, Dataset
+    monkeypatch.setitem(sys.modules, 'h5py', stub)
+    st = mrdis.data.VolumeStore.from_h5('brats.h5', 'cpu')
+    assert st.shape == (6, 5, 9) and sorted(st.vols) == sorted(f'{s}/{c}' for s in vols for c in vols[s])
+    for s in vols:
+        for c in vols[s]:
+            assert torch.equal(st.vols[f'{s}/{c}'], torch.from_numpy(vols[s][c]).permute(2, 0, 1))      # stored (D, H, W)
+    only = mrdis.data.VolumeStore.from_h5('brats.h5', 'cpu', keys={'S1/T2', 'S0/seg'})
+    assert sorted(only.vols) == ['S0/seg', 'S1/T2'] and 'S1/T2' in only and 'S1/T1' not in only and only.ptr('S1/T1') == 0
+    with pytest.raises(ValueError):
+        mrdis.data.VolumeStore.from_h5('bad.h5', 'cpu')                  # volumes of one file share their shape
+    monkeypatch.setitem(sys.modules, 'h5py', None)                      # import h5py -> ImportError
+    with pytest.raises(RuntimeError, match='h5py is not installed'):
+        mrdis.data.VolumeStore.from_h5('brats.h5', 'cpu')
