@@ -25,11 +25,12 @@ struct Co4Params {
 namespace {
 constexpr unsigned CO4_OOB = 0xfffffff0u;
 typedef unsigned co4_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 co4_bf16x8 __attribute__((ext_vector_type(8)));
 }
 
 // HALVES = Ci / 16 (2 | 4), TPW = 16-pixel tiles per wave and row = W / 64 (1 | 2 | 4).  XB: the input is a bf16 view -- a lane's 16-byte
-// load then holds EIGHT channels (k-step 8 h' + j <-> channel 32 h' + 8 kq + j: the filter rows follow the same map), widened to fp32
-// in registers (exact), so the MFMAs and everything after them are those of the fp32 form.
+// load then holds EIGHT channels (k 8 kq + j of load h' <-> channel 32 h' + 8 kq + j: the filter rows follow the same map): the B operand of a
+// bf16 MFMA as it stands; everything after the MFMAs is that of the fp32 form.
 template <int HALVES, int TPW, bool XB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) {
     constexpr int CI = 16 * HALVES, KS = CI / 4;
@@ -41,17 +42,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
     const int n = b / p.segs, r0 = (b - n * p.segs) * p.R, r1 = min(r0 + p.R, p.H);
 
     // A = filter rows: row i = 16 rt + l16 <-> cout l16 >> 2, tap 4 rt + (l16 & 3); k-step 4 h + j <-> channel 16 h + 4 kq + j
-    float a[KS][3];
+    // XB: the GEMM runs on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16: the 32 channels of a 16-byte load per lane are ONE MFMA instead of eight fp32 ones,
+    // at 16 instead of 32 cycles each).  The pixel operand is bf16 already; the fp32 filter is split into THREE bf16 terms, w = hi + mid + lo (each the bf16
+    // rounding of what the terms before it left: 3 x 8 mantissa bits cover fp32's 24), so the products are those of the fp32 form, exactly, and only the order
+    // of the fp32 sum differs -- 9 bf16 MFMAs per 32 channels and tile (144 cycles) against 24 fp32 ones (768).
+    float a[XB ? 1 : KS][3];
+    co4_bf16x8 ab[XB ? NLD : 1][3][3];                 // [load h][row tile][term]
     {
         const int co = l16 >> 2, tl = l16 & 3;
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt) {
             const int tap = 4 * rt + tl;
             const int tf = p.flip ? 8 - tap : tap;
+            if (XB) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int ch = XB ? 32 * (ks >> 3) + 8 * kq + (ks & 7) : 16 * (ks >> 2) + 4 * kq + (ks & 3);
-                a[ks][rt] = tap < 9 ? p.w[(tf * CI + ch) * p.wld + co] : 0.f;
+                for (int h = 0; h < NLD; ++h)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float wv = tap < 9 ? p.w[(tf * CI + 32 * h + 8 * kq + j) * p.wld + co] : 0.f;
+                        const __bf16 hi = (__bf16)wv; const float r1 = wv - (float)hi;
+                        const __bf16 mid = (__bf16)r1; const __bf16 lo = (__bf16)(r1 - (float)mid);
+                        ab[h][rt][0][j] = hi; ab[h][rt][1][j] = mid; ab[h][rt][2][j] = lo;
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int ch = 16 * (ks >> 2) + 4 * kq + (ks & 3);
+                    a[ks][rt] = tap < 9 ? p.w[(tf * CI + ch) * p.wld + co] : 0.f;
+                }
             }
         }
     }
@@ -85,13 +103,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
 #pragma unroll
             for (int h = 0; h < NLD; ++h) {
                 if (XB) {
-                    const unsigned u[4] = {xr[t][h].x, xr[t][h].y, xr[t][h].z, xr[t][h].w};
+                    const co4_bf16x8 xb = __builtin_bit_cast(co4_bf16x8, xr[t][h]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float xv = __uint_as_float((j & 1) ? (u[j >> 1] & 0xffff0000u) : (u[j >> 1] << 16));
+                    for (int term = 2; term >= 0; --term)      // smallest terms first
 #pragma unroll
-                        for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * h + j][rt], xv, acc[rt], 0, 0, 0);
-                    }
+                        for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[h][rt][term], xb, acc[rt], 0, 0, 0);
                 } else {
                 const float xv[4] = {__uint_as_float(xr[t][h].x), __uint_as_float(xr[t][h].y), __uint_as_float(xr[t][h].z), __uint_as_float(xr[t][h].w)};
 #pragma unroll
