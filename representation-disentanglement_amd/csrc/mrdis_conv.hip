@@ -886,7 +886,49 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     const int ntiles = (int)p.ntiles;
     const int cot = blockIdx.y;                         // 32*NS couts per y-slice of the grid
     // filter -> registers: b[t][j][ns] = w[t][2*half + j][co]
-    float b[9][2][NS];
+    // OBF16 (the layer opens / closes a bf16 stretch): the product runs on the bf16 matrix pipe, v_mfma_f32_32x32x16_bf16 -- SEVEN MFMAs of 32 cycles per
+    // strip instead of eighteen fp32 ones of 64 (the fp32 form is bound by them: 0.65 of the fp32 MFMA peak at the headline shape).  Both fp32 operands
+    // are carried to 16 mantissa bits as two bf16 terms, v = hi + mid (hi = bf16(v), mid = bf16(v - hi)), and the three products that matter are
+    // summed: x_hi w_hi + x_mid w_hi + x_hi w_mid (the fourth is below 2^-18 of the first) -- 2^-16 relative against the fp32 product, far under the
+    // bf16 rounding of the output.  k runs over (tap, product, channel): 27 groups of four channels + 1 of zeros = 7 k-steps of 32.  A half-wave owns
+    // whole taps: the lower one taps 0-3 and the (hi, hi) (mid, hi) products of tap 8, the upper one taps 4-7 and tap 8's (hi, mid) -- so a lane
+    // loads FIVE taps of 16 bytes (its four + tap 8) instead of nine of 8, and the x side of the seven k-steps is the same expression of those five
+    // loads in both half-waves: (L0h L0m) (L0h L1h) (L1m L1h) (L2h L2m) (L2h L3h) (L3m L3h) (L4h L4m); the filter side, set up once, is
+    // (wh wh) (wm wh) (wh wm) ... and for tap 8 (wh wh) in the lower, (wm 0) in the upper half-wave.
+    typedef __bf16 c4_bf16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 c4_bf16x4 __attribute__((ext_vector_type(4)));
+    constexpr int NTAPL = OBF16 ? 5 : 9;               // tap loads per strip
+    constexpr int NKS = OBF16 ? 7 : 9;                 // pipeline slots (k-steps | taps) per strip
+    float b[OBF16 ? 1 : 9][2][NS];
+    c4_bf16x8 bw[OBF16 ? 7 : 1][NS];
+    if (OBF16) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+            const int co = (cot * NS + ns) * 32 + m;
+            const int coc = co < p.Co ? co : p.Co - 1;
+            c4_bf16x4 wh[5], wm[5];                    // local tap l: tap 4 half + l (l < 4), tap 8 (l = 4)
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                const int tap = l < 4 ? 4 * half + l : 8;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = co < p.Co ? p.w[((p.flip ? 8 - tap : tap) * p.wrows + c) * p.Co + coc] : 0.f;
+                    const __bf16 h = (__bf16)v;
+                    wh[l][c] = h; wm[l][c] = (__bf16)(v - (float)h);
+                }
+            }
+            const c4_bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            // group sequence of the filter side: per local tap l < 4: wh wh wm (against x: h m h); tap 8: lower half wh wh, upper half wm 0
+            c4_bf16x4 seq[14];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { seq[3 * l] = wh[l]; seq[3 * l + 1] = wh[l]; seq[3 * l + 2] = wm[l]; }
+            seq[12] = half ? wm[4] : wh[4]; seq[13] = half ? z4 : wh[4];
+#pragma unroll
+            for (int s7 = 0; s7 < 7; ++s7)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { bw[s7][ns][c] = seq[2 * s7][c]; bw[s7][ns][4 + c] = seq[2 * s7 + 1][c]; }
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -898,17 +940,22 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
                 const float v = p.w[((p.flip ? 8 - t : t) * p.wrows + 2 * half + j) * p.Co + coc];
                 b[t][j][ns] = co < p.Co ? v : 0.f;
             }
+    }
     // bias in the accumulator layout (every register of a lane belongs to cout m).  Passing it once through
     // the matrix pipe (0*0 + bias) gives the compiler an accumulator-class value it can keep resident.
+    // (OBF16: the bias is ONE value per lane, added where the accumulator is rounded to bf16 -- a resident accumulator set per 32 couts is 16 VGPRs the
+    //  seven-MFMA form cannot spare; its first MFMA takes the inline constant 0 as C)
     f32x16 bv[NS];
+    float bias_m[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
         const int co = (cot * NS + ns) * 32 + m;
         const float v = (p.bias != nullptr && co < p.Co) ? p.bias[co < p.Co ? co : 0] : 0.f;
+        bias_m[ns] = v;
         f32x16 t16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t16[r] = v;
-        bv[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, t16, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) t16[r] = OBF16 ? 0.f : v;
+        if (OBF16) bv[ns] = t16; else bv[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, t16, 0, 0, 0);
     }
     const int tpi = p.tilesW * p.tilesH;
     // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
@@ -925,7 +972,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // geometry in bytes (host guarantees: image bytes < C4_OOB, every 24-bit multiply operand < 2^24)
     const unsigned pix = 4u * p.ldx, rowbytes = pix * (unsigned)p.W, imgbytes = rowbytes * (unsigned)p.H;
     const unsigned opix = (OBF16 ? 2u : 4u) * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
-    const unsigned lane_off = 8u * half;
+    const unsigned lane_off = OBF16 ? 0u : 8u * half;  // (bf16 matrix pipe: a lane loads all four channels of its tap)
     // OBF16: the cout pair this lane stores; odd lanes store the pair of the NEXT position of the strip row (P(r) + 1 for even r never leaves
     // the row), which is one output pixel further -- a lane constant, so the per-register part stays a wave-uniform scalar operand as in fp32
     const unsigned st_lane = OBF16 ? 2u * (m & ~1u) + 64u * NS * cot + ((m & 1) ? opix : 0u)
@@ -957,7 +1004,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)a, 0, __builtin_amdgcn_readfirstlane((int)yrec), 0x00020000);
     };
     // 9 tap byte offsets of a strip: 3 row bases x 3 column offsets, each either valid or C4_OOB.
-    auto strip_offsets = [&](int th, int tw, unsigned (&voff)[9]) {
+    auto strip_offsets = [&](int th, int tw, unsigned (&voff)[NTAPL]) {
         const unsigned h = (unsigned)(th * p.TH) + ty, w_ = (unsigned)(tw * p.TW) + tx;
         const unsigned r1 = __umul24(h, rowbytes) + lane_off, c1 = __umul24(w_, pix);
         unsigned rb[3], cb[3];
@@ -967,10 +1014,19 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         cb[0] = (w_ - 1u < uW) ? c1 - pix : C4_OOB;
         cb[1] = (w_ < uW) ? c1 : C4_OOB;
         cb[2] = (w_ + 1u < uW) ? c1 + pix : C4_OOB;
+        if (OBF16) {                                   // load l of a lane: tap 4 half + l (l < 4), tap 8 (l = 4)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int t0 = l, t1 = 4 + l;
+                voff[l] = half ? rb[t1 / 3] + cb[t1 % 3] : rb[t0 / 3] + cb[t0 % 3];
+            }
+            voff[4] = rb[2] + cb[2];
+        } else {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) voff[3 * r + c] = rb[r] + cb[c];
+            for (int c = 0; c < 3; ++c) voff[(3 * r + c) % NTAPL] = rb[r] + cb[c];
+        }
     };
     // accumulator register r of a lane is strip position P(r) + 4*half, P(r) = (r&3) + 8*(r>>2): row P/TW,
     // column P%TW (+4*half never crosses a strip row: TW >= 8).  The per-register part of the store offset is
@@ -979,10 +1035,22 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         const unsigned o = __umul24(__umul24((unsigned)(th * p.TH), uW) + (unsigned)(tw * p.TW) + 4u * half, opix) + st_lane;
         return o;
     };
-    auto load_tap = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, float2& dst) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0);
-        dst = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    auto load_tap = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, auto& dst) {
+        if constexpr (OBF16) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+            dst = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0);
+            dst = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+        }
     };
+    // a loaded tap as two bf16 terms: hi = bf16(x) (round to nearest even), mid = bf16(x - hi)
+    auto split_tap = [&](const float4& x, c4_bf16x4& hi, c4_bf16x4& mid) {
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)xv[c]; hi[c] = h; mid[c] = (__bf16)(xv[c] - (float)h); }
+    };
+    auto cat8 = [](const c4_bf16x4& lo, const c4_bf16x4& hi) -> c4_bf16x8 { return c4_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
     unsigned lane_ok_off[NS];                          // C4_OOB for lanes whose cout does not exist
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) lane_ok_off[ns] = ((cot * NS + ns) * 32 + m < p.Co) ? 0u : C4_OOB;
@@ -1003,7 +1071,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
                 }
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns) {
-                    float a0 = acc[ns][r0], a1 = acc[ns][r1];
+                    float a0 = acc[ns][r0] + bias_m[ns], a1 = acc[ns][r1] + bias_m[ns];
                     if (LRELU) { a0 = fmaxf(a0, 0.2f * a0); a1 = fmaxf(a1, 0.2f * a1); }
                     const float send = odd ? a0 : a1;                                  // what the neighbour's store needs from this lane
                     const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
@@ -1040,7 +1108,8 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // Two accumulator sets alternate as well (the set of strip i-1 is stored while strip i computes).
     // Loads are issued BEFORE the stores of an iteration slot, so waiting for a load never waits for a
     // younger store (vmcnt retires in order).
-    float2 X0[9], X1[9];
+    typedef typename std::conditional<OBF16, float4, float2>::type xtap_t;
+    xtap_t X0[NTAPL], X1[NTAPL];
     int cn = tile / tpi, c_rem = tile - cn * tpi, cth = c_rem / p.tilesW, ctw = c_rem - cth * p.tilesW;
     int ln = cn, lth = cth, ltw = ctw;                  // strip the next loads belong to
     int ltile = tile;
@@ -1051,14 +1120,35 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // loads and four (dropped) stores -- and no MFMAs, so the wait-count pass sees the same number of
     // outstanding operations on the loop-entry path as on the back edge and keeps the two-strip prefetch
     // distance instead of clamping it to the shorter path.
-    auto step = [&](auto pro, f32x16 (&acc)[NS], const f32x16 (&prev)[NS], float2 (&X)[9]) {
+    auto step = [&](auto pro, f32x16 (&acc)[NS], const f32x16 (&prev)[NS], xtap_t (&X)[NTAPL]) {
         constexpr bool PRO = decltype(pro)::value;
         const bool have_l = ltile < ntiles;                               // prefetch past the end -> strip 0
-        unsigned vo[9];
+        unsigned vo[NTAPL];
         strip_offsets(have_l ? lth : 0, have_l ? ltw : 0, vo);
         const __amdgpu_buffer_rsrc_t rsx = x_desc(have_l ? ln : 0);
         const __amdgpu_buffer_rsrc_t rsy = y_desc(pn);
         const unsigned cso = PRO ? C4_OOB : store_offset(cth, ctw);
+        if constexpr (OBF16) {
+            c4_bf16x4 xh[5], xm[5];
+            if (!PRO) {
+#pragma unroll
+                for (int l = 0; l < 5; ++l) split_tap(X[l], xh[l], xm[l]);
+            }
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                if (!PRO) {
+                    // x side of k-step t (see the top of the kernel)
+                    const c4_bf16x8 a8 = t == 0 ? cat8(xh[0], xm[0]) : t == 1 ? cat8(xh[0], xh[1]) : t == 2 ? cat8(xm[1], xh[1]) : t == 3 ? cat8(xh[2], xm[2])
+                                       : t == 4 ? cat8(xh[2], xh[3]) : t == 5 ? cat8(xm[3], xh[3]) : cat8(xh[4], xm[4]);
+#pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bw[t][ns], t == 0 ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : acc[ns], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t >= 2) load_tap(rsx, vo[t - 2], X[t - 2]);           // (the split terms above are what the MFMAs read: the raw taps are free)
+                if (t >= 3) store_group(prev, rsy, pso, pth, ptw, t - 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (!PRO) {
@@ -1077,6 +1167,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
             load_tap(rsx, vo[t], X[t]);
             if (t >= 5) store_group(prev, rsy, pso, pth, ptw, t - 5);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (!PRO) {
             pso = cso; pn = cn; pth = cth; ptw = ctw;
@@ -1111,7 +1202,7 @@ template <int NS, bool LRELU, bool FULL, bool OBF16 = false>
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) { c4conv_body<NS, LRELU, FULL, OBF16>(p); }
 // the 32-cout bf16-output form on exact strips (the si_layers' forward at 256x256): left alone the allocator takes 95 + 48 registers,
 // one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to four waves.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
 
 static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int obytes = 4) {
     if (!(Ci == 4 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (ldx % 2 == 0) && (((uintptr_t)x & 7) == 0) && Co >= 16)) return false;

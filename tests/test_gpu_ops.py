@@ -1199,7 +1199,9 @@ def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
 def test_c_from_4_data_gradient_fp32_dy_bf16_out(mrdis, case):
     """MRDIS_DT_XBF16_YF32 data gradient of a C -> 4 3x3 layer (ana_dec.output under bf16 storage): the Cin = 4 kernel convolves the fp32
     gradient with the reversed taps and writes bf16.  The filter arrives in the 16-row layout [9][16][C] of the padded bf16 kernels.
-    Same arithmetic as the fp32 call, rounded once at the store: bit-equal to its result cast to bf16."""
+    The bf16-output form multiplies on the bf16 matrix pipe with both fp32 operands carried as two bf16 terms (2^-16 relative against the fp32
+    product) and rounds once at the store: its result is the fp32 call's cast to bf16 except where that sits within 2^-16 of a rounding
+    boundary -- well under 1 % of the elements, and then the neighbouring bf16 value."""
     hip = mrdis.hip
     N, C, H, W = case
     w = rnd((4, C, 3, 3), 8, 0.1)
@@ -1211,7 +1213,13 @@ def test_c_from_4_data_gradient_fp32_dy_bf16_out(mrdis, case):
     out = hip.empty_nhwc(N, C, H, W, dev(), torch.bfloat16)
     got = hip.conv2d_bwd_data(dy, tkc16, (H, W), 3, 3, 1, 1, out=out, may_decline=True)
     assert got is not None and got.dtype == torch.bfloat16
-    assert torch.equal(got, want.to(torch.bfloat16))
+    ref = want.to(torch.bfloat16)
+    differs = (got != ref)
+    assert float(differs.float().mean()) < 0.01, float(differs.float().mean())
+    gf, rf = got.float(), ref.float()
+    # one bf16 step, or -- where the nine taps cancel -- 2^-15 of the scale of what was summed
+    assert bool(((gf - rf).abs() <= 2.0 ** -7 * rf.abs() + 2.0 ** -15 * float(want.abs().max())).all()), 'more than one bf16 step away from the fp32 result'
+    close(got, want, rtol=4e-3, what='bf16-pipe C <- 4 dgrad vs the fp32 kernel')
 
 
 def test_conv_bf16_storage_random_shapes(mrdis):
