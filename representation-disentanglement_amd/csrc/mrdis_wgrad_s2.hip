@@ -528,6 +528,180 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- 4 -> C, stride 1, bf16 dy
+// The same weight (+ bias) gradient under `compute_dtype: bf16` (dy is a bf16 view: MRDIS_DT_XF32_YBF16) on the bf16 matrix pipe.  wgrad_c4_kernel<NT, true>
+// widens dy to fp32 and IS the fp32 kernel: 384 fp32 MFMAs of 32 cycles per 256-pixel row, 41 us of matrix-pipe time on the 256x256 level against 30 us of
+// memory time -- 90 us measured.  Here the reduction axis (the pixels of a row) is the K of v_mfma_f32_16x16x32_bf16, 32 pixels per MFMA:
+//   * dy rows sit in LDS as they are in memory ([pixel][C] bf16, no widening); the B operand (8 consecutive pixels of one cout per lane) comes out of
+//     two transposing reads, ds_read_b64_tr_b16 (a 16-lane group reads 4 pixel rows x 16 couts and lane i receives cout i of the 4 pixels);
+//   * the fp32 anatomy map is split into THREE bf16 terms on its way into LDS, x = hi + mid + lo (3 x 8 mantissa bits: exact), stored PLANAR --
+//     [ring slot][term][channel][pixel + 1] -- so that the A operand of patch row (tap, ci) is 8 consecutive bf16 of one plane, an aligned 16-byte LDS read
+//     + the next dword, shifted by the tap column tx in registers (v_alignbit_b32);  the products are those of the fp32 form, exactly, only the
+//     order of the fp32 sum differs;
+//   * patch row 36 (unused in the third 16-row tile) is a row of ones: its D row is the column sum of dy, the bias gradient, for free.
+// 9 NT bf16 MFMAs of 16 cycles per 32 pixels; slab format, row split across the four waves, final cross-wave sum and the slab reduction are wgrad_c4_kernel's.
+typedef __bf16 wc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wc_s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_c4b_kernel(const WgradC4Params p) {
+    constexpr int MT = 3, CO = 16 * NT, YI = 4;
+    constexpr int DYPB = 2 * CO + (CO == 32 ? 0 : 16);            // bytes of a dy pixel row in LDS: the four rows of a transposing read fall on distinct banks
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int W = p.W, PL = W + 16;                    // plane length (bf16 elements): pixel b at index b + 1, zero columns at 0 and W + 1
+    __bf16* xs = reinterpret_cast<__bf16*>(smem_b);   // [4 slots][3 terms][4 ci][PL]
+    unsigned char* dys = smem_b + (size_t)2 * 48 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n = split / p.segs, oy0 = (split - n * p.segs) * p.R, oy1 = min(oy0 + p.R, p.H);
+
+    // patch row m = 16 mt + l16 = 4 tap + ci of this lane in each row tile; m = 36: ones; m > 36: zeros
+    int aty[MT], aoff[MT], atx[MT]; bool aok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l16;
+        aok[mt] = m < 36;
+        const int tap = aok[mt] ? m >> 2 : 0, ci = m & 3;
+        aty[mt] = tap / 3;
+        aoff[mt] = ci * PL + 8 * kq;                   // + (slot * 3 + term) * 4 * PL + b0: 16-byte aligned; the tap column tx = tap % 3 shifts in registers
+        atx[mt] = tap % 3;
+    }
+    const bool ones_row = l16 == 4;                    // (in row tile 2)
+    const int q4 = l16 >> 2, p4 = l16 & 3;
+    const int boff = (8 * kq + q4) * DYPB + 8 * p4;    // transposing read: this lane supplies row q4, columns 4 p4 .. + 3 of its group's block
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    for (int i = tid; i < 48 * PL / 2; i += 256) reinterpret_cast<unsigned*>(xs)[i] = 0u;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 xr[2], yr[2][YI];
+    auto load_set = [&](auto S_, int iy, int oy) {    // input row iy and dy row oy; nothing to fetch -> offsets out of range -> zeros
+        constexpr int S = decltype(S_)::value;
+        const bool xok = tid < W && iy <= oy1 && (unsigned)iy < (unsigned)p.H;
+        xr[S] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xok ? 4u * (unsigned)(((n * p.H + iy) * W + tid) * p.ldx) : S2_OOB), 0, 0);
+        const bool on = oy >= 0 && oy < oy1;
+        const unsigned ybase = 2u * (unsigned)((n * p.H + oy) * W * p.lddy);
+#pragma unroll
+        for (int j = 0; j < YI; ++j) {
+            const int idx = tid + 256 * j;            // 16-byte piece (pixel, q) of the row: valid while < W * 2 NT
+            const int pix = idx / (2 * NT), q = idx - pix * (2 * NT);
+            yr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((on && idx < W * 2 * NT) ? ybase + 2u * (unsigned)(pix * p.lddy + 8 * q) : S2_OOB), 0, 0);
+        }
+    };
+    auto store_set = [&](auto S_, int iy, bool with_dy) {
+        constexpr int S = decltype(S_)::value;
+        if (tid < W) {
+            __bf16* dst = xs + (size_t)((iy + 1) & 3) * 12 * PL + tid + 1;
+            const float xv[4] = {__uint_as_float(xr[S].x), __uint_as_float(xr[S].y), __uint_as_float(xr[S].z), __uint_as_float(xr[S].w)};
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const __bf16 hi = (__bf16)xv[ci]; const float r1 = xv[ci] - (float)hi;
+                const __bf16 mid = (__bf16)r1; const __bf16 lo = (__bf16)(r1 - (float)mid);
+                dst[ci * PL] = hi; dst[(4 + ci) * PL] = mid; dst[(8 + ci) * PL] = lo;
+            }
+        }
+        if (with_dy) {
+#pragma unroll
+            for (int j = 0; j < YI; ++j) {
+                const int idx = tid + 256 * j;
+                const int pix = idx / (2 * NT), q = idx - pix * (2 * NT);
+                if (idx < W * 2 * NT) *reinterpret_cast<u32x4*>(dys + pix * DYPB + 16 * q) = yr[S][j];
+            }
+        }
+    };
+    const int nsteps = W >> 5;                         // 32-pixel k-steps of a row; wave w takes steps w, w + 4, ..
+    auto compute = [&](int oy) {
+        const __bf16* arow[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) arow[mt] = xs + (size_t)((oy + aty[mt]) & 3) * 12 * PL + aoff[mt];     // input row oy - 1 + ty -> slot (oy + ty) & 3
+        for (int i = wave; i < nsteps; i += 4) {
+            const int b0 = 32 * i;
+            wc_bf16x8 bq[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                union { wc_bf16x8 v; wc_s16x4 h[2]; } u;
+                const unsigned char* src = dys + b0 * DYPB + boff + 32 * nt;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wc_s16x4 __attribute__((address_space(3)))*)(src));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wc_s16x4 __attribute__((address_space(3)))*)(src + 4 * DYPB));
+                bq[nt] = u.v;
+            }
+#pragma unroll
+            for (int term = 2; term >= 0; --term) {    // smallest terms first
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    // ten consecutive bf16 of the plane from the aligned index, as five dwords; the lane's eight start tx elements in (a misaligned
+                    // 16-byte LDS read does it in one instruction, and costs ~500 cycles: 84 us per launch against 38)
+                    const __bf16* src = arow[mt] + term * 4 * PL + b0;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(src);
+                    const unsigned d4 = *reinterpret_cast<const unsigned*>(src + 8);
+                    const unsigned dd[5] = {d.x, d.y, d.z, d.w, d4};
+                    const unsigned sh = (atx[mt] & 1) ? 16u : 0u;
+                    u32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned r = __builtin_amdgcn_alignbit(dd[j + 1], dd[j], sh);
+                        o[j] = atx[mt] == 2 ? dd[j + 1] : r;
+                    }
+                    wc_bf16x8 a = __builtin_bit_cast(wc_bf16x8, o);
+                    if (!aok[mt]) {
+                        const __bf16 fill = (mt == 2 && ones_row && term == 0) ? (__bf16)1.f : (__bf16)0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] = fill;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto step = [&](auto S_, int oy) {                // set S holds (input row oy + 2, dy row oy + 1)
+        compute(oy);
+        __syncthreads();
+        store_set(S_, oy + 2, true);
+        load_set(S_, oy + 4, oy + 3);
+        __syncthreads();
+    };
+    // prologue: rows oy0 - 1, oy0, oy0 + 1 and dy row oy0 in LDS; sets hold (oy0 + 2, dy oy0 + 1) and (oy0 + 3, dy oy0 + 2)
+    load_set(IC<0>{}, oy0 - 1, -1);
+    load_set(IC<1>{}, oy0, oy0);
+    __syncthreads();                                  // the zero fill
+    store_set(IC<0>{}, oy0 - 1, false);
+    store_set(IC<1>{}, oy0, true);
+    load_set(IC<0>{}, oy0 + 1, -1);
+    __syncthreads();
+    store_set(IC<0>{}, oy0 + 1, false);
+    load_set(IC<0>{}, oy0 + 2, oy0 + 1);
+    load_set(IC<1>{}, oy0 + 3, oy0 + 2);
+    __syncthreads();
+    for (int oy = oy0; oy < oy1; oy += 2) {           // an odd row count runs one more row on an all-zero dy row
+        step(IC<0>{}, oy);
+        step(IC<1>{}, oy + 1);
+    }
+
+    float* red = reinterpret_cast<float*>(smem_b);
+    float* out = p.slab + (long long)split * 36 * CO;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NT + nt) * 256 + (4 * kq + r) * 16 + l16] = acc[mt][nt][r];
+        __syncthreads();
+        for (int e = tid; e < NT * 256; e += 256) {
+            const int nt = e >> 8, rr = (e >> 4) & 15, cc = e & 15, m = mt * 16 + rr;
+            const float v = (red[e] + red[NT * 256 + e]) + (red[2 * NT * 256 + e] + red[3 * NT * 256 + e]);
+            if (m < 36) out[m * CO + nt * 16 + cc] = v;
+            else if (m == 36 && p.bias_slab != nullptr) p.bias_slab[(long long)split * CO + nt * 16 + cc] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- data gradient
 // dx of the same stride-2 layers (the second encoder pass back-propagates into the generated images): a window-free GEMM per dy pixel q,
 //     Z[m = (tap, ci)][q] = sum_co w[tap][co][ci] dy[q][co]            (112 = 7 tiles | 63 rows, K = Co: no padding waste),
@@ -752,8 +926,18 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float*
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + (size_t)p.splits * 36 * Co : nullptr;
     const int NT = Co / 16;
-    size_t lds = sizeof(float) * ((size_t)4 * p.rowp + (size_t)W * (Co + 16));
     const size_t red = sizeof(float) * (size_t)(4 * NT * 256);
+    if (dy_bf16 && mrdis_opt(MRDIS_OPT_MODE) != 3011) {            // the bf16 matrix pipe (debug_mode 3011: the widening fp32 form below)
+        size_t ldsb = (size_t)2 * 48 * (W + 16) + (size_t)W * (2 * Co + (Co == 32 ? 0 : 16));
+        if (ldsb < red) ldsb = red;
+        if (ldsb > 64 * 1024) return MRDIS_EUNSUPPORTED;
+        if (NT == 2) MRDIS_LAUNCH((wgrad_c4b_kernel<2>), dim3(p.splits), dim3(256), ldsb, s, p);
+        else if (NT == 4) MRDIS_LAUNCH((wgrad_c4b_kernel<4>), dim3(p.splits), dim3(256), ldsb, s, p);
+        else MRDIS_LAUNCH((wgrad_c4b_kernel<8>), dim3(p.splits), dim3(256), ldsb, s, p);
+        MRDIS_CHECK_LAUNCH();
+        return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
+    }
+    size_t lds = sizeof(float) * ((size_t)4 * p.rowp + (size_t)W * (Co + 16));
     if (lds < red) lds = red;
     if (lds > 72 * 1024) return MRDIS_EUNSUPPORTED;
     static bool attr_set = false;

@@ -1175,8 +1175,9 @@ def test_bf16_stride2_weight_gradient_parity_classes(mrdis, case):
 @pytest.mark.parametrize('case', [(2, 32, 256, 256), (9, 64, 128, 128), (32, 128, 64, 64), (3, 32, 250, 256)], ids=lambda c: 'N%d_4to%d_%dx%d' % c)
 def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
     """MRDIS_DT_XF32_YBF16 weight gradient (wgrad_c4_kernel<NT, true>): the SPADE si_layers under bf16 storage multiply the fp32 anatomy
-    map with the bf16 gradient of their output.  The kernel widens dy to fp32 on its way into LDS (exact) and then IS the fp32 kernel:
-    bit-identical to the fp32 call on dy.float(), with and without a bias sink; shapes outside the kernel decline (may_decline)."""
+    map with the bf16 gradient of their output on the bf16 matrix pipe (wgrad_c4b_kernel): the map goes in as three bf16 terms (exact), so the
+    products are those of the fp32 call on dy.float() and only the order of the fp32 sums differs; option debug_mode 3011 keeps the older form,
+    which widens dy and IS the fp32 kernel (bit-identical).  With and without a bias sink; shapes outside the kernel decline (may_decline)."""
     hip = mrdis.hip
     N, Co, H, W = case
     x = cl(rnd((N, 4, H, W), 3))
@@ -1184,7 +1185,11 @@ def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
     got = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True)
     assert got is not None
     want = hip.conv2d_bwd_weight(x, dy.float(), 3, 3, 1, 1, need_bias=True)
-    assert got[0].shape == (9, 4, Co) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert got[0].shape == (9, 4, Co)
+    close(got[0], want[0], rtol=2e-6, what='bf16-pipe si wgrad vs the fp32 kernel'); close(got[1], want[1], rtol=2e-6, what='bf16-pipe si bias gradient vs the fp32 kernel')
+    with hip.option('debug_mode', 3011):
+        old = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True)
+    assert torch.equal(old[0], want[0]) and torch.equal(old[1], want[1])
     w0 = torch.zeros(Co, 4, 3, 3, requires_grad=True)
     F.conv2d(x.cpu().contiguous(), w0, None, 1, 1).backward(dy.float().cpu().contiguous())
     close(got[0], to_tck(w0.grad), rtol=2e-5, what='si wgrad vs torch')
