@@ -2509,6 +2509,9 @@ static size_t wgrad_need(const WgradPlan& pl) {
 size_t mrdis_wgrad16_workspace(int N, int H, int W, int Ci, int Co);            // mrdis_wgrad16.hip: Cout <= 16, 3x3 s1 p1
 size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);     // mrdis_wgrad_s2.hip: Cin <= 7 stride-2 first layers
 size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co);              // mrdis_wgrad_s2.hip: the 4 -> C si_layers
+size_t mrdis_wgrad_co4b_workspace(int N, int H, int W, int Ci, int Co);
+int mrdis_run_wgrad_co4b(const void* x_bf16, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s);
 size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co, int x16_bf16);      // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
@@ -2551,6 +2554,8 @@ extern "C" size_t mrdis_conv2d_bwd_weight_workspace(int N, int H, int W, int Ci,
         if (n16 > need) need = n16;
         const size_t n4 = mrdis_wgrad_c4_workspace(N, H, W, Ci, Co);
         if (n4 > need) need = n4;
+        const size_t n4b = mrdis_wgrad_co4b_workspace(N, H, W, Ci, Co);
+        if (n4b > need) need = n4b;
     }
     { const size_t n2 = mrdis_wgrad_s2_workspace(N, H, W, Ci, Co, kh, kw, stride, pad); if (n2 > need) need = n2; }
     if (kh == 1 && kw == 1 && stride == 1 && pad == 0) { const size_t n1 = mrdis_pw_wgrad_workspace((long long)N * H * W, Ci, Co, 1); if (n1 > need) need = n1; }
@@ -2592,6 +2597,8 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     if (workspace_bytes < wgrad_need(pl)) return MRDIS_EWORKSPACE;
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     if (dtype == MRDIS_DT_XBF16_YF32) {       // the 1x1 head under bf16 storage: x bf16 (16 channels), dy fp32 (<= 8 channels)
+        if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 4)      // ana_dec.output: C -> 4, the bf16 trunk x the fp32 gradient of the anatomy logits
+            return mrdis_run_wgrad_co4b(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
         if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
         return mrdis_run_pw_wgrad(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
     }

@@ -543,9 +543,14 @@ __global__ __launch_bounds__(256) void wgrad_c4_kernel(const WgradC4Params p) {
 typedef __bf16 wc_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short wc_s16x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>
+// SWAP: the C -> 4 layer (ana_dec.output, MRDIS_DT_XBF16_YF32: x a bf16 view of C channels, dy fp32 with 4) is the same sum with the roles exchanged,
+//   dW[tap][ci][co] = sum_p x[p + off(tap)][ci] dy[p][co] = sum_p' dy[p' + off(8 - tap)][co] x[p'][ci]:
+// the four-channel fp32 tensor (`p.x` here = dy) is the one that is shifted and split, the bf16 rows (`p.dy` here = x) are the ones read transposed; the
+// slab is written in the layer's own [tap][ci][co] order (tap reversed, the two channel axes exchanged) so that the shared slab reduction needs no other
+// form, and the bias gradient (column sums of the FOUR-channel tensor over the workgroup's own rows) comes from the staging registers.
+template <int NT, int YI = 4, bool SWAP = false>
 __global__ __launch_bounds__(256) void wgrad_c4b_kernel(const WgradC4Params p) {
-    constexpr int MT = 3, CO = 16 * NT, YI = 4;
+    constexpr int MT = 3, CO = 16 * NT;
     constexpr int DYPB = 2 * CO + (CO == 32 ? 0 : 16);            // bytes of a dy pixel row in LDS: the four rows of a transposing read fall on distinct banks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int W = p.W, PL = W + 16;                    // plane length (bf16 elements): pixel b at index b + 1, zero columns at 0 and W + 1
@@ -579,6 +584,7 @@ __global__ __launch_bounds__(256) void wgrad_c4b_kernel(const WgradC4Params p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float bs4[4] = {0.f, 0.f, 0.f, 0.f};              // SWAP: this thread's share of the bias gradient
     u32x4 xr[2], yr[2][YI];
     auto load_set = [&](auto S_, int iy, int oy) {    // input row iy and dy row oy; nothing to fetch -> offsets out of range -> zeros
         constexpr int S = decltype(S_)::value;
@@ -598,6 +604,7 @@ __global__ __launch_bounds__(256) void wgrad_c4b_kernel(const WgradC4Params p) {
         if (tid < W) {
             __bf16* dst = xs + (size_t)((iy + 1) & 3) * 12 * PL + tid + 1;
             const float xv[4] = {__uint_as_float(xr[S].x), __uint_as_float(xr[S].y), __uint_as_float(xr[S].z), __uint_as_float(xr[S].w)};
+            if (SWAP && iy >= oy0 && iy < oy1) { bs4[0] += xv[0]; bs4[1] += xv[1]; bs4[2] += xv[2]; bs4[3] += xv[3]; }
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) {
                 const __bf16 hi = (__bf16)xv[ci]; const float r1 = xv[ci] - (float)hi;
@@ -695,10 +702,21 @@ __global__ __launch_bounds__(256) void wgrad_c4b_kernel(const WgradC4Params p) {
         for (int e = tid; e < NT * 256; e += 256) {
             const int nt = e >> 8, rr = (e >> 4) & 15, cc = e & 15, m = mt * 16 + rr;
             const float v = (red[e] + red[NT * 256 + e]) + (red[2 * NT * 256 + e] + red[3 * NT * 256 + e]);
-            if (m < 36) out[m * CO + nt * 16 + cc] = v;
+            if (SWAP) { if (m < 36) out[((8 - (m >> 2)) * CO + nt * 16 + cc) * 4 + (m & 3)] = v; }
+            else if (m < 36) out[m * CO + nt * 16 + cc] = v;
             else if (m == 36 && p.bias_slab != nullptr) p.bias_slab[(long long)split * CO + nt * 16 + cc] = v;
         }
         __syncthreads();
+    }
+    if (SWAP && p.bias_slab != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[c * 256 + tid] = bs4[c];
+        __syncthreads();
+        if (tid < 4) {
+            float t = 0.f;
+            for (int k = 0; k < 256; ++k) t += red[tid * 256 + k];
+            p.bias_slab[(long long)split * 4 + tid] = t;
+        }
     }
 }
 
@@ -957,6 +975,48 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float*
 #undef WC4_LAUNCH
     MRDIS_CHECK_LAUNCH();
     return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
+}
+
+// weight gradient of a C -> 4 3x3 s1 p1 layer on a bf16 input view and an fp32 gradient (MRDIS_DT_XBF16_YF32): wgrad_c4b_kernel<.., SWAP>
+static bool plan_wgrad_co4b(WgradC4Params& p, int N, int H, int W, int Ci, int Co) {
+    if (Co != 4 || (Ci != 32 && Ci != 64) || (W != 64 && W != 128 && W != 256)) return false;
+    if ((long long)W * Ci > 256 * 64 || (long long)N * H * W < 100000 || mrdis_opt(MRDIS_OPT_NOW16)) return false;    // a row of x fits the staging registers
+    p = WgradC4Params{};
+    p.N = N; p.H = H; p.W = W; p.Co = Ci;              // (the kernel's "Co" is the wide tensor's channel count)
+    int segs = mrdis_cdiv(512, N);
+    if (segs > H / 2) segs = H / 2 > 0 ? H / 2 : 1;
+    p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
+    p.splits = N * p.segs;
+    return true;
+}
+size_t mrdis_wgrad_co4b_workspace(int N, int H, int W, int Ci, int Co) {
+    WgradC4Params p;
+    if (!plan_wgrad_co4b(p, N, H, W, Ci, Co)) return 0;
+    return sizeof(float) * ((size_t)p.splits * 36 * Ci + (size_t)p.splits * 4) + 256;
+}
+int mrdis_run_wgrad_co4b(const void* x_bf16, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+    WgradC4Params p;
+    if (!plan_wgrad_co4b(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    if (lddy % 4 != 0 || ldx % 8 != 0 || ((((uintptr_t)x_bf16) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    const long long fb = 4LL * (((long long)N * H * W - 1) * lddy + 4), wb = 2LL * (((long long)N * H * W - 1) * ldx + Ci);
+    if (fb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wgrad_co4b_workspace(N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    p.x = dy; p.ldx = lddy; p.x_bytes = (unsigned)fb;               // the four-channel fp32 tensor
+    p.dy = x_bf16; p.lddy = ldx; p.dy_bytes = (unsigned)wb;         // the wide bf16 rows
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + (size_t)p.splits * 36 * Ci : nullptr;
+    const int NT = Ci / 16, pieces = W * 2 * NT / 256;              // 16-byte pieces of a wide row per thread: 1 .. 8
+    size_t lds = (size_t)2 * 48 * (W + 16) + (size_t)W * (2 * Ci + (Ci == 32 ? 0 : 16));
+    const size_t red = sizeof(float) * (size_t)(4 * NT * 256);
+    if (lds < red) lds = red;
+    if (lds > 64 * 1024) return MRDIS_EUNSUPPORTED;
+    if (NT == 2 && pieces <= 4) MRDIS_LAUNCH((wgrad_c4b_kernel<2, 4, true>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (NT == 4 && pieces <= 4) MRDIS_LAUNCH((wgrad_c4b_kernel<4, 4, true>), dim3(p.splits), dim3(256), lds, s, p);
+    else if (NT == 4 && pieces <= 8) MRDIS_LAUNCH((wgrad_c4b_kernel<4, 8, true>), dim3(p.splits), dim3(256), lds, s, p);
+    else return MRDIS_EUNSUPPORTED;
+    MRDIS_CHECK_LAUNCH();
+    return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Ci, 4, p.splits, p.bias_slab, dbias, accumulate_bias, s);
 }
 
 // data gradient of the same layers (dy (N, H/2, W/2, Co) -> dx (N, H, W, Ci)); MRDIS_EUNSUPPORTED outside what the kernel covers

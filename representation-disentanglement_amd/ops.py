@@ -659,6 +659,7 @@ def conv2d(x, w_tck, w_tkc, bias, kh, kw, stride, pad, lrelu=False, co=None):
 # batch-concatenated (G * B samples, sample block g uses filter set g) every normalisation / resize / activation kernel of the
 # decoder is ONE launch instead of G, and the G convolutions of a layer are one Python op (G calls of the C entry on batch slices):
 # a quarter of the op dispatches, autograd nodes and allocations of the per-type form.  Same kernels per sample block, same results.
+_NO_CO4B_WGRAD = _os.environ.get('MRDIS_CO4B_WGRAD', '1') == '0'      # 0: the C -> 4 layer's weight gradient on the padded bf16 kernel (A/B of wgrad_c4b_kernel<.., SWAP>)
 _GROUPED = _os.environ.get('MRDIS_GROUPED', '1') != '0'
 
 
@@ -791,12 +792,20 @@ class _GroupedConvFn(Function):
             dy = hip.cast_view(dy, torch.float32)                 # fp32 reconstruction gradient in, bf16 trunk gradient out
         elif Co_p != Co:
             if Co == 4 and dy.dtype == torch.float32 and (kh, kw, pad, ctx.stride) == (3, 3, 1, 1) and not lrelu and tkcs[0].shape[1] == 16:
-                dy4 = dy                                          # the data gradient's Cin = 4 kernel reads the fp32 gradient itself (below)
-            dy = hip.cast_view(dy, torch.bfloat16, Co_p)
+                dy4 = dy                                          # the data and weight gradients' four-channel kernels read the fp32 gradient itself (below)
+            # (the zero-padded bf16 copy is made only if one of them declines: dy_pad())
+            dy = hip.cast_view(dy, torch.bfloat16, Co_p) if dy4 is None else None
         elif dy.dtype != ctx.ydtype:
             dy = hip.cast_view(dy, ctx.ydtype)
         if lrelu:
             dy = hip.lrelu_bwd(dy, y, 0.2)
+        dy_dev = (dy if dy is not None else dy4).device
+        pad_box = [dy]
+
+        def dy_pad():
+            if pad_box[0] is None:
+                pad_box[0] = hip.cast_view(dy4, torch.bfloat16, Co_p)
+            return pad_box[0]
         H, W = ctx.xshape
         x32 = ctx.x32
         xdt = torch.bfloat16 if _COMPUTE_DTYPE == hip.DT_BF16 else x_dtype          # the (padded) input view's storage type
@@ -805,9 +814,9 @@ class _GroupedConvFn(Function):
         need_x = ctx.needs_input_grad[0]
         dxb = None
         dx4 = None
-        if need_x and x32 is not None and dy.dtype == torch.bfloat16 and tkcs[0].shape[2] == 16:
+        if need_x and x32 is not None and dy is not None and dy.dtype == torch.bfloat16 and tkcs[0].shape[2] == 16:
             # si_layers: dx of the 4-channel fp32 map straight from the window-free 4-cout kernel on the bf16 gradient (MRDIS_DT_XF32_YBF16)
-            dx4 = hip.empty_nhwc(G * B, 4, H, W, dy.device, torch.float32)
+            dx4 = hip.empty_nhwc(G * B, 4, H, W, dy_dev, torch.float32)
             for g in range(G):
                 if hip.conv2d_bwd_data(dy[g * B:(g + 1) * B], tkcs[g], (H, W), 3, 3, 1, 1, out=dx4[g * B:(g + 1) * B], may_decline=True) is None:
                     dx4 = None
@@ -820,17 +829,29 @@ class _GroupedConvFn(Function):
                 gbuf._mrdis_gb_private = True                  # hip.gb_slot takes the in-place path for tagged buffers only
                 dxb = gbuf[:, Ci:]
             else:
-                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, dy.device, xdt)
+                dxb = hip.empty_nhwc(G * B, Ci_p, H, W, dy_dev, xdt)
         sink = _grad_sink(bias) if (bias is not None and Co_p == Co) else None
         dws, db_total = [], None
         for g in range(G):
-            dyg = dy[g * B:(g + 1) * B]
+            dyg = dy[g * B:(g + 1) * B] if dy is not None else None          # (None: a four-channel fp32 gradient whose padded bf16 copy nobody has asked for yet)
             if need_x and dx4 is None:
                 # ana_dec.output (C -> 4): fp32 dy x reversed taps on the Cin = 4 kernel with a bf16 output (MRDIS_DT_XBF16_YF32), else the bf16 MFMA kernel
                 if dy4 is None or dxb.dtype != torch.bfloat16 or hip.conv2d_bwd_data(dy4[g * B:(g + 1) * B], tkcs[g], (H, W), 3, 3, 1, 1, out=dxb[g * B:(g + 1) * B],
                                                                                       may_decline=True) is None:
+                    if dyg is None:
+                        dyg = dy_pad()[g * B:(g + 1) * B]
                     hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
             res = None
+            if dy4 is not None and x32 is None and xin is not None and xin.dtype == torch.bfloat16 and not _NO_CO4B_WGRAD:
+                # ... and its weight gradient: the bf16 trunk x the fp32 gradient on the bf16 matrix pipe (wgrad_c4b_kernel<.., SWAP>) -- (9, C, 4) + the 4 bias sums
+                r4 = hip.conv2d_bwd_weight(xin if share_x else xin[g * B:(g + 1) * B], dy4[g * B:(g + 1) * B], 3, 3, 1, 1, need_bias=bias is not None, may_decline=True)
+                if r4 is not None:
+                    dw4, db4 = r4
+                    if dw4.shape[1] != Cif or Cof != 4:
+                        dw4 = torch.nn.functional.pad(dw4[:, :Cif], (0, Cof - 4))      # the filter's stored shape (column-padded mixing layout)
+                    if db4 is not None and Co_p != Co:
+                        db4 = torch.nn.functional.pad(db4, (0, Co_p - Co))           # (cut back to Co below, like the padded kernel's)
+                    res = (dw4, db4)
             if x32 is not None:          # si_layers: fp32 map x bf16 gradient on the Cin = 4 kernel -- (9, 4, C), no padded copy of the map
                 res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, may_decline=True)
                 if res is None:
@@ -844,6 +865,8 @@ class _GroupedConvFn(Function):
                 if xin is None:
                     xin = hip.cast_view(x32, torch.bfloat16, Ci_p)
                 xg = xin if share_x else xin[g * B:(g + 1) * B]
+                if dyg is None:
+                    dyg = dy_pad()[g * B:(g + 1) * B]
                 res = hip.conv2d_bwd_weight(xg, dyg, kh, kw, ctx.stride, pad, need_bias=bias is not None, bias_sink=sink, dtype=dt)
                 if padded:
                     res = (res[0][:, :Cif, :Cof].contiguous(), res[1])

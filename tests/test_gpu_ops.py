@@ -1200,6 +1200,28 @@ def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
                                  3, 3, 1, 1, may_decline=True) is None
 
 
+@pytest.mark.parametrize('case', [(2, 64, 256, 256), (8, 32, 128, 128), (32, 64, 64, 64), (3, 32, 250, 256), (5, 64, 101, 256)], ids=lambda c: 'N%d_%dto4_%dx%d' % c)
+def test_c_to_4_weight_gradient_bf16_x_fp32_dy(mrdis, case):
+    """MRDIS_DT_XBF16_YF32 weight gradient of a C -> 4 3x3 layer (ana_dec.output under bf16 storage; wgrad_c4b_kernel<.., SWAP>): the bf16 trunk times the
+    fp32 gradient of the four anatomy logits on the bf16 matrix pipe -- the gradient goes in as three bf16 terms (exact), so against torch fp32 on the same
+    operands only the order of the sums differs.  (9, C, 4) in the layer's own tap order, and the four bias sums; with a bias sink; narrow maps decline."""
+    hip = mrdis.hip
+    N, C, H, W = case
+    x = cl(rnd((N, C, H, W), 41)).to(torch.bfloat16)
+    dy = cl(rnd((N, 4, H, W), 42))
+    got = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True)
+    assert got is not None and got[0].shape == (9, C, 4) and got[1].shape == (4,)
+    w0 = torch.zeros(4, C, 3, 3, requires_grad=True)
+    F.conv2d(x.float().cpu().contiguous(), w0, None, 1, 1).backward(dy.cpu().contiguous())
+    close(got[0], to_tck(w0.grad), rtol=2e-5, what='C -> 4 wgrad vs torch')
+    close(got[1], dy.cpu().sum((0, 2, 3)), rtol=2e-5, what='C -> 4 bias gradient vs torch')
+    sink = torch.full((4,), -1.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, bias_sink=sink, may_decline=True)
+    assert none is None and torch.equal(dw2, got[0]) and torch.equal(sink, got[1] - 1.0)
+    assert hip.conv2d_bwd_weight(x[:, :, :, :40].contiguous(memory_format=torch.channels_last), dy[:, :, :, :40].contiguous(memory_format=torch.channels_last),
+                                 3, 3, 1, 1, may_decline=True) is None
+
+
 @pytest.mark.parametrize('case', [(2, 64, 256, 256), (3, 64, 70, 96), (5, 32, 32, 40)], ids=lambda c: 'N%d_%dfrom4_%dx%d' % c)
 def test_c_from_4_data_gradient_fp32_dy_bf16_out(mrdis, case):
     """MRDIS_DT_XBF16_YF32 data gradient of a C -> 4 3x3 layer (ana_dec.output under bf16 storage): the Cin = 4 kernel convolves the fp32

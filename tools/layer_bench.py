@@ -132,7 +132,11 @@ def main():
                     if hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True) is not None:
                         f_dgrad = lambda: hip.conv2d_bwd_data(dys, wkp, (hi, wi), k, k, s, p, out=dxo4, may_decline=True)      # noqa: E731
 
+                co4w = co == 4 and k == 3 and s == 1 and ci % 16 == 0 and hip.conv2d_bwd_weight(xs, dys, k, k, s, p, may_decline=True) is not None
+
                 def f_wgrad():
+                    if co4w:                              # C -> 4: the bf16 trunk x the fp32 gradient (wgrad_c4b_kernel<.., SWAP>), no padded bf16 copy of dy
+                        return hip.conv2d_bwd_weight(xs, dys, k, k, s, p, may_decline=True)
                     if ci == 4 and k == 3 and s == 1:
                         return hip.conv2d_bwd_weight(xs, dys, k, k, s, p, may_decline=True) if c4w else hip.conv2d_bwd_weight(xs, hip.cast_view(dys, torch.float32), k, k, s, p)
                     return hip.conv2d_bwd_weight(xin, dyp if cop == co else hip.cast_view(dys, B16, cop), k, k, s, p, dtype=hip.DT_F32_BF16M)
