@@ -335,6 +335,12 @@ def test_layer_zoo_at_bench_scale_bf16(mrdis, case):
             w4 = w.clone().requires_grad_(True)
             F.conv2d(xd[S].float().cpu().contiguous(), w4, b, s, p).backward(dy_s)
             wg_ref = w4.grad
+        if Co == 4 and k == 3 and s == 1 and path == 'bf16' and W in (64, 128, 256):
+            # the C -> 4 layer's weight gradient multiplies the bf16 trunk with the fp32 gradient itself (wgrad_c4b_kernel<.., SWAP>, MRDIS_DT_XBF16_YF32)
+            w4 = w.clone().requires_grad_(True)
+            dy_s = dyd[S].float().cpu().contiguous()
+            F.conv2d(xd[S].float().cpu().contiguous(), w4, b, s, p).backward(dy_s)
+            wg_ref = w4.grad
         assert rel(dw_s, to_tck(wg_ref)) <= 4e-4, ('wgrad vs torch', name, rel(dw_s, to_tck(wg_ref)))   # fp32 accumulation of bf16 products
         assert rel(db_s, dy_s.sum((0, 2, 3))) <= 4e-4, ('dbias vs torch', name)
         del dys, dw_s, db_s
