@@ -182,6 +182,10 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
  *                        that the mixing launch writes for narrow layers under bf16 storage.  MRDIS_EUNSUPPORTED elsewhere.        */
 #define MRDIS_DT_XBF16_YF32 3
 #define MRDIS_DT_XF32_YBF16 4
+/* mrdis_conv2d_bwd_weight only, OR-ed onto one of the two mixed-storage types: dw_tck has the STORED shape of a filter that the mixing launch keeps
+ * zero-padded to 16 -- [T][16][Co] for a 4 -> C layer (MRDIS_DT_XF32_YBF16), [T][Ci][16] for a C -> 4 layer (MRDIS_DT_XBF16_YF32) -- and the rows /
+ * columns beyond the layer's own are written as zeros (no pad of the result afterwards).  MRDIS_EUNSUPPORTED where the four-channel kernels decline. */
+#define MRDIS_DT_DW_PAD16   0x100
 /* w_wino (fp32 paths, may be NULL): the filter already in the Winograd domain, the image mrdis_wino_u_jobs builds from w_tck (role:
  * forward) -- used where a software-pipelined Winograd kernel takes the layer, ignored elsewhere.  w_wino_fmt: the format that image was
  * BUILT in (the job's fmt: 2 | 4 | 5; ignored when w_wino is NULL); MRDIS_EINVAL if no image of this filter shape can have it.  Format 2

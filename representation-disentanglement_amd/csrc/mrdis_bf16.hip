@@ -18,6 +18,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bw_u32x2 __attribute__((ext_vector_type(2)));
 
 
 __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
@@ -161,6 +163,7 @@ __device__ __forceinline__ void bconv_body(const TapConvParams& p, const BConvGe
     load_item(tile, 0, true);
     bool first = true;
     const bool lrelu = (p.epilogue & MRDIS_EPI_LRELU) != 0;
+    const bool wide8 = std::is_same<TS, __bf16>::value && (p.epilogue & 0x100) != 0;          // host: Cout % 8 == 0, ldout % 8 == 0, 16-byte aligned view, not debug_nopack
     while (tile < g.tiles) {
         __syncthreads();                           // everyone is done reading the previous item's LDS images
         store_item(first || !w_resident);
@@ -208,6 +211,32 @@ __device__ __forceinline__ void bconv_body(const TapConvParams& p, const BConvGe
                 const int n = n0 + pos_nb[i], a = a0 + pos_ty[i], b = b0 + pos_tx[i];
                 if (n >= p.N || a >= p.A || b >= p.B) continue;
                 TS* dst = outp + ((long long)(n * p.Hout + a * p.os + p.oh0) * p.Wout + b * p.os + p.ow0) * p.ldout;
+                if (wide8) {
+                    // bf16 output: the two half-waves of a position swap one 4-cout piece (v_permlane32_swap), every lane then holds 8 consecutive couts -- one
+                    // 16-byte store instead of two of 8 (8-byte pieces reach L2 as 16 bytes per line and instruction and halve the write rate:
+                    // tools/micro/store_pattern.hip).  Both lanes of a pair own the same position, so they take the same branches above.
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) {
+                        bw_u32x2 pk[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int co = co0 + 32 * (wave_c * WC + j) + 8 * q + 4 * half;
+                            float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+                            if (p.bias && co < p.Cout) { const float4 bb = *reinterpret_cast<const float4*>(p.bias + co); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                            if (lrelu) { v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y; v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w; }
+                            bf16x4 r; r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+                            pk[q] = __builtin_bit_cast(bw_u32x2, r);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q][0], pk[q + 1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q][1], pk[q + 1][1], false, false);
+                            const int co = co0 + 32 * (wave_c * WC + j) + 8 * (q + half);          // this lane's eight consecutive couts
+                            if (co < p.Cout && !(ABL & 16)) *reinterpret_cast<bw_u32x4*>(reinterpret_cast<__bf16*>(dst) + co) = bw_u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < WC; ++j)
 #pragma unroll
@@ -308,6 +337,7 @@ int mrdis_run_bconv(TapConvParams p, int dh_max, int dw_max, hipStream_t s, BCon
     if (p.ldin % (st_bf16 ? 8 : 4) != 0 || p.ldout % 4 != 0 || (((uintptr_t)p.in | (uintptr_t)p.w_bf16) & 15) != 0 ||
         ((uintptr_t)p.out & (st_bf16 ? 7 : 15)) != 0) return MRDIS_EUNSUPPORTED;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (st_bf16 && p.Cout % 8 == 0 && p.ldout % 8 == 0 && (((uintptr_t)p.out) & 15) == 0 && !mrdis_opt(MRDIS_OPT_NOPACK)) p.epilogue |= 0x100;      // 16-byte output stores
     // tile shape by cout width: (WAVES_C, WP, WC) -> BM x BN
     struct Cfg { int waves_c, wp, wc; };
     Cfg c;
@@ -608,7 +638,6 @@ __global__ __launch_bounds__(512) void bwgrad_pack_kernel(const BWgradPack pk) {
 // multiplied, tile i+1 goes from registers to LDS and the loads of tile i+2 are issued, one per MFMA; loads are buffer loads with
 // out-of-range offsets for padding / ragged tiles (no branches: counted vmcnt); the lane constants of the transposing reads and the
 // staging offsets are tile-invariant.  Same products, same order per workgroup: results identical to bwgrad_kernel's.
-typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
 template <int V_> struct BwIC { static constexpr int value = V_; };
 constexpr unsigned BW_OOB = 0xfffffff0u;
 __device__ __forceinline__ int bw_opaque(int idx) { asm volatile("" : "+v"(idx)); return idx; }

@@ -2511,9 +2511,9 @@ size_t mrdis_wgrad_s2_workspace(int N, int H, int W, int Ci, int Co, int kh, int
 size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co);              // mrdis_wgrad_s2.hip: the 4 -> C si_layers
 size_t mrdis_wgrad_co4b_workspace(int N, int H, int W, int Ci, int Co);
 int mrdis_run_wgrad_co4b(const void* x_bf16, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
+                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s, int pad16);
 int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s);
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s, int pad16 = 0);
 size_t mrdis_pw_wgrad_workspace(long long npix, int Ci, int Co, int x16_bf16);      // mrdis_pointwise.hip: the 1x1 16 -> <= 8 head
 int mrdis_run_pw_wgrad(const void* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        long long npix, int Ci, int Co, int accumulate_bias, int x16_bf16, hipStream_t s);
@@ -2588,6 +2588,11 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
                                        float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                                        int N, int H, int W, int Ci, int Co,
                                        int kh, int kw, int stride, int pad, int accumulate_bias, int dtype, void* stream) {
+    // MRDIS_DT_DW_PAD16 (mixed-storage calls only): dw_tck has the stored shape of a filter of the mixing launch -- [T][16][Co] for the 4 -> C layers,
+    // [T][Ci][16] for the C -> 4 layer -- and the rows / columns beyond the layer's own are written as zeros
+    const int pad16 = (dtype & MRDIS_DT_DW_PAD16) ? 1 : 0;
+    dtype &= ~MRDIS_DT_DW_PAD16;
+    if (pad16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
     const float* x = reinterpret_cast<const float*>(x_); const float* dy = reinterpret_cast<const float*>(dy_);
     WgradPlan pl;
@@ -2598,13 +2603,13 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     if (((uintptr_t)workspace & 15) != 0) return MRDIS_EALIGN;
     if (dtype == MRDIS_DT_XBF16_YF32) {       // the 1x1 head under bf16 storage: x bf16 (16 channels), dy fp32 (<= 8 channels)
         if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && Co == 4)      // ana_dec.output: C -> 4, the bf16 trunk x the fp32 gradient of the anatomy logits
-            return mrdis_run_wgrad_co4b(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
-        if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0)) return MRDIS_EUNSUPPORTED;
+            return mrdis_run_wgrad_co4b(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream, pad16);
+        if (!(kh == 1 && kw == 1 && stride == 1 && pad == 0) || pad16) return MRDIS_EUNSUPPORTED;
         return mrdis_run_pw_wgrad(x_, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, (long long)N * H * W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
     }
     if (dtype == MRDIS_DT_XF32_YBF16) {       // the 4 -> C si_layers under bf16 storage: x the fp32 anatomy map, dy bf16
         if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4)) return MRDIS_EUNSUPPORTED;
-        return mrdis_run_wgrad_c4(x, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream);
+        return mrdis_run_wgrad_c4(x, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream, pad16);
     }
     if (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) {
         rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,

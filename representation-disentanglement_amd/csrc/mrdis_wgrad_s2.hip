@@ -207,14 +207,23 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(const WgradS2Params p) {
     }
 }
 
+// pad (rin, cin, rout, cout; all 0 = none): dw is [T][rout][cout] around the slabs' [T][rin][cin] -- the zero rows / columns of a filter stored in the
+// 16-row or 16-column layout of the mixing launch are written here instead of by a pad of the result (total then counts the PADDED elements)
+struct SlabPad { int rin, cin, rout, cout; };
 __global__ __launch_bounds__(1024) void wgrad_s2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int total, int Co, int nslab,
-                                                               const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
+                                                               const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias, SlabPad pad) {
     // 32 outputs x 32 slab lanes per block; a lane walks its slabs four at a time (independent loads in flight), fixed order throughout
     __shared__ float red[32][33];
     const int nout = total + (dbias != nullptr ? Co : 0);
     const int i = blockIdx.x * 32 + threadIdx.x, y = threadIdx.y;
     const float* src = nullptr; long long stride = 0;
-    if (i < total) { src = slab + i; stride = total; }
+    if (i < total) {
+        if (pad.rout == 0) { src = slab + i; stride = total; }
+        else {
+            const int c = i % pad.cout, tr = i / pad.cout, r = tr % pad.rout, t = tr / pad.rout;
+            if (r < pad.rin && c < pad.cin) { src = slab + (t * pad.rin + r) * pad.cin + c; stride = (long long)(total / (pad.rout * pad.cout)) * pad.rin * pad.cin; }
+        }
+    }
     else if (i < nout) { src = bslab + (i - total); stride = Co; }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (src != nullptr) {
@@ -830,7 +839,16 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgradS2Params p)
 int mrdis_launch_slab_reduce(const float* slab, float* dw, int total, int Co, int nslab, const float* bslab, float* dbias, int accumulate_bias,
                              hipStream_t s) {
     const int nout = total + (dbias ? Co : 0);
-    MRDIS_LAUNCH(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias);
+    MRDIS_LAUNCH(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias, SlabPad{0, 0, 0, 0});
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+// the same with dw = [T][rout][cout] around slabs of [T][rin][cin]
+static int launch_slab_reduce_padded(const float* slab, float* dw, int T, int rin, int cin, int rout, int cout, int Co, int nslab, const float* bslab,
+                                     float* dbias, int accumulate_bias, hipStream_t s) {
+    const int total = T * rout * cout, nout = total + (dbias ? Co : 0);
+    MRDIS_LAUNCH(wgrad_s2_reduce_kernel, dim3(mrdis_cdiv(nout, 32)), dim3(32, 32), 0, s, slab, dw, total, Co, nslab, bslab, dbias, accumulate_bias,
+                 SlabPad{rin, cin, rout, cout});
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }
@@ -933,7 +951,7 @@ size_t mrdis_wgrad_c4_workspace(int N, int H, int W, int Ci, int Co) {
 
 // weight gradient of a 4 -> C 3x3 s1 p1 layer; MRDIS_EUNSUPPORTED outside what the kernel covers
 int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s) {
+                       int N, int H, int W, int Ci, int Co, int accumulate_bias, int dy_bf16, hipStream_t s, int pad16) {
     WgradC4Params p;
     if (!plan_wgrad_c4(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
     if (ldx % 4 != 0 || lddy % (dy_bf16 ? 8 : 4) != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
@@ -953,8 +971,10 @@ int mrdis_run_wgrad_c4(const float* x, int ldx, const void* dy, int lddy, float*
         else if (NT == 4) MRDIS_LAUNCH((wgrad_c4b_kernel<4>), dim3(p.splits), dim3(256), ldsb, s, p);
         else MRDIS_LAUNCH((wgrad_c4b_kernel<8>), dim3(p.splits), dim3(256), ldsb, s, p);
         MRDIS_CHECK_LAUNCH();
+        if (pad16) return launch_slab_reduce_padded(p.slab, dw_tck, 9, 4, Co, 16, Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
         return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Co, Co, p.splits, p.bias_slab, dbias, accumulate_bias, s);
     }
+    if (pad16) return MRDIS_EUNSUPPORTED;
     size_t lds = sizeof(float) * ((size_t)4 * p.rowp + (size_t)W * (Co + 16));
     if (lds < red) lds = red;
     if (lds > 72 * 1024) return MRDIS_EUNSUPPORTED;
@@ -995,7 +1015,7 @@ size_t mrdis_wgrad_co4b_workspace(int N, int H, int W, int Ci, int Co) {
     return sizeof(float) * ((size_t)p.splits * 36 * Ci + (size_t)p.splits * 4) + 256;
 }
 int mrdis_run_wgrad_co4b(const void* x_bf16, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
-                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+                         int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s, int pad16) {
     WgradC4Params p;
     if (!plan_wgrad_co4b(p, N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
     if (lddy % 4 != 0 || ldx % 8 != 0 || ((((uintptr_t)x_bf16) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
@@ -1016,6 +1036,7 @@ int mrdis_run_wgrad_co4b(const void* x_bf16, int ldx, const float* dy, int lddy,
     else if (NT == 4 && pieces <= 8) MRDIS_LAUNCH((wgrad_c4b_kernel<4, 8, true>), dim3(p.splits), dim3(256), lds, s, p);
     else return MRDIS_EUNSUPPORTED;
     MRDIS_CHECK_LAUNCH();
+    if (pad16) return launch_slab_reduce_padded(p.slab, dw_tck, 9, Ci, 4, Ci, 16, 4, p.splits, p.bias_slab, dbias, accumulate_bias, s);
     return mrdis_launch_slab_reduce(p.slab, dw_tck, 36 * Ci, 4, p.splits, p.bias_slab, dbias, accumulate_bias, s);
 }
 

@@ -541,6 +541,7 @@ def conv_out_hw(H, W, kh, kw, stride, pad):
 
 
 DT_F32, DT_F32_BF16M, DT_BF16 = 0, 1, 2          # include/mrdis.h MRDIS_DT_*
+DT_DW_PAD16 = 0x100                            # conv2d_bwd_weight(pad16=True): dw in the stored 16-row / 16-column shape of the filter (mrdis.h)
 DT_XBF16_YF32, DT_XF32_YBF16 = 3, 4              # mixed storage at the ends of a bf16 stretch (layer input x / output y)
 
 
@@ -660,17 +661,21 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
 fallbacks = collections.Counter()      # routes that left the bf16 kernels for fp32 kernels between view casts (tests read it)
 
 
-def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32, may_decline=False):
+def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None, dtype=DT_F32, may_decline=False, pad16=False):
     """-> (dw_tck, dbias).  bias_sink: a (Co,) buffer the bias gradient is ADDED to in the reduce launch
     (then dbias is returned as None).  dtype DT_F32_BF16M: bf16 MFMA operands where the geometry allows.
     may_decline: mixed-storage views (x fp32 / dy bf16: the si_layers; x bf16 / dy fp32: the 1x1 head) only have their dedicated
-    kernels -- return None instead of raising when the geometry is outside them (the caller then casts a view)."""
+    kernels -- return None instead of raising when the geometry is outside them (the caller then casts a view).
+    pad16 (mixed-storage views with a four-channel side only): dw_tck comes back in the stored shape of a filter of the mixing launch,
+    (T, 16, Co) for a 4 -> C layer / (T, Ci, 16) for a C -> 4 layer, zeros beyond the layer's own rows / columns (MRDIS_DT_DW_PAD16)."""
     lib = load()
     x, ldx = nhwc(x)
     dy, lddy = nhwc(dy)
     N, Ci, H, W = x.shape
     Co = dy.shape[1]
-    dw = torch.empty((kh * kw, Ci, Co), dtype=torch.float32, device=x.device)
+    if pad16:
+        assert x.dtype is not dy.dtype and 4 in (Ci, Co), 'pad16: the four-channel mixed-storage kernels only'
+    dw = torch.empty((kh * kw, 16 if (pad16 and Ci == 4) else Ci, 16 if (pad16 and Co == 4 and Ci != 4) else Co), dtype=torch.float32, device=x.device)
     db = torch.empty(Co, dtype=torch.float32, device=x.device) if (need_bias and bias_sink is None) else None
     nb = _ws_bytes(lib.mrdis_conv2d_bwd_weight_workspace, N, H, W, Ci, Co, kh, kw, stride, pad)
     if nb == 0:
@@ -679,7 +684,7 @@ def conv2d_bwd_weight(x, dy, kh, kw, stride, pad, need_bias=True, bias_sink=None
     sink = bias_sink if (need_bias and bias_sink is not None) else None
     if x.dtype is not dy.dtype:      # bf16 storage: the 1x1 head (x bf16, dy fp32: MRDIS_DT_XBF16_YF32), the si_layers (x fp32, dy bf16: MRDIS_DT_XF32_YBF16)
         rc = lib.mrdis_conv2d_bwd_weight(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), _ptr(sink if sink is not None else db), _ptr(ws), nb,
-                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _dt_xy(x, dy), _stream())
+                                         N, H, W, Ci, Co, kh, kw, stride, pad, 1 if sink is not None else 0, _dt_xy(x, dy) | (DT_DW_PAD16 if pad16 else 0), _stream())
         if rc == -2 and may_decline:
             return None
         _chk(rc, 'conv2d_bwd_weight (mixed storage)')

@@ -844,22 +844,25 @@ class _GroupedConvFn(Function):
             res = None
             if dy4 is not None and x32 is None and xin is not None and xin.dtype == torch.bfloat16 and not _NO_CO4B_WGRAD:
                 # ... and its weight gradient: the bf16 trunk x the fp32 gradient on the bf16 matrix pipe (wgrad_c4b_kernel<.., SWAP>) -- (9, C, 4) + the 4 bias sums
-                r4 = hip.conv2d_bwd_weight(xin if share_x else xin[g * B:(g + 1) * B], dy4[g * B:(g + 1) * B], 3, 3, 1, 1, need_bias=bias is not None, may_decline=True)
+                p16 = Cof == 16 and Cif == xin.shape[1]                    # the filter is stored column-padded (mixing layout): the reduce launch writes that shape
+                r4 = hip.conv2d_bwd_weight(xin if share_x else xin[g * B:(g + 1) * B], dy4[g * B:(g + 1) * B], 3, 3, 1, 1, need_bias=bias is not None, may_decline=True,
+                                           pad16=p16)
                 if r4 is not None:
                     dw4, db4 = r4
-                    if dw4.shape[1] != Cif or Cof != 4:
-                        dw4 = torch.nn.functional.pad(dw4[:, :Cif], (0, Cof - 4))      # the filter's stored shape (column-padded mixing layout)
+                    if dw4.shape[1] != Cif or dw4.shape[2] != Cof:
+                        dw4 = torch.nn.functional.pad(dw4[:, :Cif], (0, Cof - 4))      # the filter's stored shape
                     if db4 is not None and Co_p != Co:
                         db4 = torch.nn.functional.pad(db4, (0, Co_p - Co))           # (cut back to Co below, like the padded kernel's)
                     res = (dw4, db4)
             if x32 is not None:          # si_layers: fp32 map x bf16 gradient on the Cin = 4 kernel -- (9, 4, C), no padded copy of the map
-                res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, may_decline=True)
+                res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], dyg, kh, kw, 1, pad, need_bias=bias is not None, bias_sink=sink, may_decline=True,
+                                            pad16=(Cif == 16 and Ci == 4 and dyg.dtype == torch.bfloat16))     # (9, 16, C) straight from the reduce launch
                 if res is None:
                     # maps narrower than 64: the fp32 thin-layer kernel on the fp32 map and an fp32 copy of the (small) gradient -- the bf16 kernel
                     # would run a 16-row padded layer through 128 slabs (19 vs 45 us per call at 32x32)
                     res = hip.conv2d_bwd_weight(x32 if share_x else x32[g * B:(g + 1) * B], hip.cast_view(dyg, torch.float32), kh, kw, 1, pad,
                                                 need_bias=bias is not None, bias_sink=sink)
-                if Cif > Ci:
+                if Cif > res[0].shape[1]:
                     res = (torch.nn.functional.pad(res[0], (0, 0, 0, Cif - Ci)), res[1])      # rows of the 16-row mixing layout beyond the map's channels: zero
             if res is None:
                 if xin is None:

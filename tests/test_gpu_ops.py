@@ -1196,6 +1196,8 @@ def test_si_layer_weight_gradient_fp32_map_bf16_gradient(mrdis, case):
     sink = torch.full((Co,), -1.0, device=dev())
     dw2, none = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, bias_sink=sink, may_decline=True)
     assert none is None and torch.equal(dw2, got[0]) and torch.equal(sink, got[1] - 1.0)
+    dw16, db16 = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True, pad16=True)      # the stored 16-row shape of the filter
+    assert dw16.shape == (9, 16, Co) and torch.equal(dw16, F.pad(got[0], (0, 0, 0, 12))) and torch.equal(db16, got[1])
     assert hip.conv2d_bwd_weight(x[:, :, :, :40].contiguous(memory_format=torch.channels_last), dy[:, :, :, :40].contiguous(memory_format=torch.channels_last),
                                  3, 3, 1, 1, may_decline=True) is None
 
@@ -1218,6 +1220,8 @@ def test_c_to_4_weight_gradient_bf16_x_fp32_dy(mrdis, case):
     sink = torch.full((4,), -1.0, device=dev())
     dw2, none = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, bias_sink=sink, may_decline=True)
     assert none is None and torch.equal(dw2, got[0]) and torch.equal(sink, got[1] - 1.0)
+    dw16, db16 = hip.conv2d_bwd_weight(x, dy, 3, 3, 1, 1, need_bias=True, may_decline=True, pad16=True)      # the stored (column-padded) shape of the filter
+    assert dw16.shape == (9, C, 16) and torch.equal(dw16, F.pad(got[0], (0, 12))) and torch.equal(db16, got[1])
     assert hip.conv2d_bwd_weight(x[:, :, :, :40].contiguous(memory_format=torch.channels_last), dy[:, :, :, :40].contiguous(memory_format=torch.channels_last),
                                  3, 3, 1, 1, may_decline=True) is None
 
