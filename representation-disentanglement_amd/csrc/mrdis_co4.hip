@@ -31,8 +31,13 @@ typedef __bf16 co4_bf16x8 __attribute__((ext_vector_type(8)));
 // HALVES = Ci / 16 (2 | 4), TPW = 16-pixel tiles per wave and row = W / 64 (1 | 2 | 4).  XB: the input is a bf16 view -- a lane's 16-byte
 // load then holds EIGHT channels (k 8 kq + j of load h' <-> channel 32 h' + 8 kq + j: the filter rows follow the same map): the B operand of a
 // bf16 MFMA as it stands; everything after the MFMAs is that of the fp32 form.
-template <int HALVES, int TPW, bool XB = false>
+// SPLIT (fp32 x, option split6): the same bf16 MFMAs with BOTH operands as three bf16 terms -- a lane's two 16-byte loads of a 32-channel group are its
+// eight k-slots (slot 4 u + v <-> channel 32 g + 16 u + 4 kq + v), split in registers (v = hi + mid + lo, each the bf16 rounding of what is left), and the six
+// products of order <= 2 are summed in fp32: (hi, hi) (mid, hi) (hi, mid) (lo, hi) (hi, lo) (mid, mid); what is dropped is below 2^-23 of the product.
+// 18 bf16 MFMAs of 16 cycles per 32 channels and tile against 24 fp32 ones of 32.
+template <int HALVES, int TPW, bool XB = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) {
+    static_assert(!(XB && SPLIT), "SPLIT is the fp32-input form");
     constexpr int CI = 16 * HALVES, KS = CI / 4;
     constexpr int NLD = XB ? HALVES / 2 : HALVES;      // 16-byte loads per lane and tile
     extern __shared__ __attribute__((aligned(16))) float zs[];      // [9][W + 2][4]
@@ -46,20 +51,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
     // at 16 instead of 32 cycles each).  The pixel operand is bf16 already; the fp32 filter is split into THREE bf16 terms, w = hi + mid + lo (each the bf16
     // rounding of what the terms before it left: 3 x 8 mantissa bits cover fp32's 24), so the products are those of the fp32 form, exactly, and only the order
     // of the fp32 sum differs -- 9 bf16 MFMAs per 32 channels and tile (144 cycles) against 24 fp32 ones (768).
-    float a[XB ? 1 : KS][3];
-    co4_bf16x8 ab[XB ? NLD : 1][3][3];                 // [load h][row tile][term]
+    constexpr int NG = XB ? NLD : HALVES / 2;          // 32-channel groups
+    float a[(XB || SPLIT) ? 1 : KS][3];
+    co4_bf16x8 ab[(XB || SPLIT) ? NG : 1][3][3];       // [32-channel group][row tile][term]
     {
         const int co = l16 >> 2, tl = l16 & 3;
 #pragma unroll
         for (int rt = 0; rt < 3; ++rt) {
             const int tap = 4 * rt + tl;
             const int tf = p.flip ? 8 - tap : tap;
-            if (XB) {
+            if (XB || SPLIT) {
 #pragma unroll
-                for (int h = 0; h < NLD; ++h)
+                for (int h = 0; h < NG; ++h)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float wv = tap < 9 ? p.w[(tf * CI + 32 * h + 8 * kq + j) * p.wld + co] : 0.f;
+                        const int ch = XB ? 32 * h + 8 * kq + j : 32 * h + 16 * (j >> 2) + 4 * kq + (j & 3);
+                        const float wv = tap < 9 ? p.w[(tf * CI + ch) * p.wld + co] : 0.f;
                         const __bf16 hi = (__bf16)wv; const float r1 = wv - (float)hi;
                         const __bf16 mid = (__bf16)r1; const __bf16 lo = (__bf16)(r1 - (float)mid);
                         ab[h][rt][0][j] = hi; ab[h][rt][1][j] = mid; ab[h][rt][2][j] = lo;
@@ -100,6 +107,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_co4_kernel(const Co4Params p) 
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (SPLIT) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const unsigned u[8] = {xr[t][2 * g].x, xr[t][2 * g].y, xr[t][2 * g].z, xr[t][2 * g].w, xr[t][2 * g + 1].x, xr[t][2 * g + 1].y, xr[t][2 * g + 1].z, xr[t][2 * g + 1].w};
+                    co4_bf16x8 xh, xm, xl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = __uint_as_float(u[j]);
+                        const __bf16 hi = (__bf16)v; const float r1 = v - (float)hi;
+                        const __bf16 mid = (__bf16)r1;
+                        xh[j] = hi; xm[j] = mid; xl[j] = (__bf16)(r1 - (float)mid);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) {   // smallest products first
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][1], xm, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][0], xl, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][2], xh, acc[rt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][0], xm, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][1], xh, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[g][rt][0], xh, acc[rt], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int h = 0; h < NLD; ++h) {
                 if (XB) {
@@ -150,12 +183,14 @@ int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, flo
     Co4Params p{};
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.ldx = ldx; p.ldy = ldy; p.flip = flip; p.lrelu = lrelu;
     p.x_bytes = (unsigned)xb; p.wld = wld;
-    int segs = mrdis_cdiv(512, N);                     // ~512 workgroups, each a run of consecutive rows of one image
+    int segs = mrdis_cdiv(512, N);                     // ~512 workgroups, each a run of consecutive rows of one image (768 - 2048: no faster)
     if (segs > H / 4) segs = H / 4 > 0 ? H / 4 : 1;
     p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
     const size_t lds = sizeof(float) * (size_t)9 * (W + 2) * 4;
     const dim3 grid(N * p.segs), block(256);
+    const bool split = !x_bf16 && mrdis_opt(MRDIS_OPT_SPLIT6) > 0;
 #define CO4_LAUNCH(HV, TP) { if (x_bf16) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
+                             else if (split) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false, true>), grid, block, lds, s, p); \
                              else MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }
     const int tpw = W / 64;
     if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4) else if (tpw == 2) CO4_LAUNCH(4, 2) else CO4_LAUNCH(4, 1) }

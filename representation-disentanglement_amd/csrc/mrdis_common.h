@@ -16,7 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Process-wide switches.  Each is read from its environment variable ONCE (first use) and afterwards only changes through
 // mrdis_set_option(): no getenv() on the launch path.  Boolean debug switches: variable present = 1.  Value switches: -1 = unset.
 enum {
-    MRDIS_OPT_WINO, MRDIS_OPT_NT_MB, MRDIS_OPT_WINO_PIPE, MRDIS_OPT_WINO_U, MRDIS_OPT_WINO4, MRDIS_OPT_WINO4R, MRDIS_OPT_BCONV4,
+    MRDIS_OPT_WINO, MRDIS_OPT_NT_MB, MRDIS_OPT_WINO_PIPE, MRDIS_OPT_WINO_U, MRDIS_OPT_WINO4, MRDIS_OPT_WINO4R, MRDIS_OPT_BCONV4, MRDIS_OPT_SPLIT6,
     MRDIS_OPT_NO16, MRDIS_OPT_NOTHIN, MRDIS_OPT_NOC4, MRDIS_OPT_NODMA, MRDIS_OPT_NO16_3D, MRDIS_OPT_BILGEN, MRDIS_OPT_NOW16, MRDIS_OPT_NOPACK,
     MRDIS_OPT_MODE, MRDIS_OPT_BN, MRDIS_OPT_KC, MRDIS_OPT_BM, MRDIS_OPT_C4_TW, MRDIS_OPT_WGSPLIT, MRDIS_OPT_BN3, MRDIS_OPT_KC3,
     MRDIS_OPT_COUNT

@@ -594,6 +594,16 @@ def test_conv3x3_4_couts_gemm_gather(mrdis, case):
     finally:
         hip.set_option('debug_now16', 0)
     close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs co4'); close(ref_dx, dx.cpu(), rtol=2e-5, what='tile kernel vs co4 dgrad')
+    # option split6: the same products from three bf16 terms per operand on the bf16 matrix pipe (six of the nine, the rest below 2^-23 of a product) --
+    # at the exact fp32 kernel's own level against a float64 reference: its error may not exceed twice the fp32 kernel's (+ 1e-7 of the scale)
+    want64 = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    with hip.option('split6', 1):
+        got6 = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+        dx6 = hip.conv2d_bwd_data(xv, to_tkc(w2).to(dev()), (H, W), 3, 3, 1, 1)
+    sc = float(want64.abs().max())
+    e32, e6 = float((got.cpu().double() - want64).abs().max()) / sc, float((got6.cpu().double() - want64).abs().max()) / sc
+    assert e6 <= 2.0 * e32 + 1e-7, ('split6 forward', e6, e32)
+    close(got6, got, rtol=2e-6, what='split6 vs fp32 MFMA, forward'); close(dx6, dx, rtol=2e-6, what='split6 vs fp32 MFMA, data gradient')
 
 
 @pytest.mark.parametrize('case', [(3, 32, 150, 256), (5, 64, 100, 128), (9, 128, 64, 64), (2, 32, 256, 256), (30, 128, 63, 64)], ids=str)
