@@ -538,6 +538,30 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms_direct = float(t)
 
+    # the four-channel thin layers with fp32 MFMA (option split6 = 0) instead of the six-product bf16 split the default policy uses for them: same run, same
+    # box, a few steps -- beside the headline, with the loss both ways (the split is accepted only at the exact kernels' own error level: tests)
+    split6 = None
+    if a.dtype == 'f32' and not a.no_direct and mrdis.hip.get_option('split6') != 0:
+        mrdis.hip.set_option('split6', 0)
+        nd = max(2, min(a.steps, 5))
+        step(xd, maskd, mimgd, mask, targets=tgt)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nd):
+            step(xd, maskd, mimgd, mask, targets=tgt)
+        sync()
+        ms_off = (time.perf_counter() - t0) / nd * 1e3
+        mrdis.hip.set_option('split6', 1)
+        if world > 1:
+            t = torch.tensor([ms_off], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_off = float(t)
+        split6 = {'ms_per_step_fp32_mfma_only': round(ms_off, 2),
+                  'what': 'option split6 = 1 (default): the 3x3 stride-1 layers with a four-channel side (4 -> C forward, C -> 4 forward and data gradient) multiply on '
+                          'v_mfma_f32_32x32x16_bf16 / 16x16x32 with both fp32 operands as three bf16 terms and the six products of order <= 2 summed in fp32 '
+                          '(dropped: < 2^-23 of a product); = 0: fp32 MFMA.  Unit tests hold the split within 2e-6 of the fp32 kernels and at <= 2x their error against float64',
+                  'steps_timed': nd}
+
     if rank == 0:
         out = {
             'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
@@ -568,6 +592,7 @@ def main():
             'mfma_peak_dtype': 'f32' if a.dtype == 'f32' else 'bf16',
             'key_aliases': {'step_tflops_f32': 'step_tflops', 'mfma_f32_peak_tflops': 'mfma_peak_tflops', 'step_tflops_f32_direct_only': 'step_tflops_direct_only'},      # round-2 names of the same fields
             'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),
+            'split6': split6,
             'step_tflops_direct_only': None if ms_direct is None else round(
                 FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
         }

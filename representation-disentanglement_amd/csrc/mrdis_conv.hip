@@ -876,8 +876,15 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // bf16 stretch).  A lane owns ONE cout, so a bf16 store of its own would be 2 bytes; adjacent lanes exchange one value per register pair
 // (DPP quad_perm 1,0,3,2) and each stores a packed cout PAIR: even lanes (m, m+1) of position r, odd lanes (m-1, m) of position r + 1 --
 // half the store instructions of the fp32 form, every one of them 4 bytes per lane.
-template <int NS, bool LRELU, bool FULL, bool OBF16>   // FULL: the strips tile the image exactly (no per-store position checks)
+// SPLIT6 (fp32 output, option split6): the bf16 matrix pipe at fp32 accuracy -- BOTH operands as three bf16 terms (v = hi + mid + lo, 3 x 8 mantissa bits) and
+// the six products of order <= 2, x_h w_h + x_m w_h + x_h w_m + x_l w_h + x_h w_l + x_m w_m (what is dropped is below 2^-23 of a product): 54 groups of four
+// channels = 14 k-steps of 32 cycles against 18 fp32 MFMAs of 64.  Same ownership of whole taps by the half-waves as the two-term form below; per tap the
+// x side of its three k-steps is (h m) (h l) (h m) against the filter's (wh wh) (wm wh) (wl wm); tap 8: (h m) (h l) against (wh wh) (wm wh) in the lower and
+// (wl wm) (0 0) in the upper half-wave.
+template <int NS, bool LRELU, bool FULL, bool OBF16, bool SPLIT6 = false>   // FULL: the strips tile the image exactly (no per-store position checks)
 __device__ __forceinline__ void c4conv_body(const C4Params& p) {
+    static_assert(!(OBF16 && SPLIT6), "SPLIT6 is the fp32-output form");
+    constexpr bool BFP = OBF16 || SPLIT6;              // the product runs on the bf16 matrix pipe
     const int lane = threadIdx.x & 63, half = lane >> 5, m = lane & 31;
     const unsigned ty = m / p.TW, tx = m - ty * p.TW;
     // wave-uniform strip bookkeeping lives in SGPRs (readfirstlane makes the uniformity provable)
@@ -897,10 +904,37 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // (wh wh) (wm wh) (wh wm) ... and for tap 8 (wh wh) in the lower, (wm 0) in the upper half-wave.
     typedef __bf16 c4_bf16x8 __attribute__((ext_vector_type(8)));
     typedef __bf16 c4_bf16x4 __attribute__((ext_vector_type(4)));
-    constexpr int NTAPL = OBF16 ? 5 : 9;               // tap loads per strip
-    constexpr int NKS = OBF16 ? 7 : 9;                 // pipeline slots (k-steps | taps) per strip
-    float b[OBF16 ? 1 : 9][2][NS];
-    c4_bf16x8 bw[OBF16 ? 7 : 1][NS];
+    constexpr int NTAPL = BFP ? 5 : 9;                 // tap loads per strip
+    constexpr int NKS = SPLIT6 ? 14 : (OBF16 ? 7 : 9); // pipeline slots (k-steps | taps) per strip
+    float b[BFP ? 1 : 9][2][NS];
+    c4_bf16x8 bw[BFP ? NKS : 1][NS];
+    if (SPLIT6) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+            const int co = (cot * NS + ns) * 32 + m;
+            const int coc = co < p.Co ? co : p.Co - 1;
+            c4_bf16x4 wh[5], wm[5], wl[5];             // local tap l: tap 4 half + l (l < 4), tap 8 (l = 4)
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                const int tap = l < 4 ? 4 * half + l : 8;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = co < p.Co ? p.w[((p.flip ? 8 - tap : tap) * p.wrows + c) * p.Co + coc] : 0.f;
+                    const __bf16 h = (__bf16)v; const float r1 = v - (float)h; const __bf16 mi = (__bf16)r1;
+                    wh[l][c] = h; wm[l][c] = mi; wl[l][c] = (__bf16)(r1 - (float)mi);
+                }
+            }
+            const c4_bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            c4_bf16x4 seq[28];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { seq[6 * l] = wh[l]; seq[6 * l + 1] = wh[l]; seq[6 * l + 2] = wm[l]; seq[6 * l + 3] = wh[l]; seq[6 * l + 4] = wl[l]; seq[6 * l + 5] = wm[l]; }
+            seq[24] = half ? wl[4] : wh[4]; seq[25] = half ? wm[4] : wh[4]; seq[26] = half ? z4 : wm[4]; seq[27] = half ? z4 : wh[4];
+#pragma unroll
+            for (int s14 = 0; s14 < 14; ++s14)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { bw[s14][ns][c] = seq[2 * s14][c]; bw[s14][ns][4 + c] = seq[2 * s14 + 1][c]; }
+        }
+    } else
     if (OBF16) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
@@ -954,8 +988,8 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         bias_m[ns] = v;
         f32x16 t16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t16[r] = OBF16 ? 0.f : v;
-        if (OBF16) bv[ns] = t16; else bv[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, t16, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) t16[r] = BFP ? 0.f : v;
+        if (BFP) bv[ns] = t16; else bv[ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, t16, 0, 0, 0);
     }
     const int tpi = p.tilesW * p.tilesH;
     // strip index -> (n, th, tw), advanced incrementally by the grid stride (no divisions in the loop)
@@ -972,7 +1006,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // geometry in bytes (host guarantees: image bytes < C4_OOB, every 24-bit multiply operand < 2^24)
     const unsigned pix = 4u * p.ldx, rowbytes = pix * (unsigned)p.W, imgbytes = rowbytes * (unsigned)p.H;
     const unsigned opix = (OBF16 ? 2u : 4u) * p.ldy, oimgbytes = opix * (unsigned)p.W * (unsigned)p.H;
-    const unsigned lane_off = OBF16 ? 0u : 8u * half;  // (bf16 matrix pipe: a lane loads all four channels of its tap)
+    const unsigned lane_off = BFP ? 0u : 8u * half;    // (bf16 matrix pipe: a lane loads all four channels of its tap)
     // OBF16: the cout pair this lane stores; odd lanes store the pair of the NEXT position of the strip row (P(r) + 1 for even r never leaves
     // the row), which is one output pixel further -- a lane constant, so the per-register part stays a wave-uniform scalar operand as in fp32
     const unsigned st_lane = OBF16 ? 2u * (m & ~1u) + 64u * NS * cot + ((m & 1) ? opix : 0u)
@@ -1014,7 +1048,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         cb[0] = (w_ - 1u < uW) ? c1 - pix : C4_OOB;
         cb[1] = (w_ < uW) ? c1 : C4_OOB;
         cb[2] = (w_ + 1u < uW) ? c1 + pix : C4_OOB;
-        if (OBF16) {                                   // load l of a lane: tap 4 half + l (l < 4), tap 8 (l = 4)
+        if (BFP) {                                     // load l of a lane: tap 4 half + l (l < 4), tap 8 (l = 4)
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 const int t0 = l, t1 = 4 + l;
@@ -1036,7 +1070,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         return o;
     };
     auto load_tap = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, auto& dst) {
-        if constexpr (OBF16) {
+        if constexpr (BFP) {
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
             dst = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         } else {
@@ -1049,6 +1083,14 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         const float xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const __bf16 h = (__bf16)xv[c]; hi[c] = h; mid[c] = (__bf16)(xv[c] - (float)h); }
+    };
+    auto split_tap3 = [&](const float4& x, c4_bf16x4& hi, c4_bf16x4& mid, c4_bf16x4& lo) {
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const __bf16 h = (__bf16)xv[c]; const float r1 = xv[c] - (float)h; const __bf16 mi = (__bf16)r1;
+            hi[c] = h; mid[c] = mi; lo[c] = (__bf16)(r1 - (float)mi);
+        }
     };
     auto cat8 = [](const c4_bf16x4& lo, const c4_bf16x4& hi) -> c4_bf16x8 { return c4_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
     unsigned lane_ok_off[NS];                          // C4_OOB for lanes whose cout does not exist
@@ -1096,7 +1138,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
             }
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
-                float v = acc[ns][r];
+                float v = SPLIT6 ? acc[ns][r] + bias_m[ns] : acc[ns][r];
                 if (LRELU) v = fmaxf(v, 0.2f * v);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)((vo | lane_ok_off[ns]) + 128u * ns), (int)soff, C4_STORE_NT);
             }
@@ -1108,7 +1150,7 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
     // Two accumulator sets alternate as well (the set of strip i-1 is stored while strip i computes).
     // Loads are issued BEFORE the stores of an iteration slot, so waiting for a load never waits for a
     // younger store (vmcnt retires in order).
-    typedef typename std::conditional<OBF16, float4, float2>::type xtap_t;
+    typedef typename std::conditional<BFP, float4, float2>::type xtap_t;
     xtap_t X0[NTAPL], X1[NTAPL];
     int cn = tile / tpi, c_rem = tile - cn * tpi, cth = c_rem / p.tilesW, ctw = c_rem - cth * p.tilesW;
     int ln = cn, lth = cth, ltw = ctw;                  // strip the next loads belong to
@@ -1128,6 +1170,26 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
         const __amdgpu_buffer_rsrc_t rsx = x_desc(have_l ? ln : 0);
         const __amdgpu_buffer_rsrc_t rsy = y_desc(pn);
         const unsigned cso = PRO ? C4_OOB : store_offset(cth, ctw);
+        if constexpr (SPLIT6) {
+            // a tap is split when its first k-step comes up and its raw registers are refilled (strip i + 2) behind its last one: one tap's three terms live at a
+            // time (all five up front: 192 VGPRs, two waves per SIMD)
+            c4_bf16x4 xh, xm, xl;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 14; ++t) {
+                const int l = t / 3;                   // k-steps 3 l .. 3 l + 2 belong to local tap l (12, 13: tap 8)
+                if (!PRO) {
+                    if (t % 3 == 0) split_tap3(X[l], xh, xm, xl);
+                    const c4_bf16x8 a8 = (t % 3 == 1) ? cat8(xh, xl) : cat8(xh, xm);
+#pragma unroll
+                    for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, bw[t][ns], t == 0 ? zero16 : acc[ns], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 2 || t == 5 || t == 8 || t == 11 || t == 13) load_tap(rsx, vo[l], X[l]);
+                if (t == 6 || t == 7 || t == 9 || t == 10) store_group(prev, rsy, pso, pth, ptw, t < 8 ? t - 6 : t - 7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         if constexpr (OBF16) {
             c4_bf16x4 xh[5], xm[5];
             if (!PRO) {
@@ -1200,6 +1262,8 @@ __device__ __forceinline__ void c4conv_body(const C4Params& p) {
 }
 template <int NS, bool LRELU, bool FULL, bool OBF16 = false>
 __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) { c4conv_body<NS, LRELU, FULL, OBF16>(p); }
+template <bool LRELU, bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_split6_kernel(const C4Params p) { c4conv_body<1, LRELU, FULL, false, true>(p); }
 // the 32-cout bf16-output form on exact strips (the si_layers' forward at 256x256): left alone the allocator takes 95 + 48 registers,
 // one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to four waves.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
@@ -1227,7 +1291,8 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     p.tilesW = mrdis_cdiv(W, p.TW); p.tilesH = mrdis_cdiv(H, p.TH);
     p.ntiles = (long long)N * p.tilesW * p.tilesH;
     const int co32 = mrdis_cdiv(Co, 32);
-    const int NS = (co32 % 2 == 0 && co32 >= 2) ? 2 : 1;
+    const bool split6 = !obf16 && mrdis_opt(MRDIS_OPT_SPLIT6) > 0;        // six bf16 products per fp32 product; 32 couts per workgroup (14 x 4 filter registers per 32)
+    const int NS = (co32 % 2 == 0 && co32 >= 2 && !split6) ? 2 : 1;
     const int ny = co32 / NS;
     long long blocks = (p.ntiles + 3) / 4;
     // persistent grid: exactly the number of workgroups the chip holds at once (one wave of workgroups,
@@ -1246,6 +1311,10 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
 #define C4_LAUNCH(ns, lr, fa) MRDIS_LAUNCH((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
+    if (split6) {
+        if (p.lrelu) { if (fast) MRDIS_LAUNCH((c4conv_split6_kernel<true, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_split6_kernel<true, false>), grid, dim3(256), 0, s, p); }
+        else { if (fast) MRDIS_LAUNCH((c4conv_split6_kernel<false, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_split6_kernel<false, false>), grid, dim3(256), 0, s, p); }
+    } else
     if (obf16) {       // the si_layers' forward (flip = 0) and the C <- 4 data gradient (flip = 1: run time); no LeakyReLU follows either
         if (NS == 2) { if (fast) MRDIS_LAUNCH((c4conv_kernel<2, false, true, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_kernel<2, false, false, true>), grid, dim3(256), 0, s, p); }
         else { if (fast) MRDIS_LAUNCH(c4conv_obf16_kernel, grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_kernel<1, false, false, true>), grid, dim3(256), 0, s, p); }

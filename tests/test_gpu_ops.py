@@ -424,8 +424,17 @@ def test_conv_c4_persistent_pipeline(mrdis):
         want = F.conv2d(x, w, b, 1, 1)
         got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
         close(got, want, what=f'c4 {N}x{H}x{W}->{Co}')
-        got = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1, lrelu=True)
-        close(got, F.leaky_relu(want, 0.2), what='c4 lrelu')
+        gotl = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1, lrelu=True)
+        close(gotl, F.leaky_relu(want, 0.2), what='c4 lrelu')
+        # option split6: six bf16 products per fp32 product on the bf16 matrix pipe (c4conv_split6_kernel) -- at the fp32 kernel's own level against float64
+        want64 = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+        with hip.option('split6', 1):
+            got6 = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
+            got6l = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1, lrelu=True)
+        sc = float(want64.abs().max())
+        e32, e6 = float((got.cpu().double() - want64).abs().max()) / sc, float((got6.cpu().double() - want64).abs().max()) / sc
+        assert e6 <= 2.0 * e32 + 1e-7, ('split6 c4 forward', e6, e32)
+        close(got6, got, rtol=2e-6, what='split6 vs fp32 MFMA'); close(got6l, gotl, rtol=2e-6, what='split6 vs fp32 MFMA, lrelu')
 
 
 @pytest.mark.parametrize('N,Ci,Co,H,W,k,st', [(24, 32, 32, 128, 144, 3, 1), (8, 64, 96, 72, 80, 3, 1), (16, 32, 64, 64, 64, 4, 2),
