@@ -542,6 +542,7 @@ def main():
     # box, a few steps -- beside the headline, with the loss both ways (the split is accepted only at the exact kernels' own error level: tests)
     split6 = None
     if a.dtype == 'f32' and not a.no_direct and mrdis.hip.get_option('split6') != 0:
+        prev6 = mrdis.hip.get_option('split6')
         mrdis.hip.set_option('split6', 0)
         nd = max(2, min(a.steps, 5))
         step(xd, maskd, mimgd, mask, targets=tgt)
@@ -551,13 +552,13 @@ def main():
             step(xd, maskd, mimgd, mask, targets=tgt)
         sync()
         ms_off = (time.perf_counter() - t0) / nd * 1e3
-        mrdis.hip.set_option('split6', 1)
+        mrdis.hip.set_option('split6', prev6)
         if world > 1:
             t = torch.tensor([ms_off], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms_off = float(t)
         split6 = {'ms_per_step_fp32_mfma_only': round(ms_off, 2),
-                  'what': 'option split6 = 1 (default): the 3x3 stride-1 layers with a four-channel side (4 -> C forward, C -> 4 forward and data gradient) multiply on '
+                  'what': 'option split6 = 1 (default): the 3x3 stride-1 layers with a four-channel side (4 -> C forward / C <- 4 data gradient up to 32 couts, C -> 4 forward / 4 <- C data gradient) multiply on '
                           'v_mfma_f32_32x32x16_bf16 / 16x16x32 with both fp32 operands as three bf16 terms and the six products of order <= 2 summed in fp32 '
                           '(dropped: < 2^-23 of a product); = 0: fp32 MFMA.  Unit tests hold the split within 2e-6 of the fp32 kernels and at <= 2x their error against float64',
                   'steps_timed': nd}

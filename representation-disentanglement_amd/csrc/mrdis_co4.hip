@@ -188,7 +188,7 @@ int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, flo
     p.R = mrdis_cdiv(H, segs); p.segs = mrdis_cdiv(H, p.R);
     const size_t lds = sizeof(float) * (size_t)9 * (W + 2) * 4;
     const dim3 grid(N * p.segs), block(256);
-    const bool split = !x_bf16 && mrdis_opt(MRDIS_OPT_SPLIT6) > 0;
+    const bool split = !x_bf16 && (mrdis_opt(MRDIS_OPT_SPLIT6) == 1 || mrdis_opt(MRDIS_OPT_SPLIT6) == 3 || mrdis_opt(MRDIS_OPT_SPLIT6) == 4);      // (option split6: mrdis_conv.hip, run_c4conv)
 #define CO4_LAUNCH(HV, TP) { if (x_bf16) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
                              else if (split) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false, true>), grid, block, lds, s, p); \
                              else MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }

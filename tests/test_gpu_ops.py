@@ -428,7 +428,7 @@ def test_conv_c4_persistent_pipeline(mrdis):
         close(gotl, F.leaky_relu(want, 0.2), what='c4 lrelu')
         # option split6: six bf16 products per fp32 product on the bf16 matrix pipe (c4conv_split6_kernel) -- at the fp32 kernel's own level against float64
         want64 = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
-        with hip.option('split6', 1):
+        with hip.option('split6', 4):                   # (4: every width; the default 1 takes <= 32 couts)
             got6 = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
             got6l = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1, lrelu=True)
         sc = float(want64.abs().max())
