@@ -173,13 +173,16 @@ int mrdis_mix_jobs_bwd(const void* jobs, int njobs, int total_blocks, const void
  * LAYER's input x (= dx) and output y (= dy), the same code goes to its forward, data-gradient and weight-gradient entry points.
  *   MRDIS_DT_XBF16_YF32  x / dx bf16 views, y / dy fp32: the 1x1 decoder head 16 -> <= 8 (forward, data gradient, weight gradient); the 3x3
  *                        C -> 4 layer (ana_dec.output): forward (x bf16, C = 32 / 64, y (N, H, W, 4) fp32; w_tck is then [9][C][16], columns >= 4
- *                        zero) and data gradient (dy fp32 -> dx bf16; w_tkc is then [9][16][Ci], rows >= 4 zero)
+ *                        zero), data gradient (dy fp32 -> dx bf16; w_tkc is then [9][16][Ci], rows >= 4 zero) and weight gradient (x bf16 with
+ *                        C = 32 / 64, dy (N, H, W, 4) fp32 -> dw_tck (9, C, 4) + the 4 bias sums; maps 64 / 128 / 256 wide, else MRDIS_EUNSUPPORTED)
  *   MRDIS_DT_XF32_YBF16  x / dx fp32, y / dy bf16: the 3x3 4 -> C si_layers -- forward (w_tck is then the [9][16][Co] layout, rows >= 4 zero),
  *                        weight gradient (dw_tck (9, 4, Co); maps 64 / 128 / 256 wide, Co 32 / 64 / 128, else MRDIS_EUNSUPPORTED) and data
  *                        gradient (dy bf16, Co = 32 / 64 -> dx (N, H, W, 4) fp32; w_tkc is then [9][Co][16], columns >= 4 zero)
+ *                        (the 16-row / 16-column filter layouts are those the mixing launch writes for narrow layers under bf16 storage)
+ * These kernels multiply on the bf16 matrix pipe with the fp32 side carried as two (bf16-output forms) or three (fp32-output forms: exact
+ * products) bf16 terms; MRDIS_EUNSUPPORTED outside the shapes named.
  * Under MRDIS_DT_BF16 mrdis_conv2d_bwd_weight also takes the stride-2 layers (3x3 / 4x4, pad 1, even H and W, Ci 16 or a multiple of 32, Co % 8 == 0):
- * four input-parity classes in one launch.
- *                        that the mixing launch writes for narrow layers under bf16 storage.  MRDIS_EUNSUPPORTED elsewhere.        */
+ * four input-parity classes in one launch.                                                                                          */
 #define MRDIS_DT_XBF16_YF32 3
 #define MRDIS_DT_XF32_YBF16 4
 /* mrdis_conv2d_bwd_weight only, OR-ed onto one of the two mixed-storage types: dw_tck has the STORED shape of a filter that the mixing launch keeps
