@@ -131,6 +131,130 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const C16Params p) 
     }
 }
 
+// ---- six-product form (option split6; Ci = 32): the same convolution on the bf16 matrix pipe at fp32 accuracy.  The fp32 form above is bound by its 288
+// fp32 MFMAs of 32 cycles per wave and tile (19.3 GFLOP at 113 TF/s = 0.72 of the fp32 MFMA peak; the layer moves 402 MB: 75 us at the rate the narrow
+// layers stream).  Both operands become three bf16 terms, v = hi + mid + lo (each the bf16 rounding of what the terms before it left), and the six products of
+// order <= 2 are summed in fp32 (dropped: < 2^-23 of a product): K = 32 channels is ONE v_mfma_f32_16x16x32_bf16, so a tap of a 16-pixel tile is 6 MFMAs of
+// 16 cycles instead of 8 of 32.  The split of x happens once per input pixel, on its way from the staging registers into LDS: a pixel is three 64-byte runs
+// [hi | mid | lo] of 32 bf16 (+ 16 bytes: pitch 208 B = 52 words, the 16 pixels of a tile land on 16 distinct 4-bank groups), and a lane's B operand of
+// (tap, term) is one ds_read_b128.  The filter's three terms stay in registers (108 VGPRs).
+typedef __bf16 c16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 c16_bf16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void conv3x3_c16_split6_kernel(const C16Params p) {
+    constexpr int CI = 32, Q = CI / 4, PB = 208;                     // float4 pieces per pixel, LDS pixel pitch in BYTES
+    constexpr int XR = (C16_NPX * Q + 255) / 256;                    // staging items per thread (11)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];     // [340][208 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+
+    // the filter: A operand of tap g, term: row l16 = cout, k-slot j <-> channel 8 kq + j
+    c16_bf16x8 a[9][3];
+#pragma unroll
+    for (int g = 0; g < 9; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = p.w[(g * CI + 8 * kq + j) * 16 + l16];
+            const __bf16 hi = (__bf16)v; const float r1 = v - (float)hi; const __bf16 mid = (__bf16)r1;
+            a[g][0][j] = hi; a[g][1][j] = mid; a[g][2][j] = (__bf16)(r1 - (float)mid);
+        }
+    const float4 bv = p.bias ? make_float4(p.bias[4 * kq], p.bias[4 * kq + 1], p.bias[4 * kq + 2], p.bias[4 * kq + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    int s_l[XR], s_ry[XR], s_rx[XR], s_q[XR];                        // s_l: LDS byte offset of the item's hi quad, or -1
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + 256 * it, pi = idx / Q;
+        s_q[it] = 4 * (idx - pi * Q);
+        s_ry[it] = pi / C16_RW; s_rx[it] = pi - s_ry[it] * C16_RW;
+        s_l[it] = idx < C16_NPX * Q ? pi * PB + 2 * s_q[it] : -1;
+    }
+    c16_u32x4 xr[XR];
+    auto load_tile = [&](int tile) {                  // tile >= ntiles: every offset out of range -> zeros, no branch around a load
+        const bool on = tile < p.ntiles;
+        int t = tile;
+        const int tx = t % p.tilesX; t /= p.tilesX;
+        const int ty = t % p.tilesY;
+        const int n = t / p.tilesY;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int h = ty * C16_TH - 1 + s_ry[it], w_ = tx * C16_TW - 1 + s_rx[it];
+            const bool ok = on && s_l[it] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldx + s_q[it]) : C16_OOB), 0, 0);
+        }
+    };
+    auto store_tile = [&]() {                         // four fp32 channels -> their three bf16 terms, 8 bytes into each of the pixel's runs
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            if (s_l[it] < 0) continue;
+            const float xv[4] = {__uint_as_float(xr[it].x), __uint_as_float(xr[it].y), __uint_as_float(xr[it].z), __uint_as_float(xr[it].w)};
+            c16_bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const __bf16 h_ = (__bf16)xv[c]; const float r1 = xv[c] - (float)h_; const __bf16 m_ = (__bf16)r1;
+                hi[c] = h_; mid[c] = m_; lo[c] = (__bf16)(r1 - (float)m_);
+            }
+            *reinterpret_cast<c16_bf16x4*>(smem_b + s_l[it]) = hi;
+            *reinterpret_cast<c16_bf16x4*>(smem_b + s_l[it] + 64) = mid;
+            *reinterpret_cast<c16_bf16x4*>(smem_b + s_l[it] + 128) = lo;
+        }
+    };
+
+    // MFMA role: tiles t = 0..3 of the wave = (row 2 wave + (t >> 1), columns 16 (t & 1) ..); B operand: pixel l16 of the tile, channels 8 kq .. + 7
+    int boff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) boff[t] = ((2 * wave + (t >> 1)) * C16_RW + 16 * (t & 1) + l16) * PB + 16 * kq;
+
+    int tile = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    load_tile(tile);
+    store_tile();
+    __syncthreads();
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        load_tile(tile + gridDim.x);
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int go = ((g / 3) * C16_RW + (g % 3)) * PB;
+            c16_bf16x8 xh[4], xm[4], xl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xh[t] = *reinterpret_cast<const c16_bf16x8*>(smem_b + boff[t] + go);
+                xm[t] = *reinterpret_cast<const c16_bf16x8*>(smem_b + boff[t] + go + 64);
+                xl[t] = *reinterpret_cast<const c16_bf16x8*>(smem_b + boff[t] + go + 128);
+            }
+            // smallest products first; the four tiles of a wave share every A register
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][1], xm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][0], xl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][2], xh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][0], xm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][1], xh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g][0], xh[t], acc[t], 0, 0, 0);
+        }
+        {
+            int t_ = tile;
+            const int tx = t_ % p.tilesX; t_ /= p.tilesX;
+            const int ty = t_ % p.tilesY;
+            const int n = t_ / p.tilesY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int oy = ty * C16_TH + 2 * wave + (t >> 1), ox = tx * C16_TW + 16 * (t & 1) + l16;
+                float4 o = make_float4(acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w);
+                if (p.lrelu) { o.x = o.x > 0.f ? o.x : 0.2f * o.x; o.y = o.y > 0.f ? o.y : 0.2f * o.y; o.z = o.z > 0.f ? o.z : 0.2f * o.z; o.w = o.w > 0.f ? o.w : 0.2f * o.w; }
+                if (oy < p.H && ox < p.W) *reinterpret_cast<float4*>(p.y + ((long long)(n * p.H + oy) * p.W + ox) * p.ldy + 4 * kq) = o;
+            }
+        }
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+}
+
 // returns MRDIS_EUNSUPPORTED outside what the kernel covers (the caller then runs the generic narrow-output kernel)
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
                   int lrelu, hipStream_t s) {
@@ -147,6 +271,14 @@ int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias
     p.ntiles = (int)nt; p.x_bytes = (unsigned)xb;
     const int grid = p.ntiles < 512 ? p.ntiles : 512;
     const size_t lds = sizeof(float) * (size_t)C16_NPX * (Ci + 4);
+    if (Ci == 32 && (mrdis_opt(MRDIS_OPT_SPLIT6) == 1 || mrdis_opt(MRDIS_OPT_SPLIT6) == 5)) {      // (5: this kernel only)
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)conv3x3_c16_split6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) return MRDIS_ELAUNCH;
+            attr_set = true;
+        }
+        MRDIS_LAUNCH(conv3x3_c16_split6_kernel, dim3(grid), dim3(256), (size_t)C16_NPX * 208, s, p);
+    } else
     if (Ci == 32) MRDIS_LAUNCH((conv3x3_c16_kernel<2>), dim3(grid), dim3(256), lds, s, p);
     else MRDIS_LAUNCH((conv3x3_c16_kernel<1>), dim3(grid), dim3(256), lds, s, p);
     MRDIS_CHECK_LAUNCH();

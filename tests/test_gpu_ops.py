@@ -571,6 +571,18 @@ def test_conv3x3_16_couts_register_filter(mrdis, case):
     finally:
         hip.set_option('debug_now16', 0)
     close(ref, got.cpu(), rtol=2e-5, what='tile kernel vs c16')
+    # the six-product form (option split6, Ci = 32: conv3x3_c16_split6_kernel) against the fp32 MFMA form (split6 = 0) and a float64 reference
+    with hip.option('split6', 0):
+        got32 = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+    with hip.option('split6', 5):
+        got6 = hip.conv2d_fwd(xv, w_tck, bd, 3, 3, 1, 1)
+    want64 = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    sc = float(want64.abs().max())
+    e32, e6 = float((got32.cpu().double() - want64).abs().max()) / sc, float((got6.cpu().double() - want64).abs().max()) / sc
+    assert e6 <= 2.0 * e32 + 1e-7, ('split6 c16 forward', e6, e32)
+    close(got6, got32, rtol=2e-6, what='split6 vs fp32 MFMA (c16)')
+    if Ci == 32:
+        assert not torch.equal(got6, got32), 'the six-product kernel did not run'
 
 
 @pytest.mark.parametrize('case', [(2, 64, 256, 256), (3, 32, 70, 256), (5, 64, 128, 128), (9, 32, 100, 128), (17, 64, 64, 64), (20, 32, 61, 64)], ids=str)
