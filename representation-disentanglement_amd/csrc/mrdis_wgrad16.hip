@@ -144,6 +144,186 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const Wgrad16Params p) 
     }
 }
 
+// ---- six-product form (option split6; Ci = 32, Co = 16: sp6.out): the same weight gradient on the bf16 matrix pipe at fp32 accuracy.  wgrad16_kernel is
+// bound by its fp32 MFMAs (19.3 GFLOP at 88 TF/s; the layer moves 402 MB: 75 us at the narrow layers' streaming rate).  Here the reduction axis -- 32
+// consecutive positions of a box row -- is the K of v_mfma_f32_16x16x32_bf16, both operands are three bf16 terms (v = hi + mid + lo, split once per element
+// on its way into LDS) and the six products of order <= 2 are summed in fp32.  The tap shift is put on the NARROW operand:
+//     dW[t][ci][co] = sum_q x[q][ci] dy[q - off(t)][co],
+// so the x operand of a row (2 ci tiles x 3 terms, transposing reads ds_read_b64_tr_b16 from [pixel][32 ch] planes) is read ONCE for the nine taps, and only
+// the 32-byte dy rows (halo'd 10 x 34 box, [pixel][16 co] planes) are re-read per tap: 66 LDS reads per 108 MFMAs of a row.  A wave keeps all 9 x 2
+// accumulators (72 VGPRs); the four waves of a workgroup take rows r, r + 4 of an 8 x 32 box; boxes are walked with a grid stride with the next box in flight
+// in registers.  Slab layout, in-block wave reduction and the slab reduction launch are wgrad16_kernel's (a workgroup writes both 16-channel slices).
+typedef __bf16 w16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 w16_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short w16_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned w16_u32x4 __attribute__((ext_vector_type(4)));
+struct Wgrad16SParams {
+    const float* x; const float* dy; float* slab; float* bias_slab;
+    int N, H, W, ldx, lddy;
+    int tilesA, tilesB, numTiles, splits;
+    unsigned x_bytes, dy_bytes;
+};
+#define W6_TH 8
+#define W6_TW 32
+#define W6_YW (W6_TW + 2)
+#define W6_YPX ((W6_TH + 2) * W6_YW)
+__global__ __launch_bounds__(256, 2) void wgrad16_split6_kernel(const Wgrad16SParams p) {
+    constexpr int XPX = W6_TH * W6_TW;                 // 256 x pixels (64-byte rows per term), 340 dy pixels (32-byte rows per term)
+    constexpr int XPLANE = XPX * 64, YPLANE = W6_YPX * 32;
+    constexpr int XR = 8, YR = 6;                      // 16-byte fp32 pieces per thread: 256 x 8 / 256, ceil(340 x 4 / 256)
+    constexpr unsigned OOB = 0xfffffff0u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+    unsigned char* xs = smem6;                         // [3 terms][256 px][32 ch] bf16
+    unsigned char* ys = smem6 + 3 * XPLANE;            // [3 terms][340 px][16 co] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+
+    // transposing reads: lane (q4, p4) of a 16-lane group supplies the address of pixel-row q4, columns 4 p4 .. + 3 of the group's 4 x 16 block and
+    // receives column l16 (a channel / a cout) of the four pixel rows; group kq covers positions 8 kq .. 8 kq + 7 of the k-step in two reads
+    const int q4 = l16 >> 2, p4 = l16 & 3;
+    const int xoff = (8 * kq + q4) * 64 + 8 * p4;      // + (row * 32) * 64 + 32 mt (channels 16 mt ..) + 4 * 64 (second read) + term * XPLANE
+    const int yoff = (8 * kq + q4) * 32 + 8 * p4;      // + ((row - ty + 2) * 34 + 2 - tx) * 32 + 4 * 32 + term * YPLANE
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float bs4[4] = {0.f, 0.f, 0.f, 0.f};              // this thread's share of the bias gradient: couts 4 (tid & 3) .. + 3
+
+    w16_u32x4 xr[XR], yr[YR];
+    auto load_box = [&](int box) {                    // box >= numTiles: every offset out of range -> zeros
+        const bool on = box < p.numTiles;
+        int tt = box;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int n = tt / p.tilesA;
+        const int a0 = ta * W6_TH, b0 = tb * W6_TW;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 3, q = idx & 7;
+            const int h = a0 + (px >> 5), w_ = b0 + (px & 31);
+            const bool ok = on && h < p.H && w_ < p.W;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldx + 4 * q) : OOB), 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 2, q = idx & 3;
+            const int ly = px / W6_YW, lx = px - ly * W6_YW;
+            const int h = a0 - 1 + ly, w_ = b0 - 1 + lx;
+            const bool ok = on && px < W6_YPX && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            yr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)(ok ? 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.lddy + 4 * q) : OOB), 0, 0);
+        }
+    };
+    auto split4 = [](const w16_u32x4& v, w16_bf16x4& hi, w16_bf16x4& mid, w16_bf16x4& lo) {
+        const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const __bf16 h_ = (__bf16)f[c]; const float r1 = f[c] - (float)h_; const __bf16 m_ = (__bf16)r1;
+            hi[c] = h_; mid[c] = m_; lo[c] = (__bf16)(r1 - (float)m_);
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 3, q = idx & 7;
+            w16_bf16x4 hi, mid, lo; split4(xr[it], hi, mid, lo);
+            unsigned char* d = xs + px * 64 + 8 * q;
+            *reinterpret_cast<w16_bf16x4*>(d) = hi; *reinterpret_cast<w16_bf16x4*>(d + XPLANE) = mid; *reinterpret_cast<w16_bf16x4*>(d + 2 * XPLANE) = lo;
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 2, q = idx & 3;
+            if (px >= W6_YPX) continue;
+            const int ly = px / W6_YW, lx = px - ly * W6_YW;
+            if (ly >= 1 && ly <= W6_TH && lx >= 1 && lx <= W6_TW) {      // the box's own positions: the bias gradient (fp32, before the split)
+                bs4[0] += __uint_as_float(yr[it].x); bs4[1] += __uint_as_float(yr[it].y); bs4[2] += __uint_as_float(yr[it].z); bs4[3] += __uint_as_float(yr[it].w);
+            }
+            w16_bf16x4 hi, mid, lo; split4(yr[it], hi, mid, lo);
+            unsigned char* d = ys + px * 32 + 8 * q;
+            *reinterpret_cast<w16_bf16x4*>(d) = hi; *reinterpret_cast<w16_bf16x4*>(d + YPLANE) = mid; *reinterpret_cast<w16_bf16x4*>(d + 2 * YPLANE) = lo;
+        }
+    };
+    int box = split;
+    load_box(box);
+    store_box();
+    __syncthreads();
+    for (; box < p.numTiles; box += p.splits) {
+        load_box(box + p.splits);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wave + 4 * rr;
+            // x operand of the row: [ci tile mt][term], read once for the nine taps
+            w16_bf16x8 ax[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const unsigned char* a = xs + term * XPLANE + row * (32 * 64) + xoff + 32 * mt;
+                    union { w16_bf16x8 v; w16_s16x4 h[2]; } u;
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(a));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(a + 4 * 64));
+                    ax[mt][term] = u.v;
+                }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t % 3;
+                w16_bf16x8 by[3];
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const unsigned char* b = ys + term * YPLANE + ((row - ty + 2) * W6_YW + 2 - tx) * 32 + yoff;
+                    union { w16_bf16x8 v; w16_s16x4 h[2]; } u;
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(b));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(b + 4 * 32));
+                    by[term] = u.v;
+                }
+                // six products of order <= 2 (terms 0 = hi, 1 = mid, 2 = lo), smallest first
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][1], by[1], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][2], by[0], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][0], by[2], acc[t][mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][1], by[0], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][0], by[1], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][0], by[0], acc[t][mt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        store_box();
+        __syncthreads();
+    }
+    // cross-wave reduction through LDS (fixed order), then slab[split][ci tile][tap][16 ci][16 co] -- as wgrad16_kernel
+    float* red = reinterpret_cast<float*>(smem6);      // [4 waves][9][256]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float* out = p.slab + (((long long)split * 2 + mt) * 9) * 256;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 9 + t) * 256 + (4 * kq + r) * 16 + l16] = acc[t][mt][r];
+        __syncthreads();
+        for (int i = tid; i < 9 * 256; i += 256)
+            out[i] = (red[i] + red[9 * 256 + i]) + (red[2 * 9 * 256 + i] + red[3 * 9 * 256 + i]);
+    }
+    if (p.bias_slab != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[c * 256 + tid] = bs4[c];      // thread tid holds couts 4 (tid & 3) + c
+        __syncthreads();
+        if (tid < 16) {
+            const int qd = tid >> 2, c = tid & 3;
+            float t_ = 0.f;
+            for (int k = qd; k < 256; k += 4) t_ += red[c * 256 + k];
+            p.bias_slab[(long long)split * 16 + tid] = t_;
+        }
+    }
+}
+
 __global__ void wgrad16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int nCi, int nslab,
                                       const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
     __shared__ float red[16][65];
@@ -206,6 +386,31 @@ int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float*
     p.x = x; p.dy = dy; p.ldx = ldx; p.lddy = lddy;
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + (size_t)p.splits * p.nCi * 9 * 256 : nullptr;
+    if (Ci == 32 && Co == 16 && (mrdis_opt(MRDIS_OPT_SPLIT6) == 1 || mrdis_opt(MRDIS_OPT_SPLIT6) == 6)) {      // six bf16 products per fp32 product (6: this kernel only)
+        const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + Ci), yb = 4LL * (((long long)N * H * W - 1) * lddy + Co);
+        if (xb < 0x7fffffffLL && yb < 0x7fffffffLL) {
+            Wgrad16SParams q{};
+            q.x = x; q.dy = dy; q.slab = p.slab; q.bias_slab = p.bias_slab; q.N = N; q.H = H; q.W = W; q.ldx = ldx; q.lddy = lddy;
+            q.tilesA = mrdis_cdiv(H, W6_TH); q.tilesB = mrdis_cdiv(W, W6_TW);
+            const long long nt6 = (long long)N * q.tilesA * q.tilesB;
+            q.numTiles = (int)nt6; q.splits = p.splits < q.numTiles ? p.splits : q.numTiles;      // (the slabs of plan_wgrad16: [splits][2][9][256] + [splits][16])
+            q.x_bytes = (unsigned)xb; q.dy_bytes = (unsigned)yb;
+            const size_t lds6 = 3 * (size_t)(W6_TH * W6_TW * 64) + 3 * (size_t)(W6_YPX * 32);
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)wgrad16_split6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return MRDIS_ELAUNCH;
+                attr_set = true;
+            }
+            MRDIS_LAUNCH(wgrad16_split6_kernel, dim3(q.splits), dim3(256), lds6, s, q);
+            MRDIS_CHECK_LAUNCH();
+            const long long nout6 = 9LL * Ci * Co + (dbias ? Co : 0);
+            int SL6 = 1;
+            while (SL6 < 16 && SL6 * 8 <= q.splits) SL6 <<= 1;
+            MRDIS_LAUNCH(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout6, 64)), dim3(64, SL6), 0, s, p.slab, dw_tck, Ci, Co, 2, q.splits, p.bias_slab, dbias, accumulate_bias);
+            MRDIS_CHECK_LAUNCH();
+            return MRDIS_OK;
+        }
+    }
     const size_t lds = sizeof(float) * (size_t)(4 * 9 * 256);           // reduction buffer (36 KB) >= dys + x box (19.5 KB)
     // (two slices per workgroup -- dy staged once, wgrad16_kernel<2> -- measured slower: 338 vs 289 us on 32 -> 16 at 256x256, B = 32;
     //  the kernel lives on workgroup-level overlap of its staging and MFMA phases, and half as many workgroups overlap less)

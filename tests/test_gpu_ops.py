@@ -380,6 +380,20 @@ def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
     dw, db = mrdis.hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
     close(dw, to_tck(w.grad), rtol=2e-4, what='wgrad16')
     close(db, b.grad, rtol=2e-4, what='dbias')
+    if Ci == 32 and Co == 16:
+        # the six-product form (option split6: wgrad16_split6_kernel, taken by default) against the fp32 MFMA form and a float64 reference
+        hip = mrdis.hip
+        with hip.option('split6', 0):
+            dw32, db32 = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+        with hip.option('split6', 6):
+            dw6, db6 = hip.conv2d_bwd_weight(cl(x), cl(gy), 3, 3, 1, 1, need_bias=True)
+        w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), w64, None, 1, 1).backward(gy.double())
+        ref = to_tck(w64.grad); sc = float(ref.abs().max())
+        e32, e6 = float((dw32.cpu().double() - ref).abs().max()) / sc, float((dw6.cpu().double() - ref).abs().max()) / sc
+        assert e6 <= 2.0 * e32 + 1e-7, ('split6 wgrad16', e6, e32)
+        close(dw6, dw32, rtol=2e-6, what='split6 vs fp32 MFMA (wgrad16)'); close(db6, db32, rtol=2e-6, what='split6 bias gradient')
+        assert not torch.equal(dw6, dw32), 'the six-product kernel did not run'
 
 
 @pytest.mark.parametrize('wino', ['1', '2'])
