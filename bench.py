@@ -558,7 +558,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms_off = float(t)
         split6 = {'ms_per_step_fp32_mfma_only': round(ms_off, 2),
-                  'what': 'option split6 = 1 (default): the 3x3 stride-1 layers with a four-channel side (4 -> C forward / C <- 4 data gradient up to 32 couts, C -> 4 forward / 4 <- C data gradient) multiply on '
+                  'what': 'option split6 = 1 (default): the thin 3x3 stride-1 layers -- a four-channel side (4 -> C forward / C <- 4 data gradient up to 32 couts, C -> 4 forward / 4 <- C data gradient) and sp6.out (32 -> 16 forward, weight gradient) -- multiply on '
                           'v_mfma_f32_32x32x16_bf16 / 16x16x32 with both fp32 operands as three bf16 terms and the six products of order <= 2 summed in fp32 '
                           '(dropped: < 2^-23 of a product); = 0: fp32 MFMA.  Unit tests hold the split within 2e-6 of the fp32 kernels and at <= 2x their error against float64',
                   'steps_timed': nd}
