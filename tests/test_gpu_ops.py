@@ -369,7 +369,7 @@ def test_winograd_pipelined_wgrad(mrdis, case):
     close(sink - 1, b.grad, rtol=2e-4, what='dbias accumulated into a sink')
 
 
-@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 32, 16, 240, 232), (1, 16, 8, 321, 333), (3, 48, 12, 200, 180)])
+@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 32, 16, 240, 232), (1, 16, 8, 321, 333), (3, 48, 12, 200, 180), (2, 32, 16, 243, 251), (5, 32, 16, 129, 160)])
 def test_wgrad_narrow_cout(mrdis, N, Ci, Co, H, W):
     """mrdis_wgrad16.hip: weight / bias gradient of 3x3 s1 layers with 8..16 couts on large maps (sp6.out), 16-channel input
     slices, ragged boxes at the right / bottom edges, a cout count that is not 16."""
