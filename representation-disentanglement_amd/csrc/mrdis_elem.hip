@@ -572,7 +572,10 @@ __global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__
                                                             const float* __restrict__ s1, T* __restrict__ dxl, int lddx, T* __restrict__ dgm, int lddg,
                                                             T* __restrict__ dbt, int lddb, int Hi, int Wi, int C, int tiles_x,
                                                             const T* __restrict__ xlo, int ldxlo, float* __restrict__ part = nullptr,
-                                                            float* __restrict__ abuf = nullptr) {      // abuf (ONEPASS, bf16 maps): A leaves in fp32, dense (N, Hi, Wi, C)
+                                                            float* __restrict__ abuf = nullptr, int abl = 0) {      // abuf (ONEPASS, bf16 maps): A leaves in fp32, dense (N, Hi, Wi, C); abl: timing-only ablations (-DSPADE_UP2_ABL builds)
+#ifndef SPADE_UP2_ABL
+    abl = 0;
+#endif
     // xlo: z is not stored -- it is the x2 resize of xlo (N, Hi, Wi, C); the workgroup's 10 x 10 low-resolution neighbourhood goes through LDS and every
     // full-resolution z is interpolated from it exactly as bilinear_up2_fwd_kernel formed (and stored) it
     __shared__ __attribute__((aligned(16))) float tile[UB_R * UB_R * UB_CC];         // dz of the 18 x 18 pixels x 32 channels: 41.5 KB
@@ -585,22 +588,36 @@ __global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__
     const long long img = (long long)n * Ho * Wo;
     const int tid = threadIdx.x;
     // ---- phase 1: dz (and d gamma, d beta) of the full-resolution pixels (2 i0 - 1 + ry, 2 j0 - 1 + rx), ry, rx < 18
-    const int q1 = tid % Q, p1 = tid / Q, pstep = NT / Q;                             // host: NT % Q == 0
+    // (index arithmetic: a timing-only build without any memory traffic still took 40 % of the kernel's time, and a third of its VALU stream was address
+    //  arithmetic -- 85 v_mul_lo_u32 and 35 v_mad_u64_u32 at a quarter of the rate.  Q is a power of two (host), the pixel walk is incremental, and a pixel's
+    //  offset inside its image is a 24-bit multiply on top of per-image base pointers)
+    const int lq = 31 - __clz(Q);                                                     // host: Q in {1, 2, 4, 8}
+    const int q1 = tid & (Q - 1), p1 = tid >> lq, pstep = NT >> lq;
+    const int dry = pstep / UB_R, drx = pstep - dry * UB_R;                           // (wave-uniform)
     constexpr int MAXIT = UB_IT<NT>::value;
     const int c = c0 + 4 * q1;
+    const T* const dout_n = dout + img * lddo + c;
+    const T* const g_n = g + img * ldg + c;
+    const T* const z_n = XLO ? nullptr : z + img * ldz + c;
+    T* const dgm_n = dgm + img * lddg + c;
+    T* const dbt_n = dbt ? dbt + img * lddb + c : nullptr;
     // all streaming loads of this thread first (a pixel outside the image / past the tile: the image's pixel 0, flagged off)
     Vec<4> dv[MAXIT], gv[MAXIT], zv[XLO ? 1 : MAXIT];
-    long long pixv[MAXIT];
+    int pixv[MAXIT];                                                                  // pixel index inside the image, or -1
+    {
+        int ry = p1 / UB_R, rx = p1 - (p1 / UB_R) * UB_R, px = p1;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int px = p1 + it * pstep;
-        const int ry = px / UB_R, rx = px - ry * UB_R;
-        const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
-        const bool ok = px < UB_R * UB_R && (unsigned)h < (unsigned)Ho && (unsigned)w_ < (unsigned)Wo;
-        pixv[it] = ok ? img + (long long)h * Wo + w_ : -1;
-        const long long pix = ok ? pixv[it] : img;
-        dv[it].load(dout + pix * lddo + c); gv[it].load(g + pix * ldg + c);
-        if (!XLO) zv[it].load(z + pix * ldz + c);
+        for (int it = 0; it < MAXIT; ++it) {
+            const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
+            const bool ok = px < UB_R * UB_R && (unsigned)h < (unsigned)Ho && (unsigned)w_ < (unsigned)Wo;
+            pixv[it] = ok ? (int)__umul24((unsigned)h, (unsigned)Wo) + w_ : -1;
+            const unsigned pl = ok ? (unsigned)pixv[it] : 0u;
+            if (!(abl & 1)) { dv[it].load(dout_n + __umul24(pl, (unsigned)lddo)); gv[it].load(g_n + __umul24(pl, (unsigned)ldg)); }
+            else { for (int k = 0; k < 4; ++k) { dv[it].v[k] = 1.f + k; gv[it].v[k] = 0.5f; } }
+            if (!XLO) zv[it].load(z_n + __umul24(pl, (unsigned)ldz));
+            px += pstep; rx += drx; ry += dry;
+            if (rx >= UB_R) { rx -= UB_R; ry += 1; }
+        }
     }
     float mu[4], rs[4], a0[4], a1[4];
 #pragma unroll
@@ -618,16 +635,19 @@ __global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__
         }
         __syncthreads();
     }
+    int ry_ = p1 / UB_R, rx_ = p1 - (p1 / UB_R) * UB_R, px_ = p1;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int px = p1 + it * pstep;
+        const int px = px_, ry = ry_, rx = rx_;
+        px_ += pstep; rx_ += drx; ry_ += dry;
+        if (rx_ >= UB_R) { rx_ -= UB_R; ry_ += 1; }
         if (pixv[it] < 0) continue;
-        const int ry = px / UB_R, rx = px - ry * UB_R;
         const int h = 2 * i0 - 1 + ry, w_ = 2 * j0 - 1 + rx;
-        const long long pix = pixv[it];
+        const unsigned pix = (unsigned)pixv[it];
         const Vec<4>& d = dv[it]; const Vec<4>& gg = gv[it];
         Vec<4> zz, og;
-        if (XLO) {
+        if (XLO && (abl & 2)) { for (int k = 0; k < 4; ++k) zz.v[k] = 0.25f * k; }
+        else if (XLO) {
             // (h, w) -> low-resolution rows / columns and weights as up2_value; tile coordinates = low-resolution index - (i0 - 1), clamped rows are copies
             const int i = h >> 1, j = w_ >> 1;
             int r0, r1, q0_, q1_; float A0, A1, B0, B1;
@@ -655,8 +675,10 @@ __global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__
         }
         *reinterpret_cast<float4*>(tile + (px * (UB_CC / 4) + q1) * 4) = dz;
         if (ry >= 1 && ry <= 2 * UB_T && rx >= 1 && rx <= 2 * UB_T) {                 // this workgroup's own 16 x 16 pixels
-            og.store(dgm + pix * lddg + c);
-            if (dbt) d.store(dbt + pix * lddb + c);                                   // d beta = dout
+            if (!(abl & 4)) {
+            og.store(dgm_n + __umul24(pix, (unsigned)lddg));
+            if (dbt) d.store(dbt_n + __umul24(pix, (unsigned)lddb));                  // d beta = dout
+            }
             if (ONEPASS) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { ps0[k] += dzp[k]; ps1[k] += dzp[k] * ((zz.v[k] - mu[k]) * rs[k]); }
@@ -679,8 +701,9 @@ __global__ __launch_bounds__(NT) void spade_bwd_up2_kernel(const T* __restrict__
     }
     __syncthreads();
     // ---- phase 2: the resize's adjoint from LDS
+    if (abl & 8) return;
     for (int it = tid; it < UB_T * UB_T * Q; it += NT) {
-        const int q = it % Q, lp = it / Q, li = lp / UB_T, lj = lp - li * UB_T;
+        const int q = it & (Q - 1), lp = it >> lq, li = lp / UB_T, lj = lp - li * UB_T;
         const int i = i0 + li, j = j0 + lj;
         if (i >= Hi || j >= Wi) continue;
         int rr[4] = {2 * li, 2 * li + 1, 2 * li + 2, 2 * li + 3};                     // tile rows of full-resolution rows 2i-1 .. 2i+2
@@ -777,6 +800,14 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
     // channel chunks of 32: the last one may be narrower; the threads split as (pixel, quad) need NT % quads == 0: quads in {1, 2, 4, 8}
     const int lastq = ((C - 1) % UB_CC + 1) / 4;
     if (!v || N > 65535 || C > 65535 * UB_CC || (lastq & (lastq - 1)) != 0) return MRDIS_EUNSUPPORTED;
+    {   // the kernel forms a pixel's element offset inside its image with 24-bit multiplies
+        const long long px_img = 4LL * Hi * Wi;
+        long long ldmax = lddo > ldg ? lddo : ldg;
+        if (lddg > ldmax) ldmax = lddg;
+        if (dbeta && lddb > ldmax) ldmax = lddb;
+        if (!xlo && ldz > ldmax) ldmax = ldz;
+        if (px_img >= (1 << 24) || ldmax >= (1 << 24) || px_img * ldmax >= 0xffffffffLL) return MRDIS_EUNSUPPORTED;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = mrdis_cdiv(Wi, UB_T), tiles_y = mrdis_cdiv(Hi, UB_T);
     {
@@ -793,7 +824,8 @@ static int instnorm_spade_bwd_up2_impl(const T* dout, int lddo, const T* z, int 
             float* abuf = f32 ? nullptr : t1 + (size_t)N * C;
             if (NW == 8)       // (reading a stored z instead of interpolating it from xlo was measured level to slower: the kernel is not bound by the interpolation)
                 MRDIS_LAUNCH((spade_bwd_up2_kernel<T, true, 512, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(512), 0, s, dout, lddo, z, ldz, gamma, ldg,
-                                   save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
+                                   save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf,
+                                   (mrdis_opt(MRDIS_OPT_MODE) >= 2100 && mrdis_opt(MRDIS_OPT_MODE) < 2200) ? (int)mrdis_opt(MRDIS_OPT_MODE) - 2100 : 0);
             else
                 MRDIS_LAUNCH((spade_bwd_up2_kernel<T, true, 256, true>), dim3(tiles_x * tiles_y, N, mrdis_cdiv(C, UB_CC)), dim3(256), 0, s, dout, lddo, z, ldz, gamma, ldg,
                                    save_mean, save_rstd, nullptr, nullptr, dx, lddx, dgamma, lddg, dbeta, lddb, Hi, Wi, C, tiles_x, xlo, ldxlo, part1, abuf);
