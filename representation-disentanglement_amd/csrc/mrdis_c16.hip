@@ -255,6 +255,147 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_split6_kernel(const C16Par
     }
 }
 
+// ---- the other direction of the same layer (option split6): 16 -> 32 channels, i.e. the DATA GRADIENT of sp6.out (dy 16 channels, dx 32; the filter is the
+// layer's [tap][16][32] = w_tkc, taps reversed).  K = 16 channels is exactly one v_mfma_f32_32x32x16_bf16 (A = filter: 32 couts x 16 channels; B = 32 pixels
+// of a row x 16 channels), six products per tap and 32-pixel tile.  Same structure as conv3x3_c16_split6_kernel: a pixel in LDS is [hi | mid | lo] runs of
+// 16 bf16 (pitch 112 B), the filter's three terms stay in registers (108 VGPRs), a wave owns two rows of the 8 x 32 tile.  D[cout][pixel]: lane = pixel,
+// registers = couts 8 g + 4 half .. + 3: four 16-byte stores per tile (32 bytes per 128-byte line and instruction).
+__global__ __launch_bounds__(256, 2) void conv3x3_c16t_split6_kernel(const C16Params p) {
+    constexpr int CI = 16, Q = CI / 4, PB = 112;                     // float4 pieces per pixel, LDS pixel pitch in bytes
+    constexpr int XR = (C16_NPX * Q + 255) / 256;                    // staging items per thread (6)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];     // [340][112 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = lane & 31, half = lane >> 5;
+
+    // the filter: A operand of tap g, term: row e = cout (of 32), k-slot j <-> channel 8 half + j.  p.lrelu carries the tap flip (1: data gradient)
+    c16_bf16x8 a[9][3];
+#pragma unroll
+    for (int g = 0; g < 9; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gf = p.lrelu ? 8 - g : g;
+            const float v = p.w[(gf * CI + 8 * half + j) * 32 + e];
+            const __bf16 hi = (__bf16)v; const float r1 = v - (float)hi; const __bf16 mid = (__bf16)r1;
+            a[g][0][j] = hi; a[g][1][j] = mid; a[g][2][j] = (__bf16)(r1 - (float)mid);
+        }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    int s_l[XR], s_ry[XR], s_rx[XR], s_q[XR];
+#pragma unroll
+    for (int it = 0; it < XR; ++it) {
+        const int idx = tid + 256 * it, pi = idx / Q;
+        s_q[it] = 4 * (idx - pi * Q);
+        s_ry[it] = pi / C16_RW; s_rx[it] = pi - s_ry[it] * C16_RW;
+        s_l[it] = idx < C16_NPX * Q ? pi * PB + 2 * s_q[it] : -1;
+    }
+    c16_u32x4 xr[XR];
+    auto load_tile = [&](int tile) {
+        const bool on = tile < p.ntiles;
+        int t = tile;
+        const int tx = t % p.tilesX; t /= p.tilesX;
+        const int ty = t % p.tilesY;
+        const int n = t / p.tilesY;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int h = ty * C16_TH - 1 + s_ry[it], w_ = tx * C16_TW - 1 + s_rx[it];
+            const bool ok = on && s_l[it] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? 4u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldx + s_q[it]) : C16_OOB), 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            if (s_l[it] < 0) continue;
+            const float xv[4] = {__uint_as_float(xr[it].x), __uint_as_float(xr[it].y), __uint_as_float(xr[it].z), __uint_as_float(xr[it].w)};
+            c16_bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const __bf16 h_ = (__bf16)xv[c]; const float r1 = xv[c] - (float)h_; const __bf16 m_ = (__bf16)r1;
+                hi[c] = h_; mid[c] = m_; lo[c] = (__bf16)(r1 - (float)m_);
+            }
+            *reinterpret_cast<c16_bf16x4*>(smem_t + s_l[it]) = hi;
+            *reinterpret_cast<c16_bf16x4*>(smem_t + s_l[it] + 32) = mid;
+            *reinterpret_cast<c16_bf16x4*>(smem_t + s_l[it] + 64) = lo;
+        }
+    };
+    // MFMA role: tiles t = 0, 1 of the wave = rows 2 wave + t, all 32 columns; B operand: pixel e of the row, channels 8 half .. + 7
+    int boff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) boff[t] = ((2 * wave + t) * C16_RW + e) * PB + 16 * half;
+
+    int tile = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    load_tile(tile);
+    store_tile();
+    __syncthreads();
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        load_tile(tile + gridDim.x);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int go = ((g / 3) * C16_RW + (g % 3)) * PB;
+            c16_bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xh[t] = *reinterpret_cast<const c16_bf16x8*>(smem_t + boff[t] + go);
+                xm[t] = *reinterpret_cast<const c16_bf16x8*>(smem_t + boff[t] + go + 32);
+                xl[t] = *reinterpret_cast<const c16_bf16x8*>(smem_t + boff[t] + go + 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][1], xm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0], xl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][2], xh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0], xm[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][1], xh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][0], xh[t], acc[t], 0, 0, 0);
+        }
+        {
+            int t_ = tile;
+            const int tx = t_ % p.tilesX; t_ /= p.tilesX;
+            const int ty = t_ % p.tilesY;
+            const int n = t_ / p.tilesY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oy = ty * C16_TH + 2 * wave + t, ox = tx * C16_TW + e;
+                if (oy < p.H && ox < p.W) {
+                    float* dst = p.y + ((long long)(n * p.H + oy) * p.W + ox) * p.ldy + 4 * half;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(dst + 8 * g4) = make_float4(acc[t][4 * g4], acc[t][4 * g4 + 1], acc[t][4 * g4 + 2], acc[t][4 * g4 + 3]);
+                }
+            }
+        }
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+}
+
+// the 16 -> 32 six-product kernel as a data gradient (dy (N, H, W, 16) -> dx (N, H, W, 32), w_tkc = [9][16][32], taps reversed) or a forward (flip = 0)
+int mrdis_run_c16t_split6(const float* x, int ldx, const float* w_t_ci_co, float* y, int ldy, int N, int H, int W, int flip, hipStream_t s) {
+    if (ldx % 4 != 0 || ldy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if ((long long)N * H * W < 65536 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;
+    if (!(mrdis_opt(MRDIS_OPT_SPLIT6) == 1 || mrdis_opt(MRDIS_OPT_SPLIT6) == 7)) return MRDIS_EUNSUPPORTED;      // (7: this kernel only)
+    const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + 16);
+    if (xb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    C16Params p{};
+    p.x = x; p.w = w_t_ci_co; p.bias = nullptr; p.y = y; p.N = N; p.H = H; p.W = W; p.Ci = 16; p.ldx = ldx; p.ldy = ldy; p.lrelu = flip;
+    p.tilesY = mrdis_cdiv(H, C16_TH); p.tilesX = mrdis_cdiv(W, C16_TW);
+    const long long nt = (long long)N * p.tilesY * p.tilesX;
+    if (nt > 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    p.ntiles = (int)nt; p.x_bytes = (unsigned)xb;
+    const int grid = p.ntiles < 512 ? p.ntiles : 512;
+    MRDIS_LAUNCH(conv3x3_c16t_split6_kernel, dim3(grid), dim3(256), (size_t)C16_NPX * 112, s, p);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
 // returns MRDIS_EUNSUPPORTED outside what the kernel covers (the caller then runs the generic narrow-output kernel)
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co,
                   int lrelu, hipStream_t s) {

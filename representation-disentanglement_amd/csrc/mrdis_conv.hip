@@ -1292,7 +1292,7 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     p.ntiles = (long long)N * p.tilesW * p.tilesH;
     const int co32 = mrdis_cdiv(Co, 32);
     // option split6: 1 (default): here for <= 32 couts (wider layers would run as two 32-cout slices: 107 -> 123 us on 4 <- 64 at 256x256), and the C -> 4 kernel |
-    // 2: here only, every width | 3: the C -> 4 kernel only | 4: both, every width | 5 / 6: only the 32 -> 16 forward (mrdis_c16.hip) / its weight gradient (mrdis_wgrad16.hip), both also under 1 | 0: fp32 MFMA everywhere
+    // 2: here only, every width | 3: the C -> 4 kernel only | 4: both, every width | 5 / 6 / 7: only the 32 -> 16 forward (mrdis_c16.hip) / its weight gradient (mrdis_wgrad16.hip) / its data gradient (16 -> 32, mrdis_c16.hip), all also under 1 | 0: fp32 MFMA everywhere
     const long long s6 = mrdis_opt(MRDIS_OPT_SPLIT6);
     const bool split6 = !obf16 && ((s6 == 1 && co32 == 1) || s6 == 2 || s6 == 4);        // six bf16 products per fp32 product; 32 couts per workgroup (14 x 4 filter registers per 32)
     const int NS = (co32 % 2 == 0 && co32 >= 2 && !split6) ? 2 : 1;
@@ -1446,6 +1446,7 @@ int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, flo
                   int x_bf16 = 0, int wld = 4);
 // mrdis_c16.hip: 3x3 s1 p1 with 16 output channels, filter in registers
 int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias, float* y, int ldy, int N, int H, int W, int Ci, int Co, int lrelu, hipStream_t s);
+int mrdis_run_c16t_split6(const float* x, int ldx, const float* w_t_ci_co, float* y, int ldy, int N, int H, int W, int flip, hipStream_t s);      // mrdis_c16.hip: 16 -> 32, six bf16 products
 int mrdis_run_pw_dgrad(const float* dy, int lddy, const float* w_tkc, void* dx, int lddx, long long npix, int Ci, int Co, int x16_bf16, hipStream_t s);
 
 extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, const void* w_bf16_tkc, const float* bias,
@@ -1561,6 +1562,10 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
         // exactly the [tap][4][Cout'] filter layout of the Cin = 4 kernel
         if (!st_bf16 && c4_eligible(dy, lddy, lddx, N, H, W, Co, Ci, kh, kw, stride, pad) && !mrdis_opt(MRDIS_OPT_NOC4))
             return run_c4conv(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Ci, 0, (hipStream_t)stream, 1);
+        if (!bf && !st_bf16 && kh == 3 && kw == 3 && pad == 1 && Co == 16 && Ci == 32) {      // sp6.out's data gradient on the six-product kernel (option split6; mrdis_c16.hip)
+            rc = mrdis_run_c16t_split6(dy, lddy, w_tkc, dx, lddx, N, H, W, 1, (hipStream_t)stream);
+            if (rc != MRDIS_EUNSUPPORTED) return rc;
+        }
         if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
             rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, w_wino, w_wino_fmt);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
