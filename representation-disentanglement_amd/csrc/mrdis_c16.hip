@@ -381,7 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16t_split6_kernel(const C16Pa
 int mrdis_run_c16t_split6(const float* x, int ldx, const float* w_t_ci_co, float* y, int ldy, int N, int H, int W, int flip, hipStream_t s) {
     if (ldx % 4 != 0 || ldy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0) return MRDIS_EUNSUPPORTED;
     if ((long long)N * H * W < 65536 || mrdis_opt(MRDIS_OPT_NOW16)) return MRDIS_EUNSUPPORTED;
-    if (!(mrdis_opt(MRDIS_OPT_SPLIT6) == 1 || mrdis_opt(MRDIS_OPT_SPLIT6) == 7)) return MRDIS_EUNSUPPORTED;      // (7: this kernel only)
+    // NOT part of the default policy (option split6 = 1): alone the kernel beats the layer's Winograd F(4x4) data gradient (149 vs 169 us), in the step it does
+    // not (same-box A/B 133.1-133.5 vs 132.7-133.2 ms: the F(4x4) kernel moves the same bytes with a quarter of the multiplies).  split6 = 7 selects it.
+    if (mrdis_opt(MRDIS_OPT_SPLIT6) != 7) return MRDIS_EUNSUPPORTED;
     const long long xb = 4LL * (((long long)N * H * W - 1) * ldx + 16);
     if (xb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
     C16Params p{};

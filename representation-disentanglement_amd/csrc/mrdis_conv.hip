@@ -1292,7 +1292,7 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     p.ntiles = (long long)N * p.tilesW * p.tilesH;
     const int co32 = mrdis_cdiv(Co, 32);
     // option split6: 1 (default): here for <= 32 couts (wider layers would run as two 32-cout slices: 107 -> 123 us on 4 <- 64 at 256x256), and the C -> 4 kernel |
-    // 2: here only, every width | 3: the C -> 4 kernel only | 4: both, every width | 5 / 6 / 7: only the 32 -> 16 forward (mrdis_c16.hip) / its weight gradient (mrdis_wgrad16.hip) / its data gradient (16 -> 32, mrdis_c16.hip), all also under 1 | 0: fp32 MFMA everywhere
+    // 2: here only, every width | 3: the C -> 4 kernel only | 4: both, every width | 5 / 6: only the 32 -> 16 forward (mrdis_c16.hip) / its weight gradient (mrdis_wgrad16.hip), both also under 1 | 7: only its data gradient (16 -> 32, mrdis_c16.hip; not under 1: no gain in the step) | 0: fp32 MFMA everywhere
     const long long s6 = mrdis_opt(MRDIS_OPT_SPLIT6);
     const bool split6 = !obf16 && ((s6 == 1 && co32 == 1) || s6 == 2 || s6 == 4);        // six bf16 products per fp32 product; 32 couts per workgroup (14 x 4 filter registers per 32)
     const int NS = (co32 % 2 == 0 && co32 >= 2 && !split6) ? 2 : 1;
