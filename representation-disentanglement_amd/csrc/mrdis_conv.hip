@@ -2596,6 +2596,8 @@ int mrdis_run_pw_wgrad(const void* x, int ldx, const float* dy, int lddy, float*
                        long long npix, int Ci, int Co, int accumulate_bias, int x16_bf16, hipStream_t s);
 int mrdis_run_wgrad_s2(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
                        int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int accumulate_bias, hipStream_t s);
+int mrdis_run_wgrad16_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);      // mrdis_wgrad16.hip: bf16 views, 32 -> 16
 int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float* dw_tck, float* dbias, void* workspace,
                       size_t workspace_bytes, int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s);
 size_t mrdis_wino_wgrad_workspace(int N, int H, int W, int Ci, int Co);
@@ -2687,6 +2689,10 @@ extern "C" int mrdis_conv2d_bwd_weight(const void* x_, int ldx, const void* dy_,
     if (dtype == MRDIS_DT_XF32_YBF16) {       // the 4 -> C si_layers under bf16 storage: x the fp32 anatomy map, dy bf16
         if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 4)) return MRDIS_EUNSUPPORTED;
         return mrdis_run_wgrad_c4(x, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, 1, (hipStream_t)stream, pad16);
+    }
+    if (dtype == MRDIS_DT_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Ci == 32 && Co == 16) {      // sp6.out on bf16 views (mrdis_wgrad16.hip)
+        rc = mrdis_run_wgrad16_bf16(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, accumulate_bias, (hipStream_t)stream);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
     if (dtype == MRDIS_DT_F32_BF16M || dtype == MRDIS_DT_BF16) {
         rc = mrdis_run_bwgrad(x_, ldx, dy_, lddy, dw_tck, dbias, workspace, workspace_bytes, N, H, W, Ci, Co, kh, kw, stride, pad,

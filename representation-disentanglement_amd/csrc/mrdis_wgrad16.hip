@@ -324,6 +324,134 @@ __global__ __launch_bounds__(256, 2) void wgrad16_split6_kernel(const Wgrad16SPa
     }
 }
 
+// ---- the same weight gradient on bf16 views (MRDIS_DT_BF16: x (N, H, W, 32) and dy (N, H, W, 16) stored in bf16): the structure of wgrad16_split6_kernel
+// with ONE term per operand -- the 16-byte pieces of both tensors go from global memory into the [pixel][C] LDS images as they are (no split, no conversion),
+// 18 bf16 MFMAs per 32-position row.  The generic bf16 kernel (bwgrad3_kernel<1, 1>) keeps a 32 x 32 accumulator block per tap for this 32 x 16 problem and
+// runs it in 81 us; the layer moves 201 MB.
+__global__ __launch_bounds__(256, 2) void wgrad16_bf16_kernel(const Wgrad16SParams p) {
+    constexpr int XPX = W6_TH * W6_TW;
+    constexpr int XR = 4, YR = 3;                      // 16-byte bf16 pieces per thread: 256 x 4 / 256, ceil(340 x 2 / 256)
+    constexpr unsigned OOB = 0xfffffff0u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    unsigned char* xs = smem7;                         // [256 px][32 ch] bf16
+    unsigned char* ys = smem7 + XPX * 64;              // [340 px][16 co] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const int q4 = l16 >> 2, p4 = l16 & 3;
+    const int xoff = (8 * kq + q4) * 64 + 8 * p4;
+    const int yoff = (8 * kq + q4) * 32 + 8 * p4;
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // this thread's share of the bias gradient: couts 8 (tid & 1) .. + 7
+
+    w16_u32x4 xr[XR], yr[YR];
+    auto load_box = [&](int box) {
+        const bool on = box < p.numTiles;
+        int tt = box;
+        const int tb = tt % p.tilesB; tt /= p.tilesB;
+        const int ta = tt % p.tilesA;
+        const int n = tt / p.tilesA;
+        const int a0 = ta * W6_TH, b0 = tb * W6_TW;
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 2, q = idx & 3;
+            const int h = a0 + (px >> 5), w_ = b0 + (px & 31);
+            const bool ok = on && h < p.H && w_ < p.W;
+            xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(ok ? 2u * (unsigned)(((n * p.H + h) * p.W + w_) * p.ldx + 8 * q) : OOB), 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 1, q = idx & 1;
+            const int ly = px / W6_YW, lx = px - ly * W6_YW;
+            const int h = a0 - 1 + ly, w_ = b0 - 1 + lx;
+            const bool ok = on && px < W6_YPX && (unsigned)h < (unsigned)p.H && (unsigned)w_ < (unsigned)p.W;
+            yr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)(ok ? 2u * (unsigned)(((n * p.H + h) * p.W + w_) * p.lddy + 8 * q) : OOB), 0, 0);
+        }
+    };
+    auto store_box = [&]() {
+#pragma unroll
+        for (int it = 0; it < XR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 2, q = idx & 3;
+            *reinterpret_cast<w16_u32x4*>(xs + px * 64 + 16 * q) = xr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < YR; ++it) {
+            const int idx = tid + 256 * it, px = idx >> 1, q = idx & 1;
+            if (px >= W6_YPX) continue;
+            const int ly = px / W6_YW, lx = px - ly * W6_YW;
+            if (ly >= 1 && ly <= W6_TH && lx >= 1 && lx <= W6_TW) {      // the box's own positions: the bias gradient (fp32 sum of the bf16 values)
+                const unsigned u[4] = {yr[it].x, yr[it].y, yr[it].z, yr[it].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bs8[2 * k] += __uint_as_float(u[k] << 16); bs8[2 * k + 1] += __uint_as_float(u[k] & 0xffff0000u); }
+            }
+            *reinterpret_cast<w16_u32x4*>(ys + px * 32 + 16 * q) = yr[it];
+        }
+    };
+
+    int box = split;
+    load_box(box);
+    store_box();
+    __syncthreads();
+    for (; box < p.numTiles; box += p.splits) {
+        load_box(box + p.splits);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wave + 4 * rr;
+            w16_bf16x8 ax[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned char* a = xs + row * (32 * 64) + xoff + 32 * mt;
+                union { w16_bf16x8 v; w16_s16x4 h[2]; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(a));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(a + 4 * 64));
+                ax[mt] = u.v;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t % 3;
+                const unsigned char* b = ys + ((row - ty + 2) * W6_YW + 2 - tx) * 32 + yoff;
+                union { w16_bf16x8 v; w16_s16x4 h[2]; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(b));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w16_s16x4 __attribute__((address_space(3)))*)(b + 4 * 32));
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[0], u.v, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[1], u.v, acc[t][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        store_box();
+        __syncthreads();
+    }
+    float* red = reinterpret_cast<float*>(smem7);      // [4 waves][9][256] (host: the LDS is at least that large)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float* out = p.slab + (((long long)split * 2 + mt) * 9) * 256;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 9 + t) * 256 + (4 * kq + r) * 16 + l16] = acc[t][mt][r];
+        __syncthreads();
+        for (int i = tid; i < 9 * 256; i += 256)
+            out[i] = (red[i] + red[9 * 256 + i]) + (red[2 * 9 * 256 + i] + red[3 * 9 * 256 + i]);
+    }
+    if (p.bias_slab != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[c * 256 + tid] = bs8[c];      // thread tid holds couts 8 (tid & 1) + c
+        __syncthreads();
+        if (tid < 16) {
+            const int hf = tid >> 3, c = tid & 7;
+            float t_ = 0.f;
+            for (int k = hf; k < 256; k += 2) t_ += red[c * 256 + k];
+            p.bias_slab[(long long)split * 16 + tid] = t_;
+        }
+    }
+}
+
 __global__ void wgrad16_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Ci, int Co, int nCi, int nslab,
                                       const float* __restrict__ bslab, float* __restrict__ dbias, int accumulate_bias) {
     __shared__ float red[16][65];
@@ -421,6 +549,36 @@ int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float*
     while (SL < 16 && SL * 8 <= p.splits) SL <<= 1;
     MRDIS_LAUNCH(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, p.slab, dw_tck, Ci, Co, p.nCi, p.splits,
                        p.bias_slab, dbias, accumulate_bias);
+    MRDIS_CHECK_LAUNCH();
+    return MRDIS_OK;
+}
+
+// bf16 views (MRDIS_DT_BF16), Ci = 32, Co = 16, 3x3 s1 p1, large maps: wgrad16_bf16_kernel; MRDIS_EUNSUPPORTED elsewhere (the caller runs the generic bf16 kernel)
+int mrdis_run_wgrad16_bf16(const void* x, int ldx, const void* dy, int lddy, float* dw_tck, float* dbias, void* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Ci, int Co, int accumulate_bias, hipStream_t s) {
+    Wgrad16Params p;
+    if (Ci != 32 || Co != 16 || !plan_wgrad16(p, N, H, W, Ci, Co) || mrdis_opt(MRDIS_OPT_MODE) == 3030) return MRDIS_EUNSUPPORTED;      // (debug_mode 3030: the generic kernel, for A/B)
+    if (ldx % 8 != 0 || lddy % 8 != 0 || ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return MRDIS_EUNSUPPORTED;
+    if (workspace_bytes + 256 < mrdis_wgrad16_workspace(N, H, W, Ci, Co)) return MRDIS_EUNSUPPORTED;
+    const long long xb = 2LL * (((long long)N * H * W - 1) * ldx + Ci), yb = 2LL * (((long long)N * H * W - 1) * lddy + Co);
+    if (xb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
+    Wgrad16SParams q{};
+    q.x = reinterpret_cast<const float*>(x); q.dy = reinterpret_cast<const float*>(dy);
+    q.slab = reinterpret_cast<float*>(workspace); q.bias_slab = dbias ? q.slab + (size_t)p.splits * p.nCi * 9 * 256 : nullptr;
+    q.N = N; q.H = H; q.W = W; q.ldx = ldx; q.lddy = lddy;
+    q.tilesA = mrdis_cdiv(H, W6_TH); q.tilesB = mrdis_cdiv(W, W6_TW);
+    const long long nt = (long long)N * q.tilesA * q.tilesB;
+    q.numTiles = (int)nt; q.splits = p.splits < q.numTiles ? p.splits : q.numTiles;
+    q.x_bytes = (unsigned)xb; q.dy_bytes = (unsigned)yb;
+    size_t lds = (size_t)(W6_TH * W6_TW * 64) + (size_t)(W6_YPX * 32);
+    const size_t red = sizeof(float) * (size_t)(4 * 9 * 256);
+    if (lds < red) lds = red;
+    MRDIS_LAUNCH(wgrad16_bf16_kernel, dim3(q.splits), dim3(256), lds, s, q);
+    MRDIS_CHECK_LAUNCH();
+    const long long nout = 9LL * Ci * Co + (dbias ? Co : 0);
+    int SL = 1;
+    while (SL < 16 && SL * 8 <= q.splits) SL <<= 1;
+    MRDIS_LAUNCH(wgrad16_reduce_kernel, dim3(mrdis_cdiv(nout, 64)), dim3(64, SL), 0, s, q.slab, dw_tck, Ci, Co, 2, q.splits, q.bias_slab, dbias, accumulate_bias);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -641,6 +641,29 @@ def test_conv3x3_4_couts_gemm_gather(mrdis, case):
     close(got6, got, rtol=2e-6, what='split6 vs fp32 MFMA, forward'); close(dx6, dx, rtol=2e-6, what='split6 vs fp32 MFMA, data gradient')
 
 
+@pytest.mark.parametrize('case', [(2, 240, 232), (1, 321, 333), (5, 129, 160), (3, 256, 256)], ids=str)
+def test_bf16_weight_gradient_32_to_16(mrdis, case):
+    """wgrad16_bf16_kernel (mrdis_wgrad16.hip): sp6.out's weight + bias gradient on bf16 views (MRDIS_DT_BF16) -- K = 32 positions per
+    v_mfma_f32_16x16x32_bf16, transposing LDS reads, the tap shift on the 16-cout operand.  Exact products of the bf16 operands, fp32 sums: against torch
+    fp32 on the same bf16-valued operands to fp32 rounding, and against the generic bf16 kernel (debug_mode 3030: bwgrad3 / bwgrad), which it replaces."""
+    N, H, W = case
+    hip = mrdis.hip
+    B16 = torch.bfloat16
+    x = rnd((N, 32, H, W), 131).bfloat16(); dy = rnd((N, 16, H, W), 132).bfloat16()
+    w0 = torch.zeros(16, 32, 3, 3, requires_grad=True); b0 = torch.zeros(16, requires_grad=True)
+    F.conv2d(x.float(), w0, b0, 1, 1).backward(dy.float())
+    xd, dyd = cl(x.float()).to(B16), cl(dy.float()).to(B16)
+    dw, db = hip.conv2d_bwd_weight(xd, dyd, 3, 3, 1, 1, need_bias=True)
+    close(dw, to_tck(w0.grad), rtol=2e-5, what='bf16 32 -> 16 wgrad vs torch'); close(db, b0.grad, rtol=2e-5, what='bf16 32 -> 16 dbias vs torch')
+    with hip.option('debug_mode', 3030):
+        dw_g, db_g = hip.conv2d_bwd_weight(xd, dyd, 3, 3, 1, 1, need_bias=True)
+    close(dw, dw_g, rtol=2e-6, what='vs the generic bf16 kernel'); close(db, db_g, rtol=2e-6, what='dbias vs the generic bf16 kernel')
+    assert not torch.equal(dw, dw_g), 'the dedicated kernel did not run'
+    sink = torch.full((16,), -1.0, device=dev())
+    dw2, none = hip.conv2d_bwd_weight(xd, dyd, 3, 3, 1, 1, need_bias=True, bias_sink=sink)
+    assert none is None and torch.equal(dw2, dw) and torch.equal(sink, db - 1.0)
+
+
 @pytest.mark.parametrize('case', [(2, 203, 171), (4, 128, 160), (1, 256, 256), (5, 129, 130)], ids=str)
 def test_data_gradient_16_to_32_six_products(mrdis, case):
     """conv3x3_c16t_split6_kernel (mrdis_c16.hip): the data gradient of sp6.out (dy 16 channels -> dx 32) on the bf16 matrix pipe -- three bf16 terms per fp32
