@@ -42,7 +42,8 @@ FLOP_PER_SLICE_160x192 = 2.784e11
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=1, help='ranks = GPUs of this node; must equal WORLD_SIZE when started by a launcher (mandatory there: the default 1 is refused '
+                                                        'under WORLD_SIZE > 1); N > 1 without a launcher starts the N ranks itself')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (slices)')
@@ -82,51 +83,74 @@ def _time_conv(hip, xs, w, b, ys, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def measure_traffic_inrun(timeout_s=240):
-    """HBM bytes per launch of the north-star kernel from the PMC counters, measured IN THIS RUN: two child processes (never an exec: this process has
-    initialised the GPU), `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/northstar_conv.py 12` and the same with WRITE_SIZE (separate passes, the
-    program itself after `--`), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950, both in KiB).  Returns (bytes, provenance), or
-    (None, reason) when rocprofv3 is missing / a pass fails (the caller then reports the stored number of profiles/northstar_conv_pmc.json and says so)."""
+def _run_group(cmd, cwd, env, timeout_s):
+    """run a child in its OWN process group and, on timeout, kill the whole group (rocprofv3 is a wrapper: killing only it would orphan the python
+    grandchild that holds the GPU) -- then wait, so nothing outlives this call.  Returns (returncode or None on timeout, combined output)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        return p.returncode, out
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = p.communicate()
+        return None, out
+
+
+def measure_traffic_inrun(timeout_s=240, script=('northstar_conv.py', '12'), kernel_substr='c4conv', n_last=12, what='tools/northstar_conv.py'):
+    """HBM bytes per launch of ONE kernel from the PMC counters, measured IN THIS RUN: two child processes (never an exec: this process has
+    initialised the GPU), `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/<script>` and the same with WRITE_SIZE (separate passes, the
+    program itself after `--`), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950, both in KiB).  Default: the north-star conv;
+    roofline_step uses it for the full-resolution F(4x4) kernels.  Returns (bytes, provenance, kernel name seen in the counter file), or
+    (None, reason, None) when rocprofv3 is missing / a pass fails (the caller then reports the stored number and says so)."""
     import csv
     import shutil
-    import subprocess
     import tempfile
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if exe is None:
-        return None, 'rocprofv3 not found'
+        return None, 'rocprofv3 not found', None
     if os.environ.get('MRDIS_BENCH_NO_PMC'):
-        return None, 'MRDIS_BENCH_NO_PMC set'
+        return None, 'MRDIS_BENCH_NO_PMC set', None
     env = dict(os.environ, TMPDIR='/tmp')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     got = {}
+    kname = None
     t0 = time.time()
     with tempfile.TemporaryDirectory(prefix='mrdis_pmc_', dir='/tmp') as d:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', counter.lower(), '--',
-                   sys.executable if os.path.basename(sys.executable).startswith('python') else 'python3', os.path.join(ROOT, 'tools', 'northstar_conv.py'), '12']
+                   sys.executable if os.path.basename(sys.executable).startswith('python') else 'python3', os.path.join(ROOT, 'tools', script[0])] + list(script[1:])
             try:
-                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+                rc, txt = _run_group(cmd, '/tmp', env, timeout_s)
             except Exception as ex:                                   # noqa: BLE001 -- a profiler that cannot run must not take the benchmark down
-                return None, f'{counter} pass: {type(ex).__name__}'
-            if r.returncode != 0:
-                return None, f'{counter} pass: rc {r.returncode}: ' + (r.stdout or '')[-160:].replace('\n', ' ')
+                return None, f'{counter} pass: {type(ex).__name__}', None
+            if rc is None:
+                return None, f'{counter} pass: timed out after {timeout_s} s (process group killed)', None
+            if rc != 0:
+                return None, f'{counter} pass: rc {rc}: ' + (txt or '')[-160:].replace('\n', ' '), None
             path = None
             for root_, _, files in os.walk(d):
                 for f in files:
                     if f.startswith(counter.lower()) and f.endswith('counter_collection.csv'):
                         path = os.path.join(root_, f)
             if path is None:
-                return None, f'{counter} pass: no counter_collection.csv'
-            vals = [float(row['Counter_Value']) for row in csv.DictReader(open(path)) if row['Counter_Name'] == counter and 'c4conv' in row['Kernel_Name']]
-            if len(vals) < 8:
-                return None, f'{counter} pass: {len(vals)} north-star launches in the counter file'
-            vals = vals[-12:]                                         # the timed launches (the check / warm-up launches come first)
+                return None, f'{counter} pass: no counter_collection.csv', None
+            rows = [row for row in csv.DictReader(open(path)) if row['Counter_Name'] == counter and kernel_substr in row['Kernel_Name']]
+            vals = [float(row['Counter_Value']) for row in rows]
+            if len(vals) < min(8, n_last):
+                return None, f'{counter} pass: {len(vals)} launches of {kernel_substr} in the counter file', None
+            kname = rows[-1]['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+            vals = vals[-n_last:]                                     # the timed launches (the check / warm-up launches come first)
             got[counter] = sum(vals) / len(vals)
     rd, wr = 2.0 * got['FETCH_SIZE'] * 1024.0, got['WRITE_SIZE'] * 1024.0
-    return rd + wr, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of tools/northstar_conv.py, '
-                     f'{time.time() - t0:.0f} s), mean over 12 launches; read = 2 x FETCH_SIZE x 1024 = {rd / 1e6:.1f} MB (gfx950 half-count correction), '
-                     f'write = WRITE_SIZE x 1024 = {wr / 1e6:.1f} MB')
+    return rd + wr, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of {what}, '
+                     f'{time.time() - t0:.0f} s), mean over {n_last} launches; read = 2 x FETCH_SIZE x 1024 = {rd / 1e6:.1f} MB (gfx950 half-count correction), '
+                     f'write = WRITE_SIZE x 1024 = {wr / 1e6:.1f} MB'), kname
 
 
 def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
@@ -149,10 +173,16 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     want = F.conv2d(x_cpu, w_cpu, b_cpu, 1, 1)
     err = float((ys[0].cpu() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-5, f'north-star conv output differs from torch fp32: rel {err:.2e}'
+    hip.launch_counts(reset=True)
     us_rot = _time_conv(hip, xs, w, b, ys, iters)
+    six = hip.launch_counts()['split6_c4'] > 0               # which form the library's policy launched (option split6)
     if not extras:          # tools/northstar_conv.py under rocprofv3 --pmc: only launches of the north-star shape
         return {'us_per_launch': round(us_rot, 2), 'achieved': round(NS_BYTES / (us_rot * 1e-6) / 1e9, 1)}
     us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
+    us_f32 = None
+    if six:                 # the exact-fp32 MFMA form of the same kernel (option split6 = 0), same buffers, same run
+        with hip.option('split6', 0):
+            us_f32 = _time_conv(hip, xs, w, b, ys, iters)
     # the ceiling of a store-only kernel on THIS device, over the same rotating output buffers (236 MB each): the layer's algorithmic traffic is 89 % stores
     for i in range(4):
         hip.stream_fill(ys[i % nrot])
@@ -173,7 +203,7 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     us6 = _time_conv(hip, xs6, w, b, ys6, iters)
     del xs6, ys6
     achieved = NS_BYTES / (us_rot * 1e-6) / 1e9
-    traffic, traffic_src = measure_traffic_inrun() if pmc_inrun else (None, None)
+    traffic, traffic_src, kname = measure_traffic_inrun() if pmc_inrun else (None, None, None)
     pmc = os.path.join(ROOT, 'profiles', 'northstar_conv_pmc.json')
     if traffic is None and os.path.exists(pmc):
         try:
@@ -184,7 +214,10 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
         except Exception:
             traffic = None
     gbs = lambda nbytes, us: round(nbytes / (us * 1e-6) / 1e9, 1)
-    return {'bound': 'hbm', 'kernel': 'c4conv_kernel<1> (3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC)',
+    kernel = ('c4conv_split6_kernel<false, true> (six bf16 products per fp32 product, fp32-equivalent: DESIGN 4.1)' if six else 'c4conv_kernel<1, false, true> (fp32 MFMA)')
+    return {'bound': 'hbm', 'kernel': kernel + ' -- 3x3 s1, 32x4x240x240 -> 32ch, fp32 NHWC', 'kernel_name_in_counter_file': kname,
+            'fp32_mfma_form': None if us_f32 is None else {'kernel': 'c4conv_kernel<1, false, true> (option split6 = 0: v_mfma_f32_32x32x2_f32, exact fp32)', 'us_per_launch': round(us_f32, 2),
+                                                           'achieved': gbs(NS_BYTES, us_f32), 'frac': round(gbs(NS_BYTES, us_f32) / HBM_PEAK_GBS, 4)},
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us_rot, 2),
             'timing': f'{iters} launches over {nrot} rotating x/y pairs (1.06 GB, beyond the 256 MiB Infinity Cache), HIP events',
@@ -199,17 +232,21 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
             'tflops': round(2 * 9 * NS['Ci'] * NS['Co'] * NS['N'] * NS['H'] * NS['W'] / (us_rot * 1e-6) / 1e12, 2)}
 
 
-def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
+def roofline_step(mrdis, dev, B, H, W, dtype, iters=6, only=None, pmc_inrun=False):
     """The three kernel families that dominate the step -- the fused gamma | beta convolutions of the full-, half- and
     quarter-resolution SPADE blocks (reference model.py:2443-2444; 16 calls each per step, forward + data gradient + weight
     gradient = ~40 % of the step) -- timed live with HIP events at the shapes of the timed step and priced against the MFMA peak
     of the arithmetic type.  fp32: Winograd F(2x2,3x3) executes 4/9 and F(4x4,3x3) 1/4 of the direct multiplies, so `frac` = direct-equivalent
     FLOPs x that factor / time / 157.3 TF (the kernels' own MFMA work against the matrix pipe); bf16: direct FLOPs / time / bf16 peak,
-    and the HBM fraction of the layer's algorithmic bytes beside it (these layers are HBM-bound in bf16)."""
+    and the HBM fraction of the layer's algorithmic bytes beside it (these layers are HBM-bound in bf16).
+    `only` = (layer, entry): just that entry point (tools/step_kernel.py under rocprofv3 --pmc); `pmc_inrun`: the full-resolution F(4x4) entries (sp6
+    fwd_spade, sp6 dgrad) also carry `traffic` = HBM bytes per launch from in-run PMC child passes, beside their algorithmic bytes."""
     hip = mrdis.hip
     bf = dtype != 'f32'
     out = []
     for name, ci, d in (('sp6.gamma+beta', 32, 1), ('sp5.gamma+beta', 64, 2), ('sp4.gamma+beta', 128, 4)):
+        if only is not None and only[0] != name:
+            continue
         co, h, w = 2 * ci, H // d, W // d
         el = torch.bfloat16 if dtype == 'bf16' else torch.float32
         x = torch.randn(B, ci, h, w, device=dev).to(el).contiguous(memory_format=torch.channels_last)
@@ -270,7 +307,12 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
         nbytes = x.element_size() * x.numel() + dy.element_size() * dy.numel()
         row = {'layer': name, 'shape': f'{B}x{ci}x{h}x{w} -> {co}ch 3x3 s1', 'calls_per_step': 16, 'direct_gflop': round(flop / 1e9, 2),
                'algorithmic_bytes': nbytes}
+        # what each entry point must move once (fp32): forward x + y; data gradient dy + dx; weight gradient x + dy; fused-SPADE forward x + z in, mix + gamma out
+        esz = x.element_size()
+        abytes = {'fwd': esz * B * h * w * (ci + co), 'dgrad': esz * B * h * w * (co + ci), 'wgrad': esz * B * h * w * (ci + co), 'fwd_spade': esz * B * h * w * 4 * ci}
         for k_, fn in fns.items():
+            if only is not None and only[1] != k_:
+                continue
             # >= 20 ms of warm-up per entry point (and >= 30 launches): from idle the first launches run ~20 % slower (497 vs 407 us on this
             # layer, tools/rs_probe.py) until the chip has ramped its clocks; inside the training step it has.  (Thirty launches of a 120 us
             # bf16 kernel were not enough: 161 us here against 118 us in tools/layer_bench.py.)
@@ -295,7 +337,12 @@ def roofline_step(mrdis, dev, B, H, W, dtype, iters=6):
                 name_, fac = algos[k_]
                 row[k_] = {'us': round(us, 1), 'direct_equiv_tflops': round(flop / us / 1e6, 1), 'algorithm': name_,
                            'executed_multiplies_per_direct_multiply': round(fac, 4),
-                           'frac_mfma': round(flop * fac / us / 1e6 / MFMA_F32_PEAK_TF, 3)}
+                           'frac_mfma': round(flop * fac / us / 1e6 / MFMA_F32_PEAK_TF, 3),
+                           'algorithmic_bytes': abytes[k_], 'frac_hbm': round(abytes[k_] / us / 1e3 / HBM_PEAK_GBS, 3)}
+                if pmc_inrun and only is None and name == 'sp6.gamma+beta' and k_ in ('fwd_spade', 'dgrad'):
+                    tr, src, kn = measure_traffic_inrun(script=('step_kernel.py', name, k_, str(B), str(H), str(W)), kernel_substr='wino4', n_last=6,
+                                                        what=f'tools/step_kernel.py {name} {k_}')
+                    row[k_].update(traffic=tr, traffic_over_algorithmic=None if tr is None else round(tr / abytes[k_], 3), traffic_source=src, kernel_name_in_counter_file=kn)
         out.append(row)
         del x, dy, yo, dxo
     return {'bound': 'mfma' if not bf else 'hbm', 'peak': MFMA_F32_PEAK_TF if not bf else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if not bf else 'GB/s',
@@ -389,7 +436,12 @@ def self_launch(a):
 def dry_run(a, world, rank):
     """Launcher rehearsal (no GPU): the ranks rendezvous over gloo exactly as they would over RCCL and rank 0 prints who reported."""
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29555')
+    if 'MASTER_PORT' not in os.environ:            # only ever the single-process case (a launcher sets it): any free port, so concurrent runs on one host do not collide
+        import socket
+        assert world == 1, 'dry run with WORLD_SIZE > 1 needs the launcher\'s MASTER_PORT'
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(s_.getsockname()[1])
     dist.init_process_group('gloo', rank=rank, world_size=world)
     mine = torch.tensor([rank], dtype=torch.int64)
     got = [torch.zeros_like(mine) for _ in range(world)]
@@ -407,8 +459,8 @@ def main():
         sys.exit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != a.gpus:
-        print(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE = {world} ranks; refusing to report a number for the wrong job',
-              file=sys.stderr, flush=True)
+        print(f'bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE = {world} ranks; refusing to report a number for the wrong job '
+              f'(under torchrun / torch.distributed.run pass --gpus {world} explicitly: the default is --gpus 1)', file=sys.stderr, flush=True)
         sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -445,7 +497,8 @@ def main():
         cfg.update(lambda_recon_y=1.0, out_num_ch=4)
     cfg = mrdis.derive_config(cfg, dev)
     # the step's dominant kernels at the step's shapes (before the model exists: 1.6 GB of operands of their own)
-    rstep = roofline_step(mrdis, dev, B, H, W, a.dtype) if (rank == 0 and not a.no_roofline) else None
+    # (world == 1 only: at N > 1 rank 0's extra legs run AFTER the process group is destroyed, so that no other rank waits in an RCCL barrier for them)
+    rstep = roofline_step(mrdis, dev, B, H, W, a.dtype, pmc_inrun=(not a.no_pmc and a.dtype == 'f32')) if (world == 1 and not a.no_roofline) else None
     torch.cuda.empty_cache()
     if a.roofline_only:
         assert world == 1
@@ -481,6 +534,7 @@ def main():
         step.reducer.exposed_ms()                 # reset the exchange diagnostics (warm-up steps)
         step.reducer.timing = True
     sync()
+    mrdis.hip.launch_counts(reset=True)
     t0 = time.perf_counter()
     host_ms = 0.0
     for _ in range(a.steps):
@@ -488,6 +542,7 @@ def main():
         loss, parts, _ = step(xd, maskd, mimgd, mask, targets=tgt)
         host_ms += (time.perf_counter() - h0) * 1e3
     torch.cuda.synchronize()
+    lib_launches = mrdis.hip.launch_counts()['all'] / a.steps
     dt_local = time.perf_counter() - t0           # this rank's own time for the K steps (before the closing barrier)
     sync()
     dt = time.perf_counter() - t0
@@ -598,6 +653,9 @@ def main():
                 FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
         }
         log(f'timed: {ms:.1f} ms/step -> {value:.2f} slices/s (host enqueue {host_ms:.1f} ms/step)')
+        out['library_launches_per_step'] = round(lib_launches, 1)
+        out['library_launches_note'] = ('kernel launches issued by libmrdis_hip per timed step, counted by the library (mrdis_launch_count("all")); ATen glue kernels are not in it '
+                                        '(profiles/*_dispatch_counts_*.txt has every dispatch from rocprofv3)')
         out['host_enqueue_ms_per_step'] = round(host_ms, 1)
         out['host_enqueue_note'] = 'host time inside step() during the timed region: mostly waiting on the full launch queue (the step is GPU-bound); host_ms_unblocked is the cost proper'
         if world == 1 and not a.no_roofline:
@@ -608,17 +666,22 @@ def main():
             out['ddp'] = ddp
             out['allreduce_wait_ms'] = ddp['allreduce_wait_ms']
             out['bytes_reduced'] = ddp['bytes_reduced_per_step']
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()        # ranks 1..N-1 are done here; rank 0's extra legs below keep nobody waiting
+    if rank == 0:
         if not a.no_roofline:
+            if rstep is None:
+                rstep = roofline_step(mrdis, dev, B, H, W, a.dtype)
             out['roofline'] = roofline_conv(mrdis, dev, pmc_inrun=(world == 1 and not a.no_pmc))
             log(f'roofline: {out["roofline"]}')
             out['roofline_step'] = rstep
             log(f'roofline_step: {rstep}')
+            if world > 1:
+                out['roofline_note'] = 'N > 1: both roofline legs ran on rank 0 after destroy_process_group() (outside the timed region, no rank waiting); PMC traffic passes are N = 1 only'
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(M, H, W, adv)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -420,6 +420,7 @@ int mrdis_run_c16(const float* x, int ldx, const float* w_tck, const float* bias
             if (hipFuncSetAttribute((const void*)conv3x3_c16_split6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) return MRDIS_ELAUNCH;
             attr_set = true;
         }
+        mrdis_count(MRDIS_CNT_SPLIT6_C16);
         MRDIS_LAUNCH(conv3x3_c16_split6_kernel, dim3(grid), dim3(256), (size_t)C16_NPX * 208, s, p);
     } else
     if (Ci == 32) MRDIS_LAUNCH((conv3x3_c16_kernel<2>), dim3(grid), dim3(256), lds, s, p);

@@ -192,6 +192,7 @@ int mrdis_run_co4(const void* x, int ldx, const float* w, const float* bias, flo
 #define CO4_LAUNCH(HV, TP) { if (x_bf16) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, true>), grid, block, lds, s, p); \
                              else if (split) MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false, true>), grid, block, lds, s, p); \
                              else MRDIS_LAUNCH((conv3x3_co4_kernel<HV, TP, false>), grid, block, lds, s, p); }
+    if (split) mrdis_count(MRDIS_CNT_SPLIT6_CO4);
     const int tpw = W / 64;
     if (Ci == 64) { if (tpw == 4) CO4_LAUNCH(4, 4) else if (tpw == 2) CO4_LAUNCH(4, 2) else CO4_LAUNCH(4, 1) }
     else { if (tpw == 4) CO4_LAUNCH(2, 4) else if (tpw == 2) CO4_LAUNCH(2, 2) else CO4_LAUNCH(2, 1) }

@@ -23,17 +23,19 @@ enum {
 };
 long long mrdis_opt(int id);      // mrdis_elem.hip
 
-// Launch counters of the Winograd kernel families (host side, one increment per launch): what a test asks to know which form actually ran
+// Launch counters of the Winograd / bf16 / six-product (split6) kernel families (host side, one increment per launch): what a test asks to know which form actually ran
 // (mrdis_launch_count("wino4") ...; mrdis_elem.hip).
 enum { MRDIS_CNT_WINO, MRDIS_CNT_WINO_SPADE, MRDIS_CNT_WINO2, MRDIS_CNT_WINO2_SPADE, MRDIS_CNT_WINO4, MRDIS_CNT_WINO4_SPADE, MRDIS_CNT_WINO4N, MRDIS_CNT_WINO4R,
-       MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_BCONV3, MRDIS_CNT_BCONV3_SPADE, MRDIS_CNT_BCONV4, MRDIS_CNT_BCONV4_SPADE, MRDIS_CNT_COUNT };
+       MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_BCONV3, MRDIS_CNT_BCONV3_SPADE, MRDIS_CNT_BCONV4, MRDIS_CNT_BCONV4_SPADE,
+       MRDIS_CNT_SPLIT6_C4, MRDIS_CNT_SPLIT6_C16, MRDIS_CNT_SPLIT6_WGRAD16, MRDIS_CNT_SPLIT6_CO4,
+       MRDIS_CNT_ALL /* every launch of the library */, MRDIS_CNT_COUNT };
 void mrdis_count(int id);
 
 // Every kernel launch of the library goes through MRDIS_LAUNCH: it records, per kernel expression, the largest DYNAMIC LDS size it was launched with
 // (rocprofv3's kernel trace reports only the static group segment: 0 for the `extern __shared__` kernels, e.g. the 155 KB of wino4_kernel).
 // mrdis_dynamic_lds_table (mrdis_elem.hip) hands the table out; bench.py puts it into its JSON line, tools/prof_summary.py into the per-kernel tables.
 void mrdis_note_lds(const char* kernel_expr, size_t bytes);
-#define MRDIS_LAUNCH(kernel, grid, block, lds, s, ...) do { if ((size_t)(lds) != 0) mrdis_note_lds(#kernel, (size_t)(lds)); hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__); } while (0)
+#define MRDIS_LAUNCH(kernel, grid, block, lds, s, ...) do { mrdis_count(MRDIS_CNT_ALL); if ((size_t)(lds) != 0) mrdis_note_lds(#kernel, (size_t)(lds)); hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__); } while (0)
 
 static inline int mrdis_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -1265,7 +1265,8 @@ __global__ __launch_bounds__(256) void c4conv_kernel(const C4Params p) { c4conv_
 template <bool LRELU, bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_split6_kernel(const C4Params p) { c4conv_body<1, LRELU, FULL, false, true>(p); }
 // the 32-cout bf16-output form on exact strips (the si_layers' forward at 256x256): left alone the allocator takes 95 + 48 registers,
-// one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to four waves.
+// one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to three waves per SIMD (round 5: the
+// two-term form needs 149 registers; run_c4conv sizes the persistent grid from THIS instantiation's occupancy).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
 
 static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int obytes = 4) {
@@ -1300,21 +1301,26 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     long long blocks = (p.ntiles + 3) / 4;
     // persistent grid: exactly the number of workgroups the chip holds at once (one wave of workgroups,
     // no tail round); residency is queried once per instantiation.
-    static int occ[3] = {0, 0, 0}, ncu = 0;
-    if (!occ[NS]) {
+    // (per instantiation: the six-product and bf16-output forms are pinned to three waves per SIMD, the fp32 form holds four workgroups per CU)
+    static int occ[4] = {0, 0, 0, 0}, ncu = 0;
+    const int oi = split6 ? 0 : (obf16 && NS == 1) ? 3 : NS;
+    if (!occ[oi]) {
         int o = 0;
-        if (NS == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
+        if (oi == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_split6_kernel<false, true>, 256, 0);
+        else if (oi == 3) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_obf16_kernel, 256, 0);
+        else if (NS == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
-        occ[NS] = o > 0 ? o : 2;
+        occ[oi] = o > 0 ? o : 2;
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    long long cap = (long long)ncu * occ[NS] / ny; if (cap < ncu) cap = ncu;
+    long long cap = (long long)ncu * occ[oi] / ny; if (cap < ncu) cap = ncu;
     if (blocks > cap) blocks = cap;
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
 #define C4_LAUNCH(ns, lr, fa) MRDIS_LAUNCH((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)
     if (split6) {
+        mrdis_count(MRDIS_CNT_SPLIT6_C4);
         if (p.lrelu) { if (fast) MRDIS_LAUNCH((c4conv_split6_kernel<true, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_split6_kernel<true, false>), grid, dim3(256), 0, s, p); }
         else { if (fast) MRDIS_LAUNCH((c4conv_split6_kernel<false, true>), grid, dim3(256), 0, s, p); else MRDIS_LAUNCH((c4conv_split6_kernel<false, false>), grid, dim3(256), 0, s, p); }
     } else

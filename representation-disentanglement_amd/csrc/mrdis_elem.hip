@@ -5,6 +5,7 @@
 // Reductions are two-level with a fixed summation order (partials in fp32 over
 // short runs, combination in fp64) so every result is bit-reproducible.
 #include "mrdis_common.h"
+#include <mutex>
 #include <type_traits>
 #include <stdlib.h>
 #include <string.h>
@@ -1971,7 +1972,8 @@ extern "C" long long mrdis_get_option(const char* name) {
 
 namespace {
 const char* const CNT_NAMES[MRDIS_CNT_COUNT] = {"wino", "wino_spade", "wino2", "wino2_spade", "wino4", "wino4_spade", "wino4n", "wino4r",
-                                                "wino_wgrad", "wino_wgrad2", "wino4_wgrad", "bconv3", "bconv3_spade", "bconv4", "bconv4_spade"};
+                                                "wino_wgrad", "wino_wgrad2", "wino4_wgrad", "bconv3", "bconv3_spade", "bconv4", "bconv4_spade",
+                                                "split6_c4", "split6_c16", "split6_wgrad16", "split6_co4", "all"};
 long long g_counts[MRDIS_CNT_COUNT];
 }  // namespace
 void mrdis_count(int id) { __atomic_fetch_add(&g_counts[id], 1LL, __ATOMIC_RELAXED); }
@@ -1988,23 +1990,29 @@ extern "C" void mrdis_launch_count_reset(void) {
 namespace {
 struct LdsNote { const char* expr; size_t bytes; };
 LdsNote g_lds[128]; int g_nlds = 0;
+std::mutex g_lds_mu;        // forward (main thread) and backward (autograd thread) both launch
 }  // namespace
 void mrdis_note_lds(const char* kernel_expr, size_t bytes) {       // host, launch path: a pointer compare per known kernel (string literals are unique per call site)
+    const int n = __atomic_load_n(&g_nlds, __ATOMIC_ACQUIRE);
+    for (int i = 0; i < n; ++i)        // known kernel at a size already seen: no lock (entries are only ever appended, bytes only ever grow)
+        if (g_lds[i].expr == kernel_expr && bytes <= g_lds[i].bytes) return;
+    std::lock_guard<std::mutex> lk(g_lds_mu);
     for (int i = 0; i < g_nlds; ++i)
         if (g_lds[i].expr == kernel_expr) { if (bytes > g_lds[i].bytes) g_lds[i].bytes = bytes; return; }
-    if (g_nlds < 128) { g_lds[g_nlds].expr = kernel_expr; g_lds[g_nlds].bytes = bytes; ++g_nlds; }
+    if (g_nlds < 128) { g_lds[g_nlds].expr = kernel_expr; g_lds[g_nlds].bytes = bytes; __atomic_store_n(&g_nlds, g_nlds + 1, __ATOMIC_RELEASE); }
 }
-// "kernel expression=bytes" lines, at most cap - 1 characters; returns the number of entries
+// "kernel expression=bytes" lines, at most cap - 1 characters, only whole lines; returns the number of entries written
 extern "C" int mrdis_dynamic_lds_table(char* buf, int cap) {
-    int pos = 0;
+    int pos = 0, written = 0;
     if (!buf || cap < 1) return MRDIS_EINVAL;
     buf[0] = 0;
+    std::lock_guard<std::mutex> lk(g_lds_mu);
     for (int i = 0; i < g_nlds; ++i) {
         const int n = snprintf(buf + pos, (size_t)(cap - pos), "%s=%zu\n", g_lds[i].expr, g_lds[i].bytes);
-        if (n < 0 || pos + n >= cap) break;
-        pos += n;
+        if (n < 0 || pos + n >= cap) { buf[pos] = 0; break; }      // the entry did not fit: drop its truncated text
+        pos += n; ++written;
     }
-    return g_nlds;
+    return written;
 }
 
 extern "C" const char* mrdis_strerror(int code) {

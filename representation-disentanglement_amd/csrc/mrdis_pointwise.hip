@@ -174,7 +174,7 @@ static int pw_grid(long long nitems, int per_thread) {
     if (g > 4096) g = 4096;
     return (int)(g < 1 ? 1 : g);
 }
-#define PW_BY_CO(K, T, ...) switch (Co) { case 1: K<1, T> __VA_ARGS__; break; case 2: K<2, T> __VA_ARGS__; break; case 3: K<3, T> __VA_ARGS__; break; \
+#define PW_BY_CO(K, T, ...) mrdis_count(MRDIS_CNT_ALL); switch (Co) { case 1: K<1, T> __VA_ARGS__; break; case 2: K<2, T> __VA_ARGS__; break; case 3: K<3, T> __VA_ARGS__; break; \
     case 4: K<4, T> __VA_ARGS__; break; case 5: K<5, T> __VA_ARGS__; break; case 6: K<6, T> __VA_ARGS__; break; case 7: K<7, T> __VA_ARGS__; break; default: K<8, T> __VA_ARGS__; break; }
 
 // each returns MRDIS_EUNSUPPORTED outside what it covers (16 channels on the wide side -- fp32 or bf16 views --, <= 8 fp32 channels on the narrow one)

@@ -529,6 +529,7 @@ int mrdis_run_wgrad16(const float* x, int ldx, const float* dy, int lddy, float*
                 if (hipFuncSetAttribute((const void*)wgrad16_split6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return MRDIS_ELAUNCH;
                 attr_set = true;
             }
+            mrdis_count(MRDIS_CNT_SPLIT6_WGRAD16);
             MRDIS_LAUNCH(wgrad16_split6_kernel, dim3(q.splits), dim3(256), lds6, s, q);
             MRDIS_CHECK_LAUNCH();
             const long long nout6 = 9LL * Ci * Co + (dbias ? Co : 0);

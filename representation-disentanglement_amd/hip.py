@@ -137,7 +137,26 @@ def get_option(name):
     return int(load().mrdis_get_option(name.encode()))
 
 
-KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade')
+# every switch of csrc/mrdis_elem.hip OPT_DEFS (tests/test_abi.py checks that the library knows each name)
+OPTION_NAMES = ('wino', 'nt_mb', 'wino_pipe', 'wino_u', 'wino4', 'wino4r', 'bconv4', 'split6', 'debug_no16', 'debug_nothin', 'debug_noc4', 'debug_nodma',
+                'debug_no16_3d', 'debug_bilgen', 'debug_now16', 'debug_nopack', 'debug_mode', 'debug_bn', 'debug_kc', 'debug_bm', 'debug_c4_tw',
+                'debug_wgsplit', 'debug_bn3', 'debug_kc3')
+
+
+def options_snapshot():
+    """{name: value} of every process-wide switch; `options_restore(snap)` puts them back (tests/conftest.py does so around every test)."""
+    return {n: get_option(n) for n in OPTION_NAMES}
+
+
+def options_restore(snap):
+    for n, v in snap.items():
+        if get_option(n) != v:
+            set_option(n, v)
+
+
+KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade',
+                                   'split6_c4', 'split6_c16', 'split6_wgrad16', 'split6_co4',
+                                   'all')        # 'all': every kernel launch of the library (bench.py: library_launches_per_step)
 
 
 def stream_fill(t, value=0.0):
@@ -155,13 +174,15 @@ def dynamic_lds():
     out = {}
     for line in buf.value.decode().splitlines():
         expr, _, b = line.rpartition('=')
+        if not expr or not b.isdigit():        # (the library only hands out whole lines; never let a diagnostic take the caller down)
+            continue
         name = re.sub(r'<.*', '', expr.strip().lstrip('(')).strip()
         out[name] = max(out.get(name, 0), int(b))
     return out
 
 
 def launch_counts(reset=False):
-    """{family: launches since load / the last reset} of the Winograd kernel families (include/mrdis.h mrdis_launch_count)"""
+    """{family: launches since load / the last reset} of the Winograd, bf16 LDS-DMA and six-product (split6) kernel families (include/mrdis.h mrdis_launch_count)"""
     lib = load()
     out = {f: int(lib.mrdis_launch_count(f.encode())) for f in WINO_FAMILIES}
     if reset:

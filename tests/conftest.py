@@ -32,15 +32,30 @@ def mrdis():
 
 @pytest.fixture(autouse=True)
 def _restore_library_options():
-    """tests switch kernel-selection options (hip.set_option) in-process: put the defaults back after each test."""
+    """tests switch kernel-selection options (hip.set_option) in-process: EVERY switch of the library is snapshotted before a test and put back
+    after it, so no test runs under the policy another one forced (bconv4, split6, debug_mode ...) and results do not depend on test order or -k."""
+    m = sys.modules.get('mrdis')
+    loaded = m is not None and getattr(m.hip, '_lib', None) is not None
+    snap = m.hip.options_snapshot() if loaded else None
     yield
     m = sys.modules.get('mrdis')
     if m is not None and getattr(m.hip, '_lib', None) is not None:
-        m.hip.set_option('wino', int(os.environ.get('MRDIS_WINO', '1')))
-        m.hip.set_option('nt_mb', int(os.environ.get('MRDIS_NT_MB', '128')))
-        m.hip.set_option('wino_pipe', int(os.environ.get('MRDIS_WINO_PIPE', '1')))
-        m.hip.set_option('wino_u', int(os.environ.get('MRDIS_WINO_U', '1')))
-        m.hip.set_option('wino4', int(os.environ.get('MRDIS_WINO4', '1')))
-        m.hip.set_option('wino4r', int(os.environ.get('MRDIS_WINO4R', '1')))
-        m.hip.set_option('debug_now16', 1 if 'MRDIS_DEBUG_NOW16' in os.environ else 0)
-        m.hip.set_option('debug_nopack', 1 if 'MRDIS_DEBUG_NOPACK' in os.environ else 0)
+        if snap is None:        # the library was first loaded inside this test: its load-time values (environment / defaults) are what to go back to
+            snap = _LOAD_DEFAULTS.get('snap')
+        if snap is not None:
+            m.hip.options_restore(snap)
+
+
+_LOAD_DEFAULTS = {}
+
+
+@pytest.fixture(autouse=True, scope='session')
+def _record_load_defaults():
+    """the option table as the library built it from the environment, taken before any test can change it"""
+    try:
+        import mrdis as m
+        m.hip.load()
+        _LOAD_DEFAULTS['snap'] = m.hip.options_snapshot()
+    except Exception:       # no library (a CPU box before build()): the tests that need it fail loudly on their own
+        pass
+    yield

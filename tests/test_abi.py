@@ -74,3 +74,22 @@ def test_mix_job_struct_matches_library():
     lib = mrdis.hip.load()
     assert ctypes.sizeof(mrdis.hip.MixJob) == lib.mrdis_mix_job_bytes() == 368
     assert 1 <= lib.mrdis_mix_job_blocks(32, 16, 9) <= 128
+
+
+def test_option_and_counter_tables_match_the_library(mrdis):
+    """hip.OPTION_NAMES / hip.KERNEL_FAMILIES (what tests/conftest.py snapshots and the parity tests assert on) are names the library knows;
+    the dynamic-LDS table hands out whole lines only (host-only calls)."""
+    hip = mrdis.hip
+    lib = hip.load()
+    snap = hip.options_snapshot()
+    assert len(snap) == len(hip.OPTION_NAMES) == len(set(hip.OPTION_NAMES))
+    for name, v in snap.items():
+        hip.set_option(name, v)                    # raises on a name the library does not know
+    assert lib.mrdis_set_option(b'no_such_option', 1) == -1
+    for fam in hip.KERNEL_FAMILIES:
+        assert lib.mrdis_launch_count(fam.encode()) >= 0, fam
+    assert lib.mrdis_launch_count(b'no_such_family') == -1
+    assert isinstance(hip.dynamic_lds(), dict)
+    import ctypes
+    tiny = ctypes.create_string_buffer(4)
+    assert lib.mrdis_dynamic_lds_table(tiny, 4) >= 0 and b'=' not in tiny.value.replace(b'\n', b'')[:0]

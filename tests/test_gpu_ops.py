@@ -183,12 +183,12 @@ def test_bf16_lds_dma_conv_bit_identical(mrdis, case):
     wb_f, wb_b = hip.cast_bf16(w_tkc), hip.cast_bf16(w_tck)
     out = {}
     for mode in (0, 2):                                 # bconv3 | bconv4 wherever it applies
-        hip.set_option('bconv4', mode)
-        hip.launch_counts(reset=True)
-        y = hip.conv2d_fwd(xb, w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f)
-        y0 = hip.conv2d_fwd(xb, w_tck, None, 3, 3, 1, 1, w_bf16=wb_f)
-        g = hip.conv2d_bwd_data(gyb, w_tkc, (H, W), 3, 3, 1, 1, w_bf16=wb_b) if Co % 32 == 0 else None
-        c = hip.launch_counts()
+        with hip.option('bconv4', mode):
+            hip.launch_counts(reset=True)
+            y = hip.conv2d_fwd(xb, w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f)
+            y0 = hip.conv2d_fwd(xb, w_tck, None, 3, 3, 1, 1, w_bf16=wb_f)
+            g = hip.conv2d_bwd_data(gyb, w_tkc, (H, W), 3, 3, 1, 1, w_bf16=wb_b) if Co % 32 == 0 else None
+            c = hip.launch_counts()
         assert (c['bconv4'] > 0) == (mode != 0) and (c['bconv3'] > 0) == (mode == 0), (mode, c)
         out[mode] = (y, y0, g)
     for mode in (2,):
@@ -199,10 +199,10 @@ def test_bf16_lds_dma_conv_bit_identical(mrdis, case):
     close(out[2][0].float(), ref, rtol=1.5e-2, what='bf16 LDS-DMA fwd vs torch on bf16-rounded operands')
     # a channel-slice input view (ld > Cin) whose last pixel ends exactly at the descriptor's record count, and an output slice of a wider buffer
     if Co % 8 == 0:
-        hip.set_option('bconv4', 2)
         wide_in = cl(torch.cat([rnd((N, 8, H, W), 9), x], 1)).to(B16)
         wide_out = hip.empty_nhwc(N, Co + 8, H, W, dev(), B16); wide_out.zero_()
-        hip.conv2d_fwd(wide_in[:, 8:], w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f, out=wide_out[:, 8:])
+        with hip.option('bconv4', 2):
+            hip.conv2d_fwd(wide_in[:, 8:], w_tck, b.to(dev()), 3, 3, 1, 1, lrelu=True, w_bf16=wb_f, out=wide_out[:, 8:])
         assert torch.equal(wide_out[:, 8:], out[0][0]) and float(wide_out[:, :8].float().abs().max()) == 0.0
 
 
@@ -217,10 +217,10 @@ def test_gb_spade_fused_epilogue_bf16_lds_dma(mrdis, case):
     w_tck = to_tck(w).to(dev()); wb = hip.cast_bf16(to_tkc(w).to(dev()))
     res = {}
     for mode in (0, 2):
-        hip.set_option('bconv4', mode)
-        hip.launch_counts(reset=True)
-        res[mode] = hip.gb_spade_fwd(x, w_tck, b, z, 1e-5, w_bf16=wb)
-        c = hip.launch_counts()
+        with hip.option('bconv4', mode):
+            hip.launch_counts(reset=True)
+            res[mode] = hip.gb_spade_fwd(x, w_tck, b, z, 1e-5, w_bf16=wb)
+            c = hip.launch_counts()
         assert res[mode] is not None and (c['bconv4_spade'] > 0) == (mode != 0) and (c['bconv3_spade'] > 0) == (mode == 0), (mode, c)
     for mode in (2,):
         for a, b_ in zip(res[0], res[mode]):
@@ -1216,9 +1216,8 @@ def test_bf16_weight_gradient_lds_dma_bit_identical(mrdis, case):
     B16 = torch.bfloat16
     x = rnd((N, Ci, H, W), 1).to(B16); gy = rnd((N, Co, H, W), 2).to(B16)
     xd, gyd = cl(x), cl(gy)
-    hip.set_option('debug_mode', 3010)
-    dw2, db2 = hip.conv2d_bwd_weight(xd, gyd, 3, 3, 1, 1, need_bias=True)
-    hip.set_option('debug_mode', -1)
+    with hip.option('debug_mode', 3010):
+        dw2, db2 = hip.conv2d_bwd_weight(xd, gyd, 3, 3, 1, 1, need_bias=True)
     dw3, db3 = hip.conv2d_bwd_weight(xd, gyd, 3, 3, 1, 1, need_bias=True)
     assert torch.equal(dw2, dw3) and torch.equal(db2, db3)
     wz = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
