@@ -56,6 +56,9 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16m'],
                     help="f32 (headline: exact fp32 MFMA, fp32 activations) | bf16 (BASELINE configs[2]: bf16 activations in HBM, bf16 MFMA operands, "
                          "fp32 accumulate / statistics / master weights / optimizer) | bf16m (bf16 MFMA operands on fp32 activations)")
+    ap.add_argument('--graph', action='store_true', help='the timed steps as HIP-graph replays (trainer.GraphedTrainStep; also MRDIS_GRAPH=1): forward, losses, backward, clip, Adam '
+                                                         'recorded once after two eager iterations; >= 3 untimed warm-up steps are run so that the timed region only replays')
+    ap.add_argument('--no-graph-leg', action='store_true', help='skip the extra graph-replay timing beside the (eager) headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (the stored number is reported instead)')
@@ -394,7 +397,7 @@ def cpu_baseline(M, H, W, adv):
                       f'{dt:.2f} s/step'}
 
 
-def host_unblocked_ms(mrdis, cfg, dev, B, M, adv, steps=4):
+def host_unblocked_ms(mrdis, cfg, dev, B, M, adv, steps=4, graph=False):
     """What the HOST needs to enqueue one step when the launch queue never fills: the same step (same launch count: it does not depend on the
     map size) on 64x64 slices, where the GPU finishes long before the host, timed per step between synchronisations.  `host_enqueue_ms_per_step` of the
     timed region is mostly back-pressure from the full queue; this number is what decides whether N ranks on one host stay GPU-bound."""
@@ -402,6 +405,8 @@ def host_unblocked_ms(mrdis, cfg, dev, B, M, adv, steps=4):
     torch.manual_seed(10); np.random.seed(10)
     model = mrdis.build_model(small).train()
     step = mrdis.TrainStep(model, small)
+    if graph:                                       # the same question for the graph-replayed step: closures re-drawn, one copy kernel, one graph launch
+        step = mrdis.GraphedTrainStep(step, warm=1)
     x, mask, mask_img = mrdis.synthetic_batch(B, M, 64, 64, seed=10)
     xd = x.to(dev).contiguous(memory_format=torch.channels_last); maskd, mimgd = mask.to(dev), mask_img.to(dev)
     ts = []
@@ -506,7 +511,12 @@ def main():
         return
     torch.manual_seed(10); np.random.seed(10)                       # main_missing.py:18-21; same init on every rank
     model = mrdis.build_model(cfg).train()
+    graph_on = a.graph or os.environ.get('MRDIS_GRAPH', '0') not in ('', '0')
     step = mrdis.TrainStep(model, cfg)
+    eager_step = step
+    if graph_on:
+        step = mrdis.GraphedTrainStep(step)
+        a.warmup = max(a.warmup, step.warm + 1)
     x, mask, mask_img = mrdis.synthetic_batch(B, M, a.slice, a.slice, seed=10 + rank, drop=a.drop)
     x = mrdis.fit_to_model(x, (H, W), fill=-10.0)
     mask_img = (x[:, 0] == 0).float()
@@ -580,11 +590,11 @@ def main():
         prev = mrdis.hip.get_option('wino')
         mrdis.hip.set_option('wino', 0)
         nd = max(2, min(a.steps, 5))
-        step(xd, maskd, mimgd, mask, targets=tgt)
+        eager_step(xd, maskd, mimgd, mask, targets=tgt)
         sync()
         t0 = time.perf_counter()
         for _ in range(nd):
-            step(xd, maskd, mimgd, mask, targets=tgt)
+            eager_step(xd, maskd, mimgd, mask, targets=tgt)
         sync()
         ms_direct = (time.perf_counter() - t0) / nd * 1e3
         mrdis.hip.set_option('wino', prev)
@@ -600,11 +610,11 @@ def main():
         prev6 = mrdis.hip.get_option('split6')
         mrdis.hip.set_option('split6', 0)
         nd = max(2, min(a.steps, 5))
-        step(xd, maskd, mimgd, mask, targets=tgt)
+        eager_step(xd, maskd, mimgd, mask, targets=tgt)
         sync()
         t0 = time.perf_counter()
         for _ in range(nd):
-            step(xd, maskd, mimgd, mask, targets=tgt)
+            eager_step(xd, maskd, mimgd, mask, targets=tgt)
         sync()
         ms_off = (time.perf_counter() - t0) / nd * 1e3
         mrdis.hip.set_option('split6', prev6)
@@ -618,6 +628,27 @@ def main():
                           '(dropped: < 2^-23 of a product); = 0: fp32 MFMA.  Unit tests hold the split within 2e-6 of the fp32 kernels and at <= 2x their error against float64',
                   'steps_timed': nd}
 
+    # the same step as HIP-graph replays (or, under --graph, eagerly): beside the headline, never as `value`
+    graph_leg = None
+    if not a.no_graph_leg and not a.no_direct and world == 1:
+        try:
+            nd = max(2, min(a.steps, 5))
+            other = eager_step if graph_on else mrdis.GraphedTrainStep(eager_step, warm=1)
+            for _ in range(3):                      # (graph: one eager iteration on the capture stream, the recording, one replay)
+                other(xd, maskd, mimgd, mask, targets=tgt)
+            sync()
+            t0 = time.perf_counter(); h_ms = 0.0
+            for _ in range(nd):
+                h0 = time.perf_counter(); lg, _, _ = other(xd, maskd, mimgd, mask, targets=tgt); h_ms += (time.perf_counter() - h0) * 1e3
+            sync()
+            graph_leg = {'mode': 'eager' if graph_on else 'graph replay', 'ms_per_step': round((time.perf_counter() - t0) / nd * 1e3, 2),
+                         'host_enqueue_ms_per_step': round(h_ms / nd, 2), 'steps_timed': nd, 'loss': round(float(lg), 5),
+                         'stats': None if graph_on else dict(other.stats),
+                         'what': 'trainer.GraphedTrainStep: forward, losses, backward(s), clip, Adam recorded into one HIP graph; per step the host re-draws eps / the '
+                                 'sim_s + adv_s pairs / the mask weights (ops.host_value), ships them with one copy kernel and launches the graph.  Bit-identical to the eager '
+                                 'step (tests/test_gpu_graph.py); opt-in (--graph, MRDIS_GRAPH=1, config graph: true)'}
+        except Exception as ex:                     # noqa: BLE001 -- an extra leg must not take the headline down
+            graph_leg = {'error': f'{type(ex).__name__}: {ex}'[:300]}
     if rank == 0:
         out = {
             'metric': 'MR slices/sec (train step, recon+adv+latent losses)' if adv else 'MR slices/sec (train step, recon+latent losses, lambda_adv_s=0)',
@@ -649,6 +680,7 @@ def main():
             'key_aliases': {'step_tflops_f32': 'step_tflops', 'mfma_f32_peak_tflops': 'mfma_peak_tflops', 'step_tflops_f32_direct_only': 'step_tflops_direct_only'},      # round-2 names of the same fields
             'ms_per_step_direct_only': None if ms_direct is None else round(ms_direct, 2),
             'split6': split6,
+            'graph': {'headline_mode': 'graph replay' if graph_on else 'eager', 'other_mode': graph_leg},
             'step_tflops_direct_only': None if ms_direct is None else round(
                 FLOP_PER_SLICE_160x192 * (H * W) / (160 * 192) * (M / 4.0) ** 2 * B / (ms_direct * 1e-3) / 1e12, 2),
         }
@@ -660,6 +692,7 @@ def main():
         out['host_enqueue_note'] = 'host time inside step() during the timed region: mostly waiting on the full launch queue (the step is GPU-bound); host_ms_unblocked is the cost proper'
         if world == 1 and not a.no_roofline:
             out['host_ms_unblocked'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv)
+            out['host_ms_unblocked_graph'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv, graph=True)
             log(f'host_ms_unblocked: {out["host_ms_unblocked"]} ms/step')
         out['dynamic_lds_bytes'] = mrdis.hip.dynamic_lds()         # per kernel family: what rocprofv3's LDS column cannot show (tools/prof_summary.py merges it in)
         if ddp is not None:

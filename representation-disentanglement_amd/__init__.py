@@ -19,7 +19,7 @@ from .model import (CondConv2d, Conv2d, HipConv2d, BatchNorm2d, Conv_BN_Act_New,
                     Act_Deconv_BN_Concat_New, AnatomyEncoderEncNew, AnatomyEncoderDecNew,
                     ModalityEncoderNew, SPADEBlockNew, SPADENewShared, SPADENewNotShared,
                     Discriminator, MultimodalModel, expand_type)
-from .trainer import (TrainStep, EvalStep, ArenaAdam, GradAllReduce, DEFAULT_CONFIG, load_config_yaml,   # noqa: F401
+from .trainer import (TrainStep, GraphedTrainStep, make_train_step, regular_mask, EvalStep, ArenaAdam, GradAllReduce, DEFAULT_CONFIG, load_config_yaml,   # noqa: F401
                       derive_config, build_model, synthetic_batch, fit_to_model, forward_losses,
                       save_checkpoint, load_checkpoint_model, LOSS_KEYS)
 

@@ -320,6 +320,12 @@ class _Mailbox:
 _mailbox = None
 
 
+def copy_bytes(src, dst, nbytes):
+    """word-wise copy by a kernel on the current stream (include/mrdis.h mrdis_copy_bytes); src may be a PINNED host tensor"""
+    assert nbytes % 4 == 0 and nbytes <= src.numel() * src.element_size() and nbytes <= dst.numel() * dst.element_size()
+    _chk(load().mrdis_copy_bytes(src.data_ptr(), _ptr(dst), int(nbytes), _stream()), 'copy_bytes')
+
+
 def to_device_small(t_cpu, device):
     """CPU tensor (<= 64 KB, element size 4 or 8) -> new device tensor, stream-ordered, without the copy engine; None if it does not qualify."""
     global _mailbox

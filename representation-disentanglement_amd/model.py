@@ -887,7 +887,8 @@ class MultimodalModel(nn.Module):
 
     # ---- model.py:3159-3162: eps is drawn from the CPU generator, then moved
     def sample(self, z_mean, z_log_var):
-        eps = ops.to_device(torch.normal(0, 1, size=(z_mean.shape[0], z_mean.shape[1])), self.device)
+        shape = (z_mean.shape[0], z_mean.shape[1])
+        eps = ops.host_value(lambda: torch.normal(0, 1, size=shape), self.device)        # a graph replay draws again, in the same order
         return z_mean + eps * torch.exp(0.5 * z_log_var)
 
     # ---- model.py:3164-3185
@@ -1015,15 +1016,13 @@ class MultimodalModel(nn.Module):
 
     def compute_recon_loss_y_list(self, gt, y_list, mask, p=2, mask_host=None):                 # :3268-3278
         mh = _host_mask(mask, mask_host)
-        errs, rows = [], []
-        for i in range(len(y_list)):
-            if mh[:, i].sum() == 0:
-                continue
+        errs = []
+        terms = [i for i in range(len(y_list)) if mh[:, i].sum() != 0]
+        for i in terms:
             errs.append(self.compute_recon_loss(gt, y_list[i], p))
-            rows.append(mh[:, i] / float(mh[:, i].sum()))
         if not errs:
             return torch.zeros((), device=self.device)
-        return (torch.stack(errs) * self._weights(rows)).sum() / len(errs)
+        return (torch.stack(errs) * self._weights(lambda m: [m[:, i] / float(m[:, i].sum()) for i in terms], mh)).sum() / len(errs)
 
     def compute_segmentation_loss_y(self, gt, y, weight=(1., 5., 5., 5.)):                      # :3287-3297
         w = torch.tensor(weight, dtype=torch.float32, device=y.device)
@@ -1057,25 +1056,28 @@ class MultimodalModel(nn.Module):
     # reduction: the weights (mask / count / number of terms) come from the host copy of the mask, so a term costs its
     # HIP reduction and nothing else (the loop form issued ~1000 one-workgroup torch kernels per step, forward and
     # backward).  Term order, the skip rules and the quirks are unchanged.
-    def _weights(self, rows):
-        """rows: list of numpy (B,) weight vectors -> (T, B) device tensor (one H2D copy)."""
-        return ops.to_device(torch.from_numpy(np.stack(rows).astype(np.float32)), self.device)
+    def _weights(self, rows_of, mh):
+        """rows_of(mh) -> list of numpy (B,) weight vectors -> (T, B) device tensor (one H2D copy).  Handed over as a function of the
+        host mask: a step recorded for graph replay (trainer.GraphedTrainStep) evaluates it again on every replay's own mask
+        (ops.step_mask_host()); the eager step evaluates it once, on `mh`."""
+        def make():
+            cur = ops.step_mask_host()                 # None outside a graph replay
+            return torch.from_numpy(np.stack(rows_of(mh if cur is None else cur)).astype(np.float32))
+        return ops.host_value(make, self.device)
 
     def compute_recon_loss_x_list(self, gt_list, x_list, mask, p=2, mask_host=None):             # :3315-3325
         mh = _host_mask(mask, mask_host)
-        errs, rows = [], []
-        for i in range(len(x_list)):
-            if mh[:, i].sum() == 0:
-                continue
+        errs = []
+        terms = [i for i in range(len(x_list)) if mh[:, i].sum() != 0]
+        for i in terms:
             errs.append(self.compute_recon_loss(gt_list[i], x_list[i], p))
-            rows.append(mh[:, i] / float(mh[:, i].sum()))
         if not errs:
             return torch.zeros((), device=self.device)
-        return (torch.stack(errs) * self._weights(rows)).sum() / len(errs)
+        return (torch.stack(errs) * self._weights(lambda m: [m[:, i] / float(m[:, i].sum()) for i in terms], mh)).sum() / len(errs)
 
     def compute_recon_loss_x_mix_list(self, gt_list, x_list, mask, p=2, mask_host=None):         # :3327-3341
         mh = _host_mask(mask, mask_host)
-        errs, rows = [], []
+        errs, pairs = [], []
         M = mh.shape[1]
         idx = 0
         for i in range(M):
@@ -1087,11 +1089,11 @@ class MultimodalModel(nn.Module):
                     continue
                 # QUIRK (:3337-3338): x_list is indexed by a counter that only advances on non-empty pairs
                 errs.append(self.compute_recon_loss(gt_list[j], x_list[idx], p))
-                rows.append(mm_h / float(mm_h.sum()))
+                pairs.append((i, j))
                 idx += 1
         if not errs:
             return torch.zeros((), device=self.device)
-        return (torch.stack(errs) * self._weights(rows)).sum() / idx
+        return (torch.stack(errs) * self._weights(lambda m: [m[:, i] * m[:, j] / float((m[:, i] * m[:, j]).sum()) for i, j in pairs], mh)).sum() / idx
 
     def compute_latent_z_loss(self, zi_mean_list, zi_mean_list_new, mask, mask_host=None):       # :3384-3394
         mh = _host_mask(mask, mask_host)
@@ -1100,7 +1102,7 @@ class MultimodalModel(nn.Module):
             return torch.zeros((), device=self.device)
         z0 = torch.stack([zi_mean_list[i] for i in terms])                       # (T, B, Z)
         z1 = torch.stack([zi_mean_list_new[i] for i in terms])
-        w = self._weights([mh[:, i] / float(mh[:, i].sum()) for i in terms])      # (T, B)
+        w = self._weights(lambda m: [m[:, i] / float(m[:, i].sum()) for i in terms], mh)      # (T, B)
         return (torch.abs(z0 - z1).sum(2) * w).sum() / len(terms)
 
     def compute_cosine(self, x, y):                                                              # :3407-3415
@@ -1118,36 +1120,62 @@ class MultimodalModel(nn.Module):
         loss = torch.zeros((), device=self.device)
         if len(si_list) == 1:
             return loss
-        if len(si_list) == 2:
-            i, j = 0, 1
+        M = len(si_list)
+        st = {}
+
+        def draw():                                    # host RNG, :3485 (a graph replay draws again)
+            if M == 2:
+                st['ij'] = (0, 1)
+            else:
+                sel = np.random.choice(M, 2, replace=False)
+                st['ij'] = (int(sel[0]), int(sel[1]))
+            return torch.tensor(st['ij'], dtype=torch.long)
+
+        def weights():                                 # mask_i * mask_j * roll(mask_i) / count of the drawn pair, from the host mask
+            cur = ops.step_mask_host()
+            m = mh if cur is None else cur
+            i, j = st['ij']
+            mm_h = m[:, i] * m[:, j] * np.concatenate([m[1:, i], m[0:1, i]], 0)
+            return torch.from_numpy((mm_h / float(mm_h.sum())).astype(np.float32))
+        if ops.recording_host_values():
+            # the drawn pair is DATA of the recorded step: pool every map, pick rows i, j on the device (trainer.GraphedTrainStep only records
+            # steps whose mask leaves no (i, j) term empty, so the branch below is the same for every pair)
+            sel = ops.host_value(draw, self.device)
+            C = torch.stack([self.compute_compact_s(s) for s in si_list])         # (M, B, D)
+            si_c, sj_c = C.index_select(0, sel[0:1])[0], C.index_select(0, sel[1:2])[0]
         else:
-            sel = np.random.choice(len(si_list), 2, replace=False)                               # host RNG, :3485
-            i, j = int(sel[0]), int(sel[1])
-        mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
-        mm_h = mh[:, i] * mh[:, j] * mperm_h
-        if mm_h.sum() > 0:
-            mm = mask[:, i] * mask[:, j] * torch.cat([mask[1:, i], mask[0:1, i]], 0)
+            draw()
+            i, j = st['ij']
+            mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
+            if (mh[:, i] * mh[:, j] * mperm_h).sum() <= 0:
+                return loss                                                                      # reference returns int 0 (:3512)
             si_c = self.compute_compact_s(si_list[i])
             sj_c = self.compute_compact_s(si_list[j])
-            # compact(roll(s_i)) == roll(compact(s_i)): pooling is per-sample
-            si_perm_c = torch.cat([si_c[1:], si_c[0:1]], 0)
-            sim = self.compute_cosine(si_c, sj_c)
-            sim_mix = self.compute_cosine(si_perm_c, si_c)
-            return (mm * torch.clamp_min(margin - sim + sim_mix, 0)).sum() / float(mm_h.sum())
-        return loss                                                                              # reference returns int 0 (:3512)
+        # compact(roll(s_i)) == roll(compact(s_i)): pooling is per-sample
+        si_perm_c = torch.cat([si_c[1:], si_c[0:1]], 0)
+        sim = self.compute_cosine(si_c, sj_c)
+        sim_mix = self.compute_cosine(si_perm_c, si_c)
+        return (ops.host_value(weights, self.device) * torch.clamp_min(margin - sim + sim_mix, 0)).sum()
 
     def compute_similarity_z_loss(self, zi_list, mask, margin=0.1, mask_host=None):              # :3537-3557
         mh = _host_mask(mask, mask_host)
         if len(zi_list) == 1:
             return torch.zeros((), device=self.device)
-        I, J, rows = [], [], []
+        I, J = [], []
         for i in range(len(zi_list) - 1):
             mperm_h = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
             for j in range(i + 1, len(zi_list)):
                 mm_h = mh[:, i] * mh[:, j] * mperm_h
                 if mm_h.sum() == 0:
                     continue
-                I.append(i); J.append(j); rows.append(mm_h / float(mm_h.sum()))
+                I.append(i); J.append(j)
+
+        def rows_of(m):
+            out = []
+            for i, j in zip(I, J):
+                mm = m[:, i] * m[:, j] * np.concatenate([m[1:, i], m[0:1, i]], 0)
+                out.append(mm / float(mm.sum()))
+            return out
         if not I:
             return torch.zeros((), device=self.device)
         Z = torch.stack(list(zi_list))                                            # (M, B, Z)
@@ -1160,33 +1188,59 @@ class MultimodalModel(nn.Module):
             yn = torch.sqrt(torch.sum(y * y, 2) + 1e-8).clamp_min(1e-8)
             return torch.sum(x * y, 2) / (xn * yn)
         hinge = torch.clamp_min(margin - cos(zi, zp) + cos(zi, zj), 0)             # (P, B)
-        return (hinge * self._weights(rows)).sum() / len(I)
+        return (hinge * self._weights(rows_of, mh)).sum() / len(I)
 
     def compute_adversarial_loss(self, si_list, mask, mask_host=None):                           # :3559-3587
         mh = _host_mask(mask, mask_host)
-        if len(si_list) == 2:
-            i, j = 0, 1
+        M = len(si_list)
+        st = {}
+
+        def draw():
+            if M == 2:
+                st['ij'] = (0, 1)
+            else:
+                sel = np.random.choice(M, 2, replace=False)
+                st['ij'] = (int(sel[0]), int(sel[1]))
+            return torch.tensor(st['ij'], dtype=torch.long)
+
+        def col_weights(k):                            # mask[:, i or j] / its count, from the host mask (zeros for an empty column: the term vanishes)
+            def make():
+                cur = ops.step_mask_host()
+                m = mh if cur is None else cur
+                c = m[:, st['ij'][k]]
+                n = float(c.sum())
+                return torch.from_numpy((c / n if n > 0 else 0.0 * c).astype(np.float32))
+            return make
+        if ops.recording_host_values():
+            # the pair as data of the recorded step: the selected anatomy maps are gathered on the device (NHWC rows of the stacked maps)
+            sel = ops.host_value(draw, self.device)
+            S = torch.stack([s.permute(0, 2, 3, 1) for s in si_list])                 # (M, B, H, W, C) dense
+            s_i = S.index_select(0, sel[0:1])[0].permute(0, 3, 1, 2)
+            s_j = S.index_select(0, sel[1:2])[0].permute(0, 3, 1, 2)
         else:
-            sel = np.random.choice(len(si_list), 2, replace=False)
-            i, j = int(sel[0]), int(sel[1])
-        d0 = self.discrim_s(si_list[i]).squeeze(1)
-        d1 = self.discrim_s(si_list[j]).squeeze(1)
+            draw()
+            s_i, s_j = si_list[st['ij'][0]], si_list[st['ij'][1]]
+        i, j = st['ij']
+        d0 = self.discrim_s(s_i).squeeze(1)
+        d1 = self.discrim_s(s_j).squeeze(1)
         bce = lambda d, tgt: F.binary_cross_entropy_with_logits(d, tgt, reduction='none')
         zero = torch.zeros((), device=self.device)
 
-        def wmean(m, mhc, v):
-            m = m.reshape((-1,) + (1,) * (v.dim() - 1)) if v.dim() > 1 else m
-            return (m * v).sum() / float(mhc.sum())
-        if mh[:, i].sum() == 0:
+        def wsum(w, v):
+            w = w.reshape((-1,) + (1,) * (v.dim() - 1)) if v.dim() > 1 else w
+            return (w * v).sum()
+        if mh[:, i].sum() == 0 and not ops.recording_host_values():
             dl0 = gl0 = zero
         else:
-            dl0 = wmean(mask[:, i], mh[:, i], bce(d0, torch.zeros_like(d0)))
-            gl0 = wmean(mask[:, i], mh[:, i], bce(d0, torch.ones_like(d0)))
-        if mh[:, j].sum() == 0:
+            w0 = ops.host_value(col_weights(0), self.device)
+            dl0 = wsum(w0, bce(d0, torch.zeros_like(d0)))
+            gl0 = wsum(w0, bce(d0, torch.ones_like(d0)))
+        if mh[:, j].sum() == 0 and not ops.recording_host_values():
             dl1 = gl1 = zero
         else:
-            dl1 = wmean(mask[:, j], mh[:, j], bce(d1, torch.ones_like(d1)))
-            gl1 = wmean(mask[:, j], mh[:, j], bce(d1, torch.ones_like(d1)))                      # QUIRK (sic) :3580
+            w1 = ops.host_value(col_weights(1), self.device)
+            dl1 = wsum(w1, bce(d1, torch.ones_like(d1)))
+            gl1 = wsum(w1, bce(d1, torch.ones_like(d1)))                                          # QUIRK (sic) :3580
         return 0.5 * (dl0 + dl1), 0.5 * (gl0 + gl1)
 
 

@@ -5,6 +5,7 @@ libmrdis_hip.so (include/mrdis.h); there is no arithmetic here.  Tensors stay
 logically NCHW (reference interface) and physically NHWC (channels_last).
 """
 import contextlib
+import numpy as _np
 import os as _os
 
 import torch
@@ -1389,14 +1390,135 @@ def to_device(t_cpu, device):
     queued on the stream (62 ms per step were spent in three such copies); a pinned source is stream-ordered, but the runtime still
     waits on the host for the preceding kernel before it programs the copy engine: ~0.5 ms of GPU idle time per transfer, ten
     transfers per step (the CPU-drawn eps of `sample`, loss weights, index lists).  Small tensors therefore go through a ring of
-    pinned slots that a copy KERNEL reads (hip.to_device_small); anything else through the pinned-memory cache."""
+    pinned slots that a copy KERNEL reads (hip.to_device_small); anything else through the pinned-memory cache.
+    While a step is being recorded for graph replay (HostValues.recording) the tensor is a CONSTANT of the recorded step: it gets a slot
+    of the step's host-value block and is sent again, unchanged, with every replay."""
     if torch.device(device).type != 'cuda':
         return t_cpu.to(device)
+    if _HOST_VALUES is not None and _HOST_VALUES.recording:
+        return _HOST_VALUES.add(lambda: t_cpu, t_cpu)
     if _MAILBOX:
         out = hip.to_device_small(t_cpu, device)
         if out is not None:
             return out
     return t_cpu.pin_memory().to(device, non_blocking=True)
+
+
+# --------------------------------------------------------------------------- host-drawn values of a step (graph replay)
+# A training step consumes values that only the HOST can produce: eps of `sample` (the reference draws it from the CPU generator,
+# model.py:3159-3162), the (i, j) pair of sim_s / adv_s (np.random.choice, :3485), the loss weights derived from the batch's mask.
+# The model hands each of them over as a CLOSURE (host_value(fn, device)): an eager step calls it once and ships the result; a step
+# recorded into a HIP graph (trainer.GraphedTrainStep) keeps the closure, and every replay calls the closures again IN THE RECORDED
+# ORDER -- the global torch / numpy generators advance exactly as in the eager step -- packs the results into one pinned block and
+# ships the block with ONE copy kernel in front of the graph launch; the recorded kernels read their values from fixed device slots.
+_HOST_VALUES = None
+_STEP_MASK_HOST = None        # the (B, M) numpy mask of the step being built / replayed (closures read it through step_mask_host())
+
+
+def step_mask_host():
+    """the host mask closures must use: the replayed step's own mask while a recorded step refills its values, else None (= the mask the
+    eager caller passed)"""
+    return _STEP_MASK_HOST if _REPLAYING else None
+
+
+_REPLAYING = False
+
+
+def set_step_mask_host(mh):
+    global _STEP_MASK_HOST
+    _STEP_MASK_HOST = None if mh is None else _np.asarray(mh.numpy() if isinstance(mh, torch.Tensor) else mh, dtype=_np.float32)
+
+
+class HostValues:
+    """The host-value block of ONE recorded step: a device buffer with a 16-byte aligned slot per value, the closures that
+    produce the values, and a small ring of pinned staging blocks (a block is rewritten only after the event behind its last
+    copy kernel has completed, so the host may run several replays ahead of the GPU)."""
+    CAP = 1 << 18           # bytes
+    NRING = 4
+
+    def __init__(self, device):
+        self.device = device
+        self.dev = torch.zeros(self.CAP, dtype=torch.uint8, device=device)
+        self.ring = [torch.zeros(self.CAP, dtype=torch.uint8).pin_memory() for _ in range(self.NRING)]
+        self.events = [None] * self.NRING
+        self.k = 0
+        self.sources = []       # (fn, offset, nbytes, shape, dtype)
+        self.used = 0
+        self.recording = False
+        self.stage = None       # the pinned block being filled for the next launch
+
+    def _begin_fill(self):
+        k = self.k
+        self.k = (k + 1) % self.NRING
+        ev = self.events[k]
+        if ev is not None:
+            ev.synchronize()
+        self.stage = self.ring[k]
+        self._stage_k = k
+
+    def add(self, fn, value=None):
+        """recording: call fn (unless its value is given), give it a slot, return the device view the recorded kernels will read"""
+        t = fn() if value is None else value
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        off = self.used
+        if nbytes == 0 or off + nbytes > self.CAP:
+            raise RuntimeError(f'host-value block full ({off} + {nbytes} of {self.CAP} bytes)')
+        self.used = (off + nbytes + 15) // 16 * 16
+        self.sources.append((fn, off, nbytes, tuple(t.shape), t.dtype))
+        self.stage[off:off + nbytes].copy_(t.view(-1).view(torch.uint8))
+        return self.dev[off:off + nbytes].view(t.dtype).view(t.shape)
+
+    def start_recording(self):
+        self.sources, self.used = [], 0
+        self._begin_fill()
+        self.recording = True
+
+    def stop_recording(self):
+        self.recording = False
+
+    def refill(self):
+        """replay: call every closure again, in the recorded order, into a fresh pinned block"""
+        global _REPLAYING
+        self._begin_fill()
+        st = self.stage
+        _REPLAYING = True
+        try:
+            for fn, off, nbytes, shape, dtype in self.sources:
+                t = fn().contiguous()
+                if tuple(t.shape) != shape or t.dtype != dtype:
+                    raise RuntimeError(f'host value changed its shape between the recorded step and a replay: {tuple(t.shape)} {t.dtype} vs {shape} {dtype}')
+                st[off:off + nbytes].copy_(t.view(-1).view(torch.uint8))
+        finally:
+            _REPLAYING = False
+
+    def ship(self):
+        """one copy kernel: pinned block -> device slots, on the current stream (in front of the graph launch)"""
+        n = max(16, self.used)
+        hip.copy_bytes(self.stage, self.dev, n)
+        k = self._stage_k
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+
+
+def host_value(fn, device):
+    """fn() -> CPU tensor produced on the host for THIS step (a draw from the global generators, a function of step_mask_host()).
+    Eager: called once, shipped through the mailbox.  Recording for graph replay: kept, see HostValues."""
+    if _HOST_VALUES is not None and _HOST_VALUES.recording and torch.device(device).type == 'cuda':
+        return _HOST_VALUES.add(fn)
+    return to_device(fn(), device)
+
+
+def recording_host_values():
+    """a step is being recorded for graph replay: host draws that select tensors (sim_s / adv_s pairs) must become data"""
+    return _HOST_VALUES is not None and _HOST_VALUES.recording
+
+
+def set_host_values(hv):
+    global _HOST_VALUES
+    prev, _HOST_VALUES = _HOST_VALUES, hv
+    return prev
 
 
 _MAILBOX = _os.environ.get('MRDIS_MAILBOX', '1') != '0'

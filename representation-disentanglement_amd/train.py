@@ -38,7 +38,7 @@ import torch.distributed as dist
 import yaml
 
 from .data import BatchLoader, SliceDataset, VolumeStore, load_idx_list
-from .trainer import (DEFAULT_CONFIG, LOSS_KEYS, EvalStep, TrainStep, build_model, derive_config, load_checkpoint_model,
+from .trainer import (DEFAULT_CONFIG, LOSS_KEYS, EvalStep, TrainStep, make_train_step, build_model, derive_config, load_checkpoint_model,
                       load_config_yaml, save_checkpoint)
 
 SEED = 10                                                                   # main_missing.py:18
@@ -280,7 +280,7 @@ class Run:
                          self.model.input_decoder_list):
                 for p in part.parameters():
                     p.requires_grad = False
-        self.step = TrainStep(self.model, config, force_exchange=force_exchange)    # joins the default process group when there is one
+        self.step = make_train_step(self.model, config, force_exchange=force_exchange)    # joins the default process group when there is one; `graph: true` / MRDIS_GRAPH=1: HIP-graph replays
         self.eval_step = EvalStep(self.model, config)
         self.optimizer, self.optimizer_d_s = self.step.optimizer, self.step.optimizer_d_s
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min', factor=0.1, patience=5, min_lr=1e-5)   # :119

@@ -35,6 +35,7 @@ DEFAULT_CONFIG = {
     'ckpt_name': 'model_best.pth.tar', 'ckpt_timelabel': None,
     # keys added by this implementation (defaults reproduce the reference)
     'backend': 'hip', 'is_patch_gan': False,
+    'graph': None,                     # true: steady-state iterations as HIP-graph replays (trainer.GraphedTrainStep); None: MRDIS_GRAPH decides (default off)
     'compute_dtype': 'f32',            # BASELINE configs[2]: 'bf16' = bf16 activations + bf16 MFMA operands + fp32 accumulate; 'bf16m' = bf16 MFMA operands only
 }
 
@@ -679,28 +680,47 @@ class TrainStep:
     def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None, it=None):
         """`it`: the loader index of this batch inside its epoch -- the reference steps on (it + 1) % accum == 0 with `it`
         restarting every epoch (:155, :282), a pending accumulation carries over; None = count iterations here."""
-        cfg, model, opt = self.config, self.model, self.optimizer
-        adv = cfg['lambda_adv_s'] > 0
         if mask_host is None:
             mask_host = mask.cpu()
+        do_step = self._advance(it)
+        loss, parts, aux, scale = self._forward_backward(inputs, mask, mask_img, mask_host, targets, do_step)
+        self._apply(scale, do_step)
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
+
+    def _advance(self, it):
         self.iter = self.iter + 1 if it is None else it + 1
-        do_step = (self.iter % self.accum) == 0                                                  # :282
+        return (self.iter % self.accum) == 0                                                     # :282
+
+    def _forward_backward(self, inputs, mask, mask_img, mask_host, targets, do_step, exchange=True):
+        """forward, losses, backward pass(es) into the optimizers' gradient buffers (:165-271).  exchange = False: no data-parallel
+        exchange here (GraphedTrainStep reduces the arenas itself between its two graphs); returns the scale the optimizers apply."""
+        cfg, model, opt = self.config, self.model, self.optimizer
+        adv = cfg['lambda_adv_s'] > 0
         with ops.mix_cache():
             loss, parts, aux = forward_losses(model, cfg, inputs, mask, mask_img, mask_host, targets=targets)
             if opt.used is not None and opt.n_flags:
-                opt.mark_active(ops.to_device(torch.from_numpy(model.active_decoders(mask_host)), mask.device))
-            scale = self._backward(loss, opt, retain_graph=adv and do_step)                      # :268-271
+                def active():
+                    cur = ops.step_mask_host()
+                    return torch.from_numpy(model.active_decoders(mask_host if cur is None else cur))
+                opt.mark_active(ops.host_value(active, mask.device))
+            scale = self._backward(loss, opt, retain_graph=adv and do_step, exchange=exchange)    # :268-271
             if adv and do_step:
                 # discriminator-loss gradients on the same (un-stepped) graph, into optimizer_d_s' own buffer
                 od = self.optimizer_d_s
                 od.attach_grads()
                 try:
-                    self._backward(parts['adv_s_d'], od)
+                    self._backward(parts['adv_s_d'], od, exchange=exchange)
                 finally:
                     opt.attach_grads()
         if opt.used is None:
             opt._build()
         opt.check_new_grads()
+        return loss, parts, aux, scale
+
+    def _apply(self, scale, do_step):
+        """clip, Adam step(s), zero the gradient buffers (:272-289)."""
+        cfg, opt = self.config, self.optimizer
+        adv = cfg['lambda_adv_s'] > 0
         if self.accum == 1:
             opt.step(fused_clip=True, grad_scale=scale, use_gates=True)                          # :272 + :283
             self.last_grad_norm_sq = opt.norm_finite
@@ -722,13 +742,12 @@ class TrainStep:
             od.step(fused_clip=False, grad_scale=scale)                                          # :287-289 (no clip on the d-step)
             od.zero_grad()
         flush_batch_counters()                                                                   # BatchNorm2d.num_batches_tracked of this step's calls, one launch
-        return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
 
-    def _backward(self, loss, target, retain_graph=False):
+    def _backward(self, loss, target, retain_graph=False, exchange=True):
         """backward() with the gradient exchange armed around it; returns the scale the optimizer applies (1 / world).  A
         backward that raises leaves the reducer disarmed and its mid-backward hook removed."""
         red = self.reducer
-        if red is None:
+        if red is None or not exchange:
             loss.backward(retain_graph=retain_graph)
             return 1.0
         red.begin(target)
@@ -743,6 +762,155 @@ class TrainStep:
         """the 11 scalars of main_missing.py:253-263 in one D2H copy."""
         vec = torch.stack([parts[k].float().reshape(()) for k in LOSS_KEYS]).cpu()
         return {k: float(vec[i]) for i, k in enumerate(LOSS_KEYS)}
+
+
+def regular_mask(mask_host):
+    """True when no loss term of main_missing.py:165-251 is pruned for this batch mask whichever (i, j) pair sim_s / adv_s draw: every
+    modality present, every pair of modalities shares a sample, every (i, j) has a sample b with mask[b, i] mask[b, j] mask[b + 1, i] -- then
+    the kernel sequence of the step does not depend on the mask's VALUES and a recorded step can be replayed for it."""
+    mh = np.asarray(mask_host.numpy() if isinstance(mask_host, torch.Tensor) else mask_host, dtype=np.float32)
+    M = mh.shape[1]
+    if (mh.sum(0) == 0).any():
+        return False
+    for i in range(M):
+        roll = np.concatenate([mh[1:, i], mh[0:1, i]], 0)
+        for j in range(M):
+            if i != j and ((mh[:, i] * mh[:, j]).sum() == 0 or (mh[:, i] * mh[:, j] * roll).sum() == 0):
+                return False
+    return True
+
+
+class GraphedTrainStep:
+    """TrainStep whose steady-state iterations are HIP-graph replays (config key `graph: true`, MRDIS_GRAPH=1, bench.py --graph).
+
+    The library neither allocates nor synchronises and every host-produced value of a step (eps, the sim_s / adv_s pairs, the loss
+    weights of the batch's mask, the decoder gate flags) reaches the device through ops.host_value closures, so one iteration --
+    forward, losses, backward pass(es), clip, Adam, counters (main_missing.py:165-289) -- is recorded ONCE per configuration
+    (step / accumulate phase, learning rates, shapes) after `WARM` eager iterations on the capture stream, and replayed thereafter:
+    per step the host re-draws the closures in the recorded order (the global torch / numpy generators advance exactly as in the
+    eager step, host draws model.py:3159-3162, 3485), ships them with one copy kernel, copies the batch into the static input
+    buffers and launches the graph -- ~1.5 ms of host time instead of 45-70.  A batch whose mask would prune a loss term
+    (regular_mask() false: a modality absent from the whole batch ...) runs as an eager step, as does everything before the
+    recording.  Results are bit-identical to the eager TrainStep (tests/test_gpu_graph.py).
+
+    Data parallel (world > 1): two graphs -- forward + backward(s) | clip + Adam -- with the gradient arenas all-reduced eagerly in
+    between (one collective per arena; the bucketed overlap of the eager path is given up for a host-free step: the exchange is
+    ~1 % of the step).  Returned tensors (loss, parts, aux) are static buffers of the graph: valid until the next call."""
+    WARM = 2
+
+    def __init__(self, step, warm=None):
+        self.step = step
+        self.warm = self.WARM if warm is None else int(warm)
+        self.entries, self.seen = {}, {}
+        self.stream = None
+        self.static = None
+        self.stats = {'replays': 0, 'captures': 0, 'eager': 0, 'eager_irregular_mask': 0}
+
+    def __getattr__(self, name):                 # optimizer, reducer, losses_to_host, last_grad_norm_sq, accum ... are the wrapped step's
+        return getattr(self.__dict__['step'], name)
+
+    def _static_inputs(self, inputs, mask, mask_img, targets):
+        st = self.static
+        if st is None or st[0].shape != inputs.shape or st[0].dtype != inputs.dtype or (targets is None) != (st[3] is None):
+            st = self.static = [torch.empty_like(inputs), torch.empty_like(mask), torch.empty_like(mask_img),
+                                None if targets is None else torch.empty_like(targets)]
+            self.entries.clear(); self.seen.clear()
+        for dst, src in zip(st, (inputs, mask, mask_img, targets)):
+            if src is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        return st
+
+    def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None, it=None):
+        ts = self.step
+        if mask_host is None:
+            mask_host = mask.cpu()
+        if not inputs.is_cuda:
+            return ts(inputs, mask, mask_img, mask_host, targets, it)
+        if not regular_mask(mask_host):
+            self.stats['eager'] += 1; self.stats['eager_irregular_mask'] += 1
+            return ts(inputs, mask, mask_img, mask_host, targets, it)
+        do_step = ts._advance(it)
+        opt, od = ts.optimizer, ts.optimizer_d_s
+        key = (bool(do_step), tuple(inputs.shape), inputs.dtype, targets is not None, float(opt.lr), None if od is None else float(od.lr), ops.compute_dtype())
+        x, m, mi, tg = self._static_inputs(inputs, mask, mask_img, targets)
+        ent = self.entries.get(key)
+        if ent is None:
+            for k in [k for k in self.entries if k[:4] == key[:4] and k != key]:      # a scheduler moved the learning rate: the old recording is dead
+                del self.entries[k]
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            if n < self.warm:                    # eager, on the capture stream: workspaces, plans and caches reach their final size there
+                self.stats['eager'] += 1
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    loss, parts, aux, scale = ts._forward_backward(x, m, mi, mask_host, tg, do_step)
+                    ts._apply(scale, do_step)
+                torch.cuda.current_stream().wait_stream(self.stream)
+                return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
+            ent = self.entries[key] = self._record(x, m, mi, mask_host, tg, do_step)
+            self.stats['captures'] += 1
+        else:
+            ops.set_step_mask_host(mask_host)
+            ent['hv'].refill()
+            self.stats['replays'] += 1
+        self._launch(ent, do_step)
+        return ent['out']
+
+    def _exchanging(self):
+        red = self.step.reducer
+        return red is not None and red.exchanging
+
+    def _record(self, x, m, mi, mask_host, tg, do_step):
+        ts = self.step
+        dev = x.device
+        split = self._exchanging()
+        hv = ops.HostValues(dev)
+        prev = ops.set_host_values(hv)
+        ops.set_step_mask_host(mask_host)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), None
+        try:
+            hv.start_recording()
+            with torch.cuda.graph(g1, stream=self.stream, capture_error_mode='thread_local'):
+                loss, parts, aux, _ = ts._forward_backward(x, m, mi, mask_host, tg, do_step, exchange=False)
+                if not split:
+                    ts._apply(1.0, do_step)
+                out = (loss.detach(), {k: v.detach() for k, v in parts.items()}, aux)
+            hv.stop_recording()
+            if split:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=self.stream, capture_error_mode='thread_local'):
+                    ts._apply(1.0 / ts.reducer.world, do_step)
+        finally:
+            hv.stop_recording()
+            ops.set_host_values(prev)
+        return {'g1': g1, 'g2': g2, 'hv': hv, 'out': out}
+
+    def _launch(self, ent, do_step):
+        ts = self.step
+        ent['hv'].ship()
+        ent['g1'].replay()
+        if ent['g2'] is not None:
+            red = ts.reducer
+            dist.all_reduce(ts.optimizer._g_full, op=dist.ReduceOp.SUM, group=red.group)
+            if ts.optimizer_d_s is not None and do_step:
+                dist.all_reduce(ts.optimizer_d_s._g_full, op=dist.ReduceOp.SUM, group=red.group)
+            ent['g2'].replay()
+        if ts.accum == 1 or do_step:
+            ts.optimizer.step_count += 1
+            if ts.optimizer_d_s is not None and do_step:
+                ts.optimizer_d_s.step_count += 1
+
+
+def make_train_step(model, config, **kw):
+    """TrainStep, wrapped for graph replay when the configuration (`graph: true`) or the environment (MRDIS_GRAPH=1) asks for it."""
+    step = TrainStep(model, config, **kw)
+    want = config.get('graph', None)
+    if want is None:
+        want = os.environ.get('MRDIS_GRAPH', '0') not in ('', '0')
+    return GraphedTrainStep(step) if want else step
 
 
 class EvalStep:
