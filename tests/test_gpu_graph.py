@@ -13,16 +13,17 @@ DEV = torch.device('cuda:0')
 
 def _batches(mrdis, n, B, M, H, W):
     out = []
-    seed = 40
-    while len(out) < n:
+    for seed in range(40, 400):                          # (B = 8, M = 4: about half of the drop-off masks leave every loss term in place)
+        if len(out) == n:
+            break
         x, mask, mask_img = mrdis.synthetic_batch(B, M, H, W, seed=seed, drop=True)
-        seed += 1
         if mrdis.regular_mask(mask):                     # (a batch whose mask prunes a loss term is an eager step: tested separately)
             out.append((x.to(DEV).contiguous(memory_format=torch.channels_last), mask, mask_img.to(DEV)))
+    assert len(out) == n
     return out
 
 
-def _run(mrdis, graph, steps, batch_size, B, M=3, H=64, W=96, dtype='f32', force=False, warm=None):
+def _run(mrdis, graph, steps, batch_size, B, M=4, H=64, W=96, dtype='f32', force=False, warm=None):
     cfg = dict(mrdis.DEFAULT_CONFIG)
     cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=batch_size, lambda_adv_s=1.0, compute_dtype=dtype)
     cfg = mrdis.derive_config(cfg, DEV)
@@ -47,7 +48,7 @@ def _run(mrdis, graph, steps, batch_size, B, M=3, H=64, W=96, dtype='f32', force
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('case', [(8, 16, 4, 'f32'), (12, 8, 8, 'f32'), (8, 16, 4, 'bf16')], ids=str)
+@pytest.mark.parametrize('case', [(8, 16, 8, 'f32'), (12, 8, 8, 'f32'), (8, 16, 8, 'bf16')], ids=str)
 def test_graph_replay_is_bit_identical_to_the_eager_step(mrdis, case):
     """(steps, config.batch_size, B, dtype): accum = 1 | the reference's default schedule (accum = 2: two recordings, accumulate / step) | bf16 storage"""
     steps, bs, B, dtype = case
@@ -65,7 +66,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(mrdis, case):
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_irregular_mask_runs_eagerly_and_lr_change_records_again(mrdis):
-    B, M, H, W = 4, 3, 64, 96
+    B, M, H, W = 8, 4, 64, 96
     cfg = dict(mrdis.DEFAULT_CONFIG)
     cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=H, input_width=W, batch_size=16, lambda_adv_s=1.0)
     cfg = mrdis.derive_config(cfg, DEV)
