@@ -1123,9 +1123,12 @@ class MultimodalModel(nn.Module):
         M = len(si_list)
         st = {}
 
-        def draw():                                    # host RNG, :3485 (a graph replay draws again)
+        def draw():                                    # host RNG, :3485 (a graph replay draws again, or is handed the caller's draw)
+            fp = ops.forced_pair('sim_s')
             if M == 2:
                 st['ij'] = (0, 1)
+            elif fp is not None:
+                st['ij'] = fp
             else:
                 sel = np.random.choice(M, 2, replace=False)
                 st['ij'] = (int(sel[0]), int(sel[1]))
@@ -1196,8 +1199,11 @@ class MultimodalModel(nn.Module):
         st = {}
 
         def draw():
+            fp = ops.forced_pair('adv_s')
             if M == 2:
                 st['ij'] = (0, 1)
+            elif fp is not None:
+                st['ij'] = fp
             else:
                 sel = np.random.choice(M, 2, replace=False)
                 st['ij'] = (int(sel[0]), int(sel[1]))
@@ -1211,15 +1217,10 @@ class MultimodalModel(nn.Module):
                 n = float(c.sum())
                 return torch.from_numpy((c / n if n > 0 else 0.0 * c).astype(np.float32))
             return make
-        if ops.recording_host_values():
-            # the pair as data of the recorded step: the selected anatomy maps are gathered on the device (NHWC rows of the stacked maps)
-            sel = ops.host_value(draw, self.device)
-            S = torch.stack([s.permute(0, 2, 3, 1) for s in si_list])                 # (M, B, H, W, C) dense
-            s_i = S.index_select(0, sel[0:1])[0].permute(0, 3, 1, 2)
-            s_j = S.index_select(0, sel[1:2])[0].permute(0, 3, 1, 2)
-        else:
-            draw()
-            s_i, s_j = si_list[st['ij'][0]], si_list[st['ij'][1]]
+        # (a step recorded for graph replay is recorded PER adv_s pair -- trainer.GraphedTrainStep hands the pair in: selecting the two maps on the
+        # device instead would send zero gradients through the anatomy network of the other modalities in the discriminator-loss backward, +5 % per step)
+        draw()
+        s_i, s_j = si_list[st['ij'][0]], si_list[st['ij'][1]]
         i, j = st['ij']
         d0 = self.discrim_s(s_i).squeeze(1)
         d1 = self.discrim_s(s_j).squeeze(1)

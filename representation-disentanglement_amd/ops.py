@@ -1510,6 +1510,20 @@ def host_value(fn, device):
     return to_device(fn(), device)
 
 
+_FORCED_PAIRS = None
+
+
+def set_forced_pairs(pairs):
+    """{'sim_s': (i, j), 'adv_s': (i, j)} drawn by the caller (trainer.GraphedTrainStep draws them from np.random in the model's own order
+    BEFORE the step, because the adv_s pair selects which recorded graph replays) or None: the model draws for itself (model.py:3485)."""
+    global _FORCED_PAIRS
+    _FORCED_PAIRS = pairs
+
+
+def forced_pair(kind):
+    return None if _FORCED_PAIRS is None else _FORCED_PAIRS.get(kind)
+
+
 def recording_host_values():
     """a step is being recorded for graph replay: host draws that select tensors (sim_s / adv_s pairs) must become data"""
     return _HOST_VALUES is not None and _HOST_VALUES.recording

@@ -789,9 +789,12 @@ class GraphedTrainStep:
     (step / accumulate phase, learning rates, shapes) after `WARM` eager iterations on the capture stream, and replayed thereafter:
     per step the host re-draws the closures in the recorded order (the global torch / numpy generators advance exactly as in the
     eager step, host draws model.py:3159-3162, 3485), ships them with one copy kernel, copies the batch into the static input
-    buffers and launches the graph -- ~1.5 ms of host time instead of 45-70.  A batch whose mask would prune a loss term
-    (regular_mask() false: a modality absent from the whole batch ...) runs as an eager step, as does everything before the
-    recording.  Results are bit-identical to the eager TrainStep (tests/test_gpu_graph.py).
+    buffers and launches the graph -- ~1.5 ms of host time instead of 45-70.  The adv_s pair picks two anatomy maps, i.e. which
+    kernels run: it is drawn here, before the launch, and there is one recording per ordered pair (12 for M = 4, all made at the
+    first recording, in one memory pool); the sim_s pair is data of the graph (every map is pooled, rows i, j picked on the device).
+    A batch whose mask would prune a loss term (regular_mask() false: a modality absent from the whole batch ...) runs as an
+    eager step, as does everything before the recording.  Results are bit-identical to the eager TrainStep
+    (tests/test_gpu_graph.py); the third return value (aux: the step's activations) is None on replayed steps.
 
     Data parallel (world > 1): two graphs -- forward + backward(s) | clip + Adam -- with the gradient arenas all-reduced eagerly in
     between (one collective per arena; the bucketed overlap of the eager path is given up for a host-free step: the exchange is
@@ -820,12 +823,34 @@ class GraphedTrainStep:
                 dst.copy_(src, non_blocking=True)
         return st
 
+    def _predraw(self):
+        """the step's two np.random draws (sim_s pair, then adv_s pair: model.py:3485, 3563), made here in the model's own order: the adv_s pair
+        selects WHICH recorded graph replays, so it must be known before the launch.  The model then uses these instead of drawing."""
+        cfg = self.step.config
+        M = len(cfg['contrast_list'])
+        pairs = {}
+        if M > 2:
+            if cfg['lambda_sim_s'] > 0:
+                sel = np.random.choice(M, 2, replace=False); pairs['sim_s'] = (int(sel[0]), int(sel[1]))
+            if cfg['lambda_adv_s'] > 0:
+                sel = np.random.choice(M, 2, replace=False); pairs['adv_s'] = (int(sel[0]), int(sel[1]))
+        return pairs
+
     def __call__(self, inputs, mask, mask_img, mask_host=None, targets=None, it=None):
         ts = self.step
         if mask_host is None:
             mask_host = mask.cpu()
         if not inputs.is_cuda:
             return ts(inputs, mask, mask_img, mask_host, targets, it)
+        pairs = self._predraw()
+        ops.set_forced_pairs(pairs)
+        try:
+            return self._call(inputs, mask, mask_img, mask_host, targets, it, pairs)
+        finally:
+            ops.set_forced_pairs(None)
+
+    def _call(self, inputs, mask, mask_img, mask_host, targets, it, pairs):
+        ts = self.step
         if not regular_mask(mask_host):
             self.stats['eager'] += 1; self.stats['eager_irregular_mask'] += 1
             return ts(inputs, mask, mask_img, mask_host, targets, it)
@@ -833,9 +858,9 @@ class GraphedTrainStep:
         opt, od = ts.optimizer, ts.optimizer_d_s
         key = (bool(do_step), tuple(inputs.shape), inputs.dtype, targets is not None, float(opt.lr), None if od is None else float(od.lr), ops.compute_dtype())
         x, m, mi, tg = self._static_inputs(inputs, mask, mask_img, targets)
-        ent = self.entries.get(key)
-        if ent is None:
-            for k in [k for k in self.entries if k[:4] == key[:4] and k != key]:      # a scheduler moved the learning rate: the old recording is dead
+        group = self.entries.get(key)
+        if group is None:
+            for k in [k for k in self.entries if k[:4] == key[:4] and k != key]:      # a scheduler moved the learning rate: the old recordings are dead
                 del self.entries[k]
             n = self.seen.get(key, 0)
             self.seen[key] = n + 1
@@ -849,12 +874,11 @@ class GraphedTrainStep:
                     ts._apply(scale, do_step)
                 torch.cuda.current_stream().wait_stream(self.stream)
                 return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
-            ent = self.entries[key] = self._record(x, m, mi, mask_host, tg, do_step)
-            self.stats['captures'] += 1
-        else:
-            ops.set_step_mask_host(mask_host)
-            ent['hv'].refill()
-            self.stats['replays'] += 1
+            group = self.entries[key] = self._record_all(x, m, mi, mask_host, tg, do_step, pairs)
+        ent = group[pairs.get('adv_s')]
+        ops.set_step_mask_host(mask_host)
+        ent['hv'].refill()                       # eps and the mask weights of THIS step (the closures draw from the global torch generator in the recorded order)
+        self.stats['replays'] += 1
         self._launch(ent, do_step)
         return ent['out']
 
@@ -862,7 +886,29 @@ class GraphedTrainStep:
         red = self.step.reducer
         return red is not None and red.exchanging
 
-    def _record(self, x, m, mi, mask_host, tg, do_step):
+    def _record_all(self, x, m, mi, mask_host, tg, do_step, pairs):
+        """one recording per adv_s pair (M (M - 1) ordered pairs; one when the model does not draw), all in ONE memory pool: replays never overlap and
+        a recording keeps nothing but its loss scalars alive, so the pool holds one step's activations.  Recording executes no kernel and, with the
+        generators restored afterwards, consumes no draw: the step itself then runs as the first replay."""
+        cfg = self.step.config
+        M = len(cfg['contrast_list'])
+        variants = [None]
+        if 'adv_s' in pairs:
+            variants = [(i, j) for i in range(M) for j in range(M) if i != j]
+        pool = torch.cuda.graph_pool_handle()
+        rng = (torch.get_rng_state(), np.random.get_state())
+        group = {}
+        try:
+            for v in variants:
+                ops.set_forced_pairs(dict(pairs, adv_s=v) if v is not None else pairs)
+                group[v] = self._record(x, m, mi, mask_host, tg, do_step, pool)
+                self.stats['captures'] += 1
+        finally:
+            ops.set_forced_pairs(pairs)
+            torch.set_rng_state(rng[0]); np.random.set_state(rng[1])
+        return group
+
+    def _record(self, x, m, mi, mask_host, tg, do_step, pool):
         ts = self.step
         dev = x.device
         split = self._exchanging()
@@ -873,15 +919,16 @@ class GraphedTrainStep:
         g1, g2 = torch.cuda.CUDAGraph(), None
         try:
             hv.start_recording()
-            with torch.cuda.graph(g1, stream=self.stream, capture_error_mode='thread_local'):
+            with torch.cuda.graph(g1, pool=pool, stream=self.stream, capture_error_mode='thread_local'):
                 loss, parts, aux, _ = ts._forward_backward(x, m, mi, mask_host, tg, do_step, exchange=False)
                 if not split:
                     ts._apply(1.0, do_step)
-                out = (loss.detach(), {k: v.detach() for k, v in parts.items()}, aux)
+                out = (loss.detach(), {k: v.detach() for k, v in parts.items()}, None)      # (aux would pin a step's activations per recording)
+                del loss, parts, aux
             hv.stop_recording()
             if split:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self.stream, capture_error_mode='thread_local'):
+                with torch.cuda.graph(g2, pool=pool, stream=self.stream, capture_error_mode='thread_local'):
                     ts._apply(1.0 / ts.reducer.world, do_step)
         finally:
             hv.stop_recording()

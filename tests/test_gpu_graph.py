@@ -55,8 +55,8 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(mrdis, case):
     ref_w, ref_b, ref_l, ref_p, _ = _run(mrdis, False, steps, bs, B, dtype=dtype)
     got_w, got_b, got_l, got_p, step = _run(mrdis, True, steps, bs, B, dtype=dtype)
     st = step.stats
-    nkeys = 1 if bs >= 16 else 2
-    assert st['captures'] == nkeys and st['eager'] == 2 * nkeys and st['replays'] == steps - 3 * nkeys, st
+    nkeys = 1 if bs >= 16 else 2                         # (one recording per ordered adv_s pair and configuration: 12 for M = 4)
+    assert st['captures'] == 12 * nkeys and st['eager'] == 2 * nkeys and st['replays'] == steps - 2 * nkeys, st
     assert got_l == ref_l, (got_l, ref_l)
     assert got_p == ref_p
     assert torch.equal(ref_w, got_w), float((ref_w - got_w).abs().max())
@@ -76,15 +76,15 @@ def test_irregular_mask_runs_eagerly_and_lr_change_records_again(mrdis):
     (x, mask, mask_img), = _batches(mrdis, 1, B, M, H, W)
     for _ in range(3):
         step(x, mask.to(DEV), mask_img, mask)
-    assert step.stats['captures'] == 1 and step.stats['replays'] == 1
+    assert step.stats['captures'] == 12 and step.stats['replays'] == 2
     hole = mask.clone(); hole[:, 1] = 0                   # modality 1 absent from the whole batch: recon / mix terms are pruned
     assert not mrdis.regular_mask(hole)
     step(x, hole.to(DEV), mask_img, hole)
-    assert step.stats['eager_irregular_mask'] == 1 and step.stats['captures'] == 1
+    assert step.stats['eager_irregular_mask'] == 1 and step.stats['captures'] == 12
     step.optimizer.param_groups[0]['lr'] *= 0.1           # ReduceLROnPlateau: the recorded Adam launch carries the old rate
     for _ in range(3):
         loss, _, _ = step(x, mask.to(DEV), mask_img, mask)
-    assert step.stats['captures'] == 2 and len(step.entries) == 1 and np.isfinite(float(loss))
+    assert step.stats['captures'] == 24 and len(step.entries) == 1 and np.isfinite(float(loss))
 
 
 def _free_port():
@@ -103,7 +103,7 @@ def test_graph_replay_with_the_exchange_between_two_graphs(mrdis):
     try:
         got_w, got_b, got_l, _, step = _run(mrdis, True, 6, 8, 8, force=True, warm=1)
         assert step.reducer is not None and step.reducer.exchanging
-        assert all(e['g2'] is not None for e in step.entries.values()) and step.stats['captures'] == 2
+        assert all(e['g2'] is not None for grp in step.entries.values() for e in grp.values()) and step.stats['captures'] == 24
         assert got_l == ref_l and torch.equal(ref_w, got_w) and torch.equal(ref_b, got_b)
     finally:
         dist.destroy_process_group()
