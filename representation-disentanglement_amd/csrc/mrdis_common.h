@@ -19,9 +19,11 @@ enum {
     MRDIS_OPT_WINO, MRDIS_OPT_NT_MB, MRDIS_OPT_WINO_PIPE, MRDIS_OPT_WINO_U, MRDIS_OPT_WINO4, MRDIS_OPT_WINO4R, MRDIS_OPT_BCONV4, MRDIS_OPT_SPLIT6,
     MRDIS_OPT_NO16, MRDIS_OPT_NOTHIN, MRDIS_OPT_NOC4, MRDIS_OPT_NODMA, MRDIS_OPT_NO16_3D, MRDIS_OPT_BILGEN, MRDIS_OPT_NOW16, MRDIS_OPT_NOPACK,
     MRDIS_OPT_MODE, MRDIS_OPT_BN, MRDIS_OPT_KC, MRDIS_OPT_BM, MRDIS_OPT_C4_TW, MRDIS_OPT_WGSPLIT, MRDIS_OPT_BN3, MRDIS_OPT_KC3,
+    MRDIS_OPT_C4_GRID, MRDIS_OPT_C4_BLOCKS,
     MRDIS_OPT_COUNT
 };
 long long mrdis_opt(int id);      // mrdis_elem.hip
+void mrdis_opt_note(int id, long long value);      // diagnostics a launcher leaves behind (read with mrdis_get_option)
 
 // Launch counters of the Winograd / bf16 / six-product (split6) kernel families (host side, one increment per launch): what a test asks to know which form actually ran
 // (mrdis_launch_count("wino4") ...; mrdis_elem.hip).

@@ -1314,8 +1314,10 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    long long cap = (long long)ncu * occ[oi] / ny; if (cap < ncu) cap = ncu;
+    const long long per_cu = mrdis_opt(MRDIS_OPT_C4_GRID) > 0 ? mrdis_opt(MRDIS_OPT_C4_GRID) : occ[oi];
+    long long cap = (long long)ncu * per_cu / ny; if (cap < ncu) cap = ncu;
     if (blocks > cap) blocks = cap;
+    mrdis_opt_note(MRDIS_OPT_C4_BLOCKS, blocks);
     const bool fast = (W % p.TW == 0) && (H % p.TH == 0);      // FULL: strips tile the image exactly
     const dim3 grid((int)blocks, ny);
 #define C4_LAUNCH(ns, lr, fa) MRDIS_LAUNCH((c4conv_kernel<ns, lr, fa>), grid, dim3(256), 0, s, p)

@@ -1939,6 +1939,8 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"debug_mode", "MRDIS_DEBUG_MODE", 0, -1}, {"debug_bn", "MRDIS_DEBUG_BN", 0, -1}, {"debug_kc", "MRDIS_DEBUG_KC", 0, -1},
     {"debug_bm", "MRDIS_DEBUG_BM", 0, -1}, {"debug_c4_tw", "MRDIS_DEBUG_C4_TW", 0, -1}, {"debug_wgsplit", "MRDIS_DEBUG_WGSPLIT", 0, -1},
     {"debug_bn3", "MRDIS_DEBUG_BN3", 0, -1}, {"debug_kc3", "MRDIS_DEBUG_KC3", 0, -1},
+    {"c4_grid", "MRDIS_C4_GRID", 0, 0},      // persistent grid of the Cin = 4 kernels (run_c4conv): 0 = workgroups per CU from the occupancy query of the launched instantiation | k > 0: k workgroups per CU
+    {"debug_c4_blocks", "MRDIS_DEBUG_C4_BLOCKS", 0, -1},      // read-only diagnostic: grid.x of the last run_c4conv launch
 };
 long long* opt_table() {
     static long long* table = [] {
@@ -1959,6 +1961,7 @@ int opt_index(const char* name) {
 }
 }  // namespace
 long long mrdis_opt(int id) { return opt_table()[id]; }
+void mrdis_opt_note(int id, long long value) { opt_table()[id] = value; }
 extern "C" int mrdis_set_option(const char* name, long long value) {
     const int i = opt_index(name);
     if (i < 0) return MRDIS_EINVAL;

@@ -140,7 +140,7 @@ def get_option(name):
 # every switch of csrc/mrdis_elem.hip OPT_DEFS (tests/test_abi.py checks that the library knows each name)
 OPTION_NAMES = ('wino', 'nt_mb', 'wino_pipe', 'wino_u', 'wino4', 'wino4r', 'bconv4', 'split6', 'debug_no16', 'debug_nothin', 'debug_noc4', 'debug_nodma',
                 'debug_no16_3d', 'debug_bilgen', 'debug_now16', 'debug_nopack', 'debug_mode', 'debug_bn', 'debug_kc', 'debug_bm', 'debug_c4_tw',
-                'debug_wgsplit', 'debug_bn3', 'debug_kc3')
+                'debug_wgsplit', 'debug_bn3', 'debug_kc3', 'c4_grid', 'debug_c4_blocks')
 
 
 def options_snapshot():
