@@ -1266,7 +1266,7 @@ template <bool LRELU, bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_split6_kernel(const C4Params p) { c4conv_body<1, LRELU, FULL, false, true>(p); }
 // the 32-cout bf16-output form on exact strips (the si_layers' forward at 256x256): left alone the allocator takes 95 + 48 registers,
 // one wave per SIMD fewer than the fp32 form's 88 + 32 -- and the kernel lives on waves in flight (72 vs 51 us).  Pinned to three waves per SIMD (round 5: the
-// two-term form needs 149 registers; run_c4conv sizes the persistent grid from THIS instantiation's occupancy).
+// two-term form needs 149 registers); the persistent grid stays at four workgroups per CU (run_c4conv: measured).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void c4conv_obf16_kernel(const C4Params p) { c4conv_body<1, false, true, true>(p); }
 
 static bool c4_eligible(const float* x, int ldx, int ldy, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int obytes = 4) {
@@ -1301,14 +1301,15 @@ static int run_c4conv(const float* x, int ldx, const float* w, const float* bias
     long long blocks = (p.ntiles + 3) / 4;
     // persistent grid: exactly the number of workgroups the chip holds at once (one wave of workgroups,
     // no tail round); residency is queried once per instantiation.
-    // (per instantiation: the six-product and bf16-output forms are pinned to three waves per SIMD, the fp32 form holds four workgroups per CU)
-    static int occ[4] = {0, 0, 0, 0}, ncu = 0;
-    const int oi = split6 ? 0 : (obf16 && NS == 1) ? 3 : NS;
+    // Grid policy, measured (tools/c4_grid_probe.py, round 6): FOUR workgroups per CU for every form.  The six-product and bf16-output forms are pinned to
+    // three waves per SIMD, so only three of the four are resident at a time -- sizing the grid by their own occupancy (768 workgroups) was slower: 59.6 vs
+    // 53.6 us at 256x256, 52.7 vs 51.8 us at 240x240 (the fourth workgroup of a CU starts as the first drains and evens out the tail).  Option c4_grid = k
+    // overrides the number per CU.
+    static int occ[3] = {0, 0, 0}, ncu = 0;
+    const int oi = NS;
     if (!occ[oi]) {
         int o = 0;
-        if (oi == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_split6_kernel<false, true>, 256, 0);
-        else if (oi == 3) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_obf16_kernel, 256, 0);
-        else if (NS == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
+        if (NS == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<2, false, true>, 256, 0);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, c4conv_kernel<1, false, true>, 256, 0);
         occ[oi] = o > 0 ? o : 2;
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);

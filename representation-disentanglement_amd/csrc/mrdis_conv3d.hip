@@ -22,23 +22,8 @@
 // input (one tap group per class; inside a class the input view is stride 1 with doubled pitches), so the staged
 // halo is the size of the position box instead of eight times it.
 #include "mrdis_common.h"
+#include "mrdis_conv3d.h"
 #include <stdlib.h>
-
-#define T3_TAPS 27
-#define T3_TAB_INTS 320   // tab_in[128] tab_out[128] tap_xoff[32] tap_widx[32]
-
-struct Conv3dParams {
-    const float* in; const float* w; const float* bias; const float* res; float* out;
-    int N, Din, Hin, Win, Cin, ldin;
-    int Dout, Hout, Wout, Cout, ldout, ldres;
-    int Z, A, B, os, od0, oh0, ow0, is;
-    int ntaps;
-    int dd[T3_TAPS], dh[T3_TAPS], dw[T3_TAPS], widx[T3_TAPS];
-    int dd_min, dh_min, dw_min;
-    int TD, TH, TW, TinD, TinH, TinW;
-    int tilesZ, tilesA, tilesB, coTiles;
-    int vec_in, vec_w;
-};
 
 template <int KC, int BN>
 __global__ __launch_bounds__(256) void tapconv3d_kernel(const Conv3dParams p) {
@@ -508,6 +493,10 @@ static int run_tapconv3d(Conv3dParams p, hipStream_t s) {
     { const int v = (int)mrdis_opt(MRDIS_OPT_BN3); if (v == 32 || v == 64) BN = v; }
     p.vec_in = (p.Cin % 4 == 0) && (p.ldin % 4 == 0) && (((uintptr_t)p.in & 15) == 0);
     p.vec_w = (p.Cout % 4 == 0) && (((uintptr_t)p.w & 15) == 0);
+    if (p.Cin == 16 && p.Cout == 16 && !mrdis_opt(MRDIS_OPT_NO16_3D)) {       // full-resolution BasicBlock layers: six bf16 products per fp32 product (mrdis_conv3d_s6.hip)
+        const int rc6 = mrdis_run_conv3d16_s6(p, ptiles, s);
+        if (rc6 != MRDIS_EUNSUPPORTED) return rc6;
+    }
     if (p.Cout <= 16 && p.Cin <= 32 && p.vec_in && ptiles <= 0x7fffffffLL && !mrdis_opt(MRDIS_OPT_NO16_3D)) {
         const int KC16 = p.Cin <= 4 ? 4 : (p.Cin <= 8 ? 8 : (p.Cin <= 16 ? 16 : 32));
         const long long npix = (long long)p.TinD * p.TinH * p.TinW;

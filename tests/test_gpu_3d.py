@@ -328,3 +328,36 @@ def test_nvnet3d_step_at_config4_size(mrdis):
     for n in g0:
         err = float((g1[n] - g0[n]).double().norm())
         assert err <= 2e-3 * float(g0[n].double().norm()) + 2e-5 * tot, (n, err)
+
+
+@pytest.mark.parametrize('N,D,H,W', [(2, 64, 64, 64), (4, 50, 44, 70), (1, 36, 128, 112)])
+def test_conv3d_16_to_16_six_product_kernel(mrdis, N, D, H, W):
+    """conv3d16_s6_kernel (mrdis_conv3d_s6.hip, option split6): the BasicBlock convolutions (16 -> 16, 3x3x3, stride 1: model.py:1861-1864) with both
+    fp32 operands as three bf16 terms and the six products of order <= 2 on v_mfma_f32_16x16x32_bf16 -- forward (+ bias, + fused residual) and data
+    gradient (flipped taps) against the fp32 MFMA kernel (split6 = 0) and a float64 reference: within 2e-6 of the fp32 kernel, at most 2x its error
+    against float64; exact boxes (64^3), ragged boxes in every direction, a volume that is one box deep in places.  The launch counter proves which ran."""
+    hip = mrdis.hip
+    x = seeded((N, 16, D, H, W), 1); w = seeded((16, 16, 3, 3, 3), 2, 0.1); b = seeded((16,), 3)
+    res = seeded((N, 16, D, H, W), 4); dy = seeded((N, 16, D, H, W), 5)
+    conv = mrdis.HipConv3d(16, 16, (3, 3, 3), padding=(1, 1, 1)).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+    out = {}
+    for s6 in (0, 1):
+        with hip.option('split6', s6):
+            hip.launch_counts(reset=True)
+            xg = cl3(x).requires_grad_(True)
+            y = conv(xg, residual=cl3(res))
+            y.backward(cl3(dy))
+            n6 = hip.launch_counts()['split6_c3d']
+            assert (n6 == 2) == (s6 == 1), (s6, n6)                  # forward + data gradient
+            out[s6] = (y.detach().cpu().double(), xg.grad.detach().cpu().double())
+            conv.zero_grad()
+    y64 = F.conv3d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    g64 = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=1)
+    for k, (name, ref) in enumerate((('fwd', y64), ('dgrad', g64))):
+        scale = float(ref.abs().max())
+        e0, e1 = float((out[0][k] - ref).abs().max()) / scale, float((out[1][k] - ref).abs().max()) / scale
+        d01 = float((out[0][k] - out[1][k]).abs().max()) / scale
+        assert d01 <= 2e-6, (name, 'six-product vs fp32 kernel', d01)
+        assert e1 <= max(2.0 * e0, 5e-7), (name, 'vs float64', e1, e0)
