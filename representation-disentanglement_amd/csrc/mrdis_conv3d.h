@@ -21,3 +21,6 @@ struct Conv3dParams {
 
 // mrdis_conv3d_s6.hip: 3x3x3 / stride 1, 16 -> 16 channels as six bf16 products per fp32 product (option split6); MRDIS_EUNSUPPORTED outside that
 int mrdis_run_conv3d16_s6(const Conv3dParams& p, long long ptiles_hint, hipStream_t s);
+// the same layers' weight (+ bias) gradient as slabs for wgrad3d16_reduce_kernel (CW = 16, nCi = nCo = 1)
+int mrdis_run_wgrad3d16_s6(const float* x, int ldx, const float* dy, int lddy, float* slab, size_t slab_bytes, int want_bias,
+                           int N, int D, int H, int W, int* splits_out, float** bias_slab_out, hipStream_t s);

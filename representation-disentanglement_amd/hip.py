@@ -155,7 +155,7 @@ def options_restore(snap):
 
 
 KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade',
-                                   'split6_c4', 'split6_c16', 'split6_wgrad16', 'split6_co4', 'split6_c3d',
+                                   'split6_c4', 'split6_c16', 'split6_wgrad16', 'split6_co4', 'split6_c3d', 'split6_w3d',
                                    'all')        # 'all': every kernel launch of the library (bench.py: library_launches_per_step)
 
 
