@@ -23,4 +23,4 @@ struct Conv3dParams {
 int mrdis_run_conv3d16_s6(const Conv3dParams& p, long long ptiles_hint, hipStream_t s);
 // the same layers' weight (+ bias) gradient as slabs for wgrad3d16_reduce_kernel (CW = 16, nCi = nCo = 1)
 int mrdis_run_wgrad3d16_s6(const float* x, int ldx, const float* dy, int lddy, float* slab, size_t slab_bytes, int want_bias,
-                           int N, int D, int H, int W, int* splits_out, float** bias_slab_out, hipStream_t s);
+                           int N, int D, int H, int W, int Ci, int Co, int* splits_out, float** bias_slab_out, hipStream_t s);

@@ -1262,15 +1262,16 @@ extern "C" int mrdis_conv3d_bwd_weight(const float* x, int ldx, const float* dy,
         rc = mrdis_run_wino_wgrad3d(x, ldx, dy, lddy, dw_tck, dbias, workspace, workspace_bytes, N, D, H, W, Ci, Co, s);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
-    if (Ci == 16 && Co == 16 && k == 3 && stride == 1 && pad == 1 && !mrdis_opt(MRDIS_OPT_NO16_3D)) {      // six bf16 products per fp32 product (mrdis_conv3d_s6.hip)
+    if (Ci % 16 == 0 && Co % 16 == 0 && k == 3 && stride == 1 && pad == 1 && !mrdis_opt(MRDIS_OPT_NO16_3D) &&
+        !wino3d_wgrad_wanted(N, D, H, W, Ci, Co, stride)) {      // six bf16 products per fp32 product (mrdis_conv3d_s6.hip)
         int nsl = 0; float* bsl = nullptr;
-        rc = mrdis_run_wgrad3d16_s6(x, ldx, dy, lddy, reinterpret_cast<float*>(workspace), workspace_bytes, dbias != nullptr, N, D, H, W, &nsl, &bsl, s);
+        rc = mrdis_run_wgrad3d16_s6(x, ldx, dy, lddy, reinterpret_cast<float*>(workspace), workspace_bytes, dbias != nullptr, N, D, H, W, Ci, Co, &nsl, &bsl, s);
         if (rc == MRDIS_OK) {
             const long long nout6 = (long long)T3_TAPS * Ci * Co + (dbias ? Co : 0);
             int SL = 1;
             while (SL < 16 && SL * 8 <= nsl) SL <<= 1;
             MRDIS_LAUNCH(wgrad3d16_reduce_kernel, dim3(mrdis_cdiv(nout6, 64)), dim3(64, SL), 0, s, reinterpret_cast<float*>(workspace), dw_tck, Ci, Co, 16,
-                               1, 1, nsl, bsl, dbias);
+                               Ci / 16, Co / 16, nsl, bsl, dbias);
             MRDIS_CHECK_LAUNCH();
             return MRDIS_OK;
         }

@@ -248,6 +248,7 @@ struct Wgrad3dS6Params {
     const float* x; const float* dy; float* slab; float* bias_slab;
     int N, D, H, W, ldx, lddy;
     int tilesZ, tilesA, tilesB, numTiles, splits;
+    int nCi, nCo;                      // 16-channel slices of x / dy: one workgroup column per (slice of x, slice of dy) pair, as wgrad3d16_kernel
 };
 
 __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params p) {
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params
     unsigned char* const xs = w6_smem;                         // [3 terms][32 rows][18 px][16 ch] bf16
     unsigned char* const ys = w6_smem + 3 * W6D_XPLANE;        // [3 terms][6][10][18 px][16 co] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
-    const int split = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int lb = mrdis_xcd_remap((int)blockIdx.x, (int)gridDim.x);      // the (cic, coc) workgroups of a split share x / dy boxes: same XCD
+    const int coc = lb % p.nCo, cic = (lb / p.nCo) % p.nCi, split = lb / (p.nCo * p.nCi);
     const int q4 = l16 >> 2, p4 = l16 & 3, rowsel = kq & 1, xpos = 8 * (kq >> 1) + q4;
     // per-lane bases of the transposing reads (k-step row ya, tap (r, s, u) add compile-time offsets; the second read of an operand is + 4 pixels = 128 B)
     const int xbase = ((wave * S6_TH + 2 * rowsel) * 18 + xpos) * 32 + 8 * p4;
@@ -276,8 +278,8 @@ __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params
         const int tz = tt % p.tilesZ;
         const int n = tt / p.tilesZ;
         const int z0 = tz * S6_TD, a0 = ta * S6_TH, b0 = tb * S6_TW;
-        const float* __restrict__ xn = p.x + (long long)n * p.D * p.H * p.W * p.ldx + qc;
-        const float* __restrict__ yn = p.dy + (long long)n * p.D * p.H * p.W * p.lddy + qc;
+        const float* __restrict__ xn = p.x + (long long)n * p.D * p.H * p.W * p.ldx + 16 * cic + qc;
+        const float* __restrict__ yn = p.dy + (long long)n * p.D * p.H * p.W * p.lddy + 16 * coc + qc;
 #pragma unroll
         for (int it = 0; it < W6D_XR; ++it) {
             const int px = (tid + 256 * it) >> 2;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params
     }
     // cross-wave reduction through LDS (fixed order), then slab[split][tap][16 ci][16 co] -- the layout wgrad3d16_reduce_kernel sums
     float* red = reinterpret_cast<float*>(w6_smem);            // [4 waves][27][256]
-    float* out = p.slab + (long long)split * 27 * 256;
+    float* out = p.slab + (long long)lb * 27 * 256;
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 27; ++t)
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params
     __syncthreads();
     for (int i = tid; i < 27 * 256; i += 256)
         out[i] = (red[i] + red[27 * 256 + i]) + (red[2 * 27 * 256 + i] + red[3 * 27 * 256 + i]);
-    if (p.bias_slab != nullptr) {
+    if (p.bias_slab != nullptr && cic == 0) {
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) red[c * 256 + tid] = bs4[c];      // thread tid holds couts 4 (tid & 3) + c
@@ -400,20 +402,23 @@ __global__ __launch_bounds__(256) void wgrad3d16_s6_kernel(const Wgrad3dS6Params
             const int qd = tid >> 2, c = tid & 3;
             float t_ = 0.f;
             for (int k = qd; k < 256; k += 4) t_ += red[c * 256 + k];
-            p.bias_slab[(long long)split * 16 + tid] = t_;
+            p.bias_slab[((long long)split * p.nCo + coc) * 16 + tid] = t_;
         }
     }
 }
 
-// Weight (+ bias) slabs of a 16 -> 16, 3x3x3, stride-1 layer; *splits_out = the number of slabs for wgrad3d16_reduce_kernel (CW = 16, one ci / co tile).
-// MRDIS_EUNSUPPORTED outside what the kernel covers (then the fp32 kernel runs).  Option split6: 1 (default) and 9 (this kernel only) select it.
+// Weight (+ bias) slabs of a 3x3x3 stride-1 layer whose channel counts are multiples of 16 (16 -> 16 at full resolution, 32 -> 32 one level down, 32 -> 16 of the
+// VAE branch ...); *splits_out = the number of slabs per (ci slice, co slice) for wgrad3d16_reduce_kernel (CW = 16).  MRDIS_EUNSUPPORTED outside what the kernel
+// covers (then the fp32 kernels run).  Option split6: 1 (default) and 9 (this kernel only) select it.
 int mrdis_run_wgrad3d16_s6(const float* x, int ldx, const float* dy, int lddy, float* slab, size_t slab_bytes, int want_bias,
-                           int N, int D, int H, int W, int* splits_out, float** bias_slab_out, hipStream_t s) {
+                           int N, int D, int H, int W, int Ci, int Co, int* splits_out, float** bias_slab_out, hipStream_t s) {
     const long long s6 = mrdis_opt(MRDIS_OPT_SPLIT6);
     if (s6 != 1 && s6 != 9) return MRDIS_EUNSUPPORTED;
+    if (Ci % 16 != 0 || Co % 16 != 0 || Ci > 64 || Co > 64) return MRDIS_EUNSUPPORTED;
     if (ldx % 4 != 0 || lddy % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)slab)) & 15) != 0) return MRDIS_EUNSUPPORTED;
     Wgrad3dS6Params p{};
     p.x = x; p.dy = dy; p.N = N; p.D = D; p.H = H; p.W = W; p.ldx = ldx; p.lddy = lddy;
+    p.nCi = Ci / 16; p.nCo = Co / 16;
     p.tilesZ = mrdis_cdiv(D, S6_TD); p.tilesA = mrdis_cdiv(H, S6_TH); p.tilesB = mrdis_cdiv(W, S6_TW);
     const long long nt = (long long)N * p.tilesZ * p.tilesA * p.tilesB;
     if (nt > 0x7fffffffLL || nt < 512 || (long long)D * H * W < 32768 || (long long)D * H * W >= 0x7fffffffLL) return MRDIS_EUNSUPPORTED;
@@ -424,14 +429,17 @@ int mrdis_run_wgrad3d16_s6(const float* x, int ldx, const float* dy, int lddy, f
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    p.splits = p.numTiles < ncu ? p.numTiles : ncu;              // one workgroup per CU (155 KB of LDS)
-    const size_t need = sizeof(float) * ((size_t)p.splits * 27 * 256 + (size_t)p.splits * 16);
+    const int pairs = p.nCi * p.nCo;
+    int splits = ncu / pairs; if (splits < 1) splits = 1;         // one workgroup per CU (155 KB of LDS): splits x slice pairs fill the chip once
+    if (splits > p.numTiles) splits = p.numTiles;
+    p.splits = splits;
+    const size_t need = sizeof(float) * ((size_t)splits * pairs * 27 * 256 + (size_t)splits * p.nCo * 16);
     if (slab_bytes < need) return MRDIS_EUNSUPPORTED;
     p.slab = slab;
-    p.bias_slab = want_bias ? slab + (size_t)p.splits * 27 * 256 : nullptr;
+    p.bias_slab = want_bias ? slab + (size_t)splits * pairs * 27 * 256 : nullptr;
     mrdis_count(MRDIS_CNT_SPLIT6_W3D);
-    MRDIS_LAUNCH(wgrad3d16_s6_kernel, dim3(p.splits), dim3(256), W6D_LDS, s, p);
+    MRDIS_LAUNCH(wgrad3d16_s6_kernel, dim3(splits * pairs), dim3(256), W6D_LDS, s, p);
     MRDIS_CHECK_LAUNCH();
-    *splits_out = p.splits; *bias_slab_out = p.bias_slab;
+    *splits_out = splits; *bias_slab_out = p.bias_slab;
     return MRDIS_OK;
 }

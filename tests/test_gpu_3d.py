@@ -365,3 +365,27 @@ def test_conv3d_16_to_16_six_product_kernel(mrdis, N, D, H, W):
         # (the weight gradient sums ~1e5 .. 1e6 products per element: both kernels sit at their fp32 summation error there, compared against float64)
         assert d01 <= (2e-6 if k < 2 else 2e-5), (name, 'six-product vs fp32 kernel', d01)
         assert e1 <= max(2.0 * e0, 5e-7), (name, 'vs float64', e1, e0)
+
+
+@pytest.mark.parametrize('N,Ci,Co,D,H,W', [(1, 32, 32, 64, 64, 64), (1, 32, 16, 64, 64, 64), (3, 16, 48, 40, 52, 36)])
+def test_conv3d_weight_gradient_six_product_channel_slices(mrdis, N, Ci, Co, D, H, W):
+    """wgrad3d16_s6_kernel on layers wider than 16 channels: one workgroup column per (16-channel slice of x, 16-cout slice of dy) pair (block2 32 -> 32 at 64^3,
+    vconv1 32 -> 16 of the VAE branch: model.py:1861-1864, 1969-1984), slabs summed by the fp32 kernel's ordered reduction: weight + bias gradient against the
+    fp32 kernel (split6 = 0) and float64."""
+    hip = mrdis.hip
+    x = seeded((N, Ci, D, H, W), 1); dy = seeded((N, Co, D, H, W), 5)
+    xd, dyd = cl3(x), cl3(dy)
+    out = {}
+    for s6 in (0, 1):
+        with hip.option('split6', s6):
+            hip.launch_counts(reset=True)
+            dw, db = hip.conv3d_bwd_weight(xd, dyd, 3, 1, 1, True)
+            assert (hip.launch_counts()['split6_w3d'] == 1) == (s6 == 1)
+            out[s6] = (dw.detach().cpu().double(), db.detach().cpu().double())
+    w64 = torch.nn.grad.conv3d_weight(x.double(), (Co, Ci, 3, 3, 3), dy.double(), padding=1).permute(2, 3, 4, 1, 0).reshape(27, Ci, Co)      # [tap][ci][co]
+    b64 = dy.double().sum((0, 2, 3, 4))
+    for k, (name, ref) in enumerate((('wgrad', w64), ('bgrad', b64))):
+        scale = float(ref.abs().max())
+        e0, e1 = float((out[0][k] - ref).abs().max()) / scale, float((out[1][k] - ref).abs().max()) / scale
+        assert float((out[0][k] - out[1][k]).abs().max()) / scale <= 2e-5, name
+        assert e1 <= max(2.0 * e0, 5e-7), (name, e1, e0)
