@@ -52,10 +52,15 @@ def layer_table(B, S, c, reps):
         t_d = timeit(lambda: mrdis.hip.conv3d_bwd_data(dy, w_tkc, tuple(x.shape), 3, st, 1), reps)
         t_w = timeit(lambda: mrdis.hip.conv3d_bwd_weight(x, dy, 3, st, 1, True), reps)
         mb = 4.0 * (x.numel() + y.numel()) / 1e6
+        # roofline leg (round 6): direct-convolution FLOPs / time against the fp32 MFMA peak (157.3 TF/s; the hybrid Winograd and the six-product kernels execute
+        # fewer / cheaper multiplies, so their fraction can exceed what an fp32 MFMA kernel could reach) and algorithmic bytes (x + y, fp32) / time against 8 TB/s
+        frac = lambda t: (round(flop / t / 1e6 / 157.3, 3), round(mb / t * 1e3 / 8000.0, 3))
         rows.append(dict(layer=name, ci=ci, co=co, size=s, stride=st, gflop=round(flop / 1e9, 2), mb=round(mb, 1),
                          fwd_us=round(t_f, 1), dgrad_us=round(t_d, 1), wgrad_us=round(t_w, 1),
                          fwd_tf=round(flop / t_f / 1e6, 1), dgrad_tf=round(flop / t_d / 1e6, 1), wgrad_tf=round(flop / t_w / 1e6, 1),
-                         fwd_gbs=round(mb / t_f * 1e3, 0)))
+                         fwd_gbs=round(mb / t_f * 1e3, 0),
+                         fwd_frac_mfma_hbm=frac(t_f), dgrad_frac_mfma_hbm=frac(t_d), wgrad_frac_mfma_hbm=frac(t_w),
+                         bound='mfma' if flop / (mb * 1e6) > 157.3e12 / 8e12 else 'hbm'))
         print(json.dumps(rows[-1]), flush=True)
         del x, y, dy
     return rows

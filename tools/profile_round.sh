@@ -23,5 +23,14 @@ python tools/prof_summary.py step $OUT/bench_kernel_trace.csv $OUT/${TAG}_bench_
 python tools/dispatch_counts.py $OUT/bench_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_f32.txt
 python tools/dispatch_counts.py $OUT/bf16_kernel_stats.csv 7 > $OUT/${TAG}_dispatch_counts_bf16.txt
 python tools/prof_summary.py pmc $OUT/ns_fetch_counter_collection.csv $OUT/ns_write_counter_collection.csv $OUT/northstar_conv_pmc.json c4conv "" $TAG
+# the 3-D path: NVNet3D step under the profiler + the per-layer table with roofline fractions, six-product kernels on / off
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b3d -- python tools/bench3d.py > $OUT/${TAG}_bench3d_profiled.json 2> $OUT/bench3d.err
+python tools/prof_summary.py stats $OUT/b3d_kernel_stats.csv $OUT/b3d_kernel_trace.csv $OUT/${TAG}_bench3d_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python tools/bench3d.py ($TAG): NVNet3D step on 4x4x128^3"
+python tools/bench3d.py > $OUT/${TAG}_bench3d.json 2>> $OUT/bench3d.err
+MRDIS_SPLIT6=0 python tools/bench3d.py > $OUT/${TAG}_bench3d_split6_off.json 2>> $OUT/bench3d.err
+python tools/bench3d.py --layers > $OUT/${TAG}_bench3d_layers.txt 2>> $OUT/bench3d.err
+# the graph-replayed step under the profiler (kernel time per step must equal the eager step's)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o graph -- python bench.py --graph --no-direct --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_graph_profiled.json 2> $OUT/bench_graph_profiled.err
+python tools/dispatch_counts.py $OUT/graph_kernel_stats.csv 8 > $OUT/${TAG}_dispatch_counts_graph_f32.txt
 rm -f $OUT/*_kernel_trace.csv $OUT/*_counter_collection.csv
 ls -la $OUT
