@@ -851,10 +851,10 @@ class GraphedTrainStep:
 
     def _call(self, inputs, mask, mask_img, mask_host, targets, it, pairs):
         ts = self.step
+        do_step = ts._advance(it)
         if not regular_mask(mask_host):
             self.stats['eager'] += 1; self.stats['eager_irregular_mask'] += 1
-            return ts(inputs, mask, mask_img, mask_host, targets, it)
-        do_step = ts._advance(it)
+            return self._eager(inputs, mask, mask_img, mask_host, targets, do_step)
         opt, od = ts.optimizer, ts.optimizer_d_s
         key = (bool(do_step), tuple(inputs.shape), inputs.dtype, targets is not None, float(opt.lr), None if od is None else float(od.lr), ops.compute_dtype())
         x, m, mi, tg = self._static_inputs(inputs, mask, mask_img, targets)
@@ -870,10 +870,9 @@ class GraphedTrainStep:
                 self.stats['eager'] += 1
                 self.stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
-                    loss, parts, aux, scale = ts._forward_backward(x, m, mi, mask_host, tg, do_step)
-                    ts._apply(scale, do_step)
+                    out = self._eager(x, m, mi, mask_host, tg, do_step)
                 torch.cuda.current_stream().wait_stream(self.stream)
-                return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
+                return out
             group = self.entries[key] = self._record_all(x, m, mi, mask_host, tg, do_step, pairs)
         ent = group[pairs.get('adv_s')]
         ops.set_step_mask_host(mask_host)
@@ -881,6 +880,27 @@ class GraphedTrainStep:
         self.stats['replays'] += 1
         self._launch(ent, do_step)
         return ent['out']
+
+    def _eager(self, x, m, mi, mask_host, tg, do_step):
+        """an un-recorded iteration (warm-up, or a batch whose mask prunes loss terms).  Under data parallelism it issues the SAME collectives as a replayed one
+        -- one all-reduce per gradient arena between backward and the optimizer -- because whether a rank replays or not depends on ITS batch's mask: a rank
+        on the bucketed exchange of TrainStep would never pair with a rank that replays."""
+        ts = self.step
+        if self._exchanging():
+            loss, parts, aux, _ = ts._forward_backward(x, m, mi, mask_host, tg, do_step, exchange=False)
+            self._all_reduce(do_step)
+            ts._apply(1.0 / ts.reducer.world, do_step)
+        else:
+            loss, parts, aux, scale = ts._forward_backward(x, m, mi, mask_host, tg, do_step)
+            ts._apply(scale, do_step)
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
+
+    def _all_reduce(self, do_step):
+        ts = self.step
+        red = ts.reducer
+        dist.all_reduce(ts.optimizer._g_full, op=dist.ReduceOp.SUM, group=red.group)
+        if ts.optimizer_d_s is not None and do_step:
+            dist.all_reduce(ts.optimizer_d_s._g_full, op=dist.ReduceOp.SUM, group=red.group)
 
     def _exchanging(self):
         red = self.step.reducer
@@ -940,10 +960,7 @@ class GraphedTrainStep:
         ent['hv'].ship()
         ent['g1'].replay()
         if ent['g2'] is not None:
-            red = ts.reducer
-            dist.all_reduce(ts.optimizer._g_full, op=dist.ReduceOp.SUM, group=red.group)
-            if ts.optimizer_d_s is not None and do_step:
-                dist.all_reduce(ts.optimizer_d_s._g_full, op=dist.ReduceOp.SUM, group=red.group)
+            self._all_reduce(do_step)
             ent['g2'].replay()
         if ts.accum == 1 or do_step:
             ts.optimizer.step_count += 1

@@ -74,7 +74,7 @@ def _emulate(mrdis, dev):
     return _signature(model, step)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, graph=False):
     import datetime
     import traceback
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -87,6 +87,8 @@ def _worker(rank, world, port, q):
         model, step = _build(mrdis, dev)
         red = step.reducer
         assert red is not None and red.world == world and red.exchanging
+        if graph:                                                      # rank 1 (full masks) replays recorded graphs, rank 0 (a modality missing) cannot: eager
+            step = mrdis.GraphedTrainStep(step, warm=1)
         torch.manual_seed(100 + rank); np.random.seed(100)             # eps per rank, the sim_s / adv_s pair identical on every rank
         losses = []
         for it in range(ITERS):
@@ -96,7 +98,7 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         ex = red.exposed_ms()
         flags_seen = step.optimizer.gate_steps[:step.optimizer.n_flags].cpu().tolist()
-        q.put((rank, 'ok', _signature(model, step), losses, ex, flags_seen))
+        q.put((rank, 'ok', _signature(model, step), losses, dict(ex, graph_stats=dict(step.stats) if graph else None), flags_seen))
     except BaseException:                                            # noqa: BLE001 -- report instead of leaving the other rank in a collective
         q.put((rank, 'error', traceback.format_exc(), None, None, None))
     finally:
@@ -131,3 +133,29 @@ def test_two_ranks_with_divergent_missing_modalities_equal_the_averaged_gradient
     # every backward pass issued the same collectives on both ranks; decoder 2 stepped on both (its gate flag arrives from rank 1 only)
     assert ex0['finish_calls'] == ex1['finish_calls'] == ITERS + ITERS // 2 and ex0['bytes_reduced'] == ex1['bytes_reduced']
     assert flags0 == flags1 and all(f == ITERS // 2 for f in flags0), (flags0, flags1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_graph_replay_on_one_eager_fallback_on_the_other(mrdis):
+    """the same job with GraphedTrainStep: rank 1's batches (full masks) are replayed from recorded graphs, rank 0's (modality 2 missing: loss terms pruned)
+    run eagerly -- both issue one all-reduce per gradient arena between backward and the optimizer, so they pair whatever each rank's mask decides.
+    Weights and Adam moments identical across ranks and to the averaged-gradient oracle."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=400) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[1] == 'ok', r[2]
+    (_, _, sig0, losses0, ex0, _), (_, _, sig1, losses1, ex1, _) = res
+    assert ex0['graph_stats']['eager_irregular_mask'] == ITERS and ex0['graph_stats']['replays'] == 0, ex0
+    assert ex1['graph_stats']['replays'] == 2 and ex1['graph_stats']['eager'] == 2, ex1
+    emu = _emulate(mrdis, torch.device('cuda:0'))
+    for n, a, b, e in zip(['weights', 'adam m', 'adam v', 'adam vmax', 'adam_d m', 'adam_d v'], sig0, sig1, emu):
+        assert a == b, (n, 'differs across ranks', a, b)
+        assert a == e, (n, 'differs from the averaged-gradient oracle', a, e)
