@@ -868,11 +868,7 @@ class GraphedTrainStep:
                 self.stream = torch.cuda.Stream()
             if n < self.warm:                    # eager, on the capture stream: workspaces, plans and caches reach their final size there
                 self.stats['eager'] += 1
-                self.stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.stream):
-                    out = self._eager(x, m, mi, mask_host, tg, do_step)
-                torch.cuda.current_stream().wait_stream(self.stream)
-                return out
+                return self._eager(x, m, mi, mask_host, tg, do_step, side=self.stream)
             group = self.entries[key] = self._record_all(x, m, mi, mask_host, tg, do_step, pairs)
         ent = group[pairs.get('adv_s')]
         ops.set_step_mask_host(mask_host)
@@ -881,18 +877,32 @@ class GraphedTrainStep:
         self._launch(ent, do_step)
         return ent['out']
 
-    def _eager(self, x, m, mi, mask_host, tg, do_step):
+    def _eager(self, x, m, mi, mask_host, tg, do_step, side=None):
         """an un-recorded iteration (warm-up, or a batch whose mask prunes loss terms).  Under data parallelism it issues the SAME collectives as a replayed one
         -- one all-reduce per gradient arena between backward and the optimizer -- because whether a rank replays or not depends on ITS batch's mask: a rank
-        on the bucketed exchange of TrainStep would never pair with a rank that replays."""
+        on the bucketed exchange of TrainStep would never pair with a rank that replays.  side: run the kernels on the capture stream (warm-up); the
+        collectives stay on the caller's stream, as in a replayed step."""
         ts = self.step
+        cur = torch.cuda.current_stream()
+
+        def on(fn):
+            if side is None:
+                return fn()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out = fn()
+            cur.wait_stream(side)
+            return out
         if self._exchanging():
-            loss, parts, aux, _ = ts._forward_backward(x, m, mi, mask_host, tg, do_step, exchange=False)
+            loss, parts, aux, _ = on(lambda: ts._forward_backward(x, m, mi, mask_host, tg, do_step, exchange=False))
             self._all_reduce(do_step)
-            ts._apply(1.0 / ts.reducer.world, do_step)
+            on(lambda: ts._apply(1.0 / ts.reducer.world, do_step))
         else:
-            loss, parts, aux, scale = ts._forward_backward(x, m, mi, mask_host, tg, do_step)
-            ts._apply(scale, do_step)
+            def both():
+                loss, parts, aux, scale = ts._forward_backward(x, m, mi, mask_host, tg, do_step)
+                ts._apply(scale, do_step)
+                return loss, parts, aux
+            loss, parts, aux = on(both)
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, aux
 
     def _all_reduce(self, do_step):

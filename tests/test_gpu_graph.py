@@ -105,5 +105,7 @@ def test_graph_replay_with_the_exchange_between_two_graphs(mrdis):
         assert step.reducer is not None and step.reducer.exchanging
         assert all(e['g2'] is not None for grp in step.entries.values() for e in grp.values()) and step.stats['captures'] == 24
         assert got_l == ref_l and torch.equal(ref_w, got_w) and torch.equal(ref_b, got_b)
+        del step
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
