@@ -70,11 +70,18 @@ def parse():
     return ap.parse_args()
 
 
-def _time_conv(hip, xs, w, b, ys, iters):
+def _time_conv(hip, xs, w, b, ys, iters, warm_ms=20.0):
     """average launch duration (us) over `iters` launches cycling through the (x, y) buffer pairs; HIP events on the launch
-    stream (torch's current stream is the stream the C ABI is handed)."""
+    stream (torch's current stream is the stream the C ABI is handed).  Warm-up: launches until >= `warm_ms` of GPU time have gone by -- from idle
+    (this leg follows host-side work: the CPU reference convolution, tiny host-timing steps) the first launches run 10-30 % slower until the chip has
+    ramped its clocks (tools/c4_grid_probe.py: 68 vs 52 us for the same launch); inside the training step it has."""
     n = len(xs)
-    for i in range(max(3, n)):
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record()
+    for i in range(max(8, n)):
+        hip.conv2d_fwd(xs[i % n], w, b, 3, 3, 1, 1, out=ys[i % n])
+    w1.record(); torch.cuda.synchronize()
+    for i in range(max(0, int(8 * (warm_ms / max(w0.elapsed_time(w1), 0.05) - 1.0)))):
         hip.conv2d_fwd(xs[i % n], w, b, 3, 3, 1, 1, out=ys[i % n])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -177,7 +184,6 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     err = float((ys[0].cpu() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-5, f'north-star conv output differs from torch fp32: rel {err:.2e}'
     hip.launch_counts(reset=True)
-    _time_conv(hip, xs, w, b, ys, iters)                      # (first pass over freshly allocated buffers reads 10-30 % high: tools/c4_grid_probe.py; the second is reported)
     us_rot = _time_conv(hip, xs, w, b, ys, iters)
     six = hip.launch_counts()['split6_c4'] > 0               # which form the library's policy launched (option split6)
     if not extras:          # tools/northstar_conv.py under rocprofv3 --pmc: only launches of the north-star shape
@@ -186,7 +192,6 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     us_f32 = None
     if six:                 # the exact-fp32 MFMA form of the same kernel (option split6 = 0), same buffers, same run
         with hip.option('split6', 0):
-            _time_conv(hip, xs, w, b, ys, iters)
             us_f32 = _time_conv(hip, xs, w, b, ys, iters)
     # the ceiling of a store-only kernel on THIS device, over the same rotating output buffers (236 MB each): the layer's algorithmic traffic is 89 % stores
     for i in range(4):
@@ -225,7 +230,7 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
                                                            'achieved': gbs(NS_BYTES, us_f32), 'frac': round(gbs(NS_BYTES, us_f32) / HBM_PEAK_GBS, 4)},
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_bytes': NS_BYTES, 'us_per_launch': round(us_rot, 2),
-            'timing': f'{iters} launches over {nrot} rotating x/y pairs (1.06 GB, beyond the 256 MiB Infinity Cache), HIP events',
+            'timing': f'{iters} launches over {nrot} rotating x/y pairs (1.06 GB, beyond the 256 MiB Infinity Cache) after >= 20 ms of warm-up launches (clock ramp), HIP events',
             'output_checked': f'vs torch fp32 conv2d on the host, max rel err {err:.1e}',
             'store_only_ceiling': {'gbs': round(fill_gbs, 1), 'us_for_this_output': round(us_fill, 2), 'kernel_time_over_it': round(us_rot / us_fill, 3),
                                    'note': 'mrdis_stream_fill: a kernel that ONLY writes the 236 MB output (non-temporal 16-byte stores, contiguous run per workgroup, nothing '
