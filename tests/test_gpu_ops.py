@@ -449,6 +449,12 @@ def test_conv_c4_persistent_pipeline(mrdis):
         e32, e6 = float((got.cpu().double() - want64).abs().max()) / sc, float((got6.cpu().double() - want64).abs().max()) / sc
         assert e6 <= 2.0 * e32 + 1e-7, ('split6 c4 forward', e6, e32)
         close(got6, got, rtol=2e-6, what='split6 vs fp32 MFMA'); close(got6l, gotl, rtol=2e-6, what='split6 vs fp32 MFMA, lrelu')
+        # option c4_grid: the persistent grid (workgroups per CU) only changes which workgroup takes which strips: bit-identical results
+        for grid in (1, 2, 7):
+            with hip.option('c4_grid', grid):
+                gg = hip.conv2d_fwd(cl(x), to_tck(w).to(dev()), b.to(dev()), 3, 3, 1, 1)
+                assert hip.get_option('debug_c4_blocks') > 0
+            assert torch.equal(gg, got), ('c4_grid', grid)
 
 
 @pytest.mark.parametrize('N,Ci,Co,H,W,k,st', [(24, 32, 32, 128, 144, 3, 1), (8, 64, 96, 72, 80, 3, 1), (16, 32, 64, 64, 64, 4, 2),
