@@ -366,21 +366,27 @@ class AnatomyEncoderDecNew(nn.Module):
         self.up_1 = Act_Deconv_BN_Concat_New(4 * c, c, is_cond=is_cond)
         self.output = Act_Deconv_BN_Concat_New(2 * c, out_num_ch, is_last=True, is_cond=is_cond)
 
-    def forward(self, down_list, inputs_type=None):
+    def forward(self, down_list, inputs_type=None, need_out=True):
+        """need_out = False: stop behind up_1 -- the caller does not read the anatomy map (second encoder pass of main_missing.py:228-231 when the modality
+        encoder takes no s: the map is dead there); every BatchNorm of the network has run by then, so the module's state is what the full pass leaves."""
         if inputs_type is None:
             inputs_type = expand_type(1.0, down_list[0].shape[0], down_list[0].device)   # :2286-2287
         u4 = self.up_4(down_list[3], down_list[4], inputs_type)
         u3 = self.up_3(down_list[2], u4, inputs_type)
         u2 = self.up_2(down_list[1], u3, inputs_type)
         u1 = self.up_1(down_list[0], u2, inputs_type)
+        if not need_out:
+            return None, None
         out = self.output(None, u1, inputs_type)
         return out, out
 
-    def forward_grouped(self, down_list, types):
+    def forward_grouped(self, down_list, types, need_out=True):
         u4 = self.up_4.forward_grouped(down_list[3], down_list[4], types)
         u3 = self.up_3.forward_grouped(down_list[2], u4, types)
         u2 = self.up_2.forward_grouped(down_list[1], u3, types)
         u1 = self.up_1.forward_grouped(down_list[0], u2, types)
+        if not need_out:
+            return None, None
         out = self.output.forward_grouped(None, u1, types)
         return out, out
 
@@ -866,13 +872,23 @@ class MultimodalModel(nn.Module):
             return base.view(M * B, H, W, c).permute(0, 3, 1, 2)
         return torch.cat(list(inputs_list), 0)
 
-    def compute_anatomy_encoding(self, inputs_list, mask_img):
+    def modality_encoder_reads_s(self):
+        """whether compute_modality_encoding consumes the anatomy maps (config others.mod_enc_s; model.py:2374: the modality encoder concatenates s only then)"""
+        return any(getattr(e, 's_num_ch', 1) != 0 for e in self.modality_encoder_list)
+
+    def compute_anatomy_encoding(self, inputs_list, mask_img, need_maps=True):
+        """need_maps = False (the second encoder pass of main_missing.py:228-231 when the modality encoder takes no s): the maps are dead -- nothing reads them,
+        no gradient reaches them -- so the pass stops behind the last BatchNorm of the anatomy network (the x2 resize to full resolution, the 64 -> 4
+        convolution and the masked softmax of the last block are skipped: 1.5 ms per step at B = 32); the network's state (BatchNorm running statistics,
+        counters) is exactly what the full pass leaves.  Returns [None] * M then."""
         if self._encoders_grouped():
             M, B = self.modality_num, inputs_list[0].shape[0]
             types = [self._type(i, B) for i in range(M)]
             x = self._cat_inputs(inputs_list)
             feats = self.anatomy_encoder_enc_list[0].forward_grouped(x, types)
-            si, _ = self.anatomy_encoder_dec.forward_grouped(feats, types)
+            si, _ = self.anatomy_encoder_dec.forward_grouped(feats, types, need_out=need_maps)
+            if not need_maps:
+                return [None] * M
             m_all = mask_img if mask_img is None else mask_img.repeat(M, 1, 1)
             return list(ops.split_batch(ops.softmax_mask_drop(si, m_all, 100.0), M))
         si_list = []
@@ -881,8 +897,8 @@ class MultimodalModel(nn.Module):
             t = self._type(i, B)
             enc = self.anatomy_encoder_enc_list[0 if self.shared_ana_enc else i]
             feats = enc(inputs_list[i], t)
-            si, _ = self.anatomy_encoder_dec(feats, t)
-            si_list.append(ops.softmax_mask_drop(si, mask_img, 100.0))                           # :3150-3153
+            si, _ = self.anatomy_encoder_dec(feats, t, need_out=need_maps)
+            si_list.append(None if not need_maps else ops.softmax_mask_drop(si, mask_img, 100.0))   # :3150-3153
         return si_list
 
     # ---- model.py:3159-3162: eps is drawn from the CPU generator, then moved

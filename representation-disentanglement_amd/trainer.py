@@ -564,6 +564,7 @@ class GradAllReduce:
 
 # --------------------------------------------------------------------------- one training iteration
 _PLANAR_INPUTS = os.environ.get('MRDIS_PLANAR_INPUTS', '1') != '0'
+_SKIP_DEAD_MAPS = os.environ.get('MRDIS_SKIP_DEAD_MAPS', '1') != '0'      # 0: the second encoder pass also computes its (unread) anatomy maps, as the reference does
 
 LOSS_KEYS = ('recon_y', 'recon_y_fused', 'recon_x', 'recon_x_mix', 'kl', 'latent_z', 'sim_s', 'sim_z',
              'adv_s', 'adv_s_d', 'all')
@@ -620,7 +621,9 @@ def forward_losses(model, config, inputs, mask, mask_img, mask_host, phase='trai
         parts['recon_x_mix'] = model.compute_recon_loss_x_mix_list(inputs_list, xi_fake_mix_list, mask, p, mask_host)
         loss = loss + config['lambda_recon_x_mix'] * parts['recon_x_mix']
     if config['lambda_latent_z'] > 0:                                                            # :228-233
-        si_new = model.compute_anatomy_encoding(xi_fake_list, mask_img)
+        # (the maps of this second pass are read by the modality encoder only under others.mod_enc_s: otherwise the pass runs for its BatchNorm state alone)
+        dead_maps = _SKIP_DEAD_MAPS and hasattr(model, 'modality_encoder_reads_s') and not model.modality_encoder_reads_s()
+        si_new = model.compute_anatomy_encoding(xi_fake_list, mask_img, need_maps=False) if dead_maps else model.compute_anatomy_encoding(xi_fake_list, mask_img)
         _, mu_new, _ = model.compute_modality_encoding(xi_fake_list, si_new, phase=phase)
         parts['latent_z'] = model.compute_latent_z_loss(mu_list, mu_new, mask, mask_host)
         loss = loss + config['lambda_latent_z'] * parts['latent_z']

@@ -892,3 +892,30 @@ def test_batchnorm_call_counter_is_flushed(mrdis):
     assert int(bn.num_batches_tracked) == 5
     bn.load_state_dict(ref.state_dict())
     assert int(bn.state_dict()['num_batches_tracked']) == 3
+
+
+def test_skipping_the_dead_anatomy_maps_of_the_second_pass_changes_nothing(mrdis):
+    """main_missing.py:228-231 encodes the reconstructions again; with others.mod_enc_s = False nothing reads that pass's anatomy maps, so its last block
+    (x2 resize to full resolution, 64 -> 4 convolution, masked softmax) is skipped (MRDIS_SKIP_DEAD_MAPS, default on).  Loss, every weight after the step,
+    BatchNorm running statistics and counters must be BIT-IDENTICAL to the step that computes them."""
+    B, M, H, W = 2, 3, 64, 96
+    res = {}
+    for skip in (False, True):
+        mrdis.trainer._SKIP_DEAD_MAPS = skip
+        try:
+            cfg = _cfg(mrdis, M, H, W, 16, adv=True)
+            torch.manual_seed(10); np.random.seed(10)
+            model = mrdis.build_model(cfg).train()
+            step = mrdis.TrainStep(model, cfg)
+            inputs, mask, mask_img = make_inputs(B, M, H, W, seed=10, drop=True)
+            torch.manual_seed(11); np.random.seed(11)
+            losses = []
+            for _ in range(2):
+                loss, parts, _ = step(cl(inputs), mask.to(DEV), mask_img.to(DEV), mask)
+                losses.append({k: float(v) for k, v in parts.items()})
+            res[skip] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(),
+                         torch.cat([b.detach().float().reshape(-1) for b in model.buffers()]).cpu())
+        finally:
+            mrdis.trainer._SKIP_DEAD_MAPS = True
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
