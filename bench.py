@@ -189,12 +189,11 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     six = hip.launch_counts()['split6_c4'] > 0               # which form the library's policy launched (option split6)
     if not extras:          # tools/northstar_conv.py under rocprofv3 --pmc: only launches of the north-star shape
         return {'us_per_launch': round(us_rot, 2), 'achieved': round(NS_BYTES / (us_rot * 1e-6) / 1e9, 1)}
-    us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
-    us_sus = _time_conv(hip, xs, w, b, ys, 4 * iters, warm_ms=20.0)       # the same launches after 20 ms of back-to-back launches: the sustained rate
     us_f32 = None
-    if six:                 # the exact-fp32 MFMA form of the same kernel (option split6 = 0), same buffers, same run
+    if six:                 # the exact-fp32 MFMA form of the same kernel (option split6 = 0), same buffers, same run, same burst protocol
         with hip.option('split6', 0):
             us_f32 = _time_conv(hip, xs, w, b, ys, iters)
+    us_one = _time_conv(hip, xs[:1], w, b, ys[:1], iters)
     # the ceiling of a store-only kernel on THIS device, over the same rotating output buffers (236 MB each): the layer's algorithmic traffic is 89 % stores
     for i in range(4):
         hip.stream_fill(ys[i % nrot])
@@ -207,13 +206,14 @@ def roofline_conv(mrdis, dev, iters=24, extras=True, pmc_inrun=False):
     torch.cuda.synchronize()
     us_fill = e0.elapsed_time(e1) * 1e3 / iters
     fill_gbs = ys[0].numel() * 4 / (us_fill * 1e-6) / 1e9
-    del xs, ys
     n6 = NS['N'] * 256 * 256
     bytes6 = 4 * (n6 * NS['Ci'] + n6 * NS['Co'] + NS['Co'] * NS['Ci'] * 9 + NS['Co'])
     xs6 = [torch.randn(NS['N'], NS['Ci'], 256, 256, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(nrot)]
     ys6 = [hip.empty_nhwc(NS['N'], NS['Co'], 256, 256, dev) for _ in range(nrot)]
     us6 = _time_conv(hip, xs6, w, b, ys6, iters)
     del xs6, ys6
+    us_sus = _time_conv(hip, xs, w, b, ys, 4 * iters, warm_ms=20.0)       # last: the 240x240 launches again after 20 ms of back-to-back launches (the sustained rate)
+    del xs, ys
     achieved = NS_BYTES / (us_rot * 1e-6) / 1e9
     traffic, traffic_src, kname = measure_traffic_inrun() if pmc_inrun else (None, None, None)
     pmc = os.path.join(ROOT, 'profiles', 'northstar_conv_pmc.json')

@@ -10,7 +10,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py --no-direct --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_profiled.json 2> $OUT/bench_profiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bf16 -- python bench.py --dtype bf16 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_bf16_profiled.json 2> $OUT/bench_bf16_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bf16 -- python bench.py --dtype bf16 --no-cpu-baseline --no-roofline --no-graph-leg > $OUT/${TAG}_bench_bf16_profiled.json 2> $OUT/bench_bf16_profiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o roof -- python bench.py --roofline-only > $OUT/${TAG}_roofline_profiled.json 2> $OUT/roofline_profiled.err
 python tools/prof_summary.py stats $OUT/bf16_kernel_stats.csv $OUT/bf16_kernel_trace.csv $OUT/${TAG}_bench_bf16_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --dtype bf16 --no-roofline ($TAG)" $OUT/${TAG}_bench_bf16_profiled.json
 python tools/prof_summary.py stats $OUT/roof_kernel_stats.csv $OUT/roof_kernel_trace.csv $OUT/${TAG}_roofline_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only ($TAG): north-star conv + the step's dominant kernels, no training step"
