@@ -449,6 +449,12 @@ int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* x, int ldx,
                              const float* save_mean, const float* save_rstd, float* dx, int lddx,
                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                              int N, long long P, int C, int G, int relu, void* stream);
+/* the same with a second gradient of x summed in: dx = (GroupNorm+ReLU backward) + add (add: (N, P, C) rows, ld = ldadd; NULL = none).  BasicBlock's input
+ * x feeds the normalised branch AND the residual addition (model.py:1873): both gradients of x then leave in one pass instead of autograd's extra add.   */
+int mrdis_groupnorm_relu_bwd_add(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_rstd, float* dx, int lddx,
+                                 float* dgamma, float* dbeta, const float* add, int ldadd, void* workspace, size_t workspace_bytes,
+                                 int N, long long P, int C, int G, int relu, void* stream);
 
 /* nn.Upsample(scale_factor=2) (nearest, model.py:1995-2003, 1898-1911) fused with the skip addition of
  * UNet3D.forward (model.py:2029-2040): y (N,2D,2H,2W,C) = x[d/2,h/2,w/2] + skip (skip may be NULL); contiguous NDHWC.

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, int lddx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ coef,
-                                                           long long P, int C, int G, int rpb, int relu) {
+                                                           long long P, int C, int G, int rpb, int relu,
+                                                           const float* __restrict__ add, int ldadd) {      // add (may be NULL): a second gradient of x, summed in here
     const int C4 = C >> 2, RL = 256 / C4, cg = C / G;
     const int tid = threadIdx.x, q = tid % C4, rl = tid / C4, n = blockIdx.y;
     float be[4], rs[4], mu[4], c1[4], c2[4], ga[4];
@@ -175,13 +176,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float* xb = x + (long long)n * P * ldx + 4 * q;
     const float* dyb = dy + (long long)n * P * lddy + 4 * q;
     float* dxb = dx + (long long)n * P * lddx + 4 * q;
+    const float* adb = add ? add + (long long)n * P * ldadd + 4 * q : nullptr;
     for (long long r = r0 + rl; r < r1; r += 2 * RL) {
-        float4 v[2], d[2];
+        float4 v[2], d[2], ad[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const long long rr = r + (long long)u * RL;
             v[u] = rr < r1 ? *reinterpret_cast<const float4*>(xb + rr * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
             d[u] = rr < r1 ? *reinterpret_cast<const float4*>(dyb + rr * lddy) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ad[u] = (adb && rr < r1) ? *reinterpret_cast<const float4*>(adb + rr * ldadd) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                 const float dz = (relu && !(xh * ga[k] + be[k] > 0.f)) ? 0.f : dv[k];
                 o[k] = rs[k] * (dz * ga[k] - c1[k] - xh * c2[k]);
             }
-            *reinterpret_cast<float4*>(dxb + rr * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dxb + rr * lddx) = adb ? make_float4(o[0] + ad[u].x, o[1] + ad[u].y, o[2] + ad[u].z, o[3] + ad[u].w) : make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -255,10 +258,19 @@ extern "C" int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* 
                                         const float* save_mean, const float* save_rstd, float* dx, int lddx,
                                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                                         int N, long long P, int C, int G, int relu, void* stream) {
+    return mrdis_groupnorm_relu_bwd_add(dy, lddy, x, ldx, gamma, beta, save_mean, save_rstd, dx, lddx, dgamma, dbeta, nullptr, 0, workspace, workspace_bytes,
+                                        N, P, C, G, relu, stream);
+}
+
+extern "C" int mrdis_groupnorm_relu_bwd_add(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta,
+                                            const float* save_mean, const float* save_rstd, float* dx, int lddx,
+                                            float* dgamma, float* dbeta, const float* add, int ldadd, void* workspace, size_t workspace_bytes,
+                                            int N, long long P, int C, int G, int relu, void* stream) {
     if (!dy || !x || !gamma || !beta || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || N <= 0 || P <= 0)
         return MRDIS_EINVAL;
     if (!gn_ok(C, G, ldx, lddx) || lddy % 4 != 0 || ldx < C || lddx < C || lddy < C) return MRDIS_EUNSUPPORTED;
-    if ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)workspace) & 15) != 0) return MRDIS_EALIGN;
+    if (add && (ldadd % 4 != 0 || ldadd < C)) return MRDIS_EUNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)add) & 15) != 0) return MRDIS_EALIGN;
     if (workspace_bytes < mrdis_groupnorm_workspace(N, P, C, G)) return MRDIS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = gn_chunks(P);
@@ -275,7 +287,7 @@ extern "C" int mrdis_groupnorm_relu_bwd(const float* dy, int lddy, const float* 
     MRDIS_CHECK_LAUNCH();
     int rpb; const int nb = gn_row_blocks(P, C, N, 2, &rpb);
     MRDIS_LAUNCH(gn_bwd_apply_kernel, dim3(nb, N), dim3(256), 0, s, dy, lddy, x, ldx, dx, lddx,
-                       gamma, beta, save_mean, save_rstd, coef, P, C, G, rpb, relu ? 1 : 0);
+                       gamma, beta, save_mean, save_rstd, coef, P, C, G, rpb, relu ? 1 : 0, add, ldadd);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

@@ -99,6 +99,7 @@ _SIGS = {
     'mrdis_groupnorm_workspace': (_Z, [_I, _L, _I, _I]),
     'mrdis_groupnorm_relu_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _Z, _I, _L, _I, _I, _F, _I, _P]),
     'mrdis_groupnorm_relu_bwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _I, _L, _I, _I, _I, _P]),
+    'mrdis_groupnorm_relu_bwd_add': (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _I, _L, _I, _I, _I, _P]),
     'mrdis_upsample2x_add_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mrdis_upsample2x_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
 }
@@ -1176,9 +1177,14 @@ def groupnorm_relu_fwd(x, gamma, beta, G, eps, relu):
     return y, mean, rstd
 
 
-def groupnorm_relu_bwd(dy, x, gamma, beta, mean, rstd, G, relu):
+def groupnorm_relu_bwd(dy, x, gamma, beta, mean, rstd, G, relu, add=None):
+    """add: a second gradient of x (same shape), summed into dx by the same pass (include/mrdis.h mrdis_groupnorm_relu_bwd_add)"""
     x, ld = ndhwc(x)
     dy, lddy = ndhwc(dy)
+    ldadd = 0
+    if add is not None:
+        add, ldadd = ndhwc(add)
+        assert tuple(add.shape) == tuple(x.shape)
     N, C, D, H, W = x.shape
     P = D * H * W
     dx = empty_ndhwc(N, C, D, H, W, x.device)
@@ -1186,9 +1192,9 @@ def groupnorm_relu_bwd(dy, x, gamma, beta, mean, rstd, G, relu):
     dbeta = torch.empty_like(dgamma)
     lib = load()
     ws = _ws(lib.mrdis_groupnorm_workspace(N, P, C, G), x.device)
-    _chk(lib.mrdis_groupnorm_relu_bwd(dy.data_ptr(), lddy, x.data_ptr(), ld, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                                      rstd.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      N, P, C, G, int(relu), _stream()), 'groupnorm_relu_bwd')
+    _chk(lib.mrdis_groupnorm_relu_bwd_add(dy.data_ptr(), lddy, x.data_ptr(), ld, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), dx.data_ptr(), C, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(add), ldadd, ws.data_ptr(), ws.numel(),
+                                          N, P, C, G, int(relu), _stream()), 'groupnorm_relu_bwd')
     return dx, dgamma, dbeta
 
 
