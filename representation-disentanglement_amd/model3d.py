@@ -15,6 +15,8 @@ from torch.autograd import Function
 
 from . import hip, ops
 
+_GN_TAP = __import__('os').environ.get('MRDIS_GN_TAP', '1') != '0'      # BasicBlock: residual gradient summed inside the GroupNorm backward (0: autograd's add)
+
 
 # --------------------------------------------------------------------------- autograd pairing
 class _Conv3d(Function):
@@ -142,7 +144,7 @@ class BasicBlock(nn.Module):
         self.conv2 = HipConv3d(out_channels, out_channels, kernel_size=(3, 3, 3), padding=(1, 1, 1))
 
     def forward(self, x):
-        if x.requires_grad and torch.is_grad_enabled():
+        if _GN_TAP and x.requires_grad and torch.is_grad_enabled():
             g, x = groupnorm_relu_tap(x, self.gn1)                         # the residual path's gradient joins the branch's inside the GroupNorm backward
         else:
             g = groupnorm_relu(x, self.gn1)

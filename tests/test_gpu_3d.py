@@ -389,3 +389,27 @@ def test_conv3d_weight_gradient_six_product_channel_slices(mrdis, N, Ci, Co, D, 
         e0, e1 = float((out[0][k] - ref).abs().max()) / scale, float((out[1][k] - ref).abs().max()) / scale
         assert float((out[0][k] - out[1][k]).abs().max()) / scale <= 2e-5, name
         assert e1 <= max(2.0 * e0, 5e-7), (name, e1, e0)
+
+
+def test_basic_block_residual_gradient_inside_the_groupnorm_backward(mrdis):
+    """BasicBlock (model.py:1856-1876): x feeds gn1 and the residual addition.  With MRDIS_GN_TAP (default) both gradients of x are summed inside the GroupNorm
+    backward pass (mrdis_groupnorm_relu_bwd_add) instead of by autograd's extra add: every gradient must be BIT-IDENTICAL to the two-step form."""
+    m3 = mrdis.model3d
+    torch.manual_seed(3)
+    blk = mrdis.BasicBlock(16, 16).to(DEV)
+    x = cl3(seeded((2, 16, 12, 20, 24), 1)); dy = cl3(seeded((2, 16, 12, 20, 24), 2))
+    res = {}
+    for tap in (False, True):
+        m3._GN_TAP = tap
+        try:
+            xg = x.clone().requires_grad_(True)
+            pre = xg * 1.0                                   # (a non-leaf input, as inside the network)
+            y = blk(pre)
+            y.backward(dy)
+            res[tap] = (y.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+            blk.zero_grad()
+        finally:
+            m3._GN_TAP = True
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    for a, b in zip(res[False][2], res[True][2]):
+        assert torch.equal(a, b)
