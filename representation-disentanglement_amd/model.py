@@ -166,6 +166,13 @@ def flush_batch_counters():
     _BN_PENDING.clear()
 
 
+def discard_batch_counters():
+    """forget the pending counter increments (a graph recording that failed half-way ran forward code whose kernels never executed)"""
+    for m in list(_BN_PENDING):
+        m._nbt_pending = 0
+    _BN_PENDING.clear()
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d; training-mode forward/backward in HIP."""
 

@@ -17,7 +17,7 @@ import torch.distributed as dist
 import yaml
 
 from . import hip, ops
-from .model import MultimodalModel, flush_batch_counters
+from .model import MultimodalModel, flush_batch_counters, discard_batch_counters
 
 # config.yaml of the reference, verbatim keys and defaults (src/config.yaml:1-91)
 DEFAULT_CONFIG = {
@@ -872,7 +872,18 @@ class GraphedTrainStep:
             if n < self.warm:                    # eager, on the capture stream: workspaces, plans and caches reach their final size there
                 self.stats['eager'] += 1
                 return self._eager(x, m, mi, mask_host, tg, do_step, side=self.stream)
-            group = self.entries[key] = self._record_all(x, m, mi, mask_host, tg, do_step, pairs)
+            try:
+                group = self._record_all(x, m, mi, mask_host, tg, do_step, pairs)
+            except Exception as ex:                  # noqa: BLE001 -- a step that cannot be recorded (host-value block full, an op that refuses capture) trains eagerly
+                import warnings
+                warnings.warn(f'GraphedTrainStep: recording failed ({type(ex).__name__}: {ex}); this configuration runs eagerly from here on')
+                torch.cuda.synchronize()
+                discard_batch_counters()
+                group = 'eager'
+            self.entries[key] = group
+        if group == 'eager':
+            self.stats['eager'] += 1
+            return self._eager(x, m, mi, mask_host, tg, do_step)
         ent = group[pairs.get('adv_s')]
         ops.set_step_mask_host(mask_host)
         ent['hv'].refill()                       # eps and the mask weights of THIS step (the closures draw from the global torch generator in the recorded order)

@@ -109,3 +109,20 @@ def test_graph_replay_with_the_exchange_between_two_graphs(mrdis):
     finally:
         torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_a_step_that_cannot_be_recorded_trains_eagerly(mrdis):
+    """a recording that raises half-way (here: the host-value block is made too small) must leave the step usable: the configuration falls back to eager
+    iterations with the same results, the generators and the BatchNorm counters untouched by the aborted recording."""
+    ref_w, ref_b, ref_l, _, _ = _run(mrdis, False, 4, 16, 8)
+    cap = mrdis.ops.HostValues.CAP
+    mrdis.ops.HostValues.CAP = 64
+    try:
+        with pytest.warns(UserWarning, match='recording failed'):
+            got_w, got_b, got_l, _, step = _run(mrdis, True, 4, 16, 8, warm=1)
+    finally:
+        mrdis.ops.HostValues.CAP = cap
+    assert step.stats['captures'] == 0 and step.stats['replays'] == 0 and step.stats['eager'] == 4
+    assert got_l == ref_l and torch.equal(ref_w, got_w) and torch.equal(ref_b, got_b)
