@@ -198,7 +198,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                 const float dz = (relu && !(xh * ga[k] + be[k] > 0.f)) ? 0.f : dv[k];
                 o[k] = rs[k] * (dz * ga[k] - c1[k] - xh * c2[k]);
             }
-            *reinterpret_cast<float4*>(dxb + rr * lddx) = adb ? make_float4(o[0] + ad[u].x, o[1] + ad[u].y, o[2] + ad[u].z, o[3] + ad[u].w) : make_float4(o[0], o[1], o[2], o[3]);
+            if (adb) {
+                // the sum must round exactly as autograd's separate add does: hipcc (-ffp-contract=fast) would fuse the multiply above with this add into an
+                // FMA (one rounding instead of two; __fadd_rn is contracted as well) -- the empty asm makes the product opaque first
+#pragma unroll
+                for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(o[k]));
+                *reinterpret_cast<float4*>(dxb + rr * lddx) = make_float4(o[0] + ad[u].x, o[1] + ad[u].y, o[2] + ad[u].z, o[3] + ad[u].w);
+            } else {
+                *reinterpret_cast<float4*>(dxb + rr * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
 }
