@@ -941,6 +941,8 @@ class GraphedTrainStep:
             variants = [(i, j) for i in range(M) for j in range(M) if i != j]
         pool = torch.cuda.graph_pool_handle()
         rng = (torch.get_rng_state(), np.random.get_state())
+        ts = self.step
+        counts = (ts.optimizer.step_count, None if ts.optimizer_d_s is None else ts.optimizer_d_s.step_count)      # host-side call counters: recording is not stepping
         group = {}
         try:
             for v in variants:
@@ -950,6 +952,9 @@ class GraphedTrainStep:
         finally:
             ops.set_forced_pairs(pairs)
             torch.set_rng_state(rng[0]); np.random.set_state(rng[1])
+            ts.optimizer.step_count = counts[0]
+            if ts.optimizer_d_s is not None:
+                ts.optimizer_d_s.step_count = counts[1]
         return group
 
     def _record(self, x, m, mi, mask_host, tg, do_step, pool):
