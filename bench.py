@@ -705,7 +705,11 @@ def main():
         out['host_enqueue_note'] = 'host time inside step() during the timed region: mostly waiting on the full launch queue (the step is GPU-bound); host_ms_unblocked is the cost proper'
         if world == 1 and not a.no_roofline:
             out['host_ms_unblocked'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv)
-            out['host_ms_unblocked_graph'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv, graph=True)
+            try:
+                out['host_ms_unblocked_graph'] = host_unblocked_ms(mrdis, cfg, dev, B, M, adv, graph=True)
+            except Exception as ex:                 # noqa: BLE001 -- an extra leg must not take the headline down
+                out['host_ms_unblocked_graph'] = None
+                out['host_ms_unblocked_graph_error'] = f'{type(ex).__name__}: {ex}'[:200]
             log(f'host_ms_unblocked: {out["host_ms_unblocked"]} ms/step')
         out['dynamic_lds_bytes'] = mrdis.hip.dynamic_lds()         # per kernel family: what rocprofv3's LDS column cannot show (tools/prof_summary.py merges it in)
         if ddp is not None:
