@@ -114,3 +114,33 @@ def test_ten_steps_from_yaml_then_resume(m, tmp_path):
     assert run2.scheduler.state_dict()['last_epoch'] == run.scheduler.state_dict()['last_epoch'] == 2
     got_p, got_md = four_more(run2)
     assert torch.equal(want_p, got_p) and torch.equal(want_md, got_md)
+
+
+@pytest.mark.gpu
+def test_entry_point_with_graph_replay_trains_the_same_weights(m, tmp_path):
+    """`graph: true` in config.yaml (or MRDIS_GRAPH=1): the entry point's steady-state iterations are HIP-graph replays (trainer.GraphedTrainStep) -- epochs,
+    validation passes (model.eval() / train() around them), the accumulation schedule (accum = 4) and the checkpoints in between; weights, Adam moments and
+    the per-epoch statistics must equal the eager run's bit for bit."""
+    dev = torch.device('cuda:0')
+    res = {}
+    for graph in (False, True):
+        root = tmp_path / ('g' if graph else 'e')
+        root.mkdir()
+        base = dict(contrast_list=['T1', 'T2', 'T2_FLAIR'], input_height=64, input_width=96, batch_size=8, epochs=2, gpu='0', graph=graph,
+                    data_source='synthetic', ckpt_root=str(root / 'ckpt'), ckpt_timelabel='t0', lambda_adv_s=1.0, shuffle=True)
+        (root / 'config.yaml').write_text(yaml.dump(base))
+        cfg = m.train.setup_config(str(root / 'config.yaml'), device=dev)
+        run = m.train.Run(cfg, log=lambda *a: None)
+        assert isinstance(run.step, m.GraphedTrainStep) == graph and run.step.accum == 2
+        run.train(max_iters_per_epoch=8)
+        torch.cuda.synchronize()
+        rows = open(os.path.join(cfg['ckpt_path'], 'stat.csv')).read().strip().split('\n')
+        res[graph] = (run.optimizer.flat_p.clone(), run.optimizer.m.clone(), run.optimizer_d_s.v.clone(), rows,
+                      torch.cat([b.detach().float().reshape(-1) for b in run.model.buffers()]).clone())
+        if graph:
+            st = run.step.stats
+            assert st['replays'] >= 8 and st['captures'] == 2 * 6, st          # two configurations (accumulate / step) x 6 ordered adv_s pairs (M = 3)
+    for a, b in zip(res[False][:3], res[True][:3]):
+        assert torch.equal(a, b)
+    assert res[False][3] == res[True][3]
+    assert torch.equal(res[False][4], res[True][4])
