@@ -1164,11 +1164,18 @@ class MultimodalModel(nn.Module):
             mm_h = m[:, i] * m[:, j] * np.concatenate([m[1:, i], m[0:1, i]], 0)
             return torch.from_numpy((mm_h / float(mm_h.sum())).astype(np.float32))
         if ops.recording_host_values():
-            # the drawn pair is DATA of the recorded step: pool every map, pick rows i, j on the device (trainer.GraphedTrainStep only records
-            # steps whose mask leaves no (i, j) term empty, so the branch below is the same for every pair)
-            sel = ops.host_value(draw, self.device)
+            # the drawn pair is DATA of the recorded step: pool every map and pick rows i, j with one-hot weights from the host (trainer.GraphedTrainStep only
+            # records steps whose mask leaves no (i, j) term empty, so the branch below is the same for every pair).  1 * x + 0 * y + 0 * z is x bit for bit, and
+            # only multiplies / sums are recorded: torch's index_select / index_add_ pair gave garbage gradients from the second replay on (ROCm 7.0, round 6)
+            def onehots():
+                draw()
+                oh = np.zeros((2, M), dtype=np.float32)
+                oh[0, st['ij'][0]] = 1.0; oh[1, st['ij'][1]] = 1.0
+                return torch.from_numpy(oh)
+            oh = ops.host_value(onehots, self.device)                              # (2, M)
             C = torch.stack([self.compute_compact_s(s) for s in si_list])         # (M, B, D)
-            si_c, sj_c = C.index_select(0, sel[0:1])[0], C.index_select(0, sel[1:2])[0]
+            si_c = (oh[0].reshape(M, 1, 1) * C).sum(0)
+            sj_c = (oh[1].reshape(M, 1, 1) * C).sum(0)
         else:
             draw()
             i, j = st['ij']

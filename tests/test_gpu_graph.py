@@ -126,3 +126,42 @@ def test_a_step_that_cannot_be_recorded_trains_eagerly(mrdis):
         mrdis.ops.HostValues.CAP = cap
     assert step.stats['captures'] == 0 and step.stats['replays'] == 0 and step.stats['eager'] == 4
     assert got_l == ref_l and torch.equal(ref_w, got_w) and torch.equal(ref_b, got_b)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('M', [3, 4])
+def test_graph_replay_with_repeated_and_changing_pairs(mrdis, M):
+    """the sim_s / adv_s pairs handed in by the wrapper: the SAME pair several iterations in a row (a first form that selected the sim_s rows with
+    index_select passed with ever-changing pairs and gave garbage gradients from the second replay with a repeated pair), then every adv_s recording in
+    turn, against the eager step with the same pairs: losses and weights bit-identical."""
+    ops = mrdis.ops
+    pairs_seq = [((1, 2), (0, 1))] * 4 + [((0, 2), (2, 1)), ((0, 2), (2, 1)), ((2, 0), (1, 0)), ((0, 1), (0, 2)), ((1, 0), (1, 2)), ((1, 2), (2, 0))]
+    res = {}
+    for graph in (False, True):
+        cfg = dict(mrdis.DEFAULT_CONFIG)
+        cfg.update(contrast_list=[f'm{i}' for i in range(M)], input_height=64, input_width=96, batch_size=16, lambda_adv_s=1.0)
+        cfg = mrdis.derive_config(cfg, DEV)
+        torch.manual_seed(10); np.random.seed(10)
+        model = mrdis.build_model(cfg).train()
+        base = mrdis.TrainStep(model, cfg)
+        step = mrdis.GraphedTrainStep(base, warm=1) if graph else base
+        torch.manual_seed(100); np.random.seed(100)
+        out = []
+        for k, (ps, pa) in enumerate(pairs_seq):
+            x, mask, mask_img = mrdis.synthetic_batch(8, M, 64, 96, seed=60 + k)
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+            pairs = {'sim_s': ps, 'adv_s': pa}
+            if graph:
+                step._predraw = lambda p=pairs: dict(p)
+                loss, _, _ = step(xd, mask.to(DEV), mask_img.to(DEV), mask)
+            else:
+                ops.set_forced_pairs(pairs)
+                try:
+                    loss, _, _ = step(xd, mask.to(DEV), mask_img.to(DEV), mask)
+                finally:
+                    ops.set_forced_pairs(None)
+            out.append((float(loss), float(base.optimizer.flat_p.double().abs().sum()), float(base.last_grad_norm_sq[0])))
+        res[graph] = (out, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    assert res[False][0] == res[True][0], [a == b for a, b in zip(res[False][0], res[True][0])]
+    assert torch.equal(res[False][1], res[True][1])
