@@ -1723,11 +1723,20 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int ldx, float* 
     }
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, float* __restrict__ dx, int lddx, int N, int H, int W,
-                                   int C, int Ho, int Wo) {
-    EW_LOOP((long long)N * Ho * Wo * C) {
-        const int c = (int)(idx % C); const long long r = idx / C;
-        const int n = (int)(r / ((long long)Ho * Wo));
-        dx[((long long)n * H * W + arg[idx]) * lddx + c] = dy[idx];    // windows are disjoint: no atomics
+                                   int C, int k, int Ho, int Wo) {
+    // one thread per element of dx: dy of its window where it was the maximum, 0 elsewhere and in the rows / columns the floor leaves out.  Every element
+    // is written by exactly one thread: no memset in front (a hipMemsetAsync node recorded into a HIP graph did not run again on later replays, round 6)
+    EW_LOOP((long long)N * H * W * C) {
+        const int c = (int)(idx % C); long long r = idx / C;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const int n = (int)(r / H);
+        const int ho = h / k, wo = w / k;
+        float v = 0.f;
+        if (ho < Ho && wo < Wo) {
+            const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + c;
+            if (arg[o] == h * W + w) v = dy[o];
+        }
+        dx[((long long)n * H * W + (long long)h * W + w) * lddx + c] = v;
     }
 }
 extern "C" int mrdis_maxpool_fwd(const float* x, int ldx, float* y, int32_t* argmax, int N, int H, int W, int C,
@@ -1743,10 +1752,8 @@ extern "C" int mrdis_maxpool_bwd(const float* dy, const int32_t* argmax, float* 
     if (!dy || !argmax || !dx || N < 1 || C < 1 || k < 1 || H < k || W < k) return MRDIS_EINVAL;
     const int Ho = H / k, Wo = W / k;
     hipStream_t s = (hipStream_t)stream;
-    // dx is a dense (N,H,W,C) view: zero it first (async, capture-safe)
-    if (lddx == C) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, s) != hipSuccess) return MRDIS_ELAUNCH; }
-    else return MRDIS_EUNSUPPORTED;
-    MRDIS_LAUNCH(maxpool_bwd_kernel, dim3(ew_blocks((long long)N * Ho * Wo * C)), dim3(256), 0, s, dy, argmax, dx, lddx, N, H, W, C, Ho, Wo);
+    if (lddx < C) return MRDIS_EINVAL;
+    MRDIS_LAUNCH(maxpool_bwd_kernel, dim3(ew_blocks((long long)N * H * W * C)), dim3(256), 0, s, dy, argmax, dx, lddx, N, H, W, C, k, Ho, Wo);
     MRDIS_CHECK_LAUNCH();
     return MRDIS_OK;
 }

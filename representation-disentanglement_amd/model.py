@@ -1165,8 +1165,8 @@ class MultimodalModel(nn.Module):
             return torch.from_numpy((mm_h / float(mm_h.sum())).astype(np.float32))
         if ops.recording_host_values():
             # the drawn pair is DATA of the recorded step: pool every map and pick rows i, j with one-hot weights from the host (trainer.GraphedTrainStep only
-            # records steps whose mask leaves no (i, j) term empty, so the branch below is the same for every pair).  1 * x + 0 * y + 0 * z is x bit for bit, and
-            # only multiplies / sums are recorded: torch's index_select / index_add_ pair gave garbage gradients from the second replay on (ROCm 7.0, round 6)
+            # records steps whose mask leaves no (i, j) term empty, so the branch below is the same for every pair).  1 * x + 0 * y + 0 * z is x bit for bit
+            # and the unselected maps receive exact zeros, as in the eager step
             def onehots():
                 draw()
                 oh = np.zeros((2, M), dtype=np.float32)

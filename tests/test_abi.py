@@ -93,3 +93,18 @@ def test_option_and_counter_tables_match_the_library(mrdis):
     import ctypes
     tiny = ctypes.create_string_buffer(4)
     assert lib.mrdis_dynamic_lds_table(tiny, 4) >= 0 and b'=' not in tiny.value.replace(b'\n', b'')[:0]
+
+
+def test_library_issues_no_memset_or_memcpy_calls():
+    """the training step is recorded into HIP graphs (trainer.GraphedTrainStep): a hipMemsetAsync node did not run again on later replays (round 6, max_pool
+    backward), so device buffers are cleared / copied by kernels only"""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'representation-disentanglement_amd', 'csrc')
+    bad = []
+    for f in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
+        for n, line in enumerate(open(f), 1):
+            code = line.split('//')[0]
+            if re.search(r'hipMem(set|cpy)\w*\s*\(', code):
+                bad.append(f'{os.path.basename(f)}:{n}')
+    assert not bad, bad

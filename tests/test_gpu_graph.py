@@ -132,9 +132,10 @@ def test_a_step_that_cannot_be_recorded_trains_eagerly(mrdis):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('M', [3, 4])
 def test_graph_replay_with_repeated_and_changing_pairs(mrdis, M):
-    """the sim_s / adv_s pairs handed in by the wrapper: the SAME pair several iterations in a row (a first form that selected the sim_s rows with
-    index_select passed with ever-changing pairs and gave garbage gradients from the second replay with a repeated pair), then every adv_s recording in
-    turn, against the eager step with the same pairs: losses and weights bit-identical."""
+    """the sim_s / adv_s pairs handed in by the wrapper: the SAME pair several iterations in a row, then other adv_s recordings in turn, against the eager
+    step with the same pairs: losses, gradient norms and weights bit-identical.  (Found by the entry-point test: max_pool's backward zeroed dx with
+    hipMemsetAsync, and that memset node did not run again on later replays of a recorded graph -- garbage gradients from the second replay on.  The
+    kernel now writes every element of dx itself; no memset / memcpy call is left in the library.)"""
     ops = mrdis.ops
     pairs_seq = [((1, 2), (0, 1))] * 4 + [((0, 2), (2, 1)), ((0, 2), (2, 1)), ((2, 0), (1, 0)), ((0, 1), (0, 2)), ((1, 0), (1, 2)), ((1, 2), (2, 0))]
     res = {}
