@@ -794,7 +794,7 @@ class GraphedTrainStep:
     eager step, host draws model.py:3159-3162, 3485), ships them with one copy kernel, copies the batch into the static input
     buffers and launches the graph -- ~1.5 ms of host time instead of 45-70.  The adv_s pair picks two anatomy maps, i.e. which
     kernels run: it is drawn here, before the launch, and there is one recording per ordered pair (12 for M = 4, all made at the
-    first recording, in one memory pool); the sim_s pair is data of the graph (every map is pooled, rows i, j picked on the device).
+    first recording, in one memory pool); the sim_s pair is data of the graph (every map is pooled, rows i, j picked by one-hot weights).
     A batch whose mask would prune a loss term (regular_mask() false: a modality absent from the whole batch ...) runs as an
     eager step, as does everything before the recording.  Results are bit-identical to the eager TrainStep
     (tests/test_gpu_graph.py); the third return value (aux: the step's activations) is None on replayed steps.
