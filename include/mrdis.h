@@ -221,6 +221,15 @@ long long mrdis_wino_u_image_floats_fmt(int R, int S, int spadeC, int fmt);
 int mrdis_wino_u_job_blocks(int R, int S, int spadeC);
 int mrdis_wino_u_jobs(const void* jobs, int njobs, int total_blocks, void* stream);
 
+/* Six-product filter image (option split6; mrdis_s6conv.hip): the layers without a Winograd form -- the 4x4 / 3x3 stride-2 convolutions of the encoders,
+ * F.conv2d at model.py:2104 -- multiply on the bf16 matrix pipe with both fp32 operands split into three bf16 terms (the six products of order <= 2,
+ * fp32 accumulation: fp32-equivalent results).  The filter is split ONCE into this image; the convolution entry points take it through their w_wino
+ * argument with w_wino_fmt = 6 (fp32 views only; without it, or where the geometry does not fit, the fp32 MFMA kernels run).
+ * w = [taps][Cred][Cout] fp32: role forward: w_tck (Cred = Ci, Cout = Co); role data gradient: w_tkc (Cred = Co, Cout = Ci).
+ * image: mrdis_s6_filter_image_bytes(taps, Cred, Cout) bytes, 16-byte aligned (0: Cred is not a multiple of 8).                                  */
+size_t mrdis_s6_filter_image_bytes(int taps, int Cred, int Cout);
+int mrdis_s6_filter_image(const float* w, int taps, int Cred, int Cout, void* image, size_t image_bytes, void* stream);
+
 /* data gradient (autograd convolution_backward, input part).
  * dy view (N,Ho,Wo,Co) ld=lddy -> dx view (N,H,W,Ci) ld=lddx ; w_tkc layout. */
 int mrdis_conv2d_bwd_data(const void* dy, int lddy, const float* w_tkc, const void* w_bf16_tck,

@@ -29,7 +29,7 @@ void mrdis_opt_note(int id, long long value);      // diagnostics a launcher lea
 // (mrdis_launch_count("wino4") ...; mrdis_elem.hip).
 enum { MRDIS_CNT_WINO, MRDIS_CNT_WINO_SPADE, MRDIS_CNT_WINO2, MRDIS_CNT_WINO2_SPADE, MRDIS_CNT_WINO4, MRDIS_CNT_WINO4_SPADE, MRDIS_CNT_WINO4N, MRDIS_CNT_WINO4R,
        MRDIS_CNT_WINO_WGRAD, MRDIS_CNT_WINO_WGRAD2, MRDIS_CNT_WINO4_WGRAD, MRDIS_CNT_BCONV3, MRDIS_CNT_BCONV3_SPADE, MRDIS_CNT_BCONV4, MRDIS_CNT_BCONV4_SPADE,
-       MRDIS_CNT_SPLIT6_C4, MRDIS_CNT_SPLIT6_C16, MRDIS_CNT_SPLIT6_WGRAD16, MRDIS_CNT_SPLIT6_CO4, MRDIS_CNT_SPLIT6_C3D, MRDIS_CNT_SPLIT6_W3D,
+       MRDIS_CNT_SPLIT6_C4, MRDIS_CNT_SPLIT6_C16, MRDIS_CNT_SPLIT6_WGRAD16, MRDIS_CNT_SPLIT6_CO4, MRDIS_CNT_SPLIT6_C3D, MRDIS_CNT_SPLIT6_W3D, MRDIS_CNT_SPLIT6_TAP,
        MRDIS_CNT_ALL /* every launch of the library */, MRDIS_CNT_COUNT };
 void mrdis_count(int id);
 

@@ -27,6 +27,7 @@
 // fixed order by a second kernel (bit-reproducible, no float atomics).
 #include "mrdis_common.h"
 #include "mrdis_tapconv.h"
+#include "mrdis_s6conv.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -667,7 +668,7 @@ static int launch_tapconv_t(const TapConvParams& p, size_t lds, int nblk, int BM
 }
 
 // a planned (not yet launched) tapconv_kernel launch: run_tapconv fills it instead of launching when asked to
-struct TapLaunch { TapConvParams p; int KC, BN, BM, nblk; size_t lds; bool set; BConvLaunch b; };
+struct TapLaunch { TapConvParams p; int KC, BN, BM, nblk; size_t lds; bool set; BConvLaunch b; S6ConvLaunch s6; };
 template <int KC, int BN>
 static int launch_tapconv_pack_t(const TapLaunch (&L)[4], hipStream_t s) {
     TapConvPack pk;
@@ -687,7 +688,7 @@ static size_t tapconv_lds(const TapConvParams& p, int KC, int BN, int BM = TC_BM
 
 // fills tiling fields and launches.  `p` must have geometry + taps set.
 static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullptr) {
-    if (defer) { defer->set = false; defer->b.set = false; }
+    if (defer) { defer->set = false; defer->b.set = false; defer->s6.set = false; }
     if (p.ntaps < 1 || p.ntaps > MRDIS_MAX_TAPS) return MRDIS_EUNSUPPORTED;
     if (p.A <= 0 || p.B <= 0 || p.N <= 0) return MRDIS_OK;   // empty launch
     int dh_max = p.dh[0], dw_max = p.dw[0];
@@ -703,6 +704,10 @@ static int run_tapconv(TapConvParams p, hipStream_t s, TapLaunch* defer = nullpt
         if (rc != MRDIS_EUNSUPPORTED || p.dtype == MRDIS_DT_BF16) return rc;         // bf16 views never reach the fp32 kernels
     }
     if (p.dtype == MRDIS_DT_BF16) return MRDIS_EUNSUPPORTED;
+    if (p.dtype == MRDIS_DT_F32 && p.s6_img) {     // fp32 operands as three bf16 terms on the bf16 matrix pipe (option split6; mrdis_s6conv.hip): the caller brought the filter image
+        const int rc = mrdis_run_s6conv(p, p.s6_img, p.s6_taps, dh_max, dw_max, s, defer ? &defer->s6 : nullptr);
+        if (rc != MRDIS_EUNSUPPORTED) return rc;
+    }
     TileChoice tc = choose_tile(p.N, p.A, p.B);
     bool small_map = false;
     // small maps with many channels (the 16x16 / 8x8 levels of the encoders: 2048 output positions, K = 16 taps x 256 channels): 128-position
@@ -1462,6 +1467,8 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
                                 void* y_, int ldy, int N, int H, int W, int Ci, int Co,
                                 int kh, int kw, int stride, int pad, int epilogue, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (dtype < MRDIS_DT_F32 || dtype > MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
+    const void* s6_img = nullptr;                  // w_wino_fmt 6: not a Winograd image but the six-product image of w_tck (mrdis_s6_filter_image): the layer goes to mrdis_s6conv.hip
+    if (w_wino && w_wino_fmt == MRDIS_S6_IMAGE_FMT) { s6_img = dtype == MRDIS_DT_F32 ? w_wino : nullptr; w_wino = nullptr; w_wino_fmt = 0; }
     const float* x = reinterpret_cast<const float*>(x_); float* y = reinterpret_cast<float*>(y_);   // bf16 views when dtype == MRDIS_DT_BF16
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
@@ -1499,7 +1506,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
         rc = mrdis_run_c16(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
-    if (!bf && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
+    if (!bf && !s6_img && wino_wanted(N, H, W, Ci, Co, kh, kw, stride, pad)) {
         rc = run_wino(x, ldx, w_tck, bias, y, ldy, N, H, W, Ci, Co, 0, (epilogue & MRDIS_EPI_LRELU) ? 1 : 0, (hipStream_t)stream, w_wino, w_wino_fmt);
         if (rc != MRDIS_EUNSUPPORTED) return rc;
     }
@@ -1516,6 +1523,7 @@ extern "C" int mrdis_conv2d_fwd(const void* x_, int ldx, const float* w_tck, con
         }
     p.epilogue = epilogue;
     p.w_bf16 = bf ? w_bf16_tkc : nullptr; p.dtype = dtype;
+    p.s6_img = s6_img; p.s6_taps = kh * kw;
     return run_tapconv(p, (hipStream_t)stream);
 }
 
@@ -1523,6 +1531,8 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
                                      void* dx_, int lddx, int N, int H, int W, int Ci, int Co,
                                      int kh, int kw, int stride, int pad, int dtype, const float* w_wino, int w_wino_fmt, void* stream) {
     if (dtype != MRDIS_DT_F32 && dtype != MRDIS_DT_F32_BF16M && dtype != MRDIS_DT_BF16 && dtype != MRDIS_DT_XBF16_YF32 && dtype != MRDIS_DT_XF32_YBF16) return MRDIS_EUNSUPPORTED;
+    const void* s6_img = nullptr;                  // w_wino_fmt 6: the six-product image of w_tkc (reduction over Co, Ci output channels)
+    if (w_wino && w_wino_fmt == MRDIS_S6_IMAGE_FMT) { s6_img = dtype == MRDIS_DT_F32 ? w_wino : nullptr; w_wino = nullptr; w_wino_fmt = 0; }
     const float* dy = reinterpret_cast<const float*>(dy_); float* dx = reinterpret_cast<float*>(dx_);
     const bool st_bf16 = dtype == MRDIS_DT_BF16;
     int Ho, Wo;
@@ -1554,6 +1564,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
     base.N = N; base.Hin = Ho; base.Win = Wo; base.Cin = Co; base.ldin = lddy;
     base.Hout = H; base.Wout = W; base.Cout = Ci; base.ldout = lddx;
     base.is = 1; base.epilogue = 0;
+    base.s6_img = s6_img; base.s6_taps = kh * kw;
     const bool bf = bf16m_wanted(dtype, w_bf16_tck, Co, Ci);      // the data gradient reduces over Co and produces Ci channels
     if (st_bf16 && !bf) return MRDIS_EUNSUPPORTED;
     base.w_bf16 = bf ? w_bf16_tck : nullptr; base.dtype = dtype;
@@ -1575,7 +1586,7 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
             rc = mrdis_run_c16t_split6(dy, lddy, w_tkc, dx, lddx, N, H, W, 1, (hipStream_t)stream);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
-        if (!bf && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
+        if (!bf && !s6_img && wino_wanted(N, H, W, Co, Ci, kh, kw, stride, pad)) {
             rc = run_wino(dy, lddy, w_tkc, nullptr, dx, lddx, N, H, W, Co, Ci, 1, 0, (hipStream_t)stream, w_wino, w_wino_fmt);
             if (rc != MRDIS_EUNSUPPORTED) return rc;
         }
@@ -1619,6 +1630,16 @@ extern "C" int mrdis_conv2d_bwd_data(const void* dy_, int lddy, const float* w_t
                 BConvLaunch LB[4];
                 for (int k = 0; k < 4; ++k) LB[k] = L[k].b;
                 rc = mrdis_launch_bconv_planned(LB, (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        }
+        {   // classes planned for the six-product kernel
+            bool any = false;
+            for (int k = 0; k < 4; ++k) any = any || L[k].s6.set;
+            if (any) {
+                S6ConvLaunch LS[4];
+                for (int k = 0; k < 4; ++k) LS[k] = L[k].s6;
+                rc = mrdis_launch_s6conv_planned(LS, (hipStream_t)stream);
                 if (rc) return rc;
             }
         }

@@ -1983,7 +1983,7 @@ extern "C" long long mrdis_get_option(const char* name) {
 namespace {
 const char* const CNT_NAMES[MRDIS_CNT_COUNT] = {"wino", "wino_spade", "wino2", "wino2_spade", "wino4", "wino4_spade", "wino4n", "wino4r",
                                                 "wino_wgrad", "wino_wgrad2", "wino4_wgrad", "bconv3", "bconv3_spade", "bconv4", "bconv4_spade",
-                                                "split6_c4", "split6_c16", "split6_wgrad16", "split6_co4", "split6_c3d", "split6_w3d", "all"};
+                                                "split6_c4", "split6_c16", "split6_wgrad16", "split6_co4", "split6_c3d", "split6_w3d", "split6_tap", "all"};
 long long g_counts[MRDIS_CNT_COUNT];
 }  // namespace
 void mrdis_count(int id) { __atomic_fetch_add(&g_counts[id], 1LL, __ATOMIC_RELAXED); }

@@ -18,6 +18,7 @@ struct TapConvParams {
     int prefetch;                 // staging mode of tapconv_kernel: 0 generic | 1 hoisted descriptors + register prefetch
     const void* w_bf16;           // bf16 filter with the REDUCTION axis contiguous, [tap][Cout][Cin] of this launch (or nullptr)
     int dtype;                    // MRDIS_DT_*
+    const void* s6_img; int s6_taps;      // six-product filter image of this launch's filter (mrdis_s6_filter_image) and its tap count, or nullptr (mrdis_s6conv.hip)
 };
 
 

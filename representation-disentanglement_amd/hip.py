@@ -48,6 +48,8 @@ _SIGS = {
     'mrdis_wino_u_job_bytes': (_Z, []),
     'mrdis_wino_u_format': (_I, [_I, _I, _I]),
     'mrdis_wino_u_image_floats': (_L, [_I, _I, _I]),
+    'mrdis_s6_filter_image_bytes': (ctypes.c_size_t, [_I, _I, _I]),
+    'mrdis_s6_filter_image': (_I, [_P, _I, _I, _I, _P, ctypes.c_size_t, _P]),
     'mrdis_wino_u_image_floats_fmt': (_L, [_I, _I, _I, _I]),
     'mrdis_wino_u_job_blocks': (_I, [_I, _I, _I]),
     'mrdis_wino_u_jobs': (_I, [_P, _I, _I, _P]),
@@ -156,7 +158,7 @@ def options_restore(snap):
 
 
 KERNEL_FAMILIES = WINO_FAMILIES = ('wino', 'wino_spade', 'wino2', 'wino2_spade', 'wino4', 'wino4_spade', 'wino4n', 'wino4r', 'wino_wgrad', 'wino_wgrad2', 'wino4_wgrad', 'bconv3', 'bconv3_spade', 'bconv4', 'bconv4_spade',
-                                   'split6_c4', 'split6_c16', 'split6_wgrad16', 'split6_co4', 'split6_c3d', 'split6_w3d',
+                                   'split6_c4', 'split6_c16', 'split6_wgrad16', 'split6_co4', 'split6_c3d', 'split6_w3d', 'split6_tap',
                                    'all')        # 'all': every kernel launch of the library (bench.py: library_launches_per_step)
 
 
@@ -380,12 +382,37 @@ def wino_u_image_floats(R, S, spadeC=0, fmt=None):
     return int(load().mrdis_wino_u_image_floats_fmt(R, S, spadeC, fmt))
 
 
-def wino_image_fmt(img, R, S, spadeC=0):
+S6_IMAGE_FMT = 6
+
+
+def s6_filter_image_bytes(taps, Cred, Cout):
+    return int(load().mrdis_s6_filter_image_bytes(int(taps), int(Cred), int(Cout)))
+
+
+def s6_filter_image(w):
+    """w [taps][Cred][Cout] fp32 (w_tck for the forward pass, w_tkc for the data gradient) -> its six-product image (mrdis_s6conv.hip), a float32-typed
+    tensor that travels in the auxiliary-filter slot of conv2d_fwd / conv2d_bwd_data (attribute mrdis_fmt = 6); None where the layer has no such image."""
+    T, R, S = w.shape
+    nb = s6_filter_image_bytes(T, R, S)
+    if nb == 0 or nb >= 2 ** 31 or w.dtype is not torch.float32:
+        return None
+    w = w.contiguous()
+    img = torch.empty(nb // 4, dtype=torch.float32, device=w.device)
+    _chk(load().mrdis_s6_filter_image(_ptr(w), T, R, S, _ptr(img), nb, _stream()), 's6_filter_image')
+    img.mrdis_fmt = S6_IMAGE_FMT
+    return img
+
+
+def wino_image_fmt(img, R, S, spadeC=0, taps=0):
     """The format a Winograd filter image was BUILT in: it travels with the image (attribute `mrdis_fmt`, set by whoever built it) and goes to
     the library beside the pointer -- never re-derived from the current value of the option 'wino4', which may have changed since.  Images
     without the attribute (tests, tools) are recognised by their size, which differs between the formats of one filter shape."""
     fmt = getattr(img, 'mrdis_fmt', None)
     n = img.numel()
+    if fmt == S6_IMAGE_FMT or (fmt is None and taps and s6_filter_image_bytes(taps, R, S) == 4 * n):
+        if s6_filter_image_bytes(taps, R, S) != 4 * n:
+            raise MrdisError(f'six-product image of {4 * n} bytes, a [{taps}][{R}][{S}] filter needs {s6_filter_image_bytes(taps, R, S)}')
+        return S6_IMAGE_FMT
     if fmt is None:
         hits = [f for f in (2, 4, 5) if wino_u_image_floats(R, S, spadeC, f) == n]
         if len(hits) != 1:
@@ -625,8 +652,9 @@ def conv2d_fwd(x, w_tck, bias, kh, kw, stride, pad, lrelu=False, out=None, w_bf1
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Co, Ci) and w_bf16.is_contiguous()
     wfmt = 0
     if w_wino is not None:
-        assert w_wino.dtype == torch.float32 and kh == 3 and kw == 3
-        wfmt = wino_image_fmt(w_wino, Ci, Co)
+        assert w_wino.dtype == torch.float32
+        wfmt = wino_image_fmt(w_wino, Ci, Co, taps=T)
+        assert wfmt == S6_IMAGE_FMT or (kh == 3 and kw == 3)
     dt = DT_BF16 if mixed == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)     # bf16 views: bf16 kernels only
     rc = lib.mrdis_conv2d_fwd(_ptr(x), ldx, _ptr(w_tck), _ptr(w_bf16), _ptr(bias), _ptr(y), ldy, N, H, W, Ci, Co, kh, kw, stride, pad,
                               1 if lrelu else 0, dt, _ptr(w_wino) if dt == DT_F32 else None, wfmt, _stream())
@@ -670,8 +698,9 @@ def conv2d_bwd_data(dy, w_tkc, in_hw, kh, kw, stride, pad, w_bf16=None, out=None
         assert w_bf16.dtype == torch.bfloat16 and tuple(w_bf16.shape) == (T, Ci, Co) and w_bf16.is_contiguous()
     wfmt = 0
     if w_wino is not None:
-        assert w_wino.dtype == torch.float32 and kh == 3 and kw == 3
-        wfmt = wino_image_fmt(w_wino, Co, Ci)
+        assert w_wino.dtype == torch.float32
+        wfmt = wino_image_fmt(w_wino, Co, Ci, taps=T)
+        assert wfmt == S6_IMAGE_FMT or (kh == 3 and kw == 3)
     dt = DT_BF16 if _dt(dy) == DT_BF16 else (DT_F32 if w_bf16 is None else DT_F32_BF16M)
     rc = lib.mrdis_conv2d_bwd_data(_ptr(dy), lddy, _ptr(w_tkc), _ptr(w_bf16), _ptr(dx), ldo, N, H, W, Ci, Co, kh, kw, stride, pad, dt,
                                    _ptr(w_wino) if dt == DT_F32 else None, wfmt, _stream())

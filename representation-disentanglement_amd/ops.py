@@ -841,7 +841,8 @@ class _GroupedConvFn(Function):
                                                                                       may_decline=True) is None:
                     if dyg is None:
                         dyg = dy_pad()[g * B:(g + 1) * B]
-                    hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=ctx.wbs[g], out=dxb[g * B:(g + 1) * B])
+                    wb_g = ctx.wbs[g] if ctx.wbs[g] is not None else s6_dgrad_image(dyg, tkcs[g], (H, W), kh, kw, ctx.stride)
+                    hip.conv2d_bwd_data(dyg, tkcs[g], (H, W), kh, kw, ctx.stride, pad, w_bf16=wb_g, out=dxb[g * B:(g + 1) * B])
             res = None
             if dy4 is not None and x32 is None and xin is not None and xin.dtype == torch.bfloat16 and not _NO_CO4B_WGRAD:
                 # ... and its weight gradient: the bf16 trunk x the fp32 gradient on the bf16 matrix pipe (wgrad_c4b_kernel<.., SWAP>) -- (9, C, 4) + the 4 bias sums
@@ -1547,6 +1548,22 @@ def cached_mix(key, make):
     return hit
 
 
+# --------------------------------------------------------------------------- six-product filter images (mrdis_s6conv.hip)
+# The data gradient of the 4x4 stride-2 encoder convolutions (model.py:2104 under :1935-1990) has no Winograd form; on maps of >= 16k positions the
+# six-product kernel (fp32 operands as three bf16 terms on the bf16 matrix pipe, fp32-equivalent results) runs it in 69-75 us where the fp32 MFMA kernel
+# takes 92-112 (tools/s6conv_check.py; the forward pass and the smaller maps gain nothing and stay where they were).  The filter's image is built once per
+# mixed kernel and step (the mix cache scope) by one small launch.  MRDIS_S6_DGRAD=0: off.
+_S6_DGRAD = _os.environ.get('MRDIS_S6_DGRAD', '1') != '0'
+
+
+def s6_dgrad_image(dy, w_tkc, in_hw, kh, kw, stride):
+    if not _S6_DGRAD or stride != 2 or kh != 4 or kw != 4 or type(dy) is not torch.Tensor or dy.dtype is not torch.float32 or not dy.is_cuda \
+            or w_tkc.dtype is not torch.float32 or w_tkc.shape[1] % 8 != 0 or w_tkc.shape[2] % 4 != 0 or w_tkc.shape[2] < 16 \
+            or dy.shape[0] * in_hw[0] * in_hw[1] < 32768 or _COMPUTE_DTYPE != hip.DT_F32:
+        return None
+    return cached_mix(('s6d', id(w_tkc)), lambda: (w_tkc, hip.s6_filter_image(w_tkc)))[1]      # (the tuple keeps w_tkc alive: its id stays unique inside the scope)
+
+
 # --------------------------------------------------------------------------- torch.ops.mrdis.*
 # Dispatcher-visible custom ops over the C ABI: schema, CUDA kernel (ctypes -> libmrdis_hip.so), fake
 # (meta) kernel and autograd formula for each, so `torch.ops.mrdis.*` composes with torch's tooling (opcheck,
@@ -1685,6 +1702,8 @@ class _Conv2dFn(Function):
             # (~10 us of Python each, ~1000 per step) buy nothing here
             if lrelu:
                 dy = hip.lrelu_bwd(dy, y, 0.2)
+            if wb_bwd is None and ctx.needs_input_grad[0]:
+                wb_bwd = s6_dgrad_image(dy, w_tkc, (H, W), kh, kw, stride)
             dx = hip.conv2d_bwd_data(dy, w_tkc, (H, W), kh, kw, stride, pad, w_bf16=wb_bwd) if ctx.needs_input_grad[0] else None
             if want_w:
                 sink = _grad_sink(ctx.bias_param) if has_bias else None

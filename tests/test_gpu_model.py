@@ -229,7 +229,7 @@ def test_train_step_vs_oracle_at_256_default_policy(mrdis):
         loss.backward()
     counts = mrdis.hip.launch_counts()
     dump_measured('wino_launch_counts.jsonl', dict(what='oracle 256x256 B8 M4', policy='default', **counts))
-    for fam in ('wino4', 'wino4_spade', 'wino4_wgrad', 'wino2', 'split6_c4', 'split6_co4', 'split6_c16', 'split6_wgrad16'):       # (split6: the default-on six-product kernels)
+    for fam in ('wino4', 'wino4_spade', 'wino4_wgrad', 'wino2', 'split6_c4', 'split6_co4', 'split6_c16', 'split6_wgrad16', 'split6_tap'):       # (split6: the default-on six-product kernels)
         assert counts[fam] > 0, (fam, counts)
     assert counts['wino4r'] + counts['wino4n'] > 0, counts
     assert abs(float(loss) - float(rloss)) <= 1e-3 * abs(float(rloss))

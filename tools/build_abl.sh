@@ -16,3 +16,6 @@ ls -la ../../ab/libmrdis_abl.so
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DBCONV3_ABLATIONS -c -o ../../ab/mrdis_bf16p_abl.o mrdis_bf16p.hip
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DBCONV4_ABLATIONS -c -o ../../ab/mrdis_bf16q_abl.o mrdis_bf16q.hip
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl_bf16.so $(ls *.o | grep -v "mrdis_bf16p.o\|mrdis_bf16q.o") ../../ab/mrdis_bf16p_abl.o ../../ab/mrdis_bf16q_abl.o
+# ab/libmrdis_abl_s6t.so: the six-product tap kernel built -DS6T_STAMPS (in-kernel stamps; tools/s6conv_stamps.py)
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-value -Wno-unused-variable -DS6T_STAMPS -c -o ../../ab/mrdis_s6conv_abl.o mrdis_s6conv.hip
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/libmrdis_abl_s6t.so $(ls *.o | grep -v "mrdis_s6conv.o") ../../ab/mrdis_s6conv_abl.o
