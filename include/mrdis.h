@@ -80,8 +80,8 @@ long long mrdis_get_option(const char* name);
 /* Launches since load / the last reset of one kernel family (counted on the host at launch): "wino" | "wino_spade" (phase-by-phase F(2x2)),
  * "wino2" | "wino2_spade" (pipelined F(2x2)), "wino4" | "wino4_spade" (F(4x4) 64-cout forms), "wino4n" | "wino4r" (32-cout forms: shared transform / register-fed),
  * "wino_wgrad" | "wino_wgrad2" (F(2x2) weight gradient), "wino4_wgrad" (F(3x3,4x4)); "bconv3" | "bconv3_spade" | "bconv4" | "bconv4_spade" (bf16 3x3 forms);
- * "split6_c4" | "split6_c16" | "split6_wgrad16" | "split6_co4" | "split6_c3d" | "split6_w3d" (option split6: the 4 -> C kernel, the 32 -> 16 forward, its weight gradient, the
- * C -> 4 kernel, the 3-D 16 -> 16 forward / data-gradient and weight-gradient kernels as six bf16 products per fp32 product); "all" (every kernel launch of the library).  MRDIS_EINVAL for an unknown name.  Diagnostics: the parity tests
+ * "split6_c4" | "split6_c16" | "split6_wgrad16" | "split6_co4" | "split6_c3d" | "split6_w3d" | "split6_tap" (option split6: the 4 -> C kernel, the 32 -> 16 forward, its weight gradient, the
+ * C -> 4 kernel, the 3-D 16 -> 16 forward / data-gradient and weight-gradient kernels, the tap-table kernel fed by mrdis_s6_filter_image, as six bf16 products per fp32 product); "all" (every kernel launch of the library).  MRDIS_EINVAL for an unknown name.  Diagnostics: the parity tests
  * use it to prove that the form under test is the one that ran. */
 long long mrdis_launch_count(const char* family);
 void mrdis_launch_count_reset(void);

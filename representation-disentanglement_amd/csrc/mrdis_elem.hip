@@ -1938,7 +1938,7 @@ const OptDef OPT_DEFS[MRDIS_OPT_COUNT] = {
     {"wino4", "MRDIS_WINO4", 0, 1},          // 1: F(4x4, 3x3) (mrdis_wino4.hip) for the filters mrdis_wino_u_format() names, where the grid fills the chip | 0: never | 2: wherever the kernel applies
     {"wino4r", "MRDIS_WINO4R", 0, 1},        // <= 32 couts: 1: the register-fed F(4x4, 3x3) form (mrdis_wino4r.hip) for <= 64 reduction channels and inputs beyond the Infinity Cache | 0: the shared-transform form | 2 / 3: always its 64-tile / channel-split form
     {"bconv4", "MRDIS_BCONV4", 0, 1},        // bf16 3x3 stride-1 layers: 1: the LDS-DMA kernel (mrdis_bf16q.hip) where the launch fills the chip | 0: bconv3_kernel (mrdis_bf16p.hip) | 2: wherever it applies
-    {"split6", "MRDIS_SPLIT6", 0, 1},        // thin fp32 3x3 stride-1 layers on the bf16 matrix pipe: both fp32 operands as three bf16 terms, the six products of order <= 2 summed in fp32 (2^-23 relative per product).  1: the 4 -> C kernel for <= 32 couts, the C -> 4 kernel, sp6.out forward + weight gradient (32 -> 16) | 0: fp32 MFMA | 2 .. 7: one 2-D kernel at a time, see run_c4conv | 8 / 9: only the 3-D 16 -> 16 forward + data gradient / weight gradient kernel (mrdis_conv3d_s6.hip; both also under 1)
+    {"split6", "MRDIS_SPLIT6", 0, 1},        // thin fp32 3x3 stride-1 layers on the bf16 matrix pipe: both fp32 operands as three bf16 terms, the six products of order <= 2 summed in fp32 (2^-23 relative per product).  1: the 4 -> C kernel for <= 32 couts, the C -> 4 kernel, sp6.out forward + weight gradient (32 -> 16) | 0: fp32 MFMA | 2 .. 7: one 2-D kernel at a time, see run_c4conv | 8 / 9: only the 3-D 16 -> 16 forward + data gradient / weight gradient kernel (mrdis_conv3d_s6.hip; both also under 1) | 10: only the tap-table kernel for launches that bring a filter image (mrdis_s6conv.hip; also under 1)
     {"debug_no16", "MRDIS_DEBUG_NO16", 1, 0}, {"debug_nothin", "MRDIS_DEBUG_NOTHIN", 1, 0}, {"debug_noc4", "MRDIS_DEBUG_NOC4", 1, 0},
     {"debug_nodma", "MRDIS_DEBUG_NODMA", 1, 0}, {"debug_no16_3d", "MRDIS_DEBUG_NO16_3D", 1, 0},
     {"debug_bilgen", "MRDIS_DEBUG_BILGEN", 1, 0}, {"debug_now16", "MRDIS_DEBUG_NOW16", 1, 0},

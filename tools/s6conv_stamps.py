@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 hip.set_option('debug_bm', -1); hip.set_option('debug_bn', -1)
 st_ = buf.cpu().numpy().reshape(4, 4, CAP)
 names = {1: 'top', 2: 'barrier A', 3: 'stored', 4: 'barrier B', 5: 'loads issued', 6: 'MFMA loop', 7: 'epilogue'}
-print(f'{what} {Ci}->{Co} k{k} s{st} {H}x{H}: s_memtime ticks (100 MHz: 1 tick = 10 ns = ~24 shader cycles)')
+print(f'{what} {Ci}->{Co} k{k} s{st} {H}x{H}: s_memtime ticks (shader clock: 241k ticks = the 115 us of the launch)')
 for wg in range(2):
     for wave in (0, 3):
         v = st_[wg, wave]; v = v[v != 0]
