@@ -346,6 +346,18 @@ int s6t_ncu() {
     return ncu;
 }
 
+// workgroups of one instantiation a CU holds at a given dynamic LDS size (the runtime's answer: registers AND LDS), cached per (instantiation, form, size)
+template <typename K>
+int s6t_occ_of(K kernel, size_t lds) {
+    static size_t seen_lds[4]; static int seen_n[4]; static int nseen = 0;
+    for (int i = 0; i < nseen; ++i) if (seen_lds[i] == lds) return seen_n[i];
+    int n = 0;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, lds) != hipSuccess || n < 1) n = 1;
+    seen_lds[nseen & 3] = lds; seen_n[nseen & 3] = n; if (nseen < 4) ++nseen;
+    return n;
+}
+
 // w [tap][reduction channel][output channel] fp32 -> the image above; one thread per row (q, g, tap, e)
 __global__ void s6_filter_image_kernel(const float* __restrict__ w, int taps, int Cred, int Cout, unsigned char* __restrict__ img) {
     const int G = (Cout + 31) / 32, Q = Cred / 8;
@@ -422,11 +434,11 @@ int mrdis_run_s6conv(TapConvParams p, const void* image, int taps_img, int dh_ma
             while ((p.is * TinWp) % 16 != want) ++TinWp;
         }
     };
-    // the configuration: most workgroups per CU first (their staging phases overlap each other's MFMAs), then enough blocks to fill the chip twice, then the
-    // tile area (MFMAs per operand read), then the channel chunk.  debug_mode = 100 kc + 10 wp + wc forces one.
+    // the configuration, by measured preference (tools/s6conv_abl.py, B = 32 encoder layers): 16-channel chunks before 32 before 8; few taps (the parity
+    // classes of a stride-2 data gradient): 64 positions x 32 couts per wave before the square tile before the small ones; many taps (a 4x4 / 3x3 forward):
+    // the square tile first (every filter row is read once per 64 positions).  debug_mode = 100 kc + 10 wp + wc forces one.
     const long long force = mrdis_opt(MRDIS_OPT_MODE);
     const Cfg* best = nullptr; size_t best_lds = 0; long long best_score = -1;
-    const long long npos_all = (long long)p.N * p.A * p.B;
     for (const Cfg& c : menu) {
         if (force > 0 && force != 100LL * c.kc + 10 * c.wp + c.wc) continue;
         if (p.Cin % c.kc != 0) continue;
@@ -438,9 +450,10 @@ int mrdis_run_s6conv(TapConvParams p, const void* image, int taps_img, int dh_ma
         if ((long long)qx * c.wc * p.ntaps * (S6T_PLANE / 16) > c.wr * 256LL) continue;
         const size_t lds = (size_t)qx * c.wc * p.ntaps * S6T_PLANE + (size_t)s6t_pitch(c.kc) * p.NB * p.TinH * TinWp;
         if (lds > 156 * 1024) continue;
-        const long long blocks = ((npos_all + 128 * c.wp - 1) / (128 * c.wp)) * ((p.Cout + 32 * c.wc - 1) / (32 * c.wc));
-        const int per_cu = lds <= 52 * 1024 ? 3 : (lds <= 78 * 1024 ? 2 : 1);
-        const long long score = (long long)per_cu * 1000000 + (blocks >= 2LL * ncu ? 100000 : 0) + (long long)(c.wp * c.wc) * 10000 + c.kc * 10 - (c.xr + c.wr);
+        const int kc_rank = c.kc == 16 ? 3 : (c.kc == 32 ? 2 : 1);
+        const int tile = 10 * c.wp + c.wc;
+        const int tile_rank = p.ntaps <= 4 ? (tile == 21 ? 4 : tile == 22 ? 3 : tile == 11 ? 2 : 1) : (tile == 22 ? 4 : tile == 11 ? 3 : tile == 12 ? 2 : 1);
+        const long long score = 1000LL * kc_rank + 100 * tile_rank - (c.xr + c.wr);
         if (score > best_score) { best_score = score; best = &c; best_lds = lds; }
     }
     if (!best) return MRDIS_EUNSUPPORTED;
@@ -456,8 +469,11 @@ int mrdis_run_s6conv(TapConvParams p, const void* image, int taps_img, int dh_ma
     g.stamps = reinterpret_cast<unsigned long long*>((uintptr_t)(mrdis_opt(MRDIS_OPT_BM) > 0 ? mrdis_opt(MRDIS_OPT_BM) : 0));      // stamp buffer (device pointer) and stamps per wave, via options debug_bm / debug_bn
     g.cap_stamps = (int)mrdis_opt(MRDIS_OPT_BN);
 #endif
-    int per_cu = (int)((156 * 1024) / (lds + 512)); if (per_cu < 1) per_cu = 1;
-    { const int occ = c.wp * c.wc == 1 ? (c.kc == 32 ? 2 : 3) : (c.wp * c.wc == 4 || c.wc == 2 ? 1 : 2); if (per_cu > occ) per_cu = occ; }      // waves per SIMD the register allocation of the instantiation leaves (hipcc -Rpass-analysis=kernel-resource-usage)
+    int per_cu = 1;                                // persistent grid: what the CUs hold at once of THIS instantiation (its registers and its LDS)
+#define S6T_OCC(KC_, A_, B_, XR_, WR_) if (c.kc == KC_ && c.wp == A_ && c.wc == B_ && c.xr == XR_ && c.wr == WR_) \
+        per_cu = defer ? s6t_occ_of(s6conv_pack_kernel<KC_, A_, B_, XR_, WR_>, lds) : s6t_occ_of(s6conv_kernel<KC_, A_, B_, XR_, WR_>, lds);
+    S6T_CASES(S6T_OCC)
+#undef S6T_OCC
     long long per_cot = (long long)ncu * per_cu / p.coTiles;
     if (defer) per_cot /= 4;                       // the four parity classes of a stride-2 data gradient share one launch
     { const long long v = mrdis_opt(MRDIS_OPT_WGSPLIT); if (v > 0) per_cot = v; }      // debug_wgsplit: workgroups per cout tile
