@@ -2900,6 +2900,15 @@ struct MixPtrs { float* tck[MIX_MAX_TYPES]; float* tkc[MIX_MAX_TYPES]; __bf16* b
 struct MixCPtrs { const float* p[MIX_MAX_TYPES]; };
 // (bx, gx): block index and block count of this filter's share of the grid -- blockIdx.x / gridDim.x for the one-layer launch, the
 // job's block range for the all-layers launch (mix_jobs_fwd_kernel)
+// ---- tiled backward (round 6).  W is [E][Co][Ci][T] (the reference's parameter layout), the gradients of the mixed filters arrive as [T][Ci][Co]: walked
+// element by element in W order, every gradient read is a 4-byte gather (16 x the sectors), and every type's row of blocks reads W again.  In the tiled form
+// a thread owns a (cout, channel) pair, i.e. T contiguous parameters per expert (a wave touches 8 rows of 8 T floats), and the gradients come through an LDS
+// tile filled in 128-byte rows.  Same sums in the same order as the element-wise body below (which remains for E > 3, M > 4 and other tap counts).  The
+// forward mix was tried in the same form (LDS tile, 128-byte rows on both output layouts) and was no faster than its scattered stores (75 vs 66 us per
+// launch): L2 merges those; it stays element-wise.
+constexpr int MIXT_E = 3, MIXT_M = 4;      // (the model: 3 experts, <= 4 modality types; anything larger takes the element-wise bodies)
+__device__ __forceinline__ bool mix_tiled_ok(int E, int M, int T) { return E <= MIXT_E && M <= MIXT_M && (T == 1 || T == 9 || T == 16); }
+
 __device__ __forceinline__ void mix_fwd_body(const float* __restrict__ W, const float* __restrict__ fcw, const float* __restrict__ fcb,
                                              const float* __restrict__ types, int emb, float* __restrict__ r_out,
                                              float* __restrict__ w_tck, float* __restrict__ w_tkc, __bf16* __restrict__ b_tck, __bf16* __restrict__ b_tkc,
@@ -2941,10 +2950,91 @@ __global__ void mix_routed_multi_fwd_kernel(const float* __restrict__ W, const f
 }
 // block (b, m): partial dr[m][e] = <dw_m, W[e]> over the block's elements; the m == 0 blocks also write
 // dW[e] = sum_m r[m][e] dw_m (types in order m = 0..M-1; a type without gradient contributes nothing).
+// one block per tile does ALL types: W is read once (not once per type), every gradient once (not twice), in 128-byte rows through a double-buffered LDS
+// tile (one barrier per gradient); dW[e] = sum_m r[m][e] dw_m in the same order as below: bit-identical; the routing dots in double as below (other order of
+// the partial sums: equal to ~1e-16 relative before they are rounded to fp32)
+template <int T>
+__device__ __forceinline__ void mix_bwd_tiled(const MixCPtrs& dw, const float* __restrict__ W, const float* __restrict__ r, float* __restrict__ dW,
+                                              float* __restrict__ part, int M, int E, int Co, int Ci, int accumulate, int ld_dw, int bx, int gx, int cip,
+                                              double (*red)[4], float* __restrict__ gt_) {      // gt_: 2 x 9 x 8 x 33 floats of LDS, [buffer][tap][channel 8][cout 32 (+1)]
+    constexpr int TP = T > 9 ? 8 : T;                 // taps per pass (16 taps: two passes of 8 -- the per-thread W chunk and sums stay in registers)
+    const long long total = (long long)Co * Ci * T;
+    const int tid = threadIdx.x, tco = tid >> 3, tci = tid & 7, sco = tid & 31, sci = tid >> 5;
+    const int tilesI = (Ci + 7) / 8, ntiles = ((Co + 31) / 32) * tilesI;
+    double dr[MIXT_M][MIXT_E];
+    float rr[MIXT_M][MIXT_E];
+#pragma unroll
+    for (int mm = 0; mm < MIXT_M; ++mm)
+#pragma unroll
+        for (int e = 0; e < MIXT_E; ++e) { dr[mm][e] = 0.0; rr[mm][e] = (mm < M && e < E) ? r[mm * E + e] : 0.f; }
+    int buf = 0;
+    for (int tl = bx; tl < ntiles; tl += gx) {
+        const int co0 = (tl / tilesI) * 32, ci0 = (tl % tilesI) * 8;
+        const int co = co0 + tco, ci = ci0 + tci;
+        const bool own = co < Co && ci < Ci, sok = co0 + sco < Co && ci0 + sci < Ci;
+        const long long i0 = ((long long)co * Ci + ci) * T;
+#pragma unroll
+        for (int t0 = 0; t0 < T; t0 += TP) {
+            float wv[MIXT_E][TP], acc[MIXT_E][TP];
+#pragma unroll
+            for (int e = 0; e < MIXT_E; ++e)
+#pragma unroll
+                for (int t = 0; t < TP; ++t) { wv[e][t] = (own && e < E) ? W[(long long)e * total + i0 + t0 + t] : 0.f; acc[e][t] = 0.f; }
+#pragma unroll
+            for (int mm = 0; mm < MIXT_M; ++mm) {
+                if (mm >= M) break;
+                const float* __restrict__ gp = dw.p[mm];
+                if (gp == nullptr) continue;           // (block-uniform) a type without gradient contributes nothing
+                float* L = gt_ + buf * (9 * 8 * 33);
+#pragma unroll
+                for (int t = 0; t < TP; ++t) L[(t * 8 + sci) * 33 + sco] = sok ? gp[((long long)(t0 + t) * cip + ci0 + sci) * ld_dw + co0 + sco] : 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    const float g = L[(t * 8 + tci) * 33 + tco];
+#pragma unroll
+                    for (int e = 0; e < MIXT_E; ++e) {
+                        dr[mm][e] += (double)g * (double)wv[e][t];
+                        acc[e][t] += rr[mm][e] * g;
+                    }
+                }
+                buf ^= 1;                              // the next gradient lands in the other buffer: nobody still reads it (everyone passed the barrier above after its reads of two gradients ago)
+            }
+            if (own)
+#pragma unroll
+                for (int e = 0; e < MIXT_E; ++e)
+                    if (e < E)
+#pragma unroll
+                        for (int t = 0; t < TP; ++t) { float* d_ = dW + (long long)e * total + i0 + t0 + t; *d_ = accumulate ? *d_ + acc[e][t] : acc[e][t]; }      // accumulate: dW is a gradient sink
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int mm = 0; mm < MIXT_M; ++mm) {
+        if (mm >= M) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < MIXT_E; ++e) {
+            const double v = mrdis_wave_sum_d(dr[mm][e]);
+            if (lane == 0) red[e][wave] = v;
+        }
+        __syncthreads();
+        if (tid < 8 && tid < E) part[((long long)mm * gx + bx) * 8 + tid] = (float)((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]));
+    }
+}
+
 __device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __restrict__ W, const float* __restrict__ r,
                                              float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw,
                                              int m, int bx, int gx, int cip) {
     __shared__ double red[8][4];
+    if (mix_tiled_ok(E, M, T) && blockDim.x == 256) {
+        if (m != 0) return;                            // (the grid still has one row of blocks per type)
+        __shared__ float gt[2 * 9 * 8 * 33];
+        if (T == 9) mix_bwd_tiled<9>(dw, W, r, dW, part, M, E, Co, Ci, accumulate, ld_dw, bx, gx, cip, red, gt);
+        else if (T == 16) mix_bwd_tiled<16>(dw, W, r, dW, part, M, E, Co, Ci, accumulate, ld_dw, bx, gx, cip, red, gt);
+        else mix_bwd_tiled<1>(dw, W, r, dW, part, M, E, Co, Ci, accumulate, ld_dw, bx, gx, cip, red, gt);
+        return;
+    }
     const long long total = (long long)Co * Ci * T;
     const float* __restrict__ g_m = dw.p[m];
     double dr[8];
@@ -2990,7 +3080,7 @@ __device__ __forceinline__ void mix_bwd_body(const MixCPtrs& dw, const float* __
         part[((long long)m * gx + bx) * 8 + threadIdx.x] =
             (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
-__global__ void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
+__global__ __launch_bounds__(256) void mix_multi_bwd_kernel(MixCPtrs dw, const float* __restrict__ W, const float* __restrict__ r,
                                      float* __restrict__ dW, float* __restrict__ part, int M, int E, int Co, int Ci, int T, int accumulate, int ld_dw) {
     mix_bwd_body(dw, W, r, dW, part, M, E, Co, Ci, T, accumulate, ld_dw, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, Ci);
 }
@@ -3046,7 +3136,7 @@ __global__ void mix_jobs_fwd_kernel(const MixJob* __restrict__ jobs, int njobs, 
                  j->tap_tkc, m, (int)blockIdx.x - j->block0, j->nblk, j->ci_pitch);
 }
 // dw: [njobs][MIX_MAX_TYPES] gradient pointers of this step (null: that label's filter got no gradient)
-__global__ void mix_jobs_bwd_kernel(const MixJob* __restrict__ jobs, int njobs, const float* const* __restrict__ dw, int M) {
+__global__ __launch_bounds__(256) void mix_jobs_bwd_kernel(const MixJob* __restrict__ jobs, int njobs, const float* const* __restrict__ dw, int M) {
     const MixJob* j = mix_find_job(jobs, njobs, (int)blockIdx.x);
     MixCPtrs g;
     const float* const* gp = dw + (long long)(j - jobs) * MIX_MAX_TYPES;
