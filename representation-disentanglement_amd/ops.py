@@ -1550,8 +1550,8 @@ def cached_mix(key, make):
 
 # --------------------------------------------------------------------------- six-product filter images (mrdis_s6conv.hip)
 # The data gradient of the 4x4 stride-2 encoder convolutions (model.py:2104 under :1935-1990) has no Winograd form; on maps of >= 16k positions the
-# six-product kernel (fp32 operands as three bf16 terms on the bf16 matrix pipe, fp32-equivalent results) runs it in 69-75 us where the fp32 MFMA kernel
-# takes 92-112 (tools/s6conv_check.py; the forward pass and the smaller maps gain nothing and stay where they were).  The filter's image is built once per
+# six-product kernel (fp32 operands as three bf16 terms on the bf16 matrix pipe, fp32-equivalent results) runs it in 69-80 us where the fp32 MFMA kernel
+# takes 96-112 (tools/s6conv_check.py; the forward pass and the smaller maps gain nothing and stay where they were).  The filter's image is built once per
 # mixed kernel and step (the mix cache scope) by one small launch.  MRDIS_S6_DGRAD=0: off.
 _S6_DGRAD = _os.environ.get('MRDIS_S6_DGRAD', '1') != '0'
 
