@@ -14,7 +14,7 @@ B = 32
 LAYERS = [('ana.down_2', 32, 64, 4, 2, 1, 128), ('ana.down_3', 64, 128, 4, 2, 1, 64), ('ana.down_4', 128, 256, 4, 2, 1, 32), ('mod.conv3', 32, 64, 3, 2, 1, 64),
           ('sp2.out', 128, 128, 3, 1, 1, 16)]
 CFGS = [('auto', -1, -1)] + [(f'{kc}.{wp}x{wc}', 100 * kc + 10 * wp + wc, -1) for kc in (8, 16, 32) for (wp, wc) in ((1, 2), (2, 2), (2, 1), (1, 1))] + [(f'1621g{g}', 1621, g) for g in (32, 64, 128, 256)]
-print(f'{"layer":12s} pass  ' + ' '.join(f'{c[0]:>7s}' for c in CFGS) + '   fp32   (us; debug_mode forces the wave tile, debug_kc the channel chunk; 0.0 = declined)')
+print(f'{"layer":12s} pass  ' + ' '.join(f'{c[0]:>7s}' for c in CFGS) + '   fp32   (us; debug_mode = 100 kc + 10 wp + wc forces the instantiation, 1621gN also the workgroups per cout tile; 0.0 = declined)')
 for name, Ci, Co, k, st, pad, H in LAYERS:
     x = torch.randn(B, Ci, H, H); w = torch.randn(Co, Ci, k, k) * 0.05; b = torch.randn(Co)
     Ho = (H + 2 * pad - k) // st + 1
